@@ -1,0 +1,149 @@
+/*
+ * include/tensorrec_hip.h -- C ABI of libtensorrec_hip.so (gfx950 / MI355X).
+ *
+ * The reference (jfkirk/tensorrec) has no FFI of its own: its hot path is a chain of TensorFlow-1.x op calls made
+ * from Python.  Each entry point below replaces one such op chain; the reference call site it stands in for is
+ * cited as tensorrec/<file>:<line>.  INTEGRATION.md shows the ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless the name says otherwise; the library never allocates, frees,
+ *     synchronises or keeps a pointer after returning; `stream` is a hipStream_t (NULL = default stream) and
+ *     all work is enqueued on it;
+ *   - matrices are row-major fp32 unless stated; indices int32, row pointers int64;
+ *   - return value: TREC_OK (0) or an error code; trec_last_error() gives the message (thread-local);
+ *     nothing throws across this boundary.
+ */
+#ifndef TENSORREC_HIP_H
+#define TENSORREC_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TREC_OK 0
+#define TREC_ERR_INVALID 1
+#define TREC_ERR_LAUNCH 2
+#define TREC_ERR_UNSUPPORTED 3
+
+/* dtype of the score-GEMM operands */
+#define TREC_DTYPE_F32 0   /* exact fp32 (v_mfma_f32_32x32x2_f32): k-ordered fmaf chain */
+#define TREC_DTYPE_BF16 1  /* bf16 operands, fp32 accumulate (v_mfma_f32_32x32x16_bf16)  */
+/* prediction mode */
+#define TREC_MODE_DOT 0        /* also cosine: operands are row-normalised first          */
+#define TREC_MODE_EUCLIDEAN 1
+
+int trec_abi_version(void);
+const char* trec_last_error(void);
+int trec_device_cu_count(void);
+
+/* ---- K1: sparse features x dense weights ------------------------------------------------------------------
+ * tf.sparse_tensor_dense_matmul: representation_graphs.py:40 (Linear), :119 (ReLU layer 1),
+ * recommendation_graphs.py:15 (biases).  CSR operand (indptr[n_rows+1], indices[nnz], values[nnz]); if val_perm is
+ * non-NULL the value of entry j is values[val_perm[j]] (transposed operand of the backward pass:
+ * dW = X^T . dOut is this same call on the transposed CSR).  epilogue: 0 none | 1 row L2-normalise
+ * (representation_graphs.py:57; writes 1/norm to out_inv_norm if non-NULL) | 2 add col_bias[d] then ReLU
+ * (representation_graphs.py:119-120).  accumulate != 0: out += result (epilogue must be 0).               */
+int trec_spmm_csr(const int64_t* indptr, const int32_t* indices, const float* values, const int32_t* val_perm,
+                  int64_t n_rows, int64_t nnz, const float* W, int32_t d, const float* col_bias, int32_t epilogue,
+                  int32_t accumulate, float* out, float* out_inv_norm, void* stream);
+/* project_biases, recommendation_graphs.py:4-19: out[r] = sum_j X[r,j] * beta[j] */
+int trec_spmv_csr(const int64_t* indptr, const int32_t* indices, const float* values, const int32_t* val_perm,
+                  int64_t n_rows, const float* beta, float* out, void* stream);
+/* tf.sparse_tensor_to_dense, representation_graphs.py:74 (FeaturePassThrough) */
+int trec_csr_to_dense(const int64_t* indptr, const int32_t* indices, const float* values, int64_t n_rows,
+                      int32_t n_cols, float* out, void* stream);
+/* tf.nn.l2_normalize(x, 1): prediction_graphs.py:68-69, recommendation_graphs.py:119-120; and its gradient */
+int trec_row_l2norm_fwd(const float* x, int64_t n_rows, int32_t d, float* y, float* inv_norm, void* stream);
+int trec_row_l2norm_bwd(const float* y, const float* inv_norm, const float* dy, int64_t n_rows, int32_t d, float* dx,
+                        void* stream);
+/* gradient of tf.nn.relu (representation_graphs.py:119) and of the broadcast bias add (column sums) */
+int trec_relu_bwd(const float* out, const float* dout, int64_t n, float* dpre, void* stream);
+int trec_colsum(const float* x, int64_t n_rows, int32_t d, float* out, void* stream);
+/* tf.matmul(relu, linear_weights), representation_graphs.py:121, and its two gradients:
+ * C[M,N] (+)= op(A) . op(B), fp32 on MFMA; trans flags select A^T / B^T (row-major storage, lda/ldb/ldc in elements) */
+int trec_gemm_f32(int32_t trans_a, int32_t trans_b, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                  const float* B, int64_t ldb, float* C, int64_t ldc, int32_t accumulate, void* stream);
+
+/* ---- K2: user x item score contraction --------------------------------------------------------------------
+ * tf.matmul(user_repr, item_repr, transpose_b=True): prediction_graphs.py:50 (DotProduct), :94 (Euclidean),
+ * recommendation_graphs.py:121 (relative_cosine); + bias_prediction_dense, recommendation_graphs.py:41.
+ * Operands are prepared once by trec_score_prep: [n, kpad] with kpad = trec_score_kpad(d), zero padded, fp32 or bf16,
+ * optionally row-normalised (cosine) and/or with the squared row norm emitted (euclidean, prediction_graphs.py:87-90). */
+int trec_score_kpad(int32_t d);                                   /* 32 / 64 / 128 / 256, or -1 if d > 256       */
+int trec_score_rows_per_workgroup(int32_t dtype, int32_t kpad);
+int trec_score_tile_rows(int32_t dtype, int32_t kpad);
+int trec_score_topk_capacity(void);                               /* entries per partial list (16)               */
+int trec_score_prep(const float* repr, int64_t n, int32_t d, int32_t kpad, int32_t normalize, int32_t dtype, void* out,
+                    float* out_sqnorm, void* stream);
+/* predict(): out[u, i] = score(u, i) (+ user_bias[u]) (+ item_bias[i]) -- tensorrec.py:662 */
+int trec_score_gemm_store(const void* users, const void* items, int32_t dtype, int32_t kpad, int64_t n_users,
+                          int64_t n_items, const float* user_bias, const float* item_bias, int32_t mode,
+                          const float* user_sqnorm, const float* item_sqnorm, float* out, int64_t ld_out,
+                          int32_t variant, void* stream);
+/* fused top-k (first tf.nn.top_k of rank_predictions, recommendation_graphs.py:80, truncated to <= 16): writes
+ * n_parts = trec_score_topk_parts(...) sorted partial lists per user, [n_users, n_parts, 16] values + item indices
+ * (index + item_index_base; empty slots = (-inf, -1)); finish with trec_topk_merge.                          */
+int trec_score_topk_parts(int32_t dtype, int32_t kpad, int64_t n_items, int32_t n_chunks);
+int trec_score_gemm_topk(const void* users, const void* items, int32_t dtype, int32_t kpad, int64_t n_users,
+                         int64_t n_items, int32_t item_index_base, const float* user_bias, const float* item_bias,
+                         int32_t mode, const float* user_sqnorm, const float* item_sqnorm, int32_t n_chunks,
+                         float* part_vals, int32_t* part_idx, int32_t variant, void* stream);
+/* k best of n_cand candidates per user, ordered (value desc, index asc) = tf.nn.top_k tie rule; also the merge
+ * step after the all-gather of per-shard lists */
+int trec_topk_merge(const float* part_vals, const int32_t* part_idx, int64_t n_users, int32_t n_cand, int32_t k,
+                    float* out_vals, int32_t* out_idx, void* stream);
+
+/* ---- K3: per-pair ("serial") scores -----------------------------------------------------------------------
+ * prediction_graphs.py:52-55 (dot), :70-72 (cosine after l2norm), :105-117 (euclidean) fused with
+ * bias_prediction_serial, recommendation_graphs.py:55-57.  xu == NULL: user of pair p is p / pairs_per_user
+ * (the [U, S] sample layout of util.py:16-19).  bwd accumulates (+=) into dU / dV / d_*_bias (fp32 atomics). */
+int trec_pair_score_fwd(const float* U, const float* V, const int32_t* xu, const int32_t* xi, int64_t n_pairs,
+                        int32_t pairs_per_user, int32_t d, int32_t mode, const float* user_bias,
+                        const float* item_bias, float* out, void* stream);
+int trec_pair_score_bwd(const float* U, const float* V, const int32_t* xu, const int32_t* xi, const float* grad,
+                        int64_t n_pairs, int32_t pairs_per_user, int32_t d, int32_t mode, float* dU, float* dV,
+                        float* d_user_bias, float* d_item_bias, void* stream);
+
+/* ---- K4: ranks ----------------------------------------------------------------------------------------------
+ * rank_predictions, recommendation_graphs.py:73-82 (double tf.nn.top_k) as an exact count; int32, 1 = best. */
+int trec_rank_rows(const float* scores, int64_t n_users, int64_t n_items, int64_t ld_scores, int32_t* ranks,
+                   int64_t ld_ranks, void* stream);
+/* partial rank counts of selected (user, item) pairs over item columns [begin, end) of a score slab whose first
+ * column is global item `col_offset`; item shards sum their counts (add_one on exactly one of them) */
+int trec_rank_of_pairs(const float* scores, int64_t ld_scores, int64_t col_offset, int64_t begin, int64_t end,
+                       const int32_t* xu, const int32_t* xi, const float* target_scores, int64_t n_pairs,
+                       int32_t add_one, int32_t* out, void* stream);
+
+/* ---- K6: losses ---------------------------------------------------------------------------------------------
+ * WMRB / BalancedWMRB, loss_graphs.py:153-180 / :189-227.  Interactions are CSR over users (indptr[n_users+1]);
+ * pos_slot[p] = position of interaction p in the compacted positive vector or -1; pos_weight (NULL for plain
+ * WMRB) = value_p / per-item positive sum.  loss, smr: [n_positive].                                          */
+int trec_wmrb_fwd(const int64_t* indptr, const int32_t* pos_slot, const float* pos_weight, const float* pred_serial,
+                  const float* sample_pred, int64_t n_users, int64_t n_items, int32_t n_sampled, float* loss,
+                  float* smr, void* stream);
+int trec_wmrb_bwd(const int64_t* indptr, const int32_t* pos_slot, const float* pos_weight, const float* pred_serial,
+                  const float* sample_pred, const float* smr, const float* grad_loss, int64_t n_users,
+                  int64_t n_items, int32_t n_sampled, float* d_pred_serial, float* d_sample_pred, void* stream);
+/* RMSE, loss_graphs.py:58-59 */
+int trec_rmse_fwd(const float* y, const float* pred, int64_t n, float* partial_ws, int32_t n_partial, float* loss,
+                  void* stream);
+int trec_rmse_bwd(const float* y, const float* pred, const float* loss, const float* grad_loss, int64_t n,
+                  float* d_pred, void* stream);
+
+/* ---- K7: negative sampling ----------------------------------------------------------------------------------
+ * sample_items, util.py:12-21 (host np.random.choice per user behind tf.py_func, tensorrec.py:298-302).
+ * out: int32 [n_users, n_sampled], user-major.  replace == 0: distinct per user (keyed permutation).          */
+int trec_sample_items(int64_t n_users, int32_t n_items, int32_t n_sampled, int32_t replace, uint64_t seed,
+                      uint32_t step, int32_t* out, void* stream);
+
+/* ---- K8: optimiser --------------------------------------------------------------------------------------------
+ * tf.train.AdamOptimizer(lr).minimize (tensorrec.py:489) + gradient of alpha * sum(tf.nn.l2_loss(w)) (:487-488):
+ * g' = grad + w * l2_coef, then the TF-1.x ApplyAdam element update.  In place on w, m, v.                    */
+int trec_adam_tf_step(float* w, float* m, float* v, const float* grad, int64_t n, float lr_t, float beta1,
+                      float beta2, float epsilon, float l2_coef, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TENSORREC_HIP_H */

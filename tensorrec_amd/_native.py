@@ -1,0 +1,119 @@
+"""
+ctypes binding of libtensorrec_hip.so (include/tensorrec_hip.h).
+
+PyTorch is used for device memory and streams only: every entry point takes raw device pointers
+(``tensor.data_ptr()``) and the current HIP stream.  There is NO fallback: if the library is missing, fails to
+load, or a tensor is not on a GPU, the call raises -- the product path never computes on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch  # noqa: F401  (must be imported first: it loads the HIP runtime that the library binds to)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtensorrec_hip.so")
+
+_vp, _i32, _i64, _u32, _u64, _f = (ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32,
+                                   ctypes.c_uint64, ctypes.c_float)
+
+# name -> argtypes, in the order of include/tensorrec_hip.h
+SIGNATURES = {
+    "trec_abi_version": [],
+    "trec_device_cu_count": [],
+    "trec_spmm_csr": [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp],
+    "trec_spmv_csr": [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp],
+    "trec_csr_to_dense": [_vp, _vp, _vp, _i64, _i32, _vp, _vp],
+    "trec_row_l2norm_fwd": [_vp, _i64, _i32, _vp, _vp, _vp],
+    "trec_row_l2norm_bwd": [_vp, _vp, _vp, _i64, _i32, _vp, _vp],
+    "trec_relu_bwd": [_vp, _vp, _i64, _vp, _vp],
+    "trec_colsum": [_vp, _i64, _i32, _vp, _vp],
+    "trec_gemm_f32": [_i32, _i32, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp],
+    "trec_score_kpad": [_i32],
+    "trec_score_rows_per_workgroup": [_i32, _i32],
+    "trec_score_tile_rows": [_i32, _i32],
+    "trec_score_topk_capacity": [],
+    "trec_score_prep": [_vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
+    "trec_score_gemm_store": [_vp, _vp, _i32, _i32, _i64, _i64, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _i32, _vp],
+    "trec_score_topk_parts": [_i32, _i32, _i64, _i32],
+    "trec_score_gemm_topk": [_vp, _vp, _i32, _i32, _i64, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32,
+                             _vp],
+    "trec_topk_merge": [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp],
+    "trec_pair_score_fwd": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
+    "trec_pair_score_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
+    "trec_rank_rows": [_vp, _i64, _i64, _i64, _vp, _i64, _vp],
+    "trec_rank_of_pairs": [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _i32, _vp, _vp],
+    "trec_wmrb_fwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp],
+    "trec_wmrb_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp],
+    "trec_rmse_fwd": [_vp, _vp, _i64, _vp, _i32, _vp, _vp],
+    "trec_rmse_bwd": [_vp, _vp, _vp, _vp, _i64, _vp, _vp],
+    "trec_sample_items": [_i64, _i32, _i32, _i32, _u64, _u32, _vp, _vp],
+    "trec_adam_tf_step": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _vp],
+}
+
+_lib = None
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes handle.  Raises NativeLibraryError if the .so is absent or incomplete."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`make -C tensorrec_amd/csrc`.  tensorrec_amd has no CPU fallback." % LIB_PATH)
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as exc:  # pragma: no cover
+        raise NativeLibraryError("cannot load %s: %s" % (LIB_PATH, exc))
+    for name, argtypes in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise NativeLibraryError("%s does not export %s (stale build?)" % (LIB_PATH, name))
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+    lib.trec_last_error.argtypes = []
+    lib.trec_last_error.restype = ctypes.c_char_p
+    _lib = lib
+    return lib
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise NativeLibraryError("tensorrec_amd needs an MI355X (torch.cuda.is_available() is False); "
+                                 "there is no CPU fallback")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  Refuses host tensors and non-contiguous views."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise NativeLibraryError("expected a GPU tensor, got device=%s" % t.device)
+    if not t.is_contiguous():
+        raise NativeLibraryError("expected a contiguous tensor")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def call(name, *args):
+    """Invoke an entry point on the current torch stream; raise with the library's message on failure."""
+    lib = load()
+    rc = getattr(lib, name)(*args, stream())
+    if rc != 0:
+        raise RuntimeError("%s failed (code %d): %s" % (name, rc, lib.trec_last_error().decode()))
+
+
+def query(name, *args):
+    """Entry points that return a value instead of a status (no stream argument)."""
+    return getattr(load(), name)(*args)

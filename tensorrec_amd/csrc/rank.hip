@@ -1,0 +1,133 @@
+// tensorrec_amd/csrc/rank.hip -- K4: item ranks per user, exact and sort-free.
+//
+// Replaces rank_predictions (tensorrec/recommendation_graphs.py:73-82): two full tf.nn.top_k sorts per user.
+// The double sort is exactly a count (tests/test_oracle_golden.py::test_rank_is_counting...):
+//     rank[u, i] = 1 + #{ j : s[u,j] > s[u,i]  or  (s[u,j] == s[u,i] and j < i) }
+// so ranks are integer work on the score matrix: bit-exact by construction, and a count over an item range is
+// additive -- item shards just sum their partial counts (sharding.py), no cross-shard sort.
+//
+// rank_rows_kernel: grid (item blocks of 1024, users).  A block owns 1024 target items of one user (4 per
+// thread, in registers) and streams the user's whole score row through LDS in 2048-float tiles; every LDS read
+// is a wave-wide broadcast of a float4, compared against the 4 register targets (16 compares per ds_read_b128).
+// Tiles entirely below / above the block's target range need a single predicate (>= resp. >); only the diagonal
+// tiles evaluate the index tie-break.
+//
+// rank_of_pairs_kernel: ranks for selected (user, item) pairs only, counting over a [begin, end) item range --
+// the item-shardable form used for evaluation at sizes where the [U, I] matrix cannot exist.
+#include "common.hpp"
+
+#define RANK_TGT 1024
+#define RANK_TILE 2048
+
+__global__ __launch_bounds__(256) void rank_rows_kernel(const float* __restrict__ scores, int64_t n_items,
+                                                       int64_t ld, int32_t* __restrict__ ranks, int64_t ld_out)
+{
+    __shared__ __attribute__((aligned(16))) float tile[RANK_TILE];
+    const int64_t u = blockIdx.y;
+    const float* row = scores + u * ld;
+    const int64_t tgt0 = (int64_t)blockIdx.x * RANK_TGT;
+    // thread t owns targets tgt0 + t + 256*e  (coalesced loads/stores)
+    float tv[4];
+    int64_t tix[4];
+    int cnt[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        tix[e] = tgt0 + threadIdx.x + 256 * e;
+        tv[e] = (tix[e] < n_items) ? row[tix[e]] : 0.f;
+        cnt[e] = 0;
+    }
+    const int64_t tgt_end = tgt0 + RANK_TGT;
+    for (int64_t j0 = 0; j0 < n_items; j0 += RANK_TILE) {
+        __syncthreads();
+        for (int q = threadIdx.x; q < RANK_TILE; q += 256) {
+            const int64_t j = j0 + q;
+            tile[q] = (j < n_items) ? row[j] : -INFINITY;     // padding never beats anything (and NaN compares false)
+        }
+        __syncthreads();
+        const int64_t jend = j0 + RANK_TILE;
+        const bool padded = jend > n_items;
+        if (jend <= tgt0 && !padded) {
+            // every j in the tile is below every target index: beats when s_j >= s_i
+            for (int q = 0; q < RANK_TILE; q += 4) {
+                const f32x4 s = *(const f32x4*)(tile + q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    cnt[e] += (s.x >= tv[e]) + (s.y >= tv[e]) + (s.z >= tv[e]) + (s.w >= tv[e]);
+            }
+        } else if (j0 >= tgt_end) {
+            // every j is above every target index: beats only when strictly greater (padding is -inf)
+            for (int q = 0; q < RANK_TILE; q += 4) {
+                const f32x4 s = *(const f32x4*)(tile + q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    cnt[e] += (s.x > tv[e]) + (s.y > tv[e]) + (s.z > tv[e]) + (s.w > tv[e]);
+            }
+        } else {
+            for (int q = 0; q < RANK_TILE; ++q) {
+                const float s = tile[q];
+                const int64_t j = j0 + q;
+                if (j >= n_items) break;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) cnt[e] += (s > tv[e]) || (s == tv[e] && j < tix[e]);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (tix[e] < n_items) ranks[u * ld_out + tix[e]] = cnt[e] + 1;
+}
+
+// one wave per (user, item) pair; counts over items [begin, end) of the user's score row.
+// out[p] (+)= count  (+1 added by the caller once all shards are summed, or here when add_one != 0)
+__global__ __launch_bounds__(256) void rank_of_pairs_kernel(const float* __restrict__ scores, int64_t ld,
+                                                           int64_t col_offset, int64_t begin, int64_t end,
+                                                           const int32_t* __restrict__ xu,
+                                                           const int32_t* __restrict__ xi,
+                                                           const float* __restrict__ target_scores, int64_t n_pairs,
+                                                           int add_one, int32_t* __restrict__ out)
+{
+    const int64_t p = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (p >= n_pairs) return;
+    const int lane = lane_id();
+    const int64_t u = xu[p], i = xi[p];
+    const float si = target_scores[p];
+    const float* row = scores + u * ld - col_offset;     // row[j] valid for j in [begin, end)
+    int cnt = 0;
+    for (int64_t j = begin + lane; j < end; j += 64) {
+        const float s = row[j];
+        cnt += (s > si) || (s == si && j < i);
+    }
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+    if (lane == 0) out[p] = cnt + (add_one ? 1 : 0);
+}
+
+extern "C" int trec_rank_rows(const float* scores, int64_t n_users, int64_t n_items, int64_t ld_scores,
+                              int32_t* ranks, int64_t ld_ranks, void* stream)
+{
+    TREC_REQUIRE(scores && ranks, "trec_rank_rows: null pointer");
+    TREC_REQUIRE(ld_scores >= n_items && ld_ranks >= n_items, "trec_rank_rows: leading dimension < n_items");
+    TREC_REQUIRE(n_users <= 65535 * (int64_t)65535, "trec_rank_rows: too many users for one launch");
+    if (n_users == 0 || n_items == 0) return TREC_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned bx = (unsigned)ceil_div64(n_items, RANK_TGT);
+    // gridDim.y is limited to 65535: launch in user slabs
+    for (int64_t u0 = 0; u0 < n_users; u0 += 65535) {
+        const unsigned by = (unsigned)((n_users - u0 < 65535) ? (n_users - u0) : 65535);
+        hipLaunchKernelGGL(rank_rows_kernel, dim3(bx, by), dim3(256), 0, st, scores + u0 * ld_scores, n_items,
+                           ld_scores, ranks + u0 * ld_ranks, ld_ranks);
+    }
+    return trec_check_launch("trec_rank_rows");
+}
+
+extern "C" int trec_rank_of_pairs(const float* scores, int64_t ld_scores, int64_t col_offset, int64_t begin,
+                                  int64_t end, const int32_t* xu, const int32_t* xi, const float* target_scores,
+                                  int64_t n_pairs, int32_t add_one, int32_t* out, void* stream)
+{
+    TREC_REQUIRE(scores && xu && xi && target_scores && out, "trec_rank_of_pairs: null pointer");
+    TREC_REQUIRE(begin <= end, "trec_rank_of_pairs: begin > end");
+    if (n_pairs == 0) return TREC_OK;
+    hipLaunchKernelGGL(rank_of_pairs_kernel, dim3((unsigned)ceil_div64(n_pairs * 64, 256)), dim3(256), 0,
+                       (hipStream_t)stream, scores, ld_scores, col_offset, begin, end, xu, xi, target_scores, n_pairs,
+                       add_one, out);
+    return trec_check_launch("trec_rank_of_pairs");
+}

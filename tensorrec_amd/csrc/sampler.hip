@@ -1,0 +1,101 @@
+// tensorrec_amd/csrc/sampler.hip -- K7: negative-item sampling on the device.
+//
+// Replaces the host callback sample_items (tensorrec/util.py:12-21, hooked in by tf.py_func at
+// tensorrec/tensorrec.py:298-302): n_users separate np.random.choice calls, O(n_users * n_items) host work under
+// the GIL every step.  Same contract: an int [n_users, n_sampled] table (user-major, util.py:16-19), uniform over ALL
+// items (positives are not excluded, util.py:13), distinct within a user when replace == 0.
+//
+// NumPy's MT19937 stream cannot be reproduced by a parallel sampler, so this is a different (counter-based)
+// generator with the same distribution; parity of a training step is checked with host-supplied samples
+// ("replay"), and this kernel is checked bit-for-bit against its own integer restatement
+// (oracle/device_sampler.py) plus distribution tests.
+//
+//   replace == 0 : sample s of user u is pi_u(s), where pi_u is a keyed pseudo-random PERMUTATION of
+//                  [0, n_items): a 6-round unbalanced Feistel network on ceil(log2 n_items) bits with
+//                  cycle-walking.  Distinctness is structural -- no rejection table, no memory, O(1) per sample.
+//   replace == 1 : Philox4x32-10 word -> (word * n_items) >> 32.
+// Keys come from Philox4x32-10 with counter (user, 0, step, stream) and key (seed_lo, seed_hi).
+#include "common.hpp"
+
+#define PHILOX_M0 0xD2511F53u
+#define PHILOX_M1 0xCD9E8D57u
+#define PHILOX_W0 0x9E3779B9u
+#define PHILOX_W1 0xBB67AE85u
+
+struct u4 { uint32_t x, y, z, w; };
+
+__host__ __device__ inline u4 philox4x32_10(u4 c, uint32_t k0, uint32_t k1)
+{
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)PHILOX_M0 * c.x, p1 = (uint64_t)PHILOX_M1 * c.z;
+        u4 n;
+        n.x = (uint32_t)(p1 >> 32) ^ c.y ^ k0;
+        n.y = (uint32_t)p1;
+        n.z = (uint32_t)(p0 >> 32) ^ c.w ^ k1;
+        n.w = (uint32_t)p0;
+        c = n;
+        k0 += PHILOX_W0; k1 += PHILOX_W1;
+    }
+    return c;
+}
+
+__host__ __device__ inline uint32_t feistel_f(uint32_t r, uint32_t key)
+{
+    uint32_t h = r * 0x9E3779B1u + key;
+    h ^= h >> 15; h *= 0x85EBCA77u;
+    h ^= h >> 13; h *= 0xC2B2AE3Du;
+    h ^= h >> 16;
+    return h;
+}
+
+// one application of the keyed permutation on [0, 2^bits)
+__host__ __device__ inline uint32_t feistel_permute(uint32_t x, int bits, const uint32_t* keys)
+{
+    int wl = bits >> 1, wr = bits - wl;                 // widths of (L, R)
+    uint32_t L = x >> wr, R = x & ((1u << wr) - 1u);
+    for (int r = 0; r < 6; ++r) {
+        const uint32_t nl = R;
+        const uint32_t nr = (L ^ feistel_f(R, keys[r])) & ((1u << wl) - 1u);
+        L = nl; R = nr;
+        const int t = wl; wl = wr; wr = t;
+    }
+    return (L << wr) | R;
+}
+
+__global__ __launch_bounds__(256) void sample_items_kernel(int64_t n_users, int32_t n_items, int32_t n_sampled,
+                                                          int replace, uint32_t seed_lo, uint32_t seed_hi,
+                                                          uint32_t step, int bits, int32_t* __restrict__ out)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_users * n_sampled) return;
+    const int64_t u = idx / n_sampled;
+    const uint32_t s = (uint32_t)(idx - u * n_sampled);
+    if (replace) {
+        const u4 r = philox4x32_10(u4{(uint32_t)u, s >> 2, step, 2u + (uint32_t)(u >> 32)}, seed_lo, seed_hi);
+        const uint32_t w = (s & 3) == 0 ? r.x : (s & 3) == 1 ? r.y : (s & 3) == 2 ? r.z : r.w;
+        out[idx] = (int32_t)(((uint64_t)w * (uint64_t)(uint32_t)n_items) >> 32);
+        return;
+    }
+    const u4 ka = philox4x32_10(u4{(uint32_t)u, (uint32_t)(u >> 32), step, 0u}, seed_lo, seed_hi);
+    const u4 kb = philox4x32_10(u4{(uint32_t)u, (uint32_t)(u >> 32), step, 1u}, seed_lo, seed_hi);
+    const uint32_t keys[6] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y};
+    uint32_t x = s;
+    do { x = feistel_permute(x, bits, keys); } while (x >= (uint32_t)n_items);   // cycle-walk back into [0, n_items)
+    out[idx] = (int32_t)x;
+}
+
+extern "C" int trec_sample_items(int64_t n_users, int32_t n_items, int32_t n_sampled, int32_t replace, uint64_t seed,
+                                 uint32_t step, int32_t* out, void* stream)
+{
+    TREC_REQUIRE(out, "trec_sample_items: null pointer");
+    TREC_REQUIRE(n_items >= 1 && n_sampled >= 1, "trec_sample_items: n_items and n_sampled must be >= 1");
+    // np.random.choice(replace=False) raises when size > population (util.py:13); same contract here
+    TREC_REQUIRE(replace || n_sampled <= n_items, "trec_sample_items: cannot take a larger sample than population when replace is false");
+    if (n_users == 0) return TREC_OK;
+    int bits = 2;
+    while (bits < 31 && (1u << bits) < (uint32_t)n_items) ++bits;
+    const int64_t total = n_users * (int64_t)n_sampled;
+    hipLaunchKernelGGL(sample_items_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       n_users, n_items, n_sampled, replace, (uint32_t)seed, (uint32_t)(seed >> 32), step, bits, out);
+    return trec_check_launch("trec_sample_items");
+}

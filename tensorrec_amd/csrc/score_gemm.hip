@@ -1,0 +1,557 @@
+// tensorrec_amd/csrc/score_gemm.hip -- K2: the user x item score contraction on MFMA with fused epilogues.
+//
+// Replaces tf.matmul(user_repr, item_repr, transpose_b=True) at tensorrec/prediction_graphs.py:50
+// (DotProduct), :94 (Euclidean) and tensorrec/recommendation_graphs.py:121 (relative_cosine), the bias
+// broadcast at recommendation_graphs.py:41 and -- in TOPK mode -- the first tf.nn.top_k of
+// rank_predictions (recommendation_graphs.py:80) truncated to k, WITHOUT writing the [U, I] matrix.
+//
+// Shape of the problem: K = n_components is short (<= 256), so there is no K loop over tiles: the
+// "resident" operand R (users) lives in registers as MFMA fragments for the whole kernel and the
+// "streamed" operand T (items) flows through a double-buffered, XOR-swizzled LDS tile, exactly once
+// per workgroup.  Every workgroup is 4 waves (one per SIMD); a wave owns NCB column blocks of 32
+// resident rows.  Two workgroups share a CU so one's MFMAs overlap the other's epilogue VALU.
+//
+//   STORE epilogue  acc = mfma(R, T): rows = users, cols = items  -> lanes run along items, so the
+//                   fp32 tile is written with 128-byte row segments (predict()).
+//   TOPK  epilogue  acc = mfma(T, R): rows = items, cols = users -> lane & 31 IS the user, so each
+//                   lane keeps a sorted top-KTOP list for its user in registers and the common path
+//                   is "max of my 16 scores <= my threshold -> skip".  Lists are merged by
+//                   trec_topk_merge (wave-shuffle selection, value desc / index asc).
+//
+// Arithmetic types (runtime `dtype`): 0 = fp32 on v_mfma_f32_32x32x2_f32 -- an exact fp32 fmaf chain
+// in k order, bit-identical to oracle/tr_oracle.c:orc_score_dense; 1 = bf16 operands on
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulate (the throughput mode named by BASELINE.json).
+#include "common.hpp"
+#include <math.h>
+
+#define EPI_STORE 0
+#define EPI_TOPK 1
+#define KTOP 16
+
+struct ScoreParams {
+    const void* R;            // resident operand [n_r, KT] (fp32 or bf16), users
+    const void* T;            // streamed operand [n_t, KT], items
+    int64_t n_r, n_t;
+    int64_t chunk_len;        // streamed rows per chunk (multiple of BN)
+    int n_chunks;
+    int n_rblocks;
+    const float* r_bias;      // nullable [n_r]   user bias   (added first, recommendation_graphs.py:41)
+    const float* t_bias;      // nullable [n_t]   item bias   (added second)
+    const float* r_sqnorm;    // euclid only [n_r]
+    const float* t_sqnorm;    // euclid only [n_t]
+    int euclid;
+    float* out;               // STORE: [n_r, ld_out]
+    int64_t ld_out;
+    float* part_vals;         // TOPK: [n_r, n_parts, KTOP]
+    int32_t* part_idx;
+    int n_parts;              // 2 * n_chunks
+    int32_t t_index_base;     // added to item indices written by TOPK (item shards)
+};
+
+template <int DT> struct ElemOf;
+template <> struct ElemOf<0> { static constexpr int BYTES = 4; };
+template <> struct ElemOf<1> { static constexpr int BYTES = 2; };
+
+template <int CH> __device__ __forceinline__ int swz(int row) {
+    // physical 16-byte chunk = logical chunk ^ swz(row); makes a 16-lane ds_read_b128 group hit 16 distinct slots
+    if (CH >= 16) return row & 15;
+    if (CH == 8) return (row >> 1) & 7;
+    if (CH == 4) return (row >> 2) & 3;
+    return 0;
+}
+
+__device__ __forceinline__ int cd_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }  // 32x32 C/D row of reg r
+
+// sorted-descending insertion; `s` is -inf for lanes that do not qualify (then nothing moves)
+__device__ __forceinline__ void topk_insert(float (&tv)[KTOP], int32_t (&ti)[KTOP], float s, int32_t id)
+{
+    bool ge_j = tv[KTOP - 1] >= s;
+#pragma unroll
+    for (int j = KTOP - 1; j >= 0; --j) {
+        const bool ge_jm1 = (j == 0) ? true : (tv[j - 1] >= s);
+        const float pv = (j == 0) ? 0.f : tv[j - 1];
+        const int32_t pi = (j == 0) ? 0 : ti[j - 1];
+        tv[j] = ge_j ? tv[j] : (ge_jm1 ? s : pv);
+        ti[j] = ge_j ? ti[j] : (ge_jm1 ? id : pi);
+        ge_j = ge_jm1;
+    }
+}
+
+template <int DT, int KT, int BN, int NCB, int EPI, bool GLDS, bool EUCLID, int WPS>
+__global__ __launch_bounds__(256, WPS) void score_gemm_kernel(ScoreParams p)
+{
+    constexpr int ES = ElemOf<DT>::BYTES;
+    constexpr int RB = KT * ES;              // bytes per operand row
+    constexpr int CH = RB / 16;              // 16-byte chunks per row
+    constexpr int KS = (DT == 1) ? KT / 16 : KT / 2;   // MFMA k-steps
+    constexpr int TILE_BYTES = BN * RB;
+    constexpr int NSLOT = BN * CH / 256;     // 16-byte staging slots per thread per tile
+    static_assert(BN * CH % 256 == 0 && NSLOT >= 1, "tile too small for 256 threads");
+    static_assert(BN % 32 == 0, "BN must be a multiple of the 32-row MFMA block");
+
+    constexpr int RW = 4 * NCB * 32;         // resident rows per workgroup
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 * TILE_BYTES + (STORE: 2 * RW floats)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+
+    const int rblock = blockIdx.x % p.n_rblocks;
+    const int chunk = blockIdx.x / p.n_rblocks;
+    const int64_t r_base = ((int64_t)rblock * 4 + wave) * (NCB * 32);       // first resident row of this wave
+    const int64_t t_begin = (int64_t)chunk * p.chunk_len;
+    const int64_t t_end = (t_begin + p.chunk_len < p.n_t) ? t_begin + p.chunk_len : p.n_t;
+    const int n_tiles = (int)((t_end - t_begin + BN - 1) / BN);
+
+    // ---- resident fragments: straight from global into registers, once ----
+    bf16x8 rfb[(DT == 1) ? NCB : 1][(DT == 1) ? KS : 1];
+    float rff[(DT == 0) ? NCB : 1][(DT == 0) ? KS : 1];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+        int64_t row = r_base + cb * 32 + l31;
+        if (row >= p.n_r) row = p.n_r - 1;                                   // clamped rows are never written
+        const char* src = (const char*)p.R + row * (int64_t)RB;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (DT == 1) rfb[cb][ks] = *(const bf16x8*)(src + (ks * 2 + half) * 16);
+            else rff[cb][ks] = *(const float*)(src + (2 * ks + half) * 4);
+        }
+    }
+
+    // ---- epilogue constants ----
+    float r_bias_col[NCB], r_sq_col[NCB];          // TOPK: my user's bias / squared norm (lane & 31 is the user)
+    float* r_bias_lds = (float*)(smem + 2 * TILE_BYTES);   // STORE: per resident row, read back as float4 per 4-row group
+    float* r_sq_lds = r_bias_lds + RW;
+    if (EPI == EPI_TOPK) {
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            int64_t u = r_base + cb * 32 + l31;
+            if (u >= p.n_r) u = p.n_r - 1;
+            r_bias_col[cb] = p.r_bias ? p.r_bias[u] : 0.f;
+            r_sq_col[cb] = EUCLID ? p.r_sqnorm[u] : 0.f;
+        }
+    } else {
+        for (int i = tid; i < RW; i += 256) {
+            int64_t u = (int64_t)rblock * RW + i;
+            if (u >= p.n_r) u = p.n_r - 1;
+            r_bias_lds[i] = p.r_bias ? p.r_bias[u] : 0.f;
+            r_sq_lds[i] = EUCLID ? p.r_sqnorm[u] : 0.f;
+        }
+    }
+
+    float tv[(EPI == EPI_TOPK) ? NCB : 1][KTOP];
+    int32_t ti[(EPI == EPI_TOPK) ? NCB : 1][KTOP];
+    if (EPI == EPI_TOPK) {
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int j = 0; j < KTOP; ++j) { tv[cb][j] = -INFINITY; ti[cb][j] = -1; }
+    }
+
+    // ---- staging of the streamed tile: slot q = i*256 + tid  ->  (row, physical chunk) ----
+    u32x4 stage[GLDS ? 1 : NSLOT];
+    auto stage_issue = [&](int tile, int buf) {
+        const int64_t row0 = t_begin + (int64_t)tile * BN;
+#pragma unroll
+        for (int i = 0; i < NSLOT; ++i) {
+            const int q = i * 256 + tid;
+            const int row = q / CH, pc = q % CH;
+            const int kc = pc ^ swz<CH>(row);
+            int64_t grow = row0 + row;
+            if (grow >= p.n_t) grow = p.n_t - 1;
+            const char* src = (const char*)p.T + grow * (int64_t)RB + kc * 16;
+            if (GLDS) {
+                char* dst = smem + buf * TILE_BYTES + (i * 256 + wave * 64) * 16;   // wave-uniform; lane*16 is implicit
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            } else {
+                stage[i] = *(const u32x4*)src;
+            }
+        }
+    };
+    auto stage_commit = [&](int buf) {
+        if (!GLDS) {
+#pragma unroll
+            for (int i = 0; i < NSLOT; ++i) *(u32x4*)(smem + buf * TILE_BYTES + (i * 256 + tid) * 16) = stage[i];
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    };
+
+    stage_issue(0, 0);
+    stage_commit(0);
+    __syncthreads();
+
+    for (int t = 0; t < n_tiles; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < n_tiles) stage_issue(t + 1, buf ^ 1);
+        const char* tile = smem + buf * TILE_BYTES;
+        const int64_t tile_row0 = t_begin + (int64_t)t * BN;
+        const bool partial = tile_row0 + BN > p.n_t;
+
+#pragma unroll 1
+        for (int rb = 0; rb < BN / 32; ++rb) {
+            f32x16 acc[NCB];
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
+
+            const int lrow = rb * 32 + l31;
+            const char* rowp = tile + lrow * RB;
+            const int sw = swz<CH>(lrow);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if (DT == 1) {
+                    const bf16x8 tf = *(const bf16x8*)(rowp + (((ks * 2 + half) ^ sw) * 16));
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb) {
+                        if (EPI == EPI_TOPK) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf, rfb[cb][ks], acc[cb], 0, 0, 0);
+                        else acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rfb[cb][ks], tf, acc[cb], 0, 0, 0);
+                    }
+                } else {
+                    const int k = 2 * ks + half;
+                    const float tf = *(const float*)(rowp + (((k >> 2) ^ sw) * 16) + (k & 3) * 4);
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb) {
+                        if (EPI == EPI_TOPK) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(tf, rff[cb][ks], acc[cb], 0, 0, 0);
+                        else acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(rff[cb][ks], tf, acc[cb], 0, 0, 0);
+                    }
+                }
+            }
+
+            const int64_t blk_row0 = tile_row0 + rb * 32;     // first streamed row (item) of this 32-block
+            if (EPI == EPI_TOPK) {
+                // rows of acc = items blk_row0 + cd_row(r, half); col = my user
+                float tb[16], tq[16];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int64_t i0 = blk_row0 + 8 * q + 4 * half;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        int64_t ii = i0 + e;
+                        if (ii >= p.n_t) ii = p.n_t - 1;
+                        tb[q * 4 + e] = p.t_bias ? p.t_bias[ii] : 0.f;
+                        tq[q * 4 + e] = EUCLID ? p.t_sqnorm[ii] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) {
+                    f32x16 s = acc[cb];
+                    float m = -INFINITY;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float v = s[r];
+                        if (EUCLID) {
+                            float dist = (r_sq_col[cb] - 2.0f * v) + tq[r];
+                            dist = fmaxf(dist, 1e-16f);
+                            v = -1.0f * sqrtf(dist);
+                        }
+                        if (p.r_bias) v = v + r_bias_col[cb];
+                        if (p.t_bias) v = v + tb[r];
+                        if (partial && blk_row0 + cd_row(r, half) >= p.n_t) v = -INFINITY;
+                        s[r] = v;
+                        m = fmaxf(m, v);
+                    }
+                    if (__any(m > tv[cb][KTOP - 1])) {
+#pragma unroll 1
+                        for (int r = 0; r < 16; ++r) {
+                            const float v = s[r];
+                            const bool q = v > tv[cb][KTOP - 1];
+                            if (__any(q))
+                                topk_insert(tv[cb], ti[cb], q ? v : -INFINITY,
+                                            (int32_t)(blk_row0 + cd_row(r, half)) + p.t_index_base);
+                        }
+                    }
+                }
+            } else {
+                const int64_t item = blk_row0 + l31;
+                const bool item_ok = item < p.n_t;
+                const int64_t ic = item_ok ? item : p.n_t - 1;
+                const float tbv = p.t_bias ? p.t_bias[ic] : 0.f;
+                const float tqv = EUCLID ? p.t_sqnorm[ic] : 0.f;
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int lrow4 = (wave * NCB + cb) * 32 + 8 * q + 4 * half;     // 4 consecutive resident rows
+                        const f32x4 rb4 = *(const f32x4*)(r_bias_lds + lrow4);
+                        const f32x4 rq4 = *(const f32x4*)(r_sq_lds + lrow4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int r = q * 4 + e;
+                            const int64_t u = r_base + cb * 32 + cd_row(r, half);
+                            float v = acc[cb][r];
+                            if (EUCLID) {
+                                float dist = (rq4[e] - 2.0f * v) + tqv;
+                                dist = fmaxf(dist, 1e-16f);
+                                v = -1.0f * sqrtf(dist);
+                            }
+                            if (p.r_bias) v = v + rb4[e];
+                            if (p.t_bias) v = v + tbv;
+                            if (item_ok && u < p.n_r) p.out[u * p.ld_out + item] = v;
+                        }
+                    }
+            }
+        }
+
+        if (t + 1 < n_tiles) stage_commit(buf ^ 1);
+        __syncthreads();
+    }
+
+    if (EPI == EPI_TOPK) {
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            const int64_t u = r_base + cb * 32 + l31;
+            if (u < p.n_r) {
+                const int64_t o = (u * p.n_parts + (chunk * 2 + half)) * KTOP;
+#pragma unroll
+                for (int j = 0; j < KTOP; j += 4) {
+                    *(f32x4*)(p.part_vals + o + j) = (f32x4){tv[cb][j], tv[cb][j + 1], tv[cb][j + 2], tv[cb][j + 3]};
+                    *(int4*)(p.part_idx + o + j) = make_int4(ti[cb][j], ti[cb][j + 1], ti[cb][j + 2], ti[cb][j + 3]);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// topk_merge: one wave per user; candidates [n_cand] = n_parts * kcap, CPL per lane in registers;
+// k rounds of wave-wide arg-best on (value desc, index asc) with __shfl_xor butterflies.
+template <int CPL>
+__global__ __launch_bounds__(256) void topk_merge_kernel(const float* __restrict__ pv, const int32_t* __restrict__ pi,
+                                                        int64_t n_users, int n_cand, int k, float* __restrict__ ov,
+                                                        int32_t* __restrict__ oi)
+{
+    const int64_t u = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (u >= n_users) return;
+    const int lane = lane_id();
+    float v[CPL];
+    int32_t id[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+        const int j = c * 64 + lane;
+        v[c] = -INFINITY; id[c] = 0x7fffffff;
+        if (j < n_cand) {
+            const int32_t raw = pi[u * n_cand + j];
+            if (raw >= 0) { v[c] = pv[u * n_cand + j]; id[c] = raw; }
+        }
+    }
+    for (int t = 0; t < k; ++t) {
+        float bv = v[0]; int32_t bi = id[0];
+#pragma unroll
+        for (int c = 1; c < CPL; ++c) {
+            const bool better = (v[c] > bv) || (v[c] == bv && id[c] < bi);
+            bv = better ? v[c] : bv; bi = better ? id[c] : bi;
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ovv = __shfl_xor(bv, off, 64);
+            const int32_t oii = __shfl_xor(bi, off, 64);
+            const bool better = (ovv > bv) || (ovv == bv && oii < bi);
+            bv = better ? ovv : bv; bi = better ? oii : bi;
+        }
+        // every lane now holds the winner; retire it where it lives (indices are unique among real candidates)
+#pragma unroll
+        for (int c = 0; c < CPL; ++c)
+            if (id[c] == bi && bi != 0x7fffffff) { v[c] = -INFINITY; id[c] = 0x7fffffff; }
+        if (lane == 0) {
+            ov[u * k + t] = (bi == 0x7fffffff) ? -INFINITY : bv;
+            oi[u * k + t] = (bi == 0x7fffffff) ? -1 : bi;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// score_prep: fp32 representation [n, d] -> MFMA operand [n, KT] (fp32 or bf16, zero padded to KT),
+// optionally row-normalised (cosine: prediction_graphs.py:68-69 / recommendation_graphs.py:119-120) and/or
+// with the row squared norm emitted (euclidean: prediction_graphs.py:87-90).  One wave per row.
+__global__ __launch_bounds__(256) void score_prep_kernel(const float* __restrict__ x, int64_t n, int d, int kt,
+                                                        int normalize, int dtype, void* __restrict__ out,
+                                                        float* __restrict__ sqnorm)
+{
+    const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (row >= n) return;
+    const int lane = lane_id();
+    const float* xr = x + row * (int64_t)d;
+    float scale = 1.0f;
+    if (normalize || sqnorm) {
+        float ss = 0.f;
+        for (int c = lane; c < d; c += 64) ss = fmaf(xr[c], xr[c], ss);
+        for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+        if (normalize) scale = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
+        if (sqnorm && lane == 0) sqnorm[row] = ss;    // squared norm of the UN-normalised row
+    }
+    for (int c0 = lane * 2; c0 < kt; c0 += 128) {
+        float a = (c0 < d) ? xr[c0] : 0.f, b = (c0 + 1 < d) ? xr[c0 + 1] : 0.f;
+        if (normalize) { a *= scale; b *= scale; }
+        if (dtype == 0) {
+            float* o = (float*)out + row * (int64_t)kt + c0;
+            o[0] = a; o[1] = b;
+        } else {
+            unsigned int packed = (unsigned int)f32_to_bf16_rne(a) | ((unsigned int)f32_to_bf16_rne(b) << 16);
+            *((unsigned int*)((unsigned short*)out + row * (int64_t)kt + c0)) = packed;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+template <int DT, int KT, int BN, int NCB, int EPI, bool GLDS, bool EUCLID>
+static int launch_score(const ScoreParams& p, hipStream_t st)
+{
+    constexpr int LDS = 2 * BN * KT * ElemOf<DT>::BYTES + (EPI == EPI_STORE ? 2 * 4 * NCB * 32 * 4 : 0);
+    // 2 workgroups per CU (256 registers per lane) unless the resident fragments + top-k lists need more
+    constexpr int WPS = ((DT == 0 && KT >= 128) || KT == 256 || (EUCLID && KT >= 128)) ? 1 : 2;
+    auto kern = score_gemm_kernel<DT, KT, BN, NCB, EPI, GLDS, EUCLID, WPS>;
+    static bool attr_set = false;
+    if (!attr_set && LDS > 48 * 1024) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    const unsigned blocks = (unsigned)p.n_rblocks * (unsigned)p.n_chunks;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), LDS, st, p);
+    return trec_check_launch("trec_score_gemm");
+}
+
+struct ScoreCfg { int bn, ncb; };
+static ScoreCfg score_cfg(int dtype, int kt)
+{
+    if (dtype == 1) return ScoreCfg{64, kt <= 128 ? 2 : 1};
+    return ScoreCfg{32, 1};
+}
+
+extern "C" int trec_score_kpad(int32_t d)
+{
+    if (d <= 32) return 32;
+    if (d <= 64) return 64;
+    if (d <= 128) return 128;
+    if (d <= 256) return 256;
+    return -1;
+}
+
+// resident rows handled by one workgroup for (dtype, kpad): 4 waves * NCB * 32
+extern "C" int trec_score_rows_per_workgroup(int32_t dtype, int32_t kpad) { return 4 * score_cfg(dtype, kpad).ncb * 32; }
+extern "C" int trec_score_tile_rows(int32_t dtype, int32_t kpad) { return score_cfg(dtype, kpad).bn; }
+extern "C" int trec_score_topk_capacity(void) { return KTOP; }
+
+template <int EPI>
+static int dispatch_score(int dtype, int kt, int variant, const ScoreParams& p, hipStream_t st)
+{
+    const bool glds = (variant & 1) != 0;
+#define TREC_SCORE_CASE(DT, KTV, BNV, NCBV)                                            \
+    if (dtype == DT && kt == KTV) {                                                    \
+        if (p.euclid) return launch_score<DT, KTV, BNV, NCBV, EPI, false, true>(p, st);  \
+        if (glds) return launch_score<DT, KTV, BNV, NCBV, EPI, true, false>(p, st);    \
+        return launch_score<DT, KTV, BNV, NCBV, EPI, false, false>(p, st);             \
+    }
+    TREC_SCORE_CASE(1, 32, 64, 2)
+    TREC_SCORE_CASE(1, 64, 64, 2)
+    TREC_SCORE_CASE(1, 128, 64, 2)
+    TREC_SCORE_CASE(1, 256, 64, 1)
+    TREC_SCORE_CASE(0, 32, 32, 1)
+    TREC_SCORE_CASE(0, 64, 32, 1)
+    TREC_SCORE_CASE(0, 128, 32, 1)
+    TREC_SCORE_CASE(0, 256, 32, 1)
+#undef TREC_SCORE_CASE
+    trec_set_last_error("trec_score_gemm: unsupported (dtype, kpad)");
+    return TREC_ERR_UNSUPPORTED;
+}
+
+static int fill_common(ScoreParams& p, const void* users, const void* items, int dtype, int kpad, int64_t n_users,
+                       int64_t n_items, const float* user_bias, const float* item_bias, int mode,
+                       const float* user_sqnorm, const float* item_sqnorm, int n_chunks)
+{
+    TREC_REQUIRE(users && items, "trec_score_gemm: null operand");
+    TREC_REQUIRE(dtype == 0 || dtype == 1, "trec_score_gemm: dtype must be 0 (fp32) or 1 (bf16)");
+    TREC_REQUIRE(kpad == 32 || kpad == 64 || kpad == 128 || kpad == 256, "trec_score_gemm: kpad must be 32/64/128/256");
+    TREC_REQUIRE(n_users >= 1 && n_items >= 1, "trec_score_gemm: empty operand");
+    TREC_REQUIRE(mode == 0 || mode == 1, "trec_score_gemm: mode must be 0 (dot) or 1 (euclidean)");
+    TREC_REQUIRE(mode == 0 || (user_sqnorm && item_sqnorm), "trec_score_gemm: euclidean mode needs squared norms");
+    TREC_REQUIRE(n_chunks >= 1, "trec_score_gemm: n_chunks must be >= 1");
+    const ScoreCfg c = score_cfg(dtype, kpad);
+    p.R = users; p.T = items; p.n_r = n_users; p.n_t = n_items;
+    p.n_rblocks = (int)ceil_div64(n_users, 4 * c.ncb * 32);
+    int64_t cl = ceil_div64(ceil_div64(n_items, n_chunks), c.bn) * c.bn;
+    p.chunk_len = cl;
+    p.n_chunks = (int)ceil_div64(n_items, cl);
+    p.r_bias = user_bias; p.t_bias = item_bias; p.r_sqnorm = user_sqnorm; p.t_sqnorm = item_sqnorm;
+    p.euclid = mode;
+    return TREC_OK;
+}
+
+extern "C" int trec_score_gemm_store(const void* users, const void* items, int32_t dtype, int32_t kpad,
+                                     int64_t n_users, int64_t n_items, const float* user_bias,
+                                     const float* item_bias, int32_t mode, const float* user_sqnorm,
+                                     const float* item_sqnorm, float* out, int64_t ld_out, int32_t variant,
+                                     void* stream)
+{
+    ScoreParams p = {};
+    TREC_REQUIRE(out && ld_out >= n_items, "trec_score_gemm_store: bad output");
+    // enough chunks to put >= 2 workgroups on every CU when the user count alone cannot
+    const int rows_wg = trec_score_rows_per_workgroup(dtype, kpad);
+    int n_chunks = 1;
+    if (rows_wg > 0) {
+        const int64_t rblocks = ceil_div64(n_users, rows_wg);
+        while (rblocks * n_chunks < 1024 && n_chunks < 64 && ceil_div64(n_items, n_chunks * 2) >= 256) n_chunks *= 2;
+    }
+    int rc = fill_common(p, users, items, dtype, kpad, n_users, n_items, user_bias, item_bias, mode, user_sqnorm,
+                         item_sqnorm, n_chunks);
+    if (rc) return rc;
+    p.out = out; p.ld_out = ld_out;
+    return dispatch_score<EPI_STORE>(dtype, kpad, variant, p, (hipStream_t)stream);
+}
+
+// number of partial lists per user that trec_score_gemm_topk writes for a requested chunk count
+extern "C" int trec_score_topk_parts(int32_t dtype, int32_t kpad, int64_t n_items, int32_t n_chunks)
+{
+    const ScoreCfg c = score_cfg(dtype, kpad);
+    if (n_chunks < 1 || n_items < 1) return -1;
+    const int64_t cl = ceil_div64(ceil_div64(n_items, n_chunks), c.bn) * c.bn;
+    return 2 * (int)ceil_div64(n_items, cl);
+}
+
+extern "C" int trec_score_gemm_topk(const void* users, const void* items, int32_t dtype, int32_t kpad,
+                                    int64_t n_users, int64_t n_items, int32_t item_index_base,
+                                    const float* user_bias, const float* item_bias, int32_t mode,
+                                    const float* user_sqnorm, const float* item_sqnorm, int32_t n_chunks,
+                                    float* part_vals, int32_t* part_idx, int32_t variant, void* stream)
+{
+    ScoreParams p = {};
+    TREC_REQUIRE(part_vals && part_idx, "trec_score_gemm_topk: null workspace");
+    int rc = fill_common(p, users, items, dtype, kpad, n_users, n_items, user_bias, item_bias, mode, user_sqnorm,
+                         item_sqnorm, n_chunks);
+    if (rc) return rc;
+    p.part_vals = part_vals; p.part_idx = part_idx; p.n_parts = 2 * p.n_chunks; p.t_index_base = item_index_base;
+    return dispatch_score<EPI_TOPK>(dtype, kpad, variant, p, (hipStream_t)stream);
+}
+
+extern "C" int trec_topk_merge(const float* part_vals, const int32_t* part_idx, int64_t n_users, int32_t n_cand,
+                               int32_t k, float* out_vals, int32_t* out_idx, void* stream)
+{
+    TREC_REQUIRE(part_vals && part_idx && out_vals && out_idx, "trec_topk_merge: null pointer");
+    TREC_REQUIRE(k >= 1 && n_cand >= 1 && n_cand <= 1024, "trec_topk_merge: need 1 <= n_cand <= 1024, k >= 1");
+    if (n_users == 0) return TREC_OK;
+    const unsigned blocks = (unsigned)ceil_div64(n_users * 64, 256);
+    hipStream_t st = (hipStream_t)stream;
+    const int cpl = (n_cand + 63) / 64;
+#define TREC_MERGE(CPLV) hipLaunchKernelGGL((topk_merge_kernel<CPLV>), dim3(blocks), dim3(256), 0, st, part_vals, part_idx, n_users, n_cand, k, out_vals, out_idx)
+    if (cpl <= 1) TREC_MERGE(1);
+    else if (cpl <= 2) TREC_MERGE(2);
+    else if (cpl <= 4) TREC_MERGE(4);
+    else if (cpl <= 8) TREC_MERGE(8);
+    else TREC_MERGE(16);
+#undef TREC_MERGE
+    return trec_check_launch("trec_topk_merge");
+}
+
+extern "C" int trec_score_prep(const float* repr, int64_t n, int32_t d, int32_t kpad, int32_t normalize,
+                               int32_t dtype, void* out, float* out_sqnorm, void* stream)
+{
+    TREC_REQUIRE(repr && out, "trec_score_prep: null pointer");
+    TREC_REQUIRE(d >= 1 && kpad >= d && kpad % 2 == 0, "trec_score_prep: need kpad >= d, kpad even");
+    TREC_REQUIRE(dtype == 0 || dtype == 1, "trec_score_prep: dtype must be 0 or 1");
+    if (n == 0) return TREC_OK;
+    hipLaunchKernelGGL(score_prep_kernel, dim3((unsigned)ceil_div64(n * 64, 256)), dim3(256), 0, (hipStream_t)stream,
+                       repr, n, d, kpad, normalize, dtype, out, out_sqnorm);
+    return trec_check_launch("trec_score_prep");
+}

@@ -1,0 +1,403 @@
+// tensorrec_amd/csrc/spmm.hip -- K1: CSR gather-SpMM and the row-wise companions.
+//
+// Replaces tf.sparse_tensor_dense_matmul at tensorrec/representation_graphs.py:40 (Linear),
+// :119 (ReLU layer 1) and tensorrec/recommendation_graphs.py:15 (bias projection), the row
+// tf.nn.l2_normalize at representation_graphs.py:57 / prediction_graphs.py:68-69 /
+// recommendation_graphs.py:119-120, and tf.nn.relu(tf.add(..)) at representation_graphs.py:119-120.
+// The backward of the SpMM w.r.t. the weights (a dense [F,d] gradient in TF) is the same
+// kernel run on the transposed CSR, so it is deterministic and atomics-free.
+//
+// HBM-bound: every output row is a gather of nnz(row) weight rows (d*4 B each) plus one row
+// write.  A "subgroup" of LPR = pow2(d/4) lanes owns R consecutive rows; each lane keeps
+// float4 accumulators and the first non-zero of all R rows is fetched as one batch so that a
+// wave has R*64/LPR independent weight-row gathers in flight (identity features = 1 nnz/row).
+// Accumulation order is CSR order with one fmaf per element == oracle/tr_oracle.c:orc_spmm_csr.
+#include "common.hpp"
+
+#define L2NORM_EPS 1e-12f
+
+template <int LOG2W>
+__device__ __forceinline__ float subgroup_sum(float v, int lpr) {
+    // butterfly over the lpr lanes of this subgroup (lpr is a power of two <= 64)
+    for (int off = lpr >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// EPI: 0 none | 1 row L2-normalise (writes inv norm) | 2 + col_bias, ReLU
+template <int ITERS, int R, int EPI>
+__global__ __launch_bounds__(256) void spmm_csr_vec4_kernel(
+    const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, const float* __restrict__ values,
+    const int32_t* __restrict__ val_perm, int64_t n_rows, const float* __restrict__ W, int d, int lpr_log2,
+    const float* __restrict__ col_bias, int accumulate, float* __restrict__ out, float* __restrict__ out_inv)
+{
+    const int lpr = 1 << lpr_log2;
+    const int sub_lane = threadIdx.x & (lpr - 1);
+    const int64_t sg = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> lpr_log2;
+    const int64_t row0 = sg * R;
+    if (row0 >= n_rows) return;
+
+    int col[ITERS];
+    bool cvalid[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        col[it] = (it * lpr + sub_lane) * 4;
+        cvalid[it] = col[it] < d;
+    }
+
+    f32x4 acc[R][ITERS];
+    int64_t s[R], e[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t row = row0 + r;
+        const bool v = row < n_rows;
+        s[r] = v ? indptr[row] : 0;
+        e[r] = v ? indptr[row + 1] : 0;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            acc[r][it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (accumulate && v && cvalid[it]) acc[r][it] = *(const f32x4*)(out + row * (int64_t)d + col[it]);
+        }
+    }
+    // batch the first non-zero of the R rows: R independent index loads, then R independent gathers
+    int32_t c0[R];
+    float v0[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        c0[r] = 0; v0[r] = 0.f;
+        if (s[r] < e[r]) {
+            c0[r] = indices[s[r]];
+            v0[r] = values[val_perm ? (int64_t)val_perm[s[r]] : s[r]];
+        }
+    }
+    f32x4 x0[R][ITERS];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            x0[r][it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (s[r] < e[r] && cvalid[it]) x0[r][it] = *(const f32x4*)(W + (int64_t)c0[r] * d + col[it]);
+        }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (s[r] < e[r]) {
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {
+                acc[r][it].x = fmaf(v0[r], x0[r][it].x, acc[r][it].x);
+                acc[r][it].y = fmaf(v0[r], x0[r][it].y, acc[r][it].y);
+                acc[r][it].z = fmaf(v0[r], x0[r][it].z, acc[r][it].z);
+                acc[r][it].w = fmaf(v0[r], x0[r][it].w, acc[r][it].w);
+            }
+        }
+    // remaining non-zeros, two gathers in flight per row
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        int64_t j = s[r] + 1;
+        for (; j + 1 < e[r]; j += 2) {
+            const int32_t ca = indices[j], cb = indices[j + 1];
+            const float va = values[val_perm ? (int64_t)val_perm[j] : j];
+            const float vb = values[val_perm ? (int64_t)val_perm[j + 1] : j + 1];
+            f32x4 xa[ITERS], xb[ITERS];
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {
+                xa[it] = xb[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (cvalid[it]) {
+                    xa[it] = *(const f32x4*)(W + (int64_t)ca * d + col[it]);
+                    xb[it] = *(const f32x4*)(W + (int64_t)cb * d + col[it]);
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {
+                acc[r][it].x = fmaf(vb, xb[it].x, fmaf(va, xa[it].x, acc[r][it].x));
+                acc[r][it].y = fmaf(vb, xb[it].y, fmaf(va, xa[it].y, acc[r][it].y));
+                acc[r][it].z = fmaf(vb, xb[it].z, fmaf(va, xa[it].z, acc[r][it].z));
+                acc[r][it].w = fmaf(vb, xb[it].w, fmaf(va, xa[it].w, acc[r][it].w));
+            }
+        }
+        if (j < e[r]) {
+            const int32_t ca = indices[j];
+            const float va = values[val_perm ? (int64_t)val_perm[j] : j];
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it)
+                if (cvalid[it]) {
+                    const f32x4 xa = *(const f32x4*)(W + (int64_t)ca * d + col[it]);
+                    acc[r][it].x = fmaf(va, xa.x, acc[r][it].x);
+                    acc[r][it].y = fmaf(va, xa.y, acc[r][it].y);
+                    acc[r][it].z = fmaf(va, xa.z, acc[r][it].z);
+                    acc[r][it].w = fmaf(va, xa.w, acc[r][it].w);
+                }
+        }
+    }
+    // epilogue + store
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t row = row0 + r;
+        if (row >= n_rows) continue;
+        if (EPI == 1) {
+            float ss = 0.f;
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it)
+                if (cvalid[it])
+                    ss += acc[r][it].x * acc[r][it].x + acc[r][it].y * acc[r][it].y +
+                          acc[r][it].z * acc[r][it].z + acc[r][it].w * acc[r][it].w;
+            ss = subgroup_sum<0>(ss, lpr);
+            const float inv = 1.0f / sqrtf(fmaxf(ss, L2NORM_EPS));
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) acc[r][it] *= inv;
+            if (out_inv && sub_lane == 0) out_inv[row] = inv;
+        } else if (EPI == 2) {
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it)
+                if (cvalid[it]) {
+                    const f32x4 b = *(const f32x4*)(col_bias + col[it]);
+                    acc[r][it].x = fmaxf(acc[r][it].x + b.x, 0.f);
+                    acc[r][it].y = fmaxf(acc[r][it].y + b.y, 0.f);
+                    acc[r][it].z = fmaxf(acc[r][it].z + b.z, 0.f);
+                    acc[r][it].w = fmaxf(acc[r][it].w + b.w, 0.f);
+                }
+        }
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it)
+            if (cvalid[it]) *(f32x4*)(out + row * (int64_t)d + col[it]) = acc[r][it];
+    }
+}
+
+// generic fallback: any d (d % 4 != 0 or d > 1024); one thread per output element
+__global__ __launch_bounds__(256) void spmm_csr_scalar_kernel(
+    const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, const float* __restrict__ values,
+    const int32_t* __restrict__ val_perm, int64_t n_rows, const float* __restrict__ W, int d, int accumulate,
+    float* __restrict__ out)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_rows * d) return;
+    const int64_t row = idx / d;
+    const int c = (int)(idx - row * d);
+    float acc = accumulate ? out[idx] : 0.f;
+    for (int64_t j = indptr[row]; j < indptr[row + 1]; ++j) {
+        const float v = values[val_perm ? (int64_t)val_perm[j] : j];
+        acc = fmaf(v, W[(int64_t)indices[j] * d + c], acc);
+    }
+    out[idx] = acc;
+}
+
+// one wave per row: y = x * 1/sqrt(max(sum x^2, eps))  (tf.nn.l2_normalize(x, 1) [external])
+__global__ __launch_bounds__(256) void row_l2norm_fwd_kernel(const float* __restrict__ x, int64_t n_rows, int d,
+                                                            float* __restrict__ y, float* __restrict__ inv_out)
+{
+    const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (row >= n_rows) return;
+    const int lane = lane_id();
+    const float* xr = x + row * (int64_t)d;
+    float ss = 0.f;
+    for (int c = lane; c < d; c += 64) ss = fmaf(xr[c], xr[c], ss);
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+    const float inv = 1.0f / sqrtf(fmaxf(ss, L2NORM_EPS));
+    for (int c = lane; c < d; c += 64) y[row * (int64_t)d + c] = xr[c] * inv;
+    if (inv_out && lane == 0) inv_out[row] = inv;
+}
+
+// dx = (dy - y * sum(y*dy)) * inv ; where the norm was clamped (inv == 1/sqrt(eps)) dx = dy * inv
+__global__ __launch_bounds__(256) void row_l2norm_bwd_kernel(const float* __restrict__ y, const float* __restrict__ inv,
+                                                            const float* __restrict__ dy, int64_t n_rows, int d,
+                                                            float* __restrict__ dx)
+{
+    const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (row >= n_rows) return;
+    const int lane = lane_id();
+    const float* yr = y + row * (int64_t)d;
+    const float* gr = dy + row * (int64_t)d;
+    float t = 0.f;
+    for (int c = lane; c < d; c += 64) t = fmaf(yr[c], gr[c], t);
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+    const float iv = inv[row];
+    const float inv_eps = 1.0f / sqrtf(L2NORM_EPS);
+    if (iv >= inv_eps) t = 0.f;
+    for (int c = lane; c < d; c += 64) dx[row * (int64_t)d + c] = (gr[c] - yr[c] * t) * iv;
+}
+
+__global__ __launch_bounds__(256) void bias_relu_kernel(float* __restrict__ x, const float* __restrict__ col_bias,
+                                                       int64_t n, int d)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    x[idx] = fmaxf(x[idx] + col_bias[idx % d], 0.f);
+}
+
+// d_pre = d_out * (out > 0)   (gradient of tf.nn.relu)
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ out, const float* __restrict__ dout,
+                                                      int64_t n, float* __restrict__ dpre)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    dpre[idx] = out[idx] > 0.f ? dout[idx] : 0.f;
+}
+
+// column sums of a row-major [n_rows, d] matrix (gradient of the broadcast ReLU bias).
+// grid.x = column tiles of 64, each block walks rows with 4 waves then combines through LDS.
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int64_t n_rows, int d,
+                                                    float* __restrict__ out)
+{
+    __shared__ float part[4][64];
+    const int lane = lane_id(), w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    float acc = 0.f;
+    if (c < d)
+        for (int64_t r = w; r < n_rows; r += 4) acc += x[r * (int64_t)d + c];
+    part[w][lane] = acc;
+    __syncthreads();
+    if (w == 0 && c < d) out[c] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+}
+
+// b[r] = sum_j X[r,j] * beta[j]   (project_biases, recommendation_graphs.py:4-19), fmaf in CSR order
+__global__ __launch_bounds__(256) void spmv_csr_kernel(const int64_t* __restrict__ indptr,
+                                                      const int32_t* __restrict__ indices,
+                                                      const float* __restrict__ values,
+                                                      const int32_t* __restrict__ val_perm, int64_t n_rows,
+                                                      const float* __restrict__ beta, float* __restrict__ out)
+{
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n_rows) return;
+    float acc = 0.f;
+    for (int64_t j = indptr[row]; j < indptr[row + 1]; ++j)
+        acc = fmaf(values[val_perm ? (int64_t)val_perm[j] : j], beta[indices[j]], acc);
+    out[row] = acc;
+}
+
+// dense[r, c] = X[r, c]  (tf.sparse_tensor_to_dense, representation_graphs.py:74); out pre-zeroed by caller
+__global__ __launch_bounds__(256) void csr_to_dense_kernel(const int64_t* __restrict__ indptr,
+                                                          const int32_t* __restrict__ indices,
+                                                          const float* __restrict__ values, int64_t n_rows, int n_cols,
+                                                          float* __restrict__ out)
+{
+    const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (row >= n_rows) return;
+    for (int64_t j = indptr[row] + lane_id(); j < indptr[row + 1]; j += 64)
+        out[row * (int64_t)n_cols + indices[j]] = values[j];
+}
+
+// ------------------------------------------------------------------------------------------
+static int pow2ceil_log2(int x) { int l = 0; while ((1 << l) < x) ++l; return l; }
+
+template <int EPI>
+static int launch_vec4(const int64_t* indptr, const int32_t* indices, const float* values, const int32_t* val_perm,
+                       int64_t n_rows, const float* W, int d, const float* col_bias, int accumulate, float* out,
+                       float* out_inv, int64_t nnz_hint, hipStream_t st)
+{
+    const int n4 = d / 4;
+    int lpr_log2 = pow2ceil_log2(n4);
+    if (lpr_log2 > 6) lpr_log2 = 6;
+    const int lpr = 1 << lpr_log2;
+    const int iters = (n4 + lpr - 1) / lpr;
+    // R = 4 rows per subgroup when rows are short (embedding-style gathers), else 1
+    const bool short_rows = nnz_hint >= 0 && nnz_hint <= 4 * n_rows && n_rows >= 4096;
+    const int R = short_rows ? 4 : 1;
+    const int64_t subgroups = ceil_div64(n_rows, R);
+    const int64_t threads = subgroups * lpr;
+    const unsigned blocks = (unsigned)ceil_div64(threads, 256);
+#define TREC_SPMM_LAUNCH(IT, RR)                                                                                   \
+    hipLaunchKernelGGL((spmm_csr_vec4_kernel<IT, RR, EPI>), dim3(blocks), dim3(256), 0, st, indptr, indices, values, \
+                       val_perm, n_rows, W, d, lpr_log2, col_bias, accumulate, out, out_inv)
+    if (R == 4) {
+        if (iters == 1) TREC_SPMM_LAUNCH(1, 4);
+        else if (iters == 2) TREC_SPMM_LAUNCH(2, 4);
+        else TREC_SPMM_LAUNCH(4, 4);
+    } else {
+        if (iters == 1) TREC_SPMM_LAUNCH(1, 1);
+        else if (iters == 2) TREC_SPMM_LAUNCH(2, 1);
+        else TREC_SPMM_LAUNCH(4, 1);
+    }
+#undef TREC_SPMM_LAUNCH
+    return trec_check_launch("trec_spmm_csr");
+}
+
+extern "C" int trec_spmm_csr(const int64_t* indptr, const int32_t* indices, const float* values,
+                             const int32_t* val_perm, int64_t n_rows, int64_t nnz, const float* W, int32_t d,
+                             const float* col_bias, int32_t epilogue, int32_t accumulate, float* out,
+                             float* out_inv_norm, void* stream)
+{
+    TREC_REQUIRE(indptr && indices && values && W && out, "trec_spmm_csr: null pointer");
+    TREC_REQUIRE(d >= 1 && n_rows >= 0, "trec_spmm_csr: bad sizes");
+    TREC_REQUIRE(epilogue >= 0 && epilogue <= 2, "trec_spmm_csr: epilogue must be 0, 1 or 2");
+    TREC_REQUIRE(epilogue != 2 || col_bias, "trec_spmm_csr: epilogue 2 needs col_bias");
+    TREC_REQUIRE(!(accumulate && epilogue), "trec_spmm_csr: accumulate cannot be combined with an epilogue");
+    if (n_rows == 0) return TREC_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (d % 4 == 0 && d <= 1024) {
+        if (epilogue == 0) return launch_vec4<0>(indptr, indices, values, val_perm, n_rows, W, d, col_bias, accumulate, out, out_inv_norm, nnz, st);
+        if (epilogue == 1) return launch_vec4<1>(indptr, indices, values, val_perm, n_rows, W, d, col_bias, accumulate, out, out_inv_norm, nnz, st);
+        return launch_vec4<2>(indptr, indices, values, val_perm, n_rows, W, d, col_bias, accumulate, out, out_inv_norm, nnz, st);
+    }
+    const int64_t total = n_rows * (int64_t)d;
+    hipLaunchKernelGGL(spmm_csr_scalar_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, st, indptr,
+                       indices, values, val_perm, n_rows, W, d, accumulate, out);
+    int rc = trec_check_launch("trec_spmm_csr(scalar)");
+    if (rc) return rc;
+    if (epilogue == 1) {
+        hipLaunchKernelGGL(row_l2norm_fwd_kernel, dim3((unsigned)ceil_div64(n_rows * 64, 256)), dim3(256), 0, st, out,
+                           n_rows, d, out, out_inv_norm);
+        return trec_check_launch("trec_spmm_csr(l2norm)");
+    }
+    if (epilogue == 2) {
+        hipLaunchKernelGGL(bias_relu_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, st, out, col_bias,
+                           total, d);
+        return trec_check_launch("trec_spmm_csr(bias_relu)");
+    }
+    return TREC_OK;
+}
+
+extern "C" int trec_row_l2norm_fwd(const float* x, int64_t n_rows, int32_t d, float* y, float* inv_norm, void* stream)
+{
+    TREC_REQUIRE(x && y && d >= 1, "trec_row_l2norm_fwd: bad arguments");
+    if (n_rows == 0) return TREC_OK;
+    hipLaunchKernelGGL(row_l2norm_fwd_kernel, dim3((unsigned)ceil_div64(n_rows * 64, 256)), dim3(256), 0,
+                       (hipStream_t)stream, x, n_rows, d, y, inv_norm);
+    return trec_check_launch("trec_row_l2norm_fwd");
+}
+
+extern "C" int trec_row_l2norm_bwd(const float* y, const float* inv_norm, const float* dy, int64_t n_rows, int32_t d,
+                                   float* dx, void* stream)
+{
+    TREC_REQUIRE(y && inv_norm && dy && dx && d >= 1, "trec_row_l2norm_bwd: bad arguments");
+    if (n_rows == 0) return TREC_OK;
+    hipLaunchKernelGGL(row_l2norm_bwd_kernel, dim3((unsigned)ceil_div64(n_rows * 64, 256)), dim3(256), 0,
+                       (hipStream_t)stream, y, inv_norm, dy, n_rows, d, dx);
+    return trec_check_launch("trec_row_l2norm_bwd");
+}
+
+extern "C" int trec_relu_bwd(const float* out, const float* dout, int64_t n, float* dpre, void* stream)
+{
+    TREC_REQUIRE(out && dout && dpre, "trec_relu_bwd: null pointer");
+    if (n == 0) return TREC_OK;
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, (hipStream_t)stream, out,
+                       dout, n, dpre);
+    return trec_check_launch("trec_relu_bwd");
+}
+
+extern "C" int trec_colsum(const float* x, int64_t n_rows, int32_t d, float* out, void* stream)
+{
+    TREC_REQUIRE(x && out && d >= 1, "trec_colsum: bad arguments");
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((d + 63) / 64)), dim3(256), 0, (hipStream_t)stream, x, n_rows, d,
+                       out);
+    return trec_check_launch("trec_colsum");
+}
+
+extern "C" int trec_spmv_csr(const int64_t* indptr, const int32_t* indices, const float* values,
+                             const int32_t* val_perm, int64_t n_rows, const float* beta, float* out, void* stream)
+{
+    TREC_REQUIRE(indptr && indices && values && beta && out, "trec_spmv_csr: null pointer");
+    if (n_rows == 0) return TREC_OK;
+    hipLaunchKernelGGL(spmv_csr_kernel, dim3((unsigned)ceil_div64(n_rows, 256)), dim3(256), 0, (hipStream_t)stream,
+                       indptr, indices, values, val_perm, n_rows, beta, out);
+    return trec_check_launch("trec_spmv_csr");
+}
+
+extern "C" int trec_csr_to_dense(const int64_t* indptr, const int32_t* indices, const float* values, int64_t n_rows,
+                                 int32_t n_cols, float* out, void* stream)
+{
+    TREC_REQUIRE(indptr && indices && values && out, "trec_csr_to_dense: null pointer");
+    if (n_rows == 0) return TREC_OK;
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)n_rows * (size_t)n_cols, (hipStream_t)stream);
+    if (e != hipSuccess) { trec_set_last_error("trec_csr_to_dense: memset failed"); return TREC_ERR_LAUNCH; }
+    hipLaunchKernelGGL(csr_to_dense_kernel, dim3((unsigned)ceil_div64(n_rows * 64, 256)), dim3(256), 0,
+                       (hipStream_t)stream, indptr, indices, values, n_rows, n_cols, out);
+    return trec_check_launch("trec_csr_to_dense");
+}

@@ -1,0 +1,388 @@
+"""
+Launchers and autograd bindings for the HIP kernels (include/tensorrec_hip.h).
+
+Each differentiable op is a ``torch.autograd.Function`` whose forward AND backward are hand-written kernels; torch
+autograd only strings them together, which is what lets user-defined graphs (plain torch ops) mix with the built-in
+ones -- the reference gets the same composability from TF's autodiff.  Nothing here computes on the CPU.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _native as N
+from .sparse import SparseFeatures, Interactions, PairIndex
+
+DTYPE_F32, DTYPE_BF16 = 0, 1
+MODE_DOT, MODE_EUCLIDEAN = 0, 1
+EPI_NONE, EPI_L2NORM, EPI_BIAS_RELU = 0, 1, 2
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ------------------------------------------------------------------------------------------------ K1
+def spmm_raw(indptr, indices, values, perm, n_rows, nnz, w, col_bias=None, epilogue=EPI_NONE, accumulate=False,
+             out=None, want_inv=False):
+    w = _f32c(w)
+    d = w.shape[1]
+    if out is None:
+        out = torch.empty((n_rows, d), dtype=torch.float32, device=w.device)
+    inv = torch.empty((n_rows,), dtype=torch.float32, device=w.device) if want_inv else None
+    N.call("trec_spmm_csr", N.ptr(indptr), N.ptr(indices), N.ptr(values), N.ptr(perm), n_rows, nnz, N.ptr(w), d,
+           N.ptr(col_bias), epilogue, 1 if accumulate else 0, N.ptr(out), N.ptr(inv))
+    return (out, inv) if want_inv else out
+
+
+def _spmm_t(feats: SparseFeatures, dout):
+    """dW[F, d] = X^T . dOut -- the same gather kernel on the transposed CSR."""
+    indptr_t, rows_t, perm_t = feats.transposed()
+    return spmm_raw(indptr_t, rows_t, feats.values, perm_t, feats.shape[1], feats.nnz, dout)
+
+
+class _SpMM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, w, feats):
+        ctx.feats = feats
+        return spmm_raw(feats.indptr, feats.indices, feats.values, None, feats.shape[0], feats.nnz, w)
+
+    @staticmethod
+    def backward(ctx, dout):
+        return _spmm_t(ctx.feats, _f32c(dout)), None
+
+
+class _SpMMNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, w, feats):
+        y, inv = spmm_raw(feats.indptr, feats.indices, feats.values, None, feats.shape[0], feats.nnz, w,
+                          epilogue=EPI_L2NORM, want_inv=True)
+        ctx.feats = feats
+        ctx.save_for_backward(y, inv)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, inv = ctx.saved_tensors
+        dx = torch.empty_like(y)
+        N.call("trec_row_l2norm_bwd", N.ptr(y), N.ptr(inv), N.ptr(_f32c(dy)), y.shape[0], y.shape[1], N.ptr(dx))
+        return _spmm_t(ctx.feats, dx), None
+
+
+class _SpMMBiasRelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, w, bias, feats):
+        b = _f32c(bias).reshape(-1)
+        out = spmm_raw(feats.indptr, feats.indices, feats.values, None, feats.shape[0], feats.nnz, w, col_bias=b,
+                       epilogue=EPI_BIAS_RELU)
+        ctx.feats = feats
+        ctx.bias_shape = bias.shape
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (out,) = ctx.saved_tensors
+        dpre = torch.empty_like(out)
+        N.call("trec_relu_bwd", N.ptr(out), N.ptr(_f32c(dout)), out.numel(), N.ptr(dpre))
+        dbias = torch.empty((out.shape[1],), dtype=torch.float32, device=out.device)
+        N.call("trec_colsum", N.ptr(dpre), out.shape[0], out.shape[1], N.ptr(dbias))
+        return _spmm_t(ctx.feats, dpre), dbias.reshape(ctx.bias_shape), None
+
+
+def sparse_dense_matmul(feats: SparseFeatures, w):
+    """tf.sparse_tensor_dense_matmul(features, w)"""
+    return _SpMM.apply(w, feats)
+
+
+def sparse_dense_matmul_l2norm(feats, w):
+    return _SpMMNorm.apply(w, feats)
+
+
+def sparse_dense_matmul_bias_relu(feats, w, bias):
+    return _SpMMBiasRelu.apply(w, bias, feats)
+
+
+class _SpMV(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, beta, feats):
+        ctx.feats = feats
+        ctx.beta_shape = beta.shape
+        out = torch.empty((feats.shape[0],), dtype=torch.float32, device=beta.device)
+        N.call("trec_spmv_csr", N.ptr(feats.indptr), N.ptr(feats.indices), N.ptr(feats.values), None, feats.shape[0],
+               N.ptr(_f32c(beta).reshape(-1)), N.ptr(out))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        feats = ctx.feats
+        indptr_t, rows_t, perm_t = feats.transposed()
+        dbeta = torch.empty((feats.shape[1],), dtype=torch.float32, device=dout.device)
+        N.call("trec_spmv_csr", N.ptr(indptr_t), N.ptr(rows_t), N.ptr(feats.values), N.ptr(perm_t), feats.shape[1],
+               N.ptr(_f32c(dout)), N.ptr(dbeta))
+        return dbeta.reshape(ctx.beta_shape), None
+
+
+def sparse_matvec(feats, beta):
+    return _SpMV.apply(beta, feats)
+
+
+def sparse_to_dense(feats: SparseFeatures):
+    out = torch.empty(feats.shape, dtype=torch.float32, device=feats.device)
+    N.call("trec_csr_to_dense", N.ptr(feats.indptr), N.ptr(feats.indices), N.ptr(feats.values), feats.shape[0],
+           feats.shape[1], N.ptr(out))
+    return out
+
+
+class _RowL2Norm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _f32c(x)
+        y = torch.empty_like(x)
+        inv = torch.empty((x.shape[0],), dtype=torch.float32, device=x.device)
+        N.call("trec_row_l2norm_fwd", N.ptr(x), x.shape[0], x.shape[1], N.ptr(y), N.ptr(inv))
+        ctx.save_for_backward(y, inv)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, inv = ctx.saved_tensors
+        dx = torch.empty_like(y)
+        N.call("trec_row_l2norm_bwd", N.ptr(y), N.ptr(inv), N.ptr(_f32c(dy)), y.shape[0], y.shape[1], N.ptr(dx))
+        return dx
+
+
+def l2_normalize_rows(x):
+    """tf.nn.l2_normalize(x, 1)"""
+    return _RowL2Norm.apply(x)
+
+
+def gemm_raw(a, b, trans_a=False, trans_b=False):
+    a, b = _f32c(a), _f32c(b)
+    m = a.shape[1] if trans_a else a.shape[0]
+    k = a.shape[0] if trans_a else a.shape[1]
+    n = b.shape[0] if trans_b else b.shape[1]
+    c = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    N.call("trec_gemm_f32", 1 if trans_a else 0, 1 if trans_b else 0, m, n, k, N.ptr(a), a.shape[1], N.ptr(b),
+           b.shape[1], N.ptr(c), n, 0)
+    return c
+
+
+class _MatMul(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.save_for_backward(a, b)
+        return gemm_raw(a, b)
+
+    @staticmethod
+    def backward(ctx, dc):
+        a, b = ctx.saved_tensors
+        dc = _f32c(dc)
+        return gemm_raw(dc, b, trans_b=True), gemm_raw(a, dc, trans_a=True)
+
+
+def matmul(a, b):
+    """tf.matmul(a, b) for the dense layer of ReLURepresentationGraph"""
+    return _MatMul.apply(a, b)
+
+
+# ------------------------------------------------------------------------------------------------ K3
+def _idx32(x):
+    if isinstance(x, PairIndex):
+        return x.idx32, x.pairs_per_user
+    return x.to(torch.int32).contiguous(), 0
+
+
+class _PairScore(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, u, v, ub, ib, xu32, xi32, pairs_per_user, mode):
+        u, v = _f32c(u), _f32c(v)
+        n_pairs = xi32.numel()
+        out = torch.empty((n_pairs,), dtype=torch.float32, device=u.device)
+        N.call("trec_pair_score_fwd", N.ptr(u), N.ptr(v), N.ptr(xu32), N.ptr(xi32), n_pairs, pairs_per_user, u.shape[1],
+               mode, N.ptr(ub), N.ptr(ib), N.ptr(out))
+        ctx.save_for_backward(u, v)
+        ctx.meta = (xu32, xi32, pairs_per_user, mode, ub is not None, ib is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        u, v = ctx.saved_tensors
+        xu32, xi32, ppu, mode, has_ub, has_ib = ctx.meta
+        g = _f32c(g)
+        du, dv = torch.zeros_like(u), torch.zeros_like(v)
+        dub = torch.zeros((u.shape[0],), dtype=torch.float32, device=u.device) if has_ub else None
+        dib = torch.zeros((v.shape[0],), dtype=torch.float32, device=u.device) if has_ib else None
+        N.call("trec_pair_score_bwd", N.ptr(u), N.ptr(v), N.ptr(xu32), N.ptr(xi32), N.ptr(g), xi32.numel(), ppu,
+               u.shape[1], mode, N.ptr(du), N.ptr(dv), N.ptr(dub), N.ptr(dib))
+        return du, dv, dub, dib, None, None, None, None
+
+
+def pair_score(user_repr, item_repr, x_user, x_item, mode=MODE_DOT, user_bias=None, item_bias=None):
+    """Serial prediction for (x_user[p], x_item[p]) pairs, optionally fused with the serial bias add."""
+    xu32, ppu = _idx32(x_user)
+    xi32, _ = _idx32(x_item)
+    if ppu > 0:
+        xu32 = None                      # implicit users: pair p -> p // pairs_per_user
+    ub = _f32c(user_bias) if user_bias is not None else None
+    ib = _f32c(item_bias) if item_bias is not None else None
+    return _PairScore.apply(user_repr, item_repr, ub, ib, xu32, xi32, ppu, mode)
+
+
+# ------------------------------------------------------------------------------------------------ K6
+class _WMRB(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred_serial, sample_pred, inter: Interactions, weight):
+        pred_serial, sample_pred = _f32c(pred_serial), _f32c(sample_pred)
+        n_users, n_items = inter.shape
+        S = sample_pred.shape[1]
+        loss = torch.empty((inter.n_positive,), dtype=torch.float32, device=pred_serial.device)
+        smr = torch.empty_like(loss)
+        N.call("trec_wmrb_fwd", N.ptr(inter.indptr), N.ptr(inter.pos_slot), N.ptr(weight), N.ptr(pred_serial),
+               N.ptr(sample_pred), n_users, n_items, S, N.ptr(loss), N.ptr(smr))
+        ctx.inter, ctx.weight = inter, weight
+        ctx.save_for_backward(pred_serial, sample_pred, smr)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gl):
+        pred_serial, sample_pred, smr = ctx.saved_tensors
+        inter = ctx.inter
+        n_users, n_items = inter.shape
+        S = sample_pred.shape[1]
+        dp = torch.empty_like(pred_serial)
+        ds = torch.empty_like(sample_pred)
+        N.call("trec_wmrb_bwd", N.ptr(inter.indptr), N.ptr(inter.pos_slot), N.ptr(ctx.weight), N.ptr(pred_serial),
+               N.ptr(sample_pred), N.ptr(smr), N.ptr(_f32c(gl)), n_users, n_items, S, N.ptr(dp), N.ptr(ds))
+        return dp, ds, None, None
+
+
+def wmrb_loss(pred_serial, sample_pred, interactions, balanced=False):
+    if sample_pred.shape[0] != interactions.shape[0]:
+        raise ValueError("tf_sample_predictions must have one row per user")
+    weight = interactions.balanced_weight() if balanced else None
+    return _WMRB.apply(pred_serial, sample_pred, interactions, weight)
+
+
+class _RMSE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, y):
+        pred, y = _f32c(pred), _f32c(y)
+        n = pred.numel()
+        n_partial = max(1, min(1024, (n + 4095) // 4096))
+        ws = torch.empty((n_partial,), dtype=torch.float32, device=pred.device)
+        loss = torch.empty((1,), dtype=torch.float32, device=pred.device)
+        N.call("trec_rmse_fwd", N.ptr(y), N.ptr(pred), n, N.ptr(ws), n_partial, N.ptr(loss))
+        ctx.save_for_backward(pred, y, loss)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gl):
+        pred, y, loss = ctx.saved_tensors
+        dp = torch.empty_like(pred)
+        N.call("trec_rmse_bwd", N.ptr(y), N.ptr(pred), N.ptr(loss), N.ptr(_f32c(gl).reshape(1)), pred.numel(),
+               N.ptr(dp))
+        return dp, None
+
+
+def rmse_loss(pred_serial, interactions_serial):
+    return _RMSE.apply(pred_serial, interactions_serial)
+
+
+# ------------------------------------------------------------------------------------------------ K2 / K4 / K7 / K8
+def score_kpad(d):
+    k = N.query("trec_score_kpad", int(d))
+    if k < 0:
+        raise ValueError("n_components = %d is beyond the MFMA score kernel's limit of 256" % d)
+    return k
+
+
+def score_prep(repr_, dtype=DTYPE_F32, normalize=False, want_sqnorm=False):
+    """fp32 [n, d] representation -> MFMA operand [n, kpad] (fp32 or bf16), (squared row norms or None)."""
+    x = _f32c(repr_.detach())
+    n, d = x.shape
+    kpad = score_kpad(d)
+    if dtype == DTYPE_F32 and kpad == d and not normalize and not want_sqnorm:
+        return x, None, kpad
+    out = torch.empty((n, kpad), dtype=torch.float32 if dtype == DTYPE_F32 else torch.bfloat16, device=x.device)
+    sq = torch.empty((n,), dtype=torch.float32, device=x.device) if want_sqnorm else None
+    N.call("trec_score_prep", N.ptr(x), n, d, kpad, 1 if normalize else 0, dtype, N.ptr(out), N.ptr(sq))
+    return out, sq, kpad
+
+
+def score_store(users_op, items_op, dtype, kpad, user_bias=None, item_bias=None, mode=MODE_DOT, user_sq=None,
+                item_sq=None, variant=0, out=None):
+    n_u, n_i = users_op.shape[0], items_op.shape[0]
+    if out is None:
+        out = torch.empty((n_u, n_i), dtype=torch.float32, device=users_op.device)
+    N.call("trec_score_gemm_store", N.ptr(users_op), N.ptr(items_op), dtype, kpad, n_u, n_i, N.ptr(user_bias),
+           N.ptr(item_bias), mode, N.ptr(user_sq), N.ptr(item_sq), N.ptr(out), out.stride(0), variant)
+    return out
+
+
+def topk_chunks_for(n_users, dtype, kpad, n_items):
+    """Item chunks so that the launch has >= ~2 workgroups per CU even for small user batches."""
+    rows_wg = N.query("trec_score_rows_per_workgroup", dtype, kpad)
+    rblocks = (n_users + rows_wg - 1) // rows_wg
+    chunks = 1
+    while rblocks * chunks < 1024 and chunks < 32 and n_items // (chunks * 2) >= 512:
+        chunks *= 2
+    return chunks
+
+
+def score_topk(users_op, items_op, dtype, kpad, k, user_bias=None, item_bias=None, mode=MODE_DOT, user_sq=None,
+               item_sq=None, item_index_base=0, n_chunks=None, variant=0, workspace=None):
+    """Fused score + per-user top-k without materialising [U, I].  Returns (values [U, k], item indices [U, k]),
+    ordered (value desc, index asc)."""
+    cap = N.query("trec_score_topk_capacity")
+    if k > cap:
+        raise ValueError("fused top-k supports k <= %d (got %d)" % (cap, k))
+    n_u, n_i = users_op.shape[0], items_op.shape[0]
+    if n_chunks is None:
+        n_chunks = topk_chunks_for(n_u, dtype, kpad, n_i)
+    n_parts = N.query("trec_score_topk_parts", dtype, kpad, n_i, n_chunks)
+    if workspace is None:
+        pv = torch.empty((n_u, n_parts, cap), dtype=torch.float32, device=users_op.device)
+        pi = torch.empty((n_u, n_parts, cap), dtype=torch.int32, device=users_op.device)
+    else:
+        pv, pi = workspace
+    N.call("trec_score_gemm_topk", N.ptr(users_op), N.ptr(items_op), dtype, kpad, n_u, n_i, item_index_base,
+           N.ptr(user_bias), N.ptr(item_bias), mode, N.ptr(user_sq), N.ptr(item_sq), n_chunks, N.ptr(pv), N.ptr(pi),
+           variant)
+    return topk_merge(pv.reshape(n_u, n_parts * cap), pi.reshape(n_u, n_parts * cap), k)
+
+
+def topk_merge(cand_vals, cand_idx, k):
+    n_u, n_cand = cand_vals.shape
+    ov = torch.empty((n_u, k), dtype=torch.float32, device=cand_vals.device)
+    oi = torch.empty((n_u, k), dtype=torch.int32, device=cand_vals.device)
+    N.call("trec_topk_merge", N.ptr(cand_vals), N.ptr(cand_idx), n_u, n_cand, k, N.ptr(ov), N.ptr(oi))
+    return ov, oi
+
+
+def rank_rows(scores):
+    scores = _f32c(scores)
+    ranks = torch.empty(scores.shape, dtype=torch.int32, device=scores.device)
+    N.call("trec_rank_rows", N.ptr(scores), scores.shape[0], scores.shape[1], scores.stride(0), N.ptr(ranks),
+           ranks.stride(0))
+    return ranks
+
+
+def rank_of_pairs(scores, col_offset, begin, end, xu32, xi32, target_scores, add_one=True):
+    out = torch.empty((xu32.numel(),), dtype=torch.int32, device=scores.device)
+    N.call("trec_rank_of_pairs", N.ptr(scores), scores.stride(0), col_offset, begin, end, N.ptr(xu32), N.ptr(xi32),
+           N.ptr(target_scores), xu32.numel(), 1 if add_one else 0, N.ptr(out))
+    return out
+
+
+def sample_items(n_users, n_items, n_sampled, replace, seed, step, device="cuda"):
+    out = torch.empty((n_users, n_sampled), dtype=torch.int32, device=device)
+    N.call("trec_sample_items", n_users, n_items, n_sampled, 1 if replace else 0, int(seed) & (2 ** 64 - 1),
+           int(step) & 0xFFFFFFFF, N.ptr(out))
+    return out
+
+
+def adam_tf_step(w, m, v, grad, lr_t, l2_coef, beta1=0.9, beta2=0.999, eps=1e-8):
+    N.call("trec_adam_tf_step", N.ptr(w), N.ptr(m), N.ptr(v), N.ptr(_f32c(grad)), w.numel(), float(lr_t), beta1, beta2,
+           eps, float(l2_coef))

@@ -1,0 +1,594 @@
+"""
+TensorRec -- the public object API of tensorrec/tensorrec.py:26-917, executed on one MI355X.
+
+Same constructor, ``fit`` / ``fit_partial`` / ``predict`` / ``predict_rank`` / ``predict_similar_items`` /
+``predict_*_representation`` / ``predict_*_bias`` signatures, the same validation errors and NumPy return types.
+What differs is underneath: there is no TF graph or session; the three graph objects are executed eagerly every step
+on device tensors (``_forward`` mirrors the wiring of ``_build_tf_graph``, tensorrec.py:270-492), gradients come from
+hand-written backward kernels chained by torch autograd, and the optimiser is one fused TF-form Adam kernel per
+weight tensor.  Extensions (keyword-only, after the reference's arguments): ``precision``, ``device``, ``sampler``,
+``seed`` and the ``predict_top_k`` method (fused MFMA score + top-k, no [U, I] matrix).
+
+Parity-critical behaviours reproduced on purpose: vector losses are summed together with a
+broadcast ``alpha * reg`` (so L2 is scaled by the loss length); Adam is dense over every weight; samples are shared
+per user and may contain positives; the interaction matrix takes its shape from the feature matrices.
+"""
+from __future__ import annotations
+
+import logging
+import math
+from itertools import cycle
+
+import numpy as np
+import torch
+from scipy import sparse as sp
+
+from . import ops
+from . import _native as N
+from .errors import (
+    ModelNotBiasedException, ModelNotFitException, ModelWithoutAttentionException, BatchNonSparseInputException
+)
+from .framework import VariableStore, variable_scope, set_seed
+from .loss_graphs import AbstractLossGraph, RMSELossGraph
+from .prediction_graphs import AbstractPredictionGraph, DotProductPredictionGraph
+from .recommendation_graphs import (
+    project_biases, bias_prediction_dense, bias_prediction_serial, rank_predictions,
+    densify_sampled_item_predictions, predict_similar_items
+)
+from .representation_graphs import AbstractRepresentationGraph, LinearRepresentationGraph
+from .sparse import SparseFeatures, Interactions, PairIndex
+from .util import calculate_batched_alpha, sample_items
+
+ADAM_BETA1, ADAM_BETA2, ADAM_EPSILON = 0.9, 0.999, 1e-8      # tf.train.AdamOptimizer defaults [external]
+
+
+class DeviceSampler(object):
+    """K7: counter-based sampling on the GPU (keyed permutation per user when ``replace`` is False)."""
+
+    def __init__(self, seed=0):
+        self.seed = int(seed)
+
+    def sample(self, n_items, n_users, n_sampled_items, replace, step, device):
+        return ops.sample_items(n_users, n_items, n_sampled_items, replace, self.seed, step, device)
+
+
+class HostSampler(object):
+    """The reference's sampler verbatim in behaviour (util.sample_items on the host, util.py:12-21), uploaded each
+    step.  ``rng`` is anything with ``.choice`` (default: the global ``np.random`` as in the reference)."""
+
+    def __init__(self, rng=None):
+        self.rng = rng if rng is not None else np.random
+
+    def sample(self, n_items, n_users, n_sampled_items, replace, step, device):
+        pairs = sample_items(n_items, n_users, n_sampled_items, replace, rng=self.rng)
+        items = pairs[:, 1].reshape(n_users, n_sampled_items).astype(np.int32)
+        return torch.from_numpy(items).to(device)
+
+
+class ReplaySampler(object):
+    """Consumes host-supplied [n_users, n_sampled_items] index tables, one per step (exact parity runs)."""
+
+    def __init__(self, tables):
+        self.tables = list(tables)
+        self.pos = 0
+
+    def sample(self, n_items, n_users, n_sampled_items, replace, step, device):
+        table = np.ascontiguousarray(self.tables[self.pos % len(self.tables)], dtype=np.int32)
+        self.pos += 1
+        if table.shape != (n_users, n_sampled_items):
+            raise ValueError("replayed sample table has shape %s, expected %s" % (table.shape, (n_users, n_sampled_items)))
+        return torch.from_numpy(table).to(device)
+
+
+def _adam_lr_t(lr, t):
+    """lr * sqrt(1 - b2^t) / (1 - b1^t) with the float32 running powers TF keeps [external]."""
+    b1p, b2p = np.float32(1.0), np.float32(1.0)
+    for _ in range(int(t)):
+        b1p = np.float32(b1p * np.float32(ADAM_BETA1))
+        b2p = np.float32(b2p * np.float32(ADAM_BETA2))
+    return float(np.float32(np.float32(lr) * np.sqrt(np.float32(1.0) - b2p) / (np.float32(1.0) - b1p)))
+
+
+class TensorRec(object):
+
+    def __init__(self,
+                 n_components=100,
+                 n_tastes=1,
+                 user_repr_graph=LinearRepresentationGraph(),
+                 item_repr_graph=LinearRepresentationGraph(),
+                 attention_graph=None,
+                 prediction_graph=DotProductPredictionGraph(),
+                 loss_graph=RMSELossGraph(),
+                 biased=True,
+                 *,
+                 precision='fp32',
+                 device=None,
+                 sampler=None,
+                 seed=None):
+        """
+        A TensorRec recommendation model (arguments as tensorrec/tensorrec.py:28-61).
+        :param precision: 'fp32' (default; exact fp32 MFMA, bit-stable ranks) or 'bf16' (bf16 operands, fp32
+        accumulate) for the dense score contraction in predict / predict_rank / predict_top_k.
+        :param device: torch device; default 'cuda' (there is no CPU execution path).
+        :param sampler: object with ``sample(n_items, n_users, n_sampled_items, replace, step, device)``;
+        default DeviceSampler(seed).
+        :param seed: int or None -- seeds weight initialisation and the default sampler.
+        """
+        # Arg Check (tensorrec.py:68-88)
+        if (n_components is None) or (n_tastes is None) or (user_repr_graph is None) or (item_repr_graph is None) \
+                or (prediction_graph is None) or (loss_graph is None):
+            raise ValueError("All arguments to TensorRec() must be non-None")
+        if n_components < 1:
+            raise ValueError("n_components must be >= 1")
+        if n_tastes < 1:
+            raise ValueError("n_tastes must be >= 1")
+        if not isinstance(user_repr_graph, AbstractRepresentationGraph):
+            raise ValueError("user_repr_graph must inherit AbstractRepresentationGraph")
+        if not isinstance(item_repr_graph, AbstractRepresentationGraph):
+            raise ValueError("item_repr_graph must inherit AbstractRepresentationGraph")
+        if not isinstance(prediction_graph, AbstractPredictionGraph):
+            raise ValueError("prediction_graph must inherit AbstractPredictionGraph")
+        if not isinstance(loss_graph, AbstractLossGraph):
+            raise ValueError("loss_graph must inherit AbstractLossGraph")
+        if attention_graph is not None:
+            if not isinstance(attention_graph, AbstractRepresentationGraph):
+                raise ValueError("attention_graph must be None or inherit AbstractRepresentationGraph")
+            if n_tastes == 1:
+                raise ValueError("attention_graph must be None if n_tastes == 1")
+        if precision not in ('fp32', 'bf16'):
+            raise ValueError("precision must be 'fp32' or 'bf16'")
+
+        self.n_components = n_components
+        self.n_tastes = n_tastes
+        self.user_repr_graph_factory = user_repr_graph
+        self.item_repr_graph_factory = item_repr_graph
+        self.attention_graph_factory = attention_graph
+        self.prediction_graph_factory = prediction_graph
+        self.loss_graph_factory = loss_graph
+        self.biased = biased
+        self.precision = precision
+        self.device = device
+        self.seed = seed
+        self.sampler = sampler
+
+        self._store = None
+        self._adam = {}
+        self._opt_step = 0
+        self._sample_step = 0
+        self.n_user_features = None
+        self.n_item_features = None
+
+    # ------------------------------------------------------------------------------------------ helpers
+    @property
+    def is_fit(self):
+        return self._store is not None
+
+    def _device(self):
+        N.require_gpu()
+        N.load()
+        return torch.device(self.device if self.device is not None else 'cuda')
+
+    @staticmethod
+    def _as_list(raw_input):
+        """util.datasets_from_raw_input (util.py:34-58) restricted to scipy inputs: tf.data.Dataset and TFRecord
+        paths are TensorFlow containers and are out of scope."""
+        if sp.issparse(raw_input):
+            return [raw_input]
+        if isinstance(raw_input, list) and all(sp.issparse(v) for v in raw_input):
+            return raw_input
+        raise ValueError('Input must be a scipy sparse matrix, an iterable of scipy sprase matrices, or a TensorFlow '
+                         'Dataset')
+
+    def _create_batches(self, interactions, user_features, item_features, user_batch_size=None):
+        """tensorrec.py:185-235 -- user batching by CSR row slices, then zip with the (cycled) item features."""
+        if user_batch_size is not None:
+            if (not sp.issparse(interactions)) or (not sp.issparse(user_features)):
+                raise BatchNonSparseInputException()
+            if not isinstance(interactions, sp.csr_matrix):
+                interactions = sp.csr_matrix(interactions)
+            if not isinstance(user_features, sp.csr_matrix):
+                user_features = sp.csr_matrix(user_features)
+            n_users = user_features.shape[0]
+            interactions_batched, user_features_batched = [], []
+            start_batch = 0
+            while start_batch < n_users:
+                end_batch = min(start_batch + user_batch_size, n_users)
+                interactions_batched.append(interactions[start_batch:end_batch])
+                user_features_batched.append(user_features[start_batch:end_batch])
+                start_batch = end_batch
+            interactions, user_features = interactions_batched, user_features_batched
+
+        int_l, uf_l, if_l = self._as_list(interactions), self._as_list(user_features), self._as_list(item_features)
+        if len(int_l) != len(uf_l):
+            raise ValueError('Number of batches in user_features and interactions must be equal.')
+        if (len(if_l) > 1) and (len(if_l) != len(uf_l)):
+            raise ValueError('Number of batches in item_features must be 1 or equal to the number of batches in '
+                             'user_features.')
+        return list(zip(int_l, uf_l, cycle(if_l)))
+
+    # ------------------------------------------------------------------------------------------ graph wiring
+    def _is_engine_graph(self):
+        return getattr(self.prediction_graph_factory, 'engine_mode', None) is not None
+
+    def _representations(self, user_feats, item_feats):
+        """Item repr, user repr (taste 0) and projected biases -- tensorrec.py:308-313, :340-346, :421-430."""
+        item_repr, item_weights = self.item_repr_graph_factory.connect_representation_graph(
+            tf_features=item_feats, n_components=self.n_components, n_features=self.n_item_features,
+            node_name_ending='item')
+        user_repr, user_weights = self.user_repr_graph_factory.connect_representation_graph(
+            tf_features=user_feats, n_components=self.n_components, n_features=self.n_user_features,
+            node_name_ending='user_{}'.format(0))
+        weights = list(item_weights) + list(user_weights)
+        user_bias = item_bias = None
+        if self.biased:
+            if user_feats is not None:
+                ub_var, user_bias = project_biases(user_feats, self.n_user_features, name='user_feature_biases')
+                weights.append(ub_var)
+            if item_feats is not None:
+                ib_var, item_bias = project_biases(item_feats, self.n_item_features, name='item_feature_biases')
+                weights.append(ib_var)
+        return user_repr, item_repr, user_bias, item_bias, weights
+
+    def _serial(self, user_repr, item_repr, x_user, x_item, user_bias, item_bias):
+        """connect_serial_prediction_graph + bias_prediction_serial (tensorrec.py:384-395, :437-449)."""
+        graph = self.prediction_graph_factory
+        pred = graph.connect_serial_prediction_graph(tf_user_representation=user_repr,
+                                                     tf_item_representation=item_repr,
+                                                     tf_x_user=x_user, tf_x_item=x_item)
+        if self.biased:
+            pred = bias_prediction_serial(pred, user_bias, item_bias, x_user, x_item)
+        return pred
+
+    def _serial_engine(self, u_in, i_in, x_user, x_item, user_bias, item_bias):
+        """Built-in prediction graphs: gather + contraction + both bias gathers in ONE kernel (K3)."""
+        return ops.pair_score(u_in, i_in, x_user, x_item, self.prediction_graph_factory.engine_mode,
+                              user_bias if self.biased else None, item_bias if self.biased else None)
+
+    def _dense_prediction(self, user_repr, item_repr, user_bias, item_bias, differentiable=False):
+        """tf_prediction: dense graph + bias broadcast (tensorrec.py:380-383, :432-435)."""
+        graph = self.prediction_graph_factory
+        if self._is_engine_graph() and not differentiable:
+            dtype = ops.DTYPE_BF16 if self.precision == 'bf16' else ops.DTYPE_F32
+            want_sq = graph.engine_mode == ops.MODE_EUCLIDEAN
+            u_op, u_sq, kpad = ops.score_prep(user_repr, dtype, normalize=graph.engine_normalize, want_sqnorm=want_sq)
+            i_op, i_sq, _ = ops.score_prep(item_repr, dtype, normalize=graph.engine_normalize, want_sqnorm=want_sq)
+            ub = user_bias.detach().contiguous() if self.biased else None
+            ib = item_bias.detach().contiguous() if self.biased else None
+            return ops.score_store(u_op, i_op, dtype, kpad, ub, ib, graph.engine_mode, u_sq, i_sq)
+        if self._is_engine_graph() and differentiable:
+            pred = _differentiable_dense(graph, user_repr, item_repr)
+        else:
+            pred = graph.connect_dense_prediction_graph(tf_user_representation=user_repr,
+                                                        tf_item_representation=item_repr)
+        if self.biased:
+            pred = bias_prediction_dense(pred, user_bias, item_bias)
+        return pred
+
+    # ------------------------------------------------------------------------------------------ fit
+    def fit(self, interactions, user_features, item_features, epochs=100, learning_rate=0.1, alpha=0.00001,
+            verbose=False, user_batch_size=None, n_sampled_items=None):
+        """Constructs the model (first call) and fits it -- arguments as tensorrec/tensorrec.py:494-526."""
+        self.fit_partial(interactions=interactions, user_features=user_features, item_features=item_features,
+                         epochs=epochs, learning_rate=learning_rate, alpha=alpha, verbose=verbose,
+                         user_batch_size=user_batch_size, n_sampled_items=n_sampled_items)
+
+    def fit_partial(self, interactions, user_features, item_features, epochs=1, learning_rate=0.1,
+                    alpha=0.00001, verbose=False, user_batch_size=None, n_sampled_items=None):
+        """One or more epochs; one optimiser step per user batch (tensorrec/tensorrec.py:539-634)."""
+        loss_graph = self.loss_graph_factory
+        if loss_graph.is_sample_based:
+            if (n_sampled_items is None) or (n_sampled_items <= 0):
+                raise ValueError("n_sampled_items must be an integer >0")
+        if (n_sampled_items is not None) and (not loss_graph.is_sample_based):
+            logging.warning('n_sampled_items was specified, but the loss graph is not sample-based')
+
+        if verbose:
+            logging.info('Processing interaction and feature data')
+        batches = self._create_batches(interactions, user_features, item_features, user_batch_size)
+
+        if self.n_tastes != 1 or self.attention_graph_factory is not None:
+            raise NotImplementedError("n_tastes > 1 / attention are not built yet (SURVEY.md 8f item 2)")
+
+        device = self._device()
+        if self._store is None:
+            # numbers of features are learned from the first batch and cannot change (tensorrec.py:598-605)
+            n_user_features = batches[0][1].shape[1]
+            n_item_features = batches[0][2].shape[1]
+            if self.seed is not None:
+                set_seed(self.seed)
+            self.n_user_features, self.n_item_features = int(n_user_features), int(n_item_features)
+            self._store = VariableStore(device)
+            if self.sampler is None:
+                self.sampler = DeviceSampler(self.seed if self.seed is not None else 0)
+
+        # upload once per call; the epoch loop below touches only device memory
+        dev_batches = []
+        item_cache = {}
+        for inter_m, uf_m, if_m in batches:
+            if uf_m.shape[1] != self.n_user_features or if_m.shape[1] != self.n_item_features:
+                raise ValueError("feature matrices must keep the number of features the model was first fit with")
+            if id(if_m) not in item_cache:
+                item_cache[id(if_m)] = SparseFeatures(if_m, device)
+            uf = SparseFeatures(uf_m, device)
+            itf = item_cache[id(if_m)]
+            inter = Interactions(inter_m, n_users=uf.shape[0], n_items=itf.shape[0], device=device)
+            dev_batches.append((inter, uf, itf))
+
+        batched_alpha = calculate_batched_alpha(num_batches=len(dev_batches), alpha=alpha)
+        if verbose:
+            logging.info('Beginning fitting')
+
+        for epoch in range(epochs):
+            for batch, (inter, uf, itf) in enumerate(dev_batches):
+                loss, serial_predictions, wr_loss = self._train_step(inter, uf, itf, learning_rate, batched_alpha,
+                                                                     n_sampled_items, want_stats=verbose)
+                if verbose:
+                    mean_loss = float(loss.mean())
+                    mean_pred = float(serial_predictions.mean())
+                    weight_reg_l2_loss = alpha * wr_loss      # the reference logs the UNbatched alpha (:631)
+                    logging.info('EPOCH {} BATCH {} loss = {}, weight_reg_l2_loss = {}, mean_pred = {}'.format(
+                        epoch, batch, mean_loss, weight_reg_l2_loss, mean_pred
+                    ))
+
+    def _train_step(self, inter, user_feats, item_feats, learning_rate, alpha, n_sampled_items, want_stats=False):
+        loss_graph = self.loss_graph_factory
+        graph = self.prediction_graph_factory
+        n_users, n_items = inter.shape
+        with variable_scope(self._store):
+            user_repr, item_repr, user_bias, item_bias, weights = self._representations(user_feats, item_feats)
+            x_user = PairIndex.make(inter.x_user, inter.x_user32)
+            x_item = PairIndex.make(inter.x_item, inter.x_item32)
+
+            engine = self._is_engine_graph()
+            if engine:
+                u_in, i_in = user_repr, item_repr
+                if graph.engine_normalize:        # cosine: normalise once, share between both serial calls
+                    u_in, i_in = ops.l2_normalize_rows(user_repr), ops.l2_normalize_rows(item_repr)
+                pred_serial = self._serial_engine(u_in, i_in, x_user, x_item, user_bias, item_bias)
+            else:
+                pred_serial = self._serial(user_repr, item_repr, x_user, x_item, user_bias, item_bias)
+
+            loss_kwargs = {
+                'tf_prediction_serial': pred_serial,
+                'tf_interactions_serial': inter.values,
+                'tf_interactions': inter,
+                'tf_n_users': n_users,
+                'tf_n_items': n_items,
+            }
+            if loss_graph.is_dense:
+                tf_prediction = self._dense_prediction(user_repr, item_repr, user_bias, item_bias, differentiable=True)
+                loss_kwargs.update({'tf_prediction': tf_prediction,
+                                    'tf_rankings': rank_predictions(tf_prediction)})
+            if loss_graph.is_sample_based:
+                self._sample_step += 1
+                samples = self.sampler.sample(n_items, n_users, int(n_sampled_items),
+                                              loss_graph.is_sampled_with_replacement, self._sample_step,
+                                              self._store.device)
+                samples = samples.to(torch.int32).contiguous()
+                if engine:
+                    xs_item = PairIndex.make(samples.reshape(-1), samples.reshape(-1), int(n_sampled_items))
+                    samp_serial = self._serial_engine(u_in, i_in, xs_item, xs_item, user_bias, item_bias)
+                else:
+                    xs_user64 = torch.arange(n_users, device=samples.device).repeat_interleave(int(n_sampled_items))
+                    xs_item64 = samples.reshape(-1).to(torch.int64)
+                    samp_serial = self._serial(user_repr, item_repr, PairIndex.make(xs_user64),
+                                               PairIndex.make(xs_item64), user_bias, item_bias)
+                loss_kwargs.update({
+                    'tf_sample_predictions': densify_sampled_item_predictions(samp_serial, n_sampled_items, n_users),
+                    'tf_n_sampled_items': n_sampled_items,
+                })
+
+            basic_loss = loss_graph.connect_loss_graph(**loss_kwargs)
+
+        # tf_loss = tf_basic_loss + alpha * reg (broadcast), minimised as a sum (tensorrec.py:487-489)
+        n_loss = int(basic_loss.numel())
+        basic_loss.sum().backward()
+
+        reg_ids = set(id(w) for w in weights)
+        self._opt_step += 1
+        lr_t = _adam_lr_t(learning_rate, self._opt_step)
+        l2 = float(np.float32(np.float32(n_loss) * np.float32(alpha)))
+        for name in self._store.order:
+            var = self._store.variables[name]
+            if name not in self._adam:
+                self._adam[name] = (torch.zeros_like(var), torch.zeros_like(var))
+            m, v = self._adam[name]
+            grad = var.grad if var.grad is not None else torch.zeros_like(var)
+            with torch.no_grad():
+                ops.adam_tf_step(var, m, v, grad, lr_t, l2 if id(var) in reg_ids else 0.0, ADAM_BETA1, ADAM_BETA2,
+                                 ADAM_EPSILON)
+            var.grad = None
+
+        if want_stats:
+            with torch.no_grad():
+                wr = float(sum(0.5 * float((w.detach() ** 2).sum()) for w in weights))
+            return basic_loss.detach(), pred_serial.detach(), wr
+        return None, None, None
+
+    # ------------------------------------------------------------------------------------------ predict
+    def _check_fit(self, method):
+        if self._store is None:
+            raise ModelNotFitException(method=method)
+
+    def _inference(self, user_features=None, item_features=None):
+        device = self._store.device
+        uf = SparseFeatures(self._single(user_features), device) if user_features is not None else None
+        itf = SparseFeatures(self._single(item_features), device) if item_features is not None else None
+        return uf, itf
+
+    def _single(self, raw):
+        mats = self._as_list(raw)
+        return mats[0] if len(mats) == 1 else sp.vstack(mats, format='csr')
+
+    def _predict_device(self, user_features, item_features):
+        uf, itf = self._inference(user_features, item_features)
+        with torch.no_grad(), variable_scope(self._store):
+            user_repr, item_repr, user_bias, item_bias, _ = self._representations(uf, itf)
+            return self._dense_prediction(user_repr, item_repr, user_bias, item_bias)
+
+    def predict(self, user_features, item_features):
+        """Recommendation scores, ndarray [n_users, n_items] float32 (tensorrec.py:636-664)."""
+        self._check_fit('predict')
+        return self._predict_device(user_features, item_features).cpu().numpy()
+
+    def predict_rank(self, user_features, item_features):
+        """Recommendation ranks, ndarray [n_users, n_items] int32, 1 = best (tensorrec.py:705-733)."""
+        self._check_fit('predict_rank')
+        pred = self._predict_device(user_features, item_features)
+        return rank_predictions(pred).cpu().numpy()
+
+    def predict_top_k(self, user_features, item_features, k=10, user_batch_size=65536, return_device=False):
+        """EXTENSION: the k best items per user -- (scores [n_users, k] float32, item ids [n_users, k] int32),
+        ordered like the first k ranks of ``predict_rank`` -- computed by the fused MFMA score + top-k kernel without
+        materialising [n_users, n_items] (which is 4 TB at 1M x 1M)."""
+        self._check_fit('predict_top_k')
+        if not self._is_engine_graph():
+            raise ValueError("predict_top_k needs a built-in prediction graph")
+        graph = self.prediction_graph_factory
+        uf, itf = self._inference(user_features, item_features)
+        dtype = ops.DTYPE_BF16 if self.precision == 'bf16' else ops.DTYPE_F32
+        want_sq = graph.engine_mode == ops.MODE_EUCLIDEAN
+        vals, idx = [], []
+        with torch.no_grad(), variable_scope(self._store):
+            user_repr, item_repr, user_bias, item_bias, _ = self._representations(uf, itf)
+            i_op, i_sq, kpad = ops.score_prep(item_repr, dtype, normalize=graph.engine_normalize, want_sqnorm=want_sq)
+            ib = item_bias.contiguous() if self.biased else None
+            for s in range(0, uf.shape[0], user_batch_size):
+                e = min(s + user_batch_size, uf.shape[0])
+                u_op, u_sq, _ = ops.score_prep(user_repr[s:e], dtype, normalize=graph.engine_normalize,
+                                               want_sqnorm=want_sq)
+                ub = user_bias[s:e].contiguous() if self.biased else None
+                v, i = ops.score_topk(u_op, i_op, dtype, kpad, k, ub, ib, graph.engine_mode, u_sq, i_sq)
+                vals.append(v)
+                idx.append(i)
+        vals, idx = torch.cat(vals), torch.cat(idx)
+        if return_device:
+            return vals, idx
+        return vals.cpu().numpy(), idx.cpu().numpy()
+
+    def predict_similar_items(self, item_features, item_ids, n_similar):
+        """Most similar items, list of lists of (item_id, score) (tensorrec.py:666-703); the query item itself is
+        included, as in the reference."""
+        self._check_fit('predict_similar_items')
+        _, itf = self._inference(None, item_features)
+        with torch.no_grad(), variable_scope(self._store):
+            item_repr, _ = self.item_repr_graph_factory.connect_representation_graph(
+                tf_features=itf, n_components=self.n_components, n_features=self.n_item_features,
+                node_name_ending='item')
+            sims = predict_similar_items(self.prediction_graph_factory, item_repr, np.array(item_ids)).cpu().numpy()
+        results = []
+        for i in range(len(item_ids)):
+            item_sims = sims[i]
+            best = np.argpartition(item_sims, -n_similar)[-n_similar:]
+            item_results = sorted(zip(best, item_sims[best]), key=lambda x: -x[1])
+            results.append(item_results)
+        return results
+
+    def predict_user_representation(self, user_features):
+        """ndarray [n_users, n_components] (tensorrec.py:735-762)."""
+        self._check_fit('predict_user_representation')
+        uf, _ = self._inference(user_features, None)
+        with torch.no_grad(), variable_scope(self._store):
+            user_repr, _ = self.user_repr_graph_factory.connect_representation_graph(
+                tf_features=uf, n_components=self.n_components, n_features=self.n_user_features,
+                node_name_ending='user_{}'.format(0))
+        return user_repr.cpu().numpy()
+
+    def predict_user_attention_representation(self, user_features):
+        self._check_fit('predict_user_attention_representation')
+        if self.attention_graph_factory is None:
+            raise ModelWithoutAttentionException()
+        raise NotImplementedError("attention is not built yet (SURVEY.md 8f item 2)")
+
+    def predict_item_representation(self, item_features):
+        """ndarray [n_items, n_components] (tensorrec.py:795-816)."""
+        self._check_fit('predict_item_representation')
+        _, itf = self._inference(None, item_features)
+        with torch.no_grad(), variable_scope(self._store):
+            item_repr, _ = self.item_repr_graph_factory.connect_representation_graph(
+                tf_features=itf, n_components=self.n_components, n_features=self.n_item_features,
+                node_name_ending='item')
+        return item_repr.cpu().numpy()
+
+    def predict_user_bias(self, user_features):
+        """ndarray [n_users] (tensorrec.py:818-842)."""
+        self._check_fit('predict_user_bias')
+        if not self.biased:
+            raise ModelNotBiasedException(actor='user')
+        uf, _ = self._inference(user_features, None)
+        with torch.no_grad(), variable_scope(self._store):
+            _, proj = project_biases(uf, self.n_user_features, name='user_feature_biases')
+        return proj.cpu().numpy()
+
+    def predict_item_bias(self, item_features):
+        """ndarray [n_items] (tensorrec.py:844-868)."""
+        self._check_fit('predict_item_bias')
+        if not self.biased:
+            raise ModelNotBiasedException(actor='item')
+        _, itf = self._inference(None, item_features)
+        with torch.no_grad(), variable_scope(self._store):
+            _, proj = project_biases(itf, self.n_item_features, name='item_feature_biases')
+        return proj.cpu().numpy()
+
+    # ------------------------------------------------------------------------------------------ weights access
+    def get_weights(self):
+        """name -> ndarray copy of every variable (EXTENSION; used by the parity tests to share weights with the
+        oracle, since the reference exposes no seed)."""
+        self._check_fit('get_weights')
+        return {k: v.detach().cpu().numpy().copy() for k, v in self._store.variables.items()}
+
+    def set_weights(self, weights, reset_optimizer=True):
+        self._check_fit('set_weights')
+        for k, arr in weights.items():
+            var = self._store.variables[k]
+            with torch.no_grad():
+                var.copy_(torch.as_tensor(np.asarray(arr, np.float32).reshape(tuple(var.shape)), device=var.device))
+        if reset_optimizer:
+            self._adam = {}
+            self._opt_step = 0
+
+    def build(self, n_user_features, n_item_features):
+        """EXTENSION: create the variables without a training step (weights then come from set_weights or the
+        initialisers); fit_partial does this implicitly on its first call."""
+        device = self._device()
+        if self._store is None:
+            if self.seed is not None:
+                set_seed(self.seed)
+            self.n_user_features, self.n_item_features = int(n_user_features), int(n_item_features)
+            self._store = VariableStore(device)
+            if self.sampler is None:
+                self.sampler = DeviceSampler(self.seed if self.seed is not None else 0)
+            uf = SparseFeatures(sp.csr_matrix((1, n_user_features), dtype=np.float32), device)
+            itf = SparseFeatures(sp.csr_matrix((1, n_item_features), dtype=np.float32), device)
+            with torch.no_grad(), variable_scope(self._store):
+                self._representations(uf, itf)
+        return self
+
+
+class _DenseDot(torch.autograd.Function):
+    """Differentiable dense scores for is_dense losses: forward = K2 STORE kernel, backward = two fp32 MFMA GEMMs."""
+
+    @staticmethod
+    def forward(ctx, u, v):
+        u_op, _, kpad = ops.score_prep(u, ops.DTYPE_F32)
+        v_op, _, _ = ops.score_prep(v, ops.DTYPE_F32)
+        ctx.save_for_backward(u, v)
+        return ops.score_store(u_op, v_op, ops.DTYPE_F32, kpad)
+
+    @staticmethod
+    def backward(ctx, g):
+        u, v = ctx.saved_tensors
+        g = g.contiguous()
+        return ops.gemm_raw(g, v), ops.gemm_raw(g, u, trans_a=True)
+
+
+def _differentiable_dense(graph, user_repr, item_repr):
+    if graph.engine_mode == ops.MODE_DOT:
+        if graph.engine_normalize:
+            user_repr, item_repr = ops.l2_normalize_rows(user_repr), ops.l2_normalize_rows(item_repr)
+        return _DenseDot.apply(user_repr, item_repr)
+    # euclidean: r_u - 2 u.i + r_i through the differentiable dot (prediction_graphs.py:84-100)
+    r_u = (user_repr ** 2).sum(dim=1, keepdim=True)
+    r_i = (item_repr ** 2).sum(dim=1, keepdim=True)
+    dist = (r_u - 2.0 * _DenseDot.apply(user_repr, item_repr)) + r_i.t()
+    return -1.0 * torch.sqrt(torch.clamp(dist, min=1e-16))
