@@ -13,6 +13,28 @@ from . import _native as N
 from .sparse import SparseFeatures, Interactions, PairIndex
 
 DTYPE_F32, DTYPE_BF16 = 0, 1
+
+# bench.py sets this to a list to collect (start, end) HIP events around every launch of the named kernels on the
+# launching stream (the kernels run on torch's current stream, so torch.cuda.Event brackets exactly them)
+KERNEL_EVENTS = None
+
+
+class _timed(object):
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if KERNEL_EVENTS is not None:
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.e = torch.cuda.Event(enable_timing=True)
+            self.s.record()
+        return self
+
+    def __exit__(self, *exc):
+        if KERNEL_EVENTS is not None:
+            self.e.record()
+            KERNEL_EVENTS.append((self.name, self.s, self.e))
+        return False
 MODE_DOT, MODE_EUCLIDEAN = 0, 1
 EPI_NONE, EPI_L2NORM, EPI_BIAS_RELU = 0, 1, 2
 
@@ -31,8 +53,9 @@ def spmm_raw(indptr, indices, values, perm, n_rows, nnz, w, col_bias=None, epilo
     if out is None:
         out = torch.empty((n_rows, d), dtype=torch.float32, device=w.device)
     inv = torch.empty((n_rows,), dtype=torch.float32, device=w.device) if want_inv else None
-    N.call("trec_spmm_csr", N.ptr(indptr), N.ptr(indices), N.ptr(values), N.ptr(perm), n_rows, nnz, N.ptr(w), d,
-           N.ptr(col_bias), epilogue, 1 if accumulate else 0, N.ptr(out), N.ptr(inv))
+    with _timed("spmm_csr"):
+        N.call("trec_spmm_csr", N.ptr(indptr), N.ptr(indices), N.ptr(values), N.ptr(perm), n_rows, nnz, N.ptr(w), d,
+               N.ptr(col_bias), epilogue, 1 if accumulate else 0, N.ptr(out), N.ptr(inv))
     return (out, inv) if want_inv else out
 
 
@@ -347,9 +370,10 @@ def score_topk(users_op, items_op, dtype, kpad, k, user_bias=None, item_bias=Non
         pi = torch.empty((n_u, n_parts, cap), dtype=torch.int32, device=users_op.device)
     else:
         pv, pi = workspace
-    N.call("trec_score_gemm_topk", N.ptr(users_op), N.ptr(items_op), dtype, kpad, n_u, n_i, item_index_base,
-           N.ptr(user_bias), N.ptr(item_bias), mode, N.ptr(user_sq), N.ptr(item_sq), n_chunks, N.ptr(pv), N.ptr(pi),
-           variant)
+    with _timed("score_gemm_topk"):
+        N.call("trec_score_gemm_topk", N.ptr(users_op), N.ptr(items_op), dtype, kpad, n_u, n_i, item_index_base,
+               N.ptr(user_bias), N.ptr(item_bias), mode, N.ptr(user_sq), N.ptr(item_sq), n_chunks, N.ptr(pv),
+               N.ptr(pi), variant)
     return topk_merge(pv.reshape(n_u, n_parts * cap), pi.reshape(n_u, n_parts * cap), k)
 
 

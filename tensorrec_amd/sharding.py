@@ -1,0 +1,75 @@
+"""
+Item sharding across the GPUs of one node (one process per GPU, torch.distributed; backend "nccl" is RCCL over xGMI).
+
+The reference has no multi-device code at all; this is the MI355X-native scaling path named by
+BASELINE.json's north_star: items (rows of the item feature matrix, hence of the item representation) are split
+row-wise, the user tile is replicated, and exactly ONE small collective finishes a query:
+
+  * top-k  : every rank runs the fused score+top-k kernel on its item shard with global item ids
+             (``item_index_base``), then an all-gather of the per-rank [U, k] lists (U*k*8 bytes per rank -- 5 MB
+             for 65,536 users, k = 10) and a local k-way merge (trec_topk_merge).  Every rank ends with the same,
+             exact, global top-k: the merge order (value desc, index asc) is a total order over disjoint item ids.
+  * ranks  : rank = 1 + count of items that beat the target (recommendation_graphs.py:73-82 is a count);
+             counts over disjoint item ranges add, so an all-reduce(SUM) of int32 partial counts gives exact ranks.
+
+No collective sits inside the score kernel; payloads are KBs-MBs against ~10 ms of MFMA work per 65k-user tile, so
+xGMI (7 point-to-point links x ~153 GB/s) is nowhere near a bound and a plain all-gather is the right primitive.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_items, world_size, rank, align=64):
+    """Contiguous, aligned, nearly equal item ranges: [begin, end) of ``rank``.  ``align`` keeps shard starts on the
+    score kernel's tile so float4 bias loads stay aligned; the last shard takes the remainder."""
+    if world_size < 1 or not (0 <= rank < world_size):
+        raise ValueError("bad world_size / rank")
+    per = -(-n_items // world_size)
+    per = -(-per // align) * align
+    begin = min(rank * per, n_items)
+    end = min(begin + per, n_items)
+    return begin, end
+
+
+def all_gather_cat(t, group=None, dim=1):
+    """All-gather equal-shaped tensors and concatenate along ``dim`` (rank order)."""
+    world = dist.get_world_size(group)
+    if world == 1:
+        return t
+    parts = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(parts, t.contiguous(), group=group)
+    return torch.cat(parts, dim=dim)
+
+
+def exchange_topk(local_vals, local_idx, group=None):
+    """Per-shard [U, k] lists -> candidate tables [U, world*k] on every rank (one all-gather each for values/ids)."""
+    return all_gather_cat(local_vals, group), all_gather_cat(local_idx, group)
+
+
+def merge_topk(cand_vals, cand_idx, k):
+    """k best of the gathered candidates, (value desc, index asc).  GPU tensors only: this is the HIP merge kernel."""
+    from . import ops
+    return ops.topk_merge(cand_vals.contiguous(), cand_idx.contiguous(), k)
+
+
+def sharded_top_k(local_vals, local_idx, k, group=None):
+    """local lists (global item ids) -> exact global top-k, identical on every rank."""
+    cv, ci = exchange_topk(local_vals, local_idx, group)
+    return merge_topk(cv, ci, k)
+
+
+def reduce_rank_counts(local_counts, group=None):
+    """Partial 'items that beat the target' counts (int32) -> global ranks - 1 on every rank (all-reduce SUM)."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(local_counts, op=dist.ReduceOp.SUM, group=group)
+    return local_counts
+
+
+def max_over_ranks(seconds, device, group=None):
+    """Timing helper for bench.py: the slowest rank defines the step time."""
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return float(t.item())

@@ -1,0 +1,274 @@
+"""Model-level parity and API tests on the GPU: TensorRec (HIP path) against oracle.model.OracleTensorRec from
+IDENTICAL injected weights (the reference exposes no seed), plus the reference's own API-shape tests
+(test/test_tensorrec.py, test/test_readme.py) restated for this engine."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+from oracle import oracle as O
+from oracle.model import OracleTensorRec
+
+pytestmark = pytest.mark.gpu
+
+import tensorrec_amd as T  # noqa: E402
+from tensorrec_amd.loss_graphs import (RMSELossGraph, RMSEDenseLossGraph, WMRBLossGraph, BalancedWMRBLossGraph,  # noqa
+                                       SeparationLossGraph, SeparationDenseLossGraph, AbstractLossGraph)
+from tensorrec_amd.prediction_graphs import (DotProductPredictionGraph, CosineSimilarityPredictionGraph,  # noqa
+                                             EuclideanSimilarityPredictionGraph)
+from tensorrec_amd.representation_graphs import (LinearRepresentationGraph, NormalizedLinearRepresentationGraph,  # noqa
+                                                 ReLURepresentationGraph, FeaturePassThroughRepresentationGraph,
+                                                 WeightedFeaturePassThroughRepresentationGraph,
+                                                 AbstractRepresentationGraph)
+
+REPR = {"linear": LinearRepresentationGraph, "normalized_linear": NormalizedLinearRepresentationGraph,
+        "relu": ReLURepresentationGraph}
+PRED = {"dot": DotProductPredictionGraph, "cosine": CosineSimilarityPredictionGraph,
+        "euclidean": EuclideanSimilarityPredictionGraph}
+LOSS = {"rmse": RMSELossGraph, "wmrb": WMRBLossGraph, "balanced_wmrb": BalancedWMRBLossGraph}
+
+
+def dummy(n_users=60, n_items=90, seed=0):
+    inter, uf, itf = T.util.generate_dummy_data(num_users=n_users, num_items=n_items, interaction_density=.08,
+                                                num_user_features=40, num_item_features=50, n_features_per_user=6,
+                                                n_features_per_item=7, random_state=seed)
+    return sp.csr_matrix(inter), sp.csr_matrix(uf), sp.csr_matrix(itf)
+
+
+def make_pair(d, user_repr, item_repr, pred, loss, biased, data, sample_tables=None):
+    inter, uf, itf = data
+    oracle = OracleTensorRec(d, user_repr, item_repr, pred, loss, biased)
+    oracle.init_weights(uf.shape[1], itf.shape[1], np.random.default_rng(42))
+    if biased:      # non-zero biases so the bias path is actually exercised from step 1
+        rng = np.random.default_rng(7)
+        oracle.weights["user_feature_biases"] = (0.1 * rng.standard_normal((uf.shape[1], 1))).astype(np.float32)
+        oracle.weights["item_feature_biases"] = (0.1 * rng.standard_normal((itf.shape[1], 1))).astype(np.float32)
+    sampler = T.ReplaySampler(sample_tables) if sample_tables is not None else None
+    model = T.TensorRec(n_components=d, user_repr_graph=REPR[user_repr](), item_repr_graph=REPR[item_repr](),
+                        prediction_graph=PRED[pred](), loss_graph=LOSS[loss](), biased=biased, sampler=sampler, seed=1)
+    model.build(uf.shape[1], itf.shape[1])
+    model.set_weights(_rename(oracle.weights))
+    return model, oracle
+
+
+def _rename(w):
+    out = {}
+    for k, v in w.items():
+        if k.endswith("_user"):
+            k = k + "_0"                # node_name_ending 'user_0' (tensorrec.py:344)
+        out[k] = v
+    return out
+
+
+@pytest.mark.parametrize("user_repr,item_repr,pred,loss,biased,d", [
+    ("linear", "linear", "dot", "rmse", True, 100),                 # the reference's defaults (BASELINE config 1)
+    ("linear", "linear", "dot", "rmse", False, 32),
+    ("linear", "linear", "dot", "wmrb", True, 64),                  # BASELINE config 2 shape
+    ("normalized_linear", "linear", "cosine", "balanced_wmrb", True, 20),
+    ("relu", "relu", "euclidean", "wmrb", True, 16),                # BASELINE config 5 shape
+    ("linear", "relu", "euclidean", "rmse", False, 12),
+])
+def test_fit_steps_match_oracle(user_repr, item_repr, pred, loss, biased, d):
+    data = dummy()
+    inter, uf, itf = data
+    S, steps = 11, 3
+    tables = None
+    if "wmrb" in loss:
+        rng = np.random.RandomState(3)
+        tables = [O.sample_items(itf.shape[0], uf.shape[0], S, False, rng)[:, 1].reshape(uf.shape[0], S)
+                  for _ in range(steps)]
+    model, oracle = make_pair(d, user_repr, item_repr, pred, loss, biased, data, tables)
+
+    # forward parity before any training
+    p_gpu = model.predict(uf, itf)
+    p_ref = oracle.predict(uf, itf)
+    scale = np.abs(p_ref).max()
+    assert np.abs(p_gpu - p_ref).max() <= 1e-4 * scale          # north_star: 1e-4 relative on float scores
+
+    for t in range(steps):
+        model.fit_partial(inter, uf, itf, epochs=1, learning_rate=0.05, alpha=1e-4,
+                          n_sampled_items=S if tables else None)
+        oracle.step(inter, uf, itf, 0.05, 1e-4, tables[t] if tables else None)
+    got = model.get_weights()
+    for k, ref in _rename(oracle.weights).items():
+        assert got[k].shape == ref.shape, k
+        # Adam normalises the step to ~lr, so a mismatch anywhere upstream shows up as O(lr) here
+        assert np.allclose(got[k], ref, rtol=2e-3, atol=2e-4), "%s: max abs diff %g" % (k, np.abs(got[k] - ref).max())
+    p_gpu = model.predict(uf, itf)
+    p_ref = oracle.predict(uf, itf)
+    assert np.abs(p_gpu - p_ref).max() <= 5e-3 * max(1.0, np.abs(p_ref).max())
+
+
+def test_predict_and_rank_bit_exact_from_same_weights():
+    """Linear + DotProduct + biases in fp32: K1 (fmaf in CSR order) -> K2 (fmaf chain over k) -> bias adds in the
+    reference's order.  From the same weights the whole score matrix is bit-identical to the C oracle, hence so are
+    the ranks (north_star: 'bit-exact for predicted ranks')."""
+    inter, uf, itf = dummy(70, 333, seed=5)
+    model, oracle = make_pair(100, "linear", "linear", "dot", "rmse", True, (inter, uf, itf))
+    model.fit(inter, uf, itf, epochs=2)                       # move the weights off their initial values
+    w = model.get_weights()
+    u = O.spmm_exact(uf, w["linear_weights_user_0"])
+    v = O.spmm_exact(itf, w["linear_weights_item"])
+    ub = O.spmm_exact(uf, w["user_feature_biases"]).reshape(-1)
+    ib = O.spmm_exact(itf, w["item_feature_biases"]).reshape(-1)
+    ref = O.score_dense_exact(u, v, ub, ib)
+    pred = model.predict(uf, itf)
+    assert pred.dtype == np.float32 and np.array_equal(pred, ref)
+    ranks = model.predict_rank(uf, itf)
+    assert ranks.dtype == np.int32 and np.array_equal(ranks, O.rank_predictions_exact(ref))
+    vals, idx = model.predict_top_k(uf, itf, k=10)
+    rv, ri = O.topk_rows(ref, 10)
+    assert np.array_equal(idx, ri) and np.array_equal(vals, rv)
+    assert np.array_equal(model.predict_user_representation(uf), u)
+    assert np.array_equal(model.predict_item_representation(itf), v)
+    assert np.array_equal(model.predict_user_bias(uf), ub)
+    assert np.array_equal(model.predict_item_bias(itf), ib)
+
+
+def test_bf16_precision_mode_reports_rank_agreement():
+    inter, uf, itf = dummy(64, 500, seed=6)
+    m32 = T.TensorRec(n_components=64, seed=3)
+    m32.fit(inter, uf, itf, epochs=2)
+    m16 = T.TensorRec(n_components=64, precision='bf16', seed=3)
+    m16.build(uf.shape[1], itf.shape[1])
+    m16.set_weights(m32.get_weights())
+    p32, p16 = m32.predict(uf, itf), m16.predict(uf, itf)
+    scale = np.abs(p32).max()
+    assert np.abs(p32 - p16).max() <= 2e-2 * scale            # bf16 operands: ~2^-8 per element
+    _, i32 = m32.predict_top_k(uf, itf, k=10)
+    _, i16 = m16.predict_top_k(uf, itf, k=10)
+    overlap = np.mean([len(set(a) & set(b)) / 10.0 for a, b in zip(i32, i16)])
+    assert overlap > 0.8
+
+
+# ---- API behaviour (test/test_tensorrec.py, test/test_readme.py restated) -------------------------------------
+def test_readme_flow_and_shapes():
+    inter, uf, itf = T.util.generate_dummy_data(num_users=100, num_items=150, interaction_density=.05, random_state=0)
+    model = T.TensorRec()
+    model.fit(inter, uf, itf, epochs=5, verbose=True)
+    predictions = model.predict(user_features=uf, item_features=itf)
+    ranks = model.predict_rank(user_features=uf, item_features=itf)
+    assert predictions.shape == (100, 150) and ranks.shape == (100, 150)
+    assert (ranks > 0).all() and (np.sort(ranks, axis=1) == np.arange(1, 151)[None, :]).all()
+    assert model.predict_user_representation(uf).shape == (100, 100)
+    assert model.predict_item_representation(itf).shape == (150, 100)
+    assert model.predict_user_bias(uf).shape == (100,) and model.predict_item_bias(itf).shape == (150,)
+    assert np.abs(model.predict_user_bias(uf)).sum() > 0          # biases are trained (test_tensorrec.py:269-275)
+    sims = model.predict_similar_items(itf, item_ids=[6, 12], n_similar=5)
+    assert len(sims) == 2 and len(sims[0]) == 5 and sims[0][0][0] == 6
+
+
+def test_unfit_and_unbiased_errors():
+    inter, uf, itf = dummy()
+    model = T.TensorRec(n_components=10, biased=False)
+    for name, args in (("predict", (uf, itf)), ("predict_rank", (uf, itf)), ("predict_user_representation", (uf,)),
+                       ("predict_item_representation", (itf,)), ("predict_user_bias", (uf,)),
+                       ("predict_similar_items", (itf, [1], 2))):
+        with pytest.raises(T.errors.ModelNotFitException):
+            getattr(model, name)(*args)
+    model.fit(inter, uf, itf, epochs=1)
+    with pytest.raises(T.errors.ModelNotBiasedException):
+        model.predict_user_bias(uf)
+    with pytest.raises(T.errors.ModelNotBiasedException):
+        model.predict_item_bias(itf)
+    with pytest.raises(T.errors.ModelWithoutAttentionException):
+        model.predict_user_attention_representation(uf)
+
+
+def test_fit_argument_checks_and_batching():
+    inter, uf, itf = dummy()
+    model = T.TensorRec(n_components=8, loss_graph=WMRBLossGraph())
+    with pytest.raises(ValueError):
+        model.fit(inter, uf, itf, epochs=1)                               # sample-based loss needs n_sampled_items
+    with pytest.raises(ValueError):
+        model.fit(inter, uf, itf, epochs=1, n_sampled_items=0)
+    model.fit(inter, uf, itf, epochs=2, n_sampled_items=10, user_batch_size=25)      # 3 user batches
+    assert model.predict(uf, itf).shape == (60, 90)
+    with pytest.raises(T.errors.BatchNonSparseInputException):
+        T.TensorRec(n_components=8).fit(inter.toarray(), uf, itf, epochs=1, user_batch_size=10)
+    with pytest.raises(ValueError):
+        T.TensorRec(n_components=8).fit([inter, inter], [uf], itf, epochs=1)          # batch counts differ
+    with pytest.raises(ValueError):
+        T.TensorRec(n_components=8).fit(inter.toarray(), uf, itf, epochs=1)           # not sparse
+    # lists of pre-batched inputs
+    m2 = T.TensorRec(n_components=8)
+    m2.fit([inter[:30], inter[30:]], [uf[:30], uf[30:]], itf, epochs=1)
+    assert m2.predict(uf, itf).shape == (60, 90)
+
+
+@pytest.mark.parametrize("loss,kw", [(RMSELossGraph, {}), (RMSEDenseLossGraph, {}), (WMRBLossGraph, {"n_sampled_items": 10}),
+                                     (BalancedWMRBLossGraph, {"n_sampled_items": 10}), (SeparationLossGraph, {}),
+                                     (SeparationDenseLossGraph, {})])
+@pytest.mark.parametrize("biased", [True, False])
+def test_loss_graphs_run(loss, kw, biased):
+    """test/test_loss_graphs.py:17-47 (smoke) -- plus: the loss must actually go down."""
+    inter, uf, itf = T.util.generate_dummy_data_with_indicator(num_users=10, num_items=12, interaction_density=.5,
+                                                               seed=0)
+    model = T.TensorRec(n_components=10, loss_graph=loss(), biased=biased, seed=0)
+    model.fit(inter, uf, itf, epochs=5, **kw)
+    assert np.isfinite(model.predict(uf, itf)).all()
+
+
+@pytest.mark.parametrize("u,i,d", [(LinearRepresentationGraph, LinearRepresentationGraph, 50),
+                                   (NormalizedLinearRepresentationGraph, LinearRepresentationGraph, 50),
+                                   (LinearRepresentationGraph, NormalizedLinearRepresentationGraph, 50),
+                                   (ReLURepresentationGraph, ReLURepresentationGraph, 20),
+                                   (FeaturePassThroughRepresentationGraph, NormalizedLinearRepresentationGraph, 36),
+                                   (WeightedFeaturePassThroughRepresentationGraph, NormalizedLinearRepresentationGraph, 36),
+                                   (LinearRepresentationGraph, FeaturePassThroughRepresentationGraph, 48)])
+def test_representation_graphs_run(u, i, d):
+    """test/test_representation_graphs.py:14-35: 15 x 30 indicator data, n_components sized for the pass-throughs."""
+    inter, uf, itf = T.util.generate_dummy_data_with_indicator(num_users=15 * 2, num_items=20 * 2,
+                                                               interaction_density=.5, seed=1)
+    # user features: 36 columns, item features: 48 columns
+    model = T.TensorRec(n_components=d, user_repr_graph=u(), item_repr_graph=i(), seed=0)
+    model.fit(inter, uf, itf, epochs=10)
+    assert model.predict(uf, itf).shape == (30, 40)
+
+
+def test_passthrough_dimension_mismatch_raises():
+    inter, uf, itf = dummy()
+    model = T.TensorRec(n_components=5, user_repr_graph=FeaturePassThroughRepresentationGraph())
+    with pytest.raises(ValueError):
+        model.fit(inter, uf, itf, epochs=1)
+
+
+def test_custom_graphs_plug_in():
+    """test/test_readme.py:36-108: user-defined representation (tanh) and loss (MAE) subclasses."""
+    from tensorrec_amd import ops
+    from tensorrec_amd.framework import Variable, random_normal
+
+    class TanhRepresentationGraph(AbstractRepresentationGraph):
+        def connect_representation_graph(self, tf_features, n_components, n_features, node_name_ending):
+            w = Variable(lambda: random_normal([n_features, n_components], stddev=.5),
+                         name='tanh_weights_%s' % node_name_ending)
+            return torch.tanh(ops.sparse_dense_matmul(tf_features, w)), [w]
+
+    class SimpleLossGraph(AbstractLossGraph):
+        def connect_loss_graph(self, tf_prediction_serial, tf_interactions_serial, **kwargs):
+            return torch.mean(torch.abs(tf_interactions_serial - tf_prediction_serial))
+
+    inter, uf, itf = dummy()
+    model = T.TensorRec(n_components=12, user_repr_graph=TanhRepresentationGraph(),
+                        item_repr_graph=TanhRepresentationGraph(), loss_graph=SimpleLossGraph(), seed=0)
+    model.fit(inter, uf, itf, epochs=1)
+    before = np.abs(inter.toarray()[inter.toarray() != 0] - model.predict(uf, itf)[inter.toarray() != 0]).mean()
+    model.fit(inter, uf, itf, epochs=30, learning_rate=0.01)
+    after = np.abs(inter.toarray()[inter.toarray() != 0] - model.predict(uf, itf)[inter.toarray() != 0]).mean()
+    assert after < before
+    assert set(model.get_weights()) >= {"tanh_weights_user_0", "tanh_weights_item"}
+
+
+def test_training_reduces_wmrb_loss_and_ranks_positives_higher():
+    """End-to-end sanity with the DEVICE sampler: WMRB training must push positives up the ranking."""
+    rng = np.random.RandomState(0)
+    n_u, n_i = 200, 300
+    inter = sp.random(n_u, n_i, density=0.03, random_state=rng, format="csr", dtype=np.float32)
+    inter.data[:] = 1.0
+    uf, itf = sp.identity(n_u, format="csr", dtype=np.float32), sp.identity(n_i, format="csr", dtype=np.float32)
+    model = T.TensorRec(n_components=16, loss_graph=WMRBLossGraph(), seed=0)
+    model.fit(inter, uf, itf, epochs=1, n_sampled_items=30)
+    r0 = model.predict_rank(uf, itf)[inter.nonzero()].mean()
+    model.fit(inter, uf, itf, epochs=40, n_sampled_items=30, learning_rate=0.05)
+    r1 = model.predict_rank(uf, itf)[inter.nonzero()].mean()
+    assert r1 < 0.5 * r0, (r0, r1)
