@@ -540,3 +540,26 @@ def test_goldens_on_gpu_recommendation_graphs(goldens):
     g = goldens["predict_similar_items"]
     got = R.predict_similar_items(CosineSimilarityPredictionGraph(), dev(g["reprs"]), [1]).cpu().numpy()
     assert (got == g["expected_sims"]).all()
+
+
+# ------------------------------------------------------------------------------------------------ item shards
+@pytest.mark.parametrize("world", [2, 8])
+def test_item_shards_merge_to_global_topk(ops, world):
+    """What N ranks do, on one GPU: per-shard fused top-k with global ids (item_index_base), lists concatenated the
+    way the all-gather lays them out, HIP merge -> the exact global top-k (tests/test_sharding_gloo.py covers the
+    collective itself)."""
+    from tensorrec_amd import sharding
+    u, v = _uv(130, 5000, 64, seed=world, integer=True)
+    rng = np.random.default_rng(2)
+    ub, ib = np.round(rng.standard_normal(130)).astype(np.float32), np.round(rng.standard_normal(5000)).astype(np.float32)
+    u_op, _, kpad = ops.score_prep(dev(u), ops.DTYPE_F32)
+    lists_v, lists_i = [], []
+    for r in range(world):
+        b, e = sharding.shard_bounds(5000, world, r, align=64)
+        v_op, _, _ = ops.score_prep(dev(v[b:e]), ops.DTYPE_F32)
+        lv, li = ops.score_topk(u_op, v_op, ops.DTYPE_F32, kpad, 10, dev(ub), dev(ib[b:e]), item_index_base=b)
+        lists_v.append(lv)
+        lists_i.append(li)
+    gv, gi = sharding.merge_topk(torch.cat(lists_v, dim=1), torch.cat(lists_i, dim=1), 10)
+    rv, ri = O.topk_rows(O.score_dense_exact(u, v, ub, ib), 10)
+    assert np.array_equal(gi.cpu().numpy(), ri) and np.array_equal(gv.cpu().numpy(), rv)
