@@ -126,7 +126,7 @@ def main():
     f_i = SparseFeatures(sp.identity(n_local, dtype=np.float32, format="csr"), device)   # this rank's item rows
     kpad = ops.score_kpad(d)
     n_chunks = ops.topk_chunks_for(U, dtype, kpad, n_local)
-    cap = 16
+    cap = T._native.query("trec_score_topk_capacity", k)
     n_parts = T._native.query("trec_score_topk_parts", dtype, kpad, n_local, n_chunks)
     ws = (torch.empty((U, n_parts, cap), dtype=torch.float32, device=device),
           torch.empty((U, n_parts, cap), dtype=torch.int32, device=device))

@@ -73,7 +73,7 @@ int trec_gemm_f32(int32_t trans_a, int32_t trans_b, int64_t M, int64_t N, int64_
 int trec_score_kpad(int32_t d);                                   /* 32 / 64 / 128 / 256, or -1 if d > 256       */
 int trec_score_rows_per_workgroup(int32_t dtype, int32_t kpad);
 int trec_score_tile_rows(int32_t dtype, int32_t kpad);
-int trec_score_topk_capacity(void);                               /* entries per partial list (16)               */
+int trec_score_topk_capacity(int32_t k);                          /* entries per partial list: 8, 12 or 16; -1 if k > 16 */
 int trec_score_prep(const float* repr, int64_t n, int32_t d, int32_t kpad, int32_t normalize, int32_t dtype, void* out,
                     float* out_sqnorm, void* stream);
 /* predict(): out[u, i] = score(u, i) (+ user_bias[u]) (+ item_bias[i]) -- tensorrec.py:662 */
@@ -82,13 +82,15 @@ int trec_score_gemm_store(const void* users, const void* items, int32_t dtype, i
                           const float* user_sqnorm, const float* item_sqnorm, float* out, int64_t ld_out,
                           int32_t variant, void* stream);
 /* fused top-k (first tf.nn.top_k of rank_predictions, recommendation_graphs.py:80, truncated to <= 16): writes
- * n_parts = trec_score_topk_parts(...) sorted partial lists per user, [n_users, n_parts, 16] values + item indices
- * (index + item_index_base; empty slots = (-inf, -1)); finish with trec_topk_merge.                          */
+ * n_parts = trec_score_topk_parts(...) sorted partial lists per user, [n_users, n_parts, capacity] values + item
+ * indices (index + item_index_base; empty slots = (-inf, -1)), capacity = trec_score_topk_capacity(k); finish with
+ * trec_topk_merge.  variant: bit 0 = stage item tiles with global_load_lds (else through registers); bits 1.. =
+ * experimental tilings of the bf16 / K=128 / capacity-12 configuration (0 = default).                        */
 int trec_score_topk_parts(int32_t dtype, int32_t kpad, int64_t n_items, int32_t n_chunks);
 int trec_score_gemm_topk(const void* users, const void* items, int32_t dtype, int32_t kpad, int64_t n_users,
                          int64_t n_items, int32_t item_index_base, const float* user_bias, const float* item_bias,
                          int32_t mode, const float* user_sqnorm, const float* item_sqnorm, int32_t n_chunks,
-                         float* part_vals, int32_t* part_idx, int32_t variant, void* stream);
+                         int32_t capacity, float* part_vals, int32_t* part_idx, int32_t variant, void* stream);
 /* k best of n_cand candidates per user, ordered (value desc, index asc) = tf.nn.top_k tie rule; also the merge
  * step after the all-gather of per-shard lists */
 int trec_topk_merge(const float* part_vals, const int32_t* part_idx, int64_t n_users, int32_t n_cand, int32_t k,

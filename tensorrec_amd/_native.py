@@ -33,12 +33,12 @@ SIGNATURES = {
     "trec_score_kpad": [_i32],
     "trec_score_rows_per_workgroup": [_i32, _i32],
     "trec_score_tile_rows": [_i32, _i32],
-    "trec_score_topk_capacity": [],
+    "trec_score_topk_capacity": [_i32],
     "trec_score_prep": [_vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
     "trec_score_gemm_store": [_vp, _vp, _i32, _i32, _i64, _i64, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _i32, _vp],
     "trec_score_topk_parts": [_i32, _i32, _i64, _i32],
-    "trec_score_gemm_topk": [_vp, _vp, _i32, _i32, _i64, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32,
-                             _vp],
+    "trec_score_gemm_topk": [_vp, _vp, _i32, _i32, _i64, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp,
+                             _i32, _vp],
     "trec_topk_merge": [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp],
     "trec_pair_score_fwd": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
     "trec_pair_score_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp],

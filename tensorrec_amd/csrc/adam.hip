@@ -12,6 +12,10 @@
 // rounded fp32 op (__f*_rn: no FMA contraction), so the update is bit-identical to oracle.adam_tf_step.
 #include "common.hpp"
 
+// HIP's __f*_rn intrinsics are plain operators, which hipcc would contract into FMAs (-ffp-contract=fast is the
+// HIP default); the TF functor and the oracle round every operation separately.
+#pragma clang fp contract(off)
+
 __device__ __forceinline__ void adam_elem(float& w, float& m, float& v, float g, float lr_t, float omb1, float omb2,
                                           float eps, float l2)
 {

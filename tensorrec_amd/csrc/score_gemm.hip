@@ -26,7 +26,7 @@
 
 #define EPI_STORE 0
 #define EPI_TOPK 1
-#define KTOP 16
+#define KTOP_MAX 16
 
 struct ScoreParams {
     const void* R;            // resident operand [n_r, KT] (fp32 or bf16), users
@@ -42,7 +42,7 @@ struct ScoreParams {
     int euclid;
     float* out;               // STORE: [n_r, ld_out]
     int64_t ld_out;
-    float* part_vals;         // TOPK: [n_r, n_parts, KTOP]
+    float* part_vals;         // TOPK: [n_r, n_parts, KTOP]  (KTOP = list capacity: 8, 12 or 16)
     int32_t* part_idx;
     int n_parts;              // 2 * n_chunks
     int32_t t_index_base;     // added to item indices written by TOPK (item shards)
@@ -63,6 +63,7 @@ template <int CH> __device__ __forceinline__ int swz(int row) {
 __device__ __forceinline__ int cd_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }  // 32x32 C/D row of reg r
 
 // sorted-descending insertion; `s` is -inf for lanes that do not qualify (then nothing moves)
+template <int KTOP>
 __device__ __forceinline__ void topk_insert(float (&tv)[KTOP], int32_t (&ti)[KTOP], float s, int32_t id)
 {
     bool ge_j = tv[KTOP - 1] >= s;
@@ -77,7 +78,7 @@ __device__ __forceinline__ void topk_insert(float (&tv)[KTOP], int32_t (&ti)[KTO
     }
 }
 
-template <int DT, int KT, int BN, int NCB, int EPI, bool GLDS, bool EUCLID, int WPS>
+template <int DT, int KT, int BN, int NCB, int EPI, bool GLDS, bool EUCLID, int WPS, int KTOP>
 __global__ __launch_bounds__(256, WPS) void score_gemm_kernel(ScoreParams p)
 {
     constexpr int ES = ElemOf<DT>::BYTES;
@@ -90,7 +91,9 @@ __global__ __launch_bounds__(256, WPS) void score_gemm_kernel(ScoreParams p)
     static_assert(BN % 32 == 0, "BN must be a multiple of the 32-row MFMA block");
 
     constexpr int RW = 4 * NCB * 32;         // resident rows per workgroup
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 * TILE_BYTES + (STORE: 2 * RW floats)
+    // LDS: 2 * TILE_BYTES | STORE: r_bias[RW], r_sq[RW] | TOPK: per buffer t_bias[BN], t_sq[BN], t_bias block max[BN/32]
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TSIDE = 2 * BN + 32;       // floats of per-tile side data per buffer (block maxima padded to 32)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -142,17 +145,29 @@ __global__ __launch_bounds__(256, WPS) void score_gemm_kernel(ScoreParams p)
 
     float tv[(EPI == EPI_TOPK) ? NCB : 1][KTOP];
     int32_t ti[(EPI == EPI_TOPK) ? NCB : 1][KTOP];
+    float tau_p[NCB];          // KTOP-th best of the OTHER half-wave's list for the same user (a valid lower bound)
     if (EPI == EPI_TOPK) {
 #pragma unroll
-        for (int cb = 0; cb < NCB; ++cb)
+        for (int cb = 0; cb < NCB; ++cb) {
+            tau_p[cb] = -INFINITY;
 #pragma unroll
             for (int j = 0; j < KTOP; ++j) { tv[cb][j] = -INFINITY; ti[cb][j] = -1; }
+        }
     }
+    float* tside = (float*)(smem + 2 * TILE_BYTES);           // TOPK side data, [2][TSIDE]
 
     // ---- staging of the streamed tile: slot q = i*256 + tid  ->  (row, physical chunk) ----
     u32x4 stage[GLDS ? 1 : NSLOT];
+    float side_b = 0.f, side_q = 0.f;
     auto stage_issue = [&](int tile, int buf) {
         const int64_t row0 = t_begin + (int64_t)tile * BN;
+        if (EPI == EPI_TOPK && tid < BN) {
+            int64_t g = row0 + tid;
+            const bool ok = g < p.n_t;
+            if (!ok) g = p.n_t - 1;
+            side_b = p.t_bias ? (ok ? p.t_bias[g] : -INFINITY) : 0.f;     // -inf: padded rows never raise the block max
+            side_q = EUCLID ? p.t_sqnorm[g] : 0.f;
+        }
 #pragma unroll
         for (int i = 0; i < NSLOT; ++i) {
             const int q = i * 256 + tid;
@@ -171,6 +186,14 @@ __global__ __launch_bounds__(256, WPS) void score_gemm_kernel(ScoreParams p)
         }
     };
     auto stage_commit = [&](int buf) {
+        if (EPI == EPI_TOPK && tid < BN) {
+            float* sd = tside + buf * TSIDE;
+            sd[tid] = side_b;
+            sd[BN + tid] = side_q;
+            float m = side_b;                                   // max over each 32-item block (lanes 0-31 / 32-63)
+            for (int off = 16; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+            if ((tid & 31) == 0) sd[2 * BN + (tid >> 5)] = m;
+        }
         if (!GLDS) {
 #pragma unroll
             for (int i = 0; i < NSLOT; ++i) *(u32x4*)(smem + buf * TILE_BYTES + (i * 256 + tid) * 16) = stage[i];
@@ -223,46 +246,55 @@ __global__ __launch_bounds__(256, WPS) void score_gemm_kernel(ScoreParams p)
 
             const int64_t blk_row0 = tile_row0 + rb * 32;     // first streamed row (item) of this 32-block
             if (EPI == EPI_TOPK) {
-                // rows of acc = items blk_row0 + cd_row(r, half); col = my user
-                float tb[16], tq[16];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int64_t i0 = blk_row0 + 8 * q + 4 * half;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        int64_t ii = i0 + e;
-                        if (ii >= p.n_t) ii = p.n_t - 1;
-                        tb[q * 4 + e] = p.t_bias ? p.t_bias[ii] : 0.f;
-                        tq[q * 4 + e] = EUCLID ? p.t_sqnorm[ii] : 0.f;
-                    }
-                }
+                // rows of acc = items blk_row0 + cd_row(r, half); col = my user.  Two-level filter:
+                //  (1) block bound: (max_r acc + user_bias) + max item bias of the block.  fp32 rounding is monotone,
+                //      so no score of the block can exceed it; if it cannot enter the list the block costs ~11 VALU.
+                //  (2) exact scores in the reference's order (acc + ub) + ib only for blocks that pass (1).
+                const float* sd = tside + buf * TSIDE;
 #pragma unroll
                 for (int cb = 0; cb < NCB; ++cb) {
-                    f32x16 s = acc[cb];
-                    float m = -INFINITY;
+                    bool need = true;
+                    if (!EUCLID && !partial) {
+                        float m = acc[cb][0];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        float v = s[r];
-                        if (EUCLID) {
-                            float dist = (r_sq_col[cb] - 2.0f * v) + tq[r];
-                            dist = fmaxf(dist, 1e-16f);
-                            v = -1.0f * sqrtf(dist);
-                        }
-                        if (p.r_bias) v = v + r_bias_col[cb];
-                        if (p.t_bias) v = v + tb[r];
-                        if (partial && blk_row0 + cd_row(r, half) >= p.n_t) v = -INFINITY;
-                        s[r] = v;
-                        m = fmaxf(m, v);
+                        for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[cb][r]);
+                        float bound = m;
+                        if (p.r_bias) bound = bound + r_bias_col[cb];
+                        if (p.t_bias) bound = bound + sd[2 * BN + rb];
+                        need = (bound > tv[cb][KTOP - 1]) && (bound >= tau_p[cb]);
                     }
-                    if (__any(m > tv[cb][KTOP - 1])) {
+                    if (__any(need)) {
+                        f32x16 s;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const f32x4 tb4 = *(const f32x4*)(sd + rb * 32 + 8 * q + 4 * half);
+                            const f32x4 tq4 = *(const f32x4*)(sd + BN + rb * 32 + 8 * q + 4 * half);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int r = q * 4 + e;
+                                float v = acc[cb][r];
+                                if (EUCLID) {
+                                    float dist = (r_sq_col[cb] - 2.0f * v) + tq4[e];
+                                    dist = fmaxf(dist, 1e-16f);
+                                    v = -1.0f * sqrtf(dist);
+                                }
+                                if (p.r_bias) v = v + r_bias_col[cb];
+                                if (p.t_bias) v = v + tb4[e];
+                                if (partial && blk_row0 + cd_row(r, half) >= p.n_t) v = -INFINITY;
+                                s[r] = v;
+                            }
+                        }
 #pragma unroll 1
                         for (int r = 0; r < 16; ++r) {
                             const float v = s[r];
-                            const bool q = v > tv[cb][KTOP - 1];
+                            // strict against my own list (earlier equal values have lower indices), non-strict against
+                            // the partner's threshold (an equal value there may carry a higher index)
+                            const bool q = (v > tv[cb][KTOP - 1]) && (v >= tau_p[cb]);
                             if (__any(q))
-                                topk_insert(tv[cb], ti[cb], q ? v : -INFINITY,
-                                            (int32_t)(blk_row0 + cd_row(r, half)) + p.t_index_base);
+                                topk_insert<KTOP>(tv[cb], ti[cb], q ? v : -INFINITY,
+                                                  (int32_t)(blk_row0 + cd_row(r, half)) + p.t_index_base);
                         }
+                        tau_p[cb] = fmaxf(tau_p[cb], __shfl_xor(tv[cb][KTOP - 1], 32, 64));
                     }
                 }
             } else {
@@ -396,15 +428,17 @@ __global__ __launch_bounds__(256) void score_prep_kernel(const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------
-template <int DT, int KT, int BN, int NCB, int EPI, bool GLDS, bool EUCLID>
+template <int DT, int KT, int BN, int NCB, int EPI, bool GLDS, bool EUCLID, int KTOP, int WPS_OVERRIDE = 0>
 static int launch_score(const ScoreParams& p, hipStream_t st)
 {
-    constexpr int LDS = 2 * BN * KT * ElemOf<DT>::BYTES + (EPI == EPI_STORE ? 2 * 4 * NCB * 32 * 4 : 0);
+    constexpr int LDS = 2 * BN * KT * ElemOf<DT>::BYTES +
+                        (EPI == EPI_STORE ? 2 * 4 * NCB * 32 * 4 : 2 * (2 * BN + 32) * 4);
     // 2 workgroups per CU (256 registers per lane) unless the resident fragments + top-k lists need more
-    constexpr int WPS = ((DT == 0 && KT >= 128) || KT == 256 || (EUCLID && KT >= 128)) ? 1 : 2;
-    auto kern = score_gemm_kernel<DT, KT, BN, NCB, EPI, GLDS, EUCLID, WPS>;
+    constexpr int WPS = WPS_OVERRIDE ? WPS_OVERRIDE
+                                     : (((DT == 0 && KT >= 128) || KT == 256 || (EUCLID && KT >= 128)) ? 1 : 2);
+    auto kern = score_gemm_kernel<DT, KT, BN, NCB, EPI, GLDS, EUCLID, WPS, KTOP>;
     static bool attr_set = false;
-    if (!attr_set && LDS > 48 * 1024) {
+    if (!attr_set && LDS > 32 * 1024) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
@@ -432,17 +466,18 @@ extern "C" int trec_score_kpad(int32_t d)
 // resident rows handled by one workgroup for (dtype, kpad): 4 waves * NCB * 32
 extern "C" int trec_score_rows_per_workgroup(int32_t dtype, int32_t kpad) { return 4 * score_cfg(dtype, kpad).ncb * 32; }
 extern "C" int trec_score_tile_rows(int32_t dtype, int32_t kpad) { return score_cfg(dtype, kpad).bn; }
-extern "C" int trec_score_topk_capacity(void) { return KTOP; }
+// capacity of the per-lane lists for a requested k: 8, 12 or 16 (k > 16 is not supported by the fused epilogue)
+extern "C" int trec_score_topk_capacity(int32_t k) { return k <= 8 ? 8 : (k <= 12 ? 12 : (k <= 16 ? 16 : -1)); }
 
-template <int EPI>
+template <int EPI, int KTOP>
 static int dispatch_score(int dtype, int kt, int variant, const ScoreParams& p, hipStream_t st)
 {
     const bool glds = (variant & 1) != 0;
-#define TREC_SCORE_CASE(DT, KTV, BNV, NCBV)                                            \
-    if (dtype == DT && kt == KTV) {                                                    \
-        if (p.euclid) return launch_score<DT, KTV, BNV, NCBV, EPI, false, true>(p, st);  \
-        if (glds) return launch_score<DT, KTV, BNV, NCBV, EPI, true, false>(p, st);    \
-        return launch_score<DT, KTV, BNV, NCBV, EPI, false, false>(p, st);             \
+#define TREC_SCORE_CASE(DT, KTV, BNV, NCBV)                                                  \
+    if (dtype == DT && kt == KTV) {                                                          \
+        if (p.euclid) return launch_score<DT, KTV, BNV, NCBV, EPI, false, true, KTOP>(p, st);  \
+        if (glds && DT == 1) return launch_score<DT, KTV, BNV, NCBV, EPI, true, false, KTOP>(p, st);  \
+        return launch_score<DT, KTV, BNV, NCBV, EPI, false, false, KTOP>(p, st);             \
     }
     TREC_SCORE_CASE(1, 32, 64, 2)
     TREC_SCORE_CASE(1, 64, 64, 2)
@@ -457,9 +492,23 @@ static int dispatch_score(int dtype, int kt, int variant, const ScoreParams& p, 
     return TREC_ERR_UNSUPPORTED;
 }
 
+// experimental tilings of the hot configuration (bf16, K = 128, dot, capacity 12), selected by variant >> 1
+static ScoreCfg score_cfg_variant(int dtype, int kt, int variant)
+{
+    if (dtype == 1 && kt == 128) {
+        switch (variant >> 1) {
+            case 1: return ScoreCfg{128, 4};     // 1 workgroup / CU, 128 users per wave, 512 registers
+            case 2: return ScoreCfg{128, 2};     // 1 workgroup / CU, 64 users per wave
+            case 3: return ScoreCfg{64, 1};      // 3 workgroups / CU, 32 users per wave
+            default: break;
+        }
+    }
+    return score_cfg(dtype, kt);
+}
+
 static int fill_common(ScoreParams& p, const void* users, const void* items, int dtype, int kpad, int64_t n_users,
                        int64_t n_items, const float* user_bias, const float* item_bias, int mode,
-                       const float* user_sqnorm, const float* item_sqnorm, int n_chunks)
+                       const float* user_sqnorm, const float* item_sqnorm, int n_chunks, int variant = 0)
 {
     TREC_REQUIRE(users && items, "trec_score_gemm: null operand");
     TREC_REQUIRE(dtype == 0 || dtype == 1, "trec_score_gemm: dtype must be 0 (fp32) or 1 (bf16)");
@@ -468,10 +517,10 @@ static int fill_common(ScoreParams& p, const void* users, const void* items, int
     TREC_REQUIRE(mode == 0 || mode == 1, "trec_score_gemm: mode must be 0 (dot) or 1 (euclidean)");
     TREC_REQUIRE(mode == 0 || (user_sqnorm && item_sqnorm), "trec_score_gemm: euclidean mode needs squared norms");
     TREC_REQUIRE(n_chunks >= 1, "trec_score_gemm: n_chunks must be >= 1");
-    const ScoreCfg c = score_cfg(dtype, kpad);
+    const ScoreCfg c = score_cfg_variant(dtype, kpad, variant);
     p.R = users; p.T = items; p.n_r = n_users; p.n_t = n_items;
     p.n_rblocks = (int)ceil_div64(n_users, 4 * c.ncb * 32);
-    int64_t cl = ceil_div64(ceil_div64(n_items, n_chunks), c.bn) * c.bn;
+    int64_t cl = ceil_div64(ceil_div64(n_items, n_chunks), 128) * 128;     // multiple of every BN in use
     p.chunk_len = cl;
     p.n_chunks = (int)ceil_div64(n_items, cl);
     p.r_bias = user_bias; p.t_bias = item_bias; p.r_sqnorm = user_sqnorm; p.t_sqnorm = item_sqnorm;
@@ -498,13 +547,13 @@ extern "C" int trec_score_gemm_store(const void* users, const void* items, int32
                          item_sqnorm, n_chunks);
     if (rc) return rc;
     p.out = out; p.ld_out = ld_out;
-    return dispatch_score<EPI_STORE>(dtype, kpad, variant, p, (hipStream_t)stream);
+    return dispatch_score<EPI_STORE, 8>(dtype, kpad, variant, p, (hipStream_t)stream);
 }
 
 // number of partial lists per user that trec_score_gemm_topk writes for a requested chunk count
 extern "C" int trec_score_topk_parts(int32_t dtype, int32_t kpad, int64_t n_items, int32_t n_chunks)
 {
-    const ScoreCfg c = score_cfg(dtype, kpad);
+    const ScoreCfg c = ScoreCfg{128, 0};     // chunk lengths are rounded to 128 rows: valid for every tiling (BN | 128)
     if (n_chunks < 1 || n_items < 1) return -1;
     const int64_t cl = ceil_div64(ceil_div64(n_items, n_chunks), c.bn) * c.bn;
     return 2 * (int)ceil_div64(n_items, cl);
@@ -514,15 +563,33 @@ extern "C" int trec_score_gemm_topk(const void* users, const void* items, int32_
                                     int64_t n_users, int64_t n_items, int32_t item_index_base,
                                     const float* user_bias, const float* item_bias, int32_t mode,
                                     const float* user_sqnorm, const float* item_sqnorm, int32_t n_chunks,
-                                    float* part_vals, int32_t* part_idx, int32_t variant, void* stream)
+                                    int32_t capacity, float* part_vals, int32_t* part_idx, int32_t variant,
+                                    void* stream)
 {
     ScoreParams p = {};
     TREC_REQUIRE(part_vals && part_idx, "trec_score_gemm_topk: null workspace");
+    TREC_REQUIRE(capacity == 8 || capacity == 12 || capacity == 16, "trec_score_gemm_topk: capacity must be 8, 12 or 16");
+    const bool experimental = dtype == 1 && kpad == 128 && capacity == 12 && mode == 0 && (variant >> 1) != 0 &&
+                              (variant >> 1) <= 3;
     int rc = fill_common(p, users, items, dtype, kpad, n_users, n_items, user_bias, item_bias, mode, user_sqnorm,
-                         item_sqnorm, n_chunks);
+                         item_sqnorm, n_chunks, experimental ? variant : 0);
     if (rc) return rc;
     p.part_vals = part_vals; p.part_idx = part_idx; p.n_parts = 2 * p.n_chunks; p.t_index_base = item_index_base;
-    return dispatch_score<EPI_TOPK>(dtype, kpad, variant, p, (hipStream_t)stream);
+    if (experimental) {
+        hipStream_t st = (hipStream_t)stream;
+        const bool glds = variant & 1;
+        switch (variant >> 1) {
+            case 1: return glds ? launch_score<1, 128, 128, 4, EPI_TOPK, true, false, 12, 1>(p, st)
+                                : launch_score<1, 128, 128, 4, EPI_TOPK, false, false, 12, 1>(p, st);
+            case 2: return glds ? launch_score<1, 128, 128, 2, EPI_TOPK, true, false, 12, 1>(p, st)
+                                : launch_score<1, 128, 128, 2, EPI_TOPK, false, false, 12, 1>(p, st);
+            default: return glds ? launch_score<1, 128, 64, 1, EPI_TOPK, true, false, 12, 3>(p, st)
+                                 : launch_score<1, 128, 64, 1, EPI_TOPK, false, false, 12, 3>(p, st);
+        }
+    }
+    if (capacity == 8) return dispatch_score<EPI_TOPK, 8>(dtype, kpad, variant, p, (hipStream_t)stream);
+    if (capacity == 12) return dispatch_score<EPI_TOPK, 12>(dtype, kpad, variant, p, (hipStream_t)stream);
+    return dispatch_score<EPI_TOPK, 16>(dtype, kpad, variant, p, (hipStream_t)stream);
 }
 
 extern "C" int trec_topk_merge(const float* part_vals, const int32_t* part_idx, int64_t n_users, int32_t n_cand,

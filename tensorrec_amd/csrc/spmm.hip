@@ -314,7 +314,8 @@ extern "C" int trec_spmm_csr(const int64_t* indptr, const int32_t* indices, cons
                              const float* col_bias, int32_t epilogue, int32_t accumulate, float* out,
                              float* out_inv_norm, void* stream)
 {
-    TREC_REQUIRE(indptr && indices && values && W && out, "trec_spmm_csr: null pointer");
+    TREC_REQUIRE(indptr && W && out, "trec_spmm_csr: null pointer");
+    TREC_REQUIRE(nnz == 0 || (indices && values), "trec_spmm_csr: null indices/values with nnz != 0");
     TREC_REQUIRE(d >= 1 && n_rows >= 0, "trec_spmm_csr: bad sizes");
     TREC_REQUIRE(epilogue >= 0 && epilogue <= 2, "trec_spmm_csr: epilogue must be 0, 1 or 2");
     TREC_REQUIRE(epilogue != 2 || col_bias, "trec_spmm_csr: epilogue 2 needs col_bias");
@@ -383,7 +384,7 @@ extern "C" int trec_colsum(const float* x, int64_t n_rows, int32_t d, float* out
 extern "C" int trec_spmv_csr(const int64_t* indptr, const int32_t* indices, const float* values,
                              const int32_t* val_perm, int64_t n_rows, const float* beta, float* out, void* stream)
 {
-    TREC_REQUIRE(indptr && indices && values && beta && out, "trec_spmv_csr: null pointer");
+    TREC_REQUIRE(indptr && beta && out, "trec_spmv_csr: null pointer");   // indices/values may be NULL when nnz == 0
     if (n_rows == 0) return TREC_OK;
     hipLaunchKernelGGL(spmv_csr_kernel, dim3((unsigned)ceil_div64(n_rows, 256)), dim3(256), 0, (hipStream_t)stream,
                        indptr, indices, values, val_perm, n_rows, beta, out);
@@ -393,7 +394,7 @@ extern "C" int trec_spmv_csr(const int64_t* indptr, const int32_t* indices, cons
 extern "C" int trec_csr_to_dense(const int64_t* indptr, const int32_t* indices, const float* values, int64_t n_rows,
                                  int32_t n_cols, float* out, void* stream)
 {
-    TREC_REQUIRE(indptr && indices && values && out, "trec_csr_to_dense: null pointer");
+    TREC_REQUIRE(indptr && out, "trec_csr_to_dense: null pointer");
     if (n_rows == 0) return TREC_OK;
     hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)n_rows * (size_t)n_cols, (hipStream_t)stream);
     if (e != hipSuccess) { trec_set_last_error("trec_csr_to_dense: memset failed"); return TREC_ERR_LAUNCH; }

@@ -358,9 +358,9 @@ def score_topk(users_op, items_op, dtype, kpad, k, user_bias=None, item_bias=Non
                item_sq=None, item_index_base=0, n_chunks=None, variant=0, workspace=None):
     """Fused score + per-user top-k without materialising [U, I].  Returns (values [U, k], item indices [U, k]),
     ordered (value desc, index asc)."""
-    cap = N.query("trec_score_topk_capacity")
-    if k > cap:
-        raise ValueError("fused top-k supports k <= %d (got %d)" % (cap, k))
+    cap = N.query("trec_score_topk_capacity", int(k))
+    if cap < 0:
+        raise ValueError("fused top-k supports k <= 16 (got %d)" % k)
     n_u, n_i = users_op.shape[0], items_op.shape[0]
     if n_chunks is None:
         n_chunks = topk_chunks_for(n_u, dtype, kpad, n_i)
@@ -372,7 +372,7 @@ def score_topk(users_op, items_op, dtype, kpad, k, user_bias=None, item_bias=Non
         pv, pi = workspace
     with _timed("score_gemm_topk"):
         N.call("trec_score_gemm_topk", N.ptr(users_op), N.ptr(items_op), dtype, kpad, n_u, n_i, item_index_base,
-               N.ptr(user_bias), N.ptr(item_bias), mode, N.ptr(user_sq), N.ptr(item_sq), n_chunks, N.ptr(pv),
+               N.ptr(user_bias), N.ptr(item_bias), mode, N.ptr(user_sq), N.ptr(item_sq), n_chunks, cap, N.ptr(pv),
                N.ptr(pi), variant)
     return topk_merge(pv.reshape(n_u, n_parts * cap), pi.reshape(n_u, n_parts * cap), k)
 

@@ -563,3 +563,21 @@ def test_item_shards_merge_to_global_topk(ops, world):
     gv, gi = sharding.merge_topk(torch.cat(lists_v, dim=1), torch.cat(lists_i, dim=1), 10)
     rv, ri = O.topk_rows(O.score_dense_exact(u, v, ub, ib), 10)
     assert np.array_equal(gi.cpu().numpy(), ri) and np.array_equal(gv.cpu().numpy(), rv)
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7])
+def test_score_topk_bf16_all_tilings(ops, variant):
+    """Every tiling of the hot configuration (bf16, K=128, top-10 -> capacity 12) gives the exact top-k of the bf16
+    score matrix, with biases, ragged sizes and several item chunks."""
+    u, v = _uv(777, 4099, 128, seed=11)
+    rng = np.random.default_rng(3)
+    ub, ib = rng.standard_normal(777).astype(np.float32), rng.standard_normal(4099).astype(np.float32)
+    u_op, _, kpad = ops.score_prep(dev(u), ops.DTYPE_BF16)
+    v_op, _, _ = ops.score_prep(dev(v), ops.DTYPE_BF16)
+    scores = ops.score_store(u_op, v_op, ops.DTYPE_BF16, kpad, dev(ub), dev(ib)).cpu().numpy()
+    for chunks in (1, 3):
+        vals, idx = ops.score_topk(u_op, v_op, ops.DTYPE_BF16, kpad, 10, dev(ub), dev(ib), n_chunks=chunks,
+                                   variant=variant)
+        rv, ri = O.topk_rows(scores, 10)
+        assert np.array_equal(vals.cpu().numpy(), rv), "chunks=%d" % chunks
+        assert np.array_equal(idx.cpu().numpy(), ri), "chunks=%d" % chunks

@@ -155,7 +155,11 @@ def test_readme_flow_and_shapes():
     assert model.predict_user_bias(uf).shape == (100,) and model.predict_item_bias(itf).shape == (150,)
     assert np.abs(model.predict_user_bias(uf)).sum() > 0          # biases are trained (test_tensorrec.py:269-275)
     sims = model.predict_similar_items(itf, item_ids=[6, 12], n_similar=5)
-    assert len(sims) == 2 and len(sims[0]) == 5 and sims[0][0][0] == 6
+    assert len(sims) == 2 and len(sims[0]) == 5
+    assert all(0 <= i < 150 for i, _ in sims[0]) and [s for _, s in sims[0]] == sorted((s for _, s in sims[0]), reverse=True)
+    cos = T.TensorRec(n_components=10, prediction_graph=T.prediction_graphs.CosineSimilarityPredictionGraph(), seed=0)
+    cos.fit(inter, uf, itf, epochs=1)
+    assert cos.predict_similar_items(itf, item_ids=[6], n_similar=3)[0][0][0] == 6     # cosine: an item is its own nearest
 
 
 def test_unfit_and_unbiased_errors():

@@ -146,11 +146,14 @@ def test_abi_pure_queries_and_argument_errors():
     lib = _native.load()
     assert [lib.trec_score_kpad(d) for d in (1, 32, 33, 64, 100, 128, 129, 256, 257)] == \
         [32, 32, 64, 64, 128, 128, 256, 256, -1]
-    assert lib.trec_score_topk_capacity() == 16
+    assert [lib.trec_score_topk_capacity(k) for k in (1, 8, 9, 10, 12, 13, 16, 17)] == [8, 8, 12, 12, 12, 16, 16, -1]
     assert lib.trec_score_rows_per_workgroup(1, 128) == 256 and lib.trec_score_rows_per_workgroup(0, 128) == 128
-    assert lib.trec_score_topk_parts(1, 128, 1000000, 4) == 8
+    assert lib.trec_score_topk_parts(1, 128, 1000000, 4) == 8 and lib.trec_score_topk_parts(0, 32, 100, 8) == 2
     rc = lib.trec_spmm_csr(None, None, None, None, 1, 1, None, 4, None, 0, 0, None, None, None)
     assert rc == 1 and b"null pointer" in lib.trec_last_error()
+    rc = lib.trec_spmm_csr(ctypes.c_void_p(8), None, None, None, 1, 1, ctypes.c_void_p(8), 4, None, 0, 0,
+                           ctypes.c_void_p(8), None, None)
+    assert rc == 1 and b"nnz != 0" in lib.trec_last_error()
     rc = lib.trec_sample_items(3, 5, 6, 0, 0, 0, ctypes.c_void_p(8), None)
     assert rc == 1 and b"larger sample than population" in lib.trec_last_error()
 
