@@ -13,8 +13,8 @@
 #include "common.hpp"
 
 // HIP's __f*_rn intrinsics are plain operators, which hipcc would contract into FMAs (-ffp-contract=fast is the
-// HIP default); the TF functor and the oracle round every operation separately.
-#pragma clang fp contract(off)
+// HIP default and ignores contract pragmas); the TF functor and the oracle round every operation separately, so this
+// file is compiled with -ffp-contract=off (see the Makefile).
 
 __device__ __forceinline__ void adam_elem(float& w, float& m, float& v, float g, float lr_t, float omb1, float omb2,
                                           float eps, float l2)

@@ -152,6 +152,7 @@ class TensorRec(object):
         self.sampler = sampler
 
         self._store = None
+        self._capture = None          # tests set this to a dict to receive the last step's loss and raw gradients
         self._adam = {}
         self._opt_step = 0
         self._sample_step = 0
@@ -385,6 +386,11 @@ class TensorRec(object):
         basic_loss.sum().backward()
 
         reg_ids = set(id(w) for w in weights)
+        if self._capture is not None:
+            self._capture['loss'] = basic_loss.detach().cpu().numpy().copy()
+            self._capture['pred_serial'] = pred_serial.detach().cpu().numpy().copy()
+            self._capture['grads'] = {n: (v.grad.detach().cpu().numpy().copy() if v.grad is not None else None)
+                                      for n, v in self._store.variables.items()}
         self._opt_step += 1
         lr_t = _adam_lr_t(learning_rate, self._opt_step)
         l2 = float(np.float32(np.float32(n_loss) * np.float32(alpha)))

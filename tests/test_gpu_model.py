@@ -85,18 +85,38 @@ def test_fit_steps_match_oracle(user_repr, item_repr, pred, loss, biased, d):
     scale = np.abs(p_ref).max()
     assert np.abs(p_gpu - p_ref).max() <= 1e-4 * scale          # north_star: 1e-4 relative on float scores
 
+    model._capture = {}
     for t in range(steps):
         model.fit_partial(inter, uf, itf, epochs=1, learning_rate=0.05, alpha=1e-4,
                           n_sampled_items=S if tables else None)
+        if t == 0:
+            # first step, identical weights on both sides: loss vector, serial predictions and RAW gradients
+            # (before Adam, without the L2 term) must agree.  Tolerance: 1e-4 of the largest gradient entry of the
+            # model -- some gradients are exactly zero in exact arithmetic (e.g. user biases under WMRB cancel
+            # between positives and samples), so a per-tensor relative bound would compare noise with noise.
+            basic, _, grads, pred_serial = oracle.loss_and_grads(inter, uf, itf, 0.0, tables[0] if tables else None)
+            cap = model._capture
+            assert np.allclose(cap['pred_serial'], pred_serial, rtol=1e-4, atol=1e-4 * np.abs(pred_serial).max())
+            assert np.allclose(cap['loss'], basic, rtol=1e-4, atol=1e-5)
+            gmax = max(np.abs(g).max() for g in grads.values() if g is not None)
+            for k, ref in _rename(grads).items():
+                if ref is None:
+                    continue
+                got_g = cap['grads'][k]
+                assert got_g is not None and got_g.shape == ref.shape, k
+                assert np.abs(got_g - ref).max() <= 1e-4 * gmax, "%s: grad diff %g (gmax %g)" % (
+                    k, np.abs(got_g - ref).max(), gmax)
         oracle.step(inter, uf, itf, 0.05, 1e-4, tables[t] if tables else None)
     got = model.get_weights()
     for k, ref in _rename(oracle.weights).items():
         assert got[k].shape == ref.shape, k
-        # Adam normalises the step to ~lr, so a mismatch anywhere upstream shows up as O(lr) here
-        assert np.allclose(got[k], ref, rtol=2e-3, atol=2e-4), "%s: max abs diff %g" % (k, np.abs(got[k] - ref).max())
+        # Adam turns a gradient into a step of ~lr whatever its size, so zero-in-exact-arithmetic gradients move by
+        # lr * noise/|noise|-like amounts; 10% of one step (0.1 * lr) is the bar after 3 steps, an upstream sign or
+        # scale error would show up as O(lr) = 0.05 per step
+        assert np.allclose(got[k], ref, rtol=2e-3, atol=5e-3), "%s: max abs diff %g" % (k, np.abs(got[k] - ref).max())
     p_gpu = model.predict(uf, itf)
     p_ref = oracle.predict(uf, itf)
-    assert np.abs(p_gpu - p_ref).max() <= 5e-3 * max(1.0, np.abs(p_ref).max())
+    assert np.abs(p_gpu - p_ref).max() <= 2e-2 * max(1.0, np.abs(p_ref).max())
 
 
 def test_predict_and_rank_bit_exact_from_same_weights():
