@@ -22,7 +22,7 @@ __device__ __forceinline__ void adam_elem(float& w, float& m, float& v, float g,
     const float gg = (l2 != 0.f) ? __fadd_rn(g, __fmul_rn(w, l2)) : g;
     m = __fadd_rn(m, __fmul_rn(__fsub_rn(gg, m), omb1));
     v = __fadd_rn(v, __fmul_rn(__fsub_rn(__fmul_rn(gg, gg), v), omb2));
-    w = __fsub_rn(w, __fdiv_rn(__fmul_rn(m, lr_t), __fadd_rn(__fsqrt_rn(v), eps)));
+    w = __fsub_rn(w, __fdiv_rn(__fmul_rn(m, lr_t), __fadd_rn(sqrtf(v), eps)));
 }
 
 __global__ __launch_bounds__(256) void adam_tf_kernel(float* __restrict__ w, float* __restrict__ m, float* __restrict__ v,
