@@ -60,6 +60,8 @@ template <int CH> __device__ __forceinline__ int swz(int row) {
     return 0;
 }
 
+__device__ __forceinline__ bool wave_any(bool x) { return __builtin_amdgcn_ballot_w64(x) != 0ull; }
+
 __device__ __forceinline__ int cd_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }  // 32x32 C/D row of reg r
 
 // sorted-descending insertion; `s` is -inf for lanes that do not qualify (then nothing moves)
@@ -78,7 +80,7 @@ __device__ __forceinline__ void topk_insert(float (&tv)[KTOP], int32_t (&ti)[KTO
     }
 }
 
-template <int DT, int KT, int BN, int NCB, int EPI, bool GLDS, bool EUCLID, int WPS, int KTOP>
+template <int DT, int KT, int BN, int NCB, int EPI, bool GLDS, bool EUCLID, int WPS, int KTOP, bool BIAS>
 __global__ __launch_bounds__(256, WPS) void score_gemm_kernel(ScoreParams p)
 {
     constexpr int ES = ElemOf<DT>::BYTES;
@@ -131,14 +133,14 @@ __global__ __launch_bounds__(256, WPS) void score_gemm_kernel(ScoreParams p)
         for (int cb = 0; cb < NCB; ++cb) {
             int64_t u = r_base + cb * 32 + l31;
             if (u >= p.n_r) u = p.n_r - 1;
-            r_bias_col[cb] = p.r_bias ? p.r_bias[u] : 0.f;
+            r_bias_col[cb] = (BIAS && p.r_bias) ? p.r_bias[u] : 0.f;
             r_sq_col[cb] = EUCLID ? p.r_sqnorm[u] : 0.f;
         }
     } else {
         for (int i = tid; i < RW; i += 256) {
             int64_t u = (int64_t)rblock * RW + i;
             if (u >= p.n_r) u = p.n_r - 1;
-            r_bias_lds[i] = p.r_bias ? p.r_bias[u] : 0.f;
+            r_bias_lds[i] = (BIAS && p.r_bias) ? p.r_bias[u] : 0.f;
             r_sq_lds[i] = EUCLID ? p.r_sqnorm[u] : 0.f;
         }
     }
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(256, WPS) void score_gemm_kernel(ScoreParams p)
             int64_t g = row0 + tid;
             const bool ok = g < p.n_t;
             if (!ok) g = p.n_t - 1;
-            side_b = p.t_bias ? (ok ? p.t_bias[g] : -INFINITY) : 0.f;     // -inf: padded rows never raise the block max
+            side_b = (BIAS && p.t_bias) ? (ok ? p.t_bias[g] : -INFINITY) : 0.f;   // -inf: padded rows never raise the block max
             side_q = EUCLID ? p.t_sqnorm[g] : 0.f;
         }
 #pragma unroll
@@ -248,27 +250,32 @@ __global__ __launch_bounds__(256, WPS) void score_gemm_kernel(ScoreParams p)
             if (EPI == EPI_TOPK) {
                 // rows of acc = items blk_row0 + cd_row(r, half); col = my user.  Two-level filter:
                 //  (1) block bound: (max_r acc + user_bias) + max item bias of the block.  fp32 rounding is monotone,
-                //      so no score of the block can exceed it; if it cannot enter the list the block costs ~11 VALU.
+                //      so no score of the block can exceed it; if it cannot enter the list the block costs ~13 VALU.
                 //  (2) exact scores in the reference's order (acc + ub) + ib only for blocks that pass (1).
+                // All index math is 32-bit and relative to the chunk; the partial-tile mask exists only inside (2).
                 const float* sd = tside + buf * TSIDE;
+                const int blk_in_chunk = t * BN + rb * 32;                   // first item of the block, chunk-relative
+                const int rows_left = (int)(p.n_t - t_begin) - blk_in_chunk; // valid rows from the block start (>= 1)
 #pragma unroll
                 for (int cb = 0; cb < NCB; ++cb) {
-                    bool need = true;
-                    if (!EUCLID && !partial) {
-                        float m = acc[cb][0];
+                    unsigned long long need = ~0ull;       // wave mask of lanes whose block bound beats their threshold
+                    if (!EUCLID) {
+                        float m = fmaxf(fmaxf(acc[cb][0], acc[cb][1]), acc[cb][2]);      // v_max3_f32 chain
 #pragma unroll
-                        for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[cb][r]);
+                        for (int r = 3; r < 15; r += 2) m = fmaxf(fmaxf(m, acc[cb][r]), acc[cb][r + 1]);
+                        m = fmaxf(m, acc[cb][15]);
                         float bound = m;
-                        if (p.r_bias) bound = bound + r_bias_col[cb];
-                        if (p.t_bias) bound = bound + sd[2 * BN + rb];
-                        need = (bound > tv[cb][KTOP - 1]) && (bound >= tau_p[cb]);
+                        if (BIAS) bound = (bound + r_bias_col[cb]) + sd[2 * BN + rb];
+                        need = __builtin_amdgcn_ballot_w64(bound > tv[cb][KTOP - 1]) &
+                               __builtin_amdgcn_ballot_w64(bound >= tau_p[cb]);
                     }
-                    if (__any(need)) {
+                    if (need != 0ull) {
                         f32x16 s;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            const f32x4 tb4 = *(const f32x4*)(sd + rb * 32 + 8 * q + 4 * half);
-                            const f32x4 tq4 = *(const f32x4*)(sd + BN + rb * 32 + 8 * q + 4 * half);
+                            f32x4 tb4, tq4;
+                            if (BIAS) tb4 = *(const f32x4*)(sd + rb * 32 + 8 * q + 4 * half);
+                            if (EUCLID) tq4 = *(const f32x4*)(sd + BN + rb * 32 + 8 * q + 4 * half);
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 const int r = q * 4 + e;
@@ -278,21 +285,26 @@ __global__ __launch_bounds__(256, WPS) void score_gemm_kernel(ScoreParams p)
                                     dist = fmaxf(dist, 1e-16f);
                                     v = -1.0f * sqrtf(dist);
                                 }
-                                if (p.r_bias) v = v + r_bias_col[cb];
-                                if (p.t_bias) v = v + tb4[e];
-                                if (partial && blk_row0 + cd_row(r, half) >= p.n_t) v = -INFINITY;
+                                if (BIAS) v = (v + r_bias_col[cb]) + tb4[e];
                                 s[r] = v;
                             }
                         }
-#pragma unroll 1
+                        if (partial) {      // clamped rows duplicate the last item: mask them (last tile of the last chunk only)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r)
+                                if (cd_row(r, half) >= rows_left) s[r] = -INFINITY;
+                        }
+                        const int32_t id0 = (int32_t)t_begin + blk_in_chunk + p.t_index_base + 4 * half;
+#pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const float v = s[r];
                             // strict against my own list (earlier equal values have lower indices), non-strict against
                             // the partner's threshold (an equal value there may carry a higher index)
                             const bool q = (v > tv[cb][KTOP - 1]) && (v >= tau_p[cb]);
-                            if (__any(q))
-                                topk_insert<KTOP>(tv[cb], ti[cb], q ? v : -INFINITY,
-                                                  (int32_t)(blk_row0 + cd_row(r, half)) + p.t_index_base);
+                            const unsigned long long qm = __builtin_amdgcn_ballot_w64(v > tv[cb][KTOP - 1]) &
+                                                          __builtin_amdgcn_ballot_w64(v >= tau_p[cb]);
+                            if (qm != 0ull)
+                                topk_insert<KTOP>(tv[cb], ti[cb], q ? v : -INFINITY, id0 + (r & 3) + 8 * (r >> 2));
                         }
                         tau_p[cb] = fmaxf(tau_p[cb], __shfl_xor(tv[cb][KTOP - 1], 32, 64));
                     }
@@ -301,7 +313,7 @@ __global__ __launch_bounds__(256, WPS) void score_gemm_kernel(ScoreParams p)
                 const int64_t item = blk_row0 + l31;
                 const bool item_ok = item < p.n_t;
                 const int64_t ic = item_ok ? item : p.n_t - 1;
-                const float tbv = p.t_bias ? p.t_bias[ic] : 0.f;
+                const float tbv = (BIAS && p.t_bias) ? p.t_bias[ic] : 0.f;
                 const float tqv = EUCLID ? p.t_sqnorm[ic] : 0.f;
 #pragma unroll
                 for (int cb = 0; cb < NCB; ++cb)
@@ -320,8 +332,7 @@ __global__ __launch_bounds__(256, WPS) void score_gemm_kernel(ScoreParams p)
                                 dist = fmaxf(dist, 1e-16f);
                                 v = -1.0f * sqrtf(dist);
                             }
-                            if (p.r_bias) v = v + rb4[e];
-                            if (p.t_bias) v = v + tbv;
+                            if (BIAS) v = (v + rb4[e]) + tbv;
                             if (item_ok && u < p.n_r) p.out[u * p.ld_out + item] = v;
                         }
                     }
@@ -428,15 +439,15 @@ __global__ __launch_bounds__(256) void score_prep_kernel(const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------
-template <int DT, int KT, int BN, int NCB, int EPI, bool GLDS, bool EUCLID, int KTOP, int WPS_OVERRIDE = 0>
-static int launch_score(const ScoreParams& p, hipStream_t st)
+template <int DT, int KT, int BN, int NCB, int EPI, bool GLDS, bool EUCLID, int KTOP, bool BIAS, int WPS_OVERRIDE = 0>
+static int launch_score_b(const ScoreParams& p, hipStream_t st)
 {
     constexpr int LDS = 2 * BN * KT * ElemOf<DT>::BYTES +
                         (EPI == EPI_STORE ? 2 * 4 * NCB * 32 * 4 : 2 * (2 * BN + 32) * 4);
     // 2 workgroups per CU (256 registers per lane) unless the resident fragments + top-k lists need more
     constexpr int WPS = WPS_OVERRIDE ? WPS_OVERRIDE
                                      : (((DT == 0 && KT >= 128) || KT == 256 || (EUCLID && KT >= 128)) ? 1 : 2);
-    auto kern = score_gemm_kernel<DT, KT, BN, NCB, EPI, GLDS, EUCLID, WPS, KTOP>;
+    auto kern = score_gemm_kernel<DT, KT, BN, NCB, EPI, GLDS, EUCLID, WPS, KTOP, BIAS>;
     static bool attr_set = false;
     if (!attr_set && LDS > 32 * 1024) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -445,6 +456,14 @@ static int launch_score(const ScoreParams& p, hipStream_t st)
     const unsigned blocks = (unsigned)p.n_rblocks * (unsigned)p.n_chunks;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), LDS, st, p);
     return trec_check_launch("trec_score_gemm");
+}
+
+// a missing bias pointer in a biased launch is treated as zeros (x + 0.0f == x), so one flag covers both sides
+template <int DT, int KT, int BN, int NCB, int EPI, bool GLDS, bool EUCLID, int KTOP, int WPS_OVERRIDE = 0>
+static int launch_score(const ScoreParams& p, hipStream_t st)
+{
+    if (p.r_bias || p.t_bias) return launch_score_b<DT, KT, BN, NCB, EPI, GLDS, EUCLID, KTOP, true, WPS_OVERRIDE>(p, st);
+    return launch_score_b<DT, KT, BN, NCB, EPI, GLDS, EUCLID, KTOP, false, WPS_OVERRIDE>(p, st);
 }
 
 struct ScoreCfg { int bn, ncb; };
@@ -479,14 +498,16 @@ static int dispatch_score(int dtype, int kt, int variant, const ScoreParams& p, 
         if (glds && DT == 1) return launch_score<DT, KTV, BNV, NCBV, EPI, true, false, KTOP>(p, st);  \
         return launch_score<DT, KTV, BNV, NCBV, EPI, false, false, KTOP>(p, st);             \
     }
+    TREC_SCORE_CASE(1, 128, 64, 2)
+    TREC_SCORE_CASE(0, 128, 32, 1)
+#ifndef TREC_SCORE_MINIMAL      // -DTREC_SCORE_MINIMAL: only K = 128 (fast rebuilds while tuning)
     TREC_SCORE_CASE(1, 32, 64, 2)
     TREC_SCORE_CASE(1, 64, 64, 2)
-    TREC_SCORE_CASE(1, 128, 64, 2)
     TREC_SCORE_CASE(1, 256, 64, 1)
     TREC_SCORE_CASE(0, 32, 32, 1)
     TREC_SCORE_CASE(0, 64, 32, 1)
-    TREC_SCORE_CASE(0, 128, 32, 1)
     TREC_SCORE_CASE(0, 256, 32, 1)
+#endif
 #undef TREC_SCORE_CASE
     trec_set_last_error("trec_score_gemm: unsupported (dtype, kpad)");
     return TREC_ERR_UNSUPPORTED;
@@ -517,6 +538,7 @@ static int fill_common(ScoreParams& p, const void* users, const void* items, int
     TREC_REQUIRE(mode == 0 || mode == 1, "trec_score_gemm: mode must be 0 (dot) or 1 (euclidean)");
     TREC_REQUIRE(mode == 0 || (user_sqnorm && item_sqnorm), "trec_score_gemm: euclidean mode needs squared norms");
     TREC_REQUIRE(n_chunks >= 1, "trec_score_gemm: n_chunks must be >= 1");
+    TREC_REQUIRE(n_items < (int64_t)1 << 31 && n_users < (int64_t)1 << 31, "trec_score_gemm: sizes must fit int32");
     const ScoreCfg c = score_cfg_variant(dtype, kpad, variant);
     p.R = users; p.T = items; p.n_r = n_users; p.n_t = n_items;
     p.n_rblocks = (int)ceil_div64(n_users, 4 * c.ncb * 32);
