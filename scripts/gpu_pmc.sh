@@ -13,7 +13,7 @@ SETS[s1]="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SAL
 SETS[s2]="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
 SETS[s3]="FETCH_SIZE GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_INSTS_SMEM"
 SETS[s4]="WRITE_SIZE TCC_HIT TCC_MISS SQ_LDS_UNALIGNED_STALL SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU"
-for s in s1 s2 s3 s4; do
+for s in ${PMC_SETS:-s1 s2 s3 s4}; do
   ( cd /tmp && timeout 600 rocprofv3 --pmc ${SETS[$s]} --kernel-trace --output-format csv -d $OUT/$s -o pmc -- python $REPO/bench.py $ARGS > $OUT/$s.json 2> $OUT/$s.err )
   echo "$s rc=$?"
 done

@@ -62,6 +62,15 @@ template <int CH> __device__ __forceinline__ int swz(int row) {
 
 __device__ __forceinline__ bool wave_any(bool x) { return __builtin_amdgcn_ballot_w64(x) != 0ull; }
 
+// largest float strictly below x (x finite or -inf, never NaN): v >= x  <=>  v > float_pred(x)
+__device__ __forceinline__ float float_pred(float x)
+{
+    const unsigned int u = __float_as_uint(x);
+    if (x == -INFINITY) return x;
+    if ((u << 1) == 0u) return __uint_as_float(0x80000001u);
+    return __uint_as_float(x > 0.f ? u - 1u : u + 1u);
+}
+
 __device__ __forceinline__ int cd_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }  // 32x32 C/D row of reg r
 
 // sorted-descending insertion; `s` is -inf for lanes that do not qualify (then nothing moves)
@@ -147,11 +156,15 @@ __global__ __launch_bounds__(256, WPS) void score_gemm_kernel(ScoreParams p)
 
     float tv[(EPI == EPI_TOPK) ? NCB : 1][KTOP];
     int32_t ti[(EPI == EPI_TOPK) ? NCB : 1][KTOP];
-    float tau_p[NCB];          // KTOP-th best of the OTHER half-wave's list for the same user (a valid lower bound)
+    // One threshold per list: a score can only matter if it is  > my own KTOP-th best (strict: earlier equal values in
+    // this lane have lower indices)  AND  >= the KTOP-th best of the OTHER half-wave's list for the same user (a
+    // valid lower bound of the final KTOP-th best; non-strict because an equal value there may carry a higher index).
+    // Both tests fold into  v > thr  with thr = max(own, float_pred(partner)).
+    float thr[NCB], tau_pp[NCB];
     if (EPI == EPI_TOPK) {
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
-            tau_p[cb] = -INFINITY;
+            thr[cb] = -INFINITY; tau_pp[cb] = -INFINITY;
 #pragma unroll
             for (int j = 0; j < KTOP; ++j) { tv[cb][j] = -INFINITY; ti[cb][j] = -1; }
         }
@@ -258,35 +271,37 @@ __global__ __launch_bounds__(256, WPS) void score_gemm_kernel(ScoreParams p)
                 const int rows_left = (int)(p.n_t - t_begin) - blk_in_chunk; // valid rows from the block start (>= 1)
 #pragma unroll
                 for (int cb = 0; cb < NCB; ++cb) {
-                    unsigned long long need = ~0ull;       // wave mask of lanes whose block bound beats their threshold
-                    if (!EUCLID) {
-                        float m = fmaxf(fmaxf(acc[cb][0], acc[cb][1]), acc[cb][2]);      // v_max3_f32 chain
+                    // ---- common path: one v_max3 chain per 4-row group, one compare ----
+                    float gm[4];
 #pragma unroll
-                        for (int r = 3; r < 15; r += 2) m = fmaxf(fmaxf(m, acc[cb][r]), acc[cb][r + 1]);
-                        m = fmaxf(m, acc[cb][15]);
-                        float bound = m;
+                    for (int q = 0; q < 4; ++q)
+                        gm[q] = fmaxf(fmaxf(fmaxf(acc[cb][4 * q], acc[cb][4 * q + 1]), acc[cb][4 * q + 2]), acc[cb][4 * q + 3]);
+                    unsigned long long need = ~0ull;
+                    if (!EUCLID) {
+                        float bound = fmaxf(fmaxf(fmaxf(gm[0], gm[1]), gm[2]), gm[3]);
                         if (BIAS) bound = (bound + r_bias_col[cb]) + sd[2 * BN + rb];
-                        need = __builtin_amdgcn_ballot_w64(bound > tv[cb][KTOP - 1]) &
-                               __builtin_amdgcn_ballot_w64(bound >= tau_p[cb]);
+                        need = __builtin_amdgcn_ballot_w64(bound > thr[cb]);
                     }
                     if (need != 0ull) {
-                        f32x16 s;
+                        // ---- rare path: exact scores, then only the 4-row groups (and elements) that can matter ----
+                        f32x16 s = acc[cb];
+                        if (BIAS || EUCLID) {
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            f32x4 tb4, tq4;
-                            if (BIAS) tb4 = *(const f32x4*)(sd + rb * 32 + 8 * q + 4 * half);
-                            if (EUCLID) tq4 = *(const f32x4*)(sd + BN + rb * 32 + 8 * q + 4 * half);
+                            for (int q = 0; q < 4; ++q) {
+                                f32x4 tb4, tq4;
+                                if (BIAS) tb4 = *(const f32x4*)(sd + rb * 32 + 8 * q + 4 * half);
+                                if (EUCLID) tq4 = *(const f32x4*)(sd + BN + rb * 32 + 8 * q + 4 * half);
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const int r = q * 4 + e;
-                                float v = acc[cb][r];
-                                if (EUCLID) {
-                                    float dist = (r_sq_col[cb] - 2.0f * v) + tq4[e];
-                                    dist = fmaxf(dist, 1e-16f);
-                                    v = -1.0f * sqrtf(dist);
+                                for (int e = 0; e < 4; ++e) {
+                                    float v = s[4 * q + e];
+                                    if (EUCLID) {
+                                        float dist = (r_sq_col[cb] - 2.0f * v) + tq4[e];
+                                        dist = fmaxf(dist, 1e-16f);
+                                        v = -1.0f * sqrtf(dist);
+                                    }
+                                    if (BIAS) v = (v + r_bias_col[cb]) + tb4[e];
+                                    s[4 * q + e] = v;
                                 }
-                                if (BIAS) v = (v + r_bias_col[cb]) + tb4[e];
-                                s[r] = v;
                             }
                         }
                         if (partial) {      // clamped rows duplicate the last item: mask them (last tile of the last chunk only)
@@ -296,17 +311,22 @@ __global__ __launch_bounds__(256, WPS) void score_gemm_kernel(ScoreParams p)
                         }
                         const int32_t id0 = (int32_t)t_begin + blk_in_chunk + p.t_index_base + 4 * half;
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const float v = s[r];
-                            // strict against my own list (earlier equal values have lower indices), non-strict against
-                            // the partner's threshold (an equal value there may carry a higher index)
-                            const bool q = (v > tv[cb][KTOP - 1]) && (v >= tau_p[cb]);
-                            const unsigned long long qm = __builtin_amdgcn_ballot_w64(v > tv[cb][KTOP - 1]) &
-                                                          __builtin_amdgcn_ballot_w64(v >= tau_p[cb]);
-                            if (qm != 0ull)
-                                topk_insert<KTOP>(tv[cb], ti[cb], q ? v : -INFINITY, id0 + (r & 3) + 8 * (r >> 2));
+                        for (int q = 0; q < 4; ++q) {
+                            const float g = fmaxf(fmaxf(fmaxf(s[4 * q], s[4 * q + 1]), s[4 * q + 2]), s[4 * q + 3]);
+                            if (__builtin_amdgcn_ballot_w64(g > thr[cb]) != 0ull) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    const float v = s[4 * q + e];
+                                    const bool hit = v > thr[cb];
+                                    if (__builtin_amdgcn_ballot_w64(hit) != 0ull) {
+                                        topk_insert<KTOP>(tv[cb], ti[cb], hit ? v : -INFINITY, id0 + 8 * q + e);
+                                        thr[cb] = fmaxf(tv[cb][KTOP - 1], tau_pp[cb]);
+                                    }
+                                }
+                            }
                         }
-                        tau_p[cb] = fmaxf(tau_p[cb], __shfl_xor(tv[cb][KTOP - 1], 32, 64));
+                        tau_pp[cb] = fmaxf(tau_pp[cb], float_pred(__shfl_xor(tv[cb][KTOP - 1], 32, 64)));
+                        thr[cb] = fmaxf(tv[cb][KTOP - 1], tau_pp[cb]);
                     }
                 }
             } else {
