@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--variant", type=int, default=int(os.environ.get("TREC_SCORE_VARIANT", "1")))
+    ap.add_argument("--chunks", type=int, default=0, help="item chunks per user block (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-users", type=int, default=1024)
     return ap.parse_args()
@@ -125,7 +126,7 @@ def main():
     f_u = SparseFeatures(sp.identity(U, dtype=np.float32, format="csr"), device)
     f_i = SparseFeatures(sp.identity(n_local, dtype=np.float32, format="csr"), device)   # this rank's item rows
     kpad = ops.score_kpad(d)
-    n_chunks = ops.topk_chunks_for(U, dtype, kpad, n_local)
+    n_chunks = args.chunks if args.chunks > 0 else ops.topk_chunks_for(U, dtype, kpad, n_local)
     cap = T._native.query("trec_score_topk_capacity", k)
     n_parts = T._native.query("trec_score_topk_parts", dtype, kpad, n_local, n_chunks)
     ws = (torch.empty((U, n_parts, cap), dtype=torch.float32, device=device),

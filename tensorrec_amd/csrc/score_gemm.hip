@@ -60,6 +60,24 @@ template <int CH> __device__ __forceinline__ int swz(int row) {
     return 0;
 }
 
+// ablation helpers: keep a value live without using it (device pass only: "v"/"s" are AMDGPU register constraints)
+__device__ __forceinline__ void keep_alive(const f32x16& x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" ::"v"(x));
+#else
+    (void)x;
+#endif
+}
+__device__ __forceinline__ void keep_alive_mask(unsigned long long x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" ::"s"(x));
+#else
+    (void)x;
+#endif
+}
+
 __device__ __forceinline__ bool wave_any(bool x) { return __builtin_amdgcn_ballot_w64(x) != 0ull; }
 
 // largest float strictly below x (x finite or -inf, never NaN): v >= x  <=>  v > float_pred(x)
@@ -89,7 +107,9 @@ __device__ __forceinline__ void topk_insert(float (&tv)[KTOP], int32_t (&ti)[KTO
     }
 }
 
-template <int DT, int KT, int BN, int NCB, int EPI, bool GLDS, bool EUCLID, int WPS, int KTOP, bool BIAS>
+// ABL (ablation, tuning builds only): 0 = full kernel, 1 = no epilogue at all (MFMA + staging ceiling),
+// 2 = common path only (block bound evaluated, rare path never taken)
+template <int DT, int KT, int BN, int NCB, int EPI, bool GLDS, bool EUCLID, int WPS, int KTOP, bool BIAS, int ABL = 0>
 __global__ __launch_bounds__(256, WPS) void score_gemm_kernel(ScoreParams p)
 {
     constexpr int ES = ElemOf<DT>::BYTES;
@@ -98,6 +118,7 @@ __global__ __launch_bounds__(256, WPS) void score_gemm_kernel(ScoreParams p)
     constexpr int KS = (DT == 1) ? KT / 16 : KT / 2;   // MFMA k-steps
     constexpr int TILE_BYTES = BN * RB;
     constexpr int NSLOT = BN * CH / 256;     // 16-byte staging slots per thread per tile
+    constexpr bool PRIO = (ABL & 4) != 0;    // tuning: raise wave priority while issuing the MFMA block
     static_assert(BN * CH % 256 == 0 && NSLOT >= 1, "tile too small for 256 threads");
     static_assert(BN % 32 == 0, "BN must be a multiple of the 32-row MFMA block");
 
@@ -174,8 +195,20 @@ __global__ __launch_bounds__(256, WPS) void score_gemm_kernel(ScoreParams p)
     // ---- staging of the streamed tile: slot q = i*256 + tid  ->  (row, physical chunk) ----
     u32x4 stage[GLDS ? 1 : NSLOT];
     float side_b = 0.f, side_q = 0.f;
+    // per-thread source offsets of the NSLOT staging slots inside a tile (bytes, relative to the tile's first row):
+    // computed once; a tile advances every slot by BN rows.  Only the last tile of the last chunk needs clamping.
+    int slot_row[NSLOT], slot_off[NSLOT];
+#pragma unroll
+    for (int i = 0; i < NSLOT; ++i) {
+        const int q = i * 256 + tid;
+        const int row = q / CH, pc = q % CH;
+        slot_row[i] = row;
+        slot_off[i] = row * RB + ((pc ^ swz<CH>(row)) * 16);
+    }
+    const char* t_chunk = (const char*)p.T + t_begin * (int64_t)RB;
     auto stage_issue = [&](int tile, int buf) {
         const int64_t row0 = t_begin + (int64_t)tile * BN;
+        const bool clamp = row0 + BN > p.n_t;                 // wave-uniform
         if (EPI == EPI_TOPK && tid < BN) {
             int64_t g = row0 + tid;
             const bool ok = g < p.n_t;
@@ -183,14 +216,15 @@ __global__ __launch_bounds__(256, WPS) void score_gemm_kernel(ScoreParams p)
             side_b = (BIAS && p.t_bias) ? (ok ? p.t_bias[g] : -INFINITY) : 0.f;   // -inf: padded rows never raise the block max
             side_q = EUCLID ? p.t_sqnorm[g] : 0.f;
         }
+        const char* tile_base = t_chunk + (int64_t)tile * (BN * RB);     // scalar
 #pragma unroll
         for (int i = 0; i < NSLOT; ++i) {
-            const int q = i * 256 + tid;
-            const int row = q / CH, pc = q % CH;
-            const int kc = pc ^ swz<CH>(row);
-            int64_t grow = row0 + row;
-            if (grow >= p.n_t) grow = p.n_t - 1;
-            const char* src = (const char*)p.T + grow * (int64_t)RB + kc * 16;
+            int off = slot_off[i];
+            if (clamp) {
+                const int last = (int)(p.n_t - 1 - row0);                   // last valid row of this tile
+                if (slot_row[i] > last) off -= (slot_row[i] - last) * RB;    // re-read the last valid row
+            }
+            const char* src = tile_base + off;
             if (GLDS) {
                 char* dst = smem + buf * TILE_BYTES + (i * 256 + wave * 64) * 16;   // wave-uniform; lane*16 is implicit
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -239,6 +273,7 @@ __global__ __launch_bounds__(256, WPS) void score_gemm_kernel(ScoreParams p)
             const int lrow = rb * 32 + l31;
             const char* rowp = tile + lrow * RB;
             const int sw = swz<CH>(lrow);
+            if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 if (DT == 1) {
@@ -259,8 +294,12 @@ __global__ __launch_bounds__(256, WPS) void score_gemm_kernel(ScoreParams p)
                 }
             }
 
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
             const int64_t blk_row0 = tile_row0 + rb * 32;     // first streamed row (item) of this 32-block
-            if (EPI == EPI_TOPK) {
+            if (EPI == EPI_TOPK && (ABL & 3) == 1) {
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) keep_alive(acc[cb]);
+            } else if (EPI == EPI_TOPK) {
                 // rows of acc = items blk_row0 + cd_row(r, half); col = my user.  Two-level filter:
                 //  (1) block bound: (max_r acc + user_bias) + max item bias of the block.  fp32 rounding is monotone,
                 //      so no score of the block can exceed it; if it cannot enter the list the block costs ~13 VALU.
@@ -282,6 +321,7 @@ __global__ __launch_bounds__(256, WPS) void score_gemm_kernel(ScoreParams p)
                         if (BIAS) bound = (bound + r_bias_col[cb]) + sd[2 * BN + rb];
                         need = __builtin_amdgcn_ballot_w64(bound > thr[cb]);
                     }
+                    if ((ABL & 3) == 2) { keep_alive_mask(need); need = 0ull; }
                     if (need != 0ull) {
                         // ---- rare path: exact scores, then only the 4-row groups (and elements) that can matter ----
                         f32x16 s = acc[cb];
@@ -459,7 +499,7 @@ __global__ __launch_bounds__(256) void score_prep_kernel(const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------
-template <int DT, int KT, int BN, int NCB, int EPI, bool GLDS, bool EUCLID, int KTOP, bool BIAS, int WPS_OVERRIDE = 0>
+template <int DT, int KT, int BN, int NCB, int EPI, bool GLDS, bool EUCLID, int KTOP, bool BIAS, int WPS_OVERRIDE = 0, int ABL = 0>
 static int launch_score_b(const ScoreParams& p, hipStream_t st)
 {
     constexpr int LDS = 2 * BN * KT * ElemOf<DT>::BYTES +
@@ -467,7 +507,7 @@ static int launch_score_b(const ScoreParams& p, hipStream_t st)
     // 2 workgroups per CU (256 registers per lane) unless the resident fragments + top-k lists need more
     constexpr int WPS = WPS_OVERRIDE ? WPS_OVERRIDE
                                      : (((DT == 0 && KT >= 128) || KT == 256 || (EUCLID && KT >= 128)) ? 1 : 2);
-    auto kern = score_gemm_kernel<DT, KT, BN, NCB, EPI, GLDS, EUCLID, WPS, KTOP, BIAS>;
+    auto kern = score_gemm_kernel<DT, KT, BN, NCB, EPI, GLDS, EUCLID, WPS, KTOP, BIAS, ABL>;
     static bool attr_set = false;
     if (!attr_set && LDS > 32 * 1024) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -538,8 +578,8 @@ static ScoreCfg score_cfg_variant(int dtype, int kt, int variant)
 {
     if (dtype == 1 && kt == 128) {
         switch (variant >> 1) {
-            case 1: return ScoreCfg{128, 4};     // 1 workgroup / CU, 128 users per wave, 512 registers
-            case 2: return ScoreCfg{128, 2};     // 1 workgroup / CU, 64 users per wave
+            case 1: return ScoreCfg{128, 2};     // default tiling with 128-row item tiles (half the barriers)
+            case 2: return ScoreCfg{128, 2};     // 1 workgroup / CU (512 registers), 64 users per wave
             case 3: return ScoreCfg{64, 1};      // 3 workgroups / CU, 32 users per wave
             default: break;
         }
@@ -612,7 +652,7 @@ extern "C" int trec_score_gemm_topk(const void* users, const void* items, int32_
     TREC_REQUIRE(part_vals && part_idx, "trec_score_gemm_topk: null workspace");
     TREC_REQUIRE(capacity == 8 || capacity == 12 || capacity == 16, "trec_score_gemm_topk: capacity must be 8, 12 or 16");
     const bool experimental = dtype == 1 && kpad == 128 && capacity == 12 && mode == 0 && (variant >> 1) != 0 &&
-                              (variant >> 1) <= 3;
+                              (variant >> 1) <= 6;
     int rc = fill_common(p, users, items, dtype, kpad, n_users, n_items, user_bias, item_bias, mode, user_sqnorm,
                          item_sqnorm, n_chunks, experimental ? variant : 0);
     if (rc) return rc;
@@ -621,12 +661,15 @@ extern "C" int trec_score_gemm_topk(const void* users, const void* items, int32_
         hipStream_t st = (hipStream_t)stream;
         const bool glds = variant & 1;
         switch (variant >> 1) {
-            case 1: return glds ? launch_score<1, 128, 128, 4, EPI_TOPK, true, false, 12, 1>(p, st)
-                                : launch_score<1, 128, 128, 4, EPI_TOPK, false, false, 12, 1>(p, st);
+            case 1: return glds ? launch_score<1, 128, 128, 2, EPI_TOPK, true, false, 12, 2>(p, st)
+                                : launch_score<1, 128, 128, 2, EPI_TOPK, false, false, 12, 2>(p, st);
             case 2: return glds ? launch_score<1, 128, 128, 2, EPI_TOPK, true, false, 12, 1>(p, st)
                                 : launch_score<1, 128, 128, 2, EPI_TOPK, false, false, 12, 1>(p, st);
-            default: return glds ? launch_score<1, 128, 64, 1, EPI_TOPK, true, false, 12, 3>(p, st)
-                                 : launch_score<1, 128, 64, 1, EPI_TOPK, false, false, 12, 3>(p, st);
+            case 3: return glds ? launch_score<1, 128, 64, 1, EPI_TOPK, true, false, 12, 3>(p, st)
+                                : launch_score<1, 128, 64, 1, EPI_TOPK, false, false, 12, 3>(p, st);
+            case 4: return launch_score_b<1, 128, 64, 2, EPI_TOPK, true, false, 12, true, 2, 1>(p, st);   // ablation
+            case 5: return launch_score_b<1, 128, 64, 2, EPI_TOPK, true, false, 12, true, 2, 2>(p, st);   // ablation
+            default: return launch_score_b<1, 128, 64, 2, EPI_TOPK, true, false, 12, true, 2, 4>(p, st);  // full + setprio
         }
     }
     if (capacity == 8) return dispatch_score<EPI_TOPK, 8>(dtype, kpad, variant, p, (hipStream_t)stream);
