@@ -36,6 +36,9 @@ extern "C" {
 int trec_abi_version(void);
 const char* trec_last_error(void);
 int trec_device_cu_count(void);
+/* benchmark-only switches between kernel variants (e.g. "spmm_rows", "spmm_nt"); never needed for correctness */
+int trec_set_tuning(const char* name, int32_t value);
+int trec_get_tuning(const char* name, int dflt);
 
 /* ---- K1: sparse features x dense weights ------------------------------------------------------------------
  * tf.sparse_tensor_dense_matmul: representation_graphs.py:40 (Linear), :119 (ReLU layer 1),

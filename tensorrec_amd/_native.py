@@ -22,6 +22,8 @@ _vp, _i32, _i64, _u32, _u64, _f = (ctypes.c_void_p, ctypes.c_int32, ctypes.c_int
 SIGNATURES = {
     "trec_abi_version": [],
     "trec_device_cu_count": [],
+    "trec_set_tuning": [ctypes.c_char_p, _i32],
+    "trec_get_tuning": [ctypes.c_char_p, ctypes.c_int],
     "trec_spmm_csr": [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp],
     "trec_spmv_csr": [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp],
     "trec_csr_to_dense": [_vp, _vp, _vp, _i64, _i32, _vp, _vp],
@@ -112,6 +114,10 @@ def call(name, *args):
     rc = getattr(lib, name)(*args, stream())
     if rc != 0:
         raise RuntimeError("%s failed (code %d): %s" % (name, rc, lib.trec_last_error().decode()))
+
+
+def set_tuning(name, value):
+    load().trec_set_tuning(name.encode(), int(value))
 
 
 def query(name, *args):

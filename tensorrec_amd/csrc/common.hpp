@@ -13,6 +13,8 @@
 #define TREC_ERR_UNSUPPORTED 3
 
 extern "C" void trec_set_last_error(const char* msg);
+// tuning knobs (benchmark-only switches between kernel variants); unknown names read as `dflt`
+extern "C" int trec_get_tuning(const char* name, int dflt);
 
 static inline int trec_check_launch(const char* what) {
     hipError_t e = hipGetLastError();

@@ -22,3 +22,21 @@ extern "C" int trec_device_cu_count(void)
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -1;
     return n;
 }
+
+// ---- tuning knobs: name -> int, set from the host side (bench / tests) to A/B kernel variants in one process ----
+#include <map>
+#include <string>
+static std::map<std::string, int>& tuning_map() { static std::map<std::string, int> m; return m; }
+
+extern "C" int trec_set_tuning(const char* name, int32_t value)
+{
+    if (!name) return TREC_ERR_INVALID;
+    tuning_map()[name] = value;
+    return TREC_OK;
+}
+
+extern "C" int trec_get_tuning(const char* name, int dflt)
+{
+    auto it = tuning_map().find(name ? name : "");
+    return it == tuning_map().end() ? dflt : it->second;
+}

@@ -24,7 +24,7 @@ __device__ __forceinline__ float subgroup_sum(float v, int lpr) {
 }
 
 // EPI: 0 none | 1 row L2-normalise (writes inv norm) | 2 + col_bias, ReLU
-template <int ITERS, int R, int EPI>
+template <int ITERS, int R, int EPI, bool NT = false>
 __global__ __launch_bounds__(256) void spmm_csr_vec4_kernel(
     const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, const float* __restrict__ values,
     const int32_t* __restrict__ val_perm, int64_t n_rows, const float* __restrict__ W, int d, int lpr_log2,
@@ -157,7 +157,11 @@ __global__ __launch_bounds__(256) void spmm_csr_vec4_kernel(
         }
 #pragma unroll
         for (int it = 0; it < ITERS; ++it)
-            if (cvalid[it]) *(f32x4*)(out + row * (int64_t)d + col[it]) = acc[r][it];
+            if (cvalid[it]) {
+                f32x4* dst = (f32x4*)(out + row * (int64_t)d + col[it]);
+                if (NT) __builtin_nontemporal_store(acc[r][it], dst);      // written once, not re-read by this kernel
+                else *dst = acc[r][it];
+            }
     }
 }
 
@@ -289,14 +293,22 @@ static int launch_vec4(const int64_t* indptr, const int32_t* indices, const floa
     const int iters = (n4 + lpr - 1) / lpr;
     // R = 4 rows per subgroup when rows are short (embedding-style gathers), else 1
     const bool short_rows = nnz_hint >= 0 && nnz_hint <= 4 * n_rows && n_rows >= 4096;
-    const int R = short_rows ? 4 : 1;
+    int R = short_rows ? 4 : 1;
+    const int tune_r = trec_get_tuning("spmm_rows", 0), tune_nt = trec_get_tuning("spmm_nt", 0);
+    if (short_rows && tune_r == 8) R = 8;
+    if (R == 8 && iters != 1) R = 4;
     const int64_t subgroups = ceil_div64(n_rows, R);
     const int64_t threads = subgroups * lpr;
     const unsigned blocks = (unsigned)ceil_div64(threads, 256);
 #define TREC_SPMM_LAUNCH(IT, RR)                                                                                   \
     hipLaunchKernelGGL((spmm_csr_vec4_kernel<IT, RR, EPI>), dim3(blocks), dim3(256), 0, st, indptr, indices, values, \
                        val_perm, n_rows, W, d, lpr_log2, col_bias, accumulate, out, out_inv)
-    if (R == 4) {
+    if (R == 8 && iters == 1) {
+        if (tune_nt) hipLaunchKernelGGL((spmm_csr_vec4_kernel<1, 8, EPI, true>), dim3(blocks), dim3(256), 0, st, indptr, indices, values, val_perm, n_rows, W, d, lpr_log2, col_bias, accumulate, out, out_inv);
+        else TREC_SPMM_LAUNCH(1, 8);
+    } else if (R == 4 && iters == 1 && tune_nt) {
+        hipLaunchKernelGGL((spmm_csr_vec4_kernel<1, 4, EPI, true>), dim3(blocks), dim3(256), 0, st, indptr, indices, values, val_perm, n_rows, W, d, lpr_log2, col_bias, accumulate, out, out_inv);
+    } else if (R >= 4) {
         if (iters == 1) TREC_SPMM_LAUNCH(1, 4);
         else if (iters == 2) TREC_SPMM_LAUNCH(2, 4);
         else TREC_SPMM_LAUNCH(4, 4);
