@@ -24,7 +24,9 @@ __device__ __forceinline__ float subgroup_sum(float v, int lpr) {
 }
 
 // EPI: 0 none | 1 row L2-normalise (writes inv norm) | 2 + col_bias, ReLU
-template <int ITERS, int R, int EPI, bool NT = false>
+// NT: non-temporal output stores (rows are written once); NTL: non-temporal weight-row loads as well (embedding-style
+// gathers where every weight row is referenced about once, so caching it only evicts useful lines)
+template <int ITERS, int R, int EPI, bool NT = false, bool NTL = false>
 __global__ __launch_bounds__(256) void spmm_csr_vec4_kernel(
     const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, const float* __restrict__ values,
     const int32_t* __restrict__ val_perm, int64_t n_rows, const float* __restrict__ W, int d, int lpr_log2,
@@ -75,7 +77,10 @@ __global__ __launch_bounds__(256) void spmm_csr_vec4_kernel(
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
             x0[r][it] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (s[r] < e[r] && cvalid[it]) x0[r][it] = *(const f32x4*)(W + (int64_t)c0[r] * d + col[it]);
+            if (s[r] < e[r] && cvalid[it]) {
+                const f32x4* src = (const f32x4*)(W + (int64_t)c0[r] * d + col[it]);
+                x0[r][it] = NTL ? __builtin_nontemporal_load(src) : *src;
+            }
         }
 #pragma unroll
     for (int r = 0; r < R; ++r)
@@ -294,20 +299,17 @@ static int launch_vec4(const int64_t* indptr, const int32_t* indices, const floa
     // R = 4 rows per subgroup when rows are short (embedding-style gathers), else 1
     const bool short_rows = nnz_hint >= 0 && nnz_hint <= 4 * n_rows && n_rows >= 4096;
     int R = short_rows ? 4 : 1;
-    const int tune_r = trec_get_tuning("spmm_rows", 0), tune_nt = trec_get_tuning("spmm_nt", 0);
-    if (short_rows && tune_r == 8) R = 8;
-    if (R == 8 && iters != 1) R = 4;
+    // defaults measured on MI355X (scripts/bench_k1.py): non-temporal stores +7% on 1M x 128 gathers
+    const int tune_nt = trec_get_tuning("spmm_nt", 1), tune_ntl = trec_get_tuning("spmm_ntload", 0);
     const int64_t subgroups = ceil_div64(n_rows, R);
     const int64_t threads = subgroups * lpr;
     const unsigned blocks = (unsigned)ceil_div64(threads, 256);
 #define TREC_SPMM_LAUNCH(IT, RR)                                                                                   \
     hipLaunchKernelGGL((spmm_csr_vec4_kernel<IT, RR, EPI>), dim3(blocks), dim3(256), 0, st, indptr, indices, values, \
                        val_perm, n_rows, W, d, lpr_log2, col_bias, accumulate, out, out_inv)
-    if (R == 8 && iters == 1) {
-        if (tune_nt) hipLaunchKernelGGL((spmm_csr_vec4_kernel<1, 8, EPI, true>), dim3(blocks), dim3(256), 0, st, indptr, indices, values, val_perm, n_rows, W, d, lpr_log2, col_bias, accumulate, out, out_inv);
-        else TREC_SPMM_LAUNCH(1, 8);
-    } else if (R == 4 && iters == 1 && tune_nt) {
-        hipLaunchKernelGGL((spmm_csr_vec4_kernel<1, 4, EPI, true>), dim3(blocks), dim3(256), 0, st, indptr, indices, values, val_perm, n_rows, W, d, lpr_log2, col_bias, accumulate, out, out_inv);
+    if (R == 4 && iters == 1 && tune_nt && !accumulate) {
+        if (tune_ntl) hipLaunchKernelGGL((spmm_csr_vec4_kernel<1, 4, EPI, true, true>), dim3(blocks), dim3(256), 0, st, indptr, indices, values, val_perm, n_rows, W, d, lpr_log2, col_bias, accumulate, out, out_inv);
+        else hipLaunchKernelGGL((spmm_csr_vec4_kernel<1, 4, EPI, true, false>), dim3(blocks), dim3(256), 0, st, indptr, indices, values, val_perm, n_rows, W, d, lpr_log2, col_bias, accumulate, out, out_inv);
     } else if (R >= 4) {
         if (iters == 1) TREC_SPMM_LAUNCH(1, 4);
         else if (iters == 2) TREC_SPMM_LAUNCH(2, 4);
