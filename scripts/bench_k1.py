@@ -36,5 +36,5 @@ case("permutation 1M x 1M, d=128", SparseFeatures(sp.csr_matrix((np.ones(n, np.f
 case("identity 1M, d=64", SparseFeatures(sp.identity(n, dtype=np.float32, format="csr"), "cuda"), 64, res)
 m = sp.random(138493, 27892, density=20 / 27892, random_state=0, dtype=np.float32, format="csr")
 case("ML-20M-like users 138k x 27.9k feats, ~20 nnz/row, d=256", SparseFeatures(m, "cuda"), 256, res)
-N.set_tuning("spmm_ntload", 0); N.set_tuning("spmm_nt", 1)
+N.set_tuning("spmm_ntload", -1); N.set_tuning("spmm_nt", 1)
 json.dump(res, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "bench_k1.json"), "w"), indent=1)
