@@ -218,39 +218,90 @@ def _idx32(x):
 
 
 class _PairScore(torch.autograd.Function):
+    """Forward: K3.  Backward for dot products:
+      * user side -- pairs are user-major (CSR over users: interactions, or S consecutive samples per user), so
+        dU = G . V is the K1 gather kernel with the pair gradients as values: deterministic, no atomics;
+      * item side -- for interactions the transposed structure makes dV = G^T . U the same kernel; for sampled pairs
+        (random items, no structure) fp32 atomics (K3 bwd) remain.
+    Euclidean pairs and unstructured index tensors use the atomic kernel for both sides."""
+
     @staticmethod
-    def forward(ctx, u, v, ub, ib, xu32, xi32, pairs_per_user, mode):
+    def forward(ctx, u, v, ub, ib, xu32, xi32, pairs_per_user, mode, inter):
         u, v = _f32c(u), _f32c(v)
         n_pairs = xi32.numel()
         out = torch.empty((n_pairs,), dtype=torch.float32, device=u.device)
         N.call("trec_pair_score_fwd", N.ptr(u), N.ptr(v), N.ptr(xu32), N.ptr(xi32), n_pairs, pairs_per_user, u.shape[1],
                mode, N.ptr(ub), N.ptr(ib), N.ptr(out))
         ctx.save_for_backward(u, v)
-        ctx.meta = (xu32, xi32, pairs_per_user, mode, ub is not None, ib is not None)
+        ctx.meta = (xu32, xi32, pairs_per_user, mode, ub is not None, ib is not None, inter)
         return out
 
     @staticmethod
     def backward(ctx, g):
         u, v = ctx.saved_tensors
-        xu32, xi32, ppu, mode, has_ub, has_ib = ctx.meta
+        xu32, xi32, ppu, mode, has_ub, has_ib, inter = ctx.meta
         g = _f32c(g)
-        du, dv = torch.zeros_like(u), torch.zeros_like(v)
-        dub = torch.zeros((u.shape[0],), dtype=torch.float32, device=u.device) if has_ub else None
-        dib = torch.zeros((v.shape[0],), dtype=torch.float32, device=u.device) if has_ib else None
-        N.call("trec_pair_score_bwd", N.ptr(u), N.ptr(v), N.ptr(xu32), N.ptr(xi32), N.ptr(g), xi32.numel(), ppu,
-               u.shape[1], mode, N.ptr(du), N.ptr(dv), N.ptr(dub), N.ptr(dib))
-        return du, dv, dub, dib, None, None, None, None
+        n_pairs = xi32.numel()
+        n_users, n_items, dev = u.shape[0], v.shape[0], u.device
+        structured = mode == MODE_DOT and (ppu > 0 or inter is not None)
+        if not structured:
+            du, dv = torch.zeros_like(u), torch.zeros_like(v)
+            dub = torch.zeros((n_users,), dtype=torch.float32, device=dev) if has_ub else None
+            dib = torch.zeros((n_items,), dtype=torch.float32, device=dev) if has_ib else None
+            N.call("trec_pair_score_bwd", N.ptr(u), N.ptr(v), N.ptr(xu32), N.ptr(xi32), N.ptr(g), n_pairs, ppu,
+                   u.shape[1], mode, N.ptr(du), N.ptr(dv), N.ptr(dub), N.ptr(dib))
+            return du, dv, dub, dib, None, None, None, None, None
+        # ---- user side: segmented gather over each user's pairs (K1 with values = g)
+        if inter is not None:
+            indptr_u = inter.indptr
+        else:
+            indptr_u = torch.arange(0, (n_users + 1) * ppu, ppu, dtype=torch.int64, device=dev)
+        du = spmm_raw(indptr_u, xi32, g, None, n_users, n_pairs, v)
+        dub = None
+        if has_ub:
+            dub = torch.empty((n_users,), dtype=torch.float32, device=dev)
+            N.call("trec_spmv_csr", N.ptr(indptr_u), N.ptr(xi32), N.ptr(g), None, n_users,
+                   N.ptr(_ones(n_items, dev)), N.ptr(dub))
+        # ---- item side
+        if inter is not None:
+            indptr_t, users_t, perm_t = inter.transposed()
+            dv = spmm_raw(indptr_t, users_t, g, perm_t, n_items, n_pairs, u)
+            dib = None
+            if has_ib:
+                dib = torch.empty((n_items,), dtype=torch.float32, device=dev)
+                N.call("trec_spmv_csr", N.ptr(indptr_t), N.ptr(users_t), N.ptr(g), N.ptr(perm_t), n_items,
+                       N.ptr(_ones(n_users, dev)), N.ptr(dib))
+        else:
+            dv = torch.zeros_like(v)
+            dib = torch.zeros((n_items,), dtype=torch.float32, device=dev) if has_ib else None
+            N.call("trec_pair_score_bwd", N.ptr(u), N.ptr(v), N.ptr(xu32), N.ptr(xi32), N.ptr(g), n_pairs, ppu,
+                   u.shape[1], mode, None, N.ptr(dv), None, N.ptr(dib))
+        return du, dv, dub, dib, None, None, None, None, None
+
+
+_ones_cache = {}
+
+
+def _ones(n, dev):
+    key = (n, str(dev))
+    if key not in _ones_cache:
+        _ones_cache.clear()
+        _ones_cache[key] = torch.ones((n,), dtype=torch.float32, device=dev)
+    return _ones_cache[key]
 
 
 def pair_score(user_repr, item_repr, x_user, x_item, mode=MODE_DOT, user_bias=None, item_bias=None):
     """Serial prediction for (x_user[p], x_item[p]) pairs, optionally fused with the serial bias add."""
     xu32, ppu = _idx32(x_user)
     xi32, _ = _idx32(x_item)
+    inter = getattr(x_user, "interactions", None) if isinstance(x_user, PairIndex) else None
+    if inter is not None and (getattr(x_item, "interactions", None) is not inter or xi32.numel() != inter.nnz):
+        inter = None
     if ppu > 0:
         xu32 = None                      # implicit users: pair p -> p // pairs_per_user
     ub = _f32c(user_bias) if user_bias is not None else None
     ib = _f32c(item_bias) if item_bias is not None else None
-    return _PairScore.apply(user_repr, item_repr, ub, ib, xu32, xi32, ppu, mode)
+    return _PairScore.apply(user_repr, item_repr, ub, ib, xu32, xi32, ppu, mode, inter)
 
 
 # ------------------------------------------------------------------------------------------------ K6

@@ -109,6 +109,24 @@ class Interactions(object):
         self.pos_slot = _dev(pos_slot, self.device)
         self._host = m
         self._balanced_weight = None
+        self._t = None
+
+    def transposed(self):
+        """(indptr_t int64 [n_items+1], users_t int32 [nnz], perm_t int32 [nnz]): the interactions grouped by item;
+        entry j of the transposed structure is serial interaction ``perm_t[j]``.  Lets the item-side gradient of the
+        serial predictions be a deterministic segmented gather (K1) instead of atomics."""
+        if self._t is None:
+            m = self._host
+            tagged = sp.csr_matrix((np.arange(1, m.nnz + 1, dtype=np.int64), m.indices, m.indptr), shape=m.shape)
+            t = sp.csr_matrix(tagged.T)
+            if not t.has_sorted_indices:
+                t = t.sorted_indices()
+            indptr_t = np.zeros(self.shape[1] + 1, np.int64)
+            indptr_t[: t.shape[0] + 1] = t.indptr
+            indptr_t[t.shape[0] + 1:] = t.indptr[-1]
+            self._t = (_dev(indptr_t, self.device), _dev(t.indices.astype(np.int32), self.device),
+                       _dev((t.data - 1).astype(np.int32), self.device))
+        return self._t
 
     @property
     def indices(self):
@@ -138,10 +156,11 @@ class PairIndex(torch.Tensor):
     p // pairs_per_user).  Custom prediction graphs can index with it like any LongTensor."""
 
     @staticmethod
-    def make(idx64, idx32=None, pairs_per_user=0):
+    def make(idx64, idx32=None, pairs_per_user=0, interactions=None):
         t = idx64.as_subclass(PairIndex)
         t.idx32 = idx32 if idx32 is not None else idx64.to(torch.int32)
         t.pairs_per_user = int(pairs_per_user)
+        t.interactions = interactions          # Interactions whose serial order these indices follow (or None)
         return t
 
     @classmethod

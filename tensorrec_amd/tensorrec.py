@@ -337,8 +337,8 @@ class TensorRec(object):
         n_users, n_items = inter.shape
         with variable_scope(self._store):
             user_repr, item_repr, user_bias, item_bias, weights = self._representations(user_feats, item_feats)
-            x_user = PairIndex.make(inter.x_user, inter.x_user32)
-            x_item = PairIndex.make(inter.x_item, inter.x_item32)
+            x_user = PairIndex.make(inter.x_user, inter.x_user32, interactions=inter)
+            x_item = PairIndex.make(inter.x_item, inter.x_item32, interactions=inter)
 
             engine = self._is_engine_graph()
             if engine:
