@@ -110,6 +110,14 @@ int trec_pair_score_bwd(const float* U, const float* V, const int32_t* xu, const
                         int64_t n_pairs, int32_t pairs_per_user, int32_t d, int32_t mode, float* dU, float* dV,
                         float* d_user_bias, float* d_item_bias, void* stream);
 
+/* Group a pair list by item (counting sort on the device): writes the transposed structure (indptr_t[n_items+1],
+ * users_t[n_pairs], perm_t[n_pairs]) so that the item-side gradient of sampled serial predictions is the trec_spmm_csr
+ * segmented gather (values = grad, val_perm = perm_t, indices = users_t) instead of atomics.
+ * workspace_i32: 2*n_items int32; workspace_i64: ceil(n_items/1024)+1 int64. */
+int trec_group_pairs_by_item(const int32_t* xu, const int32_t* xi, int64_t n_pairs, int32_t pairs_per_user,
+                             int64_t n_items, int32_t* workspace_i32, int64_t* workspace_i64, int64_t* indptr_t,
+                             int32_t* users_t, int32_t* perm_t, void* stream);
+
 /* ---- K4: ranks ----------------------------------------------------------------------------------------------
  * rank_predictions, recommendation_graphs.py:73-82 (double tf.nn.top_k) as an exact count; int32, 1 = best. */
 int trec_rank_rows(const float* scores, int64_t n_users, int64_t n_items, int64_t ld_scores, int32_t* ranks,

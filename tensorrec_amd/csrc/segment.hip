@@ -1,0 +1,125 @@
+// tensorrec_amd/csrc/segment.hip -- group (user, item) pairs by item on the device: a counting sort that yields the
+// transposed (CSC-like) structure of a pair list, so that the item-side gradient of the sampled serial predictions
+//     dV[i] = sum over pairs p with item(p) = i of  g[p] * U[user(p)]
+// (the scatter-add TF's autodiff emits for tf.gather, tensorrec/prediction_graphs.py:53-54 applied to the U*S sampled
+// pairs of tensorrec/tensorrec.py:390-395) becomes the K1 segmented gather instead of n_pairs * d fp32 atomics.
+//
+// Three passes: histogram of items (int32 atomics, one per pair), exclusive scan (two-level, 1024 items per block),
+// fill (one int32 atomic per pair for the slot inside its bucket).  The order of pairs INSIDE a bucket depends on
+// atomic arrival order, so the fp32 sums downstream are reproducible only up to summation order (as with atomics).
+#include "common.hpp"
+
+__global__ __launch_bounds__(256) void seg_hist_kernel(const int32_t* __restrict__ xi, int64_t n_pairs,
+                                                      int32_t* __restrict__ counts)
+{
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < n_pairs; p += (int64_t)gridDim.x * 256)
+        atomicAdd(counts + xi[p], 1);
+}
+
+// block b scans counts[b*1024 .. +1024) -> local exclusive prefix (int64) into indptr, block total into block_sum[b]
+__global__ __launch_bounds__(256) void seg_scan_local_kernel(const int32_t* __restrict__ counts, int64_t n,
+                                                            int64_t* __restrict__ indptr, int64_t* __restrict__ block_sum)
+{
+    __shared__ int64_t wsum[4];
+    const int64_t base = (int64_t)blockIdx.x * 1024 + threadIdx.x * 4;
+    int64_t v[4];
+    int64_t run = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = run; run += (base + e < n) ? counts[base + e] : 0; }
+    // inclusive scan of `run` across the wave, then across the 4 waves
+    int64_t inc = run;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int64_t o = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += o;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int64_t woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    const int64_t excl = woff + inc - run;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (base + e < n) indptr[base + e] = excl + v[e];
+    if (threadIdx.x == 255) block_sum[blockIdx.x] = woff + inc;
+}
+
+// single block: exclusive scan of the block sums in place (n_blocks is small: n / 1024)
+__global__ __launch_bounds__(256) void seg_scan_blocks_kernel(int64_t* __restrict__ block_sum, int n_blocks,
+                                                             int64_t* __restrict__ total_out)
+{
+    __shared__ int64_t carry_s;
+    __shared__ int64_t wsum[4];
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    for (int b0 = 0; b0 < n_blocks; b0 += 256) {
+        const int i = b0 + threadIdx.x;
+        const int64_t x = (i < n_blocks) ? block_sum[i] : 0;
+        int64_t inc = x;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int64_t o = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += o;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int64_t woff = carry_s;
+        for (int w = 0; w < wave; ++w) woff += wsum[w];
+        if (i < n_blocks) block_sum[i] = woff + inc - x;
+        __syncthreads();
+        if (threadIdx.x == 255) carry_s = woff + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total_out = carry_s;
+}
+
+__global__ __launch_bounds__(256) void seg_add_offsets_kernel(int64_t* __restrict__ indptr, int64_t n,
+                                                             const int64_t* __restrict__ block_sum,
+                                                             const int64_t* __restrict__ total)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) indptr[i] += block_sum[i >> 10];
+    if (i == n) indptr[n] = *total;
+}
+
+__global__ __launch_bounds__(256) void seg_fill_kernel(const int32_t* __restrict__ xu, const int32_t* __restrict__ xi,
+                                                      int64_t n_pairs, int32_t pairs_per_user,
+                                                      const int64_t* __restrict__ indptr, int32_t* __restrict__ cursor,
+                                                      int32_t* __restrict__ users_t, int32_t* __restrict__ perm_t)
+{
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < n_pairs; p += (int64_t)gridDim.x * 256) {
+        const int32_t i = xi[p];
+        const int64_t slot = indptr[i] + atomicAdd(cursor + i, 1);
+        users_t[slot] = xu ? xu[p] : (int32_t)(p / pairs_per_user);
+        perm_t[slot] = (int32_t)p;
+    }
+}
+
+// workspace_i32: 2 * n_items int32 (counts, cursors); workspace_i64: ceil(n_items/1024) + 1 int64
+extern "C" int trec_group_pairs_by_item(const int32_t* xu, const int32_t* xi, int64_t n_pairs, int32_t pairs_per_user,
+                                        int64_t n_items, int32_t* workspace_i32, int64_t* workspace_i64,
+                                        int64_t* indptr_t, int32_t* users_t, int32_t* perm_t, void* stream)
+{
+    TREC_REQUIRE(xi && workspace_i32 && workspace_i64 && indptr_t && users_t && perm_t, "trec_group_pairs_by_item: null pointer");
+    TREC_REQUIRE(xu || pairs_per_user >= 1, "trec_group_pairs_by_item: need xu or pairs_per_user");
+    TREC_REQUIRE(n_pairs < ((int64_t)1 << 31) && n_items >= 1, "trec_group_pairs_by_item: n_pairs must fit int32");
+    hipStream_t st = (hipStream_t)stream;
+    int32_t* counts = workspace_i32;
+    int32_t* cursor = workspace_i32 + n_items;
+    const int n_blocks = (int)ceil_div64(n_items, 1024);
+    int64_t* block_sum = workspace_i64;
+    int64_t* total = workspace_i64 + n_blocks;
+    if (hipMemsetAsync(workspace_i32, 0, sizeof(int32_t) * 2 * (size_t)n_items, st) != hipSuccess) {
+        trec_set_last_error("trec_group_pairs_by_item: memset failed");
+        return TREC_ERR_LAUNCH;
+    }
+    int64_t gb = ceil_div64(n_pairs, 256);
+    if (gb > 8192) gb = 8192;
+    if (gb < 1) gb = 1;
+    hipLaunchKernelGGL(seg_hist_kernel, dim3((unsigned)gb), dim3(256), 0, st, xi, n_pairs, counts);
+    hipLaunchKernelGGL(seg_scan_local_kernel, dim3((unsigned)n_blocks), dim3(256), 0, st, counts, n_items, indptr_t, block_sum);
+    hipLaunchKernelGGL(seg_scan_blocks_kernel, dim3(1), dim3(256), 0, st, block_sum, n_blocks, total);
+    hipLaunchKernelGGL(seg_add_offsets_kernel, dim3((unsigned)ceil_div64(n_items + 1, 256)), dim3(256), 0, st, indptr_t, n_items, block_sum, total);
+    hipLaunchKernelGGL(seg_fill_kernel, dim3((unsigned)gb), dim3(256), 0, st, xu, xi, n_pairs, pairs_per_user, indptr_t, cursor, users_t, perm_t);
+    return trec_check_launch("trec_group_pairs_by_item");
+}

@@ -272,11 +272,31 @@ class _PairScore(torch.autograd.Function):
                 N.call("trec_spmv_csr", N.ptr(indptr_t), N.ptr(users_t), N.ptr(g), N.ptr(perm_t), n_items,
                        N.ptr(_ones(n_users, dev)), N.ptr(dib))
         else:
-            dv = torch.zeros_like(v)
-            dib = torch.zeros((n_items,), dtype=torch.float32, device=dev) if has_ib else None
-            N.call("trec_pair_score_bwd", N.ptr(u), N.ptr(v), N.ptr(xu32), N.ptr(xi32), N.ptr(g), n_pairs, ppu,
-                   u.shape[1], mode, None, N.ptr(dv), None, N.ptr(dib))
+            # sampled pairs: items are random -> group the pairs by item on the device (counting sort), then the same
+            # segmented gather; replaces n_pairs * d fp32 atomics
+            indptr_t, users_t, perm_t = group_pairs_by_item(xu32, xi32, ppu, n_items)
+            dv = spmm_raw(indptr_t, users_t, g, perm_t, n_items, n_pairs, u)
+            dib = None
+            if has_ib:
+                dib = torch.empty((n_items,), dtype=torch.float32, device=dev)
+                N.call("trec_spmv_csr", N.ptr(indptr_t), N.ptr(users_t), N.ptr(g), N.ptr(perm_t), n_items,
+                       N.ptr(_ones(n_users, dev)), N.ptr(dib))
         return du, dv, dub, dib, None, None, None, None, None
+
+
+def group_pairs_by_item(xu32, xi32, pairs_per_user, n_items):
+    """(indptr_t int64 [n_items+1], users_t int32 [n_pairs], perm_t int32 [n_pairs]) for a pair list, built on the
+    device; the order of pairs inside an item's bucket is not fixed (atomic slot assignment)."""
+    dev = xi32.device
+    n_pairs = xi32.numel()
+    ws32 = torch.empty((2 * n_items,), dtype=torch.int32, device=dev)
+    ws64 = torch.empty(((n_items + 1023) // 1024 + 1,), dtype=torch.int64, device=dev)
+    indptr_t = torch.empty((n_items + 1,), dtype=torch.int64, device=dev)
+    users_t = torch.empty((n_pairs,), dtype=torch.int32, device=dev)
+    perm_t = torch.empty((n_pairs,), dtype=torch.int32, device=dev)
+    N.call("trec_group_pairs_by_item", N.ptr(xu32), N.ptr(xi32), n_pairs, pairs_per_user, n_items, N.ptr(ws32),
+           N.ptr(ws64), N.ptr(indptr_t), N.ptr(users_t), N.ptr(perm_t))
+    return indptr_t, users_t, perm_t
 
 
 _ones_cache = {}

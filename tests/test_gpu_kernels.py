@@ -581,3 +581,24 @@ def test_score_topk_bf16_all_tilings(ops, variant):
         rv, ri = O.topk_rows(scores, 10)
         assert np.array_equal(vals.cpu().numpy(), rv), "chunks=%d" % chunks
         assert np.array_equal(idx.cpu().numpy(), ri), "chunks=%d" % chunks
+
+
+def test_group_pairs_by_item(ops):
+    """device counting sort: every pair lands exactly once in its item's bucket; buckets follow item order."""
+    rng = np.random.default_rng(0)
+    for (nu, ni, S) in ((7, 5, 3), (300, 2500, 40), (1000, 97, 30)):
+        items = rng.integers(0, ni, (nu, S)).astype(np.int32)
+        xi = dev(items.reshape(-1))
+        indptr_t, users_t, perm_t = ops.group_pairs_by_item(None, xi, S, ni)
+        indptr_t, users_t, perm_t = indptr_t.cpu().numpy(), users_t.cpu().numpy(), perm_t.cpu().numpy()
+        counts = np.bincount(items.reshape(-1), minlength=ni)
+        assert np.array_equal(np.diff(indptr_t), counts) and indptr_t[0] == 0 and indptr_t[-1] == nu * S
+        assert sorted(perm_t.tolist()) == list(range(nu * S))
+        assert np.array_equal(users_t, perm_t // S)
+        bucket_of_slot = np.repeat(np.arange(ni), counts)
+        assert np.array_equal(items.reshape(-1)[perm_t], bucket_of_slot)
+    # explicit user ids
+    xu = rng.integers(0, 50, 999).astype(np.int32)
+    xi = rng.integers(0, 70, 999).astype(np.int32)
+    indptr_t, users_t, perm_t = ops.group_pairs_by_item(dev(xu), dev(xi), 0, 70)
+    assert np.array_equal(users_t.cpu().numpy(), xu[perm_t.cpu().numpy()])
