@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--variant", type=int, default=int(os.environ.get("TREC_SCORE_VARIANT", "1")))
     ap.add_argument("--chunks", type=int, default=0, help="item chunks per user block (0 = auto)")
+    ap.add_argument("--no-fit", action="store_true", help="skip the fit epochs/sec measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-users", type=int, default=1024)
     return ap.parse_args()
@@ -83,6 +84,40 @@ def cpu_baseline(n_items, d, k, n_users_sample, seed=0):
     return {"value": n_users_sample * n_items / dt, "unit": "predictions/s", "cores": cores, "kind": "port",
             "sample": "oracle (scipy CSR + torch-CPU sgemm + numpy argpartition, fp32) on %d users x %d items, "
                       "d=%d, top-%d, %.1f s" % (n_users_sample, n_items, d, k, dt)}
+
+
+def fit_epochs_per_sec(n_users, n_items, d, per_user=20, n_sampled=100, epochs=3):
+    """Second half of BASELINE.json's metric: fit epochs/sec on the same 1M x 1M, d=128 shape.  One epoch = one
+    optimiser step over all users (user_batch_size=None) through the public API: K1 fwd (user + item), K7 sampling,
+    K3 over the interactions and the U*S sampled pairs, K6 WMRB fwd+bwd, backward gathers (K1 on transposed / grouped
+    structures), K8 dense Adam on every weight.  20 uniform-random positive interactions per user."""
+    import scipy.sparse as sp
+    import torch
+    import tensorrec_amd as T
+    rng = np.random.default_rng(0)
+    cols = rng.integers(0, n_items, size=(n_users, per_user), dtype=np.int32)
+    indptr = np.arange(0, (n_users + 1) * per_user, per_user, dtype=np.int64)
+    inter = sp.csr_matrix((np.ones(n_users * per_user, np.float32), cols.reshape(-1), indptr), shape=(n_users, n_items))
+    inter.sum_duplicates()
+    inter.data[:] = 1.0
+    uf = sp.identity(n_users, dtype=np.float32, format="csr")
+    itf = sp.identity(n_items, dtype=np.float32, format="csr")
+    model = T.TensorRec(n_components=d, loss_graph=T.loss_graphs.WMRBLossGraph(), seed=0)
+    model.fit_partial(inter, uf, itf, epochs=1, n_sampled_items=n_sampled)           # build + warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    model.fit_partial(inter, uf, itf, epochs=1, n_sampled_items=n_sampled)
+    torch.cuda.synchronize()
+    one = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    model.fit_partial(inter, uf, itf, epochs=1 + epochs, n_sampled_items=n_sampled)
+    torch.cuda.synchronize()
+    per_epoch = (time.perf_counter() - t0 - one) / epochs           # removes the per-call upload of the inputs
+    return {"fit_epochs_per_sec": 1.0 / per_epoch, "sec_per_epoch": per_epoch, "epochs_timed": epochs,
+            "workload": "%d users x %d items, identity features, d=%d, Linear + DotProduct + WMRB, biased, %d "
+                        "interactions, n_sampled_items=%d, device sampler, 1 optimiser step per epoch"
+                        % (n_users, n_items, d, int(inter.nnz), n_sampled),
+            "per_call_input_upload_sec": one - per_epoch}
 
 
 def main():
@@ -222,6 +257,15 @@ def main():
     except Exception as exc:      # the measurement stands on its own; report why the check could not run
         parity = {"error": repr(exc)}
 
+    fit = None
+    if not args.no_fit and world == 1:
+        try:
+            del out, ws, w_u, w_i, f_u, f_i
+            torch.cuda.empty_cache()
+            fit = fit_epochs_per_sec(U, I, d)
+        except Exception as exc:
+            fit = {"error": repr(exc)}
+
     cpu = None
     if not args.no_cpu_baseline and world == 1:
         cpu = cpu_baseline(I, d, k, args.cpu_users)
@@ -235,7 +279,7 @@ def main():
                    "users": U, "items": I, "n_components": d, "top_k": k,
                    "parallelism": "items sharded x%d, users replicated" % world,
                    "score_kernel_variant": "global_load_lds" if args.variant & 1 else "register-staged"},
-        "roofline": roofline, "roofline_k1": roofline_k1, "cpu_baseline": cpu, "parity": parity,
+        "roofline": roofline, "roofline_k1": roofline_k1, "cpu_baseline": cpu, "parity": parity, "fit": fit,
     }
     print(json.dumps(line))
     if world > 1:

@@ -21,7 +21,7 @@ tests)
   echo "pytest rc=$?" >> $OUT/summary.log; tail -40 $OUT/pytest_gpu.log >> $OUT/summary.log ;;
 bench)
   for v in ${VARIANTS:-1 0 3 2 5 4 7 6}; do
-    timeout 600 python bench.py --steps 3 --warmup 1 --variant $v --no-cpu-baseline > $OUT/bench_v$v.json 2> $OUT/bench_v$v.err
+    timeout 600 python bench.py --steps 3 --warmup 1 --variant $v --no-cpu-baseline --no-fit > $OUT/bench_v$v.json 2> $OUT/bench_v$v.err
     echo "bench full v$v rc=$? $(python -c "import json,sys; d=json.load(open('$OUT/bench_v$v.json')); print('ms/step %.1f  K2 %.1f TF (%.3f)  K1 %.0f GB/s  parity %s' % (d['ms_per_step'], d['roofline']['achieved'], d['roofline']['frac'], d['roofline_k1']['achieved'], d['parity']))" 2>&1)" >> $OUT/summary.log
     tail -2 $OUT/bench_v$v.err >> $OUT/summary.log
   done ;;

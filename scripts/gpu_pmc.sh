@@ -7,7 +7,7 @@ REPO=$PWD
 OUT=$REPO/gpurun_out/pmc
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="${1:---steps 1 --warmup 1 --users 262144 --items 262144 --no-cpu-baseline}"
+ARGS="${1:---steps 1 --warmup 1 --users 262144 --items 262144 --no-cpu-baseline --no-fit}"
 declare -A SETS
 SETS[s1]="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_BRANCH"
 SETS[s2]="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
