@@ -44,6 +44,7 @@ struct ScoreParams {
     int64_t ld_out;
     float* part_vals;         // TOPK: [n_r, n_parts, KTOP]  (KTOP = list capacity: 8, 12 or 16)
     int32_t* part_idx;
+    int capacity;             // slots per partial list in part_vals / part_idx (>= the kernel's KTOP)
     int n_parts;              // 2 * n_chunks
     int32_t t_index_base;     // added to item indices written by TOPK (item shards)
 };
@@ -408,11 +409,17 @@ __global__ __launch_bounds__(256, WPS) void score_gemm_kernel(ScoreParams p)
         for (int cb = 0; cb < NCB; ++cb) {
             const int64_t u = r_base + cb * 32 + l31;
             if (u < p.n_r) {
-                const int64_t o = (u * p.n_parts + (chunk * 2 + half)) * KTOP;
+                const int64_t o = (u * p.n_parts + (chunk * 2 + half)) * p.capacity;
+                if (KTOP % 4 == 0 && p.capacity == KTOP) {
 #pragma unroll
-                for (int j = 0; j < KTOP; j += 4) {
-                    *(f32x4*)(p.part_vals + o + j) = (f32x4){tv[cb][j], tv[cb][j + 1], tv[cb][j + 2], tv[cb][j + 3]};
-                    *(int4*)(p.part_idx + o + j) = make_int4(ti[cb][j], ti[cb][j + 1], ti[cb][j + 2], ti[cb][j + 3]);
+                    for (int j = 0; j + 3 < KTOP; j += 4) {
+                        *(f32x4*)(p.part_vals + o + j) = (f32x4){tv[cb][j], tv[cb][j + 1], tv[cb][j + 2], tv[cb][j + 3]};
+                        *(int4*)(p.part_idx + o + j) = make_int4(ti[cb][j], ti[cb][j + 1], ti[cb][j + 2], ti[cb][j + 3]);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < KTOP; ++j) { p.part_vals[o + j] = tv[cb][j]; p.part_idx[o + j] = ti[cb][j]; }
+                    for (int j = KTOP; j < p.capacity; ++j) { p.part_vals[o + j] = -INFINITY; p.part_idx[o + j] = -1; }
                 }
             }
         }
@@ -579,7 +586,7 @@ static ScoreCfg score_cfg_variant(int dtype, int kt, int variant)
     if (dtype == 1 && kt == 128) {
         switch (variant >> 1) {
             case 1: return ScoreCfg{128, 2};     // default tiling with 128-row item tiles (half the barriers)
-            case 2: return ScoreCfg{128, 2};     // 1 workgroup / CU (512 registers), 64 users per wave
+            case 2: return ScoreCfg{64, 1};      // 32 users per wave, 4 workgroups / CU
             case 3: return ScoreCfg{64, 1};      // 3 workgroups / CU, 32 users per wave
             default: break;
         }
@@ -657,14 +664,14 @@ extern "C" int trec_score_gemm_topk(const void* users, const void* items, int32_
                          item_sqnorm, n_chunks, experimental ? variant : 0);
     if (rc) return rc;
     p.part_vals = part_vals; p.part_idx = part_idx; p.n_parts = 2 * p.n_chunks; p.t_index_base = item_index_base;
+    p.capacity = capacity;
     if (experimental) {
         hipStream_t st = (hipStream_t)stream;
         const bool glds = variant & 1;
         switch (variant >> 1) {
             case 1: return glds ? launch_score<1, 128, 128, 2, EPI_TOPK, true, false, 12, 2>(p, st)
                                 : launch_score<1, 128, 128, 2, EPI_TOPK, false, false, 12, 2>(p, st);
-            case 2: return glds ? launch_score<1, 128, 128, 2, EPI_TOPK, true, false, 12, 1>(p, st)
-                                : launch_score<1, 128, 128, 2, EPI_TOPK, false, false, 12, 1>(p, st);
+            case 2: return launch_score<1, 128, 64, 1, EPI_TOPK, true, false, 12, 4>(p, st);   // 32 users / wave, 4 WG / CU
             case 3: return glds ? launch_score<1, 128, 64, 1, EPI_TOPK, true, false, 12, 3>(p, st)
                                 : launch_score<1, 128, 64, 1, EPI_TOPK, false, false, 12, 3>(p, st);
             case 4: return launch_score_b<1, 128, 64, 2, EPI_TOPK, true, false, 12, true, 2, 1>(p, st);   // ablation
