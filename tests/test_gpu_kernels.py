@@ -602,3 +602,50 @@ def test_group_pairs_by_item(ops):
     xi = rng.integers(0, 70, 999).astype(np.int32)
     indptr_t, users_t, perm_t = ops.group_pairs_by_item(dev(xu), dev(xi), 0, 70)
     assert np.array_equal(users_t.cpu().numpy(), xu[perm_t.cpu().numpy()])
+
+
+# ------------------------------------------------------------------------------------------------ shim goldens
+def test_hip_path_vs_reference_source_fixtures(ops):
+    """HIP kernels against fixtures produced by executing the reference's own graph source on the NumPy TF stand-in
+    (tests/golden/run_reference_on_shim.py): representation graphs, losses, prediction graphs, ranks."""
+    from conftest import load_goldens
+    from tensorrec_amd.sparse import Interactions
+    sg = load_goldens("reference_shim_goldens.json")
+    tol = dict(rtol=1e-5, atol=1e-5)
+    g = sg["repr_linear"]
+    f = feats(g["features"])
+    w = dev(g["variables"]["linear_weights_user"])
+    assert np.allclose(ops.sparse_dense_matmul(f, w).cpu().numpy(), g["expected_repr"], **tol)
+    g = sg["repr_normalized_linear"]
+    got = ops.sparse_dense_matmul_l2norm(feats(g["features"]), dev(g["variables"]["linear_weights_user"]))
+    assert np.allclose(got.cpu().numpy(), g["expected_repr"], **tol)
+    for key in ("repr_relu", "repr_relu_size_5"):
+        g = sg[key]
+        v = g["variables"]
+        h = ops.sparse_dense_matmul_bias_relu(feats(g["features"]), dev(v["relu_weights_user"]), dev(v["relu_biases_user"]))
+        got = ops.matmul(h, dev(v["linear_weights_user"]))
+        assert np.allclose(got.cpu().numpy(), g["expected_repr"], rtol=1e-5, atol=1e-5)
+    g = sg["repr_passthrough"]
+    assert np.array_equal(ops.sparse_to_dense(feats(g["features"])).cpu().numpy(), g["expected_repr"])
+    # losses
+    g = sg["loss_wmrb"]
+    m = sp.csr_matrix(g["interactions"])
+    inter = Interactions(m, m.shape[0], m.shape[1], "cuda")
+    for key, balanced in (("loss_wmrb", False), ("loss_balanced_wmrb", True)):
+        g = sg[key]
+        got = ops.wmrb_loss(dev(g["prediction_serial"]), dev(g["sample_predictions"]), inter, balanced=balanced)
+        assert np.allclose(got.cpu().numpy(), g["expected_loss"], **tol)
+    g = sg["loss_rmse"]
+    assert np.allclose(float(ops.rmse_loss(dev(g["prediction_serial"]), inter.values)), g["expected_loss"], rtol=1e-5)
+    # prediction graphs
+    from tensorrec_amd.prediction_graphs import (DotProductPredictionGraph, CosineSimilarityPredictionGraph,
+                                                 EuclideanSimilarityPredictionGraph)
+    for kind, cls in (("dot", DotProductPredictionGraph), ("cosine", CosineSimilarityPredictionGraph),
+                      ("euclidean", EuclideanSimilarityPredictionGraph)):
+        g = sg["pred_" + kind]
+        u, v = dev(g["user_repr"]), dev(g["item_repr"])
+        assert np.allclose(cls().connect_dense_prediction_graph(u, v).cpu().numpy(), g["expected_dense"], **tol)
+        xu, xi = dev(g["x_user"].astype(np.int64)), dev(g["x_item"].astype(np.int64))
+        assert np.allclose(cls().connect_serial_prediction_graph(u, v, xu, xi).cpu().numpy(), g["expected_serial"], **tol)
+    g = sg["rank_predictions_ties"]
+    assert np.array_equal(ops.rank_rows(dev(g["predictions"])).cpu().numpy(), g["expected_ranks"].astype(np.int32))
