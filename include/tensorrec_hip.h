@@ -146,9 +146,10 @@ int trec_rmse_bwd(const float* y, const float* pred, const float* loss, const fl
 
 /* ---- K7: negative sampling ----------------------------------------------------------------------------------
  * sample_items, util.py:12-21 (host np.random.choice per user behind tf.py_func, tensorrec.py:298-302).
- * out: int32 [n_users, n_sampled], user-major.  replace == 0: distinct per user (keyed permutation).          */
-int trec_sample_items(int64_t n_users, int32_t n_items, int32_t n_sampled, int32_t replace, uint64_t seed,
-                      uint32_t step, int32_t* out, void* stream);
+ * out: int32 [n_users, n_sampled], user-major.  replace == 0: distinct per user (keyed permutation).  Row r is the
+ * stream of GLOBAL user user_base + r, so user shards reproduce the whole-population draw.                      */
+int trec_sample_items(int64_t n_users, int64_t user_base, int32_t n_items, int32_t n_sampled, int32_t replace,
+                      uint64_t seed, uint32_t step, int32_t* out, void* stream);
 
 /* ---- K8: optimiser --------------------------------------------------------------------------------------------
  * tf.train.AdamOptimizer(lr).minimize (tensorrec.py:489) + gradient of alpha * sum(tf.nn.l2_loss(w)) (:487-488):

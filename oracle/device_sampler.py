@@ -53,10 +53,10 @@ def _feistel_permute(x, bits, keys):
     return (L << np.uint32(wr)) | R
 
 
-def sample_items(n_users, n_items, n_sampled, replace, seed, step):
+def sample_items(n_users, n_items, n_sampled, replace, seed, step, user_base=0):
     seed = int(seed) & (2 ** 64 - 1)
     k0, k1 = seed & 0xFFFFFFFF, seed >> 32
-    u = np.repeat(np.arange(n_users, dtype=np.uint64), n_sampled)
+    u = np.repeat(np.arange(n_users, dtype=np.uint64) + np.uint64(user_base), n_sampled)
     s = np.tile(np.arange(n_sampled, dtype=np.uint32), n_users)
     u_lo, u_hi = (u & U32).astype(np.uint32), (u >> np.uint64(32)).astype(np.uint32)
     stepv = np.full(u.shape, step, np.uint32)

@@ -62,14 +62,17 @@ __host__ __device__ inline uint32_t feistel_permute(uint32_t x, int bits, const 
     return (L << wr) | R;
 }
 
-__global__ __launch_bounds__(256) void sample_items_kernel(int64_t n_users, int32_t n_items, int32_t n_sampled,
-                                                          int replace, uint32_t seed_lo, uint32_t seed_hi,
-                                                          uint32_t step, int bits, int32_t* __restrict__ out)
+__global__ __launch_bounds__(256) void sample_items_kernel(int64_t n_users, int64_t user_base, int32_t n_items,
+                                                          int32_t n_sampled, int replace, uint32_t seed_lo,
+                                                          uint32_t seed_hi, uint32_t step, int bits,
+                                                          int32_t* __restrict__ out)
 {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n_users * n_sampled) return;
-    const int64_t u = idx / n_sampled;
-    const uint32_t s = (uint32_t)(idx - u * n_sampled);
+    const int64_t ul = idx / n_sampled;
+    const uint32_t s = (uint32_t)(idx - ul * n_sampled);
+    const int64_t u = ul + user_base;          // streams are keyed by the GLOBAL user id: a user shard draws what the
+                                               // whole-population run would draw for the same users
     if (replace) {
         const u4 r = philox4x32_10(u4{(uint32_t)u, s >> 2, step, 2u + (uint32_t)(u >> 32)}, seed_lo, seed_hi);
         const uint32_t w = (s & 3) == 0 ? r.x : (s & 3) == 1 ? r.y : (s & 3) == 2 ? r.z : r.w;
@@ -84,8 +87,8 @@ __global__ __launch_bounds__(256) void sample_items_kernel(int64_t n_users, int3
     out[idx] = (int32_t)x;
 }
 
-extern "C" int trec_sample_items(int64_t n_users, int32_t n_items, int32_t n_sampled, int32_t replace, uint64_t seed,
-                                 uint32_t step, int32_t* out, void* stream)
+extern "C" int trec_sample_items(int64_t n_users, int64_t user_base, int32_t n_items, int32_t n_sampled,
+                                 int32_t replace, uint64_t seed, uint32_t step, int32_t* out, void* stream)
 {
     TREC_REQUIRE(out, "trec_sample_items: null pointer");
     TREC_REQUIRE(n_items >= 1 && n_sampled >= 1, "trec_sample_items: n_items and n_sampled must be >= 1");
@@ -96,6 +99,7 @@ extern "C" int trec_sample_items(int64_t n_users, int32_t n_items, int32_t n_sam
     while (bits < 31 && (1u << bits) < (uint32_t)n_items) ++bits;
     const int64_t total = n_users * (int64_t)n_sampled;
     hipLaunchKernelGGL(sample_items_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, (hipStream_t)stream,
-                       n_users, n_items, n_sampled, replace, (uint32_t)seed, (uint32_t)(seed >> 32), step, bits, out);
+                       n_users, user_base, n_items, n_sampled, replace, (uint32_t)seed, (uint32_t)(seed >> 32), step, bits,
+                       out);
     return trec_check_launch("trec_sample_items");
 }

@@ -471,10 +471,10 @@ def rank_of_pairs(scores, col_offset, begin, end, xu32, xi32, target_scores, add
     return out
 
 
-def sample_items(n_users, n_items, n_sampled, replace, seed, step, device="cuda"):
+def sample_items(n_users, n_items, n_sampled, replace, seed, step, device="cuda", user_base=0):
     out = torch.empty((n_users, n_sampled), dtype=torch.int32, device=device)
-    N.call("trec_sample_items", n_users, n_items, n_sampled, 1 if replace else 0, int(seed) & (2 ** 64 - 1),
-           int(step) & 0xFFFFFFFF, N.ptr(out))
+    N.call("trec_sample_items", n_users, int(user_base), n_items, n_sampled, 1 if replace else 0,
+           int(seed) & (2 ** 64 - 1), int(step) & 0xFFFFFFFF, N.ptr(out))
     return out
 
 

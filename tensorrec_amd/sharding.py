@@ -12,6 +12,12 @@ row-wise, the user tile is replicated, and exactly ONE small collective finishes
   * ranks  : rank = 1 + count of items that beat the target (recommendation_graphs.py:73-82 is a count, SURVEY.md 0);
              counts over disjoint item ranges add, so an all-reduce(SUM) of int32 partial counts gives exact ranks.
 
+Training is data-parallel over USERS (the reference's own batching axis, tensorrec.py:199-217): each rank owns a slice of
+user rows (interactions + user features), items and all weights are replicated, and one step = local forward/backward +
+all-reduce(SUM) of the weight gradients + the identical fused Adam on every rank.  Because the WMRB objective is a sum
+over interactions, this equals ONE single-process step on the union batch (not the reference's sequential per-batch
+steps).  The device sampler is keyed by global user id, so shards draw what the whole population would.
+
 No collective sits inside the score kernel; payloads are KBs-MBs against ~10 ms of MFMA work per 65k-user tile, so
 xGMI (7 point-to-point links x ~153 GB/s) is nowhere near a bound and a plain all-gather is the right primitive.
 """
@@ -65,6 +71,21 @@ def reduce_rank_counts(local_counts, group=None):
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(local_counts, op=dist.ReduceOp.SUM, group=group)
     return local_counts
+
+
+def all_reduce_sum_(tensors, group=None):
+    """In-place SUM all-reduce of a list of tensors (weight gradients of the user-sharded fit)."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        for t in tensors:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return tensors
+
+
+def all_reduce_scalar(value, device, group=None):
+    t = torch.tensor([int(value)], dtype=torch.int64, device=device)
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return int(t.item())
 
 
 def max_over_ranks(seconds, device, group=None):

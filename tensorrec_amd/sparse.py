@@ -134,13 +134,19 @@ class Interactions(object):
         return torch.stack([self.x_user, self.x_item], dim=1)
 
     def balanced_weight(self):
-        """value_p / (sum of positive values of p's item)  -- loss_graphs.py:197-202, 222-224; 0 for non-positives."""
+        """value_p / (sum of positive values of p's item)  -- loss_graphs.py:197-202, 222-224; 0 for non-positives.
+        Under a user-sharded (data-parallel) fit the per-item sums are all-reduced so they cover every user."""
         if self._balanced_weight is None:
             m = self._host
             vals = m.data.astype(np.float32)
             pos = vals > 0.0
             per_item = np.zeros(self.shape[1], np.float32)
             np.add.at(per_item, m.indices[pos], vals[pos])
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                t = _dev(per_item, self.device)
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                per_item = t.cpu().numpy()
             w = np.zeros(m.nnz, np.float32)
             w[pos] = vals[pos] / per_item[m.indices[pos]]
             self._balanced_weight = _dev(w, self.device)

@@ -48,8 +48,8 @@ class DeviceSampler(object):
     def __init__(self, seed=0):
         self.seed = int(seed)
 
-    def sample(self, n_items, n_users, n_sampled_items, replace, step, device):
-        return ops.sample_items(n_users, n_items, n_sampled_items, replace, self.seed, step, device)
+    def sample(self, n_items, n_users, n_sampled_items, replace, step, device, user_base=0):
+        return ops.sample_items(n_users, n_items, n_sampled_items, replace, self.seed, step, device, user_base)
 
 
 class HostSampler(object):
@@ -59,7 +59,7 @@ class HostSampler(object):
     def __init__(self, rng=None):
         self.rng = rng if rng is not None else np.random
 
-    def sample(self, n_items, n_users, n_sampled_items, replace, step, device):
+    def sample(self, n_items, n_users, n_sampled_items, replace, step, device, user_base=0):
         pairs = sample_items(n_items, n_users, n_sampled_items, replace, rng=self.rng)
         items = pairs[:, 1].reshape(n_users, n_sampled_items).astype(np.int32)
         return torch.from_numpy(items).to(device)
@@ -72,7 +72,7 @@ class ReplaySampler(object):
         self.tables = list(tables)
         self.pos = 0
 
-    def sample(self, n_items, n_users, n_sampled_items, replace, step, device):
+    def sample(self, n_items, n_users, n_sampled_items, replace, step, device, user_base=0):
         table = np.ascontiguousarray(self.tables[self.pos % len(self.tables)], dtype=np.int32)
         self.pos += 1
         if table.shape != (n_users, n_sampled_items):
@@ -104,7 +104,9 @@ class TensorRec(object):
                  precision='fp32',
                  device=None,
                  sampler=None,
-                 seed=None):
+                 seed=None,
+                 data_parallel=False,
+                 process_group=None):
         """
         A TensorRec recommendation model (arguments as tensorrec/tensorrec.py:28-61).
         :param precision: 'fp32' (default; exact fp32 MFMA, bit-stable ranks) or 'bf16' (bf16 operands, fp32
@@ -113,6 +115,12 @@ class TensorRec(object):
         :param sampler: object with ``sample(n_items, n_users, n_sampled_items, replace, step, device)``;
         default DeviceSampler(seed).
         :param seed: int or None -- seeds weight initialisation and the default sampler.
+        :param data_parallel: if True and torch.distributed is initialised, ``fit`` is data-parallel over USERS: every
+        rank passes its own rows of ``interactions`` / ``user_features`` (and ``user_offset=`` its first global user
+        index) plus the full ``item_features``; weight gradients are all-reduced (RCCL) once per step, so a step
+        equals the single-process step on the union of the shards (the reference's ``user_batch_size=None`` case).
+        Needs ``seed`` (identical initial weights on every rank) and a loss that is a per-interaction vector (the
+        WMRB family); see sharding.py.
         """
         # Arg Check (tensorrec.py:68-88)
         if (n_components is None) or (n_tastes is None) or (user_repr_graph is None) or (item_repr_graph is None) \
@@ -150,6 +158,10 @@ class TensorRec(object):
         self.device = device
         self.seed = seed
         self.sampler = sampler
+        self.data_parallel = bool(data_parallel)
+        self.process_group = process_group
+        if self.data_parallel and seed is None:
+            raise ValueError("data_parallel=True needs seed= so that every rank starts from the same weights")
 
         self._store = None
         self._capture = None          # tests set this to a dict to receive the last step's loss and raw gradients
@@ -163,6 +175,12 @@ class TensorRec(object):
     @property
     def is_fit(self):
         return self._store is not None
+
+    def _dp_active(self):
+        if not self.data_parallel:
+            return False
+        import torch.distributed as dist
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.process_group) > 1
 
     def _device(self):
         N.require_gpu()
@@ -267,15 +285,17 @@ class TensorRec(object):
 
     # ------------------------------------------------------------------------------------------ fit
     def fit(self, interactions, user_features, item_features, epochs=100, learning_rate=0.1, alpha=0.00001,
-            verbose=False, user_batch_size=None, n_sampled_items=None):
+            verbose=False, user_batch_size=None, n_sampled_items=None, user_offset=0):
         """Constructs the model (first call) and fits it -- arguments as tensorrec/tensorrec.py:494-526."""
         self.fit_partial(interactions=interactions, user_features=user_features, item_features=item_features,
                          epochs=epochs, learning_rate=learning_rate, alpha=alpha, verbose=verbose,
-                         user_batch_size=user_batch_size, n_sampled_items=n_sampled_items)
+                         user_batch_size=user_batch_size, n_sampled_items=n_sampled_items, user_offset=user_offset)
 
     def fit_partial(self, interactions, user_features, item_features, epochs=1, learning_rate=0.1,
-                    alpha=0.00001, verbose=False, user_batch_size=None, n_sampled_items=None):
-        """One or more epochs; one optimiser step per user batch (tensorrec/tensorrec.py:539-634)."""
+                    alpha=0.00001, verbose=False, user_batch_size=None, n_sampled_items=None, user_offset=0):
+        """One or more epochs; one optimiser step per user batch (tensorrec/tensorrec.py:539-634).
+        ``user_offset`` (extension): global index of this call's first user row -- keys the device sampler so that a
+        user shard draws what the whole population would."""
         loss_graph = self.loss_graph_factory
         if loss_graph.is_sample_based:
             if (n_sampled_items is None) or (n_sampled_items <= 0):
@@ -313,6 +333,7 @@ class TensorRec(object):
             uf = SparseFeatures(uf_m, device)
             itf = item_cache[id(if_m)]
             inter = Interactions(inter_m, n_users=uf.shape[0], n_items=itf.shape[0], device=device)
+            inter.user_base = int(user_offset) + sum(b[1].shape[0] for b in dev_batches)
             dev_batches.append((inter, uf, itf))
 
         batched_alpha = calculate_batched_alpha(num_batches=len(dev_batches), alpha=alpha)
@@ -364,7 +385,7 @@ class TensorRec(object):
                 self._sample_step += 1
                 samples = self.sampler.sample(n_items, n_users, int(n_sampled_items),
                                               loss_graph.is_sampled_with_replacement, self._sample_step,
-                                              self._store.device)
+                                              self._store.device, getattr(inter, 'user_base', 0))
                 samples = samples.to(torch.int32).contiguous()
                 if engine:
                     xs_item = PairIndex.make(samples.reshape(-1), samples.reshape(-1), int(n_sampled_items))
@@ -384,6 +405,20 @@ class TensorRec(object):
         # tf_loss = tf_basic_loss + alpha * reg (broadcast), minimised as a sum (tensorrec.py:487-489)
         n_loss = int(basic_loss.numel())
         basic_loss.sum().backward()
+
+        if self._dp_active():
+            # data-parallel over users: the objective is a sum over interactions, so the gradient of the union batch is
+            # the sum of the shard gradients -- ONE all-reduce per weight tensor (RCCL over xGMI), plus the loss length
+            from . import sharding
+            if basic_loss.dim() == 0:
+                raise NotImplementedError("data-parallel fit needs a loss that is a per-interaction vector (WMRB "
+                                          "family); %s returns a scalar" % type(loss_graph).__name__)
+            n_loss = sharding.all_reduce_scalar(n_loss, self._store.device, self.process_group)
+            for name in self._store.order:
+                var = self._store.variables[name]
+                if var.grad is None:
+                    var.grad = torch.zeros_like(var)
+            sharding.all_reduce_sum_([self._store.variables[n].grad for n in self._store.order], self.process_group)
 
         reg_ids = set(id(w) for w in weights)
         if self._capture is not None:

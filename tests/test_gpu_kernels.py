@@ -475,6 +475,10 @@ def test_sampler_bit_exact_vs_restatement(ops, replace):
                                     (1000, 1682, 168, 0, 7)):
         got = ops.sample_items(nu, ni, S, replace, seed, step).cpu().numpy()
         assert np.array_equal(got, DS.sample_items(nu, ni, S, replace, seed, step))
+        # a user shard draws exactly the rows of the whole-population table
+        if nu >= 4:
+            part = ops.sample_items(nu - 3, ni, S, replace, seed, step, user_base=3).cpu().numpy()
+            assert np.array_equal(part, got[3:])
 
 
 def test_sampler_contract(ops):

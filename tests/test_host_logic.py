@@ -154,7 +154,7 @@ def test_abi_pure_queries_and_argument_errors():
     rc = lib.trec_spmm_csr(ctypes.c_void_p(8), None, None, None, 1, 1, ctypes.c_void_p(8), 4, None, 0, 0,
                            ctypes.c_void_p(8), None, None)
     assert rc == 1 and b"nnz != 0" in lib.trec_last_error()
-    rc = lib.trec_sample_items(3, 5, 6, 0, 0, 0, ctypes.c_void_p(8), None)
+    rc = lib.trec_sample_items(3, 0, 5, 6, 0, 0, 0, ctypes.c_void_p(8), None)
     assert rc == 1 and b"larger sample than population" in lib.trec_last_error()
 
 

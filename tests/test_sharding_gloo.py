@@ -84,3 +84,27 @@ def test_exchange_and_reduce_over_gloo(world):
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
     assert dict(ret) == {r: "ok" for r in range(world)}
+
+
+def _dp_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g1 = torch.full((5, 3), float(rank + 1))
+        g2 = torch.arange(4, dtype=torch.float32) * (rank + 1)
+        sharding.all_reduce_sum_([g1, g2])
+        assert torch.equal(g1, torch.full((5, 3), float(sum(range(1, world + 1)))))
+        assert torch.equal(g2, torch.arange(4, dtype=torch.float32) * sum(range(1, world + 1)))
+        assert sharding.all_reduce_scalar(10 + rank, "cpu") == sum(10 + r for r in range(world))
+        ret[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_all_reduce_helpers_over_gloo():
+    port = _free_port()
+    mgr = mp.get_context("spawn").Manager()
+    ret = mgr.dict()
+    mp.spawn(_dp_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert dict(ret) == {0: "ok", 1: "ok"}
