@@ -64,6 +64,12 @@ def test_two_rank_fit_equals_single_process_fit():
     assert sorted(ret.keys()) == [0, 1]
     for k, v in ref.items():
         assert np.array_equal(ret[0][k], ret[1][k]), "ranks diverged on %s" % k       # identical replicas
+        if k == "user_feature_biases":
+            # Under WMRB a user bias shifts the positive and the sampled scores of that user alike, so its gradient is
+            # exactly 0 in exact arithmetic; what Adam sees is rounding noise, which it normalises to +-lr steps (in
+            # the reference as well).  Different summation orders give different noise -> only the scale is checked.
+            assert np.abs(ret[0][k]).max() <= 3 * 0.05 + 1e-6 and np.abs(v).max() <= 3 * 0.05 + 1e-6
+            continue
         # same gradient up to summation order; 0.1 * lr after 3 Adam steps (see test_fit_steps_match_oracle)
         assert np.allclose(ret[0][k], v, rtol=2e-3, atol=5e-3), "%s: %g" % (k, np.abs(ret[0][k] - v).max())
     moved = np.abs(ref["linear_weights_item"] - _initial("linear_weights_item")).max()
