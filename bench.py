@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--variant", type=int, default=int(os.environ.get("TREC_SCORE_VARIANT", "1")))
     ap.add_argument("--chunks", type=int, default=0, help="item chunks per user block (0 = auto)")
+    ap.add_argument("--method", default="auto", choices=["auto", "direct", "two_stage"])
     ap.add_argument("--no-fit", action="store_true", help="skip the fit epochs/sec measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-users", type=int, default=1024)
@@ -161,6 +162,9 @@ def main():
     f_u = SparseFeatures(sp.identity(U, dtype=np.float32, format="csr"), device)
     f_i = SparseFeatures(sp.identity(n_local, dtype=np.float32, format="csr"), device)   # this rank's item rows
     kpad = ops.score_kpad(d)
+    method = args.method
+    if method == "auto":
+        method = "two_stage" if n_local >= ops.TWO_STAGE_MIN_ITEMS else "direct"
     n_chunks = args.chunks if args.chunks > 0 else ops.topk_chunks_for(U, dtype, kpad, n_local)
     cap = T._native.query("trec_score_topk_capacity", k)
     n_parts = T._native.query("trec_score_topk_parts", dtype, kpad, n_local, n_chunks)
@@ -175,8 +179,12 @@ def main():
             ib = ops.sparse_matvec(f_i, beta_i)
             u_op, _, _ = ops.score_prep(user_repr, dtype)
             i_op, _, _ = ops.score_prep(item_repr, dtype)
-            vals, idx = ops.score_topk(u_op, i_op, dtype, kpad, k, ub, ib, item_index_base=i_begin,
-                                       n_chunks=n_chunks, variant=args.variant, workspace=ws)            # K2 + merge
+            if method == "direct":
+                vals, idx = ops.score_topk_direct(u_op, i_op, dtype, kpad, k, ub, ib, item_index_base=i_begin,
+                                                  n_chunks=n_chunks, variant=args.variant, workspace=ws)  # K2 + merge
+            else:
+                vals, idx = ops.score_topk_two_stage(u_op, i_op, dtype, kpad, k, ub, ib, item_index_base=i_begin,
+                                                     variant=args.variant)
             if world > 1:
                 vals, idx = sharding.sharded_top_k(vals, idx, k)                                          # 1 all-gather
             return vals, idx, user_repr, item_repr
@@ -209,14 +217,17 @@ def main():
     dur = {}
     for name, s, e in events:
         dur.setdefault(name, []).append(s.elapsed_time(e))
-    k2_ms = float(np.mean(dur["score_gemm_topk"]))
+    k2_name = "score_gemm_topk" if method == "direct" else "score_gemm_blockmax"
+    k2_ms = float(np.mean(dur[k2_name]))
     k2_flops = 2.0 * U * n_local * kpad                    # algorithmic: 2*U*I*d per launch (d = kpad = 128 here)
     peak = BF16_DENSE_PEAK_TFLOPS if args.precision == "bf16" else FP32_MFMA_PEAK_TFLOPS
     k2_tflops = k2_flops / (k2_ms * 1e-3) / 1e12
-    roofline = {"kernel": "score_gemm_kernel (fused top-k epilogue)", "bound": "mfma", "achieved": k2_tflops,
+    roofline = {"kernel": "score_gemm_kernel (%s epilogue)" % ("fused top-k" if method == "direct" else "superblock-max"),
+                "bound": "mfma", "achieved": k2_tflops,
                 "peak": peak, "unit": "TFLOP/s", "frac": k2_tflops / peak, "traffic": None,
-                "avg_launch_ms": k2_ms, "launches": len(dur["score_gemm_topk"]),
-                "algorithmic_flops_per_launch": k2_flops}
+                "avg_launch_ms": k2_ms, "launches": len(dur[k2_name]),
+                "algorithmic_flops_per_launch": k2_flops,
+                "other_kernels_avg_ms": {n: float(np.mean(v)) for n, v in dur.items() if n not in (k2_name, "spmm_csr")}}
     k1 = dur.get("spmm_csr", [])
     roofline_k1 = None
     if k1:
@@ -278,6 +289,7 @@ def main():
                                "DotProduct, biased, fused top-%d (BASELINE.json configs[2])" % (U, I, d, k),
                    "users": U, "items": I, "n_components": d, "top_k": k,
                    "parallelism": "items sharded x%d, users replicated" % world,
+                   "topk_method": method,
                    "score_kernel_variant": "global_load_lds" if args.variant & 1 else "register-staged"},
         "roofline": roofline, "roofline_k1": roofline_k1, "cpu_baseline": cpu, "parity": parity, "fit": fit,
     }

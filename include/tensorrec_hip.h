@@ -94,6 +94,35 @@ int trec_score_gemm_topk(const void* users, const void* items, int32_t dtype, in
                          int64_t n_items, int32_t item_index_base, const float* user_bias, const float* item_bias,
                          int32_t mode, const float* user_sqnorm, const float* item_sqnorm, int32_t n_chunks,
                          int32_t capacity, float* part_vals, int32_t* part_idx, int32_t variant, void* stream);
+/* Two-stage exact top-k (data-independent cost; what predict_top_k uses for large item sets):
+ *   1. trec_score_gemm_blockmax: blockmax[s * bm_stride + u] = max exact score of user u over items
+ *      [s*sb_rows, (s+1)*sb_rows)  (sb_rows a multiple of 128) -- the score kernel with a branch-free epilogue;
+ *   2. trec_topk_select_blocks: per user the k superblocks with the largest maxima, (max desc, index asc) -- they
+ *      contain the exact top-k, ties included (proof in csrc/topk2.hip);
+ *   3. trec_topk_group_keys + trec_group_pairs_by_item + trec_topk_pad_counts + trec_exclusive_scan_i32 +
+ *      trec_topk_fill_groups: (user, slot) pairs grouped by superblock, padded to whole workgroups, operand rows gathered;
+ *      trec_score_gemm_topk_grouped: every workgroup re-scores one superblock for its gathered rows (fused lists);
+ *   4. trec_topk_merge over the k*2 lists of each user. */
+int trec_score_gemm_blockmax(const void* users, const void* items, int32_t dtype, int32_t kpad, int64_t n_users,
+                             int64_t n_items, const float* user_bias, const float* item_bias, int32_t mode,
+                             const float* user_sqnorm, const float* item_sqnorm, int32_t sb_rows, int32_t n_chunks,
+                             float* blockmax, int64_t bm_stride, int32_t variant, void* stream);
+int trec_topk_select_blocks(const float* blockmax, int32_t n_sb, int64_t n_users, int64_t stride, int32_t k, int32_t* sel,
+                            void* stream);
+int trec_topk_group_keys(const int32_t* sel, int64_t n, int32_t n_sb, int32_t* keys, void* stream);
+int trec_topk_pad_counts(const int64_t* indptr_t, int32_t n_sb, int32_t rows_wg, int32_t* cnt_pad, void* stream);
+int trec_exclusive_scan_i32(const int32_t* counts, int64_t n, int64_t* workspace_i64, int64_t* out, void* stream);
+int trec_topk_fill_groups(const int64_t* pstart, const int64_t* indptr_t, const int32_t* users_t, const int32_t* perm_t,
+                          int32_t n_sb, int32_t rows_wg, int64_t max_rows, const void* users_op, int32_t row_bytes,
+                          const float* user_bias, const float* user_sq, void* G, float* g_bias, float* g_sq,
+                          int32_t* row_pair, int32_t* rblock_chunk, void* stream);
+int trec_score_gemm_topk_grouped(const void* users_g, const void* items, int32_t dtype, int32_t kpad, int64_t n_rows_g,
+                                 int64_t n_items, int32_t item_index_base, const float* user_bias_g,
+                                 const float* item_bias, int32_t mode, const float* user_sqnorm_g,
+                                 const float* item_sqnorm, int32_t sb_rows, const int32_t* rblock_chunk,
+                                 const int32_t* row_pair, int32_t capacity, float* part_vals, int32_t* part_idx,
+                                 int32_t variant, void* stream);
+
 /* k best of n_cand candidates per user, ordered (value desc, index asc) = tf.nn.top_k tie rule; also the merge
  * step after the all-gather of per-shard lists */
 int trec_topk_merge(const float* part_vals, const int32_t* part_idx, int64_t n_users, int32_t n_cand, int32_t k,

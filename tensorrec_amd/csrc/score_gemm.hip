@@ -26,6 +26,7 @@
 
 #define EPI_STORE 0
 #define EPI_TOPK 1
+#define EPI_BLOCKMAX 2     // per (user, item superblock) maximum only: stage 1 of the two-stage exact top-k
 #define KTOP_MAX 16
 
 struct ScoreParams {
@@ -47,6 +48,13 @@ struct ScoreParams {
     int capacity;             // slots per partial list in part_vals / part_idx (>= the kernel's KTOP)
     int n_parts;              // 2 * n_chunks
     int32_t t_index_base;     // added to item indices written by TOPK (item shards)
+    // BLOCKMAX: blockmax[(chunk superblock base + s) * bm_stride + user], superblock = sb_tiles tiles of BN rows
+    float* blockmax;
+    int64_t bm_stride;
+    int sb_tiles;
+    // grouped TOPK (stage 3): the item range of a workgroup comes from a table, results go where row_pair says
+    const int32_t* rblock_chunk;   // nullable [n_rblocks]: chunk (= superblock) index of this resident block, -1 = idle
+    const int32_t* row_pair;       // nullable [n_r]: output list id of a resident row, -1 = padding row
 };
 
 template <int DT> struct ElemOf;
@@ -133,8 +141,13 @@ __global__ __launch_bounds__(256, WPS) void score_gemm_kernel(ScoreParams p)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
 
+    constexpr bool LANEUSER = (EPI != EPI_STORE);     // acc = mfma(items, users): lane & 31 is the user
     const int rblock = blockIdx.x % p.n_rblocks;
-    const int chunk = blockIdx.x / p.n_rblocks;
+    int chunk = blockIdx.x / p.n_rblocks;
+    if (EPI == EPI_TOPK && p.rblock_chunk) {
+        chunk = p.rblock_chunk[rblock];
+        if (chunk < 0) return;                          // whole workgroup idle (padding of the grouped launch)
+    }
     const int64_t r_base = ((int64_t)rblock * 4 + wave) * (NCB * 32);       // first resident row of this wave
     const int64_t t_begin = (int64_t)chunk * p.chunk_len;
     const int64_t t_end = (t_begin + p.chunk_len < p.n_t) ? t_begin + p.chunk_len : p.n_t;
@@ -159,7 +172,7 @@ __global__ __launch_bounds__(256, WPS) void score_gemm_kernel(ScoreParams p)
     float r_bias_col[NCB], r_sq_col[NCB];          // TOPK: my user's bias / squared norm (lane & 31 is the user)
     float* r_bias_lds = (float*)(smem + 2 * TILE_BYTES);   // STORE: per resident row, read back as float4 per 4-row group
     float* r_sq_lds = r_bias_lds + RW;
-    if (EPI == EPI_TOPK) {
+    if (LANEUSER) {
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
             int64_t u = r_base + cb * 32 + l31;
@@ -191,7 +204,10 @@ __global__ __launch_bounds__(256, WPS) void score_gemm_kernel(ScoreParams p)
             for (int j = 0; j < KTOP; ++j) { tv[cb][j] = -INFINITY; ti[cb][j] = -1; }
         }
     }
-    float* tside = (float*)(smem + 2 * TILE_BYTES);           // TOPK side data, [2][TSIDE]
+    float* tside = (float*)(smem + 2 * TILE_BYTES);           // TOPK / BLOCKMAX side data, [2][TSIDE]
+    float bm[NCB];                                            // BLOCKMAX: running maximum over the current superblock
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) bm[cb] = -INFINITY;
 
     // ---- staging of the streamed tile: slot q = i*256 + tid  ->  (row, physical chunk) ----
     u32x4 stage[GLDS ? 1 : NSLOT];
@@ -210,7 +226,7 @@ __global__ __launch_bounds__(256, WPS) void score_gemm_kernel(ScoreParams p)
     auto stage_issue = [&](int tile, int buf) {
         const int64_t row0 = t_begin + (int64_t)tile * BN;
         const bool clamp = row0 + BN > p.n_t;                 // wave-uniform
-        if (EPI == EPI_TOPK && tid < BN) {
+        if (LANEUSER && tid < BN) {
             int64_t g = row0 + tid;
             const bool ok = g < p.n_t;
             if (!ok) g = p.n_t - 1;
@@ -236,7 +252,7 @@ __global__ __launch_bounds__(256, WPS) void score_gemm_kernel(ScoreParams p)
         }
     };
     auto stage_commit = [&](int buf) {
-        if (EPI == EPI_TOPK && tid < BN) {
+        if (LANEUSER && tid < BN) {
             float* sd = tside + buf * TSIDE;
             sd[tid] = side_b;
             sd[BN + tid] = side_q;
@@ -281,7 +297,7 @@ __global__ __launch_bounds__(256, WPS) void score_gemm_kernel(ScoreParams p)
                     const bf16x8 tf = *(const bf16x8*)(rowp + (((ks * 2 + half) ^ sw) * 16));
 #pragma unroll
                     for (int cb = 0; cb < NCB; ++cb) {
-                        if (EPI == EPI_TOPK) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf, rfb[cb][ks], acc[cb], 0, 0, 0);
+                        if (LANEUSER) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf, rfb[cb][ks], acc[cb], 0, 0, 0);
                         else acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rfb[cb][ks], tf, acc[cb], 0, 0, 0);
                     }
                 } else {
@@ -289,7 +305,7 @@ __global__ __launch_bounds__(256, WPS) void score_gemm_kernel(ScoreParams p)
                     const float tf = *(const float*)(rowp + (((k >> 2) ^ sw) * 16) + (k & 3) * 4);
 #pragma unroll
                     for (int cb = 0; cb < NCB; ++cb) {
-                        if (EPI == EPI_TOPK) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(tf, rff[cb][ks], acc[cb], 0, 0, 0);
+                        if (LANEUSER) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(tf, rff[cb][ks], acc[cb], 0, 0, 0);
                         else acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(rff[cb][ks], tf, acc[cb], 0, 0, 0);
                     }
                 }
@@ -297,7 +313,43 @@ __global__ __launch_bounds__(256, WPS) void score_gemm_kernel(ScoreParams p)
 
             if (PRIO) __builtin_amdgcn_s_setprio(0);
             const int64_t blk_row0 = tile_row0 + rb * 32;     // first streamed row (item) of this 32-block
-            if (EPI == EPI_TOPK && (ABL & 3) == 1) {
+            if (EPI == EPI_BLOCKMAX) {
+                // stage 1 of the two-stage top-k: only the maximum EXACT score of this 32-row block per user, folded
+                // into the superblock maximum.  No lists, no data-dependent branch: every wave does the same work.
+                const float* sd = tside + buf * TSIDE;
+                const int rows_left = (int)(p.n_t - t_begin) - (t * BN + rb * 32);
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) {
+                    float m;
+                    if (!BIAS && !EUCLID && !partial) {
+                        m = fmaxf(fmaxf(acc[cb][0], acc[cb][1]), acc[cb][2]);
+#pragma unroll
+                        for (int r = 3; r < 15; r += 2) m = fmaxf(fmaxf(m, acc[cb][r]), acc[cb][r + 1]);
+                        m = fmaxf(m, acc[cb][15]);
+                    } else {
+                        m = -INFINITY;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            f32x4 tb4, tq4;
+                            if (BIAS) tb4 = *(const f32x4*)(sd + rb * 32 + 8 * q + 4 * half);
+                            if (EUCLID) tq4 = *(const f32x4*)(sd + BN + rb * 32 + 8 * q + 4 * half);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                float v = acc[cb][4 * q + e];
+                                if (EUCLID) {
+                                    float dist = (r_sq_col[cb] - 2.0f * v) + tq4[e];
+                                    dist = fmaxf(dist, 1e-16f);
+                                    v = -1.0f * sqrtf(dist);
+                                }
+                                if (BIAS) v = (v + r_bias_col[cb]) + tb4[e];
+                                if (partial && 8 * q + 4 * half + e >= rows_left) v = -INFINITY;
+                                m = fmaxf(m, v);
+                            }
+                        }
+                    }
+                    bm[cb] = fmaxf(bm[cb], m);
+                }
+            } else if (EPI == EPI_TOPK && (ABL & 3) == 1) {
 #pragma unroll
                 for (int cb = 0; cb < NCB; ++cb) keep_alive(acc[cb]);
             } else if (EPI == EPI_TOPK) {
@@ -400,6 +452,17 @@ __global__ __launch_bounds__(256, WPS) void score_gemm_kernel(ScoreParams p)
             }
         }
 
+        if (EPI == EPI_BLOCKMAX && (((t + 1) % p.sb_tiles) == 0 || t + 1 == n_tiles)) {
+            // end of a superblock: combine the two half-wave maxima of each user, 32 consecutive floats per store
+            const int64_t sb = t_begin / ((int64_t)p.sb_tiles * BN) + t / p.sb_tiles;
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                const float v = fmaxf(bm[cb], __shfl_xor(bm[cb], 32, 64));
+                const int64_t u = r_base + cb * 32 + l31;
+                if (half == 0 && u < p.n_r) p.blockmax[sb * p.bm_stride + u] = v;
+                bm[cb] = -INFINITY;
+            }
+        }
         if (t + 1 < n_tiles) stage_commit(buf ^ 1);
         __syncthreads();
     }
@@ -408,8 +471,10 @@ __global__ __launch_bounds__(256, WPS) void score_gemm_kernel(ScoreParams p)
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
             const int64_t u = r_base + cb * 32 + l31;
-            if (u < p.n_r) {
-                const int64_t o = (u * p.n_parts + (chunk * 2 + half)) * p.capacity;
+            int64_t list = -1;
+            if (u < p.n_r) list = p.row_pair ? (int64_t)p.row_pair[u] * 2 + half : u * p.n_parts + (chunk * 2 + half);
+            if (list >= 0) {
+                const int64_t o = list * p.capacity;
                 if (KTOP % 4 == 0 && p.capacity == KTOP) {
 #pragma unroll
                     for (int j = 0; j + 3 < KTOP; j += 4) {
@@ -510,10 +575,11 @@ template <int DT, int KT, int BN, int NCB, int EPI, bool GLDS, bool EUCLID, int 
 static int launch_score_b(const ScoreParams& p, hipStream_t st)
 {
     constexpr int LDS = 2 * BN * KT * ElemOf<DT>::BYTES +
-                        (EPI == EPI_STORE ? 2 * 4 * NCB * 32 * 4 : 2 * (2 * BN + 32) * 4);
+                        (EPI == EPI_STORE ? 2 * 4 * NCB * 32 * 4 : 2 * (2 * BN + 32) * 4);     // TOPK and BLOCKMAX: side data
     // 2 workgroups per CU (256 registers per lane) unless the resident fragments + top-k lists need more
     constexpr int WPS = WPS_OVERRIDE ? WPS_OVERRIDE
-                                     : (((DT == 0 && KT >= 128) || KT == 256 || (EUCLID && KT >= 128)) ? 1 : 2);
+                        : (EPI == EPI_BLOCKMAX ? ((KT == 256 || (DT == 0 && KT >= 128)) ? 2 : 3)   // no lists: small
+                                               : (((DT == 0 && KT >= 128) || KT == 256 || (EUCLID && KT >= 128)) ? 1 : 2));
     auto kern = score_gemm_kernel<DT, KT, BN, NCB, EPI, GLDS, EUCLID, WPS, KTOP, BIAS, ABL>;
     static bool attr_set = false;
     if (!attr_set && LDS > 32 * 1024) {
@@ -682,6 +748,54 @@ extern "C" int trec_score_gemm_topk(const void* users, const void* items, int32_
     if (capacity == 8) return dispatch_score<EPI_TOPK, 8>(dtype, kpad, variant, p, (hipStream_t)stream);
     if (capacity == 12) return dispatch_score<EPI_TOPK, 12>(dtype, kpad, variant, p, (hipStream_t)stream);
     return dispatch_score<EPI_TOPK, 16>(dtype, kpad, variant, p, (hipStream_t)stream);
+}
+
+// ---- two-stage exact top-k: stage 1 (per-superblock maxima) and stage 3b (grouped re-scoring) ----------------------
+// superblock rows must be a multiple of 128 (every tile height in use divides it)
+extern "C" int trec_score_gemm_blockmax(const void* users, const void* items, int32_t dtype, int32_t kpad,
+                                        int64_t n_users, int64_t n_items, const float* user_bias,
+                                        const float* item_bias, int32_t mode, const float* user_sqnorm,
+                                        const float* item_sqnorm, int32_t sb_rows, int32_t n_chunks, float* blockmax,
+                                        int64_t bm_stride, int32_t variant, void* stream)
+{
+    ScoreParams p = {};
+    TREC_REQUIRE(blockmax && bm_stride >= n_users, "trec_score_gemm_blockmax: bad output");
+    TREC_REQUIRE(sb_rows >= 128 && sb_rows % 128 == 0, "trec_score_gemm_blockmax: sb_rows must be a multiple of 128");
+    int rc = fill_common(p, users, items, dtype, kpad, n_users, n_items, user_bias, item_bias, mode, user_sqnorm,
+                         item_sqnorm, n_chunks);
+    if (rc) return rc;
+    const ScoreCfg c = score_cfg(dtype, kpad);
+    p.chunk_len = ceil_div64(ceil_div64(n_items, n_chunks), sb_rows) * sb_rows;        // chunks are whole superblocks
+    p.n_chunks = (int)ceil_div64(n_items, p.chunk_len);
+    p.blockmax = blockmax; p.bm_stride = bm_stride; p.sb_tiles = sb_rows / c.bn;
+    return dispatch_score<EPI_BLOCKMAX, 8>(dtype, kpad, variant, p, (hipStream_t)stream);
+}
+
+// users_g: operand rows gathered by trec_topk_fill_groups ([n_rows_g, kpad], n_rows_g a multiple of the rows per
+// workgroup); workgroup w re-scores superblock rblock_chunk[w] (rows [s*sb_rows, (s+1)*sb_rows) of `items`) for its
+// rows and writes the two half-wave lists of row r to list ids 2*row_pair[r], 2*row_pair[r]+1 of part_vals / part_idx.
+extern "C" int trec_score_gemm_topk_grouped(const void* users_g, const void* items, int32_t dtype, int32_t kpad,
+                                            int64_t n_rows_g, int64_t n_items, int32_t item_index_base,
+                                            const float* user_bias_g, const float* item_bias, int32_t mode,
+                                            const float* user_sqnorm_g, const float* item_sqnorm, int32_t sb_rows,
+                                            const int32_t* rblock_chunk, const int32_t* row_pair, int32_t capacity,
+                                            float* part_vals, int32_t* part_idx, int32_t variant, void* stream)
+{
+    ScoreParams p = {};
+    TREC_REQUIRE(part_vals && part_idx && rblock_chunk && row_pair, "trec_score_gemm_topk_grouped: null pointer");
+    TREC_REQUIRE(capacity == 8 || capacity == 12 || capacity == 16, "trec_score_gemm_topk_grouped: capacity must be 8, 12 or 16");
+    TREC_REQUIRE(sb_rows >= 128 && sb_rows % 128 == 0, "trec_score_gemm_topk_grouped: sb_rows must be a multiple of 128");
+    if (n_rows_g == 0) return TREC_OK;
+    int rc = fill_common(p, users_g, items, dtype, kpad, n_rows_g, n_items, user_bias_g, item_bias, mode,
+                         user_sqnorm_g, item_sqnorm, 1);
+    if (rc) return rc;
+    p.chunk_len = sb_rows; p.n_chunks = 1;
+    p.rblock_chunk = rblock_chunk; p.row_pair = row_pair;
+    p.part_vals = part_vals; p.part_idx = part_idx; p.n_parts = 2; p.t_index_base = item_index_base;
+    p.capacity = capacity;
+    if (capacity == 8) return dispatch_score<EPI_TOPK, 8>(dtype, kpad, variant & 1, p, (hipStream_t)stream);
+    if (capacity == 12) return dispatch_score<EPI_TOPK, 12>(dtype, kpad, variant & 1, p, (hipStream_t)stream);
+    return dispatch_score<EPI_TOPK, 16>(dtype, kpad, variant & 1, p, (hipStream_t)stream);
 }
 
 extern "C" int trec_topk_merge(const float* part_vals, const int32_t* part_idx, int64_t n_users, int32_t n_cand,

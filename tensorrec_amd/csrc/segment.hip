@@ -123,3 +123,18 @@ extern "C" int trec_group_pairs_by_item(const int32_t* xu, const int32_t* xi, in
     hipLaunchKernelGGL(seg_fill_kernel, dim3((unsigned)gb), dim3(256), 0, st, xu, xi, n_pairs, pairs_per_user, indptr_t, cursor, users_t, perm_t);
     return trec_check_launch("trec_group_pairs_by_item");
 }
+
+// exclusive prefix sum of int32 counts into int64: out[i] = sum_{j<i} counts[j], out[n] = total.
+// workspace_i64: ceil(n/1024) + 1 int64
+extern "C" int trec_exclusive_scan_i32(const int32_t* counts, int64_t n, int64_t* workspace_i64, int64_t* out, void* stream)
+{
+    TREC_REQUIRE(counts && workspace_i64 && out && n >= 1, "trec_exclusive_scan_i32: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const int n_blocks = (int)ceil_div64(n, 1024);
+    int64_t* block_sum = workspace_i64;
+    int64_t* total = workspace_i64 + n_blocks;
+    hipLaunchKernelGGL(seg_scan_local_kernel, dim3((unsigned)n_blocks), dim3(256), 0, st, counts, n, out, block_sum);
+    hipLaunchKernelGGL(seg_scan_blocks_kernel, dim3(1), dim3(256), 0, st, block_sum, n_blocks, total);
+    hipLaunchKernelGGL(seg_add_offsets_kernel, dim3((unsigned)ceil_div64(n + 1, 256)), dim3(256), 0, st, out, n, block_sum, total);
+    return trec_check_launch("trec_exclusive_scan_i32");
+}

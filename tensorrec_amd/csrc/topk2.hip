@@ -1,0 +1,170 @@
+// tensorrec_amd/csrc/topk2.hip -- stages 2 and 3a of the two-stage exact top-k (stage 1 and 3b live in score_gemm.hip).
+//
+//   stage 1  score kernel, BLOCKMAX epilogue: M[s][u] = max exact score of user u over item superblock s
+//   stage 2  select_blocks_kernel: per user the K superblocks with the largest maxima, order (max desc, s asc)
+//   stage 3a group (user, slot) pairs by superblock (segment.hip counting sort), pad every group to whole workgroups,
+//            gather the users' operand rows into that order
+//   stage 3b score kernel, grouped TOPK epilogue: each workgroup re-scores ONE superblock for 256 gathered users
+//   stage 4  trec_topk_merge over the K * 2 lists of each user
+//
+// Exactness (ties included).  Let x be one of the true top-K items (order: value desc, index asc) and X its superblock.
+// If K superblocks B_1..B_K ranked before X under (max desc, s asc), each holds an item y_j with value max(B_j) >= max(X)
+// >= value(x); where the values are equal, B_j < X as superblocks are index ranges, so index(y_j) < index(x).  Then K
+// distinct items beat x -- contradiction.  Hence the K selected superblocks contain the whole top-K.
+#include "common.hpp"
+
+template <int KSEL>
+__device__ __forceinline__ void sel_insert(float (&tv)[KSEL], int32_t (&ti)[KSEL], float s, int32_t id)
+{
+    bool ge_j = tv[KSEL - 1] >= s;
+#pragma unroll
+    for (int j = KSEL - 1; j >= 0; --j) {
+        const bool ge_jm1 = (j == 0) ? true : (tv[j - 1] >= s);
+        const float pv = (j == 0) ? 0.f : tv[j - 1];
+        const int32_t pi = (j == 0) ? 0 : ti[j - 1];
+        tv[j] = ge_j ? tv[j] : (ge_jm1 ? s : pv);
+        ti[j] = ge_j ? ti[j] : (ge_jm1 ? id : pi);
+        ge_j = ge_jm1;
+    }
+}
+
+// one lane per user; blockmax is [n_sb][stride] so a wave reads 64 consecutive users per superblock (coalesced)
+template <int KSEL>
+__global__ __launch_bounds__(256) void select_blocks_kernel(const float* __restrict__ blockmax, int32_t n_sb,
+                                                           int64_t n_users, int64_t stride, int32_t k,
+                                                           int32_t* __restrict__ sel)
+{
+    const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool ok = u < n_users;
+    float tv[KSEL];
+    int32_t ti[KSEL];
+#pragma unroll
+    for (int j = 0; j < KSEL; ++j) { tv[j] = -INFINITY; ti[j] = -1; }
+    // slot k-1 (not KSEL-1) is the threshold: lists longer than k are never needed
+    for (int32_t s = 0; s < n_sb; ++s) {
+        const float v = ok ? blockmax[(int64_t)s * stride + u] : -INFINITY;
+        const bool hit = (v > tv[KSEL - 1]) || (ti[KSEL - 1] < 0 && ok);      // strict: earlier superblocks win ties
+        if (__builtin_amdgcn_ballot_w64(hit) != 0ull) sel_insert<KSEL>(tv, ti, hit ? v : -INFINITY, hit ? s : -1);
+    }
+    if (ok) {
+#pragma unroll
+        for (int j = 0; j < KSEL; ++j)
+            if (j < k) sel[u * k + j] = ti[j];
+    }
+}
+
+// keys for the counting sort: superblock id, or n_sb (a dummy bucket) for empty slots
+__global__ __launch_bounds__(256) void group_keys_kernel(const int32_t* __restrict__ sel, int64_t n, int32_t n_sb,
+                                                        int32_t* __restrict__ keys)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) keys[i] = sel[i] >= 0 ? sel[i] : n_sb;
+}
+
+// padded group sizes: every superblock's list of users is rounded up to whole workgroups of `rows_wg` rows
+__global__ __launch_bounds__(256) void pad_counts_kernel(const int64_t* __restrict__ indptr_t, int32_t n_sb,
+                                                        int32_t rows_wg, int32_t* __restrict__ cnt_pad)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i > n_sb) return;
+    if (i == n_sb) { cnt_pad[i] = 0; return; }                      // the dummy bucket is never re-scored
+    const int64_t c = indptr_t[i + 1] - indptr_t[i];
+    cnt_pad[i] = (int32_t)((c + rows_wg - 1) / rows_wg * rows_wg);
+}
+
+// one thread per 16-byte chunk of the gathered operand matrix G[max_rows][row_bytes]
+__global__ __launch_bounds__(256) void fill_groups_kernel(
+    const int64_t* __restrict__ pstart, const int64_t* __restrict__ indptr_t, const int32_t* __restrict__ users_t,
+    const int32_t* __restrict__ perm_t, int32_t n_sb, int32_t rows_wg, int64_t max_rows, const char* __restrict__ users_op,
+    int32_t row_bytes, const float* __restrict__ user_bias, const float* __restrict__ user_sq, char* __restrict__ G,
+    float* __restrict__ g_bias, float* __restrict__ g_sq, int32_t* __restrict__ row_pair,
+    int32_t* __restrict__ rblock_chunk)
+{
+    const int ch = row_bytes / 16;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t v = idx / ch;
+    const int c = (int)(idx - v * ch);
+    if (v >= max_rows) return;
+    const int64_t total = pstart[n_sb];
+    int32_t sb = -1;
+    int64_t src_user = 0;
+    int32_t pair = -1;
+    if (v < total) {
+        int lo = 0, hi = n_sb - 1;                                  // last sb with pstart[sb] <= v and a non-empty group
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (pstart[mid] <= v) lo = mid; else hi = mid - 1;
+        }
+        sb = lo;
+        const int64_t o = v - pstart[sb];
+        const int64_t cnt = indptr_t[sb + 1] - indptr_t[sb];
+        if (o < cnt) {
+            const int64_t e = indptr_t[sb] + o;
+            src_user = users_t[e];
+            pair = perm_t[e];
+        }
+    }
+    *(u32x4*)(G + v * row_bytes + c * 16) = *(const u32x4*)(users_op + src_user * row_bytes + c * 16);
+    if (c == 0) {
+        row_pair[v] = pair;
+        if (g_bias) g_bias[v] = user_bias[src_user];
+        if (g_sq) g_sq[v] = user_sq[src_user];
+        if (v % rows_wg == 0) rblock_chunk[v / rows_wg] = sb;      // -1 beyond the padded total: workgroup exits at once
+    }
+}
+
+extern "C" int trec_topk_select_blocks(const float* blockmax, int32_t n_sb, int64_t n_users, int64_t stride, int32_t k,
+                                       int32_t* sel, void* stream)
+{
+    TREC_REQUIRE(blockmax && sel, "trec_topk_select_blocks: null pointer");
+    TREC_REQUIRE(k >= 1 && k <= 16 && n_sb >= 1, "trec_topk_select_blocks: need 1 <= k <= 16, n_sb >= 1");
+    if (n_users == 0) return TREC_OK;
+    const unsigned blocks = (unsigned)ceil_div64(n_users, 256);
+    hipStream_t st = (hipStream_t)stream;
+    // the list length IS k here (threshold = k-th best): instantiate the lengths in use
+#define TREC_SEL(KS) hipLaunchKernelGGL((select_blocks_kernel<KS>), dim3(blocks), dim3(256), 0, st, blockmax, n_sb, n_users, stride, k, sel)
+    switch (k) {
+        case 1: TREC_SEL(1); break;   case 2: TREC_SEL(2); break;   case 3: TREC_SEL(3); break;   case 4: TREC_SEL(4); break;
+        case 5: TREC_SEL(5); break;   case 6: TREC_SEL(6); break;   case 7: TREC_SEL(7); break;   case 8: TREC_SEL(8); break;
+        case 9: TREC_SEL(9); break;   case 10: TREC_SEL(10); break; case 11: TREC_SEL(11); break; case 12: TREC_SEL(12); break;
+        case 13: TREC_SEL(13); break; case 14: TREC_SEL(14); break; case 15: TREC_SEL(15); break; default: TREC_SEL(16); break;
+    }
+#undef TREC_SEL
+    return trec_check_launch("trec_topk_select_blocks");
+}
+
+extern "C" int trec_topk_group_keys(const int32_t* sel, int64_t n, int32_t n_sb, int32_t* keys, void* stream)
+{
+    TREC_REQUIRE(sel && keys, "trec_topk_group_keys: null pointer");
+    if (n == 0) return TREC_OK;
+    hipLaunchKernelGGL(group_keys_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, (hipStream_t)stream, sel, n,
+                       n_sb, keys);
+    return trec_check_launch("trec_topk_group_keys");
+}
+
+extern "C" int trec_topk_pad_counts(const int64_t* indptr_t, int32_t n_sb, int32_t rows_wg, int32_t* cnt_pad, void* stream)
+{
+    TREC_REQUIRE(indptr_t && cnt_pad && rows_wg >= 1, "trec_topk_pad_counts: bad arguments");
+    hipLaunchKernelGGL(pad_counts_kernel, dim3((unsigned)((n_sb + 1 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       indptr_t, n_sb, rows_wg, cnt_pad);
+    return trec_check_launch("trec_topk_pad_counts");
+}
+
+extern "C" int trec_topk_fill_groups(const int64_t* pstart, const int64_t* indptr_t, const int32_t* users_t,
+                                     const int32_t* perm_t, int32_t n_sb, int32_t rows_wg, int64_t max_rows,
+                                     const void* users_op, int32_t row_bytes, const float* user_bias,
+                                     const float* user_sq, void* G, float* g_bias, float* g_sq, int32_t* row_pair,
+                                     int32_t* rblock_chunk, void* stream)
+{
+    TREC_REQUIRE(pstart && indptr_t && users_t && perm_t && users_op && G && row_pair && rblock_chunk,
+                 "trec_topk_fill_groups: null pointer");
+    TREC_REQUIRE(row_bytes % 16 == 0 && max_rows % rows_wg == 0, "trec_topk_fill_groups: row_bytes % 16, max_rows % rows_wg");
+    TREC_REQUIRE((g_bias == nullptr) == (user_bias == nullptr) && (g_sq == nullptr) == (user_sq == nullptr),
+                 "trec_topk_fill_groups: bias / sqnorm buffers must come in pairs");
+    if (max_rows == 0) return TREC_OK;
+    const int64_t chunks = max_rows * (row_bytes / 16);
+    hipLaunchKernelGGL(fill_groups_kernel, dim3((unsigned)ceil_div64(chunks, 256)), dim3(256), 0, (hipStream_t)stream,
+                       pstart, indptr_t, users_t, perm_t, n_sb, rows_wg, max_rows, (const char*)users_op, row_bytes,
+                       user_bias, user_sq, (char*)G, g_bias, g_sq, row_pair, rblock_chunk);
+    return trec_check_launch("trec_topk_fill_groups");
+}

@@ -425,10 +425,26 @@ def topk_chunks_for(n_users, dtype, kpad, n_items):
     return chunks
 
 
+TWO_STAGE_MIN_ITEMS = 16384      # below this the direct fused kernel is cheaper than the extra passes
+SUPERBLOCK_ROWS = 512
+
+
 def score_topk(users_op, items_op, dtype, kpad, k, user_bias=None, item_bias=None, mode=MODE_DOT, user_sq=None,
-               item_sq=None, item_index_base=0, n_chunks=None, variant=0, workspace=None):
-    """Fused score + per-user top-k without materialising [U, I].  Returns (values [U, k], item indices [U, k]),
-    ordered (value desc, index asc)."""
+               item_sq=None, item_index_base=0, n_chunks=None, variant=1, workspace=None, method="auto"):
+    """Exact per-user top-k of the score matrix without materialising it.  Returns (values [U, k], item ids [U, k]),
+    ordered (value desc, index asc).  ``method``: 'direct' (one fused pass with per-lane lists), 'two_stage'
+    (superblock maxima -> select -> re-score, data-independent cost) or 'auto'."""
+    if method == "auto":
+        method = "two_stage" if items_op.shape[0] >= TWO_STAGE_MIN_ITEMS and n_chunks is None else "direct"
+    if method == "two_stage":
+        return score_topk_two_stage(users_op, items_op, dtype, kpad, k, user_bias, item_bias, mode, user_sq, item_sq,
+                                    item_index_base, variant=variant)
+    return score_topk_direct(users_op, items_op, dtype, kpad, k, user_bias, item_bias, mode, user_sq, item_sq,
+                             item_index_base, n_chunks, variant, workspace)
+
+
+def score_topk_direct(users_op, items_op, dtype, kpad, k, user_bias=None, item_bias=None, mode=MODE_DOT, user_sq=None,
+                      item_sq=None, item_index_base=0, n_chunks=None, variant=1, workspace=None):
     cap = N.query("trec_score_topk_capacity", int(k))
     if cap < 0:
         raise ValueError("fused top-k supports k <= 16 (got %d)" % k)
@@ -446,6 +462,64 @@ def score_topk(users_op, items_op, dtype, kpad, k, user_bias=None, item_bias=Non
                N.ptr(user_bias), N.ptr(item_bias), mode, N.ptr(user_sq), N.ptr(item_sq), n_chunks, cap, N.ptr(pv),
                N.ptr(pi), variant)
     return topk_merge(pv.reshape(n_u, n_parts * cap), pi.reshape(n_u, n_parts * cap), k)
+
+
+def score_topk_two_stage(users_op, items_op, dtype, kpad, k, user_bias=None, item_bias=None, mode=MODE_DOT,
+                         user_sq=None, item_sq=None, item_index_base=0, sb_rows=None, variant=1, n_chunks=None):
+    """See include/tensorrec_hip.h ("Two-stage exact top-k") and csrc/topk2.hip for the exactness argument."""
+    cap = N.query("trec_score_topk_capacity", int(k))
+    if cap < 0:
+        raise ValueError("fused top-k supports k <= 16 (got %d)" % k)
+    dev = users_op.device
+    n_u, n_i = users_op.shape[0], items_op.shape[0]
+    sb_rows = int(sb_rows or SUPERBLOCK_ROWS)
+    n_sb = (n_i + sb_rows - 1) // sb_rows
+    ksel = min(int(k), n_sb)
+    rows_wg = N.query("trec_score_rows_per_workgroup", dtype, kpad)
+    if n_chunks is None:       # enough workgroups for 3 per CU even with few users; chunks are whole superblocks
+        rblocks = (n_u + rows_wg - 1) // rows_wg
+        n_chunks = 1
+        while rblocks * n_chunks < 1536 and n_chunks * 2 <= n_sb:
+            n_chunks *= 2
+    # ---- stage 1: superblock maxima
+    blockmax = torch.empty((n_sb, n_u), dtype=torch.float32, device=dev)
+    with _timed("score_gemm_blockmax"):
+        N.call("trec_score_gemm_blockmax", N.ptr(users_op), N.ptr(items_op), dtype, kpad, n_u, n_i, N.ptr(user_bias),
+               N.ptr(item_bias), mode, N.ptr(user_sq), N.ptr(item_sq), sb_rows, n_chunks, N.ptr(blockmax), n_u, variant)
+    # ---- stage 2: the ksel best superblocks of every user
+    sel = torch.empty((n_u, ksel), dtype=torch.int32, device=dev)
+    with _timed("topk_select_blocks"):
+        N.call("trec_topk_select_blocks", N.ptr(blockmax), n_sb, n_u, n_u, ksel, N.ptr(sel))
+    del blockmax
+    # ---- stage 3a: group (user, slot) pairs by superblock, pad groups to whole workgroups, gather operand rows
+    n_pairs = n_u * ksel
+    keys = torch.empty((n_pairs,), dtype=torch.int32, device=dev)
+    N.call("trec_topk_group_keys", N.ptr(sel), n_pairs, n_sb, N.ptr(keys))
+    indptr_t, users_t, perm_t = group_pairs_by_item(None, keys, ksel, n_sb + 1)
+    cnt_pad = torch.empty((n_sb + 1,), dtype=torch.int32, device=dev)
+    N.call("trec_topk_pad_counts", N.ptr(indptr_t), n_sb, rows_wg, N.ptr(cnt_pad))
+    pstart = torch.empty((n_sb + 2,), dtype=torch.int64, device=dev)
+    ws64 = torch.empty(((n_sb + 1 + 1023) // 1024 + 1,), dtype=torch.int64, device=dev)
+    N.call("trec_exclusive_scan_i32", N.ptr(cnt_pad), n_sb + 1, N.ptr(ws64), N.ptr(pstart))
+    max_rows = (n_pairs + min(n_sb, n_pairs) * (rows_wg - 1) + rows_wg - 1) // rows_wg * rows_wg
+    g_op = torch.empty((max_rows, kpad), dtype=users_op.dtype, device=dev)
+    g_bias = torch.empty((max_rows,), dtype=torch.float32, device=dev) if user_bias is not None else None
+    g_sq = torch.empty((max_rows,), dtype=torch.float32, device=dev) if user_sq is not None else None
+    row_pair = torch.empty((max_rows,), dtype=torch.int32, device=dev)
+    rblock_chunk = torch.empty((max_rows // rows_wg,), dtype=torch.int32, device=dev)
+    with _timed("topk_fill_groups"):
+        N.call("trec_topk_fill_groups", N.ptr(pstart), N.ptr(indptr_t), N.ptr(users_t), N.ptr(perm_t), n_sb, rows_wg,
+               max_rows, N.ptr(users_op), kpad * users_op.element_size(), N.ptr(user_bias), N.ptr(user_sq), N.ptr(g_op),
+               N.ptr(g_bias), N.ptr(g_sq), N.ptr(row_pair), N.ptr(rblock_chunk))
+    # ---- stage 3b: re-score the selected superblocks (every pair is written exactly once: ksel <= n_sb)
+    pv = torch.empty((n_pairs * 2, cap), dtype=torch.float32, device=dev)
+    pi = torch.full((n_pairs * 2, cap), -1, dtype=torch.int32, device=dev)      # unwritten lists read as empty
+    with _timed("score_gemm_topk_grouped"):
+        N.call("trec_score_gemm_topk_grouped", N.ptr(g_op), N.ptr(items_op), dtype, kpad, max_rows, n_i, item_index_base,
+               N.ptr(g_bias), N.ptr(item_bias), mode, N.ptr(g_sq), N.ptr(item_sq), sb_rows, N.ptr(rblock_chunk),
+               N.ptr(row_pair), cap, N.ptr(pv), N.ptr(pi), variant & 1)
+    # ---- stage 4: merge the ksel * 2 lists of every user
+    return topk_merge(pv.reshape(n_u, ksel * 2 * cap), pi.reshape(n_u, ksel * 2 * cap), k)
 
 
 def topk_merge(cand_vals, cand_idx, k):

@@ -653,3 +653,61 @@ def test_hip_path_vs_reference_source_fixtures(ops):
         assert np.allclose(cls().connect_serial_prediction_graph(u, v, xu, xi).cpu().numpy(), g["expected_serial"], **tol)
     g = sg["rank_predictions_ties"]
     assert np.array_equal(ops.rank_rows(dev(g["predictions"])).cpu().numpy(), g["expected_ranks"].astype(np.int32))
+
+
+# ------------------------------------------------------------------------------------------------ two-stage top-k
+@pytest.mark.parametrize("sb_rows,chunks", [(128, None), (256, 1), (512, 3)])
+@pytest.mark.parametrize("integer", [False, True])
+def test_two_stage_topk_fp32_exact(ops, sb_rows, chunks, integer):
+    """superblock maxima -> select -> grouped re-score -> merge == the reference's top-k bit for bit, ties included
+    (integer operands: thousands of exact ties, many superblocks with equal maxima)."""
+    u, v = _uv(333, 5000, 64, seed=sb_rows, integer=integer)
+    rng = np.random.default_rng(4)
+    ub, ib = rng.standard_normal(333).astype(np.float32), rng.standard_normal(5000).astype(np.float32)
+    if integer:
+        ub, ib = np.round(ub), np.round(ib)
+    u_op, _, kpad = ops.score_prep(dev(u), ops.DTYPE_F32)
+    v_op, _, _ = ops.score_prep(dev(v), ops.DTYPE_F32)
+    ref = O.score_dense_exact(u, v, ub, ib)
+    for k in (1, 10, 16):
+        vals, idx = ops.score_topk_two_stage(u_op, v_op, ops.DTYPE_F32, kpad, k, dev(ub), dev(ib), sb_rows=sb_rows,
+                                             n_chunks=chunks, item_index_base=0)
+        rv, ri = O.topk_rows(ref, k)
+        assert np.array_equal(idx.cpu().numpy(), ri), "k=%d" % k
+        assert np.array_equal(vals.cpu().numpy(), rv), "k=%d" % k
+    # unbiased + item shard offset
+    vals, idx = ops.score_topk_two_stage(u_op, v_op, ops.DTYPE_F32, kpad, 10, sb_rows=sb_rows, item_index_base=700)
+    rv, ri = O.topk_rows(O.score_dense_exact(u, v), 10)
+    assert np.array_equal(idx.cpu().numpy(), ri + 700) and np.array_equal(vals.cpu().numpy(), rv)
+
+
+def test_two_stage_topk_fewer_superblocks_than_k(ops):
+    u, v = _uv(100, 300, 32, seed=1)          # 3 superblocks of 128 < k = 10
+    u_op, _, kpad = ops.score_prep(dev(u), ops.DTYPE_F32)
+    v_op, _, _ = ops.score_prep(dev(v), ops.DTYPE_F32)
+    vals, idx = ops.score_topk_two_stage(u_op, v_op, ops.DTYPE_F32, kpad, 10, sb_rows=128)
+    rv, ri = O.topk_rows(O.score_dense_exact(u, v), 10)
+    assert np.array_equal(idx.cpu().numpy(), ri) and np.array_equal(vals.cpu().numpy(), rv)
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_two_stage_topk_bf16_and_euclid(ops, variant):
+    u, v = _uv(700, 20000, 128, seed=9)
+    rng = np.random.default_rng(5)
+    ub, ib = rng.standard_normal(700).astype(np.float32), rng.standard_normal(20000).astype(np.float32)
+    u_op, _, kpad = ops.score_prep(dev(u), ops.DTYPE_BF16)
+    v_op, _, _ = ops.score_prep(dev(v), ops.DTYPE_BF16)
+    scores = ops.score_store(u_op, v_op, ops.DTYPE_BF16, kpad, dev(ub), dev(ib)).cpu().numpy()
+    vals, idx = ops.score_topk(u_op, v_op, ops.DTYPE_BF16, kpad, 10, dev(ub), dev(ib), variant=variant)   # auto -> two-stage
+    rv, ri = O.topk_rows(scores, 10)
+    assert np.array_equal(vals.cpu().numpy(), rv) and np.array_equal(idx.cpu().numpy(), ri)
+    dv, di = ops.score_topk(u_op, v_op, ops.DTYPE_BF16, kpad, 10, dev(ub), dev(ib), variant=variant, method="direct")
+    assert np.array_equal(dv.cpu().numpy(), rv) and np.array_equal(di.cpu().numpy(), ri)
+    # euclidean, fp32
+    u, v = _uv(130, 17000, 40, seed=3)
+    u_op, u_sq, kpad = ops.score_prep(dev(u), ops.DTYPE_F32, want_sqnorm=True)
+    v_op, v_sq, _ = ops.score_prep(dev(v), ops.DTYPE_F32, want_sqnorm=True)
+    vals, idx = ops.score_topk(u_op, v_op, ops.DTYPE_F32, kpad, 5, mode=ops.MODE_EUCLIDEAN, user_sq=u_sq, item_sq=v_sq)
+    ref = O.score_dense_euclid_exact(u, v, u_sq.cpu().numpy(), v_sq.cpu().numpy())
+    rv, ri = O.topk_rows(ref, 5)
+    assert np.array_equal(idx.cpu().numpy(), ri) and np.array_equal(vals.cpu().numpy(), rv)
