@@ -87,6 +87,16 @@ __device__ __forceinline__ void keep_alive_mask(unsigned long long x)
 #endif
 }
 
+// returns x, but the compiler cannot see through it: keeps rare-path index math inside its (wave-uniform) branch
+// instead of being hoisted/if-converted into the common path
+__device__ __forceinline__ int opaque_uniform(int x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+s"(x));
+#endif
+    return x;
+}
+
 __device__ __forceinline__ bool wave_any(bool x) { return __builtin_amdgcn_ballot_w64(x) != 0ull; }
 
 // largest float strictly below x (x finite or -inf, never NaN): v >= x  <=>  v > float_pred(x)
@@ -316,21 +326,19 @@ __global__ __launch_bounds__(256, WPS) void score_gemm_kernel(ScoreParams p)
             if (EPI == EPI_BLOCKMAX) {
                 // stage 1 of the two-stage top-k: only the maximum EXACT score of this 32-row block per user, folded
                 // into the superblock maximum.  No lists, no data-dependent branch: every wave does the same work.
+                // Bias order: fp32 follows the reference, (s + b_u) + b_i per element; bf16 (no bit-exactness claim
+                // against fp32 anyway) uses (s + b_i) + b_u in ALL its epilogues, which lets b_u be added once after
+                // the max (fp32 addition is monotone, so max_r fl(x_r + b_u) == fl(max_r x_r + b_u)).
                 const float* sd = tside + buf * TSIDE;
-                const int rows_left = (int)(p.n_t - t_begin) - (t * BN + rb * 32);
 #pragma unroll
                 for (int cb = 0; cb < NCB; ++cb) {
                     float m;
-                    if (!BIAS && !EUCLID && !partial) {
-                        m = fmaxf(fmaxf(acc[cb][0], acc[cb][1]), acc[cb][2]);
-#pragma unroll
-                        for (int r = 3; r < 15; r += 2) m = fmaxf(fmaxf(m, acc[cb][r]), acc[cb][r + 1]);
-                        m = fmaxf(m, acc[cb][15]);
-                    } else {
+                    if (partial || EUCLID) {                        // wave-uniform: last tile of the last chunk, or euclid
+                        const int rows_left = opaque_uniform((int)(p.n_t - t_begin) - (t * BN + rb * 32));
                         m = -INFINITY;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            f32x4 tb4, tq4;
+                            f32x4 tb4 = {0.f, 0.f, 0.f, 0.f}, tq4 = {0.f, 0.f, 0.f, 0.f};
                             if (BIAS) tb4 = *(const f32x4*)(sd + rb * 32 + 8 * q + 4 * half);
                             if (EUCLID) tq4 = *(const f32x4*)(sd + BN + rb * 32 + 8 * q + 4 * half);
 #pragma unroll
@@ -341,11 +349,30 @@ __global__ __launch_bounds__(256, WPS) void score_gemm_kernel(ScoreParams p)
                                     dist = fmaxf(dist, 1e-16f);
                                     v = -1.0f * sqrtf(dist);
                                 }
-                                if (BIAS) v = (v + r_bias_col[cb]) + tb4[e];
-                                if (partial && 8 * q + 4 * half + e >= rows_left) v = -INFINITY;
+                                if (BIAS) v = (DT == 1) ? (v + tb4[e]) + r_bias_col[cb] : (v + r_bias_col[cb]) + tb4[e];
+                                if (8 * q + 4 * half + e >= rows_left) v = -INFINITY;
                                 m = fmaxf(m, v);
                             }
                         }
+                    } else if (BIAS) {
+                        f32x16 s = acc[cb];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const f32x4 tb4 = *(const f32x4*)(sd + rb * 32 + 8 * q + 4 * half);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                s[4 * q + e] = (DT == 1) ? s[4 * q + e] + tb4[e] : (s[4 * q + e] + r_bias_col[cb]) + tb4[e];
+                        }
+                        m = fmaxf(fmaxf(s[0], s[1]), s[2]);
+#pragma unroll
+                        for (int r = 3; r < 15; r += 2) m = fmaxf(fmaxf(m, s[r]), s[r + 1]);
+                        m = fmaxf(m, s[15]);
+                        if (DT == 1) m = m + r_bias_col[cb];
+                    } else {
+                        m = fmaxf(fmaxf(acc[cb][0], acc[cb][1]), acc[cb][2]);
+#pragma unroll
+                        for (int r = 3; r < 15; r += 2) m = fmaxf(fmaxf(m, acc[cb][r]), acc[cb][r + 1]);
+                        m = fmaxf(m, acc[cb][15]);
                     }
                     bm[cb] = fmaxf(bm[cb], m);
                 }
@@ -371,7 +398,8 @@ __global__ __launch_bounds__(256, WPS) void score_gemm_kernel(ScoreParams p)
                     unsigned long long need = ~0ull;
                     if (!EUCLID) {
                         float bound = fmaxf(fmaxf(fmaxf(gm[0], gm[1]), gm[2]), gm[3]);
-                        if (BIAS) bound = (bound + r_bias_col[cb]) + sd[2 * BN + rb];
+                        if (BIAS) bound = (DT == 1) ? (bound + sd[2 * BN + rb]) + r_bias_col[cb]
+                                                    : (bound + r_bias_col[cb]) + sd[2 * BN + rb];
                         need = __builtin_amdgcn_ballot_w64(bound > thr[cb]);
                     }
                     if ((ABL & 3) == 2) { keep_alive_mask(need); need = 0ull; }
@@ -392,15 +420,16 @@ __global__ __launch_bounds__(256, WPS) void score_gemm_kernel(ScoreParams p)
                                         dist = fmaxf(dist, 1e-16f);
                                         v = -1.0f * sqrtf(dist);
                                     }
-                                    if (BIAS) v = (v + r_bias_col[cb]) + tb4[e];
+                                    if (BIAS) v = (DT == 1) ? (v + tb4[e]) + r_bias_col[cb] : (v + r_bias_col[cb]) + tb4[e];
                                     s[4 * q + e] = v;
                                 }
                             }
                         }
                         if (partial) {      // clamped rows duplicate the last item: mask them (last tile of the last chunk only)
+                            const int rl = opaque_uniform(rows_left);
 #pragma unroll
                             for (int r = 0; r < 16; ++r)
-                                if (cd_row(r, half) >= rows_left) s[r] = -INFINITY;
+                                if (cd_row(r, half) >= rl) s[r] = -INFINITY;
                         }
                         const int32_t id0 = (int32_t)t_begin + blk_in_chunk + p.t_index_base + 4 * half;
 #pragma unroll
@@ -445,7 +474,7 @@ __global__ __launch_bounds__(256, WPS) void score_gemm_kernel(ScoreParams p)
                                 dist = fmaxf(dist, 1e-16f);
                                 v = -1.0f * sqrtf(dist);
                             }
-                            if (BIAS) v = (v + rb4[e]) + tbv;
+                            if (BIAS) v = (DT == 1) ? (v + tbv) + rb4[e] : (v + rb4[e]) + tbv;
                             if (item_ok && u < p.n_r) p.out[u * p.ld_out + item] = v;
                         }
                     }
