@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--variant", type=int, default=int(os.environ.get("TREC_SCORE_VARIANT", "1")))
     ap.add_argument("--chunks", type=int, default=0, help="item chunks per user block (0 = auto)")
     ap.add_argument("--method", default="auto", choices=["auto", "direct", "two_stage"])
+    ap.add_argument("--unbiased", action="store_true", help="diagnostic: model built with biased=False")
     ap.add_argument("--no-fit", action="store_true", help="skip the fit epochs/sec measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-users", type=int, default=1024)
@@ -175,8 +176,8 @@ def main():
         with torch.no_grad():
             user_repr = ops.spmm_raw(f_u.indptr, f_u.indices, f_u.values, None, U, f_u.nnz, w_u)          # K1
             item_repr = ops.spmm_raw(f_i.indptr, f_i.indices, f_i.values, None, n_local, f_i.nnz, w_i)    # K1
-            ub = ops.sparse_matvec(f_u, beta_u)
-            ib = ops.sparse_matvec(f_i, beta_i)
+            ub = None if args.unbiased else ops.sparse_matvec(f_u, beta_u)
+            ib = None if args.unbiased else ops.sparse_matvec(f_i, beta_i)
             u_op, _, _ = ops.score_prep(user_repr, dtype)
             i_op, _, _ = ops.score_prep(item_repr, dtype)
             if method == "direct":
