@@ -152,6 +152,8 @@ __global__ __launch_bounds__(256, WPS) void score_gemm_kernel(ScoreParams p)
     const int half = lane >> 5, l31 = lane & 31;
 
     constexpr bool LANEUSER = (EPI != EPI_STORE);     // acc = mfma(items, users): lane & 31 is the user
+    // bf16 dot/cosine with biases: the item bias is the initial accumulator (see the rb loop); euclidean needs the raw dot
+    constexpr bool BIAS_IN_ACC = BIAS && DT == 1 && !EUCLID;
     const int rblock = blockIdx.x % p.n_rblocks;
     int chunk = blockIdx.x / p.n_rblocks;
     if (EPI == EPI_TOPK && p.rblock_chunk) {
@@ -291,11 +293,35 @@ __global__ __launch_bounds__(256, WPS) void score_gemm_kernel(ScoreParams p)
 
 #pragma unroll 1
         for (int rb = 0; rb < BN / 32; ++rb) {
+            // bf16 + biases: the item bias IS the initial accumulator (C operand of the first MFMA) -- zero VALU cost.
+            // bf16 scores are therefore defined as fl-chain(b_i + sum_k u_k i_k) + b_u in every bf16 epilogue (there is
+            // no bit-exactness claim for bf16); padded rows carry b_i = -inf and mask themselves.  fp32 keeps the
+            // reference's order (s + b_u) + b_i with explicit adds.
             f32x16 acc[NCB];
+            if (BIAS_IN_ACC && LANEUSER) {
+                const float* sdi = tside + buf * TSIDE + rb * 32 + 4 * half;
+                f32x16 c0;
 #pragma unroll
-            for (int cb = 0; cb < NCB; ++cb)
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 tb4 = *(const f32x4*)(sdi + 8 * q);
+                    c0[4 * q] = tb4[0]; c0[4 * q + 1] = tb4[1]; c0[4 * q + 2] = tb4[2]; c0[4 * q + 3] = tb4[3];
+                }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
+                for (int cb = 0; cb < NCB; ++cb) acc[cb] = c0;
+            } else if (BIAS_IN_ACC) {
+                int64_t it = t_begin + (int64_t)t * BN + rb * 32 + l31;          // STORE: my column's item
+                if (it >= p.n_t) it = p.n_t - 1;
+                const float tbv0 = p.t_bias ? p.t_bias[it] : 0.f;
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[cb][r] = tbv0;
+            } else {
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
+            }
 
             const int lrow = rb * 32 + l31;
             const char* rowp = tile + lrow * RB;
@@ -349,30 +375,30 @@ __global__ __launch_bounds__(256, WPS) void score_gemm_kernel(ScoreParams p)
                                     dist = fmaxf(dist, 1e-16f);
                                     v = -1.0f * sqrtf(dist);
                                 }
-                                if (BIAS) v = (DT == 1) ? (v + tb4[e]) + r_bias_col[cb] : (v + r_bias_col[cb]) + tb4[e];
+                                if (BIAS) v = BIAS_IN_ACC ? v + r_bias_col[cb] : (v + r_bias_col[cb]) + tb4[e];
                                 if (8 * q + 4 * half + e >= rows_left) v = -INFINITY;
                                 m = fmaxf(m, v);
                             }
                         }
-                    } else if (BIAS) {
+                    } else if (BIAS && !BIAS_IN_ACC) {
                         f32x16 s = acc[cb];
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             const f32x4 tb4 = *(const f32x4*)(sd + rb * 32 + 8 * q + 4 * half);
 #pragma unroll
                             for (int e = 0; e < 4; ++e)
-                                s[4 * q + e] = (DT == 1) ? s[4 * q + e] + tb4[e] : (s[4 * q + e] + r_bias_col[cb]) + tb4[e];
+                                s[4 * q + e] = (s[4 * q + e] + r_bias_col[cb]) + tb4[e];
                         }
                         m = fmaxf(fmaxf(s[0], s[1]), s[2]);
 #pragma unroll
                         for (int r = 3; r < 15; r += 2) m = fmaxf(fmaxf(m, s[r]), s[r + 1]);
                         m = fmaxf(m, s[15]);
-                        if (DT == 1) m = m + r_bias_col[cb];
                     } else {
                         m = fmaxf(fmaxf(acc[cb][0], acc[cb][1]), acc[cb][2]);
 #pragma unroll
                         for (int r = 3; r < 15; r += 2) m = fmaxf(fmaxf(m, acc[cb][r]), acc[cb][r + 1]);
                         m = fmaxf(m, acc[cb][15]);
+                        if (BIAS) m = m + r_bias_col[cb];          // bf16: b_i already in the accumulator, b_u after the max
                     }
                     bm[cb] = fmaxf(bm[cb], m);
                 }
@@ -398,8 +424,8 @@ __global__ __launch_bounds__(256, WPS) void score_gemm_kernel(ScoreParams p)
                     unsigned long long need = ~0ull;
                     if (!EUCLID) {
                         float bound = fmaxf(fmaxf(fmaxf(gm[0], gm[1]), gm[2]), gm[3]);
-                        if (BIAS) bound = (DT == 1) ? (bound + sd[2 * BN + rb]) + r_bias_col[cb]
-                                                    : (bound + r_bias_col[cb]) + sd[2 * BN + rb];
+                        if (BIAS) bound = BIAS_IN_ACC ? bound + r_bias_col[cb]
+                                                      : (bound + r_bias_col[cb]) + sd[2 * BN + rb];
                         need = __builtin_amdgcn_ballot_w64(bound > thr[cb]);
                     }
                     if ((ABL & 3) == 2) { keep_alive_mask(need); need = 0ull; }
@@ -420,7 +446,7 @@ __global__ __launch_bounds__(256, WPS) void score_gemm_kernel(ScoreParams p)
                                         dist = fmaxf(dist, 1e-16f);
                                         v = -1.0f * sqrtf(dist);
                                     }
-                                    if (BIAS) v = (DT == 1) ? (v + tb4[e]) + r_bias_col[cb] : (v + r_bias_col[cb]) + tb4[e];
+                                    if (BIAS) v = BIAS_IN_ACC ? v + r_bias_col[cb] : (v + r_bias_col[cb]) + tb4[e];
                                     s[4 * q + e] = v;
                                 }
                             }
@@ -474,7 +500,7 @@ __global__ __launch_bounds__(256, WPS) void score_gemm_kernel(ScoreParams p)
                                 dist = fmaxf(dist, 1e-16f);
                                 v = -1.0f * sqrtf(dist);
                             }
-                            if (BIAS) v = (DT == 1) ? (v + tbv) + rb4[e] : (v + rb4[e]) + tbv;
+                            if (BIAS) v = BIAS_IN_ACC ? v + rb4[e] : (v + rb4[e]) + tbv;
                             if (item_ok && u < p.n_r) p.out[u * p.ld_out + item] = v;
                         }
                     }
