@@ -107,21 +107,22 @@ int trec_score_gemm_blockmax(const void* users, const void* items, int32_t dtype
                              int64_t n_items, const float* user_bias, const float* item_bias, int32_t mode,
                              const float* user_sqnorm, const float* item_sqnorm, int32_t sb_rows, int32_t n_chunks,
                              float* blockmax, int64_t bm_stride, int32_t variant, void* stream);
+/* tau (nullable) [n_users]: the k-th largest superblock maximum = a floor of the final k-th best score */
 int trec_topk_select_blocks(const float* blockmax, int32_t n_sb, int64_t n_users, int64_t stride, int32_t k, int32_t* sel,
-                            void* stream);
+                            float* tau, void* stream);
 int trec_topk_group_keys(const int32_t* sel, int64_t n, int32_t n_sb, int32_t* keys, void* stream);
 int trec_topk_pad_counts(const int64_t* indptr_t, int32_t n_sb, int32_t rows_wg, int32_t* cnt_pad, void* stream);
 int trec_exclusive_scan_i32(const int32_t* counts, int64_t n, int64_t* workspace_i64, int64_t* out, void* stream);
 int trec_topk_fill_groups(const int64_t* pstart, const int64_t* indptr_t, const int32_t* users_t, const int32_t* perm_t,
                           int32_t n_sb, int32_t rows_wg, int64_t max_rows, const void* users_op, int32_t row_bytes,
-                          const float* user_bias, const float* user_sq, void* G, float* g_bias, float* g_sq,
-                          int32_t* row_pair, int32_t* rblock_chunk, void* stream);
+                          const float* user_bias, const float* user_sq, const float* user_tau, void* G, float* g_bias,
+                          float* g_sq, float* g_tau, int32_t* row_pair, int32_t* rblock_chunk, void* stream);
 int trec_score_gemm_topk_grouped(const void* users_g, const void* items, int32_t dtype, int32_t kpad, int64_t n_rows_g,
                                  int64_t n_items, int32_t item_index_base, const float* user_bias_g,
                                  const float* item_bias, int32_t mode, const float* user_sqnorm_g,
                                  const float* item_sqnorm, int32_t sb_rows, const int32_t* rblock_chunk,
-                                 const int32_t* row_pair, int32_t capacity, float* part_vals, int32_t* part_idx,
-                                 int32_t variant, void* stream);
+                                 const int32_t* row_pair, const float* row_floor, int32_t capacity, float* part_vals,
+                                 int32_t* part_idx, int32_t variant, void* stream);
 
 /* k best of n_cand candidates per user, ordered (value desc, index asc) = tf.nn.top_k tie rule; also the merge
  * step after the all-gather of per-shard lists */

@@ -55,6 +55,7 @@ struct ScoreParams {
     // grouped TOPK (stage 3): the item range of a workgroup comes from a table, results go where row_pair says
     const int32_t* rblock_chunk;   // nullable [n_rblocks]: chunk (= superblock) index of this resident block, -1 = idle
     const int32_t* row_pair;       // nullable [n_r]: output list id of a resident row, -1 = padding row
+    const float* row_floor;        // nullable [n_r]: a known lower bound of the row's final k-th best score (lists start there)
 };
 
 template <int DT> struct ElemOf;
@@ -212,6 +213,12 @@ __global__ __launch_bounds__(256, WPS) void score_gemm_kernel(ScoreParams p)
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
             thr[cb] = -INFINITY; tau_pp[cb] = -INFINITY;
+            if (p.row_floor) {          // grouped re-scoring: scores below the floor cannot be in the final top-k
+                int64_t u = r_base + cb * 32 + l31;
+                if (u >= p.n_r) u = p.n_r - 1;
+                tau_pp[cb] = float_pred(p.row_floor[u]);
+                thr[cb] = tau_pp[cb];
+            }
 #pragma unroll
             for (int j = 0; j < KTOP; ++j) { tv[cb][j] = -INFINITY; ti[cb][j] = -1; }
         }
@@ -833,8 +840,9 @@ extern "C" int trec_score_gemm_topk_grouped(const void* users_g, const void* ite
                                             int64_t n_rows_g, int64_t n_items, int32_t item_index_base,
                                             const float* user_bias_g, const float* item_bias, int32_t mode,
                                             const float* user_sqnorm_g, const float* item_sqnorm, int32_t sb_rows,
-                                            const int32_t* rblock_chunk, const int32_t* row_pair, int32_t capacity,
-                                            float* part_vals, int32_t* part_idx, int32_t variant, void* stream)
+                                            const int32_t* rblock_chunk, const int32_t* row_pair,
+                                            const float* row_floor, int32_t capacity, float* part_vals,
+                                            int32_t* part_idx, int32_t variant, void* stream)
 {
     ScoreParams p = {};
     TREC_REQUIRE(part_vals && part_idx && rblock_chunk && row_pair, "trec_score_gemm_topk_grouped: null pointer");
@@ -845,7 +853,7 @@ extern "C" int trec_score_gemm_topk_grouped(const void* users_g, const void* ite
                          user_sqnorm_g, item_sqnorm, 1);
     if (rc) return rc;
     p.chunk_len = sb_rows; p.n_chunks = 1;
-    p.rblock_chunk = rblock_chunk; p.row_pair = row_pair;
+    p.rblock_chunk = rblock_chunk; p.row_pair = row_pair; p.row_floor = row_floor;
     p.part_vals = part_vals; p.part_idx = part_idx; p.n_parts = 2; p.t_index_base = item_index_base;
     p.capacity = capacity;
     if (capacity == 8) return dispatch_score<EPI_TOPK, 8>(dtype, kpad, variant & 1, p, (hipStream_t)stream);

@@ -32,7 +32,7 @@ __device__ __forceinline__ void sel_insert(float (&tv)[KSEL], int32_t (&ti)[KSEL
 template <int KSEL>
 __global__ __launch_bounds__(256) void select_blocks_kernel(const float* __restrict__ blockmax, int32_t n_sb,
                                                            int64_t n_users, int64_t stride, int32_t k,
-                                                           int32_t* __restrict__ sel)
+                                                           int32_t* __restrict__ sel, float* __restrict__ tau)
 {
     const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool ok = u < n_users;
@@ -50,6 +50,9 @@ __global__ __launch_bounds__(256) void select_blocks_kernel(const float* __restr
 #pragma unroll
         for (int j = 0; j < KSEL; ++j)
             if (j < k) sel[u * k + j] = ti[j];
+        // k superblocks have a maximum >= tv[k-1], i.e. k items score >= it: a valid floor for the final k-th best score
+        // (-inf while fewer than k superblocks exist).  The re-scoring pass starts its lists from this threshold.
+        if (tau) tau[u] = (ti[KSEL - 1] >= 0) ? tv[KSEL - 1] : -INFINITY;
     }
 }
 
@@ -76,9 +79,9 @@ __global__ __launch_bounds__(256) void pad_counts_kernel(const int64_t* __restri
 __global__ __launch_bounds__(256) void fill_groups_kernel(
     const int64_t* __restrict__ pstart, const int64_t* __restrict__ indptr_t, const int32_t* __restrict__ users_t,
     const int32_t* __restrict__ perm_t, int32_t n_sb, int32_t rows_wg, int64_t max_rows, const char* __restrict__ users_op,
-    int32_t row_bytes, const float* __restrict__ user_bias, const float* __restrict__ user_sq, char* __restrict__ G,
-    float* __restrict__ g_bias, float* __restrict__ g_sq, int32_t* __restrict__ row_pair,
-    int32_t* __restrict__ rblock_chunk)
+    int32_t row_bytes, const float* __restrict__ user_bias, const float* __restrict__ user_sq,
+    const float* __restrict__ user_tau, char* __restrict__ G, float* __restrict__ g_bias, float* __restrict__ g_sq,
+    float* __restrict__ g_tau, int32_t* __restrict__ row_pair, int32_t* __restrict__ rblock_chunk)
 {
     const int ch = row_bytes / 16;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -109,12 +112,13 @@ __global__ __launch_bounds__(256) void fill_groups_kernel(
         row_pair[v] = pair;
         if (g_bias) g_bias[v] = user_bias[src_user];
         if (g_sq) g_sq[v] = user_sq[src_user];
+        if (g_tau) g_tau[v] = (pair >= 0) ? user_tau[src_user] : INFINITY;       // padding rows never insert
         if (v % rows_wg == 0) rblock_chunk[v / rows_wg] = sb;      // -1 beyond the padded total: workgroup exits at once
     }
 }
 
 extern "C" int trec_topk_select_blocks(const float* blockmax, int32_t n_sb, int64_t n_users, int64_t stride, int32_t k,
-                                       int32_t* sel, void* stream)
+                                       int32_t* sel, float* tau, void* stream)
 {
     TREC_REQUIRE(blockmax && sel, "trec_topk_select_blocks: null pointer");
     TREC_REQUIRE(k >= 1 && k <= 16 && n_sb >= 1, "trec_topk_select_blocks: need 1 <= k <= 16, n_sb >= 1");
@@ -122,7 +126,7 @@ extern "C" int trec_topk_select_blocks(const float* blockmax, int32_t n_sb, int6
     const unsigned blocks = (unsigned)ceil_div64(n_users, 256);
     hipStream_t st = (hipStream_t)stream;
     // the list length IS k here (threshold = k-th best): instantiate the lengths in use
-#define TREC_SEL(KS) hipLaunchKernelGGL((select_blocks_kernel<KS>), dim3(blocks), dim3(256), 0, st, blockmax, n_sb, n_users, stride, k, sel)
+#define TREC_SEL(KS) hipLaunchKernelGGL((select_blocks_kernel<KS>), dim3(blocks), dim3(256), 0, st, blockmax, n_sb, n_users, stride, k, sel, tau)
     switch (k) {
         case 1: TREC_SEL(1); break;   case 2: TREC_SEL(2); break;   case 3: TREC_SEL(3); break;   case 4: TREC_SEL(4); break;
         case 5: TREC_SEL(5); break;   case 6: TREC_SEL(6); break;   case 7: TREC_SEL(7); break;   case 8: TREC_SEL(8); break;
@@ -153,18 +157,19 @@ extern "C" int trec_topk_pad_counts(const int64_t* indptr_t, int32_t n_sb, int32
 extern "C" int trec_topk_fill_groups(const int64_t* pstart, const int64_t* indptr_t, const int32_t* users_t,
                                      const int32_t* perm_t, int32_t n_sb, int32_t rows_wg, int64_t max_rows,
                                      const void* users_op, int32_t row_bytes, const float* user_bias,
-                                     const float* user_sq, void* G, float* g_bias, float* g_sq, int32_t* row_pair,
-                                     int32_t* rblock_chunk, void* stream)
+                                     const float* user_sq, const float* user_tau, void* G, float* g_bias, float* g_sq,
+                                     float* g_tau, int32_t* row_pair, int32_t* rblock_chunk, void* stream)
 {
     TREC_REQUIRE(pstart && indptr_t && users_t && perm_t && users_op && G && row_pair && rblock_chunk,
                  "trec_topk_fill_groups: null pointer");
     TREC_REQUIRE(row_bytes % 16 == 0 && max_rows % rows_wg == 0, "trec_topk_fill_groups: row_bytes % 16, max_rows % rows_wg");
-    TREC_REQUIRE((g_bias == nullptr) == (user_bias == nullptr) && (g_sq == nullptr) == (user_sq == nullptr),
+    TREC_REQUIRE((g_bias == nullptr) == (user_bias == nullptr) && (g_sq == nullptr) == (user_sq == nullptr) &&
+                     (g_tau == nullptr) == (user_tau == nullptr),
                  "trec_topk_fill_groups: bias / sqnorm buffers must come in pairs");
     if (max_rows == 0) return TREC_OK;
     const int64_t chunks = max_rows * (row_bytes / 16);
     hipLaunchKernelGGL(fill_groups_kernel, dim3((unsigned)ceil_div64(chunks, 256)), dim3(256), 0, (hipStream_t)stream,
                        pstart, indptr_t, users_t, perm_t, n_sb, rows_wg, max_rows, (const char*)users_op, row_bytes,
-                       user_bias, user_sq, (char*)G, g_bias, g_sq, row_pair, rblock_chunk);
+                       user_bias, user_sq, user_tau, (char*)G, g_bias, g_sq, g_tau, row_pair, rblock_chunk);
     return trec_check_launch("trec_topk_fill_groups");
 }

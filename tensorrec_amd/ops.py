@@ -488,8 +488,9 @@ def score_topk_two_stage(users_op, items_op, dtype, kpad, k, user_bias=None, ite
                N.ptr(item_bias), mode, N.ptr(user_sq), N.ptr(item_sq), sb_rows, n_chunks, N.ptr(blockmax), n_u, variant)
     # ---- stage 2: the ksel best superblocks of every user
     sel = torch.empty((n_u, ksel), dtype=torch.int32, device=dev)
+    tau = torch.empty((n_u,), dtype=torch.float32, device=dev) if ksel == int(k) else None   # floor needs k superblocks
     with _timed("topk_select_blocks"):
-        N.call("trec_topk_select_blocks", N.ptr(blockmax), n_sb, n_u, n_u, ksel, N.ptr(sel))
+        N.call("trec_topk_select_blocks", N.ptr(blockmax), n_sb, n_u, n_u, ksel, N.ptr(sel), N.ptr(tau))
     del blockmax
     # ---- stage 3a: group (user, slot) pairs by superblock, pad groups to whole workgroups, gather operand rows
     n_pairs = n_u * ksel
@@ -505,19 +506,20 @@ def score_topk_two_stage(users_op, items_op, dtype, kpad, k, user_bias=None, ite
     g_op = torch.empty((max_rows, kpad), dtype=users_op.dtype, device=dev)
     g_bias = torch.empty((max_rows,), dtype=torch.float32, device=dev) if user_bias is not None else None
     g_sq = torch.empty((max_rows,), dtype=torch.float32, device=dev) if user_sq is not None else None
+    g_tau = torch.empty((max_rows,), dtype=torch.float32, device=dev) if tau is not None else None
     row_pair = torch.empty((max_rows,), dtype=torch.int32, device=dev)
     rblock_chunk = torch.empty((max_rows // rows_wg,), dtype=torch.int32, device=dev)
     with _timed("topk_fill_groups"):
         N.call("trec_topk_fill_groups", N.ptr(pstart), N.ptr(indptr_t), N.ptr(users_t), N.ptr(perm_t), n_sb, rows_wg,
-               max_rows, N.ptr(users_op), kpad * users_op.element_size(), N.ptr(user_bias), N.ptr(user_sq), N.ptr(g_op),
-               N.ptr(g_bias), N.ptr(g_sq), N.ptr(row_pair), N.ptr(rblock_chunk))
+               max_rows, N.ptr(users_op), kpad * users_op.element_size(), N.ptr(user_bias), N.ptr(user_sq), N.ptr(tau),
+               N.ptr(g_op), N.ptr(g_bias), N.ptr(g_sq), N.ptr(g_tau), N.ptr(row_pair), N.ptr(rblock_chunk))
     # ---- stage 3b: re-score the selected superblocks (every pair is written exactly once: ksel <= n_sb)
     pv = torch.empty((n_pairs * 2, cap), dtype=torch.float32, device=dev)
     pi = torch.full((n_pairs * 2, cap), -1, dtype=torch.int32, device=dev)      # unwritten lists read as empty
     with _timed("score_gemm_topk_grouped"):
         N.call("trec_score_gemm_topk_grouped", N.ptr(g_op), N.ptr(items_op), dtype, kpad, max_rows, n_i, item_index_base,
                N.ptr(g_bias), N.ptr(item_bias), mode, N.ptr(g_sq), N.ptr(item_sq), sb_rows, N.ptr(rblock_chunk),
-               N.ptr(row_pair), cap, N.ptr(pv), N.ptr(pi), variant & 1)
+               N.ptr(row_pair), N.ptr(g_tau), cap, N.ptr(pv), N.ptr(pi), variant & 1)
     # ---- stage 4: merge the ksel * 2 lists of every user
     return topk_merge(pv.reshape(n_u, ksel * 2 * cap), pi.reshape(n_u, ksel * 2 * cap), k)
 
