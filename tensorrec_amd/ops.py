@@ -476,11 +476,12 @@ def score_topk_two_stage(users_op, items_op, dtype, kpad, k, user_bias=None, ite
     n_sb = (n_i + sb_rows - 1) // sb_rows
     ksel = min(int(k), n_sb)
     rows_wg = N.query("trec_score_rows_per_workgroup", dtype, kpad)
-    if n_chunks is None:       # enough workgroups for 3 per CU even with few users; chunks are whole superblocks
+    if n_chunks is None:
+        # Stage 1 has no per-chunk state, so item chunks only set the workgroup count: aim for >= 16 "rounds" of the
+        # 768 co-resident workgroups (3 per CU) so that the last, partially filled round costs < 6% (with one chunk,
+        # 1M users = 3907 workgroups = 5.09 rounds, i.e. 15% of the time is a nearly empty sixth round).
         rblocks = (n_u + rows_wg - 1) // rows_wg
-        n_chunks = 1
-        while rblocks * n_chunks < 1536 and n_chunks * 2 <= n_sb:
-            n_chunks *= 2
+        n_chunks = max(1, min(n_sb, -(-16 * 768 // rblocks)))
     # ---- stage 1: superblock maxima
     blockmax = torch.empty((n_sb, n_u), dtype=torch.float32, device=dev)
     with _timed("score_gemm_blockmax"):
