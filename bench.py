@@ -240,6 +240,25 @@ def main():
                        "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                        "traffic": None, "avg_launch_ms": k1_user_ms, "algorithmic_bytes_per_launch": bytes_user}
 
+    # ---- HBM-side traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the figure
+    # comes from the committed rocprofv3 --pmc passes of this same command (profiles/*_pmc_summary.txt), corrected as
+    # MI355X_MICROARCH.md prescribes (gfx950 FETCH_SIZE counts wide coalesced reads at half their size) ----
+    try:
+        import glob, re
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.txt")))
+        if files and world == 1 and (U, I, d) == (1_000_000, 1_000_000, 128) and method == "two_stage":
+            txt = open(files[-1]).read()
+            key = "score_gemm_kernel<1, 128, 64, 2, 2"
+            fetch = [float(m) for m in re.findall(re.escape(key) + r"[^\n]*?FETCH_SIZE=([0-9.e+]+)", txt)]
+            write = [float(m) for m in re.findall(re.escape(key) + r"[^\n]*?WRITE_SIZE=([0-9.e+]+)", txt)]
+            if fetch and write:
+                roofline["traffic"] = (2.0 * fetch[0] + write[0]) * 1024.0
+                roofline["traffic_note"] = ("bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KB from %s; fabric-side "
+                                            "reads incl. Infinity-Cache hits; algorithmic minimum is %.3g bytes"
+                                            % (os.path.basename(files[-1]), (U + n_local) * kpad * 2.0 + U * 4.0 * (n_local // 512)))
+    except Exception:
+        pass
+
     # ---- live parity check on a sample of users (oracle = checker only) ----
     parity = None
     try:
