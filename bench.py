@@ -134,11 +134,19 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()
+    dev_index = local_rank % max(1, n_dev)          # ranks share a GPU only in the single-GPU functional test below
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        # RCCL ("nccl") needs one GPU per rank; TREC_DIST_BACKEND=gloo lets the multi-rank path be exercised
+        # functionally on a one-GPU box (tests / gpurun), it is never used for a reported number
+        backend = os.environ.get("TREC_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import tensorrec_amd as T
     from tensorrec_amd import ops, sharding
