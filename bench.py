@@ -217,6 +217,15 @@ def main():
     ms_per_step = 1000.0 * elapsed / args.steps
     value = float(U) * float(I) / (elapsed / args.steps)
 
+    if world > 1:
+        # parity sample needs every rank's item rows: one untimed all-gather (shards are padded to equal length)
+        vals, idx, user_repr, item_repr_local = out
+        per = -(-I // world)
+        per = -(-per // 64) * 64
+        pad = torch.zeros((per, item_repr_local.shape[1]), dtype=item_repr_local.dtype, device=device)
+        pad[: item_repr_local.shape[0]] = item_repr_local
+        full = sharding.all_gather_cat(pad, dim=0)[:I].contiguous()
+        out = (vals, idx, user_repr, full)
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -273,7 +282,7 @@ def main():
         from oracle import oracle as O
         vals, idx, user_repr, item_repr = out
         sample = np.linspace(0, U - 1, 32).astype(np.int64)
-        if world == 1:
+        if True:
             us = user_repr[torch.from_numpy(sample).to(device)].cpu().numpy()
             it = item_repr.cpu().numpy()
             ref = us.astype(np.float32) @ it.T                               # fp32 sgemm reference scores
