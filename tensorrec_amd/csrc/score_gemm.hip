@@ -139,6 +139,7 @@ __global__ __launch_bounds__(256, WPS) void score_gemm_kernel(ScoreParams p)
     constexpr int TILE_BYTES = BN * RB;
     constexpr int NSLOT = BN * CH / 256;     // 16-byte staging slots per thread per tile
     constexpr bool PRIO = (ABL & 4) != 0;    // tuning: raise wave priority while issuing the MFMA block
+    constexpr int RB_UNROLL = (EPI == 2 /* EPI_BLOCKMAX */) ? BN / 32 : 1;
     static_assert(BN * CH % 256 == 0 && NSLOT >= 1, "tile too small for 256 threads");
     static_assert(BN % 32 == 0, "BN must be a multiple of the 32-row MFMA block");
 
@@ -298,7 +299,9 @@ __global__ __launch_bounds__(256, WPS) void score_gemm_kernel(ScoreParams p)
         const int64_t tile_row0 = t_begin + (int64_t)t * BN;
         const bool partial = tile_row0 + BN > p.n_t;
 
-#pragma unroll 1
+        // BLOCKMAX has a branch-free epilogue: unrolling lets the scheduler overlap block rb's max chain with block rb+1's
+        // LDS reads and MFMAs.  The list epilogues keep the loop rolled (their rare path is large).
+#pragma unroll(RB_UNROLL)
         for (int rb = 0; rb < BN / 32; ++rb) {
             // bf16 + biases: the item bias IS the initial accumulator (C operand of the first MFMA) -- zero VALU cost.
             // bf16 scores are therefore defined as fl-chain(b_i + sum_k u_k i_k) + b_u in every bf16 epilogue (there is
