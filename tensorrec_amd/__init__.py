@@ -6,6 +6,7 @@ Importing the package does not need a GPU; running any model does (there is no C
 """
 from .tensorrec import TensorRec, DeviceSampler, HostSampler, ReplaySampler
 from . import errors
+from . import eval  # noqa: A004
 from . import framework
 from . import loss_graphs
 from . import prediction_graphs
@@ -16,6 +17,6 @@ from . import util
 __version__ = '0.1.0'
 
 __all__ = [
-    "TensorRec", "DeviceSampler", "HostSampler", "ReplaySampler", "errors", "framework", "loss_graphs",
+    "TensorRec", "DeviceSampler", "HostSampler", "ReplaySampler", "errors", "eval", "framework", "loss_graphs",
     "prediction_graphs", "recommendation_graphs", "representation_graphs", "util",
 ]
