@@ -187,6 +187,20 @@ int trec_sample_items(int64_t n_users, int64_t user_base, int32_t n_items, int32
 int trec_adam_tf_step(float* w, float* m, float* v, const float* grad, int64_t n, float lr_t, float beta1,
                       float beta2, float epsilon, float l2_coef, void* stream);
 
+/* ---- K9: mixture of tastes -----------------------------------------------------------------------------------
+ * collapse_mixture_of_tastes, recommendation_graphs.py:85-109 (tf.stack + reduce_max, or + softmax(axis=0) * predictions +
+ * reduce_sum), fused with the bias add that follows it (bias_prediction_dense / _serial, :33-57; tensorrec.py:432-449).
+ * preds / attn: fp32 [n_tastes, n] (attn NULL = max over tastes), out fp32 [n].
+ * bias_mode 0: none; 1: serial pairs -- element e is (x_user[e] or e / span when x_user is NULL, x_item[e]);
+ * 2: dense -- element e is (e / span, e % span) with span = n_items.  out = (collapsed + user_bias[u]) + item_bias[i].
+ * _bwd: d_preds (and d_attn) [n_tastes, n] from grad_out [n]; reduce_max shares the gradient evenly between tied
+ * tastes as TF does.  Bias gradients are grad_out summed per user / item (trec_spmv_csr on the pair structure).      */
+int trec_collapse_tastes_fwd(const float* preds, const float* attn, int32_t n_tastes, int64_t n, int32_t bias_mode,
+                             const float* user_bias, const float* item_bias, const int32_t* x_user,
+                             const int32_t* x_item, int64_t span, float* out, void* stream);
+int trec_collapse_tastes_bwd(const float* preds, const float* attn, const float* grad_out, int32_t n_tastes, int64_t n,
+                             float* d_preds, float* d_attn, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -2,9 +2,12 @@
 oracle/model.py -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
 
 CPU restatement of ``TensorRec._build_tf_graph`` (tensorrec/tensorrec.py:270-492) and of
-one ``session.run(tf_optimizer)`` (tensorrec.py:617-622) for ``n_tastes == 1`` without
-attention.  torch-CPU float32 tensors + torch.autograd stand in for the TF graph and TF's
-autodiff; the optimiser is the TF-1.x Adam form from oracle/oracle.py.
+one ``session.run(tf_optimizer)`` (tensorrec.py:617-622), including the mixture of tastes
+(``n_tastes > 1``: one user representation per taste, max over tastes) and attention
+(softmax over per-taste attention scores; for the SAMPLED pairs the reference feeds the
+user representation where the attention representation was meant, tensorrec.py:367-372,
+so the sampled attentions equal the sampled predictions -- reproduced).  torch-CPU float32
+tensors + torch.autograd stand in for the TF graph and TF's autodiff; the optimiser is the TF-1.x Adam form from oracle/oracle.py.
 
 PARITY UNPINNED: the reference has no known-answer test for a fit step.
 The quirks of SURVEY.md 3.4 are reproduced on purpose:
@@ -45,8 +48,12 @@ class OracleTensorRec(object):
     ``loss_kind``: 'rmse' | 'wmrb' | 'balanced_wmrb'."""
 
     def __init__(self, n_components, user_repr="linear", item_repr="linear", pred_kind="dot",
-                 loss_kind="rmse", biased=True):
+                 loss_kind="rmse", biased=True, n_tastes=1, attention=None):
         self.d = n_components
+        self.n_tastes, self.attention = n_tastes, attention
+        # node_name_ending per taste (tensorrec.py:344, :352); a single taste keeps the short name "user"
+        self.user_sides = ["user"] if n_tastes == 1 else ["user_%d" % t for t in range(n_tastes)]
+        self.attn_sides = ["attn_%d" % t for t in range(n_tastes)] if attention is not None else []
         self.user_repr, self.item_repr = user_repr, item_repr
         self.pred_kind, self.loss_kind, self.biased = pred_kind, loss_kind, biased
         self.weights, self.adam_m, self.adam_v = {}, {}, {}
@@ -54,7 +61,12 @@ class OracleTensorRec(object):
 
     # ---- weights -------------------------------------------------------------------------
     def init_weights(self, n_user_features, n_item_features, rng):
-        for side, kind, nf in (("item", self.item_repr, n_item_features), ("user", self.user_repr, n_user_features)):
+        sides = [("item", self.item_repr, n_item_features)]
+        for t in range(self.n_tastes):
+            sides.append((self.user_sides[t], self.user_repr, n_user_features))
+            if self.attention is not None:
+                sides.append((self.attn_sides[t], self.attention, n_user_features))
+        for side, kind, nf in sides:
             if kind in ("linear", "normalized_linear"):
                 self.weights["linear_weights_" + side] = O.init_linear_weights(nf, self.d, rng)
             elif kind == "relu":
@@ -116,19 +128,35 @@ class OracleTensorRec(object):
         dist = (r_u - 2.0 * (u @ v.t())) + r_v.t()
         return -1.0 * torch.sqrt(torch.clamp(dist, min=1e-16))
 
+    @staticmethod
+    def _collapse(preds, attns):                                  # recommendation_graphs.py:85-109
+        stacked = torch.stack(preds)
+        if attns is not None:
+            return (stacked * torch.softmax(torch.stack(attns), dim=0)).sum(dim=0)
+        return torch.amax(stacked, dim=0)                         # ties share the gradient evenly, as tf.reduce_max
+
+    def _serial_all(self, o, xu, xi, sampled=False):
+        preds = [self._serial(u, o["item_repr"], xu, xi) for u in o["user_reprs"]]
+        attns = None
+        if self.attention is not None:
+            # tensorrec.py:367-372: the sampled attention is built from tf_user_representation
+            attns = preds if sampled else [self._serial(a, o["item_repr"], xu, xi) for a in o["attn_reprs"]]
+        s = self._collapse(preds, attns)
+        if self.biased:
+            s = s + o["user_bias"][xu] + o["item_bias"][xi]
+        return s
+
     def forward(self, W, user_features, item_features, xu=None, xi=None):
         uf, itf = _sparse(user_features), _sparse(item_features)
         item_repr = self._repr(self.item_repr, "item", itf, W)
-        user_repr = self._repr(self.user_repr, "user", uf, W)
-        out = {"user_repr": user_repr, "item_repr": item_repr}
+        user_reprs = [self._repr(self.user_repr, side, uf, W) for side in self.user_sides]
+        attn_reprs = [self._repr(self.attention, side, uf, W) for side in self.attn_sides]
+        out = {"user_repr": user_reprs[0], "user_reprs": user_reprs, "attn_reprs": attn_reprs, "item_repr": item_repr}
         if self.biased:
             out["user_bias"] = torch.sparse.mm(uf, W["user_feature_biases"]).sum(dim=1)
             out["item_bias"] = torch.sparse.mm(itf, W["item_feature_biases"]).sum(dim=1)
         if xu is not None:
-            s = self._serial(user_repr, item_repr, xu, xi)
-            if self.biased:
-                s = s + out["user_bias"][xu] + out["item_bias"][xi]
-            out["serial"] = s
+            out["serial"] = self._serial_all(out, xu, xi)
         return out
 
     # ---- predict ----------------------------------------------------------------------------
@@ -145,7 +173,9 @@ class OracleTensorRec(object):
         with torch.no_grad():
             W = self._W()
             o = self.forward(W, user_features, item_features)
-            pred = self._dense(o["user_repr"], o["item_repr"])
+            preds = [self._dense(u, o["item_repr"]) for u in o["user_reprs"]]
+            attns = [self._dense(a, o["item_repr"]) for a in o["attn_reprs"]] if self.attention is not None else None
+            pred = self._collapse(preds, attns)
             if self.biased:
                 pred = pred + o["user_bias"][:, None] + o["item_bias"][None, :]
             return pred.numpy()
@@ -156,7 +186,7 @@ class OracleTensorRec(object):
     def representations(self, user_features, item_features):
         with torch.no_grad():
             o = self.forward(self._W(), user_features, item_features)
-            return {k: v.numpy() for k, v in o.items()}
+            return {k: (v.numpy() if torch.is_tensor(v) else [x.numpy() for x in v]) for k, v in o.items()}
 
     # ---- one optimiser step (tensorrec.py:617-622) --------------------------------------------
     def loss_and_grads(self, interactions, user_features, item_features, alpha, sample_items=None):
@@ -177,9 +207,7 @@ class OracleTensorRec(object):
             S = sample_items.shape[1]
             su = torch.arange(n_users).repeat_interleave(S)
             si = torch.from_numpy(np.ascontiguousarray(sample_items, np.int64).reshape(-1))
-            samp = self._serial(o["user_repr"], o["item_repr"], su, si)
-            if self.biased:
-                samp = samp + o["user_bias"][su] + o["item_bias"][si]
+            samp = self._serial_all(o, su, si, sampled=True)
             samp = samp.reshape(n_users, S)                              # recommendation_graphs.py:68-69
             mask = y > 0.0
             pos_pred = pred_serial[mask]

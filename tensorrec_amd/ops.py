@@ -324,6 +324,112 @@ def pair_score(user_repr, item_repr, x_user, x_item, mode=MODE_DOT, user_bias=No
     return _PairScore.apply(user_repr, item_repr, ub, ib, xu32, xi32, ppu, mode, inter)
 
 
+# ------------------------------------------------------------------------------------------------ K9
+def _pair_bias_grads(g, xu32, xi32, ppu, inter, n_users, n_items, want_ub, want_ib):
+    """d user_bias / d item_bias of out[p] = ... + ub[user(p)] + ib[item(p)]: g summed per user / per item with the
+    segmented K1 matvec over the pair structure (interactions: CSR + its transpose; samples: ppu consecutive pairs per
+    user + a device counting sort by item).  Unstructured pair lists fall back to index_add_."""
+    dev = g.device
+    n_pairs = xi32.numel()
+    dub = dib = None
+    if inter is None and ppu <= 0:
+        if want_ub:
+            dub = torch.zeros((n_users,), dtype=torch.float32, device=dev).index_add_(0, xu32.long(), g)
+        if want_ib:
+            dib = torch.zeros((n_items,), dtype=torch.float32, device=dev).index_add_(0, xi32.long(), g)
+        return dub, dib
+    if want_ub:
+        indptr_u = inter.indptr if inter is not None else \
+            torch.arange(0, (n_users + 1) * ppu, ppu, dtype=torch.int64, device=dev)
+        dub = torch.empty((n_users,), dtype=torch.float32, device=dev)
+        N.call("trec_spmv_csr", N.ptr(indptr_u), N.ptr(xi32), N.ptr(g), None, n_users, N.ptr(_ones(n_items, dev)),
+               N.ptr(dub))
+    if want_ib:
+        indptr_t, users_t, perm_t = inter.transposed() if inter is not None else \
+            group_pairs_by_item(xu32, xi32, ppu, n_items)
+        dib = torch.empty((n_items,), dtype=torch.float32, device=dev)
+        N.call("trec_spmv_csr", N.ptr(indptr_t), N.ptr(users_t), N.ptr(g), N.ptr(perm_t), n_items,
+               N.ptr(_ones(n_users, dev)), N.ptr(dib))
+    return dub, dib
+
+
+class _CollapseTastes(torch.autograd.Function):
+    """K9 forward / backward; ``meta`` = (bias_mode, xu32, xi32, span, inter)."""
+
+    @staticmethod
+    def forward(ctx, preds, attn, ub, ib, meta):
+        bias_mode, xu32, xi32, span, inter = meta
+        preds = _f32c(preds)
+        attn = _f32c(attn) if attn is not None else None
+        T = preds.shape[0]
+        n = preds[0].numel()
+        out = torch.empty(preds.shape[1:], dtype=torch.float32, device=preds.device)
+        N.call("trec_collapse_tastes_fwd", N.ptr(preds), N.ptr(attn), T, n, bias_mode, N.ptr(ub), N.ptr(ib),
+               N.ptr(xu32), N.ptr(xi32), span, N.ptr(out))
+        ctx.save_for_backward(preds, attn)
+        ctx.meta = meta
+        ctx.bias_shapes = (None if ub is None else ub.numel(), None if ib is None else ib.numel())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        preds, attn = ctx.saved_tensors
+        bias_mode, xu32, xi32, span, inter = ctx.meta
+        n_ub, n_ib = ctx.bias_shapes
+        g = _f32c(g)
+        T = preds.shape[0]
+        n = preds[0].numel()
+        d_preds = torch.empty_like(preds)
+        d_attn = torch.empty_like(attn) if attn is not None else None
+        N.call("trec_collapse_tastes_bwd", N.ptr(preds), N.ptr(attn), N.ptr(g), T, n, N.ptr(d_preds), N.ptr(d_attn))
+        dub = dib = None
+        if bias_mode == 1 and (n_ub is not None or n_ib is not None):
+            ppu = span if xu32 is None else 0
+            n_users = inter.shape[0] if inter is not None else (n // ppu if ppu > 0 else (n_ub or 0))
+            n_items = inter.shape[1] if inter is not None else (n_ib or 0)
+            dub, dib = _pair_bias_grads(g.reshape(-1), xu32, xi32, ppu, inter, n_users, n_items, n_ub is not None,
+                                        n_ib is not None)
+        elif bias_mode == 2:
+            g2 = g.reshape(-1, span)
+            if n_ub is not None:
+                dub = gemm_raw(g2, _ones(span, g.device).reshape(span, 1)).reshape(-1)
+            if n_ib is not None:
+                dib = torch.empty((span,), dtype=torch.float32, device=g.device)
+                N.call("trec_colsum", N.ptr(g2), g2.shape[0], span, N.ptr(dib))
+        return d_preds, d_attn, dub, dib, None
+
+
+def collapse_tastes(tastes_predictions, tastes_attentions=None, user_bias=None, item_bias=None, x_user=None,
+                    x_item=None):
+    """collapse_mixture_of_tastes (recommendation_graphs.py:85-109) in one pass (K9), optionally fused with the bias add
+    that follows it: serial predictions pass the pair indices, dense [n_users, n_items] predictions pass none."""
+    def stacked(x):
+        return x if isinstance(x, torch.Tensor) else torch.stack(list(x))
+
+    preds = stacked(tastes_predictions)
+    attn = stacked(tastes_attentions) if tastes_attentions is not None else None
+    if preds.shape[0] > 16:
+        raise ValueError("n_tastes = %d is beyond the collapse kernel's limit of 16" % preds.shape[0])
+    ub = _f32c(user_bias) if user_bias is not None else None
+    ib = _f32c(item_bias) if item_bias is not None else None
+    if ub is None and ib is None:
+        meta = (0, None, None, 0, None)
+    elif x_item is not None:
+        xu32, ppu = _idx32(x_user)
+        xi32, _ = _idx32(x_item)
+        inter = getattr(x_user, "interactions", None) if isinstance(x_user, PairIndex) else None
+        if inter is not None and (getattr(x_item, "interactions", None) is not inter or xi32.numel() != inter.nnz):
+            inter = None
+        if ppu > 0:
+            xu32 = None
+        meta = (1, xu32, xi32, ppu, inter)
+    else:
+        if preds.dim() != 3:
+            raise ValueError("dense bias add needs [n_tastes, n_users, n_items] predictions")
+        meta = (2, None, None, preds.shape[2], None)
+    return _CollapseTastes.apply(preds, attn, ub, ib, meta)
+
+
 # ------------------------------------------------------------------------------------------------ K6
 class _WMRB(torch.autograd.Function):
     @staticmethod

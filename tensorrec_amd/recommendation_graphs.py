@@ -43,15 +43,11 @@ def rank_predictions(tf_prediction):
 
 
 def collapse_mixture_of_tastes(tastes_predictions, tastes_attentions):
-    """(recommendation_graphs.py:85-109)"""
-    stacked_predictions = torch.stack(list(tastes_predictions))
-    if tastes_attentions is not None:
-        stacked_attentions = torch.stack(list(tastes_attentions))
-        softmax_attentions = torch.softmax(stacked_attentions, dim=0)
-        return (stacked_predictions * softmax_attentions).sum(dim=0)
-    if stacked_predictions.shape[0] == 1:
-        return stacked_predictions[0]
-    return stacked_predictions.max(dim=0).values
+    """Max over the tastes, or the softmax(attention)-weighted sum (recommendation_graphs.py:85-109) -- K9, one pass."""
+    tastes_predictions = list(tastes_predictions)
+    if tastes_attentions is None and len(tastes_predictions) == 1:
+        return tastes_predictions[0]                  # reduce_max over one taste
+    return ops.collapse_tastes(tastes_predictions, tastes_attentions)
 
 
 def relative_cosine(tf_tensor_1, tf_tensor_2):

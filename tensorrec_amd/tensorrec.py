@@ -17,6 +17,8 @@ from __future__ import annotations
 
 import logging
 import math
+import os
+import pickle
 from itertools import cycle
 
 import numpy as np
@@ -229,14 +231,34 @@ class TensorRec(object):
     def _is_engine_graph(self):
         return getattr(self.prediction_graph_factory, 'engine_mode', None) is not None
 
+    def _multi(self):
+        return self.n_tastes > 1 or self.attention_graph_factory is not None
+
+    def _user_representations(self, user_feats):
+        """One user representation per taste and, with attention, one attention representation per taste
+        (tensorrec.py:339-356).  Returns (user_reprs, attention_reprs or None, weights)."""
+        user_reprs, attn_reprs, weights = [], ([] if self.attention_graph_factory is not None else None), []
+        for taste in range(self.n_tastes):
+            user_repr, user_weights = self.user_repr_graph_factory.connect_representation_graph(
+                tf_features=user_feats, n_components=self.n_components, n_features=self.n_user_features,
+                node_name_ending='user_{}'.format(taste))
+            user_reprs.append(user_repr)
+            weights.extend(user_weights)
+            if self.attention_graph_factory is not None:
+                attn_repr, attn_weights = self.attention_graph_factory.connect_representation_graph(
+                    tf_features=user_feats, n_components=self.n_components, n_features=self.n_user_features,
+                    node_name_ending='attn_{}'.format(taste))
+                attn_reprs.append(attn_repr)
+                weights.extend(attn_weights)
+        return user_reprs, attn_reprs, weights
+
     def _representations(self, user_feats, item_feats):
-        """Item repr, user repr (taste 0) and projected biases -- tensorrec.py:308-313, :340-346, :421-430."""
+        """Item repr, user (and attention) reprs per taste and projected biases -- tensorrec.py:308-313, :339-356,
+        :421-430.  Returns (user_reprs list, attn_reprs list or None, item_repr, user_bias, item_bias, weights)."""
         item_repr, item_weights = self.item_repr_graph_factory.connect_representation_graph(
             tf_features=item_feats, n_components=self.n_components, n_features=self.n_item_features,
             node_name_ending='item')
-        user_repr, user_weights = self.user_repr_graph_factory.connect_representation_graph(
-            tf_features=user_feats, n_components=self.n_components, n_features=self.n_user_features,
-            node_name_ending='user_{}'.format(0))
+        user_reprs, attn_reprs, user_weights = self._user_representations(user_feats)
         weights = list(item_weights) + list(user_weights)
         user_bias = item_bias = None
         if self.biased:
@@ -246,7 +268,64 @@ class TensorRec(object):
             if item_feats is not None:
                 ib_var, item_bias = project_biases(item_feats, self.n_item_features, name='item_feature_biases')
                 weights.append(ib_var)
-        return user_repr, item_repr, user_bias, item_bias, weights
+        return user_reprs, attn_reprs, item_repr, user_bias, item_bias, weights
+
+    def _serial_multi(self, user_ins, attn_ins, item_in, x_user, x_item, user_bias, item_bias, sampled=False):
+        """Serial predictions of a mixture-of-tastes model: per-taste serial predictions (tensorrec.py:384-395), their
+        attentions (:357-372), the collapse (:411-418) and the serial biases (:437-449), the last two in one kernel.
+
+        For the SAMPLED pairs the reference builds the attention from ``tf_user_representation`` instead of
+        ``tf_attention_representation`` (tensorrec.py:367-372), i.e. the sampled attentions ARE the sampled
+        predictions; that wiring is reproduced (the per-taste tensors are simply used twice)."""
+        graph = self.prediction_graph_factory
+
+        def one(user_in):
+            if self._is_engine_graph():
+                return ops.pair_score(user_in, item_in, x_user, x_item, graph.engine_mode, None, None)
+            return graph.connect_serial_prediction_graph(tf_user_representation=user_in,
+                                                         tf_item_representation=item_in,
+                                                         tf_x_user=x_user, tf_x_item=x_item)
+
+        preds = [one(u) for u in user_ins]
+        attns = None
+        if attn_ins is not None:
+            attns = preds if sampled else [one(a) for a in attn_ins]
+        return ops.collapse_tastes(preds, attns, user_bias if self.biased else None,
+                                   item_bias if self.biased else None, x_user, x_item)
+
+    def _dense_multi(self, user_reprs, attn_reprs, item_repr, user_bias, item_bias, differentiable=False):
+        """tf_prediction of a mixture-of-tastes model: per-taste dense graphs (tensorrec.py:357-360, :380-383), the
+        collapse (:407-410) and the bias broadcast (:432-435)."""
+        graph = self.prediction_graph_factory
+        ub = user_bias if self.biased else None
+        ib = item_bias if self.biased else None
+        if self._is_engine_graph() and not differentiable:
+            dtype = ops.DTYPE_BF16 if self.precision == 'bf16' else ops.DTYPE_F32
+            want_sq = graph.engine_mode == ops.MODE_EUCLIDEAN
+            i_op, i_sq, kpad = ops.score_prep(item_repr, dtype, normalize=graph.engine_normalize, want_sqnorm=want_sq)
+            n_u, n_i = user_reprs[0].shape[0], item_repr.shape[0]
+
+            def stack(reprs):
+                out = torch.empty((len(reprs), n_u, n_i), dtype=torch.float32, device=item_repr.device)
+                for t, r in enumerate(reprs):
+                    u_op, u_sq, _ = ops.score_prep(r, dtype, normalize=graph.engine_normalize, want_sqnorm=want_sq)
+                    ops.score_store(u_op, i_op, dtype, kpad, None, None, graph.engine_mode, u_sq, i_sq, out=out[t])
+                return out
+
+            preds = stack(user_reprs)
+            attns = stack(attn_reprs) if attn_reprs is not None else None
+            return ops.collapse_tastes(preds, attns, ub.detach() if ub is not None else None,
+                                       ib.detach() if ib is not None else None)
+
+        def one(user_repr):
+            if self._is_engine_graph():
+                return _differentiable_dense(graph, user_repr, item_repr)
+            return graph.connect_dense_prediction_graph(tf_user_representation=user_repr,
+                                                        tf_item_representation=item_repr)
+
+        preds = [one(u) for u in user_reprs]
+        attns = [one(a) for a in attn_reprs] if attn_reprs is not None else None
+        return ops.collapse_tastes(preds, attns, ub, ib)
 
     def _serial(self, user_repr, item_repr, x_user, x_item, user_bias, item_bias):
         """connect_serial_prediction_graph + bias_prediction_serial (tensorrec.py:384-395, :437-449)."""
@@ -307,9 +386,6 @@ class TensorRec(object):
             logging.info('Processing interaction and feature data')
         batches = self._create_batches(interactions, user_features, item_features, user_batch_size)
 
-        if self.n_tastes != 1 or self.attention_graph_factory is not None:
-            raise NotImplementedError("n_tastes > 1 / attention are not built yet (SURVEY.md 8f item 2)")
-
         device = self._device()
         if self._store is None:
             # numbers of features are learned from the first batch and cannot change (tensorrec.py:598-605)
@@ -357,15 +433,23 @@ class TensorRec(object):
         graph = self.prediction_graph_factory
         n_users, n_items = inter.shape
         with variable_scope(self._store):
-            user_repr, item_repr, user_bias, item_bias, weights = self._representations(user_feats, item_feats)
+            user_reprs, attn_reprs, item_repr, user_bias, item_bias, weights = \
+                self._representations(user_feats, item_feats)
+            user_repr = user_reprs[0]
+            multi = self._multi()
             x_user = PairIndex.make(inter.x_user, inter.x_user32, interactions=inter)
             x_item = PairIndex.make(inter.x_item, inter.x_item32, interactions=inter)
 
             engine = self._is_engine_graph()
-            if engine:
-                u_in, i_in = user_repr, item_repr
-                if graph.engine_normalize:        # cosine: normalise once, share between both serial calls
-                    u_in, i_in = ops.l2_normalize_rows(user_repr), ops.l2_normalize_rows(item_repr)
+            u_ins, a_ins, i_in = user_reprs, attn_reprs, item_repr
+            if engine and graph.engine_normalize:     # cosine: normalise once, share between all serial calls
+                u_ins = [ops.l2_normalize_rows(u) for u in user_reprs]
+                a_ins = [ops.l2_normalize_rows(a) for a in attn_reprs] if attn_reprs is not None else None
+                i_in = ops.l2_normalize_rows(item_repr)
+            u_in = u_ins[0]
+            if multi:
+                pred_serial = self._serial_multi(u_ins, a_ins, i_in, x_user, x_item, user_bias, item_bias)
+            elif engine:
                 pred_serial = self._serial_engine(u_in, i_in, x_user, x_item, user_bias, item_bias)
             else:
                 pred_serial = self._serial(user_repr, item_repr, x_user, x_item, user_bias, item_bias)
@@ -378,7 +462,12 @@ class TensorRec(object):
                 'tf_n_items': n_items,
             }
             if loss_graph.is_dense:
-                tf_prediction = self._dense_prediction(user_repr, item_repr, user_bias, item_bias, differentiable=True)
+                if multi:
+                    tf_prediction = self._dense_multi(user_reprs, attn_reprs, item_repr, user_bias, item_bias,
+                                                      differentiable=True)
+                else:
+                    tf_prediction = self._dense_prediction(user_repr, item_repr, user_bias, item_bias,
+                                                           differentiable=True)
                 loss_kwargs.update({'tf_prediction': tf_prediction,
                                     'tf_rankings': rank_predictions(tf_prediction)})
             if loss_graph.is_sample_based:
@@ -389,7 +478,16 @@ class TensorRec(object):
                 samples = samples.to(torch.int32).contiguous()
                 if engine:
                     xs_item = PairIndex.make(samples.reshape(-1), samples.reshape(-1), int(n_sampled_items))
-                    samp_serial = self._serial_engine(u_in, i_in, xs_item, xs_item, user_bias, item_bias)
+                    if multi:
+                        samp_serial = self._serial_multi(u_ins, a_ins, i_in, xs_item, xs_item, user_bias, item_bias,
+                                                         sampled=True)
+                    else:
+                        samp_serial = self._serial_engine(u_in, i_in, xs_item, xs_item, user_bias, item_bias)
+                elif multi:
+                    xs_user64 = torch.arange(n_users, device=samples.device).repeat_interleave(int(n_sampled_items))
+                    xs_item64 = samples.reshape(-1).to(torch.int64)
+                    samp_serial = self._serial_multi(user_reprs, attn_reprs, item_repr, PairIndex.make(xs_user64),
+                                                     PairIndex.make(xs_item64), user_bias, item_bias, sampled=True)
                 else:
                     xs_user64 = torch.arange(n_users, device=samples.device).repeat_interleave(int(n_sampled_items))
                     xs_item64 = samples.reshape(-1).to(torch.int64)
@@ -464,8 +562,10 @@ class TensorRec(object):
     def _predict_device(self, user_features, item_features):
         uf, itf = self._inference(user_features, item_features)
         with torch.no_grad(), variable_scope(self._store):
-            user_repr, item_repr, user_bias, item_bias, _ = self._representations(uf, itf)
-            return self._dense_prediction(user_repr, item_repr, user_bias, item_bias)
+            user_reprs, attn_reprs, item_repr, user_bias, item_bias, _ = self._representations(uf, itf)
+            if self._multi():
+                return self._dense_multi(user_reprs, attn_reprs, item_repr, user_bias, item_bias)
+            return self._dense_prediction(user_reprs[0], item_repr, user_bias, item_bias)
 
     def predict(self, user_features, item_features):
         """Recommendation scores, ndarray [n_users, n_items] float32 (tensorrec.py:636-664)."""
@@ -489,17 +589,23 @@ class TensorRec(object):
         uf, itf = self._inference(user_features, item_features)
         dtype = ops.DTYPE_BF16 if self.precision == 'bf16' else ops.DTYPE_F32
         want_sq = graph.engine_mode == ops.MODE_EUCLIDEAN
+        if self.attention_graph_factory is not None:
+            raise NotImplementedError("predict_top_k is not available for attention models: the softmax-weighted sum "
+                                      "over tastes does not decompose into per-taste top-k lists; use predict_rank")
         vals, idx = [], []
         with torch.no_grad(), variable_scope(self._store):
-            user_repr, item_repr, user_bias, item_bias, _ = self._representations(uf, itf)
+            user_reprs, _, item_repr, user_bias, item_bias, _ = self._representations(uf, itf)
             i_op, i_sq, kpad = ops.score_prep(item_repr, dtype, normalize=graph.engine_normalize, want_sqnorm=want_sq)
             ib = item_bias.contiguous() if self.biased else None
             for s in range(0, uf.shape[0], user_batch_size):
                 e = min(s + user_batch_size, uf.shape[0])
-                u_op, u_sq, _ = ops.score_prep(user_repr[s:e], dtype, normalize=graph.engine_normalize,
-                                               want_sqnorm=want_sq)
                 ub = user_bias[s:e].contiguous() if self.biased else None
-                v, i = ops.score_topk(u_op, i_op, dtype, kpad, k, ub, ib, graph.engine_mode, u_sq, i_sq)
+                per_taste = []
+                for user_repr in user_reprs:
+                    u_op, u_sq, _ = ops.score_prep(user_repr[s:e], dtype, normalize=graph.engine_normalize,
+                                                   want_sqnorm=want_sq)
+                    per_taste.append(ops.score_topk(u_op, i_op, dtype, kpad, k, ub, ib, graph.engine_mode, u_sq, i_sq))
+                v, i = per_taste[0] if len(per_taste) == 1 else _merge_taste_topk(per_taste, k)
                 vals.append(v)
                 idx.append(i)
         vals, idx = torch.cat(vals), torch.cat(idx)
@@ -526,20 +632,24 @@ class TensorRec(object):
         return results
 
     def predict_user_representation(self, user_features):
-        """ndarray [n_users, n_components] (tensorrec.py:735-762)."""
+        """ndarray [n_users, n_components], or [n_tastes, n_users, n_components] when n_tastes > 1
+        (tensorrec.py:735-762)."""
         self._check_fit('predict_user_representation')
         uf, _ = self._inference(user_features, None)
         with torch.no_grad(), variable_scope(self._store):
-            user_repr, _ = self.user_repr_graph_factory.connect_representation_graph(
-                tf_features=uf, n_components=self.n_components, n_features=self.n_user_features,
-                node_name_ending='user_{}'.format(0))
-        return user_repr.cpu().numpy()
+            user_reprs, _, _ = self._user_representations(uf)
+        user_repr = torch.stack(user_reprs).cpu().numpy()
+        return user_repr[0] if self.n_tastes == 1 else user_repr
 
     def predict_user_attention_representation(self, user_features):
+        """ndarray [n_tastes, n_users, n_components] (tensorrec.py:764-793)."""
         self._check_fit('predict_user_attention_representation')
         if self.attention_graph_factory is None:
             raise ModelWithoutAttentionException()
-        raise NotImplementedError("attention is not built yet (SURVEY.md 8f item 2)")
+        uf, _ = self._inference(user_features, None)
+        with torch.no_grad(), variable_scope(self._store):
+            _, attn_reprs, _ = self._user_representations(uf)
+        return torch.stack(attn_reprs).cpu().numpy()
 
     def predict_item_representation(self, item_features):
         """ndarray [n_items, n_components] (tensorrec.py:795-816)."""
@@ -588,6 +698,55 @@ class TensorRec(object):
             self._adam = {}
             self._opt_step = 0
 
+    # ------------------------------------------------------------------------------------------ persistence
+    def __getstate__(self):
+        """The python object without device state (the role of ``_break_graph_hooks``, tensorrec.py:247-257): weights
+        and optimiser slots travel in the checkpoint file next to the pickle."""
+        state = dict(self.__dict__)
+        state['_store'] = None
+        state['_adam'] = {}
+        state['_capture'] = None
+        state['process_group'] = None
+        return state
+
+    def save_model(self, directory_path):
+        """Saves the model to files in the given directory (tensorrec.py:869-893): ``tensorrec.pkl`` (the python
+        object: hyper-parameters and graph objects) and ``tensorrec_session.npz`` (every variable, its Adam slots and
+        the step counters -- what the TF checkpoint holds in the reference)."""
+        self._check_fit('save_model')
+        if not os.path.exists(directory_path):
+            os.makedirs(directory_path)
+        arrays = {}
+        for i, name in enumerate(self._store.order):
+            arrays['var/%d' % i] = self._store.variables[name].detach().cpu().numpy()
+            if name in self._adam:
+                arrays['adam_m/%d' % i] = self._adam[name][0].cpu().numpy()
+                arrays['adam_v/%d' % i] = self._adam[name][1].cpu().numpy()
+        arrays['names'] = np.array(self._store.order)
+        arrays['counters'] = np.array([self._opt_step, self._sample_step], dtype=np.int64)
+        with open(os.path.join(directory_path, 'tensorrec_session.npz'), 'wb') as file:
+            np.savez(file, **arrays)
+        with open(os.path.join(directory_path, 'tensorrec.pkl'), 'wb') as file:
+            pickle.dump(file=file, obj=self)
+
+    @classmethod
+    def load_model(cls, directory_path):
+        """Loads the model saved in the given directory (tensorrec.py:895-917) onto this process's GPU; predictions and
+        ranks are bit-identical to the saved model's and ``fit_partial`` continues from the saved optimiser state."""
+        with open(os.path.join(directory_path, 'tensorrec.pkl'), 'rb') as file:
+            model = pickle.load(file=file)
+        device = model._device()
+        with np.load(os.path.join(directory_path, 'tensorrec_session.npz'), allow_pickle=False) as ckpt:
+            names = [str(n) for n in ckpt['names']]
+            model._store = VariableStore(device)
+            for i, name in enumerate(names):
+                model._store.get(name, ckpt['var/%d' % i])
+                if 'adam_m/%d' % i in ckpt.files:
+                    model._adam[name] = (torch.from_numpy(ckpt['adam_m/%d' % i]).to(device),
+                                         torch.from_numpy(ckpt['adam_v/%d' % i]).to(device))
+            model._opt_step, model._sample_step = (int(c) for c in ckpt['counters'])
+        return model
+
     def build(self, n_user_features, n_item_features):
         """EXTENSION: create the variables without a training step (weights then come from set_weights or the
         initialisers); fit_partial does this implicitly on its first call."""
@@ -604,6 +763,30 @@ class TensorRec(object):
             with torch.no_grad(), variable_scope(self._store):
                 self._representations(uf, itf)
         return self
+
+
+def _merge_taste_topk(per_taste, k):
+    """Top-k of max-over-tastes from the per-taste top-k lists.  Exact, ties included: rounding is monotone, so adding
+    the biases before the max gives the same floats as after it, and an item of the collapsed top-k is in the top-k
+    list of the taste that attains its maximum (everything ahead of it in that list is ahead of it in the collapsed
+    order too).  The lists are [n_users, T * k] -- a few KB per user -- so the merge is index plumbing: order by item
+    id, keep the best copy of each item, then order by (score desc, item asc)."""
+    v = torch.cat([p[0] for p in per_taste], dim=1)
+    i = torch.cat([p[1] for p in per_taste], dim=1)
+    o = torch.sort(v, dim=1, descending=True, stable=True).indices
+    v, i = torch.gather(v, 1, o), torch.gather(i, 1, o)
+    key = torch.where(i < 0, torch.full_like(i, 2 ** 31 - 1), i)
+    o = torch.sort(key, dim=1, stable=True).indices           # item asc; equal items keep score-desc order
+    v, i, key = torch.gather(v, 1, o), torch.gather(i, 1, o), torch.gather(key, 1, o)
+    dup = torch.zeros_like(i, dtype=torch.bool)
+    dup[:, 1:] = key[:, 1:] == key[:, :-1]
+    v = torch.where(dup, torch.full_like(v, float('-inf')), v)
+    i = torch.where(dup | (i < 0), torch.full_like(i, -1), i)
+    key = torch.where(i < 0, torch.full_like(i, 2 ** 31 - 1), i)
+    o = torch.sort(key, dim=1, stable=True).indices           # duplicates (now -1) to the back, item asc kept
+    v, i = torch.gather(v, 1, o), torch.gather(i, 1, o)
+    o = torch.sort(v, dim=1, descending=True, stable=True).indices[:, :k]
+    return torch.gather(v, 1, o).contiguous(), torch.gather(i, 1, o).contiguous()
 
 
 class _DenseDot(torch.autograd.Function):

@@ -296,3 +296,43 @@ def test_training_reduces_wmrb_loss_and_ranks_positives_higher():
     model.fit(inter, uf, itf, epochs=40, n_sampled_items=30, learning_rate=0.05)
     r1 = model.predict_rank(uf, itf)[inter.nonzero()].mean()
     assert r1 < 0.5 * r0, (r0, r1)
+
+
+# ---- persistence (test/test_tensorrec.py:399-458 restated) ------------------------------------------------------
+@pytest.mark.parametrize("n_tastes", [1, 3])
+def test_save_and_load_model(tmp_path, n_tastes):
+    inter, uf, itf = T.util.generate_dummy_data(num_users=15, num_items=30, interaction_density=.5, num_user_features=200,
+                                                num_item_features=200, n_features_per_user=20, n_features_per_item=20,
+                                                pos_int_ratio=.5, random_state=0)
+    with pytest.raises(T.errors.ModelNotFitException):
+        T.TensorRec(n_components=10).save_model(str(tmp_path / "unfit"))
+    model = T.TensorRec(n_components=10, n_tastes=n_tastes, seed=4)
+    model.fit(inter, uf, itf, epochs=10)
+    predictions, ranks = model.predict(uf, itf), model.predict_rank(uf, itf)
+    directory = str(tmp_path / "model" / "nested")
+    model.save_model(directory_path=directory)
+    assert (predictions == model.predict(uf, itf)).all() and (ranks == model.predict_rank(uf, itf)).all()
+    new_model = T.TensorRec.load_model(directory_path=directory)
+    assert (predictions == new_model.predict(uf, itf)).all() and (ranks == new_model.predict_rank(uf, itf)).all()
+    # the optimiser state travels too: one more epoch on both gives identical weights (the RMSE step is deterministic)
+    assert (new_model._opt_step, new_model._sample_step) == (model._opt_step, model._sample_step)
+    model.fit_partial(inter, uf, itf, epochs=1)
+    new_model.fit_partial(inter, uf, itf, epochs=1)
+    a, b = model.get_weights(), new_model.get_weights()
+    assert set(a) == set(b) and all(np.array_equal(a[k], b[k]) for k in a)
+
+
+def test_fit_and_eval_and_metrics_from_gpu_ranks():
+    from oracle import eval_dense
+    inter, uf, itf = T.util.generate_dummy_data_with_indicator(num_users=10, num_items=12, interaction_density=.5,
+                                                               seed=1)
+    model = T.TensorRec(n_components=10, seed=0)
+    out = T.eval.fit_and_eval(model, uf, itf, inter, inter, {"epochs": 10}, recall_k=5, precision_k=5, ndcg_k=5)
+    assert len(out) == 6 and out[:3] == out[3:] and all(0.0 <= v <= 1.0 for v in out)
+    ranks = model.predict_rank(uf, itf)
+    for name in ("precision_at_k", "recall_at_k", "ndcg_at_k"):
+        np.testing.assert_allclose(getattr(T.eval, name)(ranks, inter, k=5), getattr(eval_dense, name)(ranks, inter, k=5),
+                                   rtol=1e-12)
+    ndcg5, ndcg10, ndcg20 = (np.mean(T.eval.ndcg_at_k(ranks, inter, k=k)) for k in (5, 10, 20))
+    assert ndcg10 >= ndcg5 and ndcg20 == ndcg10 and ndcg20 < 1                       # test/test_eval.py:80-83
+    assert T.eval.f1_score_at_k(ranks, inter, k=5) is not None
