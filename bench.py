@@ -192,8 +192,10 @@ def main():
                 vals, idx = ops.score_topk_direct(u_op, i_op, dtype, kpad, k, ub, ib, item_index_base=i_begin,
                                                   n_chunks=n_chunks, variant=args.variant, workspace=ws)  # K2 + merge
             else:
+                # item shards share ONE top-k floor per user (all-gather of k superblock maxima) before re-scoring
                 vals, idx = ops.score_topk_two_stage(u_op, i_op, dtype, kpad, k, ub, ib, item_index_base=i_begin,
-                                                     variant=args.variant)
+                                                     variant=args.variant,
+                                                     floor_exchange=sharding.shared_topk_floor if world > 1 else None)
             if world > 1:
                 vals, idx = sharding.sharded_top_k(vals, idx, k)                                          # 1 all-gather
             return vals, idx, user_repr, item_repr

@@ -107,10 +107,16 @@ int trec_score_gemm_blockmax(const void* users, const void* items, int32_t dtype
                              int64_t n_items, const float* user_bias, const float* item_bias, int32_t mode,
                              const float* user_sqnorm, const float* item_sqnorm, int32_t sb_rows, int32_t n_chunks,
                              float* blockmax, int64_t bm_stride, int32_t variant, void* stream);
-/* tau (nullable) [n_users]: the k-th largest superblock maximum = a floor of the final k-th best score */
+/* tau (nullable) [n_users]: the k-th largest superblock maximum = a floor of the final k-th best score;
+ * sel_max (nullable) [k, n_users]: the maxima of the selected superblocks, in the blockmax layout.
+ * trec_topk_group_keys: keys[i] = sel[i], or the dummy bucket n_sb for empty slots and -- when floor [n_users] is given
+ * -- for superblocks with sel_max < floor[i / k].  With item shards the floor is the k-th largest superblock maximum
+ * over ALL shards: all-gather the ranks' sel_max ([world * k, n_users] IS a blockmax table) and run
+ * trec_topk_select_blocks on it; re-scoring then totals ~k superblocks per user over all shards instead of k per shard. */
 int trec_topk_select_blocks(const float* blockmax, int32_t n_sb, int64_t n_users, int64_t stride, int32_t k, int32_t* sel,
-                            float* tau, void* stream);
-int trec_topk_group_keys(const int32_t* sel, int64_t n, int32_t n_sb, int32_t* keys, void* stream);
+                            float* sel_max, float* tau, void* stream);
+int trec_topk_group_keys(const int32_t* sel, const float* sel_max, const float* floor, int64_t n, int32_t k, int32_t n_sb,
+                         int32_t* keys, void* stream);
 int trec_topk_pad_counts(const int64_t* indptr_t, int32_t n_sb, int32_t rows_wg, int32_t* cnt_pad, void* stream);
 int trec_exclusive_scan_i32(const int32_t* counts, int64_t n, int64_t* workspace_i64, int64_t* out, void* stream);
 int trec_topk_fill_groups(const int64_t* pstart, const int64_t* indptr_t, const int32_t* users_t, const int32_t* perm_t,

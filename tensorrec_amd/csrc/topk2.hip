@@ -32,7 +32,8 @@ __device__ __forceinline__ void sel_insert(float (&tv)[KSEL], int32_t (&ti)[KSEL
 template <int KSEL>
 __global__ __launch_bounds__(256) void select_blocks_kernel(const float* __restrict__ blockmax, int32_t n_sb,
                                                            int64_t n_users, int64_t stride, int32_t k,
-                                                           int32_t* __restrict__ sel, float* __restrict__ tau)
+                                                           int32_t* __restrict__ sel, float* __restrict__ sel_max,
+                                                           float* __restrict__ tau)
 {
     const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool ok = u < n_users;
@@ -49,19 +50,32 @@ __global__ __launch_bounds__(256) void select_blocks_kernel(const float* __restr
     if (ok) {
 #pragma unroll
         for (int j = 0; j < KSEL; ++j)
-            if (j < k) sel[u * k + j] = ti[j];
+            if (j < k) {
+                sel[u * k + j] = ti[j];
+                if (sel_max) sel_max[(int64_t)j * n_users + u] = tv[j];     // [k][n_users]: the blockmax layout
+            }
         // k superblocks have a maximum >= tv[k-1], i.e. k items score >= it: a valid floor for the final k-th best score
         // (-inf while fewer than k superblocks exist).  The re-scoring pass starts its lists from this threshold.
         if (tau) tau[u] = (ti[KSEL - 1] >= 0) ? tv[KSEL - 1] : -INFINITY;
     }
 }
 
-// keys for the counting sort: superblock id, or n_sb (a dummy bucket) for empty slots
-__global__ __launch_bounds__(256) void group_keys_kernel(const int32_t* __restrict__ sel, int64_t n, int32_t n_sb,
-                                                        int32_t* __restrict__ keys)
+// keys for the counting sort: superblock id, or n_sb (a dummy bucket) for empty slots and for superblocks whose
+// maximum lies below the user's floor.  The floor is any lower bound of the user's final k-th best score -- with item
+// shards, the MAX over ranks of the per-shard tau (every shard's k-th best is a floor of the global k-th best): a
+// superblock with max < floor holds no item of the global top-k (strict: a score equal to the floor may still tie in).
+// sel_max is [k][n_users] (the blockmax layout), so the all-gathered maxima of all ranks can go straight back through
+// select_blocks_kernel, whose tau output is then the k-th largest superblock maximum over ALL shards.
+__global__ __launch_bounds__(256) void group_keys_kernel(const int32_t* __restrict__ sel,
+                                                        const float* __restrict__ sel_max,
+                                                        const float* __restrict__ floor_, int64_t n, int32_t k,
+                                                        int32_t n_sb, int32_t* __restrict__ keys)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) keys[i] = sel[i] >= 0 ? sel[i] : n_sb;
+    if (i >= n) return;
+    bool keep = sel[i] >= 0;
+    if (keep && floor_) keep = !(sel_max[(i % k) * (n / k) + i / k] < floor_[i / k]);
+    keys[i] = keep ? sel[i] : n_sb;
 }
 
 // padded group sizes: every superblock's list of users is rounded up to whole workgroups of `rows_wg` rows
@@ -118,7 +132,7 @@ __global__ __launch_bounds__(256) void fill_groups_kernel(
 }
 
 extern "C" int trec_topk_select_blocks(const float* blockmax, int32_t n_sb, int64_t n_users, int64_t stride, int32_t k,
-                                       int32_t* sel, float* tau, void* stream)
+                                       int32_t* sel, float* sel_max, float* tau, void* stream)
 {
     TREC_REQUIRE(blockmax && sel, "trec_topk_select_blocks: null pointer");
     TREC_REQUIRE(k >= 1 && k <= 16 && n_sb >= 1, "trec_topk_select_blocks: need 1 <= k <= 16, n_sb >= 1");
@@ -126,7 +140,7 @@ extern "C" int trec_topk_select_blocks(const float* blockmax, int32_t n_sb, int6
     const unsigned blocks = (unsigned)ceil_div64(n_users, 256);
     hipStream_t st = (hipStream_t)stream;
     // the list length IS k here (threshold = k-th best): instantiate the lengths in use
-#define TREC_SEL(KS) hipLaunchKernelGGL((select_blocks_kernel<KS>), dim3(blocks), dim3(256), 0, st, blockmax, n_sb, n_users, stride, k, sel, tau)
+#define TREC_SEL(KS) hipLaunchKernelGGL((select_blocks_kernel<KS>), dim3(blocks), dim3(256), 0, st, blockmax, n_sb, n_users, stride, k, sel, sel_max, tau)
     switch (k) {
         case 1: TREC_SEL(1); break;   case 2: TREC_SEL(2); break;   case 3: TREC_SEL(3); break;   case 4: TREC_SEL(4); break;
         case 5: TREC_SEL(5); break;   case 6: TREC_SEL(6); break;   case 7: TREC_SEL(7); break;   case 8: TREC_SEL(8); break;
@@ -137,12 +151,14 @@ extern "C" int trec_topk_select_blocks(const float* blockmax, int32_t n_sb, int6
     return trec_check_launch("trec_topk_select_blocks");
 }
 
-extern "C" int trec_topk_group_keys(const int32_t* sel, int64_t n, int32_t n_sb, int32_t* keys, void* stream)
+extern "C" int trec_topk_group_keys(const int32_t* sel, const float* sel_max, const float* floor_, int64_t n, int32_t k,
+                                    int32_t n_sb, int32_t* keys, void* stream)
 {
-    TREC_REQUIRE(sel && keys, "trec_topk_group_keys: null pointer");
+    TREC_REQUIRE(sel && keys && k >= 1, "trec_topk_group_keys: null pointer");
+    TREC_REQUIRE(!floor_ || sel_max, "trec_topk_group_keys: a floor needs the selected maxima");
     if (n == 0) return TREC_OK;
-    hipLaunchKernelGGL(group_keys_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, (hipStream_t)stream, sel, n,
-                       n_sb, keys);
+    hipLaunchKernelGGL(group_keys_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, (hipStream_t)stream, sel,
+                       sel_max, floor_, n, k, n_sb, keys);
     return trec_check_launch("trec_topk_group_keys");
 }
 

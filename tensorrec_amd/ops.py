@@ -536,7 +536,8 @@ SUPERBLOCK_ROWS = 512
 
 
 def score_topk(users_op, items_op, dtype, kpad, k, user_bias=None, item_bias=None, mode=MODE_DOT, user_sq=None,
-               item_sq=None, item_index_base=0, n_chunks=None, variant=1, workspace=None, method="auto"):
+               item_sq=None, item_index_base=0, n_chunks=None, variant=1, workspace=None, method="auto",
+               floor_exchange=None):
     """Exact per-user top-k of the score matrix without materialising it.  Returns (values [U, k], item ids [U, k]),
     ordered (value desc, index asc).  ``method``: 'direct' (one fused pass with per-lane lists), 'two_stage'
     (superblock maxima -> select -> re-score, data-independent cost) or 'auto'."""
@@ -544,7 +545,7 @@ def score_topk(users_op, items_op, dtype, kpad, k, user_bias=None, item_bias=Non
         method = "two_stage" if items_op.shape[0] >= TWO_STAGE_MIN_ITEMS and n_chunks is None else "direct"
     if method == "two_stage":
         return score_topk_two_stage(users_op, items_op, dtype, kpad, k, user_bias, item_bias, mode, user_sq, item_sq,
-                                    item_index_base, variant=variant)
+                                    item_index_base, variant=variant, floor_exchange=floor_exchange)
     return score_topk_direct(users_op, items_op, dtype, kpad, k, user_bias, item_bias, mode, user_sq, item_sq,
                              item_index_base, n_chunks, variant, workspace)
 
@@ -571,8 +572,13 @@ def score_topk_direct(users_op, items_op, dtype, kpad, k, user_bias=None, item_b
 
 
 def score_topk_two_stage(users_op, items_op, dtype, kpad, k, user_bias=None, item_bias=None, mode=MODE_DOT,
-                         user_sq=None, item_sq=None, item_index_base=0, sb_rows=None, variant=1, n_chunks=None):
-    """See include/tensorrec_hip.h ("Two-stage exact top-k") and csrc/topk2.hip for the exactness argument."""
+                         user_sq=None, item_sq=None, item_index_base=0, sb_rows=None, variant=1, n_chunks=None,
+                         floor_exchange=None):
+    """See include/tensorrec_hip.h ("Two-stage exact top-k") and csrc/topk2.hip for the exactness argument.
+    ``floor_exchange``: for item shards, a callable ``(sel_max [k, n_users]) -> floor [n_users]`` giving a lower bound
+    of every user's GLOBAL k-th best score (sharding.shared_topk_floor: all-gather of the selected superblock maxima +
+    their k-th largest); superblocks below it are not re-scored, so stage 3 costs ~k superblocks per user over all
+    shards together instead of k per shard.  The lists returned are then exact only after the cross-shard merge."""
     cap = N.query("trec_score_topk_capacity", int(k))
     if cap < 0:
         raise ValueError("fused top-k supports k <= 16 (got %d)" % k)
@@ -596,13 +602,20 @@ def score_topk_two_stage(users_op, items_op, dtype, kpad, k, user_bias=None, ite
     # ---- stage 2: the ksel best superblocks of every user
     sel = torch.empty((n_u, ksel), dtype=torch.int32, device=dev)
     tau = torch.empty((n_u,), dtype=torch.float32, device=dev) if ksel == int(k) else None   # floor needs k superblocks
+    sel_max = None
+    if floor_exchange is not None:                  # rows >= ksel stay -inf (a shard with fewer than k superblocks)
+        sel_max = torch.full((int(k), n_u), float('-inf'), dtype=torch.float32, device=dev)
     with _timed("topk_select_blocks"):
-        N.call("trec_topk_select_blocks", N.ptr(blockmax), n_sb, n_u, n_u, ksel, N.ptr(sel), N.ptr(tau))
+        N.call("trec_topk_select_blocks", N.ptr(blockmax), n_sb, n_u, n_u, ksel, N.ptr(sel), N.ptr(sel_max), N.ptr(tau))
     del blockmax
+    floor = None
+    if floor_exchange is not None:
+        floor = tau = floor_exchange(sel_max).contiguous()
+        sel_max = sel_max[:ksel]
     # ---- stage 3a: group (user, slot) pairs by superblock, pad groups to whole workgroups, gather operand rows
     n_pairs = n_u * ksel
     keys = torch.empty((n_pairs,), dtype=torch.int32, device=dev)
-    N.call("trec_topk_group_keys", N.ptr(sel), n_pairs, n_sb, N.ptr(keys))
+    N.call("trec_topk_group_keys", N.ptr(sel), N.ptr(sel_max), N.ptr(floor), n_pairs, ksel, n_sb, N.ptr(keys))
     indptr_t, users_t, perm_t = group_pairs_by_item(None, keys, ksel, n_sb + 1)
     cnt_pad = torch.empty((n_sb + 1,), dtype=torch.int32, device=dev)
     N.call("trec_topk_pad_counts", N.ptr(indptr_t), n_sb, rows_wg, N.ptr(cnt_pad))

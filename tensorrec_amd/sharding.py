@@ -40,13 +40,16 @@ def shard_bounds(n_items, world_size, rank, align=64):
 
 
 def all_gather_cat(t, group=None, dim=1):
-    """All-gather equal-shaped tensors and concatenate along ``dim`` (rank order)."""
+    """All-gather equal-shaped tensors and concatenate along ``dim`` (rank order): ONE collective into one buffer."""
     world = dist.get_world_size(group)
     if world == 1:
         return t
-    parts = [torch.empty_like(t) for _ in range(world)]
-    dist.all_gather(parts, t.contiguous(), group=group)
-    return torch.cat(parts, dim=dim)
+    t = t.contiguous()
+    out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, t, group=group)           # rank-major along dim 0
+    if dim == 0:
+        return out
+    return torch.cat(list(out.reshape((world,) + tuple(t.shape)).unbind(0)), dim=dim)
 
 
 def exchange_topk(local_vals, local_idx, group=None):
@@ -79,6 +82,27 @@ def all_reduce_sum_(tensors, group=None):
         for t in tensors:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return tensors
+
+
+def kth_largest_block_max(block_maxima, k):
+    """[n_blocks, n_users] superblock maxima -> [n_users] the k-th largest per user (-inf with fewer than k): the
+    stage-2 selection kernel run for its floor output only."""
+    from . import ops, _native as N
+    n_blocks, n_users = block_maxima.shape
+    sel = torch.empty((n_users, k), dtype=torch.int32, device=block_maxima.device)
+    floor = torch.empty((n_users,), dtype=torch.float32, device=block_maxima.device)
+    N.call("trec_topk_select_blocks", N.ptr(block_maxima), n_blocks, n_users, n_users, k, N.ptr(sel), None, N.ptr(floor))
+    return floor
+
+
+def shared_topk_floor(sel_max, group=None):
+    """The ``floor_exchange`` of ops.score_topk_two_stage for item shards: every rank contributes the maxima of its k
+    selected superblocks ([k, n_users], 4k bytes per user -- 40 MB at 1M users, k = 10); the k-th largest of the
+    world * k gathered maxima bounds every user's global k-th best score from below (k disjoint superblocks each hold an
+    item scoring at least that).  ONE all-gather; the result is identical on every rank."""
+    k = sel_max.shape[0]
+    gathered = all_gather_cat(sel_max, group, dim=0) if dist.is_initialized() else sel_max     # [world * k, n_users]
+    return kth_largest_block_max(gathered, k)
 
 
 def all_reduce_scalar(value, device, group=None):

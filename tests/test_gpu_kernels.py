@@ -569,6 +569,56 @@ def test_item_shards_merge_to_global_topk(ops, world):
     assert np.array_equal(gi.cpu().numpy(), ri) and np.array_equal(gv.cpu().numpy(), rv)
 
 
+@pytest.mark.parametrize("world,n_items,dtype_name", [(2, 40000, "f32"), (8, 70000, "bf16"), (4, 3000, "f32")])
+def test_item_shards_two_stage_with_shared_floor(ops, world, n_items, dtype_name):
+    """Item shards + two-stage top-k + the shared floor (what bench.py --gpus N runs): the k-th largest superblock
+    maximum over ALL shards bounds the global k-th best score from below (a first pass collects what every rank would
+    all-gather, a second pass injects the floor where the collective would sit), superblocks below it are not
+    re-scored, and the merged lists are still the exact global top-k, ties included (integer-valued scores make ties
+    abundant).  The last case has fewer superblocks than k per shard."""
+    from tensorrec_amd import sharding
+    dt = ops.DTYPE_F32 if dtype_name == "f32" else ops.DTYPE_BF16
+    n_users, k = 200, 10
+    u, v = _uv(n_users, n_items, 128, seed=world, integer=(dtype_name == "f32"))
+    rng = np.random.default_rng(2)
+    ub = np.round(rng.standard_normal(n_users)).astype(np.float32)
+    ib = np.round(rng.standard_normal(n_items)).astype(np.float32)
+    u_op, _, kpad = ops.score_prep(dev(u), dt)
+    shards = []
+    for r in range(world):
+        b, e = sharding.shard_bounds(n_items, world, r, align=64)
+        v_op, _, _ = ops.score_prep(dev(v[b:e]), dt)
+        shards.append((b, v_op, dev(ib[b:e])))
+    maxima = []
+
+    def grab(sel_max):                      # pass 1: what every rank would contribute to the all-gather
+        maxima.append(sel_max.clone())
+        return torch.full((n_users,), float('-inf'), device=sel_max.device)
+
+    for b, v_op, ibs in shards:
+        ops.score_topk_two_stage(u_op, v_op, dt, kpad, k, dev(ub), ibs, item_index_base=b, floor_exchange=grab)
+    floor = sharding.kth_largest_block_max(torch.cat(maxima, dim=0), k)
+    lists_v, lists_i, kept = [], [], 0
+    for b, v_op, ibs in shards:
+        lv, li = ops.score_topk_two_stage(u_op, v_op, dt, kpad, k, dev(ub), ibs, item_index_base=b,
+                                          floor_exchange=lambda sel_max: floor)
+        lists_v.append(lv)
+        lists_i.append(li)
+        kept += int((li >= 0).sum())
+    gv, gi = sharding.merge_topk(torch.cat(lists_v, dim=1), torch.cat(lists_i, dim=1), k)
+    if dtype_name == "f32":
+        scores = O.score_dense_exact(u, v, ub, ib)
+    else:
+        v_full, _, _ = ops.score_prep(dev(v), dt)
+        scores = ops.score_store(u_op, v_full, dt, kpad, dev(ub), dev(ib)).cpu().numpy()
+    rv, ri = O.topk_rows(scores, k)
+    assert np.array_equal(gi.cpu().numpy(), ri) and np.array_equal(gv.cpu().numpy(), rv)
+    assert (floor.cpu().numpy() <= rv[:, k - 1]).all()       # a lower bound of the true k-th best score
+    # the floor did prune: without it every shard returns k items per user (continuous scores: ties are rare)
+    if dtype_name == "bf16":
+        assert kept < 0.5 * world * n_users * k
+
+
 @pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7])
 def test_score_topk_bf16_all_tilings(ops, variant):
     """Every tiling of the hot configuration (bf16, K=128, top-10 -> capacity 12) gives the exact top-k of the bf16
