@@ -88,37 +88,52 @@ def cpu_baseline(n_items, d, k, n_users_sample, seed=0):
                       "d=%d, top-%d, %.1f s" % (n_users_sample, n_items, d, k, dt)}
 
 
-def fit_epochs_per_sec(n_users, n_items, d, per_user=20, n_sampled=100, epochs=3):
+def fit_epochs_per_sec(n_users, n_items, d, per_user=20, n_sampled=100, epochs=3, rank=0, world=1):
     """Second half of BASELINE.json's metric: fit epochs/sec on the same 1M x 1M, d=128 shape.  One epoch = one
     optimiser step over all users (user_batch_size=None) through the public API: K1 fwd (user + item), K7 sampling,
     K3 over the interactions and the U*S sampled pairs, K6 WMRB fwd+bwd, backward gathers (K1 on transposed / grouped
-    structures), K8 dense Adam on every weight.  20 uniform-random positive interactions per user."""
+    structures), K8 dense Adam on every weight.  20 uniform-random positive interactions per user.
+    N ranks: data-parallel over users (the reference's batching axis) -- every rank takes a contiguous slice of user
+    rows, items and weights are replicated, ONE all-reduce(SUM) per weight gradient per step (tensorrec_amd/sharding.py);
+    the problem stays 1M x 1M (strong scaling) and the time is the slowest rank's."""
     import scipy.sparse as sp
     import torch
     import tensorrec_amd as T
-    rng = np.random.default_rng(0)
-    cols = rng.integers(0, n_items, size=(n_users, per_user), dtype=np.int32)
-    indptr = np.arange(0, (n_users + 1) * per_user, per_user, dtype=np.int64)
-    inter = sp.csr_matrix((np.ones(n_users * per_user, np.float32), cols.reshape(-1), indptr), shape=(n_users, n_items))
+    from tensorrec_amd import sharding
+    u0, u1 = (n_users * rank) // world, (n_users * (rank + 1)) // world
+    rng = np.random.default_rng(1000 + rank)
+    n_loc = u1 - u0
+    cols = rng.integers(0, n_items, size=(n_loc, per_user), dtype=np.int32)
+    indptr = np.arange(0, (n_loc + 1) * per_user, per_user, dtype=np.int64)
+    inter = sp.csr_matrix((np.ones(n_loc * per_user, np.float32), cols.reshape(-1), indptr), shape=(n_loc, n_items))
     inter.sum_duplicates()
     inter.data[:] = 1.0
-    uf = sp.identity(n_users, dtype=np.float32, format="csr")
+    # this rank's rows of the identity user-feature matrix (all n_users feature columns stay: weights are replicated)
+    uf = sp.csr_matrix((np.ones(n_loc, np.float32), np.arange(u0, u1, dtype=np.int32),
+                        np.arange(n_loc + 1, dtype=np.int64)), shape=(n_loc, n_users))
     itf = sp.identity(n_items, dtype=np.float32, format="csr")
-    model = T.TensorRec(n_components=d, loss_graph=T.loss_graphs.WMRBLossGraph(), seed=0)
-    model.fit_partial(inter, uf, itf, epochs=1, n_sampled_items=n_sampled)           # build + warm-up
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    model.fit_partial(inter, uf, itf, epochs=1, n_sampled_items=n_sampled)
-    torch.cuda.synchronize()
-    one = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    model.fit_partial(inter, uf, itf, epochs=1 + epochs, n_sampled_items=n_sampled)
-    torch.cuda.synchronize()
-    per_epoch = (time.perf_counter() - t0 - one) / epochs           # removes the per-call upload of the inputs
+    model = T.TensorRec(n_components=d, loss_graph=T.loss_graphs.WMRBLossGraph(), seed=0, data_parallel=world > 1)
+    device = torch.device("cuda", torch.cuda.current_device())
+
+    def run(n_epochs):
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        t0 = time.perf_counter()
+        model.fit_partial(inter, uf, itf, epochs=n_epochs, n_sampled_items=n_sampled, user_offset=u0)
+        torch.cuda.synchronize()
+        return sharding.max_over_ranks(time.perf_counter() - t0, device)
+
+    run(1)                                                           # build + warm-up
+    one = run(1)
+    per_epoch = (run(1 + epochs) - one) / epochs                     # removes the per-call upload of the inputs
+    nnz = sharding.all_reduce_scalar(int(inter.nnz), device)
     return {"fit_epochs_per_sec": 1.0 / per_epoch, "sec_per_epoch": per_epoch, "epochs_timed": epochs,
             "workload": "%d users x %d items, identity features, d=%d, Linear + DotProduct + WMRB, biased, %d "
                         "interactions, n_sampled_items=%d, device sampler, 1 optimiser step per epoch"
-                        % (n_users, n_items, d, int(inter.nnz), n_sampled),
+                        % (n_users, n_items, d, nnz, n_sampled),
+            "parallelism": "single GPU" if world == 1 else
+                           "users sharded x%d (data-parallel), items + weights replicated, gradient all-reduce" % world,
             "per_call_input_upload_sec": one - per_epoch}
 
 
@@ -228,6 +243,14 @@ def main():
         pad[: item_repr_local.shape[0]] = item_repr_local
         full = sharding.all_gather_cat(pad, dim=0)[:I].contiguous()
         out = (vals, idx, user_repr, full)
+    fit = None
+    if not args.no_fit:
+        try:                      # every rank takes part (data-parallel over users for world > 1)
+            del ws
+            torch.cuda.empty_cache()
+            fit = fit_epochs_per_sec(U, I, d, rank=rank, world=world)
+        except Exception as exc:
+            fit = {"error": repr(exc)}
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -306,15 +329,6 @@ def main():
                                                                  and np.array_equal(ev.cpu().numpy(), exact_ref[0]))}
     except Exception as exc:      # the measurement stands on its own; report why the check could not run
         parity = {"error": repr(exc)}
-
-    fit = None
-    if not args.no_fit and world == 1:
-        try:
-            del out, ws, w_u, w_i, f_u, f_i
-            torch.cuda.empty_cache()
-            fit = fit_epochs_per_sec(U, I, d)
-        except Exception as exc:
-            fit = {"error": repr(exc)}
 
     cpu = None
     if not args.no_cpu_baseline and world == 1:
