@@ -193,6 +193,12 @@ int trec_sample_items(int64_t n_users, int64_t user_base, int32_t n_items, int32
 int trec_adam_tf_step(float* w, float* m, float* v, const float* grad, int64_t n, float lr_t, float beta1,
                       float beta2, float epsilon, float l2_coef, void* stream);
 
+/* ---- input files ------------------------------------------------------------------------------------------------
+ * CRC-32C (Castagnoli) of host bytes for the TFRecord framing that input_utils.py:103-105 / :141 delegate to
+ * TensorFlow.  crc = 0 starts a checksum, or pass the previous return value to continue one.  Returns the checksum's 32
+ * bits (as int).  HOST pointer, no stream: the only entry point that touches host memory.                          */
+int trec_crc32c(const void* data, uint64_t n, uint32_t crc);
+
 /* ---- K9: mixture of tastes -----------------------------------------------------------------------------------
  * collapse_mixture_of_tastes, recommendation_graphs.py:85-109 (tf.stack + reduce_max, or + softmax(axis=0) * predictions +
  * reduce_sum), fused with the bias add that follows it (bias_prediction_dense / _serial, :33-57; tensorrec.py:432-449).

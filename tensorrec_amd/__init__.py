@@ -8,6 +8,7 @@ from .tensorrec import TensorRec, DeviceSampler, HostSampler, ReplaySampler
 from . import errors
 from . import eval  # noqa: A004
 from . import framework
+from . import input_utils
 from . import loss_graphs
 from . import prediction_graphs
 from . import recommendation_graphs
@@ -17,6 +18,6 @@ from . import util
 __version__ = '0.1.0'
 
 __all__ = [
-    "TensorRec", "DeviceSampler", "HostSampler", "ReplaySampler", "errors", "eval", "framework", "loss_graphs",
+    "TensorRec", "DeviceSampler", "HostSampler", "ReplaySampler", "errors", "eval", "framework", "input_utils", "loss_graphs",
     "prediction_graphs", "recommendation_graphs", "representation_graphs", "util",
 ]

@@ -62,6 +62,7 @@ SIGNATURES = {
     "trec_rmse_fwd": [_vp, _vp, _i64, _vp, _i32, _vp, _vp],
     "trec_rmse_bwd": [_vp, _vp, _vp, _vp, _i64, _vp, _vp],
     "trec_sample_items": [_i64, _i64, _i32, _i32, _i32, _u64, _u32, _vp, _vp],
+    "trec_crc32c": [_vp, _u64, _u32],
     "trec_collapse_tastes_fwd": [_vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
     "trec_collapse_tastes_bwd": [_vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp],
     "trec_adam_tf_step": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _vp],

@@ -191,12 +191,28 @@ class TensorRec(object):
 
     @staticmethod
     def _as_list(raw_input):
-        """util.datasets_from_raw_input (util.py:34-58) restricted to scipy inputs: tf.data.Dataset and TFRecord
-        paths are TensorFlow containers and are out of scope."""
-        if sp.issparse(raw_input):
-            return [raw_input]
-        if isinstance(raw_input, list) and all(sp.issparse(v) for v in raw_input):
-            return raw_input
+        """util.datasets_from_raw_input (util.py:34-58): a scipy matrix, a dataset in the standard TensorRec format, the
+        path of a TFRecord file, or a list of those.  Everything becomes scipy CSR on the host (one upload per call);
+        ``tf.data.Dataset`` objects themselves are TensorFlow containers and cannot exist here."""
+        from .input_utils import TensorRecDataset, create_tensorrec_dataset_from_tfrecord
+
+        def one(v):
+            if sp.issparse(v):
+                return v
+            if isinstance(v, TensorRecDataset):
+                return v.to_sparse_matrix()
+            if isinstance(v, str):
+                return create_tensorrec_dataset_from_tfrecord(v).to_sparse_matrix()
+            return None
+
+        if isinstance(raw_input, list):
+            mats = [one(v) for v in raw_input]
+            if all(m is not None for m in mats):
+                return mats
+        else:
+            m = one(raw_input)
+            if m is not None:
+                return [m]
         raise ValueError('Input must be a scipy sparse matrix, an iterable of scipy sprase matrices, or a TensorFlow '
                          'Dataset')
 
@@ -577,6 +593,51 @@ class TensorRec(object):
         self._check_fit('predict_rank')
         pred = self._predict_device(user_features, item_features)
         return rank_predictions(pred).cpu().numpy()
+
+    def predict_rank_of_interactions(self, user_features, item_features, interactions, user_batch_size=None):
+        """EXTENSION: the ranks ``predict_rank`` would give, but only at the positive entries of ``interactions`` --
+        all the evaluation metrics need (eval.py multiplies the [n_users, n_items] rank matrix by the positive mask).
+        Users are walked in tiles: a [tile, n_items] score slab stays on the device and the counting kernel (K4,
+        ``trec_rank_of_pairs``) ranks each positive pair against its row, so neither scores nor ranks of the full
+        matrix ever reach the host.  Returns ``eval.PairRanks`` (accepted by every metric in place of the matrix);
+        the ranks are bit-identical to ``predict_rank(...)[rows, cols]``."""
+        from .eval import PairRanks
+        self._check_fit('predict_rank_of_interactions')
+        uf, itf = self._inference(user_features, item_features)
+        m = sp.csr_matrix(interactions)
+        m.sort_indices()
+        if m.shape[0] > uf.shape[0] or m.shape[1] > itf.shape[0]:
+            raise ValueError("interactions do not fit the feature matrices")
+        coo = m.tocoo()
+        pos = coo.data > 0
+        rows, cols, vals = coo.row[pos].astype(np.int64), coo.col[pos].astype(np.int64), coo.data[pos]
+        n_users, n_items = uf.shape[0], itf.shape[0]
+        if user_batch_size is None:
+            user_batch_size = max(64, min(n_users, (1 << 29) // max(1, n_items)))       # <= 2 GB of fp32 scores
+        device = self._store.device
+        ranks = np.zeros(len(rows), np.int32)
+        bounds = np.searchsorted(rows, np.arange(0, n_users + user_batch_size, user_batch_size))
+        with torch.no_grad(), variable_scope(self._store):
+            user_reprs, attn_reprs, item_repr, user_bias, item_bias, _ = self._representations(uf, itf)
+            for b, s in enumerate(range(0, n_users, user_batch_size)):
+                p0, p1 = bounds[b], bounds[b + 1]
+                if p0 == p1:
+                    continue
+                e = min(s + user_batch_size, n_users)
+                ub = user_bias[s:e] if user_bias is not None else None
+                if self._multi():
+                    slab = self._dense_multi([u[s:e] for u in user_reprs],
+                                             [a[s:e] for a in attn_reprs] if attn_reprs is not None else None,
+                                             item_repr, ub, item_bias)
+                else:
+                    slab = self._dense_prediction(user_reprs[0][s:e], item_repr, ub, item_bias)
+                slab = slab.contiguous()
+                xu = torch.from_numpy(rows[p0:p1] - s).to(device)
+                xi = torch.from_numpy(cols[p0:p1]).to(device)
+                target = slab[xu, xi].contiguous()
+                r = ops.rank_of_pairs(slab, 0, 0, n_items, xu.to(torch.int32), xi.to(torch.int32), target, add_one=True)
+                ranks[p0:p1] = r.cpu().numpy()
+        return PairRanks(rows, ranks, vals, n_users)
 
     def predict_top_k(self, user_features, item_features, k=10, user_batch_size=65536, return_device=False):
         """EXTENSION: the k best items per user -- (scores [n_users, k] float32, item ids [n_users, k] int32),

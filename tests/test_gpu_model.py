@@ -336,3 +336,43 @@ def test_fit_and_eval_and_metrics_from_gpu_ranks():
     ndcg5, ndcg10, ndcg20 = (np.mean(T.eval.ndcg_at_k(ranks, inter, k=k)) for k in (5, 10, 20))
     assert ndcg10 >= ndcg5 and ndcg20 == ndcg10 and ndcg20 < 1                       # test/test_eval.py:80-83
     assert T.eval.f1_score_at_k(ranks, inter, k=5) is not None
+
+
+@pytest.mark.parametrize("n_tastes", [1, 2])
+def test_rank_of_interactions_equals_rank_matrix_entries(n_tastes):
+    """Device-side ranks of the positive pairs == predict_rank()[rows, cols], tile boundaries included; the metrics
+    computed from them equal the metrics from the full matrix."""
+    inter, uf, itf = dummy(150, 333, seed=9)
+    model = T.TensorRec(n_components=16, n_tastes=n_tastes, seed=2)
+    model.fit(inter, uf, itf, epochs=3)
+    ranks = model.predict_rank(uf, itf)
+    for batch in (None, 64, 7):
+        pr = model.predict_rank_of_interactions(uf, itf, inter, user_batch_size=batch)
+        coo = sp.csr_matrix(inter).tocoo()
+        pos = coo.data > 0
+        assert np.array_equal(pr.rows, coo.row[pos]) and np.array_equal(pr.ranks, ranks[coo.row[pos], coo.col[pos]])
+    for f in (T.eval.precision_at_k, T.eval.recall_at_k, T.eval.ndcg_at_k):
+        for preserve in (False, True):
+            np.testing.assert_array_equal(f(pr, inter, k=10, preserve_rows=preserve),
+                                          f(ranks, inter, k=10, preserve_rows=preserve))
+
+
+def test_fit_from_tfrecords_and_datasets(tmp_path):
+    """test/test_tensorrec.py:169-173 and :363-397: TFRecord paths and standard-format datasets are accepted wherever
+    scipy matrices are, and give the same model."""
+    from tensorrec_amd.input_utils import write_tfrecord_from_sparse_matrix, create_tensorrec_dataset_from_sparse_matrix
+    inter, uf, itf = T.util.generate_dummy_data(num_users=15, num_items=30, interaction_density=.5, num_user_features=200,
+                                                num_item_features=200, n_features_per_user=20, n_features_per_item=20,
+                                                pos_int_ratio=.5, random_state=0)
+    paths = [write_tfrecord_from_sparse_matrix(str(tmp_path / name), m)
+             for name, m in (("interactions.tfrecord", inter), ("user_features.tfrecord", uf),
+                             ("item_features.tfrecord", itf))]
+    a = T.TensorRec(n_components=10, seed=1)
+    a.fit(inter, uf, itf, epochs=5)
+    b = T.TensorRec(n_components=10, seed=1)
+    b.fit(paths[0], paths[1], paths[2], epochs=5)
+    c = T.TensorRec(n_components=10, seed=1)
+    c.fit(*[create_tensorrec_dataset_from_sparse_matrix(m) for m in (inter, uf, itf)], epochs=5)
+    pa = a.predict(uf, itf)
+    assert np.array_equal(pa, b.predict(paths[1], paths[2])) and np.array_equal(pa, c.predict(uf, itf))
+    assert np.array_equal(a.predict_rank(uf, itf), b.predict_rank(paths[1], paths[2]))

@@ -81,8 +81,10 @@ def test_batching_logic_without_gpu():
         m._create_batches([inter, inter], [uf], itf)
     with pytest.raises(ValueError):
         m._create_batches([inter, inter], [uf, uf], [itf, itf, itf])
-    with pytest.raises(ValueError):
+    with pytest.raises(FileNotFoundError):                 # str = path of a TFRecord file (input_utils)
         m._create_batches("some.tfrecord", uf, itf)
+    with pytest.raises(ValueError):
+        m._create_batches(object(), uf, itf)
 
 
 def test_fit_fails_loudly_without_gpu():
