@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--no-fit", action="store_true", help="skip the fit epochs/sec measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-users", type=int, default=1024)
+    ap.add_argument("--tune", action="append", default=[], metavar="NAME=INT",
+                    help="diagnostic: set a kernel tuning knob (trec_set_tuning), e.g. blockmax_pipelined=0")
     return ap.parse_args()
 
 
@@ -167,6 +169,9 @@ def main():
     from tensorrec_amd import ops, sharding
     from tensorrec_amd.sparse import SparseFeatures
 
+    for kv in args.tune:
+        name, _, val = kv.partition("=")
+        T._native.set_tuning(name, int(val))
     U, I, d, k = args.users, args.items, args.components, args.k
     dtype = ops.DTYPE_BF16 if args.precision == "bf16" else ops.DTYPE_F32
     i_begin, i_end = sharding.shard_bounds(I, world, rank, align=64)

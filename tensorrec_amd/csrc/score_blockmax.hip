@@ -1,0 +1,254 @@
+// tensorrec_amd/csrc/score_blockmax.hip -- K2, stage 1 of the two-stage exact top-k, hand-scheduled.
+//
+// Same mathematics and data layout as score_gemm_kernel<.., EPI_BLOCKMAX, ..> (score_gemm.hip) for the hot
+// configuration -- bf16 operands, dot / cosine, K = 64 or 128: M[s][u] = max over the 512-item superblock s of
+// fl-chain(b_i + sum_k u_k i_k) + b_u, the user x item contraction of tensorrec/prediction_graphs.py:50 reduced by the
+// first tf.nn.top_k of rank_predictions (recommendation_graphs.py:80) to what the exact top-k needs.
+//
+// What differs is the instruction schedule inside a wave.  The generic kernel leaves it to the compiler, which (at
+// 3 waves/SIMD = 168 VGPRs) keeps ONE LDS read in flight (`ds_read; s_waitcnt lgkmcnt(0); 2 MFMA` per k-step) and
+// runs the max-chain epilogue of a 32-item block between that block's last MFMA and the next block's first one: a
+// single wave keeps the matrix pipe ~50% busy and relies on its two SIMD neighbours for the rest (measured: 63%).
+// Here one 64-item tile is ONE straight-line pipeline of 2*KS steps, pinned with sched_barrier:
+//     step s:  ds_read for step s+2   |   2 MFMAs of step s   |   a slice of the max chain of the PREVIOUS 32-item block
+// so LDS latency hides behind two steps (128 MFMA cycles) and the epilogue of block b runs under the MFMAs of block
+// b+1 (two accumulator sets).  The epilogue of a tile's second block runs under the next tile's first block, across
+// the barrier; it is flushed early only at superblock ends (every 8th tile).
+//
+// Partial tiles need no masking: staging re-reads the last valid item row (and its bias) for rows past the end, and a
+// maximum is unchanged by duplicates.
+#include "score_common.hpp"
+#include <math.h>
+#include <type_traits>
+
+namespace {
+
+constexpr int BN = 64;          // item rows per tile (two 32-row MFMA blocks)
+
+__device__ __forceinline__ int swz16(int row, int ch) {
+    // physical 16-byte chunk = logical chunk ^ swz(row) (same swizzle as score_gemm.hip)
+    return ch >= 16 ? (row & 15) : ((row >> 1) & 7);
+}
+
+// NCB: 32-user column blocks per wave (2: 256 users per workgroup, 2-3 workgroups per CU; 4: 512 users per workgroup,
+// one workgroup per CU -- half the LDS reads, tile loads and barriers per flop, the wave hides its own latencies)
+template <int KT, bool BIAS, int NCB, int WPS>
+__global__ __launch_bounds__(256, WPS) void blockmax_pipe_kernel(ScoreParams p)
+{
+    constexpr int RB = KT * 2;               // bytes per operand row
+    constexpr int CH = RB / 16;              // 16-byte chunks per row
+    constexpr int KS = KT / 16;              // MFMA k-steps per block
+    constexpr int TILE_BYTES = BN * RB;
+    constexpr int NSLOT = BN * CH / 256;     // 16-byte staging slots per thread per tile
+    constexpr int NSTEP = 2 * KS;            // pipeline steps per tile
+    constexpr int NOPS = NCB * 10;           // epilogue ops of one block: per accumulator 8 max + bias add + fold
+    constexpr int OPS = (NOPS + KS - 4) / (KS - 3);     // ops per step: the epilogue runs in local steps 1 .. KS-3
+    static_assert(KT == 64 || KT == 128, "pipelined BLOCKMAX covers K = 64 / 128");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];    // [2][TILE_BYTES] item tiles | [2][BN] item biases
+    float* side = (float*)(smem + 2 * TILE_BYTES);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int rblock = blockIdx.x % p.n_rblocks;
+    const int chunk = blockIdx.x / p.n_rblocks;
+    const int64_t r_base = ((int64_t)rblock * 4 + wave) * (NCB * 32);
+    const int64_t t_begin = (int64_t)chunk * p.chunk_len;
+    const int64_t t_end = (t_begin + p.chunk_len < p.n_t) ? t_begin + p.chunk_len : p.n_t;
+    const int n_tiles = (int)((t_end - t_begin + BN - 1) / BN);
+
+    // ---- resident user fragments, straight from global, once ----
+    bf16x8 rfb[NCB][KS];
+    float r_bias[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+        int64_t row = r_base + cb * 32 + l31;
+        if (row >= p.n_r) row = p.n_r - 1;                       // clamped rows are never written
+        const char* src = (const char*)p.R + row * (int64_t)RB;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) rfb[cb][ks] = *(const bf16x8*)(src + (ks * 2 + half) * 16);
+        r_bias[cb] = (BIAS && p.r_bias) ? p.r_bias[row] : 0.f;
+    }
+
+    // ---- staging: slot q = i*256 + tid -> (row, physical chunk); source offsets fixed per thread ----
+    int slot_off[NSLOT];
+#pragma unroll
+    for (int i = 0; i < NSLOT; ++i) {
+        const int q = i * 256 + tid;
+        const int row = q / CH, pc = q % CH;
+        slot_off[i] = row * RB + ((pc ^ swz16(row, CH)) * 16);
+    }
+    const char* t_chunk = (const char*)p.T + t_begin * (int64_t)RB;
+    float side_b = 0.f;
+    auto stage_issue = [&](int tile, int buf) {
+        const int64_t row0 = t_begin + (int64_t)tile * BN;
+        const bool clamp = row0 + BN > p.n_t;                    // wave-uniform: only the very last tile
+        if (BIAS && tid < BN) {
+            int64_t g = row0 + tid;
+            if (g >= p.n_t) g = p.n_t - 1;                       // duplicate of the last valid item: max unchanged
+            side_b = p.t_bias ? p.t_bias[g] : 0.f;
+        }
+        const char* tile_base = t_chunk + (int64_t)tile * (BN * RB);
+#pragma unroll
+        for (int i = 0; i < NSLOT; ++i) {
+            int off = slot_off[i];
+            if (clamp) {
+                const int last = (int)(p.n_t - 1 - row0);
+                const int row = (i * 256 + tid) / CH;                // recomputed here: the rare path owns no registers
+                if (row > last) off -= (row - last) * RB;
+            }
+            char* dst = smem + buf * TILE_BYTES + (i * 256 + wave * 64) * 16;       // wave-uniform; lane*16 is implicit
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tile_base + off),
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
+    auto stage_commit = [&](int buf) {
+        if (BIAS && tid < BN) side[buf * BN + tid] = side_b;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+
+    // ---- per-lane LDS read offsets of the KS operand chunks of "my" item row (row l31 of a 32-row block) ----
+    int koff[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) koff[ks] = l31 * RB + (((ks * 2 + half) ^ swz16(l31, CH)) * 16);
+    // rows 32..63 of a tile: (l31 + 32) has the same swizzle for CH = 16 (row & 15); for CH = 8 the swizzle is
+    // ((row >> 1) & 7) and 32 >> 1 = 16 leaves the low three bits alone as well -> one offset table serves both blocks.
+
+    f32x16 accA[NCB], accB[NCB];
+    float bm[NCB], m[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+        bm[cb] = -INFINITY; m[cb] = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { accA[cb][r] = -INFINITY; accB[cb][r] = -INFINITY; }
+    }
+
+    // one op of a block's epilogue: I = NCB*j + cb;  j = 0: max(x0, x1); 1..7: max3 with (x[2j], x[2j+1]); 8: + b_u; 9: fold
+    auto epi_op = [&](int I, f32x16 (&x)[NCB]) {
+        const int cb = I % NCB, j = I / NCB;
+        if (j == 0) m[cb] = fmaxf(x[cb][0], x[cb][1]);
+        else if (j <= 7) m[cb] = fmaxf(fmaxf(m[cb], x[cb][2 * j]), x[cb][2 * j + 1]);
+        else if (j == 8) { if (BIAS) m[cb] = m[cb] + r_bias[cb]; }
+        else bm[cb] = fmaxf(bm[cb], m[cb]);
+    };
+    auto read_c0 = [&](f32x16& c, const float* sdi) {      // item biases of the block's 16 rows of this half-wave
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 tb4 = *(const f32x4*)(sdi + 8 * q);
+            c[4 * q] = tb4[0]; c[4 * q + 1] = tb4[1]; c[4 * q + 2] = tb4[2]; c[4 * q + 3] = tb4[3];
+        }
+    };
+    // the NCB MFMAs of one step (acc = mfma(items, users): lane & 31 is the user).  With biases the item bias row, read
+    // into the LAST accumulator, is the C operand of every first MFMA (the last one accumulates in place).
+    auto mfma_step = [&](f32x16 (&acc)[NCB], const bf16x8& tfv, int ks) __attribute__((always_inline)) {
+        if (ks == 0) {
+            if (BIAS) {
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb)
+                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfv, rfb[cb][0], acc[NCB - 1], 0, 0, 0);
+            } else {
+                const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfv, rfb[cb][0], z, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfv, rfb[cb][ks], acc[cb], 0, 0, 0);
+        }
+    };
+
+    // one tile: 2*KS pipeline steps.  `buf` is a compile-time constant at the call site (LDS immediates).
+    auto tile_body = [&](auto bufc) __attribute__((always_inline)) {
+        constexpr int buf = decltype(bufc)::value;
+        const char* tb = smem + buf * TILE_BYTES;
+        const float* sd = side + buf * BN + 4 * half;
+        bf16x8 tf[3];
+        if (BIAS) read_c0(accA[NCB - 1], sd);
+        tf[0] = *(const bf16x8*)(tb + koff[0]);
+        tf[1] = *(const bf16x8*)(tb + koff[1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) {
+            const int blk = s / KS, ks = s % KS;
+            // (1) LDS reads two steps ahead; block B's bias row once block B's accumulators are free
+            if (s + 2 < NSTEP)
+                tf[(s + 2) % 3] = *(const bf16x8*)(tb + ((s + 2) / KS) * 32 * RB + koff[(s + 2) % KS]);
+            if (BIAS && s == KS - 2) read_c0(accB[NCB - 1], sd + 32);
+            // (2) the MFMAs of this step
+            if (blk == 0) mfma_step(accA, tf[s % 3], ks);
+            else mfma_step(accB, tf[s % 3], ks);
+            // (3) a slice of the epilogue of the block BEFORE this one (B of the previous tile under A, A under B);
+            //     it starts one step late so that the block's last MFMA has landed
+#pragma unroll
+            for (int i = 0; i < OPS; ++i) {
+                const int I = (ks - 1) * OPS + i;
+                if (ks >= 1 && I < NOPS) {
+                    if (blk == 0) epi_op(I, accB);
+                    else epi_op(I, accA);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    stage_issue(0, 0);
+    stage_commit(0);
+    __syncthreads();
+
+    for (int t = 0; t < n_tiles; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < n_tiles) stage_issue(t + 1, buf ^ 1);
+        if (buf == 0) tile_body(std::integral_constant<int, 0>{});
+        else tile_body(std::integral_constant<int, 1>{});
+
+        if (((t + 1) % p.sb_tiles) == 0 || t + 1 == n_tiles) {
+            // end of a superblock: finish block B now, combine the two half-wave maxima of each user, store, reset
+#pragma unroll
+            for (int I = 0; I < NOPS; ++I) epi_op(I, accB);
+            const int64_t sb = t_begin / ((int64_t)p.sb_tiles * BN) + t / p.sb_tiles;
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                const float v = fmaxf(bm[cb], __shfl_xor(bm[cb], 32, 64));
+                const int64_t u = r_base + cb * 32 + l31;
+                if (half == 0 && u < p.n_r) p.blockmax[sb * p.bm_stride + u] = v;
+                bm[cb] = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accB[cb][r] = -INFINITY;        // the deferred epilogue becomes a no-op
+            }
+        }
+        if (t + 1 < n_tiles) stage_commit(buf ^ 1);
+        __syncthreads();
+    }
+}
+
+template <int KT, bool BIAS, int NCB, int WPS>
+int launch_one(ScoreParams p, hipStream_t st)
+{
+    constexpr int LDS = 2 * BN * KT * 2 + 2 * BN * 4;
+    auto kern = blockmax_pipe_kernel<KT, BIAS, NCB, WPS>;
+    static bool attr_set = false;
+    if (!attr_set && LDS > 32 * 1024) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    p.n_rblocks = (int)ceil_div64(p.n_r, 4 * NCB * 32);
+    const unsigned blocks = (unsigned)p.n_rblocks * (unsigned)p.n_chunks;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), LDS, st, p);
+    return trec_check_launch("trec_score_gemm_blockmax (pipelined)");
+}
+
+}  // namespace
+
+int launch_blockmax_pipelined(const ScoreParams& p, int kt, hipStream_t st)
+{
+    if (p.euclid) return TREC_ERR_UNSUPPORTED;
+    const bool bias = p.r_bias || p.t_bias;
+    const int shape = trec_get_tuning("blockmax_shape", 2);      // 2: 64 users/wave, 2 workgroups/CU; 4: 128 users/wave, 1/CU
+    if (kt == 128 && shape == 4) return bias ? launch_one<128, true, 4, 1>(p, st) : launch_one<128, false, 4, 1>(p, st);
+    if (kt == 128) return bias ? launch_one<128, true, 2, 2>(p, st) : launch_one<128, false, 2, 2>(p, st);
+    if (kt == 64) return bias ? launch_one<64, true, 2, 3>(p, st) : launch_one<64, false, 2, 3>(p, st);
+    return TREC_ERR_UNSUPPORTED;
+}

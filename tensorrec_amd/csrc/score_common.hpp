@@ -1,0 +1,37 @@
+// tensorrec_amd/csrc/score_common.hpp -- launch parameters shared by the score kernels (score_gemm.hip,
+// score_blockmax.hip).
+#pragma once
+#include "common.hpp"
+
+struct ScoreParams {
+    const void* R;            // resident operand [n_r, KT] (fp32 or bf16), users
+    const void* T;            // streamed operand [n_t, KT], items
+    int64_t n_r, n_t;
+    int64_t chunk_len;        // streamed rows per chunk (multiple of BN)
+    int n_chunks;
+    int n_rblocks;
+    const float* r_bias;      // nullable [n_r]   user bias   (added first, recommendation_graphs.py:41)
+    const float* t_bias;      // nullable [n_t]   item bias   (added second)
+    const float* r_sqnorm;    // euclid only [n_r]
+    const float* t_sqnorm;    // euclid only [n_t]
+    int euclid;
+    float* out;               // STORE: [n_r, ld_out]
+    int64_t ld_out;
+    float* part_vals;         // TOPK: [n_r, n_parts, KTOP]  (KTOP = list capacity: 8, 12 or 16)
+    int32_t* part_idx;
+    int capacity;             // slots per partial list in part_vals / part_idx (>= the kernel's KTOP)
+    int n_parts;              // 2 * n_chunks
+    int32_t t_index_base;     // added to item indices written by TOPK (item shards)
+    // BLOCKMAX: blockmax[(chunk superblock base + s) * bm_stride + user], superblock = sb_tiles tiles of BN rows
+    float* blockmax;
+    int64_t bm_stride;
+    int sb_tiles;
+    // grouped TOPK (stage 3): the item range of a workgroup comes from a table, results go where row_pair says
+    const int32_t* rblock_chunk;   // nullable [n_rblocks]: chunk (= superblock) index of this resident block, -1 = idle
+    const int32_t* row_pair;       // nullable [n_r]: output list id of a resident row, -1 = padding row
+    const float* row_floor;        // nullable [n_r]: a known lower bound of the row's final k-th best score (lists start there)
+};
+
+// software-pipelined BLOCKMAX kernel (score_blockmax.hip): bf16 dot / cosine, kpad 64 or 128.  Returns
+// TREC_ERR_UNSUPPORTED when the configuration is not covered (the caller then uses the generic kernel).
+int launch_blockmax_pipelined(const ScoreParams& p, int kt, hipStream_t stream);

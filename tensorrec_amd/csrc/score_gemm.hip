@@ -21,42 +21,13 @@
 // Arithmetic types (runtime `dtype`): 0 = fp32 on v_mfma_f32_32x32x2_f32 -- an exact fp32 fmaf chain
 // in k order, bit-identical to oracle/tr_oracle.c:orc_score_dense; 1 = bf16 operands on
 // v_mfma_f32_32x32x16_bf16 with fp32 accumulate (the throughput mode named by BASELINE.json).
-#include "common.hpp"
+#include "score_common.hpp"
 #include <math.h>
 
 #define EPI_STORE 0
 #define EPI_TOPK 1
 #define EPI_BLOCKMAX 2     // per (user, item superblock) maximum only: stage 1 of the two-stage exact top-k
 #define KTOP_MAX 16
-
-struct ScoreParams {
-    const void* R;            // resident operand [n_r, KT] (fp32 or bf16), users
-    const void* T;            // streamed operand [n_t, KT], items
-    int64_t n_r, n_t;
-    int64_t chunk_len;        // streamed rows per chunk (multiple of BN)
-    int n_chunks;
-    int n_rblocks;
-    const float* r_bias;      // nullable [n_r]   user bias   (added first, recommendation_graphs.py:41)
-    const float* t_bias;      // nullable [n_t]   item bias   (added second)
-    const float* r_sqnorm;    // euclid only [n_r]
-    const float* t_sqnorm;    // euclid only [n_t]
-    int euclid;
-    float* out;               // STORE: [n_r, ld_out]
-    int64_t ld_out;
-    float* part_vals;         // TOPK: [n_r, n_parts, KTOP]  (KTOP = list capacity: 8, 12 or 16)
-    int32_t* part_idx;
-    int capacity;             // slots per partial list in part_vals / part_idx (>= the kernel's KTOP)
-    int n_parts;              // 2 * n_chunks
-    int32_t t_index_base;     // added to item indices written by TOPK (item shards)
-    // BLOCKMAX: blockmax[(chunk superblock base + s) * bm_stride + user], superblock = sb_tiles tiles of BN rows
-    float* blockmax;
-    int64_t bm_stride;
-    int sb_tiles;
-    // grouped TOPK (stage 3): the item range of a workgroup comes from a table, results go where row_pair says
-    const int32_t* rblock_chunk;   // nullable [n_rblocks]: chunk (= superblock) index of this resident block, -1 = idle
-    const int32_t* row_pair;       // nullable [n_r]: output list id of a resident row, -1 = padding row
-    const float* row_floor;        // nullable [n_r]: a known lower bound of the row's final k-th best score (lists start there)
-};
 
 template <int DT> struct ElemOf;
 template <> struct ElemOf<0> { static constexpr int BYTES = 4; };
@@ -833,6 +804,12 @@ extern "C" int trec_score_gemm_blockmax(const void* users, const void* items, in
     p.chunk_len = ceil_div64(ceil_div64(n_items, n_chunks), sb_rows) * sb_rows;        // chunks are whole superblocks
     p.n_chunks = (int)ceil_div64(n_items, p.chunk_len);
     p.blockmax = blockmax; p.bm_stride = bm_stride; p.sb_tiles = sb_rows / c.bn;
+    // the hot configuration (bf16 dot / cosine, K = 64 / 128) has a hand-scheduled kernel; "blockmax_pipelined" = 0
+    // selects the generic one (A/B runs and tests)
+    if (dtype == 1 && !mode && (kpad == 64 || kpad == 128) && c.bn == 64 && trec_get_tuning("blockmax_pipelined", 1)) {
+        rc = launch_blockmax_pipelined(p, kpad, (hipStream_t)stream);
+        if (rc != TREC_ERR_UNSUPPORTED) return rc;
+    }
     return dispatch_score<EPI_BLOCKMAX, 8>(dtype, kpad, variant, p, (hipStream_t)stream);
 }
 
