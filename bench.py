@@ -270,7 +270,11 @@ def main():
     k2_flops = 2.0 * U * n_local * kpad                    # algorithmic: 2*U*I*d per launch (d = kpad = 128 here)
     peak = BF16_DENSE_PEAK_TFLOPS if args.precision == "bf16" else FP32_MFMA_PEAK_TFLOPS
     k2_tflops = k2_flops / (k2_ms * 1e-3) / 1e12
-    roofline = {"kernel": "score_gemm_kernel (%s epilogue)" % ("fused top-k" if method == "direct" else "superblock-max"),
+    k2_label = "score_gemm_kernel (fused top-k epilogue)" if method == "direct" else (
+        "blockmax_pipe_kernel (superblock maxima, stage 1 of the two-stage top-k)"
+        if args.precision == "bf16" and kpad in (64, 128) and T._native.load().trec_get_tuning(b"blockmax_pipelined", 1)
+        else "score_gemm_kernel (superblock-max epilogue)")
+    roofline = {"kernel": k2_label,
                 "bound": "mfma", "achieved": k2_tflops,
                 "peak": peak, "unit": "TFLOP/s", "frac": k2_tflops / peak, "traffic": None,
                 "avg_launch_ms": k2_ms, "launches": len(dur[k2_name]),
@@ -295,9 +299,12 @@ def main():
         files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.txt")))
         if files and world == 1 and (U, I, d) == (1_000_000, 1_000_000, 128) and method == "two_stage":
             txt = open(files[-1]).read()
-            key = "score_gemm_kernel<1, 128, 64, 2, 2"
-            fetch = [float(m) for m in re.findall(re.escape(key) + r"[^\n]*?FETCH_SIZE=([0-9.e+]+)", txt)]
-            write = [float(m) for m in re.findall(re.escape(key) + r"[^\n]*?WRITE_SIZE=([0-9.e+]+)", txt)]
+            fetch = write = None
+            for key in ("blockmax_pipe_kernel<128", "score_gemm_kernel<1, 128, 64, 2, 2"):     # stage-1 kernel names
+                fetch = [float(m) for m in re.findall(re.escape(key) + r"[^\n]*?FETCH_SIZE=([0-9.e+]+)", txt)]
+                write = [float(m) for m in re.findall(re.escape(key) + r"[^\n]*?WRITE_SIZE=([0-9.e+]+)", txt)]
+                if fetch and write:
+                    break
             if fetch and write:
                 roofline["traffic"] = (2.0 * fetch[0] + write[0]) * 1024.0
                 roofline["traffic_note"] = ("bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KB from %s; fabric-side "
