@@ -24,8 +24,13 @@ def _data():
     return inter, uf, itf
 
 
-def _model(dp):
+def _model(dp, kind="linear"):
     import tensorrec_amd as T
+    if kind == "relu_euclid":      # BASELINE.json configs[4] in miniature: ReLU towers + Euclidean similarity + WMRB
+        return T.TensorRec(n_components=16, user_repr_graph=T.representation_graphs.ReLURepresentationGraph(),
+                           item_repr_graph=T.representation_graphs.ReLURepresentationGraph(),
+                           prediction_graph=T.prediction_graphs.EuclideanSimilarityPredictionGraph(),
+                           loss_graph=T.loss_graphs.WMRBLossGraph(), seed=5, data_parallel=dp)
     return T.TensorRec(n_components=16, loss_graph=T.loss_graphs.BalancedWMRBLossGraph(), seed=5, data_parallel=dp)
 
 
@@ -37,7 +42,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, bounds, ret):
+def _worker(rank, world, port, bounds, ret, kind="linear"):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -45,7 +50,7 @@ def _worker(rank, world, port, bounds, ret):
     try:
         inter, uf, itf = _data()
         b, e = bounds[rank], bounds[rank + 1]
-        model = _model(True)
+        model = _model(True, kind)
         model.fit(inter[b:e], uf[b:e], itf, epochs=3, learning_rate=0.05, n_sampled_items=20, user_offset=b)
         ret[rank] = model.get_weights()
     finally:
@@ -74,6 +79,23 @@ def test_two_rank_fit_equals_single_process_fit():
         assert np.allclose(ret[0][k], v, rtol=2e-3, atol=5e-3), "%s: %g" % (k, np.abs(ret[0][k] - v).max())
     moved = np.abs(ref["linear_weights_item"] - _initial("linear_weights_item")).max()
     assert moved > 0.05          # the comparison above is not trivially true: weights did move
+
+
+def test_two_rank_fit_relu_euclidean_wmrb():
+    """The 8-GPU fit configuration of BASELINE.json (ReLU d=256 + Euclidean + WMRB, users sharded) at toy size."""
+    inter, uf, itf = _data()
+    single = _model(False, "relu_euclid")
+    single.fit(inter, uf, itf, epochs=3, learning_rate=0.05, n_sampled_items=20)
+    ref = single.get_weights()
+    mgr = mp.get_context("spawn").Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), [0, 33, 70], ret, "relu_euclid"), nprocs=2, join=True)
+    assert sorted(ret.keys()) == [0, 1]
+    for k, v in ref.items():
+        assert np.array_equal(ret[0][k], ret[1][k]), "ranks diverged on %s" % k
+        if k == "user_feature_biases":
+            continue                                   # zero-gradient weight under WMRB (see above)
+        assert np.allclose(ret[0][k], v, rtol=2e-3, atol=5e-3), "%s: %g" % (k, np.abs(ret[0][k] - v).max())
 
 
 def _initial(name):
