@@ -639,10 +639,18 @@ class TensorRec(object):
                 ranks[p0:p1] = r.cpu().numpy()
         return PairRanks(rows, ranks, vals, n_users)
 
-    def predict_top_k(self, user_features, item_features, k=10, user_batch_size=65536, return_device=False):
+    def predict_top_k(self, user_features, item_features, k=10, user_batch_size=65536, return_device=False,
+                      item_sharded=False, item_offset=0):
         """EXTENSION: the k best items per user -- (scores [n_users, k] float32, item ids [n_users, k] int32),
         ordered like the first k ranks of ``predict_rank`` -- computed by the fused MFMA score + top-k kernel without
-        materialising [n_users, n_items] (which is 4 TB at 1M x 1M)."""
+        materialising [n_users, n_items] (which is 4 TB at 1M x 1M).
+
+        ``item_sharded=True`` (torch.distributed initialised, one process per GPU): ``item_features`` holds THIS rank's
+        rows of the item feature matrix, ``item_offset`` the global id of its first row, ``user_features`` is the same
+        on every rank.  Every rank scores its shard, the shards agree on a top-k floor (one all-gather of k superblock
+        maxima per user), and ONE all-gather of the per-shard lists + a local merge leaves the exact global top-k on
+        every rank (sharding.py)."""
+        from . import sharding
         self._check_fit('predict_top_k')
         if not self._is_engine_graph():
             raise ValueError("predict_top_k needs a built-in prediction graph")
@@ -653,6 +661,19 @@ class TensorRec(object):
         if self.attention_graph_factory is not None:
             raise NotImplementedError("predict_top_k is not available for attention models: the softmax-weighted sum "
                                       "over tastes does not decompose into per-taste top-k lists; use predict_rank")
+        import torch.distributed as dist
+        sharded = bool(item_sharded) and dist.is_available() and dist.is_initialized() and \
+            dist.get_world_size(self.process_group) > 1
+        method, floor_exchange = "auto", None
+        if sharded:
+            # every rank must take the same code path (the floor exchange is a collective): decide on the smallest shard
+            smallest = torch.tensor([itf.shape[0]], dtype=torch.int64, device=self._store.device)
+            dist.all_reduce(smallest, op=dist.ReduceOp.MIN, group=self.process_group)
+            if int(smallest.item()) >= ops.TWO_STAGE_MIN_ITEMS:
+                method = "two_stage"
+                floor_exchange = lambda sel_max: sharding.shared_topk_floor(sel_max, self.process_group)  # noqa: E731
+            else:
+                method = "direct"
         vals, idx = [], []
         with torch.no_grad(), variable_scope(self._store):
             user_reprs, _, item_repr, user_bias, item_bias, _ = self._representations(uf, itf)
@@ -665,8 +686,12 @@ class TensorRec(object):
                 for user_repr in user_reprs:
                     u_op, u_sq, _ = ops.score_prep(user_repr[s:e], dtype, normalize=graph.engine_normalize,
                                                    want_sqnorm=want_sq)
-                    per_taste.append(ops.score_topk(u_op, i_op, dtype, kpad, k, ub, ib, graph.engine_mode, u_sq, i_sq))
+                    per_taste.append(ops.score_topk(u_op, i_op, dtype, kpad, k, ub, ib, graph.engine_mode, u_sq, i_sq,
+                                                    item_index_base=int(item_offset), method=method,
+                                                    floor_exchange=floor_exchange))
                 v, i = per_taste[0] if len(per_taste) == 1 else _merge_taste_topk(per_taste, k)
+                if sharded:
+                    v, i = sharding.sharded_top_k(v, i, k, self.process_group)
                 vals.append(v)
                 idx.append(i)
         vals, idx = torch.cat(vals), torch.cat(idx)

@@ -103,3 +103,49 @@ def _initial(name):
     m = _model(False)
     m.build(uf.shape[1], itf.shape[1])
     return m.get_weights()[name]
+
+
+# ---- item-sharded predict_top_k through the public API (BASELINE.json configs[3] in miniature) ---------------------------
+def _topk_case(n_items, n_tastes):
+    import tensorrec_amd as T
+    rng = np.random.RandomState(1)
+    n_u = 150
+    uf = sp.random(n_u, 30, density=0.2, random_state=rng, format="csr", dtype=np.float32)
+    itf = sp.hstack([sp.identity(n_items, format="csr", dtype=np.float32),
+                     sp.random(n_items, 5, density=0.3, random_state=rng, format="csr", dtype=np.float32)], format="csr")
+    model = T.TensorRec(n_components=32, n_tastes=n_tastes, seed=11,
+                        prediction_graph=T.prediction_graphs.CosineSimilarityPredictionGraph())
+    model.build(uf.shape[1], itf.shape[1])
+    w = model.get_weights()
+    w["item_feature_biases"] = (0.05 * rng.standard_normal(w["item_feature_biases"].shape)).astype(np.float32)
+    w["user_feature_biases"] = (0.05 * rng.standard_normal(w["user_feature_biases"].shape)).astype(np.float32)
+    model.set_weights(w)
+    return model, uf, itf
+
+
+def _topk_worker(rank, world, port, n_items, n_tastes, ret):
+    import torch.distributed as dist
+    from tensorrec_amd import sharding
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        model, uf, itf = _topk_case(n_items, n_tastes)
+        b, e = sharding.shard_bounds(n_items, world, rank)
+        ret[rank] = model.predict_top_k(uf, itf[b:e], k=10, item_sharded=True, item_offset=b)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_items,n_tastes", [(40000, 1), (3000, 1), (40000, 2)])
+def test_item_sharded_predict_top_k_equals_single_process(n_items, n_tastes):
+    """Cosine similarity, biased, items sharded over two ranks: both ranks return the single-process result exactly
+    (two-stage path with the shared floor for 20,000-item shards, direct fused path for small ones)."""
+    model, uf, itf = _topk_case(n_items, n_tastes)
+    ref_v, ref_i = model.predict_top_k(uf, itf, k=10)
+    mgr = mp.get_context("spawn").Manager()
+    ret = mgr.dict()
+    mp.spawn(_topk_worker, args=(2, _free_port(), n_items, n_tastes, ret), nprocs=2, join=True)
+    for r in (0, 1):
+        v, i = ret[r]
+        assert np.array_equal(i, ref_i) and np.array_equal(v, ref_v), "rank %d" % r
