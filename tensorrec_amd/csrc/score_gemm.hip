@@ -860,6 +860,51 @@ extern "C" int trec_topk_merge(const float* part_vals, const int32_t* part_idx, 
     return trec_check_launch("trec_topk_merge");
 }
 
+// vectorised form for d % 4 == 0 (rows 16-byte aligned): G = min(32, KT / 4) lanes own one row, a lane converts float4
+// chunks (16 B loads, 8 B bf16 / 16 B fp32 stores) -- 768 B of traffic per 128-wide row at HBM speed instead of the
+// 8-byte accesses of the generic kernel above.
+template <int G>
+__global__ __launch_bounds__(256) void score_prep_vec4_kernel(const float* __restrict__ x, int64_t n, int d, int kt,
+                                                             int normalize, int dtype, void* __restrict__ out,
+                                                             float* __restrict__ sqnorm)
+{
+    const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    if (row >= n) return;
+    const int sub = threadIdx.x % G;
+    const float* xr = x + row * (int64_t)d;
+    f32x4 v[2];                                   // kt <= 256 = 2 * 32 lanes * 4
+    float ss = 0.f;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int c = (it * G + sub) * 4;
+        v[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (c < d) v[it] = *(const f32x4*)(xr + c);
+        ss = fmaf(v[it][0], v[it][0], ss); ss = fmaf(v[it][1], v[it][1], ss);
+        ss = fmaf(v[it][2], v[it][2], ss); ss = fmaf(v[it][3], v[it][3], ss);
+    }
+    float scale = 1.0f;
+    if (normalize || sqnorm) {
+        for (int off = G / 2; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+        if (normalize) scale = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
+        if (sqnorm && sub == 0) sqnorm[row] = ss;
+    }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int c = (it * G + sub) * 4;
+        if (c >= kt) continue;
+        f32x4 w = v[it];
+        if (normalize) { w[0] *= scale; w[1] *= scale; w[2] *= scale; w[3] *= scale; }
+        if (dtype == 0) {
+            *(f32x4*)((float*)out + row * (int64_t)kt + c) = w;
+        } else {
+            uint2 pk;
+            pk.x = (unsigned int)f32_to_bf16_rne(w[0]) | ((unsigned int)f32_to_bf16_rne(w[1]) << 16);
+            pk.y = (unsigned int)f32_to_bf16_rne(w[2]) | ((unsigned int)f32_to_bf16_rne(w[3]) << 16);
+            *(uint2*)((unsigned short*)out + row * (int64_t)kt + c) = pk;
+        }
+    }
+}
+
 extern "C" int trec_score_prep(const float* repr, int64_t n, int32_t d, int32_t kpad, int32_t normalize,
                                int32_t dtype, void* out, float* out_sqnorm, void* stream)
 {
@@ -867,7 +912,16 @@ extern "C" int trec_score_prep(const float* repr, int64_t n, int32_t d, int32_t 
     TREC_REQUIRE(d >= 1 && kpad >= d && kpad % 2 == 0, "trec_score_prep: need kpad >= d, kpad even");
     TREC_REQUIRE(dtype == 0 || dtype == 1, "trec_score_prep: dtype must be 0 or 1");
     if (n == 0) return TREC_OK;
-    hipLaunchKernelGGL(score_prep_kernel, dim3((unsigned)ceil_div64(n * 64, 256)), dim3(256), 0, (hipStream_t)stream,
+    hipStream_t st = (hipStream_t)stream;
+    if (d % 4 == 0 && kpad % 4 == 0 && kpad <= 256 && ((uintptr_t)repr % 16) == 0 && ((uintptr_t)out % 16) == 0) {
+        const int g = kpad >= 128 ? 32 : kpad / 4;              // 8, 16 or 32 lanes per row
+        const unsigned blocks = (unsigned)ceil_div64(n * g, 256);
+        if (g == 32) hipLaunchKernelGGL(score_prep_vec4_kernel<32>, dim3(blocks), dim3(256), 0, st, repr, n, d, kpad, normalize, dtype, out, out_sqnorm);
+        else if (g == 16) hipLaunchKernelGGL(score_prep_vec4_kernel<16>, dim3(blocks), dim3(256), 0, st, repr, n, d, kpad, normalize, dtype, out, out_sqnorm);
+        else hipLaunchKernelGGL(score_prep_vec4_kernel<8>, dim3(blocks), dim3(256), 0, st, repr, n, d, kpad, normalize, dtype, out, out_sqnorm);
+        return trec_check_launch("trec_score_prep");
+    }
+    hipLaunchKernelGGL(score_prep_kernel, dim3((unsigned)ceil_div64(n * 64, 256)), dim3(256), 0, st,
                        repr, n, d, kpad, normalize, dtype, out, out_sqnorm);
     return trec_check_launch("trec_score_prep");
 }
