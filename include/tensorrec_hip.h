@@ -50,7 +50,9 @@ int trec_get_tuning(const char* name, int dflt);
 int trec_spmm_csr(const int64_t* indptr, const int32_t* indices, const float* values, const int32_t* val_perm,
                   int64_t n_rows, int64_t nnz, const float* W, int32_t d, const float* col_bias, int32_t epilogue,
                   int32_t accumulate, float* out, float* out_inv_norm, void* stream);
-/* project_biases, recommendation_graphs.py:4-19: out[r] = sum_j X[r,j] * beta[j] */
+/* project_biases, recommendation_graphs.py:4-19: out[r] = sum_j X[r,j] * beta[j] (fmaf chain in CSR order).
+ * beta == NULL: out[r] = sum of the row's (permuted) values -- the bias gradients of the serial predictions, where
+ * rows are a user's / an item's pairs; 16 lanes share a row (coalesced), indices are not read.                  */
 int trec_spmv_csr(const int64_t* indptr, const int32_t* indices, const float* values, const int32_t* val_perm,
                   int64_t n_rows, const float* beta, float* out, void* stream);
 /* tf.sparse_tensor_to_dense, representation_graphs.py:74 (FeaturePassThrough) */

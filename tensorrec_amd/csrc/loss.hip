@@ -101,6 +101,101 @@ __global__ __launch_bounds__(256) void wmrb_bwd_kernel(
     }
 }
 
+// ---- wave-per-user forms (S <= 256) -------------------------------------------------------------------------
+// At the BASELINE fit shape a user has ~20 positives and 100 samples: a 256-thread workgroup per user is mostly idle
+// and the launch is bound by workgroup dispatch (1M workgroups).  Here a wave owns a user: the samples sit in <= 4
+// registers per lane (sample s = r*64 + lane, the same lane/order split as the workgroup kernels, so results are
+// bit-identical), the user's positives are loaded by the lanes in parallel (64 per pass) and broadcast with readlane.
+#define WMRB_WAVE_SR 4
+
+__global__ __launch_bounds__(256) void wmrb_fwd_wave_kernel(
+    const int64_t* __restrict__ indptr, const int32_t* __restrict__ pos_slot, const float* __restrict__ pos_weight,
+    const float* __restrict__ pred, const float* __restrict__ samp, int64_t n_users, int32_t S, float ratio,
+    float* __restrict__ loss, float* __restrict__ smr_out)
+{
+    const int64_t u = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    if (u >= n_users) return;
+    const int lane = lane_id();
+    const int64_t b = indptr[u], e = indptr[u + 1];
+    if (b == e) return;
+    float ys[WMRB_WAVE_SR];
+#pragma unroll
+    for (int r = 0; r < WMRB_WAVE_SR; ++r) ys[r] = (r * 64 + lane < S) ? samp[u * S + r * 64 + lane] : -INFINITY;
+    for (int64_t p0 = b; p0 < e; p0 += 64) {
+        const int np = (int)((e - p0 < 64) ? (e - p0) : 64);
+        int32_t slot = -1;
+        float yp = 0.f, w = 1.f;
+        if (lane < np) {
+            slot = pos_slot[p0 + lane];
+            yp = pred[p0 + lane];
+            if (pos_weight) w = pos_weight[p0 + lane];
+        }
+        float my_smr = 0.f;
+        for (int q = 0; q < np; ++q) {
+            if (__shfl(slot, q, 64) < 0) continue;                 // wave-uniform
+            const float base = 1.0f - __shfl(yp, q, 64);
+            float acc = 0.f;
+#pragma unroll
+            for (int r = 0; r < WMRB_WAVE_SR; ++r) acc += fmaxf(base + ys[r], 0.f);     // -inf padding adds 0
+            for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+            if (lane == q) my_smr = ratio * acc;
+        }
+        if (lane < np && slot >= 0) {
+            if (pos_weight) my_smr = my_smr * w;
+            smr_out[slot] = my_smr;
+            loss[slot] = logf(my_smr + 1.0f);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void wmrb_bwd_wave_kernel(
+    const int64_t* __restrict__ indptr, const int32_t* __restrict__ pos_slot, const float* __restrict__ pos_weight,
+    const float* __restrict__ pred, const float* __restrict__ samp, const float* __restrict__ smr,
+    const float* __restrict__ grad_out, int64_t n_users, int32_t S, float ratio, float* __restrict__ d_pred,
+    float* __restrict__ d_samp)
+{
+    const int64_t u = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    if (u >= n_users) return;
+    const int lane = lane_id();
+    const int64_t b = indptr[u], e = indptr[u + 1];
+    float ys[WMRB_WAVE_SR], acc[WMRB_WAVE_SR];
+#pragma unroll
+    for (int r = 0; r < WMRB_WAVE_SR; ++r) {
+        ys[r] = (r * 64 + lane < S) ? samp[u * S + r * 64 + lane] : -INFINITY;
+        acc[r] = 0.f;
+    }
+    for (int64_t p0 = b; p0 < e; p0 += 64) {
+        const int np = (int)((e - p0 < 64) ? (e - p0) : 64);
+        float c = 0.f, yp = 0.f;
+        if (lane < np) {
+            const int32_t slot = pos_slot[p0 + lane];
+            yp = pred[p0 + lane];
+            if (slot >= 0) {
+                c = grad_out[slot] * ratio / (1.0f + smr[slot]);
+                if (pos_weight) c = c * pos_weight[p0 + lane];
+            }
+        }
+        float my_dp = 0.f;
+        for (int q = 0; q < np; ++q) {
+            const float cq = __shfl(c, q, 64);
+            if (cq == 0.f) continue;                               // wave-uniform; d_pred stays 0
+            const float base = 1.0f - __shfl(yp, q, 64);
+            int cnt = 0;
+#pragma unroll
+            for (int r = 0; r < WMRB_WAVE_SR; ++r) {
+                const bool active = base + ys[r] >= 0.f;           // -inf padding is never active
+                cnt += __popcll(__builtin_amdgcn_ballot_w64(active));
+                acc[r] += active ? cq : 0.f;
+            }
+            if (lane == q) my_dp = -cq * (float)cnt;
+        }
+        if (lane < np) d_pred[p0 + lane] = my_dp;
+    }
+#pragma unroll
+    for (int r = 0; r < WMRB_WAVE_SR; ++r)
+        if (r * 64 + lane < S) d_samp[u * S + r * 64 + lane] = acc[r];
+}
+
 // ---- RMSE -------------------------------------------------------------------------------------------------
 // pass 1: per-block partial sums of squared error (fixed tree order), pass 2 (one block): combine, sqrt, and
 // optionally the backward scale.  Two launches keep the reduction order independent of scheduling.
@@ -156,6 +251,12 @@ extern "C" int trec_wmrb_fwd(const int64_t* indptr, const int32_t* pos_slot, con
     TREC_REQUIRE(n_sampled >= 1 && n_sampled <= 16384, "trec_wmrb_fwd: n_sampled must be in [1, 16384]");
     if (n_users == 0) return TREC_OK;
     const float ratio = (float)n_items / (float)n_sampled;
+    if (n_sampled <= 64 * WMRB_WAVE_SR && trec_get_tuning("wmrb_wave", 1)) {
+        hipLaunchKernelGGL(wmrb_fwd_wave_kernel, dim3((unsigned)ceil_div64(n_users * 64, 256)), dim3(256), 0,
+                           (hipStream_t)stream, indptr, pos_slot, pos_weight, pred_serial, sample_pred, n_users, n_sampled,
+                           ratio, loss, smr);
+        return trec_check_launch("trec_wmrb_fwd");
+    }
     hipLaunchKernelGGL(wmrb_fwd_kernel, dim3((unsigned)n_users), dim3(256), sizeof(float) * n_sampled,
                        (hipStream_t)stream, indptr, pos_slot, pos_weight, pred_serial, sample_pred, n_sampled, ratio,
                        loss, smr);
@@ -172,6 +273,12 @@ extern "C" int trec_wmrb_bwd(const int64_t* indptr, const int32_t* pos_slot, con
     TREC_REQUIRE(n_sampled >= 1 && n_sampled <= 16384, "trec_wmrb_bwd: n_sampled must be in [1, 16384]");
     if (n_users == 0) return TREC_OK;
     const float ratio = (float)n_items / (float)n_sampled;
+    if (n_sampled <= 64 * WMRB_WAVE_SR && trec_get_tuning("wmrb_wave", 1)) {
+        hipLaunchKernelGGL(wmrb_bwd_wave_kernel, dim3((unsigned)ceil_div64(n_users * 64, 256)), dim3(256), 0,
+                           (hipStream_t)stream, indptr, pos_slot, pos_weight, pred_serial, sample_pred, smr, grad_loss,
+                           n_users, n_sampled, ratio, d_pred_serial, d_sample_pred);
+        return trec_check_launch("trec_wmrb_bwd");
+    }
     const size_t lds = sizeof(float) * ((size_t)n_sampled + 2 * WMRB_MAX_POS_LDS);
     hipLaunchKernelGGL(wmrb_bwd_kernel, dim3((unsigned)n_users), dim3(256), lds, (hipStream_t)stream, indptr, pos_slot,
                        pos_weight, pred_serial, sample_pred, smr, grad_loss, n_sampled, ratio, d_pred_serial,

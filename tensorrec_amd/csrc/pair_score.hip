@@ -18,7 +18,13 @@
 #define MODE_EUCLID 1
 #define EUCLID_EPS 1e-16f
 
-template <int VEC>
+// PP pairs per subgroup: the PP index loads, then the 2*PP row gathers are issued back to back, so a subgroup keeps PP
+// random 512-byte rows in flight instead of one (the sampled pairs are HBM-latency-bound otherwise: 100M random item
+// rows per step at the BASELINE fit shape).  Per pair the arithmetic is unchanged: one fmaf chain over the lane's
+// columns in increasing order, then the xor-butterfly.
+// SAMEUSER: implicit users with pairs_per_user % PP == 0 -- the PP pairs of a subgroup belong to ONE user, whose row is
+// loaded once (a quarter of the cache traffic of the sampled pairs at PP = 4).
+template <int VEC, int PP, bool SAMEUSER = false>
 __global__ __launch_bounds__(256) void pair_score_fwd_kernel(
     const float* __restrict__ U, const float* __restrict__ V, const int32_t* __restrict__ xu,
     const int32_t* __restrict__ xi, int64_t n_pairs, int32_t pairs_per_user, int d, int lpr_log2, int mode,
@@ -26,36 +32,64 @@ __global__ __launch_bounds__(256) void pair_score_fwd_kernel(
 {
     const int lpr = 1 << lpr_log2;
     const int sub_lane = threadIdx.x & (lpr - 1);
-    const int64_t p = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> lpr_log2;
-    if (p >= n_pairs) return;
-    const int64_t u = xu ? (int64_t)xu[p] : p / pairs_per_user;
-    const int64_t i = xi[p];
-    const float* a = U + u * d;
-    const float* b = V + i * d;
-    float acc = 0.f;
+    const int64_t p0 = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> lpr_log2) * PP;
+    if (p0 >= n_pairs) return;
+    int64_t u[PP], i[PP];
+    bool ok[PP];
+#pragma unroll
+    for (int r = 0; r < PP; ++r) {
+        const int64_t p = p0 + r;
+        ok[r] = p < n_pairs;
+        i[r] = ok[r] ? (int64_t)xi[p] : 0;
+        u[r] = ok[r] ? (xu ? (int64_t)xu[p] : p / pairs_per_user) : 0;
+    }
+    float acc[PP];
+#pragma unroll
+    for (int r = 0; r < PP; ++r) acc[r] = 0.f;
     if (VEC == 4) {
         for (int c = sub_lane * 4; c < d; c += lpr * 4) {
-            const f32x4 x = *(const f32x4*)(a + c), y = *(const f32x4*)(b + c);
-            if (mode == MODE_DOT) {
-                acc = fmaf(x.x, y.x, acc); acc = fmaf(x.y, y.y, acc); acc = fmaf(x.z, y.z, acc); acc = fmaf(x.w, y.w, acc);
-            } else {
-                const float d0 = x.x - y.x, d1 = x.y - y.y, d2 = x.z - y.z, d3 = x.w - y.w;
-                acc = fmaf(d0, d0, acc); acc = fmaf(d1, d1, acc); acc = fmaf(d2, d2, acc); acc = fmaf(d3, d3, acc);
+            f32x4 x[PP], y[PP];
+#pragma unroll
+            for (int r = 0; r < PP; ++r) {
+                if (!SAMEUSER || r == 0) x[r] = *(const f32x4*)(U + u[r] * d + c);
+                else x[r] = x[0];
+                y[r] = *(const f32x4*)(V + i[r] * d + c);
+            }
+#pragma unroll
+            for (int r = 0; r < PP; ++r) {
+                if (mode == MODE_DOT) {
+                    acc[r] = fmaf(x[r].x, y[r].x, acc[r]); acc[r] = fmaf(x[r].y, y[r].y, acc[r]);
+                    acc[r] = fmaf(x[r].z, y[r].z, acc[r]); acc[r] = fmaf(x[r].w, y[r].w, acc[r]);
+                } else {
+                    const float d0 = x[r].x - y[r].x, d1 = x[r].y - y[r].y, d2 = x[r].z - y[r].z, d3 = x[r].w - y[r].w;
+                    acc[r] = fmaf(d0, d0, acc[r]); acc[r] = fmaf(d1, d1, acc[r]);
+                    acc[r] = fmaf(d2, d2, acc[r]); acc[r] = fmaf(d3, d3, acc[r]);
+                }
             }
         }
     } else {
         for (int c = sub_lane; c < d; c += lpr) {
-            if (mode == MODE_DOT) acc = fmaf(a[c], b[c], acc);
-            else { const float df = a[c] - b[c]; acc = fmaf(df, df, acc); }
+#pragma unroll
+            for (int r = 0; r < PP; ++r) {
+                const float a = U[u[r] * d + c], b = V[i[r] * d + c];
+                if (mode == MODE_DOT) acc[r] = fmaf(a, b, acc[r]);
+                else { const float df = a - b; acc[r] = fmaf(df, df, acc[r]); }
+            }
         }
     }
-    for (int off = lpr >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+#pragma unroll
+    for (int r = 0; r < PP; ++r)
+        for (int off = lpr >> 1; off > 0; off >>= 1) acc[r] += __shfl_xor(acc[r], off, 64);
     if (sub_lane == 0) {
-        float s = acc;
-        if (mode == MODE_EUCLID) s = -1.0f * sqrtf(fmaxf(acc, EUCLID_EPS));
-        if (ub) s = s + ub[u];
-        if (ib) s = s + ib[i];
-        out[p] = s;
+#pragma unroll
+        for (int r = 0; r < PP; ++r) {
+            if (!ok[r]) continue;
+            float s = acc[r];
+            if (mode == MODE_EUCLID) s = -1.0f * sqrtf(fmaxf(acc[r], EUCLID_EPS));
+            if (ub) s = s + ub[u[r]];
+            if (ib) s = s + ib[i[r]];
+            out[p0 + r] = s;
+        }
     }
 }
 
@@ -123,13 +157,26 @@ extern "C" int trec_pair_score_fwd(const float* U, const float* V, const int32_t
     TREC_REQUIRE(d >= 1, "trec_pair_score_fwd: d must be >= 1");
     if (n_pairs == 0) return TREC_OK;
     int vec, l2; pair_geometry(d, vec, l2);
-    const unsigned blocks = (unsigned)ceil_div64(n_pairs << l2, 256);
-    if (vec == 4)
-        hipLaunchKernelGGL((pair_score_fwd_kernel<4>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, U, V, xu, xi,
-                           n_pairs, pairs_per_user, d, l2, mode, user_bias, item_bias, out);
-    else
-        hipLaunchKernelGGL((pair_score_fwd_kernel<1>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, U, V, xu, xi,
-                           n_pairs, pairs_per_user, d, l2, mode, user_bias, item_bias, out);
+    int pp = (n_pairs >= 65536) ? trec_get_tuning("pair_fwd_pp", 4) : 1;          // small launches: fill the chip first
+    pp = (pp >= 4 && vec == 4) ? 4 : (pp >= 2 ? 2 : 1);
+    const unsigned blocks = (unsigned)ceil_div64(ceil_div64(n_pairs, pp) << l2, 256);
+#define TREC_PAIR_FWD(VECV, PPV)                                                                                    \
+    hipLaunchKernelGGL((pair_score_fwd_kernel<VECV, PPV>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, U, V, xu, \
+                       xi, n_pairs, pairs_per_user, d, l2, mode, user_bias, item_bias, out)
+    const bool same_user = !xu && pairs_per_user % 8 == 0 && vec == 4 && pp == 4 && n_pairs % 8 == 0;
+    if (same_user && trec_get_tuning("pair_fwd_same_user", 8) == 8) {
+        const unsigned blocks8 = (unsigned)ceil_div64(ceil_div64(n_pairs, 8) << l2, 256);
+        hipLaunchKernelGGL((pair_score_fwd_kernel<4, 8, true>), dim3(blocks8), dim3(256), 0, (hipStream_t)stream, U, V, xu,
+                           xi, n_pairs, pairs_per_user, d, l2, mode, user_bias, item_bias, out);
+    } else if (!xu && pairs_per_user % 4 == 0 && vec == 4 && pp == 4 && trec_get_tuning("pair_fwd_same_user", 8)) {
+        hipLaunchKernelGGL((pair_score_fwd_kernel<4, 4, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, U, V, xu,
+                           xi, n_pairs, pairs_per_user, d, l2, mode, user_bias, item_bias, out);
+    } else if (vec == 4 && pp == 4) TREC_PAIR_FWD(4, 4);
+    else if (vec == 4 && pp == 2) TREC_PAIR_FWD(4, 2);
+    else if (vec == 4) TREC_PAIR_FWD(4, 1);
+    else if (pp >= 2) TREC_PAIR_FWD(1, 2);
+    else TREC_PAIR_FWD(1, 1);
+#undef TREC_PAIR_FWD
     return trec_check_launch("trec_pair_score_fwd");
 }
 

@@ -271,6 +271,24 @@ __global__ __launch_bounds__(256) void spmv_csr_kernel(const int64_t* __restrict
     out[row] = acc;
 }
 
+// beta == NULL: plain row sums of the (permuted) values -- the bias gradients of the serial predictions (g summed per
+// user / per item).  Rows there are long (S samples per user, ~S per item), so 16 lanes share a row with coalesced
+// strided reads instead of one thread walking it.
+__global__ __launch_bounds__(256) void segsum_csr_kernel(const int64_t* __restrict__ indptr,
+                                                        const float* __restrict__ values,
+                                                        const int32_t* __restrict__ val_perm, int64_t n_rows,
+                                                        float* __restrict__ out)
+{
+    const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    if (row >= n_rows) return;
+    const int sub = threadIdx.x & 15;
+    const int64_t b = indptr[row], e = indptr[row + 1];
+    float acc = 0.f;
+    for (int64_t j = b + sub; j < e; j += 16) acc += values[val_perm ? (int64_t)val_perm[j] : j];
+    for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (sub == 0) out[row] = acc;
+}
+
 // dense[r, c] = X[r, c]  (tf.sparse_tensor_to_dense, representation_graphs.py:74); out pre-zeroed by caller
 __global__ __launch_bounds__(256) void csr_to_dense_kernel(const int64_t* __restrict__ indptr,
                                                           const int32_t* __restrict__ indices,
@@ -402,8 +420,13 @@ extern "C" int trec_colsum(const float* x, int64_t n_rows, int32_t d, float* out
 extern "C" int trec_spmv_csr(const int64_t* indptr, const int32_t* indices, const float* values,
                              const int32_t* val_perm, int64_t n_rows, const float* beta, float* out, void* stream)
 {
-    TREC_REQUIRE(indptr && beta && out, "trec_spmv_csr: null pointer");   // indices/values may be NULL when nnz == 0
+    TREC_REQUIRE(indptr && out, "trec_spmv_csr: null pointer");   // indices/values may be NULL when nnz == 0
     if (n_rows == 0) return TREC_OK;
+    if (!beta) {              // beta = ones: segmented sum of the values
+        hipLaunchKernelGGL(segsum_csr_kernel, dim3((unsigned)ceil_div64(n_rows * 16, 256)), dim3(256), 0,
+                           (hipStream_t)stream, indptr, values, val_perm, n_rows, out);
+        return trec_check_launch("trec_spmv_csr(segment sum)");
+    }
     hipLaunchKernelGGL(spmv_csr_kernel, dim3((unsigned)ceil_div64(n_rows, 256)), dim3(256), 0, (hipStream_t)stream,
                        indptr, indices, values, val_perm, n_rows, beta, out);
     return trec_check_launch("trec_spmv_csr");

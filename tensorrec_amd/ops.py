@@ -261,7 +261,7 @@ class _PairScore(torch.autograd.Function):
         if has_ub:
             dub = torch.empty((n_users,), dtype=torch.float32, device=dev)
             N.call("trec_spmv_csr", N.ptr(indptr_u), N.ptr(xi32), N.ptr(g), None, n_users,
-                   N.ptr(_ones(n_items, dev)), N.ptr(dub))
+                   None, N.ptr(dub))
         # ---- item side
         if inter is not None:
             indptr_t, users_t, perm_t = inter.transposed()
@@ -270,7 +270,7 @@ class _PairScore(torch.autograd.Function):
             if has_ib:
                 dib = torch.empty((n_items,), dtype=torch.float32, device=dev)
                 N.call("trec_spmv_csr", N.ptr(indptr_t), N.ptr(users_t), N.ptr(g), N.ptr(perm_t), n_items,
-                       N.ptr(_ones(n_users, dev)), N.ptr(dib))
+                       None, N.ptr(dib))
         else:
             # sampled pairs: items are random -> group the pairs by item on the device (counting sort), then the same
             # segmented gather; replaces n_pairs * d fp32 atomics
@@ -280,7 +280,7 @@ class _PairScore(torch.autograd.Function):
             if has_ib:
                 dib = torch.empty((n_items,), dtype=torch.float32, device=dev)
                 N.call("trec_spmv_csr", N.ptr(indptr_t), N.ptr(users_t), N.ptr(g), N.ptr(perm_t), n_items,
-                       N.ptr(_ones(n_users, dev)), N.ptr(dib))
+                       None, N.ptr(dib))
         return du, dv, dub, dib, None, None, None, None, None
 
 
@@ -342,14 +342,14 @@ def _pair_bias_grads(g, xu32, xi32, ppu, inter, n_users, n_items, want_ub, want_
         indptr_u = inter.indptr if inter is not None else \
             torch.arange(0, (n_users + 1) * ppu, ppu, dtype=torch.int64, device=dev)
         dub = torch.empty((n_users,), dtype=torch.float32, device=dev)
-        N.call("trec_spmv_csr", N.ptr(indptr_u), N.ptr(xi32), N.ptr(g), None, n_users, N.ptr(_ones(n_items, dev)),
+        N.call("trec_spmv_csr", N.ptr(indptr_u), N.ptr(xi32), N.ptr(g), None, n_users, None,
                N.ptr(dub))
     if want_ib:
         indptr_t, users_t, perm_t = inter.transposed() if inter is not None else \
             group_pairs_by_item(xu32, xi32, ppu, n_items)
         dib = torch.empty((n_items,), dtype=torch.float32, device=dev)
         N.call("trec_spmv_csr", N.ptr(indptr_t), N.ptr(users_t), N.ptr(g), N.ptr(perm_t), n_items,
-               N.ptr(_ones(n_users, dev)), N.ptr(dib))
+               None, N.ptr(dib))
     return dub, dib
 
 

@@ -433,6 +433,35 @@ def test_wmrb_fwd_bwd(ops, balanced, S):
     assert np.allclose(st.grad.cpu().numpy(), sc.grad.numpy(), rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("S", [1, 63, 100, 256])
+def test_wmrb_wave_per_user_kernels_match_workgroup_kernels(ops, S):
+    """S <= 256 runs a wave per user; it must reproduce the workgroup-per-user kernels bit for bit (same lane/order
+    split), including users without interactions, non-positive interactions and balanced weights."""
+    import tensorrec_amd as T
+    nu, ni = 133, 70
+    m, inter = _interactions(nu, ni, 0.3, seed=S)
+    rng = np.random.default_rng(S)
+    pred = rng.standard_normal(m.nnz).astype(np.float32)
+    samp = rng.standard_normal((nu, S)).astype(np.float32)
+    go = None
+    outs = []
+    for wave in (1, 0):
+        T._native.set_tuning("wmrb_wave", wave)
+        try:
+            for balanced in (False, True):
+                pt, st = dev(pred).requires_grad_(True), dev(samp).requires_grad_(True)
+                loss = ops.wmrb_loss(pt, st, inter, balanced=balanced)
+                if go is None:
+                    go = rng.standard_normal(loss.shape[0]).astype(np.float32)
+                loss.backward(dev(go))
+                outs.append((loss.detach().cpu().numpy(), pt.grad.cpu().numpy(), st.grad.cpu().numpy()))
+        finally:
+            T._native.set_tuning("wmrb_wave", 1)
+    for a, b in zip(outs[:2], outs[2:]):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+
+
 def test_wmrb_many_positives_per_user(ops):
     """more positives than one LDS pass holds (1024) -> the multi-pass accumulation path."""
     from tensorrec_amd.sparse import Interactions
