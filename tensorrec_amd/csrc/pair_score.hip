@@ -22,9 +22,9 @@
 // random 512-byte rows in flight instead of one (the sampled pairs are HBM-latency-bound otherwise: 100M random item
 // rows per step at the BASELINE fit shape).  Per pair the arithmetic is unchanged: one fmaf chain over the lane's
 // columns in increasing order, then the xor-butterfly.
-// SAMEUSER: implicit users with pairs_per_user % PP == 0 -- the PP pairs of a subgroup belong to ONE user, whose row is
-// loaded once (a quarter of the cache traffic of the sampled pairs at PP = 4).
-template <int VEC, int PP, bool SAMEUSER = false>
+// UG > 0: implicit users with pairs_per_user % UG == 0 -- every aligned group of UG pairs belongs to ONE user, whose
+// row is loaded once per group (a quarter of the cache traffic of the sampled pairs at UG = 4).
+template <int VEC, int PP, int UG = 0>
 __global__ __launch_bounds__(256) void pair_score_fwd_kernel(
     const float* __restrict__ U, const float* __restrict__ V, const int32_t* __restrict__ xu,
     const int32_t* __restrict__ xi, int64_t n_pairs, int32_t pairs_per_user, int d, int lpr_log2, int mode,
@@ -51,8 +51,8 @@ __global__ __launch_bounds__(256) void pair_score_fwd_kernel(
             f32x4 x[PP], y[PP];
 #pragma unroll
             for (int r = 0; r < PP; ++r) {
-                if (!SAMEUSER || r == 0) x[r] = *(const f32x4*)(U + u[r] * d + c);
-                else x[r] = x[0];
+                if (UG == 0 || r % (UG ? UG : 1) == 0) x[r] = *(const f32x4*)(U + u[r] * d + c);
+                else x[r] = x[r - r % (UG ? UG : 1)];
                 y[r] = *(const f32x4*)(V + i[r] * d + c);
             }
 #pragma unroll
@@ -157,20 +157,22 @@ extern "C" int trec_pair_score_fwd(const float* U, const float* V, const int32_t
     TREC_REQUIRE(d >= 1, "trec_pair_score_fwd: d must be >= 1");
     if (n_pairs == 0) return TREC_OK;
     int vec, l2; pair_geometry(d, vec, l2);
-    int pp = (n_pairs >= 65536) ? trec_get_tuning("pair_fwd_pp", 4) : 1;          // small launches: fill the chip first
+    // measured at the BASELINE fit shape (rocprofv3, 100M sampled pairs / 20M interactions, d = 128): sampled pairs
+    // 17.3 ms at 1 pair per subgroup, 13.9 at 2, 15.4 at 4, 12.4 at 4 with the shared user row; interactions 3.9 / 3.1 / 3.6
+    int pp = (n_pairs >= 65536) ? trec_get_tuning("pair_fwd_pp", (!xu && pairs_per_user % 4 == 0) ? 4 : 2) : 1;
     pp = (pp >= 4 && vec == 4) ? 4 : (pp >= 2 ? 2 : 1);
     const unsigned blocks = (unsigned)ceil_div64(ceil_div64(n_pairs, pp) << l2, 256);
 #define TREC_PAIR_FWD(VECV, PPV)                                                                                    \
     hipLaunchKernelGGL((pair_score_fwd_kernel<VECV, PPV>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, U, V, xu, \
                        xi, n_pairs, pairs_per_user, d, l2, mode, user_bias, item_bias, out)
-    const bool same_user = !xu && pairs_per_user % 8 == 0 && vec == 4 && pp == 4 && n_pairs % 8 == 0;
-    if (same_user && trec_get_tuning("pair_fwd_same_user", 8) == 8) {
-        const unsigned blocks8 = (unsigned)ceil_div64(ceil_div64(n_pairs, 8) << l2, 256);
-        hipLaunchKernelGGL((pair_score_fwd_kernel<4, 8, true>), dim3(blocks8), dim3(256), 0, (hipStream_t)stream, U, V, xu,
-                           xi, n_pairs, pairs_per_user, d, l2, mode, user_bias, item_bias, out);
-    } else if (!xu && pairs_per_user % 4 == 0 && vec == 4 && pp == 4 && trec_get_tuning("pair_fwd_same_user", 8)) {
-        hipLaunchKernelGGL((pair_score_fwd_kernel<4, 4, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, U, V, xu,
-                           xi, n_pairs, pairs_per_user, d, l2, mode, user_bias, item_bias, out);
+    const int ug = trec_get_tuning("pair_fwd_user_group", 1);       // 1: share the user row inside a subgroup's pairs
+    if (!xu && vec == 4 && ug && pp >= 2 && pairs_per_user % pp == 0) {
+        if (pp == 4)
+            hipLaunchKernelGGL((pair_score_fwd_kernel<4, 4, 4>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, U, V,
+                               xu, xi, n_pairs, pairs_per_user, d, l2, mode, user_bias, item_bias, out);
+        else
+            hipLaunchKernelGGL((pair_score_fwd_kernel<4, 2, 2>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, U, V,
+                               xu, xi, n_pairs, pairs_per_user, d, l2, mode, user_bias, item_bias, out);
     } else if (vec == 4 && pp == 4) TREC_PAIR_FWD(4, 4);
     else if (vec == 4 && pp == 2) TREC_PAIR_FWD(4, 2);
     else if (vec == 4) TREC_PAIR_FWD(4, 1);
