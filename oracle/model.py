@@ -220,6 +220,26 @@ class OracleTensorRec(object):
                 per_item = torch.zeros(n_items, dtype=torch.float32).index_add_(0, xi[mask], pos_vals)
                 smr = smr * pos_vals / per_item[xi[mask]]
             basic = torch.log(smr + 1.0)
+        elif self.loss_kind in ("rmse_dense", "separation", "separation_dense"):     # loss_graphs.py:62-134
+            def separation(pos, neg):
+                loc = neg.mean() - pos.mean()
+                scale = torch.sqrt(((neg - neg.mean()) ** 2).mean() + ((pos - pos.mean()) ** 2).mean())
+                return 1.0 - 0.5 * (1.0 + torch.erf((0.0 - loc) / (scale * 1.4142135623730951)))
+
+            if self.loss_kind == "separation":
+                basic = separation(pred_serial[y > 0.0], pred_serial[y <= 0.0])
+            else:
+                preds = [self._dense(u_, o["item_repr"]) for u_ in o["user_reprs"]]
+                attns = [self._dense(a_, o["item_repr"]) for a_ in o["attn_reprs"]] if self.attention is not None else None
+                dense_pred = self._collapse(preds, attns)
+                if self.biased:
+                    dense_pred = dense_pred + o["user_bias"][:, None] + o["item_bias"][None, :]
+                dense_inter = torch.zeros((n_users, n_items), dtype=torch.float32).index_put_((xu, xi), y, accumulate=True)
+                if self.loss_kind == "rmse_dense":
+                    basic = torch.sqrt(torch.mean((dense_inter - dense_pred) ** 2))
+                else:
+                    flat_p, flat_y = dense_pred.reshape(-1), dense_inter.reshape(-1)
+                    basic = separation(flat_p[flat_y > 0.0], flat_p[flat_y <= 0.0])
         else:
             raise ValueError(self.loss_kind)
 

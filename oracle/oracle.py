@@ -330,6 +330,35 @@ def rmse_loss(pred_serial, interactions_serial):   # :58-59
     return np.sqrt(np.mean(e * e, dtype=np.float32))
 
 
+def rmse_dense_loss(prediction, interactions):   # :62-72  tf.sparse_add(interactions, -prediction), mean over U*I
+    err = -1.0 * _f32(prediction)
+    m = sp.coo_matrix(interactions)
+    np.add.at(err, (m.row, m.col), m.data.astype(np.float32))
+    return np.sqrt(np.mean(err * err, dtype=np.float32))
+
+
+def _separation(pos, neg):                       # :90-96  tf.nn.moments = population variance; Normal(loc, scale).cdf(0)
+    pos, neg = _f32(pos), _f32(neg)
+    pos_mean, neg_mean = pos.mean(dtype=np.float32), neg.mean(dtype=np.float32)
+    pos_var = np.mean((pos - pos_mean) ** 2, dtype=np.float32)
+    neg_var = np.mean((neg - neg_mean) ** 2, dtype=np.float32)
+    loc = neg_mean - pos_mean
+    scale = np.sqrt(neg_var + pos_var)
+    cdf0 = 0.5 * (1.0 + math.erf(float((0.0 - loc) / (scale * np.float32(math.sqrt(2.0))))))
+    return np.float32(1.0 - cdf0)
+
+
+def separation_loss(pred_serial, interactions_serial):   # :75-97
+    pred_serial, y = _f32(pred_serial), _f32(interactions_serial)
+    return _separation(pred_serial[y > 0.0], pred_serial[y <= 0.0])
+
+
+def separation_dense_loss(prediction, interactions):     # :100-134: non-interacted pairs count as negatives
+    dense = np.asarray(sp.coo_matrix(interactions).todense(), dtype=np.float32).reshape(-1)
+    pred = _f32(prediction).reshape(-1)
+    return _separation(pred[dense > 0.0], pred[dense <= 0.0])
+
+
 def wmrb_loss(pred_serial, x_user, values, sample_predictions, n_items, n_sampled_items):   # :153-180
     """Returns the [P+] vector (the reference does NOT reduce it, :179-180)."""
     values = _f32(values)

@@ -720,6 +720,18 @@ def test_hip_path_vs_reference_source_fixtures(ops):
         assert np.allclose(got.cpu().numpy(), g["expected_loss"], **tol)
     g = sg["loss_rmse"]
     assert np.allclose(float(ops.rmse_loss(dev(g["prediction_serial"]), inter.values)), g["expected_loss"], rtol=1e-5)
+    # dense + separation loss graphs (loss_graphs.py:62-134) through the product classes
+    from tensorrec_amd import loss_graphs as LG
+    from tensorrec_amd.prediction_graphs import DotProductPredictionGraph as Dot
+    g = sg["loss_separation"]
+    got = LG.SeparationLossGraph().connect_loss_graph(tf_prediction_serial=dev(g["prediction_serial"]),
+                                                      tf_interactions_serial=inter.values)
+    assert np.allclose(float(got), g["expected_loss"], rtol=1e-5, atol=1e-6)
+    for key, cls in (("loss_rmse_dense", LG.RMSEDenseLossGraph), ("loss_separation_dense", LG.SeparationDenseLossGraph)):
+        g = sg[key]
+        dense = Dot().connect_dense_prediction_graph(dev(g["user_repr"]), dev(g["item_repr"]))
+        got = cls().connect_loss_graph(tf_prediction=dense, tf_interactions=inter)
+        assert np.allclose(float(got), g["expected_loss"], rtol=1e-5, atol=1e-6), key
     # prediction graphs
     from tensorrec_amd.prediction_graphs import (DotProductPredictionGraph, CosineSimilarityPredictionGraph,
                                                  EuclideanSimilarityPredictionGraph)

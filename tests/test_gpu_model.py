@@ -25,7 +25,8 @@ REPR = {"linear": LinearRepresentationGraph, "normalized_linear": NormalizedLine
         "relu": ReLURepresentationGraph}
 PRED = {"dot": DotProductPredictionGraph, "cosine": CosineSimilarityPredictionGraph,
         "euclidean": EuclideanSimilarityPredictionGraph}
-LOSS = {"rmse": RMSELossGraph, "wmrb": WMRBLossGraph, "balanced_wmrb": BalancedWMRBLossGraph}
+LOSS = {"rmse": RMSELossGraph, "wmrb": WMRBLossGraph, "balanced_wmrb": BalancedWMRBLossGraph,
+        "rmse_dense": RMSEDenseLossGraph, "separation": SeparationLossGraph, "separation_dense": SeparationDenseLossGraph}
 
 
 def dummy(n_users=60, n_items=90, seed=0):
@@ -67,6 +68,9 @@ def _rename(w):
     ("normalized_linear", "linear", "cosine", "balanced_wmrb", True, 20),
     ("relu", "relu", "euclidean", "wmrb", True, 16),                # BASELINE config 5 shape
     ("linear", "relu", "euclidean", "rmse", False, 12),
+    ("linear", "linear", "dot", "rmse_dense", True, 16),            # dense + separation losses
+    ("linear", "linear", "dot", "separation", True, 16),
+    ("normalized_linear", "linear", "cosine", "separation_dense", False, 12),
 ])
 def test_fit_steps_match_oracle(user_repr, item_repr, pred, loss, biased, d):
     data = dummy()

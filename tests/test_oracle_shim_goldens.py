@@ -54,6 +54,13 @@ def test_losses(sg):
     got = O.balanced_wmrb_loss(g["prediction_serial"], rows, cols, vals, g["sample_predictions"], g["n_items"],
                                g["n_sampled_items"], shape)
     assert np.allclose(got, g["expected_loss"], **TOL)
+    # dense + separation losses (loss_graphs.py:62-134)
+    g = sg["loss_separation"]
+    assert np.allclose(O.separation_loss(g["prediction_serial"], vals), g["expected_loss"], **TOL)
+    for key, fn in (("loss_rmse_dense", O.rmse_dense_loss), ("loss_separation_dense", O.separation_dense_loss)):
+        g = sg[key]
+        dense = O.DENSE["dot"](g["user_repr"], g["item_repr"])
+        assert np.allclose(fn(dense, sp.csr_matrix(g["interactions"])), g["expected_loss"], **TOL), key
 
 
 def test_prediction_graphs_and_ranks(sg):
