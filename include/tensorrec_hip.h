@@ -176,6 +176,23 @@ int trec_wmrb_fwd(const int64_t* indptr, const int32_t* pos_slot, const float* p
 int trec_wmrb_bwd(const int64_t* indptr, const int32_t* pos_slot, const float* pos_weight, const float* pred_serial,
                   const float* sample_pred, const float* smr, const float* grad_loss, int64_t n_users,
                   int64_t n_items, int32_t n_sampled, float* d_pred_serial, float* d_sample_pred, void* stream);
+/* One WMRB training step's user side in one pass (csrc/wmrb_fused.hip): serial + sample predictions
+ * (prediction_graphs.py:52-55 + recommendation_graphs.py:55-57 over tensorrec.py:384-395), the WMRB / BalancedWMRB loss
+ * (loss_graphs.py:153-227) and, for the SUM of the loss vector (what tensorrec.py:487-489 minimises), its gradient
+ * w.r.t. the user representation and user bias, with every item row gathered from HBM once (register-resident).  Dot
+ * scores on the given representations (cosine: pass the normalised rows).  samples: int32 [n_users, n_sampled];
+ * x_item: int32 item of every interaction (CSR order).  Outputs: loss [n_positive], pred_serial [n_interactions],
+ * dU [n_users, d], d_user_bias [n_users] (NULL iff user_bias is NULL), coef_samples [n_users, n_sampled] and
+ * coef_pairs [n_interactions] = d(sum loss)/d(prediction) per pair -- the values of the item-side gathers
+ * (trec_group_pairs_by_item + trec_spmm_csr) and item-bias segment sums.
+ * trec_wmrb_fused_lds_bytes: dynamic LDS the launch needs, or -1 if (n_sampled <= 256, d % 4 == 0, d <= 256,
+ * n_sampled + max interactions per user <= 256 rows, 128 for d > 128) does not hold -- then run the unfused kernels.   */
+int trec_wmrb_fused_lds_bytes(int32_t n_sampled, int32_t max_interactions_per_user, int32_t d);
+int trec_wmrb_fused_step(const float* U, const float* V, const float* user_bias, const float* item_bias,
+                         const int64_t* indptr, const int32_t* x_item, const int32_t* pos_slot, const float* pos_weight,
+                         const int32_t* samples, int64_t n_users, int64_t n_items, int32_t n_sampled, int32_t d,
+                         int32_t max_interactions_per_user, float* loss, float* pred_serial, float* dU,
+                         float* d_user_bias, float* coef_samples, float* coef_pairs, void* stream);
 /* RMSE, loss_graphs.py:58-59 */
 int trec_rmse_fwd(const float* y, const float* pred, int64_t n, float* partial_ws, int32_t n_partial, float* loss,
                   void* stream);

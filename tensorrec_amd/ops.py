@@ -458,6 +458,60 @@ class _WMRB(torch.autograd.Function):
         return dp, ds, None, None
 
 
+def wmrb_fused_supported(n_sampled, interactions, d):
+    """Can the one-pass WMRB step (csrc/wmrb_fused.hip) run this shape?  (LDS holds S + max interactions-per-user rows.)"""
+    if not N.load().trec_get_tuning(b"wmrb_fused", 1):
+        return False
+    return N.query("trec_wmrb_fused_lds_bytes", int(n_sampled), int(interactions.max_row_nnz), int(d)) >= 0
+
+
+def wmrb_fused_step(user_in, item_in, user_bias, item_bias, interactions, samples, balanced=False):
+    """One WMRB / BalancedWMRB step for dot scores on (user_in, item_in), upstream gradient 1 (the trainer minimises
+    the SUM of the loss vector): returns (loss [P+], pred_serial [P], d user_in, d item_in, d user_bias, d item_bias).
+    The user side -- predictions of the interactions and of the sampled pairs, loss, dU, d b_u -- is one kernel with
+    every item row gathered once; the item side groups the per-pair coefficients by item (static transposed structure
+    for the interactions, device counting sort for the samples) and runs the segmented K1 gathers / segment sums."""
+    u, v = _f32c(user_in.detach()), _f32c(item_in.detach())
+    ub = _f32c(user_bias.detach()) if user_bias is not None else None
+    ib = _f32c(item_bias.detach()) if item_bias is not None else None
+    n_users, n_items = interactions.shape
+    S = int(samples.shape[1])
+    d = u.shape[1]
+    dev = u.device
+    nnz = interactions.nnz
+    loss = torch.empty((interactions.n_positive,), dtype=torch.float32, device=dev)
+    pred = torch.empty((nnz,), dtype=torch.float32, device=dev)
+    d_u = torch.empty_like(u)
+    d_ub = torch.empty((n_users,), dtype=torch.float32, device=dev) if ub is not None else None
+    coef_s = torch.empty((n_users, S), dtype=torch.float32, device=dev)
+    coef_p = torch.empty((nnz,), dtype=torch.float32, device=dev)
+    weight = interactions.balanced_weight() if balanced else None
+    samples = samples.to(torch.int32).contiguous()
+    with _timed("wmrb_fused_step"):
+        N.call("trec_wmrb_fused_step", N.ptr(u), N.ptr(v), N.ptr(ub), N.ptr(ib), N.ptr(interactions.indptr),
+               N.ptr(interactions.x_item32), N.ptr(interactions.pos_slot), N.ptr(weight), N.ptr(samples), n_users,
+               n_items, S, d, int(interactions.max_row_nnz), N.ptr(loss), N.ptr(pred), N.ptr(d_u), N.ptr(d_ub),
+               N.ptr(coef_s), N.ptr(coef_p))
+    # ---- item side: d item_in = G^T . user_in over both pair lists, d b_i = per-item sums of the coefficients
+    d_v = torch.zeros_like(v) if nnz == 0 else None
+    d_ib = torch.zeros((n_items,), dtype=torch.float32, device=dev) if ib is not None else None
+    if nnz:
+        indptr_t, users_t, perm_t = interactions.transposed()
+        d_v = spmm_raw(indptr_t, users_t, coef_p, perm_t, n_items, nnz, u)
+        if ib is not None:
+            N.call("trec_spmv_csr", N.ptr(indptr_t), N.ptr(users_t), N.ptr(coef_p), N.ptr(perm_t), n_items, None,
+                   N.ptr(d_ib))
+    xs = samples.reshape(-1)
+    ind_s, users_s, perm_s = group_pairs_by_item(None, xs, S, n_items)
+    spmm_raw(ind_s, users_s, coef_s.reshape(-1), perm_s, n_items, n_users * S, u, accumulate=True, out=d_v)
+    if ib is not None:
+        part = torch.empty((n_items,), dtype=torch.float32, device=dev)
+        N.call("trec_spmv_csr", N.ptr(ind_s), N.ptr(users_s), N.ptr(coef_s.reshape(-1)), N.ptr(perm_s), n_items, None,
+               N.ptr(part))
+        d_ib += part
+    return loss, pred, d_u, d_v, d_ub, d_ib
+
+
 def wmrb_loss(pred_serial, sample_pred, interactions, balanced=False):
     if sample_pred.shape[0] != interactions.shape[0]:
         raise ValueError("tf_sample_predictions must have one row per user")

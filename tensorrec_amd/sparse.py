@@ -100,6 +100,7 @@ class Interactions(object):
         pos_slot = np.full(m.nnz, -1, np.int32)
         pos_slot[pos] = np.arange(int(pos.sum()), dtype=np.int32)
         self.n_positive = int(pos.sum())
+        self.max_row_nnz = int(np.diff(m.indptr).max()) if m.shape[0] and m.nnz else 0
         self.indptr = _dev(indptr, self.device)
         self.x_user = _dev(coo_rows, self.device)
         self.x_item = _dev(m.indices.astype(np.int64), self.device)

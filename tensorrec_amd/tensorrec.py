@@ -31,7 +31,7 @@ from .errors import (
     ModelNotBiasedException, ModelNotFitException, ModelWithoutAttentionException, BatchNonSparseInputException
 )
 from .framework import VariableStore, variable_scope, set_seed
-from .loss_graphs import AbstractLossGraph, RMSELossGraph
+from .loss_graphs import AbstractLossGraph, RMSELossGraph, WMRBLossGraph, BalancedWMRBLossGraph
 from .prediction_graphs import AbstractPredictionGraph, DotProductPredictionGraph
 from .recommendation_graphs import (
     project_biases, bias_prediction_dense, bias_prediction_serial, rank_predictions,
@@ -457,12 +457,21 @@ class TensorRec(object):
             x_item = PairIndex.make(inter.x_item, inter.x_item32, interactions=inter)
 
             engine = self._is_engine_graph()
+            # built-in WMRB on dot / cosine scores: one fused pass per user (csrc/wmrb_fused.hip) instead of
+            # serial scores -> loss -> autograd; only the exact built-in classes qualify (subclasses may override)
+            fused = (engine and not multi and graph.engine_mode == ops.MODE_DOT
+                     and type(loss_graph) in (WMRBLossGraph, BalancedWMRBLossGraph)
+                     and n_sampled_items is not None
+                     and ops.wmrb_fused_supported(n_sampled_items, inter, self.n_components))
             u_ins, a_ins, i_in = user_reprs, attn_reprs, item_repr
             if engine and graph.engine_normalize:     # cosine: normalise once, share between all serial calls
                 u_ins = [ops.l2_normalize_rows(u) for u in user_reprs]
                 a_ins = [ops.l2_normalize_rows(a) for a in attn_reprs] if attn_reprs is not None else None
                 i_in = ops.l2_normalize_rows(item_repr)
             u_in = u_ins[0]
+            if fused:
+                return self._fused_wmrb_step(inter, u_in, i_in, user_bias, item_bias, weights, learning_rate, alpha,
+                                             n_sampled_items, want_stats)
             if multi:
                 pred_serial = self._serial_multi(u_ins, a_ins, i_in, x_user, x_item, user_bias, item_bias)
             elif engine:
@@ -519,6 +528,34 @@ class TensorRec(object):
         # tf_loss = tf_basic_loss + alpha * reg (broadcast), minimised as a sum (tensorrec.py:487-489)
         n_loss = int(basic_loss.numel())
         basic_loss.sum().backward()
+        return self._apply_gradients(basic_loss, pred_serial, weights, n_loss, learning_rate, alpha, want_stats)
+
+    def _fused_wmrb_step(self, inter, u_in, i_in, user_bias, item_bias, weights, learning_rate, alpha, n_sampled_items,
+                         want_stats):
+        """The WMRB step with the user side in one kernel: loss values and d(sum loss)/d(representations, biases) come
+        from ops.wmrb_fused_step; autograd then only carries them through the representation graphs (K1 backward)."""
+        loss_graph = self.loss_graph_factory
+        n_users, n_items = inter.shape
+        self._sample_step += 1
+        samples = self.sampler.sample(n_items, n_users, int(n_sampled_items), loss_graph.is_sampled_with_replacement,
+                                      self._sample_step, self._store.device, getattr(inter, 'user_base', 0))
+        ub = user_bias if self.biased else None
+        ib = item_bias if self.biased else None
+        basic_loss, pred_serial, d_u, d_v, d_ub, d_ib = ops.wmrb_fused_step(u_in, i_in, ub, ib, inter, samples,
+                                                                            balanced=loss_graph.balanced)
+        tensors, grads = [u_in, i_in], [d_u, d_v]
+        if self.biased:
+            tensors += [user_bias, item_bias]
+            grads += [d_ub, d_ib]
+        live = [(t, g) for t, g in zip(tensors, grads) if t.requires_grad]      # weight-less graphs have no history
+        if live:
+            torch.autograd.backward([t for t, _ in live], [g for _, g in live])
+        return self._apply_gradients(basic_loss, pred_serial, weights, int(basic_loss.numel()), learning_rate, alpha,
+                                     want_stats)
+
+    def _apply_gradients(self, basic_loss, pred_serial, weights, n_loss, learning_rate, alpha, want_stats):
+        """Gradient all-reduce (data-parallel fit), the L2 term and the fused Adam step (tensorrec.py:487-489)."""
+        loss_graph = self.loss_graph_factory
 
         if self._dp_active():
             # data-parallel over users: the objective is a sum over interactions, so the gradient of the union batch is

@@ -380,3 +380,74 @@ def test_fit_from_tfrecords_and_datasets(tmp_path):
     pa = a.predict(uf, itf)
     assert np.array_equal(pa, b.predict(paths[1], paths[2])) and np.array_equal(pa, c.predict(uf, itf))
     assert np.array_equal(a.predict_rank(uf, itf), b.predict_rank(paths[1], paths[2]))
+
+
+@pytest.mark.parametrize("pred,loss,biased,d,S", [("dot", "wmrb", True, 128, 100), ("cosine", "balanced_wmrb", True, 64, 37),
+                                                  ("dot", "wmrb", False, 100, 200), ("dot", "balanced_wmrb", True, 256, 8)])
+def test_fused_wmrb_step_equals_unfused(pred, loss, biased, d, S):
+    """The one-pass WMRB step (csrc/wmrb_fused.hip) against the composed path (serial scores -> loss kernels -> autograd):
+    identical serial predictions (same arithmetic, d <= 128), loss vector and gradients equal up to summation order."""
+    inter, uf, itf = dummy(150, 333, seed=4)
+    inter = sp.csr_matrix(inter)
+    inter[7, :] = 0                                   # a user without interactions
+    inter.eliminate_zeros()
+    rng = np.random.RandomState(5)
+    tables = [O.sample_items(itf.shape[0], uf.shape[0], S, False, rng)[:, 1].reshape(uf.shape[0], S)]
+    caps = []
+    for fused in (1, 0):
+        T._native.set_tuning("wmrb_fused", fused)
+        try:
+            model = T.TensorRec(n_components=d, prediction_graph=PRED[pred](), loss_graph=LOSS[loss](), biased=biased,
+                                sampler=T.ReplaySampler(tables), seed=3)
+            model.build(uf.shape[1], itf.shape[1])
+            if biased:
+                w = model.get_weights()
+                r2 = np.random.default_rng(7)
+                w["user_feature_biases"] = (0.1 * r2.standard_normal(w["user_feature_biases"].shape)).astype(np.float32)
+                w["item_feature_biases"] = (0.1 * r2.standard_normal(w["item_feature_biases"].shape)).astype(np.float32)
+                model.set_weights(w)
+            model._capture = {}
+            model.fit_partial(inter, uf, itf, epochs=1, learning_rate=0.05, alpha=1e-4, n_sampled_items=S)
+            caps.append((model._capture, model.get_weights()))
+        finally:
+            T._native.set_tuning("wmrb_fused", 1)
+    (a, wa), (b, wb) = caps
+    assert np.allclose(a['loss'], b['loss'], rtol=1e-5, atol=1e-6)       # hinge sums: sequential vs lane-split order
+    if d <= 128:
+        assert np.array_equal(a['pred_serial'], b['pred_serial'])        # same arithmetic per pair
+    else:
+        assert np.allclose(a['pred_serial'], b['pred_serial'], rtol=1e-5, atol=1e-6)
+    gmax = max(np.abs(g).max() for g in b['grads'].values() if g is not None)
+    for k, gb in b['grads'].items():
+        if gb is None:
+            assert a['grads'][k] is None or not np.abs(a['grads'][k]).any(), k
+            continue
+        assert np.abs(a['grads'][k] - gb).max() <= 2e-5 * gmax, "%s: %g (gmax %g)" % (k, np.abs(a['grads'][k] - gb).max(), gmax)
+    for k in wa:
+        if k == "user_feature_biases":
+            continue                                  # zero-gradient weight under WMRB: Adam amplifies rounding noise
+        assert np.allclose(wa[k], wb[k], rtol=1e-3, atol=2e-3), k
+
+
+def test_fused_wmrb_falls_back_when_rows_do_not_fit():
+    """A user with more interactions than LDS can hold next to the samples -> the composed path runs (same results as
+    ever); custom WMRB subclasses are never fused."""
+    from tensorrec_amd import ops
+    from tensorrec_amd.sparse import Interactions
+    m = sp.csr_matrix(np.ones((3, 2600), np.float32))
+    inter = Interactions(m, 3, 2600, "cuda")
+    assert inter.max_row_nnz == 2600 and not ops.wmrb_fused_supported(40, inter, 64)
+    small = Interactions(sp.csr_matrix(np.ones((3, 20), np.float32)), 3, 2600, "cuda")
+    assert ops.wmrb_fused_supported(100, small, 128) and not ops.wmrb_fused_supported(300, small, 128)
+    assert not ops.wmrb_fused_supported(100, small, 130)
+
+    class MyWMRB(WMRBLossGraph):
+        calls = 0
+
+        def weighted_margin_rank_batch(self, **kw):
+            MyWMRB.calls += 1
+            return WMRBLossGraph.weighted_margin_rank_batch(self, **kw)
+
+    inter, uf, itf = dummy(40, 60, seed=1)
+    T.TensorRec(n_components=8, loss_graph=MyWMRB(), seed=0).fit(inter, uf, itf, epochs=2, n_sampled_items=5)
+    assert MyWMRB.calls == 2
