@@ -96,9 +96,12 @@ __global__ __launch_bounds__(256) void seg_fill_kernel(const int32_t* __restrict
 }
 
 // workspace_i32: 2 * n_items int32 (counts, cursors); workspace_i64: ceil(n_items/1024) + 1 int64
+// counts_given != 0: workspace_i32[0 .. n_items) already holds the histogram of xi (e.g. counted by the kernel that
+// consumed the pairs, trec_wmrb_fused_step) -- the histogram pass is skipped
 extern "C" int trec_group_pairs_by_item(const int32_t* xu, const int32_t* xi, int64_t n_pairs, int32_t pairs_per_user,
                                         int64_t n_items, int32_t* workspace_i32, int64_t* workspace_i64,
-                                        int64_t* indptr_t, int32_t* users_t, int32_t* perm_t, void* stream)
+                                        int64_t* indptr_t, int32_t* users_t, int32_t* perm_t, int32_t counts_given,
+                                        void* stream)
 {
     TREC_REQUIRE(xi && workspace_i32 && workspace_i64 && indptr_t && users_t && perm_t, "trec_group_pairs_by_item: null pointer");
     TREC_REQUIRE(xu || pairs_per_user >= 1, "trec_group_pairs_by_item: need xu or pairs_per_user");
@@ -109,14 +112,15 @@ extern "C" int trec_group_pairs_by_item(const int32_t* xu, const int32_t* xi, in
     const int n_blocks = (int)ceil_div64(n_items, 1024);
     int64_t* block_sum = workspace_i64;
     int64_t* total = workspace_i64 + n_blocks;
-    if (hipMemsetAsync(workspace_i32, 0, sizeof(int32_t) * 2 * (size_t)n_items, st) != hipSuccess) {
+    int32_t* zero_from = counts_given ? cursor : workspace_i32;
+    if (hipMemsetAsync(zero_from, 0, sizeof(int32_t) * (counts_given ? 1 : 2) * (size_t)n_items, st) != hipSuccess) {
         trec_set_last_error("trec_group_pairs_by_item: memset failed");
         return TREC_ERR_LAUNCH;
     }
     int64_t gb = ceil_div64(n_pairs, 256);
     if (gb > 8192) gb = 8192;
     if (gb < 1) gb = 1;
-    hipLaunchKernelGGL(seg_hist_kernel, dim3((unsigned)gb), dim3(256), 0, st, xi, n_pairs, counts);
+    if (!counts_given) hipLaunchKernelGGL(seg_hist_kernel, dim3((unsigned)gb), dim3(256), 0, st, xi, n_pairs, counts);
     hipLaunchKernelGGL(seg_scan_local_kernel, dim3((unsigned)n_blocks), dim3(256), 0, st, counts, n_items, indptr_t, block_sum);
     hipLaunchKernelGGL(seg_scan_blocks_kernel, dim3(1), dim3(256), 0, st, block_sum, n_blocks, total);
     hipLaunchKernelGGL(seg_add_offsets_kernel, dim3((unsigned)ceil_div64(n_items + 1, 256)), dim3(256), 0, st, indptr_t, n_items, block_sum, total);
