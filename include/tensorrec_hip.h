@@ -46,7 +46,8 @@ int trec_get_tuning(const char* name, int dflt);
  * non-NULL the value of entry j is values[val_perm[j]] (transposed operand of the backward pass:
  * dW = X^T . dOut is this same call on the transposed CSR).  epilogue: 0 none | 1 row L2-normalise
  * (representation_graphs.py:57; writes 1/norm to out_inv_norm if non-NULL) | 2 add col_bias[d] then ReLU
- * (representation_graphs.py:119-120).  accumulate != 0: out += result (epilogue must be 0).               */
+ * (representation_graphs.py:119-120) | 3 none, and out_inv_norm[r] = sum of the row's values (the bias gradient that
+ * accompanies a gradient gather).  accumulate != 0: out += result (and out_inv_norm += for epilogue 3); epilogue 0 / 3 only. */
 int trec_spmm_csr(const int64_t* indptr, const int32_t* indices, const float* values, const int32_t* val_perm,
                   int64_t n_rows, int64_t nnz, const float* W, int32_t d, const float* col_bias, int32_t epilogue,
                   int32_t accumulate, float* out, float* out_inv_norm, void* stream);

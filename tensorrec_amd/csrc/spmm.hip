@@ -23,7 +23,8 @@ __device__ __forceinline__ float subgroup_sum(float v, int lpr) {
     return v;
 }
 
-// EPI: 0 none | 1 row L2-normalise (writes inv norm) | 2 + col_bias, ReLU
+// EPI: 0 none | 1 row L2-normalise (writes inv norm) | 2 + col_bias, ReLU | 3 none, and the row sums of the VALUES go
+// to out_inv (the bias gradient that accompanies a gradient gather: g summed per row, for free)
 // NT: non-temporal output stores (rows are written once); NTL: non-temporal weight-row loads as well (embedding-style
 // gathers where every weight row is referenced about once, so caching it only evicts useful lines)
 template <int ITERS, int R, int EPI, bool NT = false, bool NTL = false>
@@ -47,6 +48,7 @@ __global__ __launch_bounds__(256) void spmm_csr_vec4_kernel(
     }
 
     f32x4 acc[R][ITERS];
+    float vsum[R];
     int64_t s[R], e[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -54,6 +56,7 @@ __global__ __launch_bounds__(256) void spmm_csr_vec4_kernel(
         const bool v = row < n_rows;
         s[r] = v ? indptr[row] : 0;
         e[r] = v ? indptr[row + 1] : 0;
+        vsum[r] = 0.f;
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
             acc[r][it] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -85,6 +88,7 @@ __global__ __launch_bounds__(256) void spmm_csr_vec4_kernel(
 #pragma unroll
     for (int r = 0; r < R; ++r)
         if (s[r] < e[r]) {
+            if (EPI == 3) vsum[r] += v0[r];
 #pragma unroll
             for (int it = 0; it < ITERS; ++it) {
                 acc[r][it].x = fmaf(v0[r], x0[r][it].x, acc[r][it].x);
@@ -101,6 +105,7 @@ __global__ __launch_bounds__(256) void spmm_csr_vec4_kernel(
             const int32_t ca = indices[j], cb = indices[j + 1];
             const float va = values[val_perm ? (int64_t)val_perm[j] : j];
             const float vb = values[val_perm ? (int64_t)val_perm[j + 1] : j + 1];
+            if (EPI == 3) { vsum[r] += va; vsum[r] += vb; }
             f32x4 xa[ITERS], xb[ITERS];
 #pragma unroll
             for (int it = 0; it < ITERS; ++it) {
@@ -121,6 +126,7 @@ __global__ __launch_bounds__(256) void spmm_csr_vec4_kernel(
         if (j < e[r]) {
             const int32_t ca = indices[j];
             const float va = values[val_perm ? (int64_t)val_perm[j] : j];
+            if (EPI == 3) vsum[r] += va;
 #pragma unroll
             for (int it = 0; it < ITERS; ++it)
                 if (cvalid[it]) {
@@ -149,6 +155,8 @@ __global__ __launch_bounds__(256) void spmm_csr_vec4_kernel(
 #pragma unroll
             for (int it = 0; it < ITERS; ++it) acc[r][it] *= inv;
             if (out_inv && sub_lane == 0) out_inv[row] = inv;
+        } else if (EPI == 3) {
+            if (out_inv && sub_lane == 0) out_inv[row] = accumulate ? out_inv[row] + vsum[r] : vsum[r];
         } else if (EPI == 2) {
 #pragma unroll
             for (int it = 0; it < ITERS; ++it)
@@ -277,7 +285,7 @@ __global__ __launch_bounds__(256) void spmv_csr_kernel(const int64_t* __restrict
 __global__ __launch_bounds__(256) void segsum_csr_kernel(const int64_t* __restrict__ indptr,
                                                         const float* __restrict__ values,
                                                         const int32_t* __restrict__ val_perm, int64_t n_rows,
-                                                        float* __restrict__ out)
+                                                        float* __restrict__ out, int accumulate = 0)
 {
     const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     if (row >= n_rows) return;
@@ -286,7 +294,7 @@ __global__ __launch_bounds__(256) void segsum_csr_kernel(const int64_t* __restri
     float acc = 0.f;
     for (int64_t j = b + sub; j < e; j += 16) acc += values[val_perm ? (int64_t)val_perm[j] : j];
     for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-    if (sub == 0) out[row] = acc;
+    if (sub == 0) out[row] = accumulate ? out[row] + acc : acc;
 }
 
 // dense[r, c] = X[r, c]  (tf.sparse_tensor_to_dense, representation_graphs.py:74); out pre-zeroed by caller
@@ -353,14 +361,16 @@ extern "C" int trec_spmm_csr(const int64_t* indptr, const int32_t* indices, cons
     TREC_REQUIRE(indptr && W && out, "trec_spmm_csr: null pointer");
     TREC_REQUIRE(nnz == 0 || (indices && values), "trec_spmm_csr: null indices/values with nnz != 0");
     TREC_REQUIRE(d >= 1 && n_rows >= 0, "trec_spmm_csr: bad sizes");
-    TREC_REQUIRE(epilogue >= 0 && epilogue <= 2, "trec_spmm_csr: epilogue must be 0, 1 or 2");
+    TREC_REQUIRE(epilogue >= 0 && epilogue <= 3, "trec_spmm_csr: epilogue must be 0, 1, 2 or 3");
     TREC_REQUIRE(epilogue != 2 || col_bias, "trec_spmm_csr: epilogue 2 needs col_bias");
-    TREC_REQUIRE(!(accumulate && epilogue), "trec_spmm_csr: accumulate cannot be combined with an epilogue");
+    TREC_REQUIRE(epilogue != 3 || out_inv_norm, "trec_spmm_csr: epilogue 3 needs the row-sum output");
+    TREC_REQUIRE(!(accumulate && (epilogue == 1 || epilogue == 2)), "trec_spmm_csr: accumulate cannot be combined with epilogue 1 / 2");
     if (n_rows == 0) return TREC_OK;
     hipStream_t st = (hipStream_t)stream;
     if (d % 4 == 0 && d <= 1024) {
         if (epilogue == 0) return launch_vec4<0>(indptr, indices, values, val_perm, n_rows, W, d, col_bias, accumulate, out, out_inv_norm, nnz, st);
         if (epilogue == 1) return launch_vec4<1>(indptr, indices, values, val_perm, n_rows, W, d, col_bias, accumulate, out, out_inv_norm, nnz, st);
+        if (epilogue == 3) return launch_vec4<3>(indptr, indices, values, val_perm, n_rows, W, d, col_bias, accumulate, out, out_inv_norm, nnz, st);
         return launch_vec4<2>(indptr, indices, values, val_perm, n_rows, W, d, col_bias, accumulate, out, out_inv_norm, nnz, st);
     }
     const int64_t total = n_rows * (int64_t)d;
@@ -372,6 +382,11 @@ extern "C" int trec_spmm_csr(const int64_t* indptr, const int32_t* indices, cons
         hipLaunchKernelGGL(row_l2norm_fwd_kernel, dim3((unsigned)ceil_div64(n_rows * 64, 256)), dim3(256), 0, st, out,
                            n_rows, d, out, out_inv_norm);
         return trec_check_launch("trec_spmm_csr(l2norm)");
+    }
+    if (epilogue == 3) {
+        hipLaunchKernelGGL(segsum_csr_kernel, dim3((unsigned)ceil_div64(n_rows * 16, 256)), dim3(256), 0, st, indptr, values,
+                           val_perm, n_rows, out_inv_norm, accumulate);
+        return trec_check_launch("trec_spmm_csr(row sums)");
     }
     if (epilogue == 2) {
         hipLaunchKernelGGL(bias_relu_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, st, out, col_bias,

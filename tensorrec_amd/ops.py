@@ -36,7 +36,7 @@ class _timed(object):
             KERNEL_EVENTS.append((self.name, self.s, self.e))
         return False
 MODE_DOT, MODE_EUCLIDEAN = 0, 1
-EPI_NONE, EPI_L2NORM, EPI_BIAS_RELU = 0, 1, 2
+EPI_NONE, EPI_L2NORM, EPI_BIAS_RELU, EPI_ROWSUM = 0, 1, 2, 3
 
 
 def _f32c(t):
@@ -499,21 +499,25 @@ def wmrb_fused_step(user_in, item_in, user_bias, item_bias, interactions, sample
     # ---- item side: d item_in = G^T . user_in over both pair lists, d b_i = per-item sums of the coefficients
     d_v = torch.zeros_like(v) if nnz == 0 else None
     d_ib = torch.zeros((n_items,), dtype=torch.float32, device=dev) if ib is not None else None
+    # (epilogue 3 of K1: the row sums of the gathered coefficients = d b_i come out of the same pass)
+    epi = EPI_ROWSUM if ib is not None else EPI_NONE
     if nnz:
         indptr_t, users_t, perm_t = interactions.transposed()
-        d_v = spmm_raw(indptr_t, users_t, coef_p, perm_t, n_items, nnz, u)
-        if ib is not None:
-            N.call("trec_spmv_csr", N.ptr(indptr_t), N.ptr(users_t), N.ptr(coef_p), N.ptr(perm_t), n_items, None,
-                   N.ptr(d_ib))
+        d_v = _spmm_rowsum(indptr_t, users_t, coef_p, perm_t, n_items, nnz, u, epi, False, None, d_ib)
     xs = samples.reshape(-1)
     ind_s, users_s, perm_s = group_pairs_by_item(None, xs, S, n_items, workspace_with_counts=ws32)
-    spmm_raw(ind_s, users_s, coef_s.reshape(-1), perm_s, n_items, n_users * S, u, accumulate=True, out=d_v)
-    if ib is not None:
-        part = torch.empty((n_items,), dtype=torch.float32, device=dev)
-        N.call("trec_spmv_csr", N.ptr(ind_s), N.ptr(users_s), N.ptr(coef_s.reshape(-1)), N.ptr(perm_s), n_items, None,
-               N.ptr(part))
-        d_ib += part
+    _spmm_rowsum(ind_s, users_s, coef_s.reshape(-1), perm_s, n_items, n_users * S, u, epi, True, d_v, d_ib)
     return loss, pred, d_u, d_v, d_ub, d_ib
+
+
+def _spmm_rowsum(indptr, indices, values, perm, n_rows, nnz, w, epilogue, accumulate, out, rowsum):
+    w = _f32c(w)
+    if out is None:
+        out = torch.empty((n_rows, w.shape[1]), dtype=torch.float32, device=w.device)
+    with _timed("spmm_csr"):
+        N.call("trec_spmm_csr", N.ptr(indptr), N.ptr(indices), N.ptr(values), N.ptr(perm), n_rows, nnz, N.ptr(w),
+               w.shape[1], None, epilogue, 1 if accumulate else 0, N.ptr(out), N.ptr(rowsum) if epilogue == EPI_ROWSUM else None)
+    return out
 
 
 def wmrb_loss(pred_serial, sample_pred, interactions, balanced=False):

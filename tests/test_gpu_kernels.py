@@ -109,6 +109,32 @@ def test_spmm_accumulate(ops):
     assert np.allclose(out.cpu().numpy(), base + O.spmm_exact(x, w), rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("d", [128, 6])
+def test_spmm_rowsum_epilogue(ops, d):
+    """epilogue 3: the gather result as epilogue 0 (bit-identical) plus the row sums of the (permuted) values, with and
+    without accumulation -- what the item-bias gradient rides on (vec4 path and scalar fallback)."""
+    from tensorrec_amd import _native as N
+    m = rand_csr(300, 90, 0.2, seed=d)
+    f = feats(m)
+    rng = np.random.default_rng(d)
+    w = dev(rng.standard_normal((90, d)).astype(np.float32))
+    perm = rng.permutation(m.nnz).astype(np.int32)
+    vals = rng.standard_normal(m.nnz).astype(np.float32)
+    dvals, dperm = dev(vals), dev(perm)                 # kept alive: N.ptr() takes raw pointers
+    base = ops.spmm_raw(f.indptr, f.indices, dvals, dperm, 300, m.nnz, w)
+    out = torch.empty_like(base)
+    rs = torch.empty((300,), dtype=torch.float32, device="cuda")
+    N.call("trec_spmm_csr", N.ptr(f.indptr), N.ptr(f.indices), N.ptr(dvals), N.ptr(dperm), 300, m.nnz, N.ptr(w), d,
+           None, 3, 0, N.ptr(out), N.ptr(rs))
+    assert torch.equal(out, base)
+    ref = np.array([vals[perm[m.indptr[r]:m.indptr[r + 1]]].astype(np.float64).sum() for r in range(300)])
+    assert np.allclose(rs.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+    N.call("trec_spmm_csr", N.ptr(f.indptr), N.ptr(f.indices), N.ptr(dvals), N.ptr(dperm), 300, m.nnz, N.ptr(w), d,
+           None, 3, 1, N.ptr(out), N.ptr(rs))
+    assert np.allclose(out.cpu().numpy(), 2 * base.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    assert np.allclose(rs.cpu().numpy(), 2 * ref, rtol=1e-5, atol=1e-5)
+
+
 def test_project_biases_golden(ops, goldens):
     g = goldens["project_biases"]
     f = feats(g["features"])
