@@ -16,14 +16,29 @@
 // predictions, dU, d b_u.
 //
 // The upstream gradient is the constant 1 (the trainer differentiates the SUM of the loss vector); that is what makes
-// the coefficients computable in the same pass.  Arithmetic per pair is that of pair_score_fwd_kernel (one fmaf chain
-// per lane over its columns, xor-butterfly; identical for d <= 128), so the serial predictions are bit-identical to the
-// unfused path there; hinge sums run sequentially over the samples (no cross-lane reduction at all), so losses and
-// gradients differ from the unfused kernels by summation order only.
+// the coefficients computable in the same pass.  Per pair: one fmaf chain per lane over its columns as in
+// pair_score_fwd_kernel, then DPP rotations instead of the xor-butterfly; hinge sums run sequentially over the samples
+// (no cross-lane reduction at all) -- predictions, losses and gradients equal the unfused kernels' up to summation order.
 #include "common.hpp"
 #include <math.h>
 
 namespace {
+
+// sum over the 32 lanes of a subgroup with DPP adds (one VALU instruction each, no LDS crossbar): four rotations
+// inside the 16-lane rows, then row_bcast15 carries row 0's total into row 1 -- the full sum is valid in lanes 16..31
+// of the subgroup (read it from lane 31).  ds_bpermute-based __shfl_xor costs ~5x more issue slots and latency here.
+__device__ __forceinline__ float dpp_add(float x, const int ctrl_tag)
+{
+    int v = __float_as_int(x), r;
+    switch (ctrl_tag) {
+        case 8: r = __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, false); break;    // row_ror:8
+        case 4: r = __builtin_amdgcn_update_dpp(0, v, 0x124, 0xf, 0xf, false); break;    // row_ror:4
+        case 2: r = __builtin_amdgcn_update_dpp(0, v, 0x122, 0xf, 0xf, false); break;    // row_ror:2
+        case 1: r = __builtin_amdgcn_update_dpp(0, v, 0x121, 0xf, 0xf, false); break;    // row_ror:1
+        default: r = __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false); break;   // row_bcast15 into rows 1, 3
+    }
+    return x + __int_as_float(r);
+}
 
 constexpr int SR = 4;                 // sample registers per lane in the loss phase: S <= 256
 
@@ -118,10 +133,12 @@ __global__ __launch_bounds__(256, (ITERS == 1 && RMAX == 16) ? 4 : 1) void wmrb_
         dot[r] = acc;
     }
 #pragma unroll
-    for (int off = 16; off > 0; off >>= 1)
-#pragma unroll
-        for (int r = 0; r < RMAX; ++r) dot[r] += __shfl_xor(dot[r], off, 64);
-    if (sub == 0) {
+    for (int r = 0; r < RMAX; ++r) {
+        float t = dot[r];
+        t = dpp_add(t, 8); t = dpp_add(t, 4); t = dpp_add(t, 2); t = dpp_add(t, 1);
+        dot[r] = dpp_add(t, 0);                            // lanes 16..31 of the subgroup: the 32-lane total
+    }
+    if (sub == 31) {
 #pragma unroll
         for (int r = 0; r < RMAX; ++r) {
             const int j = sg + 8 * r;

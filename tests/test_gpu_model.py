@@ -386,7 +386,7 @@ def test_fit_from_tfrecords_and_datasets(tmp_path):
                                                   ("dot", "wmrb", False, 100, 200), ("dot", "balanced_wmrb", True, 256, 8)])
 def test_fused_wmrb_step_equals_unfused(pred, loss, biased, d, S):
     """The one-pass WMRB step (csrc/wmrb_fused.hip) against the composed path (serial scores -> loss kernels -> autograd):
-    identical serial predictions (same arithmetic, d <= 128), loss vector and gradients equal up to summation order."""
+    serial predictions, loss vector and gradients equal up to summation order."""
     inter, uf, itf = dummy(150, 333, seed=4)
     inter = sp.csr_matrix(inter)
     inter[7, :] = 0                                   # a user without interactions
@@ -413,10 +413,7 @@ def test_fused_wmrb_step_equals_unfused(pred, loss, biased, d, S):
             T._native.set_tuning("wmrb_fused", 1)
     (a, wa), (b, wb) = caps
     assert np.allclose(a['loss'], b['loss'], rtol=1e-5, atol=1e-6)       # hinge sums: sequential vs lane-split order
-    if d <= 128:
-        assert np.array_equal(a['pred_serial'], b['pred_serial'])        # same arithmetic per pair
-    else:
-        assert np.allclose(a['pred_serial'], b['pred_serial'], rtol=1e-5, atol=1e-6)
+    assert np.allclose(a['pred_serial'], b['pred_serial'], rtol=1e-5, atol=1e-6)    # DPP rotations vs xor butterfly
     gmax = max(np.abs(g).max() for g in b['grads'].values() if g is not None)
     for k, gb in b['grads'].items():
         if gb is None:
