@@ -153,10 +153,13 @@ int trec_pair_score_bwd(const float* U, const float* V, const int32_t* xu, const
  * users_t[n_pairs], perm_t[n_pairs]) so that the item-side gradient of sampled serial predictions is the trec_spmm_csr
  * segmented gather (values = grad, val_perm = perm_t, indices = users_t) instead of atomics.
  * workspace_i32: 2*n_items int32; workspace_i64: ceil(n_items/1024)+1 int64.  counts_given != 0: the first n_items
- * entries of workspace_i32 already hold the histogram of xi (trec_wmrb_fused_step counts it while it gathers). */
+ * entries of workspace_i32 already hold the histogram of xi (trec_wmrb_fused_step counts it while it gathers);
+ * ranks (nullable, with counts_given): what those histogram atomics returned, i.e. every pair's position inside its
+ * bucket -- the fill pass then needs no atomics. */
 int trec_group_pairs_by_item(const int32_t* xu, const int32_t* xi, int64_t n_pairs, int32_t pairs_per_user,
                              int64_t n_items, int32_t* workspace_i32, int64_t* workspace_i64, int64_t* indptr_t,
-                             int32_t* users_t, int32_t* perm_t, int32_t counts_given, void* stream);
+                             int32_t* users_t, int32_t* perm_t, int32_t counts_given, const int32_t* ranks,
+                             void* stream);
 
 /* ---- K4: ranks ----------------------------------------------------------------------------------------------
  * rank_predictions, recommendation_graphs.py:73-82 (double tf.nn.top_k) as an exact count; int32, 1 = best. */
@@ -187,7 +190,8 @@ int trec_wmrb_bwd(const int64_t* indptr, const int32_t* pos_slot, const float* p
  * dU [n_users, d], d_user_bias [n_users] (NULL iff user_bias is NULL), coef_samples [n_users, n_sampled] and
  * coef_pairs [n_interactions] = d(sum loss)/d(prediction) per pair -- the values of the item-side gathers
  * (trec_group_pairs_by_item + trec_spmm_csr) and item-bias segment sums.  sample_hist (nullable, int32 [n_items],
- * zeroed by the caller): += the number of times every item was sampled -- the histogram pass of the counting sort.
+ * zeroed by the caller): += the number of times every item was sampled -- the histogram pass of the counting sort;
+ * sample_rank (nullable, int32 [n_users, n_sampled]): the value each of those atomics returned (rank inside the bucket).
  * trec_wmrb_fused_lds_bytes: dynamic LDS the launch needs, or -1 if (n_sampled <= 256, d % 4 == 0, d <= 256,
  * n_sampled + max interactions per user <= 256 rows, 128 for d > 128) does not hold -- then run the unfused kernels.   */
 int trec_wmrb_fused_lds_bytes(int32_t n_sampled, int32_t max_interactions_per_user, int32_t d);
@@ -195,7 +199,8 @@ int trec_wmrb_fused_step(const float* U, const float* V, const float* user_bias,
                          const int64_t* indptr, const int32_t* x_item, const int32_t* pos_slot, const float* pos_weight,
                          const int32_t* samples, int64_t n_users, int64_t n_items, int32_t n_sampled, int32_t d,
                          int32_t max_interactions_per_user, float* loss, float* pred_serial, float* dU,
-                         float* d_user_bias, float* coef_samples, float* coef_pairs, int32_t* sample_hist, void* stream);
+                         float* d_user_bias, float* coef_samples, float* coef_pairs, int32_t* sample_hist,
+                         int32_t* sample_rank, void* stream);
 /* RMSE, loss_graphs.py:58-59 */
 int trec_rmse_fwd(const float* y, const float* pred, int64_t n, float* partial_ws, int32_t n_partial, float* loss,
                   void* stream);

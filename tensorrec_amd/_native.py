@@ -54,14 +54,14 @@ SIGNATURES = {
     "trec_topk_merge": [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp],
     "trec_pair_score_fwd": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
     "trec_pair_score_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
-    "trec_group_pairs_by_item": [_vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _vp],
+    "trec_group_pairs_by_item": [_vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp],
     "trec_rank_rows": [_vp, _i64, _i64, _i64, _vp, _i64, _vp],
     "trec_rank_of_pairs": [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _i32, _vp, _vp],
     "trec_wmrb_fwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp],
     "trec_wmrb_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp],
     "trec_wmrb_fused_lds_bytes": [_i32, _i32, _i32],
     "trec_wmrb_fused_step": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp,
-                             _vp, _vp, _vp, _vp],
+                             _vp, _vp, _vp, _vp, _vp],
     "trec_rmse_fwd": [_vp, _vp, _i64, _vp, _i32, _vp, _vp],
     "trec_rmse_bwd": [_vp, _vp, _vp, _vp, _i64, _vp, _vp],
     "trec_sample_items": [_i64, _i64, _i32, _i32, _i32, _u64, _u32, _vp, _vp],

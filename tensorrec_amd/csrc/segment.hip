@@ -95,17 +95,32 @@ __global__ __launch_bounds__(256) void seg_fill_kernel(const int32_t* __restrict
     }
 }
 
+// atomic-free fill: the rank of every pair inside its bucket is already known (returned by the histogram atomics)
+__global__ __launch_bounds__(256) void seg_fill_ranked_kernel(const int32_t* __restrict__ xu, const int32_t* __restrict__ xi,
+                                                             const int32_t* __restrict__ ranks, int64_t n_pairs,
+                                                             int32_t pairs_per_user, const int64_t* __restrict__ indptr,
+                                                             int32_t* __restrict__ users_t, int32_t* __restrict__ perm_t)
+{
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < n_pairs; p += (int64_t)gridDim.x * 256) {
+        const int64_t slot = indptr[xi[p]] + ranks[p];
+        users_t[slot] = xu ? xu[p] : (int32_t)(p / pairs_per_user);
+        perm_t[slot] = (int32_t)p;
+    }
+}
+
 // workspace_i32: 2 * n_items int32 (counts, cursors); workspace_i64: ceil(n_items/1024) + 1 int64
 // counts_given != 0: workspace_i32[0 .. n_items) already holds the histogram of xi (e.g. counted by the kernel that
-// consumed the pairs, trec_wmrb_fused_step) -- the histogram pass is skipped
+// consumed the pairs, trec_wmrb_fused_step) -- the histogram pass is skipped; ranks (nullable, needs counts_given):
+// the value each of those histogram atomics returned = the pair's position inside its bucket -- the fill is atomic-free
 extern "C" int trec_group_pairs_by_item(const int32_t* xu, const int32_t* xi, int64_t n_pairs, int32_t pairs_per_user,
                                         int64_t n_items, int32_t* workspace_i32, int64_t* workspace_i64,
                                         int64_t* indptr_t, int32_t* users_t, int32_t* perm_t, int32_t counts_given,
-                                        void* stream)
+                                        const int32_t* ranks, void* stream)
 {
     TREC_REQUIRE(xi && workspace_i32 && workspace_i64 && indptr_t && users_t && perm_t, "trec_group_pairs_by_item: null pointer");
     TREC_REQUIRE(xu || pairs_per_user >= 1, "trec_group_pairs_by_item: need xu or pairs_per_user");
     TREC_REQUIRE(n_pairs < ((int64_t)1 << 31) && n_items >= 1, "trec_group_pairs_by_item: n_pairs must fit int32");
+    TREC_REQUIRE(!ranks || counts_given, "trec_group_pairs_by_item: ranks come with counts_given");
     hipStream_t st = (hipStream_t)stream;
     int32_t* counts = workspace_i32;
     int32_t* cursor = workspace_i32 + n_items;
@@ -124,7 +139,10 @@ extern "C" int trec_group_pairs_by_item(const int32_t* xu, const int32_t* xi, in
     hipLaunchKernelGGL(seg_scan_local_kernel, dim3((unsigned)n_blocks), dim3(256), 0, st, counts, n_items, indptr_t, block_sum);
     hipLaunchKernelGGL(seg_scan_blocks_kernel, dim3(1), dim3(256), 0, st, block_sum, n_blocks, total);
     hipLaunchKernelGGL(seg_add_offsets_kernel, dim3((unsigned)ceil_div64(n_items + 1, 256)), dim3(256), 0, st, indptr_t, n_items, block_sum, total);
-    hipLaunchKernelGGL(seg_fill_kernel, dim3((unsigned)gb), dim3(256), 0, st, xu, xi, n_pairs, pairs_per_user, indptr_t, cursor, users_t, perm_t);
+    if (ranks)
+        hipLaunchKernelGGL(seg_fill_ranked_kernel, dim3((unsigned)gb), dim3(256), 0, st, xu, xi, ranks, n_pairs, pairs_per_user, indptr_t, users_t, perm_t);
+    else
+        hipLaunchKernelGGL(seg_fill_kernel, dim3((unsigned)gb), dim3(256), 0, st, xu, xi, n_pairs, pairs_per_user, indptr_t, cursor, users_t, perm_t);
     return trec_check_launch("trec_group_pairs_by_item");
 }
 

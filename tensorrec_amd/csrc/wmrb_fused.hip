@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256, (ITERS == 1 && RMAX == 16) ? 4 : 1) void wmrb_
     const float* __restrict__ pos_weight, const int32_t* __restrict__ samples, int64_t n_users, int32_t S, int d,
     float ratio, int32_t max_rows, float* __restrict__ loss, float* __restrict__ pred_serial, float* __restrict__ dU,
     float* __restrict__ dub, float* __restrict__ coef_samples, float* __restrict__ coef_pairs,
-    int32_t* __restrict__ sample_hist)
+    int32_t* __restrict__ sample_hist, int32_t* __restrict__ sample_rank)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // y [max_rows4] | coef [max_rows4] | c [max_rows4] | base [max_rows4] | tmp [16 * max_rows4] | partial dU [8][d]
@@ -75,7 +75,10 @@ __global__ __launch_bounds__(256, (ITERS == 1 && RMAX == 16) ? 4 : 1) void wmrb_
         // no interactions: no loss terms, every coefficient is 0 (the samples of this user are never used)
         for (int s = tid; s < S; s += 256) {
             coef_samples[u * S + s] = 0.f;
-            if (sample_hist) atomicAdd(sample_hist + samples[u * S + s], 1);     // the sort still sees these pairs
+            if (sample_hist) {                                                   // the sort still sees these pairs
+                const int32_t rk = atomicAdd(sample_hist + samples[u * S + s], 1);
+                if (sample_rank) sample_rank[u * S + s] = rk;
+            }
         }
         for (int c = tid; c < d; c += 256) dU[u * d + c] = 0.f;
         if (dub && tid == 0) dub[u] = 0.f;
@@ -114,10 +117,19 @@ __global__ __launch_bounds__(256, (ITERS == 1 && RMAX == 16) ? 4 : 1) void wmrb_
                                                  : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
     }
-    if (sample_hist && sub == 0) {                        // histogram of the counting sort to come: fire and forget
+    if (sample_hist && sub == 0) {
+        // histogram of the counting sort to come; the value each atomic returns is the pair's rank inside its item's
+        // bucket, which makes the sort's fill pass atomic-free (issued after the row loads, consumed before the dots)
+        int32_t rk[RMAX];
 #pragma unroll
         for (int r = 0; r < RMAX; ++r)
-            if (sg + 8 * r < S) __hip_atomic_fetch_add(sample_hist + item[r], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            rk[r] = (sg + 8 * r < S) ? __hip_atomic_fetch_add(sample_hist + item[r], 1, __ATOMIC_RELAXED,
+                                                               __HIP_MEMORY_SCOPE_AGENT) : 0;
+        if (sample_rank) {
+#pragma unroll
+            for (int r = 0; r < RMAX; ++r)
+                if (sg + 8 * r < S) sample_rank[u * S + sg + 8 * r] = rk[r];
+        }
     }
     // predictions: no per-row branch (a wave holds two subgroups with different rows), so the RMAX reduction chains
     // interleave; rows past R are zeros and are simply not written
@@ -268,11 +280,12 @@ extern "C" int trec_wmrb_fused_step(const float* U, const float* V, const float*
                                     const float* pos_weight, const int32_t* samples, int64_t n_users, int64_t n_items,
                                     int32_t n_sampled, int32_t d, int32_t max_interactions_per_user, float* loss,
                                     float* pred_serial, float* dU, float* d_user_bias, float* coef_samples,
-                                    float* coef_pairs, int32_t* sample_hist, void* stream)
+                                    float* coef_pairs, int32_t* sample_hist, int32_t* sample_rank, void* stream)
 {
     TREC_REQUIRE(U && V && indptr && samples && loss && pred_serial && dU && coef_samples && coef_pairs,
                  "trec_wmrb_fused_step: null pointer");
     TREC_REQUIRE(!user_bias == !d_user_bias, "trec_wmrb_fused_step: user_bias and d_user_bias go together");
+    TREC_REQUIRE(sample_hist || !sample_rank, "trec_wmrb_fused_step: sample_rank needs sample_hist");
     const int lds = trec_wmrb_fused_lds_bytes(n_sampled, max_interactions_per_user, d);
     if (lds < 0) {
         trec_set_last_error("trec_wmrb_fused_step: configuration not covered (see trec_wmrb_fused_lds_bytes)");
@@ -286,7 +299,7 @@ extern "C" int trec_wmrb_fused_step(const float* U, const float* V, const float*
 #define TREC_FUSED(IT, RM)                                                                                             \
     hipLaunchKernelGGL((wmrb_user_fused_kernel<IT, RM>), dim3((unsigned)n_users), dim3(256), lds, st, U, V, user_bias,  \
                        item_bias, indptr, x_item, pos_slot, pos_weight, samples, n_users, n_sampled, d, ratio, max_rows, \
-                       loss, pred_serial, dU, d_user_bias, coef_samples, coef_pairs, sample_hist)
+                       loss, pred_serial, dU, d_user_bias, coef_samples, coef_pairs, sample_hist, sample_rank)
     if (d <= 128 && max_rows <= 128) TREC_FUSED(1, 16);
     else if (d <= 128) TREC_FUSED(1, 32);
     else TREC_FUSED(2, 16);

@@ -284,11 +284,12 @@ class _PairScore(torch.autograd.Function):
         return du, dv, dub, dib, None, None, None, None, None
 
 
-def group_pairs_by_item(xu32, xi32, pairs_per_user, n_items, workspace_with_counts=None):
+def group_pairs_by_item(xu32, xi32, pairs_per_user, n_items, workspace_with_counts=None, ranks=None):
     """(indptr_t int64 [n_items+1], users_t int32 [n_pairs], perm_t int32 [n_pairs]) for a pair list, built on the
     device; the order of pairs inside an item's bucket is not fixed (atomic slot assignment).
     ``workspace_with_counts``: an int32 [2 * n_items] workspace whose first half already holds the histogram of the
-    items (counted by the kernel that consumed the pairs) -- the histogram pass is then skipped."""
+    items (counted by the kernel that consumed the pairs) -- the histogram pass is then skipped; ``ranks`` (with it): the
+    values those histogram atomics returned, which makes the fill pass atomic-free."""
     dev = xi32.device
     n_pairs = xi32.numel()
     ws32 = workspace_with_counts if workspace_with_counts is not None else \
@@ -298,7 +299,8 @@ def group_pairs_by_item(xu32, xi32, pairs_per_user, n_items, workspace_with_coun
     users_t = torch.empty((n_pairs,), dtype=torch.int32, device=dev)
     perm_t = torch.empty((n_pairs,), dtype=torch.int32, device=dev)
     N.call("trec_group_pairs_by_item", N.ptr(xu32), N.ptr(xi32), n_pairs, pairs_per_user, n_items, N.ptr(ws32),
-           N.ptr(ws64), N.ptr(indptr_t), N.ptr(users_t), N.ptr(perm_t), 1 if workspace_with_counts is not None else 0)
+           N.ptr(ws64), N.ptr(indptr_t), N.ptr(users_t), N.ptr(perm_t), 1 if workspace_with_counts is not None else 0,
+           N.ptr(ranks))
     return indptr_t, users_t, perm_t
 
 
@@ -491,11 +493,12 @@ def wmrb_fused_step(user_in, item_in, user_bias, item_bias, interactions, sample
     weight = interactions.balanced_weight() if balanced else None
     samples = samples.to(torch.int32).contiguous()
     ws32 = torch.zeros((2 * n_items,), dtype=torch.int32, device=dev)     # [sample histogram | cursors] of the sort below
+    ranks = torch.empty((n_users, S), dtype=torch.int32, device=dev)
     with _timed("wmrb_fused_step"):
         N.call("trec_wmrb_fused_step", N.ptr(u), N.ptr(v), N.ptr(ub), N.ptr(ib), N.ptr(interactions.indptr),
                N.ptr(interactions.x_item32), N.ptr(interactions.pos_slot), N.ptr(weight), N.ptr(samples), n_users,
                n_items, S, d, int(interactions.max_row_nnz), N.ptr(loss), N.ptr(pred), N.ptr(d_u), N.ptr(d_ub),
-               N.ptr(coef_s), N.ptr(coef_p), N.ptr(ws32))
+               N.ptr(coef_s), N.ptr(coef_p), N.ptr(ws32), N.ptr(ranks))
     # ---- item side: d item_in = G^T . user_in over both pair lists, d b_i = per-item sums of the coefficients
     d_v = torch.zeros_like(v) if nnz == 0 else None
     d_ib = torch.zeros((n_items,), dtype=torch.float32, device=dev) if ib is not None else None
@@ -505,7 +508,7 @@ def wmrb_fused_step(user_in, item_in, user_bias, item_bias, interactions, sample
         indptr_t, users_t, perm_t = interactions.transposed()
         d_v = _spmm_rowsum(indptr_t, users_t, coef_p, perm_t, n_items, nnz, u, epi, False, None, d_ib)
     xs = samples.reshape(-1)
-    ind_s, users_s, perm_s = group_pairs_by_item(None, xs, S, n_items, workspace_with_counts=ws32)
+    ind_s, users_s, perm_s = group_pairs_by_item(None, xs, S, n_items, workspace_with_counts=ws32, ranks=ranks.reshape(-1))
     _spmm_rowsum(ind_s, users_s, coef_s.reshape(-1), perm_s, n_items, n_users * S, u, epi, True, d_v, d_ib)
     return loss, pred, d_u, d_v, d_ub, d_ib
 
