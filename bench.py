@@ -214,7 +214,7 @@ def main():
             else:
                 # item shards share ONE top-k floor per user (all-gather of k superblock maxima) before re-scoring
                 vals, idx = ops.score_topk_two_stage(u_op, i_op, dtype, kpad, k, ub, ib, item_index_base=i_begin,
-                                                     variant=args.variant,
+                                                     variant=args.variant, n_chunks=args.chunks if args.chunks > 0 else None,
                                                      floor_exchange=sharding.shared_topk_floor if world > 1 else None)
             if world > 1:
                 vals, idx = sharding.sharded_top_k(vals, idx, k)                                          # 1 all-gather
