@@ -461,8 +461,9 @@ class TensorRec(object):
             # serial scores -> loss -> autograd; only the exact built-in classes qualify (subclasses may override)
             fused = (engine and not multi and graph.engine_mode == ops.MODE_DOT
                      and type(loss_graph) in (WMRBLossGraph, BalancedWMRBLossGraph)
-                     and n_sampled_items is not None
-                     and ops.wmrb_fused_supported(n_sampled_items, inter, self.n_components))
+                     and n_sampled_items is not None and item_repr.dim() == 2 and user_reprs[0].dim() == 2
+                     and user_reprs[0].shape[1] == item_repr.shape[1]
+                     and ops.wmrb_fused_supported(n_sampled_items, inter, int(item_repr.shape[1])))
             u_ins, a_ins, i_in = user_reprs, attn_reprs, item_repr
             if engine and graph.engine_normalize:     # cosine: normalise once, share between all serial calls
                 u_ins = [ops.l2_normalize_rows(u) for u in user_reprs]
