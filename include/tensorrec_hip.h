@@ -112,7 +112,7 @@ int trec_score_gemm_blockmax(const void* users, const void* items, int32_t dtype
                              float* blockmax, int64_t bm_stride, int32_t variant, void* stream);
 /* tau (nullable) [n_users]: the k-th largest superblock maximum = a floor of the final k-th best score;
  * sel_max (nullable) [k, n_users]: the maxima of the selected superblocks, in the blockmax layout.
- * trec_topk_group_keys: keys[i] = sel[i], or the dummy bucket n_sb for empty slots and -- when floor [n_users] is given
+ * trec_topk_group_keys: keys[i] = sel[i], or -1 (skipped by trec_group_pairs_by_item) for empty slots and -- when floor [n_users] is given
  * -- for superblocks with sel_max < floor[i / k].  With item shards the floor is the k-th largest superblock maximum
  * over ALL shards: all-gather the ranks' sel_max ([world * k, n_users] IS a blockmax table) and run
  * trec_topk_select_blocks on it; re-scoring then totals ~k superblocks per user over all shards instead of k per shard. */
@@ -149,7 +149,7 @@ int trec_pair_score_bwd(const float* U, const float* V, const int32_t* xu, const
                         int64_t n_pairs, int32_t pairs_per_user, int32_t d, int32_t mode, float* dU, float* dV,
                         float* d_user_bias, float* d_item_bias, void* stream);
 
-/* Group a pair list by item (counting sort on the device): writes the transposed structure (indptr_t[n_items+1],
+/* Group a pair list by item (counting sort on the device; pairs with a negative item are skipped): writes the transposed structure (indptr_t[n_items+1],
  * users_t[n_pairs], perm_t[n_pairs]) so that the item-side gradient of sampled serial predictions is the trec_spmm_csr
  * segmented gather (values = grad, val_perm = perm_t, indices = users_t) instead of atomics.
  * workspace_i32: 2*n_items int32; workspace_i64: ceil(n_items/1024)+1 int64.  counts_given != 0: the first n_items

@@ -4,6 +4,9 @@
 // (the scatter-add TF's autodiff emits for tf.gather, tensorrec/prediction_graphs.py:53-54 applied to the U*S sampled
 // pairs of tensorrec/tensorrec.py:390-395) becomes the K1 segmented gather instead of n_pairs * d fp32 atomics.
 //
+// Pairs with a NEGATIVE item key belong to no bucket and are skipped (the two-stage top-k drops pruned (user, superblock)
+// pairs this way: routing millions of them into one dummy bucket would serialise on a single atomic counter).
+//
 // Three passes: histogram of items (int32 atomics, one per pair), exclusive scan (two-level, 1024 items per block),
 // fill (one int32 atomic per pair for the slot inside its bucket).  The order of pairs INSIDE a bucket depends on
 // atomic arrival order, so the fp32 sums downstream are reproducible only up to summation order (as with atomics).
@@ -12,8 +15,10 @@
 __global__ __launch_bounds__(256) void seg_hist_kernel(const int32_t* __restrict__ xi, int64_t n_pairs,
                                                       int32_t* __restrict__ counts)
 {
-    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < n_pairs; p += (int64_t)gridDim.x * 256)
-        atomicAdd(counts + xi[p], 1);
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < n_pairs; p += (int64_t)gridDim.x * 256) {
+        const int32_t i = xi[p];
+        if (i >= 0) atomicAdd(counts + i, 1);            // negative key = "not in any bucket" (dropped pair)
+    }
 }
 
 // block b scans counts[b*1024 .. +1024) -> local exclusive prefix (int64) into indptr, block total into block_sum[b]
@@ -89,7 +94,64 @@ __global__ __launch_bounds__(256) void seg_fill_kernel(const int32_t* __restrict
 {
     for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < n_pairs; p += (int64_t)gridDim.x * 256) {
         const int32_t i = xi[p];
+        if (i < 0) continue;
         const int64_t slot = indptr[i] + atomicAdd(cursor + i, 1);
+        users_t[slot] = xu ? xu[p] : (int32_t)(p / pairs_per_user);
+        perm_t[slot] = (int32_t)p;
+    }
+}
+
+// ---- few buckets (<= SEG_SMALL_MAX): privatised counters ------------------------------------------------------------
+// The two-stage top-k groups ~10 M (user, superblock) pairs into a few hundred to a few thousand superblocks: global
+// atomics would queue thousands deep on each counter.  Every workgroup takes a contiguous run of SEG_SMALL_RUN pairs,
+// counts it in LDS, and touches each global counter once (histogram: add its count; fill: reserve its range), so the
+// global traffic is (runs x buckets) instead of one contended atomic per pair.
+#define SEG_SMALL_MAX 4096
+#define SEG_SMALL_RUN 8192
+
+__global__ __launch_bounds__(256) void seg_hist_small_kernel(const int32_t* __restrict__ xi, int64_t n_pairs,
+                                                            int32_t n_items, int32_t* __restrict__ counts)
+{
+    __shared__ int32_t l_cnt[SEG_SMALL_MAX];
+    for (int i = threadIdx.x; i < n_items; i += 256) l_cnt[i] = 0;
+    __syncthreads();
+    const int64_t p0 = (int64_t)blockIdx.x * SEG_SMALL_RUN;
+    const int64_t p1 = (p0 + SEG_SMALL_RUN < n_pairs) ? p0 + SEG_SMALL_RUN : n_pairs;
+    for (int64_t p = p0 + threadIdx.x; p < p1; p += 256) {
+        const int32_t i = xi[p];
+        if (i >= 0) atomicAdd(l_cnt + i, 1);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_items; i += 256)
+        if (l_cnt[i]) atomicAdd(counts + i, l_cnt[i]);
+}
+
+__global__ __launch_bounds__(256) void seg_fill_small_kernel(const int32_t* __restrict__ xu, const int32_t* __restrict__ xi,
+                                                            int64_t n_pairs, int32_t pairs_per_user, int32_t n_items,
+                                                            const int64_t* __restrict__ indptr, int32_t* __restrict__ cursor,
+                                                            int32_t* __restrict__ users_t, int32_t* __restrict__ perm_t)
+{
+    __shared__ int32_t l_cnt[SEG_SMALL_MAX];        // pass 1: count of the run per bucket; pass 2: next local rank
+    __shared__ int32_t l_base[SEG_SMALL_MAX];       // start of this run's range inside the bucket
+    for (int i = threadIdx.x; i < n_items; i += 256) l_cnt[i] = 0;
+    __syncthreads();
+    const int64_t p0 = (int64_t)blockIdx.x * SEG_SMALL_RUN;
+    const int64_t p1 = (p0 + SEG_SMALL_RUN < n_pairs) ? p0 + SEG_SMALL_RUN : n_pairs;
+    for (int64_t p = p0 + threadIdx.x; p < p1; p += 256) {
+        const int32_t i = xi[p];
+        if (i >= 0) atomicAdd(l_cnt + i, 1);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_items; i += 256) {
+        const int32_t c = l_cnt[i];
+        l_base[i] = c ? atomicAdd(cursor + i, c) : 0;
+        l_cnt[i] = 0;
+    }
+    __syncthreads();
+    for (int64_t p = p0 + threadIdx.x; p < p1; p += 256) {
+        const int32_t i = xi[p];
+        if (i < 0) continue;
+        const int64_t slot = indptr[i] + l_base[i] + atomicAdd(l_cnt + i, 1);
         users_t[slot] = xu ? xu[p] : (int32_t)(p / pairs_per_user);
         perm_t[slot] = (int32_t)p;
     }
@@ -102,6 +164,7 @@ __global__ __launch_bounds__(256) void seg_fill_ranked_kernel(const int32_t* __r
                                                              int32_t* __restrict__ users_t, int32_t* __restrict__ perm_t)
 {
     for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < n_pairs; p += (int64_t)gridDim.x * 256) {
+        if (xi[p] < 0) continue;
         const int64_t slot = indptr[xi[p]] + ranks[p];
         users_t[slot] = xu ? xu[p] : (int32_t)(p / pairs_per_user);
         perm_t[slot] = (int32_t)p;
@@ -135,11 +198,18 @@ extern "C" int trec_group_pairs_by_item(const int32_t* xu, const int32_t* xi, in
     int64_t gb = ceil_div64(n_pairs, 256);
     if (gb > 8192) gb = 8192;
     if (gb < 1) gb = 1;
-    if (!counts_given) hipLaunchKernelGGL(seg_hist_kernel, dim3((unsigned)gb), dim3(256), 0, st, xi, n_pairs, counts);
+    const bool small = n_items <= SEG_SMALL_MAX && n_pairs >= 4 * SEG_SMALL_RUN;
+    const unsigned runs = (unsigned)ceil_div64(n_pairs, SEG_SMALL_RUN);
+    if (!counts_given) {
+        if (small) hipLaunchKernelGGL(seg_hist_small_kernel, dim3(runs), dim3(256), 0, st, xi, n_pairs, (int32_t)n_items, counts);
+        else hipLaunchKernelGGL(seg_hist_kernel, dim3((unsigned)gb), dim3(256), 0, st, xi, n_pairs, counts);
+    }
     hipLaunchKernelGGL(seg_scan_local_kernel, dim3((unsigned)n_blocks), dim3(256), 0, st, counts, n_items, indptr_t, block_sum);
     hipLaunchKernelGGL(seg_scan_blocks_kernel, dim3(1), dim3(256), 0, st, block_sum, n_blocks, total);
     hipLaunchKernelGGL(seg_add_offsets_kernel, dim3((unsigned)ceil_div64(n_items + 1, 256)), dim3(256), 0, st, indptr_t, n_items, block_sum, total);
-    if (ranks)
+    if (small && !ranks)
+        hipLaunchKernelGGL(seg_fill_small_kernel, dim3(runs), dim3(256), 0, st, xu, xi, n_pairs, pairs_per_user, (int32_t)n_items, indptr_t, cursor, users_t, perm_t);
+    else if (ranks)
         hipLaunchKernelGGL(seg_fill_ranked_kernel, dim3((unsigned)gb), dim3(256), 0, st, xu, xi, ranks, n_pairs, pairs_per_user, indptr_t, users_t, perm_t);
     else
         hipLaunchKernelGGL(seg_fill_kernel, dim3((unsigned)gb), dim3(256), 0, st, xu, xi, n_pairs, pairs_per_user, indptr_t, cursor, users_t, perm_t);

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void select_blocks_kernel(const float* __restr
     }
 }
 
-// keys for the counting sort: superblock id, or n_sb (a dummy bucket) for empty slots and for superblocks whose
+// keys for the counting sort: superblock id, or -1 (skipped by the sort) for empty slots and for superblocks whose
 // maximum lies below the user's floor.  The floor is any lower bound of the user's final k-th best score -- with item
 // shards, the MAX over ranks of the per-shard tau (every shard's k-th best is a floor of the global k-th best): a
 // superblock with max < floor holds no item of the global top-k (strict: a score equal to the floor may still tie in).
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void group_keys_kernel(const int32_t* __restri
     if (i >= n) return;
     bool keep = sel[i] >= 0;
     if (keep && floor_) keep = !(sel_max[(i % k) * (n / k) + i / k] < floor_[i / k]);
-    keys[i] = keep ? sel[i] : n_sb;
+    keys[i] = keep ? sel[i] : -1;            // negative keys are skipped by the counting sort (no shared dummy counter)
 }
 
 // padded group sizes: every superblock's list of users is rounded up to whole workgroups of `rows_wg` rows

@@ -706,6 +706,18 @@ def test_group_pairs_by_item(ops):
         assert np.array_equal(users_t, perm_t // S)
         bucket_of_slot = np.repeat(np.arange(ni), counts)
         assert np.array_equal(items.reshape(-1)[perm_t], bucket_of_slot)
+    # few buckets + many pairs: the privatised (LDS-counter) path; negative keys belong to no bucket
+    nu, ni, S = 5000, 300, 16
+    items = rng.integers(-1, ni, (nu, S)).astype(np.int32)
+    flat = items.reshape(-1)
+    indptr_t, users_t, perm_t = [t.cpu().numpy() for t in ops.group_pairs_by_item(None, dev(flat), S, ni)]
+    kept = flat >= 0
+    counts = np.bincount(flat[kept], minlength=ni)
+    n_kept = int(kept.sum())
+    assert np.array_equal(np.diff(indptr_t), counts) and indptr_t[-1] == n_kept
+    assert sorted(perm_t[:n_kept].tolist()) == np.nonzero(kept)[0].tolist()
+    assert np.array_equal(users_t[:n_kept], perm_t[:n_kept] // S)
+    assert np.array_equal(flat[perm_t[:n_kept]], np.repeat(np.arange(ni), counts))
     # explicit user ids
     xu = rng.integers(0, 50, 999).astype(np.int32)
     xi = rng.integers(0, 70, 999).astype(np.int32)
