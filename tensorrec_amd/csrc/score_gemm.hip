@@ -528,8 +528,42 @@ __global__ __launch_bounds__(256, WPS) void score_gemm_kernel(ScoreParams p)
 }
 
 // ------------------------------------------------------------------------------------------
-// topk_merge: one wave per user; candidates [n_cand] = n_parts * kcap, CPL per lane in registers;
-// k rounds of wave-wide arg-best on (value desc, index asc) with __shfl_xor butterflies.
+// topk_merge: one wave per user; candidates [n_cand] = n_parts * kcap, CPL per lane in registers; k rounds of
+// wave-wide arg-best on (value desc, index asc).  A candidate is packed into ONE 64-bit key -- high word: the float
+// mapped monotonically onto unsigned, low word: ~index -- so "best" is an unsigned 64-bit maximum, taken across the
+// wave with DPP row rotations + row broadcasts (VALU-only; the ds_bpermute butterflies this replaces cost ~1200 cycles
+// per round, 10 rounds per user).
+__device__ __forceinline__ unsigned long long merge_key(float v, int32_t id)
+{
+    const unsigned int u = (v == 0.f) ? 0u : __float_as_uint(v);            // -0.0 and +0.0 compare equal: one key
+    const unsigned int hi = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((unsigned long long)hi << 32) | (unsigned int)(~id);
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long dpp_max_u64(unsigned long long x)
+{
+    const int lo = (int)(unsigned int)x, hi = (int)(unsigned int)(x >> 32);
+    const unsigned int tlo = (unsigned int)__builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+    const unsigned int thi = (unsigned int)__builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+    const unsigned long long t = ((unsigned long long)thi << 32) | tlo;
+    return t > x ? t : x;
+}
+
+// maximum over the 64 lanes, returned in every lane
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long x)
+{
+    x = dpp_max_u64<0x128, 0xf>(x);      // row_ror:8
+    x = dpp_max_u64<0x124, 0xf>(x);      // row_ror:4
+    x = dpp_max_u64<0x122, 0xf>(x);      // row_ror:2
+    x = dpp_max_u64<0x121, 0xf>(x);      // row_ror:1   -> every lane: maximum of its 16-lane row
+    x = dpp_max_u64<0x142, 0xa>(x);      // row_bcast15 -> rows 1, 3 also cover rows 0, 2
+    x = dpp_max_u64<0x143, 0xc>(x);      // row_bcast31 -> row 3 covers all four rows
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)x, 63);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(x >> 32), 63);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
 template <int CPL>
 __global__ __launch_bounds__(256) void topk_merge_kernel(const float* __restrict__ pv, const int32_t* __restrict__ pi,
                                                         int64_t n_users, int n_cand, int k, float* __restrict__ ov,
@@ -538,37 +572,31 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const float* __restrict
     const int64_t u = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (u >= n_users) return;
     const int lane = lane_id();
-    float v[CPL];
-    int32_t id[CPL];
+    const unsigned long long EMPTY = merge_key(-INFINITY, 0x7fffffff);
+    unsigned long long key[CPL];
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
         const int j = c * 64 + lane;
-        v[c] = -INFINITY; id[c] = 0x7fffffff;
+        key[c] = EMPTY;
         if (j < n_cand) {
             const int32_t raw = pi[u * n_cand + j];
-            if (raw >= 0) { v[c] = pv[u * n_cand + j]; id[c] = raw; }
+            if (raw >= 0) key[c] = merge_key(pv[u * n_cand + j], raw);
         }
     }
     for (int t = 0; t < k; ++t) {
-        float bv = v[0]; int32_t bi = id[0];
+        unsigned long long best = key[0];
 #pragma unroll
-        for (int c = 1; c < CPL; ++c) {
-            const bool better = (v[c] > bv) || (v[c] == bv && id[c] < bi);
-            bv = better ? v[c] : bv; bi = better ? id[c] : bi;
-        }
-        for (int off = 32; off > 0; off >>= 1) {
-            const float ovv = __shfl_xor(bv, off, 64);
-            const int32_t oii = __shfl_xor(bi, off, 64);
-            const bool better = (ovv > bv) || (ovv == bv && oii < bi);
-            bv = better ? ovv : bv; bi = better ? oii : bi;
-        }
+        for (int c = 1; c < CPL; ++c) best = key[c] > best ? key[c] : best;
+        best = wave_max_u64(best);
         // every lane now holds the winner; retire it where it lives (indices are unique among real candidates)
 #pragma unroll
         for (int c = 0; c < CPL; ++c)
-            if (id[c] == bi && bi != 0x7fffffff) { v[c] = -INFINITY; id[c] = 0x7fffffff; }
+            if (key[c] == best && best != EMPTY) key[c] = EMPTY;
         if (lane == 0) {
-            ov[u * k + t] = (bi == 0x7fffffff) ? -INFINITY : bv;
-            oi[u * k + t] = (bi == 0x7fffffff) ? -1 : bi;
+            const unsigned int hi = (unsigned int)(best >> 32);
+            const unsigned int bits = (hi & 0x80000000u) ? (hi & 0x7fffffffu) : ~hi;
+            ov[u * k + t] = (best == EMPTY) ? -INFINITY : __uint_as_float(bits);
+            oi[u * k + t] = (best == EMPTY) ? -1 : (int32_t)(~(unsigned int)best);
         }
     }
 }
