@@ -169,3 +169,17 @@ def test_no_oracle_in_product():
                 text = open(os.path.join(dirpath, fn)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), fn
                 assert "libtr_oracle" not in text and "tr_oracle.c" not in text.replace("oracle/tr_oracle.c", ""), fn
+
+
+def test_bench_cpu_baseline_leg_and_defaults(monkeypatch):
+    """bench.py's cpu_baseline leg (the oracle timed on the host cores) on a tiny sample: the keys the measurement
+    contract names; the argument defaults are the BASELINE.json configuration (1M x 1M, d = 128, bf16, top-10, N = 1)."""
+    import sys
+    import bench
+    out = bench.cpu_baseline(n_items=3000, d=16, k=5, n_users_sample=64)
+    assert set(out) >= {"value", "unit", "cores", "kind", "sample"}
+    assert out["kind"] == "port" and out["unit"] == "predictions/s" and out["value"] > 0 and out["cores"] >= 1
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    a = bench.parse()
+    assert (a.gpus, a.users, a.items, a.components, a.k, a.precision) == (1, 1_000_000, 1_000_000, 128, 10, "bf16")
+    assert a.steps >= 1 and a.warmup >= 0
