@@ -155,11 +155,12 @@ int trec_pair_score_bwd(const float* U, const float* V, const int32_t* xu, const
  * workspace_i32: 2*n_items int32; workspace_i64: ceil(n_items/1024)+1 int64.  counts_given != 0: the first n_items
  * entries of workspace_i32 already hold the histogram of xi (trec_wmrb_fused_step counts it while it gathers);
  * ranks (nullable, with counts_given): what those histogram atomics returned, i.e. every pair's position inside its
- * bucket -- the fill pass then needs no atomics. */
+ * bucket -- the fill pass then needs no atomics; values_in / values_out (nullable, with ranks): the pairs' values are
+ * scattered along (values_out[slot] = values_in[pair]) so that the gather reads them in order; perm_t may then be NULL. */
 int trec_group_pairs_by_item(const int32_t* xu, const int32_t* xi, int64_t n_pairs, int32_t pairs_per_user,
                              int64_t n_items, int32_t* workspace_i32, int64_t* workspace_i64, int64_t* indptr_t,
                              int32_t* users_t, int32_t* perm_t, int32_t counts_given, const int32_t* ranks,
-                             void* stream);
+                             const float* values_in, float* values_out, void* stream);
 
 /* ---- K4: ranks ----------------------------------------------------------------------------------------------
  * rank_predictions, recommendation_graphs.py:73-82 (double tf.nn.top_k) as an exact count; int32, 1 = best. */

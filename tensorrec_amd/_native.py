@@ -54,7 +54,7 @@ SIGNATURES = {
     "trec_topk_merge": [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp],
     "trec_pair_score_fwd": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
     "trec_pair_score_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
-    "trec_group_pairs_by_item": [_vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp],
+    "trec_group_pairs_by_item": [_vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp],
     "trec_rank_rows": [_vp, _i64, _i64, _i64, _vp, _i64, _vp],
     "trec_rank_of_pairs": [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _i32, _vp, _vp],
     "trec_wmrb_fwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp],

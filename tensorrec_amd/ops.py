@@ -284,12 +284,13 @@ class _PairScore(torch.autograd.Function):
         return du, dv, dub, dib, None, None, None, None, None
 
 
-def group_pairs_by_item(xu32, xi32, pairs_per_user, n_items, workspace_with_counts=None, ranks=None):
+def group_pairs_by_item(xu32, xi32, pairs_per_user, n_items, workspace_with_counts=None, ranks=None, values=None):
     """(indptr_t int64 [n_items+1], users_t int32 [n_pairs], perm_t int32 [n_pairs]) for a pair list, built on the
     device; the order of pairs inside an item's bucket is not fixed (atomic slot assignment).
     ``workspace_with_counts``: an int32 [2 * n_items] workspace whose first half already holds the histogram of the
     items (counted by the kernel that consumed the pairs) -- the histogram pass is then skipped; ``ranks`` (with it): the
-    values those histogram atomics returned, which makes the fill pass atomic-free."""
+    values those histogram atomics returned, which makes the fill pass atomic-free; ``values`` (with ranks): per-pair
+    values to carry along -- the third result is then the values in bucket order instead of the permutation."""
     dev = xi32.device
     n_pairs = xi32.numel()
     ws32 = workspace_with_counts if workspace_with_counts is not None else \
@@ -297,11 +298,13 @@ def group_pairs_by_item(xu32, xi32, pairs_per_user, n_items, workspace_with_coun
     ws64 = torch.empty(((n_items + 1023) // 1024 + 1,), dtype=torch.int64, device=dev)
     indptr_t = torch.empty((n_items + 1,), dtype=torch.int64, device=dev)
     users_t = torch.empty((n_pairs,), dtype=torch.int32, device=dev)
-    perm_t = torch.empty((n_pairs,), dtype=torch.int32, device=dev)
+    carry = values is not None and ranks is not None
+    perm_t = None if carry else torch.empty((n_pairs,), dtype=torch.int32, device=dev)
+    values_t = torch.empty((n_pairs,), dtype=torch.float32, device=dev) if carry else None
     N.call("trec_group_pairs_by_item", N.ptr(xu32), N.ptr(xi32), n_pairs, pairs_per_user, n_items, N.ptr(ws32),
            N.ptr(ws64), N.ptr(indptr_t), N.ptr(users_t), N.ptr(perm_t), 1 if workspace_with_counts is not None else 0,
-           N.ptr(ranks))
-    return indptr_t, users_t, perm_t
+           N.ptr(ranks), N.ptr(values) if carry else None, N.ptr(values_t))
+    return indptr_t, users_t, (values_t if carry else perm_t)
 
 
 _ones_cache = {}
@@ -508,8 +511,9 @@ def wmrb_fused_step(user_in, item_in, user_bias, item_bias, interactions, sample
         indptr_t, users_t, perm_t = interactions.transposed()
         d_v = _spmm_rowsum(indptr_t, users_t, coef_p, perm_t, n_items, nnz, u, epi, False, None, d_ib)
     xs = samples.reshape(-1)
-    ind_s, users_s, perm_s = group_pairs_by_item(None, xs, S, n_items, workspace_with_counts=ws32, ranks=ranks.reshape(-1))
-    _spmm_rowsum(ind_s, users_s, coef_s.reshape(-1), perm_s, n_items, n_users * S, u, epi, True, d_v, d_ib)
+    ind_s, users_s, coef_t = group_pairs_by_item(None, xs, S, n_items, workspace_with_counts=ws32, ranks=ranks.reshape(-1),
+                                                 values=coef_s.reshape(-1))
+    _spmm_rowsum(ind_s, users_s, coef_t, None, n_items, n_users * S, u, epi, True, d_v, d_ib)
     return loss, pred, d_u, d_v, d_ub, d_ib
 
 
