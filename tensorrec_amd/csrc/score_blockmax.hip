@@ -32,7 +32,9 @@ __device__ __forceinline__ int swz16(int row, int ch) {
 
 // NCB: 32-user column blocks per wave (2: 256 users per workgroup, 2-3 workgroups per CU; 4: 512 users per workgroup,
 // one workgroup per CU -- half the LDS reads, tile loads and barriers per flop, the wave hides its own latencies)
-template <int KT, bool BIAS, int NCB, int WPS>
+// OVL: two accumulator sets, the epilogue of a block under the next block's MFMAs (false: one set, the epilogue right
+// after the block -- the register plan that lets a wave own 96 users)
+template <int KT, bool BIAS, int NCB, int WPS, bool OVL = true>
 __global__ __launch_bounds__(256, WPS) void blockmax_pipe_kernel(ScoreParams p)
 {
     constexpr int RB = KT * 2;               // bytes per operand row
@@ -194,6 +196,53 @@ __global__ __launch_bounds__(256, WPS) void blockmax_pipe_kernel(ScoreParams p)
         }
     };
 
+    // single accumulator set: same LDS pipeline, every block's epilogue right after its last MFMA step.  The item-bias
+    // row of a block is read straight into accumulator 0 (no staging registers): for block A at tile start, for block B
+    // as soon as block A's epilogue is done with accumulator 0 -- the other accumulators' max chains hide the LDS
+    // latency.  The first MFMA step then feeds every accumulator from it, accumulator 0 itself last (in place).
+    auto tile_body_single = [&](auto bufc) __attribute__((always_inline)) {
+        constexpr int buf = decltype(bufc)::value;
+        const char* tb = smem + buf * TILE_BYTES;
+        const float* sd = side + buf * BN + 4 * half;
+        bf16x8 tf[3];
+        if (BIAS) read_c0(accA[0], sd);
+        tf[0] = *(const bf16x8*)(tb + koff[0]);
+        tf[1] = *(const bf16x8*)(tb + koff[1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) {
+            const int blk = s / KS, ks = s % KS;
+            if (s + 2 < NSTEP)
+                tf[(s + 2) % 3] = *(const bf16x8*)(tb + ((s + 2) / KS) * 32 * RB + koff[(s + 2) % KS]);
+            if (ks == 0) {
+                if (BIAS) {
+#pragma unroll
+                    for (int cb = NCB - 1; cb >= 0; --cb)
+                        accA[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[s % 3], rfb[cb][0], accA[0], 0, 0, 0);
+                } else {
+                    const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb)
+                        accA[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[s % 3], rfb[cb][0], z, 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb)
+                    accA[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[s % 3], rfb[cb][ks], accA[cb], 0, 0, 0);
+            }
+            if (ks == KS - 1) {
+#pragma unroll
+                for (int j = 0; j < 10; ++j) epi_op(j * NCB, accA);                    // accumulator 0 first ...
+                if (BIAS && blk == 0) read_c0(accA[0], sd + 32);                       // ... then it takes block B's biases
+#pragma unroll
+                for (int j = 0; j < 10; ++j)
+#pragma unroll
+                    for (int cb = 1; cb < NCB; ++cb) epi_op(j * NCB + cb, accA);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
     stage_issue(0, 0);
     stage_commit(0);
     __syncthreads();
@@ -201,13 +250,18 @@ __global__ __launch_bounds__(256, WPS) void blockmax_pipe_kernel(ScoreParams p)
     for (int t = 0; t < n_tiles; ++t) {
         const int buf = t & 1;
         if (t + 1 < n_tiles) stage_issue(t + 1, buf ^ 1);
-        if (buf == 0) tile_body(std::integral_constant<int, 0>{});
-        else tile_body(std::integral_constant<int, 1>{});
+        if (OVL) {
+            if (buf == 0) tile_body(std::integral_constant<int, 0>{});
+            else tile_body(std::integral_constant<int, 1>{});
+        } else {
+            if (buf == 0) tile_body_single(std::integral_constant<int, 0>{});
+            else tile_body_single(std::integral_constant<int, 1>{});
+        }
 
         if (((t + 1) % p.sb_tiles) == 0 || t + 1 == n_tiles) {
             // end of a superblock: finish block B now, combine the two half-wave maxima of each user, store, reset
 #pragma unroll
-            for (int I = 0; I < NOPS; ++I) epi_op(I, accB);
+            for (int I = 0; I < NOPS; ++I) if (OVL) epi_op(I, accB);
             const int64_t sb = t_begin / ((int64_t)p.sb_tiles * BN) + t / p.sb_tiles;
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) {
@@ -224,11 +278,11 @@ __global__ __launch_bounds__(256, WPS) void blockmax_pipe_kernel(ScoreParams p)
     }
 }
 
-template <int KT, bool BIAS, int NCB, int WPS>
+template <int KT, bool BIAS, int NCB, int WPS, bool OVL = true>
 int launch_one(ScoreParams p, hipStream_t st)
 {
     constexpr int LDS = 2 * BN * KT * 2 + 2 * BN * 4;
-    auto kern = blockmax_pipe_kernel<KT, BIAS, NCB, WPS>;
+    auto kern = blockmax_pipe_kernel<KT, BIAS, NCB, WPS, OVL>;
     static bool attr_set = false;
     if (!attr_set && LDS > 32 * 1024) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -246,7 +300,12 @@ int launch_blockmax_pipelined(const ScoreParams& p, int kt, hipStream_t st)
 {
     if (p.euclid) return TREC_ERR_UNSUPPORTED;
     const bool bias = p.r_bias || p.t_bias;
-    const int shape = trec_get_tuning("blockmax_shape", 2);      // 2: 64 users/wave, 2 workgroups/CU; 4: 128 users/wave, 1/CU
+    // users per wave / accumulator sets / workgroups per CU, measured at 1M x 1M x 128, biased (profiles/r01_k2_ablation.txt):
+    //   5 (default): 128 users, one set,  2/CU  1528 TF      3:  96 users, one set,  2/CU  1468 TF
+    //   2:            64 users, two sets, 2/CU  1290-1340 TF  4: 128 users, two sets, 1/CU  1257 TF
+    const int shape = trec_get_tuning("blockmax_shape", 5);
+    if (kt == 128 && shape == 3) return bias ? launch_one<128, true, 3, 2, false>(p, st) : launch_one<128, false, 3, 2, false>(p, st);
+    if (kt == 128 && shape == 5) return bias ? launch_one<128, true, 4, 2, false>(p, st) : launch_one<128, false, 4, 2, false>(p, st);
     if (kt == 128 && shape == 4) return bias ? launch_one<128, true, 4, 1>(p, st) : launch_one<128, false, 4, 1>(p, st);
     if (kt == 128) return bias ? launch_one<128, true, 2, 2>(p, st) : launch_one<128, false, 2, 2>(p, st);
     if (kt == 64) return bias ? launch_one<64, true, 2, 3>(p, st) : launch_one<64, false, 2, 3>(p, st);
