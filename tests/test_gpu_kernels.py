@@ -692,6 +692,37 @@ def test_score_topk_bf16_all_tilings(ops, variant):
         assert np.array_equal(idx.cpu().numpy(), ri), "chunks=%d" % chunks
 
 
+@pytest.mark.parametrize("shape", [2, 3, 4, 5])
+@pytest.mark.parametrize("biased", [True, False])
+def test_blockmax_kernel_shapes_are_exact(ops, shape, biased):
+    """Every register plan of the hand-scheduled stage-1 kernel (users per wave / accumulator sets / workgroups per CU)
+    and the generic kernel produce the same superblock maxima, hence the exact top-k of the bf16 score matrix -- ragged
+    user and item counts, several chunks, superblocks that end inside a tile."""
+    import tensorrec_amd as T
+    u, v = _uv(1000, 9000 + 37, 128, seed=shape)
+    rng = np.random.default_rng(3)
+    ub = rng.standard_normal(u.shape[0]).astype(np.float32) if biased else None
+    ib = rng.standard_normal(v.shape[0]).astype(np.float32) if biased else None
+    u_op, _, kpad = ops.score_prep(dev(u), ops.DTYPE_BF16)
+    v_op, _, _ = ops.score_prep(dev(v), ops.DTYPE_BF16)
+    dub, dib = (dev(ub), dev(ib)) if biased else (None, None)
+    scores = ops.score_store(u_op, v_op, ops.DTYPE_BF16, kpad, dub, dib).cpu().numpy()
+    rv, ri = O.topk_rows(scores, 10)
+    T._native.set_tuning("blockmax_shape", shape)
+    try:
+        for chunks in (None, 3):
+            vals, idx = ops.score_topk_two_stage(u_op, v_op, ops.DTYPE_BF16, kpad, 10, dub, dib, n_chunks=chunks)
+            assert np.array_equal(idx.cpu().numpy(), ri) and np.array_equal(vals.cpu().numpy(), rv), (shape, chunks)
+    finally:
+        T._native.set_tuning("blockmax_shape", 5)
+    T._native.set_tuning("blockmax_pipelined", 0)
+    try:
+        vals, idx = ops.score_topk_two_stage(u_op, v_op, ops.DTYPE_BF16, kpad, 10, dub, dib)
+        assert np.array_equal(idx.cpu().numpy(), ri) and np.array_equal(vals.cpu().numpy(), rv)
+    finally:
+        T._native.set_tuning("blockmax_pipelined", 1)
+
+
 def test_group_pairs_by_item(ops):
     """device counting sort: every pair lands exactly once in its item's bucket; buckets follow item order."""
     rng = np.random.default_rng(0)
