@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256, WPS) void blockmax_pipe_kernel(ScoreParams p)
     constexpr int TILE_BYTES = BN * RB;
     constexpr int NSLOT = BN * CH / 256;     // 16-byte staging slots per thread per tile
     constexpr int NSTEP = 2 * KS;            // pipeline steps per tile
-    constexpr int NOPS = NCB * 10;           // epilogue ops of one block: per accumulator 8 max + bias add + fold
+    constexpr int NOPS = NCB * 8;            // epilogue ops of one block: 8 v_max3 per accumulator, folded into bm directly
     constexpr int OPS = (NOPS + KS - 4) / (KS - 3);     // ops per step: the epilogue runs in local steps 1 .. KS-3
     static_assert(KT == 64 || KT == 128, "pipelined BLOCKMAX covers K = 64 / 128");
 
@@ -119,21 +119,19 @@ __global__ __launch_bounds__(256, WPS) void blockmax_pipe_kernel(ScoreParams p)
     // ((row >> 1) & 7) and 32 >> 1 = 16 leaves the low three bits alone as well -> one offset table serves both blocks.
 
     f32x16 accA[NCB], accB[NCB];
-    float bm[NCB], m[NCB];
+    float bm[NCB];
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
-        bm[cb] = -INFINITY; m[cb] = -INFINITY;
+        bm[cb] = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { accA[cb][r] = -INFINITY; accB[cb][r] = -INFINITY; }
     }
 
-    // one op of a block's epilogue: I = NCB*j + cb;  j = 0: max(x0, x1); 1..7: max3 with (x[2j], x[2j+1]); 8: + b_u; 9: fold
+    // one op of a block's epilogue: I = NCB*j + cb, j = 0..7:  bm = max3(bm, x[2j], x[2j+1]).  The user bias is added once
+    // per superblock, after the maximum (fp32 addition is monotone: max_r fl(x_r + b) == fl(max_r x_r + b)).
     auto epi_op = [&](int I, f32x16 (&x)[NCB]) {
         const int cb = I % NCB, j = I / NCB;
-        if (j == 0) m[cb] = fmaxf(x[cb][0], x[cb][1]);
-        else if (j <= 7) m[cb] = fmaxf(fmaxf(m[cb], x[cb][2 * j]), x[cb][2 * j + 1]);
-        else if (j == 8) { if (BIAS) m[cb] = m[cb] + r_bias[cb]; }
-        else bm[cb] = fmaxf(bm[cb], m[cb]);
+        bm[cb] = fmaxf(fmaxf(bm[cb], x[cb][2 * j]), x[cb][2 * j + 1]);
     };
     auto read_c0 = [&](f32x16& c, const float* sdi) {      // item biases of the block's 16 rows of this half-wave
 #pragma unroll
@@ -232,10 +230,10 @@ __global__ __launch_bounds__(256, WPS) void blockmax_pipe_kernel(ScoreParams p)
             }
             if (ks == KS - 1) {
 #pragma unroll
-                for (int j = 0; j < 10; ++j) epi_op(j * NCB, accA);                    // accumulator 0 first ...
+                for (int j = 0; j < 8; ++j) epi_op(j * NCB, accA);                     // accumulator 0 first ...
                 if (BIAS && blk == 0) read_c0(accA[0], sd + 32);                       // ... then it takes block B's biases
 #pragma unroll
-                for (int j = 0; j < 10; ++j)
+                for (int j = 0; j < 8; ++j)
 #pragma unroll
                     for (int cb = 1; cb < NCB; ++cb) epi_op(j * NCB + cb, accA);
             }
@@ -265,7 +263,8 @@ __global__ __launch_bounds__(256, WPS) void blockmax_pipe_kernel(ScoreParams p)
             const int64_t sb = t_begin / ((int64_t)p.sb_tiles * BN) + t / p.sb_tiles;
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) {
-                const float v = fmaxf(bm[cb], __shfl_xor(bm[cb], 32, 64));
+                float v = fmaxf(bm[cb], __shfl_xor(bm[cb], 32, 64));
+                if (BIAS) v = v + r_bias[cb];
                 const int64_t u = r_base + cb * 32 + l31;
                 if (half == 0 && u < p.n_r) p.blockmax[sb * p.bm_stride + u] = v;
                 bm[cb] = -INFINITY;
