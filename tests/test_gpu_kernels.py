@@ -692,6 +692,23 @@ def test_score_topk_bf16_all_tilings(ops, variant):
         assert np.array_equal(idx.cpu().numpy(), ri), "chunks=%d" % chunks
 
 
+@pytest.mark.parametrize("n_users,n_items,sb_rows", [(5, 70, 128), (513, 129, 128), (700, 1025, 256), (64, 64, 512)])
+@pytest.mark.parametrize("kdim", [128, 64])
+def test_blockmax_kernel_small_and_ragged_sizes(ops, n_users, n_items, sb_rows, kdim):
+    """The hand-scheduled stage-1 kernel on sizes around its tile / workgroup / superblock boundaries (one tile, one
+    partial tile, a single workgroup with mostly idle rows, superblocks of 2, 4 and 8 tiles), K = 128 and K = 64."""
+    u, v = _uv(n_users, n_items, kdim, seed=n_users)
+    rng = np.random.default_rng(1)
+    ub, ib = rng.standard_normal(n_users).astype(np.float32), rng.standard_normal(n_items).astype(np.float32)
+    u_op, _, kpad = ops.score_prep(dev(u), ops.DTYPE_BF16)
+    v_op, _, _ = ops.score_prep(dev(v), ops.DTYPE_BF16)
+    scores = ops.score_store(u_op, v_op, ops.DTYPE_BF16, kpad, dev(ub), dev(ib)).cpu().numpy()
+    for k in (1, 10):
+        vals, idx = ops.score_topk_two_stage(u_op, v_op, ops.DTYPE_BF16, kpad, k, dev(ub), dev(ib), sb_rows=sb_rows)
+        rv, ri = O.topk_rows(scores, k)
+        assert np.array_equal(idx.cpu().numpy(), ri) and np.array_equal(vals.cpu().numpy(), rv), k
+
+
 @pytest.mark.parametrize("shape", [2, 3, 4, 5])
 @pytest.mark.parametrize("biased", [True, False])
 def test_blockmax_kernel_shapes_are_exact(ops, shape, biased):
