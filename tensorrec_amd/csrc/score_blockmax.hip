@@ -307,6 +307,7 @@ int launch_blockmax_pipelined(const ScoreParams& p, int kt, hipStream_t st)
     if (kt == 128 && shape == 5) return bias ? launch_one<128, true, 4, 2, false>(p, st) : launch_one<128, false, 4, 2, false>(p, st);
     if (kt == 128 && shape == 4) return bias ? launch_one<128, true, 4, 1>(p, st) : launch_one<128, false, 4, 1>(p, st);
     if (kt == 128) return bias ? launch_one<128, true, 2, 2>(p, st) : launch_one<128, false, 2, 2>(p, st);
-    if (kt == 64) return bias ? launch_one<64, true, 2, 3>(p, st) : launch_one<64, false, 2, 3>(p, st);
+    if (kt == 64 && shape == 2) return bias ? launch_one<64, true, 2, 3>(p, st) : launch_one<64, false, 2, 3>(p, st);
+    if (kt == 64) return bias ? launch_one<64, true, 4, 2, false>(p, st) : launch_one<64, false, 4, 2, false>(p, st);
     return TREC_ERR_UNSUPPORTED;
 }
