@@ -108,7 +108,8 @@ class TensorRec(object):
                  sampler=None,
                  seed=None,
                  data_parallel=False,
-                 process_group=None):
+                 process_group=None,
+                 hip_graphs=True):
         """
         A TensorRec recommendation model (arguments as tensorrec/tensorrec.py:28-61).
         :param precision: 'fp32' (default; exact fp32 MFMA, bit-stable ranks) or 'bf16' (bf16 operands, fp32
@@ -123,6 +124,9 @@ class TensorRec(object):
         equals the single-process step on the union of the shards (the reference's ``user_batch_size=None`` case).
         Needs ``seed`` (identical initial weights on every rank) and a loss that is a per-interaction vector (the
         WMRB family); see sharding.py.
+        :param hip_graphs: capture the forward + backward of a small, launch-bound training step in a HIP graph after its
+        first eager execution and replay it for the remaining epochs of a ``fit`` call (the sampler and the optimiser
+        stay outside the graph: their step counters change every step).  Large steps run eagerly either way.
         """
         # Arg Check (tensorrec.py:68-88)
         if (n_components is None) or (n_tastes is None) or (user_repr_graph is None) or (item_repr_graph is None) \
@@ -162,6 +166,7 @@ class TensorRec(object):
         self.sampler = sampler
         self.data_parallel = bool(data_parallel)
         self.process_group = process_group
+        self.hip_graphs = bool(hip_graphs)
         if self.data_parallel and seed is None:
             raise ValueError("data_parallel=True needs seed= so that every rank starts from the same weights")
 
@@ -432,10 +437,20 @@ class TensorRec(object):
         if verbose:
             logging.info('Beginning fitting')
 
+        # launch-bound steps (small batches: ~60 kernels of a few microseconds each) are captured in a HIP graph after one
+        # eager execution and replayed; see _GraphedStep
+        graphed = {}
         for epoch in range(epochs):
             for batch, (inter, uf, itf) in enumerate(dev_batches):
-                loss, serial_predictions, wr_loss = self._train_step(inter, uf, itf, learning_rate, batched_alpha,
-                                                                     n_sampled_items, want_stats=verbose)
+                step = graphed.get(batch)
+                if step is None and epoch >= 1 and epochs - epoch >= 2 and batch not in graphed and \
+                        self._graph_eligible(inter, n_sampled_items, verbose):
+                    step = graphed[batch] = _GraphedStep.capture(self, inter, uf, itf, n_sampled_items)
+                if step:
+                    loss, serial_predictions, wr_loss = step.run(self, learning_rate, batched_alpha, verbose)
+                else:
+                    loss, serial_predictions, wr_loss = self._train_step(inter, uf, itf, learning_rate, batched_alpha,
+                                                                         n_sampled_items, want_stats=verbose)
                 if verbose:
                     mean_loss = float(loss.mean())
                     mean_pred = float(serial_predictions.mean())
@@ -444,7 +459,26 @@ class TensorRec(object):
                         epoch, batch, mean_loss, weight_reg_l2_loss, mean_pred
                     ))
 
-    def _train_step(self, inter, user_feats, item_feats, learning_rate, alpha, n_sampled_items, want_stats=False):
+    def _graph_eligible(self, inter, n_sampled_items, verbose):
+        if not self.hip_graphs or self._dp_active() or self._capture is not None:
+            return False
+        pairs = inter.nnz + inter.shape[0] * int(n_sampled_items or 0)
+        dense = self.loss_graph_factory.is_dense
+        return pairs <= 4_000_000 and (not dense or inter.shape[0] * inter.shape[1] <= 4_000_000)
+
+    def _draw_samples(self, inter, n_sampled_items):
+        """tf.py_func(sample_items) of tensorrec.py:298-302: one [n_users, n_sampled_items] int32 table per step."""
+        n_users, n_items = inter.shape
+        self._sample_step += 1
+        samples = self.sampler.sample(n_items, n_users, int(n_sampled_items),
+                                      self.loss_graph_factory.is_sampled_with_replacement, self._sample_step,
+                                      self._store.device, getattr(inter, 'user_base', 0))
+        return samples.to(torch.int32).contiguous()
+
+    def _train_step(self, inter, user_feats, item_feats, learning_rate, alpha, n_sampled_items, want_stats=False,
+                    samples=None, apply=True):
+        """One optimiser step.  ``samples``: a pre-drawn sample table (graph replays feed a static buffer); ``apply=False``
+        stops after the backward pass and returns (loss, serial predictions, regularised weights, loss length)."""
         loss_graph = self.loss_graph_factory
         graph = self.prediction_graph_factory
         n_users, n_items = inter.shape
@@ -472,7 +506,7 @@ class TensorRec(object):
             u_in = u_ins[0]
             if fused:
                 return self._fused_wmrb_step(inter, u_in, i_in, user_bias, item_bias, weights, learning_rate, alpha,
-                                             n_sampled_items, want_stats)
+                                             n_sampled_items, want_stats, samples, apply)
             if multi:
                 pred_serial = self._serial_multi(u_ins, a_ins, i_in, x_user, x_item, user_bias, item_bias)
             elif engine:
@@ -497,11 +531,8 @@ class TensorRec(object):
                 loss_kwargs.update({'tf_prediction': tf_prediction,
                                     'tf_rankings': rank_predictions(tf_prediction)})
             if loss_graph.is_sample_based:
-                self._sample_step += 1
-                samples = self.sampler.sample(n_items, n_users, int(n_sampled_items),
-                                              loss_graph.is_sampled_with_replacement, self._sample_step,
-                                              self._store.device, getattr(inter, 'user_base', 0))
-                samples = samples.to(torch.int32).contiguous()
+                if samples is None:
+                    samples = self._draw_samples(inter, n_sampled_items)
                 if engine:
                     xs_item = PairIndex.make(samples.reshape(-1), samples.reshape(-1), int(n_sampled_items))
                     if multi:
@@ -529,17 +560,17 @@ class TensorRec(object):
         # tf_loss = tf_basic_loss + alpha * reg (broadcast), minimised as a sum (tensorrec.py:487-489)
         n_loss = int(basic_loss.numel())
         basic_loss.sum().backward()
+        if not apply:
+            return basic_loss, pred_serial, weights, n_loss
         return self._apply_gradients(basic_loss, pred_serial, weights, n_loss, learning_rate, alpha, want_stats)
 
     def _fused_wmrb_step(self, inter, u_in, i_in, user_bias, item_bias, weights, learning_rate, alpha, n_sampled_items,
-                         want_stats):
+                         want_stats, samples=None, apply=True):
         """The WMRB step with the user side in one kernel: loss values and d(sum loss)/d(representations, biases) come
         from ops.wmrb_fused_step; autograd then only carries them through the representation graphs (K1 backward)."""
         loss_graph = self.loss_graph_factory
-        n_users, n_items = inter.shape
-        self._sample_step += 1
-        samples = self.sampler.sample(n_items, n_users, int(n_sampled_items), loss_graph.is_sampled_with_replacement,
-                                      self._sample_step, self._store.device, getattr(inter, 'user_base', 0))
+        if samples is None:
+            samples = self._draw_samples(inter, n_sampled_items)
         ub = user_bias if self.biased else None
         ib = item_bias if self.biased else None
         basic_loss, pred_serial, d_u, d_v, d_ub, d_ib = ops.wmrb_fused_step(u_in, i_in, ub, ib, inter, samples,
@@ -551,10 +582,13 @@ class TensorRec(object):
         live = [(t, g) for t, g in zip(tensors, grads) if t.requires_grad]      # weight-less graphs have no history
         if live:
             torch.autograd.backward([t for t, _ in live], [g for _, g in live])
+        if not apply:
+            return basic_loss, pred_serial, weights, int(basic_loss.numel())
         return self._apply_gradients(basic_loss, pred_serial, weights, int(basic_loss.numel()), learning_rate, alpha,
                                      want_stats)
 
-    def _apply_gradients(self, basic_loss, pred_serial, weights, n_loss, learning_rate, alpha, want_stats):
+    def _apply_gradients(self, basic_loss, pred_serial, weights, n_loss, learning_rate, alpha, want_stats,
+                         static_grads=None):
         """Gradient all-reduce (data-parallel fit), the L2 term and the fused Adam step (tensorrec.py:487-489)."""
         loss_graph = self.loss_graph_factory
 
@@ -586,7 +620,9 @@ class TensorRec(object):
             if name not in self._adam:
                 self._adam[name] = (torch.zeros_like(var), torch.zeros_like(var))
             m, v = self._adam[name]
-            grad = var.grad if var.grad is not None else torch.zeros_like(var)
+            grad = static_grads.get(name) if static_grads is not None else var.grad
+            if grad is None:
+                grad = torch.zeros_like(var)
             with torch.no_grad():
                 ops.adam_tf_step(var, m, v, grad, lr_t, l2 if id(var) in reg_ids else 0.0, ADAM_BETA1, ADAM_BETA2,
                                  ADAM_EPSILON)
@@ -887,6 +923,49 @@ class TensorRec(object):
             with torch.no_grad(), variable_scope(self._store):
                 self._representations(uf, itf)
         return self
+
+
+class _GraphedStep(object):
+    """The forward + backward of one training step of one user batch as a HIP graph (torch.cuda.CUDAGraph over the
+    launches this library issues on torch's current stream).  Outside the graph, per replay: the sampler (its step
+    counter is a kernel argument) writes into a static sample table, and the optimiser (lr_t changes every step) reads
+    the static gradient buffers the graph fills.  Capture happens after one eager execution of the same step, so
+    every lazily built structure (transposed CSR, balanced weights, kernel attributes, Adam slots) already exists."""
+
+    @classmethod
+    def capture(cls, model, inter, uf, itf, n_sampled_items):
+        self = cls()
+        self.inter, self.S = inter, n_sampled_items
+        store = model._store
+        try:
+            sample_based = model.loss_graph_factory.is_sample_based
+            # the static sample table: capture only records launches, so its content does not matter yet (and drawing
+            # here would advance stateful samplers)
+            self.samples = torch.zeros((inter.shape[0], int(n_sampled_items)), dtype=torch.int32,
+                                       device=store.device) if sample_based else None
+            for var in store.variables.values():
+                var.grad = None
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                out = model._train_step(inter, uf, itf, 0.0, 0.0, n_sampled_items, samples=self.samples, apply=False)
+            self.loss, self.pred_serial, self.weights, self.n_loss = out
+            self.grads = {name: var.grad for name, var in store.variables.items()}
+            for var in store.variables.values():
+                var.grad = None
+            return self
+        except Exception as exc:      # capture is an optimisation: fall back to eager steps for this batch
+            logging.warning('HIP graph capture of the training step failed (%r); running eagerly', exc)
+            for var in store.variables.values():
+                var.grad = None
+            return False
+
+    def run(self, model, learning_rate, alpha, want_stats):
+        if self.samples is not None:
+            self.samples.copy_(model._draw_samples(self.inter, self.S))
+        self.graph.replay()
+        return model._apply_gradients(self.loss, self.pred_serial, self.weights, self.n_loss, learning_rate, alpha,
+                                      want_stats, static_grads=self.grads)
 
 
 def _merge_taste_topk(per_taste, k):

@@ -448,3 +448,48 @@ def test_fused_wmrb_falls_back_when_rows_do_not_fit():
     inter, uf, itf = dummy(40, 60, seed=1)
     T.TensorRec(n_components=8, loss_graph=MyWMRB(), seed=0).fit(inter, uf, itf, epochs=2, n_sampled_items=5)
     assert MyWMRB.calls == 2
+
+
+@pytest.mark.parametrize("loss,kw", [("rmse", {}), ("wmrb", {"n_sampled_items": 12}), ("balanced_wmrb", {"n_sampled_items": 12}),
+                                     ("rmse_dense", {})])
+@pytest.mark.parametrize("batch", [None, 25])
+def test_hip_graph_replay_equals_eager_steps(loss, kw, batch):
+    """A fit whose steps 2..n are HIP-graph replays (forward + backward captured after the first eager step; sampler and
+    Adam outside the graph) ends with the weights of the all-eager fit: bit-identical for the deterministic RMSE steps,
+    up to the summation order of the counting-sort buckets for the sampled losses."""
+    inter, uf, itf = dummy(60, 90, seed=3)
+    out = []
+    for graphs in (True, False):
+        model = T.TensorRec(n_components=16, loss_graph=LOSS[loss](), seed=9, hip_graphs=graphs)
+        model.fit(inter, uf, itf, epochs=6, learning_rate=0.05, user_batch_size=batch, **kw)
+        out.append((model.get_weights(), model._opt_step, model._sample_step))
+    (wa, oa, sa), (wb, ob, sb) = out
+    assert (oa, sa) == (ob, sb)
+    for k in wa:
+        if loss.startswith("rmse"):
+            assert np.array_equal(wa[k], wb[k]), k
+        elif k != "user_feature_biases":
+            assert np.allclose(wa[k], wb[k], rtol=1e-3, atol=2e-3), k
+
+
+def test_hip_graph_is_actually_used(monkeypatch):
+    import tensorrec_amd.tensorrec as TT
+    calls = {"capture": 0, "run": 0}
+    orig_capture, orig_run = TT._GraphedStep.capture.__func__, TT._GraphedStep.run
+
+    def capture(cls, *a, **k):
+        calls["capture"] += 1
+        return orig_capture(cls, *a, **k)
+
+    def run(self, *a, **k):
+        calls["run"] += 1
+        return orig_run(self, *a, **k)
+
+    monkeypatch.setattr(TT._GraphedStep, "capture", classmethod(capture))
+    monkeypatch.setattr(TT._GraphedStep, "run", run)
+    inter, uf, itf = dummy(60, 90, seed=3)
+    T.TensorRec(n_components=16, loss_graph=WMRBLossGraph(), seed=1).fit(inter, uf, itf, epochs=8, n_sampled_items=10)
+    assert calls == {"capture": 1, "run": 7}
+    calls.update(capture=0, run=0)
+    T.TensorRec(n_components=16, seed=1, hip_graphs=False).fit(inter, uf, itf, epochs=8)
+    assert calls == {"capture": 0, "run": 0}
