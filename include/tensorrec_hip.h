@@ -241,6 +241,19 @@ int trec_collapse_tastes_fwd(const float* preds, const float* attn, int32_t n_ta
 int trec_collapse_tastes_bwd(const float* preds, const float* attn, const float* grad_out, int32_t n_tastes, int64_t n,
                              float* d_preds, float* d_attn, void* stream);
 
+/* ---- whole steps as HIP graphs ----------------------------------------------------------------------------------
+ * A captured graph is replayed every step, so what changes from step to step must live in device memory:
+ * state = float[4] { beta1_power, beta2_power, lr_t, sample step (uint32 bits) }.  trec_adam_schedule_advance (first
+ * node of the graph) multiplies the powers by beta (TF's float32 running powers), forms lr_t = lr * sqrt(1 - b2p) /
+ * (1 - b1p) exactly as the host does, and bumps the sample step; trec_sample_items_dev / trec_adam_tf_step_dev are
+ * trec_sample_items / trec_adam_tf_step reading step / lr_t from that state.                                       */
+int trec_adam_schedule_advance(float* state, float learning_rate, float beta1, float beta2, int32_t bump_sample_step,
+                               void* stream);
+int trec_adam_tf_step_dev(float* w, float* m, float* v, const float* grad, int64_t n, const float* state, float beta1,
+                          float beta2, float epsilon, float l2_coef, void* stream);
+int trec_sample_items_dev(int64_t n_users, int64_t user_base, int32_t n_items, int32_t n_sampled, int32_t replace,
+                          uint64_t seed, const uint32_t* step_dev, int32_t* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -69,6 +69,9 @@ SIGNATURES = {
     "trec_collapse_tastes_fwd": [_vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
     "trec_collapse_tastes_bwd": [_vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp],
     "trec_adam_tf_step": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _vp],
+    "trec_adam_schedule_advance": [_vp, _f, _f, _f, _i32, _vp],
+    "trec_adam_tf_step_dev": [_vp, _vp, _vp, _vp, _i64, _vp, _f, _f, _f, _f, _vp],
+    "trec_sample_items_dev": [_i64, _i64, _i32, _i32, _i32, _u64, _vp, _vp, _vp],
 }
 
 _lib = None

@@ -65,10 +65,12 @@ __host__ __device__ inline uint32_t feistel_permute(uint32_t x, int bits, const 
 __global__ __launch_bounds__(256) void sample_items_kernel(int64_t n_users, int64_t user_base, int32_t n_items,
                                                           int32_t n_sampled, int replace, uint32_t seed_lo,
                                                           uint32_t seed_hi, uint32_t step, int bits,
-                                                          int32_t* __restrict__ out)
+                                                          int32_t* __restrict__ out,
+                                                          const uint32_t* __restrict__ step_dev = nullptr)
 {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n_users * n_sampled) return;
+    if (step_dev) step = *step_dev;             // the step counter lives on the device (HIP-graph replays)
     const int64_t ul = idx / n_sampled;
     const uint32_t s = (uint32_t)(idx - ul * n_sampled);
     const int64_t u = ul + user_base;          // streams are keyed by the GLOBAL user id: a user shard draws what the
@@ -87,8 +89,27 @@ __global__ __launch_bounds__(256) void sample_items_kernel(int64_t n_users, int6
     out[idx] = (int32_t)x;
 }
 
+static int sample_items_impl(int64_t n_users, int64_t user_base, int32_t n_items, int32_t n_sampled, int32_t replace,
+                             uint64_t seed, uint32_t step, const uint32_t* step_dev, int32_t* out, void* stream);
+
 extern "C" int trec_sample_items(int64_t n_users, int64_t user_base, int32_t n_items, int32_t n_sampled,
                                  int32_t replace, uint64_t seed, uint32_t step, int32_t* out, void* stream)
+{
+    return sample_items_impl(n_users, user_base, n_items, n_sampled, replace, seed, step, nullptr, out, stream);
+}
+
+// the same draw with the step counter read from device memory at execution time, so that the launch can sit inside a
+// HIP graph that is replayed every step (the counter is bumped by trec_adam_schedule_advance inside the same graph)
+extern "C" int trec_sample_items_dev(int64_t n_users, int64_t user_base, int32_t n_items, int32_t n_sampled,
+                                     int32_t replace, uint64_t seed, const uint32_t* step_dev, int32_t* out,
+                                     void* stream)
+{
+    TREC_REQUIRE(step_dev, "trec_sample_items_dev: null step counter");
+    return sample_items_impl(n_users, user_base, n_items, n_sampled, replace, seed, 0u, step_dev, out, stream);
+}
+
+static int sample_items_impl(int64_t n_users, int64_t user_base, int32_t n_items, int32_t n_sampled, int32_t replace,
+                             uint64_t seed, uint32_t step, const uint32_t* step_dev, int32_t* out, void* stream)
 {
     TREC_REQUIRE(out, "trec_sample_items: null pointer");
     TREC_REQUIRE(n_items >= 1 && n_sampled >= 1, "trec_sample_items: n_items and n_sampled must be >= 1");
@@ -100,6 +121,6 @@ extern "C" int trec_sample_items(int64_t n_users, int64_t user_base, int32_t n_i
     const int64_t total = n_users * (int64_t)n_sampled;
     hipLaunchKernelGGL(sample_items_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, (hipStream_t)stream,
                        n_users, user_base, n_items, n_sampled, replace, (uint32_t)seed, (uint32_t)(seed >> 32), step, bits,
-                       out);
+                       out, step_dev);
     return trec_check_launch("trec_sample_items");
 }

@@ -746,3 +746,24 @@ def sample_items(n_users, n_items, n_sampled, replace, seed, step, device="cuda"
 def adam_tf_step(w, m, v, grad, lr_t, l2_coef, beta1=0.9, beta2=0.999, eps=1e-8):
     N.call("trec_adam_tf_step", N.ptr(w), N.ptr(m), N.ptr(v), N.ptr(_f32c(grad)), w.numel(), float(lr_t), beta1, beta2,
            eps, float(l2_coef))
+
+
+# ------------------------------------------------------------------------------------------------ schedule on the device
+def adam_schedule_advance(state, learning_rate, beta1=0.9, beta2=0.999, bump_sample_step=False):
+    N.call("trec_adam_schedule_advance", N.ptr(state), float(learning_rate), float(beta1), float(beta2),
+           1 if bump_sample_step else 0)
+
+
+def adam_tf_step_dev(w, m, v, grad, state, l2_coef, beta1=0.9, beta2=0.999, eps=1e-8):
+    N.call("trec_adam_tf_step_dev", N.ptr(w), N.ptr(m), N.ptr(v), N.ptr(_f32c(grad)), w.numel(), N.ptr(state),
+           float(beta1), float(beta2), float(eps), float(l2_coef))
+
+
+def sample_items_dev(n_users, n_items, n_sampled, replace, seed, state, device="cuda", user_base=0):
+    """trec_sample_items with the step read from word 3 of the schedule state (uint32 bits)."""
+    import ctypes
+    out = torch.empty((n_users, n_sampled), dtype=torch.int32, device=device)
+    step_ptr = ctypes.c_void_p(state.data_ptr() + 12)
+    N.call("trec_sample_items_dev", n_users, int(user_base), n_items, n_sampled, 1 if replace else 0,
+           int(seed) & (2 ** 64 - 1), step_ptr, N.ptr(out))
+    return out

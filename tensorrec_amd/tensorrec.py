@@ -175,6 +175,8 @@ class TensorRec(object):
         self._adam = {}
         self._opt_step = 0
         self._sample_step = 0
+        self._schedule = None         # device-side {beta powers, lr_t, sample step} for HIP-graph replays
+        self._schedule_mirror = None
         self.n_user_features = None
         self.n_item_features = None
 
@@ -445,9 +447,10 @@ class TensorRec(object):
                 step = graphed.get(batch)
                 if step is None and epoch >= 1 and epochs - epoch >= 2 and batch not in graphed and \
                         self._graph_eligible(inter, n_sampled_items, verbose):
-                    step = graphed[batch] = _GraphedStep.capture(self, inter, uf, itf, n_sampled_items)
+                    step = graphed[batch] = _GraphedStep.capture(self, inter, uf, itf, n_sampled_items, learning_rate,
+                                                                 batched_alpha)
                 if step:
-                    loss, serial_predictions, wr_loss = step.run(self, learning_rate, batched_alpha, verbose)
+                    loss, serial_predictions, wr_loss = step.run(self, verbose)
                 else:
                     loss, serial_predictions, wr_loss = self._train_step(inter, uf, itf, learning_rate, batched_alpha,
                                                                          n_sampled_items, want_stats=verbose)
@@ -458,6 +461,28 @@ class TensorRec(object):
                     logging.info('EPOCH {} BATCH {} loss = {}, weight_reg_l2_loss = {}, mean_pred = {}'.format(
                         epoch, batch, mean_loss, weight_reg_l2_loss, mean_pred
                     ))
+
+    def _schedule_state(self):
+        """float32[4] on the device: {beta1_power, beta2_power, lr_t, sample step bits} for the CURRENT host counters."""
+        if getattr(self, '_schedule', None) is None:
+            self._schedule = torch.zeros((4,), dtype=torch.float32, device=self._store.device)
+            self._schedule_mirror = None
+        self._sync_schedule_state()
+        return self._schedule
+
+    def _sync_schedule_state(self):
+        """Eager steps advance only the host counters; before a replay the device state is brought back in line."""
+        if self._schedule_mirror == (self._opt_step, self._sample_step):
+            return
+        b1p, b2p = np.float32(1.0), np.float32(1.0)
+        for _ in range(int(self._opt_step)):
+            b1p = np.float32(b1p * np.float32(ADAM_BETA1))
+            b2p = np.float32(b2p * np.float32(ADAM_BETA2))
+        host = np.zeros(4, np.float32)
+        host[0], host[1] = b1p, b2p
+        host.view(np.uint32)[3] = np.uint32(self._sample_step & 0xFFFFFFFF)
+        self._schedule.copy_(torch.from_numpy(host))
+        self._schedule_mirror = (self._opt_step, self._sample_step)
 
     def _graph_eligible(self, inter, n_sampled_items, verbose):
         if not self.hip_graphs or self._dp_active() or self._capture is not None:
@@ -866,6 +891,8 @@ class TensorRec(object):
         state['_store'] = None
         state['_adam'] = {}
         state['_capture'] = None
+        state['_schedule'] = None
+        state['_schedule_mirror'] = None
         state['process_group'] = None
         return state
 
@@ -926,33 +953,54 @@ class TensorRec(object):
 
 
 class _GraphedStep(object):
-    """The forward + backward of one training step of one user batch as a HIP graph (torch.cuda.CUDAGraph over the
-    launches this library issues on torch's current stream).  Outside the graph, per replay: the sampler (its step
-    counter is a kernel argument) writes into a static sample table, and the optimiser (lr_t changes every step) reads
-    the static gradient buffers the graph fills.  Capture happens after one eager execution of the same step, so
-    every lazily built structure (transposed CSR, balanced weights, kernel attributes, Adam slots) already exists."""
+    """One training step of one user batch as ONE HIP graph (torch.cuda.CUDAGraph over the launches this library issues
+    on torch's current stream): schedule advance -> negative sampling -> forward -> loss -> every backward kernel through
+    torch autograd -> the fused Adam step of every variable.  What changes from step to step lives in device memory:
+    the model's schedule state {beta1_power, beta2_power, lr_t, sample step} (trec_adam_schedule_advance is the graph's
+    first node; the sampler and Adam launches read it).  A sampler other than the DeviceSampler stays outside and fills
+    a static table before each replay.  Capture happens after one eager execution of the same step, so every lazily
+    built structure (transposed CSR, balanced weights, kernel attributes, Adam slots) already exists."""
 
     @classmethod
-    def capture(cls, model, inter, uf, itf, n_sampled_items):
+    def capture(cls, model, inter, uf, itf, n_sampled_items, learning_rate, alpha):
         self = cls()
         self.inter, self.S = inter, n_sampled_items
         store = model._store
         try:
-            sample_based = model.loss_graph_factory.is_sample_based
-            # the static sample table: capture only records launches, so its content does not matter yet (and drawing
-            # here would advance stateful samplers)
+            loss_graph = model.loss_graph_factory
+            sample_based = loss_graph.is_sample_based
+            self.device_sampler = sample_based and type(model.sampler) is DeviceSampler
+            # a static table for samplers that run outside the graph (capture only records launches: content irrelevant)
             self.samples = torch.zeros((inter.shape[0], int(n_sampled_items)), dtype=torch.int32,
-                                       device=store.device) if sample_based else None
+                                       device=store.device) if sample_based and not self.device_sampler else None
+            state = model._schedule_state()
             for var in store.variables.values():
                 var.grad = None
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
-                out = model._train_step(inter, uf, itf, 0.0, 0.0, n_sampled_items, samples=self.samples, apply=False)
-            self.loss, self.pred_serial, self.weights, self.n_loss = out
-            self.grads = {name: var.grad for name, var in store.variables.items()}
+                ops.adam_schedule_advance(state, learning_rate, ADAM_BETA1, ADAM_BETA2, bump_sample_step=sample_based)
+                samples = self.samples
+                if self.device_sampler:
+                    samples = ops.sample_items_dev(inter.shape[0], inter.shape[1], int(n_sampled_items),
+                                                   loss_graph.is_sampled_with_replacement, model.sampler.seed, state,
+                                                   store.device, getattr(inter, 'user_base', 0))
+                out = model._train_step(inter, uf, itf, 0.0, 0.0, n_sampled_items, samples=samples, apply=False)
+                self.loss, self.pred_serial, self.weights, self.n_loss = out
+                l2 = float(np.float32(np.float32(self.n_loss) * np.float32(alpha)))
+                reg_ids = set(id(w) for w in self.weights)
+                self.grads = {}
+                for name in store.order:
+                    var = store.variables[name]
+                    m, v = model._adam[name]
+                    grad = var.grad if var.grad is not None else torch.zeros_like(var)
+                    self.grads[name] = grad
+                    with torch.no_grad():
+                        ops.adam_tf_step_dev(var, m, v, grad, state, l2 if id(var) in reg_ids else 0.0, ADAM_BETA1,
+                                             ADAM_BETA2, ADAM_EPSILON)
             for var in store.variables.values():
                 var.grad = None
+            self.sample_based = sample_based
             return self
         except Exception as exc:      # capture is an optimisation: fall back to eager steps for this batch
             logging.warning('HIP graph capture of the training step failed (%r); running eagerly', exc)
@@ -960,12 +1008,24 @@ class _GraphedStep(object):
                 var.grad = None
             return False
 
-    def run(self, model, learning_rate, alpha, want_stats):
+    def run(self, model, want_stats):
+        model._sync_schedule_state()
         if self.samples is not None:
-            self.samples.copy_(model._draw_samples(self.inter, self.S))
+            model._sample_step += 1               # the host-side sampler sees the same step number as an eager step
+            table = model.sampler.sample(self.inter.shape[1], self.inter.shape[0], int(self.S),
+                                         model.loss_graph_factory.is_sampled_with_replacement, model._sample_step,
+                                         model._store.device, getattr(self.inter, 'user_base', 0))
+            self.samples.copy_(table.to(torch.int32))
+        elif self.sample_based:
+            model._sample_step += 1
         self.graph.replay()
-        return model._apply_gradients(self.loss, self.pred_serial, self.weights, self.n_loss, learning_rate, alpha,
-                                      want_stats, static_grads=self.grads)
+        model._opt_step += 1
+        model._schedule_mirror = (model._opt_step, model._sample_step)
+        if want_stats:
+            with torch.no_grad():
+                wr = float(sum(0.5 * float((w.detach() ** 2).sum()) for w in self.weights))
+            return self.loss.detach(), self.pred_serial.detach(), wr
+        return None, None, None
 
 
 def _merge_taste_topk(per_taste, k):
