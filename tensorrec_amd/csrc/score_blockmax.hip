@@ -277,6 +277,181 @@ __global__ __launch_bounds__(256, WPS) void blockmax_pipe_kernel(ScoreParams p)
     }
 }
 
+// ---- the exact (fp32) form --------------------------------------------------------------------------------------------
+// Same stage 1 on v_mfma_f32_32x32x2_f32 -- an exact k-ordered fmaf chain, bit-identical to oracle/tr_oracle.c -- with
+// the reference's bias order (s + b_u) + b_i per element before the maximum.  An fp32 MFMA occupies the pipe for 64
+// cycles, so the only thing that matters is that the wave never waits on LDS between them: the generic kernel issues
+// `ds_read_b32; s_waitcnt lgkmcnt(0); MFMA` per k-step (42% of the fp32 MFMA peak); here the item values of the next
+// group of 8 k-steps are read while the current group's 16 MFMAs run.  64 users per wave (128 VGPRs of resident
+// fragments), 64-item tiles of 32 KB, 2 workgroups per CU.
+template <int KT, bool BIAS>
+__global__ __launch_bounds__(256, 2) void blockmax_pipe_f32_kernel(ScoreParams p)
+{
+    constexpr int NCB = 2;
+    constexpr int RB = KT * 4;               // bytes per operand row
+    constexpr int CH = RB / 16;              // 16-byte chunks per row (16 or 32)
+    constexpr int KS = KT / 2;               // MFMA k-steps per block
+    constexpr int G = 8;                     // k-steps per prefetch group
+    constexpr int TILE_BYTES = BN * RB;
+    constexpr int NSLOT = BN * CH / 256;
+    static_assert(KT == 64 || KT == 128, "pipelined fp32 BLOCKMAX covers K = 64 / 128");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];    // [2][TILE_BYTES] item tiles | [2][BN] item biases
+    float* side = (float*)(smem + 2 * TILE_BYTES);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int rblock = blockIdx.x % p.n_rblocks;
+    const int chunk = blockIdx.x / p.n_rblocks;
+    const int64_t r_base = ((int64_t)rblock * 4 + wave) * (NCB * 32);
+    const int64_t t_begin = (int64_t)chunk * p.chunk_len;
+    const int64_t t_end = (t_begin + p.chunk_len < p.n_t) ? t_begin + p.chunk_len : p.n_t;
+    const int n_tiles = (int)((t_end - t_begin + BN - 1) / BN);
+
+    float rff[NCB][KS];
+    float r_bias[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+        int64_t row = r_base + cb * 32 + l31;
+        if (row >= p.n_r) row = p.n_r - 1;
+        const float* src = (const float*)p.R + row * (int64_t)KT;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) rff[cb][ks] = src[2 * ks + half];
+        r_bias[cb] = (BIAS && p.r_bias) ? p.r_bias[row] : 0.f;
+    }
+
+    int slot_off[NSLOT];
+#pragma unroll
+    for (int i = 0; i < NSLOT; ++i) {
+        const int q = i * 256 + tid;
+        const int row = q / CH, pc = q % CH;
+        slot_off[i] = row * RB + ((pc ^ (row & 15)) * 16);
+    }
+    const char* t_chunk = (const char*)p.T + t_begin * (int64_t)RB;
+    float side_b = 0.f;
+    auto stage_issue = [&](int tile, int buf) {
+        const int64_t row0 = t_begin + (int64_t)tile * BN;
+        const bool clamp = row0 + BN > p.n_t;
+        if (BIAS && tid < BN) {
+            int64_t g = row0 + tid;
+            if (g >= p.n_t) g = p.n_t - 1;
+            side_b = p.t_bias ? p.t_bias[g] : 0.f;
+        }
+        const char* tile_base = t_chunk + (int64_t)tile * (BN * RB);
+#pragma unroll
+        for (int i = 0; i < NSLOT; ++i) {
+            int off = slot_off[i];
+            if (clamp) {
+                const int last = (int)(p.n_t - 1 - row0);
+                const int row = (i * 256 + tid) / CH;
+                if (row > last) off -= (row - last) * RB;
+            }
+            char* dst = smem + buf * TILE_BYTES + (i * 256 + wave * 64) * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tile_base + off),
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
+    auto stage_commit = [&](int buf) {
+        if (BIAS && tid < BN) side[buf * BN + tid] = side_b;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+
+    // k-step ks of "my" item row reads element k = 2 ks + half: chunk ks >> 1 (swizzled by row & 15), word 2 (ks & 1) + half
+    const int sw = l31 & 15;
+    const int row_off = l31 * RB + half * 4;
+    auto tf_addr = [&](int ks) { return row_off + (((ks >> 1) ^ sw) * 16) + (ks & 1) * 8; };
+
+    float bm[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) bm[cb] = -INFINITY;
+
+    stage_issue(0, 0);
+    stage_commit(0);
+    __syncthreads();
+
+    for (int t = 0; t < n_tiles; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < n_tiles) stage_issue(t + 1, buf ^ 1);
+        const char* tb = smem + buf * TILE_BYTES;
+        const float* sd = side + buf * BN + 4 * half;
+#pragma unroll 1
+        for (int rb = 0; rb < BN / 32; ++rb) {
+            const char* blk = tb + rb * 32 * RB;
+            f32x16 acc[NCB];
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
+            float cur[G], nxt[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) cur[g] = *(const float*)(blk + tf_addr(g));
+#pragma unroll                       // fully unrolled: the resident fragments must be addressed with constant indices
+            for (int ks0 = 0; ks0 < KS; ks0 += G) {
+                if (ks0 + G < KS) {
+#pragma unroll
+                    for (int g = 0; g < G; ++g) nxt[g] = *(const float*)(blk + tf_addr(ks0 + G + g));
+                }
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb)
+                        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[g], rff[cb][ks0 + g], acc[cb], 0, 0, 0);
+                }
+#pragma unroll
+                for (int g = 0; g < G; ++g) cur[g] = nxt[g];
+            }
+            // epilogue: (s + b_u) + b_i per element (tensorrec/recommendation_graphs.py:41), then the block maximum
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                float m = bm[cb];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 tb4 = {0.f, 0.f, 0.f, 0.f};
+                    if (BIAS) tb4 = *(const f32x4*)(sd + rb * 32 + 8 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc[cb][4 * q + e];
+                        if (BIAS) v = (v + r_bias[cb]) + tb4[e];
+                        m = fmaxf(m, v);
+                    }
+                }
+                bm[cb] = m;
+            }
+        }
+        if (((t + 1) % p.sb_tiles) == 0 || t + 1 == n_tiles) {
+            const int64_t sb = t_begin / ((int64_t)p.sb_tiles * BN) + t / p.sb_tiles;
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                const float v = fmaxf(bm[cb], __shfl_xor(bm[cb], 32, 64));
+                const int64_t u = r_base + cb * 32 + l31;
+                if (half == 0 && u < p.n_r) p.blockmax[sb * p.bm_stride + u] = v;
+                bm[cb] = -INFINITY;
+            }
+        }
+        if (t + 1 < n_tiles) stage_commit(buf ^ 1);
+        __syncthreads();
+    }
+}
+
+template <int KT, bool BIAS>
+int launch_f32(ScoreParams p, int sb_rows, hipStream_t st)
+{
+    constexpr int LDS = 2 * BN * KT * 4 + 2 * BN * 4;
+    auto kern = blockmax_pipe_f32_kernel<KT, BIAS>;
+    static bool attr_set = false;
+    if (!attr_set && LDS > 32 * 1024) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    p.n_rblocks = (int)ceil_div64(p.n_r, 4 * 2 * 32);
+    p.sb_tiles = sb_rows / BN;
+    const unsigned blocks = (unsigned)p.n_rblocks * (unsigned)p.n_chunks;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), LDS, st, p);
+    return trec_check_launch("trec_score_gemm_blockmax (pipelined fp32)");
+}
+
 template <int KT, bool BIAS, int NCB, int WPS, bool OVL = true>
 int launch_one(ScoreParams p, hipStream_t st)
 {
@@ -309,5 +484,15 @@ int launch_blockmax_pipelined(const ScoreParams& p, int kt, hipStream_t st)
     if (kt == 128) return bias ? launch_one<128, true, 2, 2>(p, st) : launch_one<128, false, 2, 2>(p, st);
     if (kt == 64 && shape == 2) return bias ? launch_one<64, true, 2, 3>(p, st) : launch_one<64, false, 2, 3>(p, st);
     if (kt == 64) return bias ? launch_one<64, true, 4, 2, false>(p, st) : launch_one<64, false, 4, 2, false>(p, st);
+    return TREC_ERR_UNSUPPORTED;
+}
+
+// fp32 (exact) operands; sb_rows: the superblock height in item rows (a multiple of 128)
+int launch_blockmax_pipelined_f32(const ScoreParams& p, int kt, int sb_rows, hipStream_t st)
+{
+    if (p.euclid || sb_rows % BN != 0) return TREC_ERR_UNSUPPORTED;
+    const bool bias = p.r_bias || p.t_bias;
+    if (kt == 128) return bias ? launch_f32<128, true>(p, sb_rows, st) : launch_f32<128, false>(p, sb_rows, st);
+    if (kt == 64) return bias ? launch_f32<64, true>(p, sb_rows, st) : launch_f32<64, false>(p, sb_rows, st);
     return TREC_ERR_UNSUPPORTED;
 }

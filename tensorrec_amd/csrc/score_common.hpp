@@ -35,3 +35,5 @@ struct ScoreParams {
 // software-pipelined BLOCKMAX kernel (score_blockmax.hip): bf16 dot / cosine, kpad 64 or 128.  Returns
 // TREC_ERR_UNSUPPORTED when the configuration is not covered (the caller then uses the generic kernel).
 int launch_blockmax_pipelined(const ScoreParams& p, int kt, hipStream_t stream);
+// the exact fp32 form (kpad 64 or 128, dot / cosine); sb_rows = superblock height in item rows
+int launch_blockmax_pipelined_f32(const ScoreParams& p, int kt, int sb_rows, hipStream_t stream);

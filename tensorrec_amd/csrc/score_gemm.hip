@@ -838,6 +838,10 @@ extern "C" int trec_score_gemm_blockmax(const void* users, const void* items, in
         rc = launch_blockmax_pipelined(p, kpad, (hipStream_t)stream);
         if (rc != TREC_ERR_UNSUPPORTED) return rc;
     }
+    if (dtype == 0 && !mode && (kpad == 64 || kpad == 128) && trec_get_tuning("blockmax_pipelined_f32", 1)) {
+        rc = launch_blockmax_pipelined_f32(p, kpad, sb_rows, (hipStream_t)stream);
+        if (rc != TREC_ERR_UNSUPPORTED) return rc;
+    }
     return dispatch_score<EPI_BLOCKMAX, 8>(dtype, kpad, variant, p, (hipStream_t)stream);
 }
 
