@@ -51,6 +51,10 @@ int trec_get_tuning(const char* name, int dflt);
 int trec_spmm_csr(const int64_t* indptr, const int32_t* indices, const float* values, const int32_t* val_perm,
                   int64_t n_rows, int64_t nnz, const float* W, int32_t d, const float* col_bias, int32_t epilogue,
                   int32_t accumulate, float* out, float* out_inv_norm, void* stream);
+/* The same gather over a CSR with packed entries int2 {column, value bits} (trec_group_pairs_by_item, packed mode);
+ * epilogue 0 or 3 (out_rowsum[r] = sum of the row's values); accumulate != 0: out += (and out_rowsum +=).            */
+int trec_spmm_csr_packed(const int64_t* indptr, const void* entries, int64_t n_rows, const float* W, int32_t d,
+                         int32_t epilogue, int32_t accumulate, float* out, float* out_rowsum, void* stream);
 /* project_biases, recommendation_graphs.py:4-19: out[r] = sum_j X[r,j] * beta[j] (fmaf chain in CSR order).
  * beta == NULL: out[r] = sum of the row's (permuted) values -- the bias gradients of the serial predictions, where
  * rows are a user's / an item's pairs; 16 lanes share a row (coalesced), indices are not read.                  */
@@ -156,7 +160,9 @@ int trec_pair_score_bwd(const float* U, const float* V, const int32_t* xu, const
  * entries of workspace_i32 already hold the histogram of xi (trec_wmrb_fused_step counts it while it gathers);
  * ranks (nullable, with counts_given): what those histogram atomics returned, i.e. every pair's position inside its
  * bucket -- the fill pass then needs no atomics; values_in / values_out (nullable, with ranks): the pairs' values are
- * scattered along (values_out[slot] = values_in[pair]) so that the gather reads them in order; perm_t may then be NULL. */
+ * scattered along (values_out[slot] = values_in[pair]) so that the gather reads them in order; perm_t may then be NULL.
+ * values_in with values_out == NULL: PACKED -- users_t is an int2[n_pairs] buffer receiving {user, value bits}, one
+ * 8-byte store per pair; consume it with trec_spmm_csr_packed. */
 int trec_group_pairs_by_item(const int32_t* xu, const int32_t* xi, int64_t n_pairs, int32_t pairs_per_user,
                              int64_t n_items, int32_t* workspace_i32, int64_t* workspace_i64, int64_t* indptr_t,
                              int32_t* users_t, int32_t* perm_t, int32_t counts_given, const int32_t* ranks,

@@ -159,7 +159,8 @@ __global__ __launch_bounds__(256) void seg_fill_small_kernel(const int32_t* __re
 
 // atomic-free fill: the rank of every pair inside its bucket is already known (returned by the histogram atomics)
 // values_in != NULL: the pairs' values travel with them (values_out[slot] = values_in[p]), so the gather that follows reads
-// them in order instead of through perm_t (one random 4-byte read per pair less)
+// them in order instead of through perm_t (one random 4-byte read per pair less); with values_out == NULL they are packed
+// next to the user id -- users_t is then an int2[n_pairs] buffer and every pair costs ONE 8-byte scattered store
 __global__ __launch_bounds__(256) void seg_fill_ranked_kernel(const int32_t* __restrict__ xu, const int32_t* __restrict__ xi,
                                                              const int32_t* __restrict__ ranks, int64_t n_pairs,
                                                              int32_t pairs_per_user, const int64_t* __restrict__ indptr,
@@ -170,7 +171,12 @@ __global__ __launch_bounds__(256) void seg_fill_ranked_kernel(const int32_t* __r
     for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < n_pairs; p += (int64_t)gridDim.x * 256) {
         if (xi[p] < 0) continue;
         const int64_t slot = indptr[xi[p]] + ranks[p];
-        users_t[slot] = xu ? xu[p] : (int32_t)(p / pairs_per_user);
+        const int32_t usr = xu ? xu[p] : (int32_t)(p / pairs_per_user);
+        if (values_in && !values_out) {          // packed: ONE 8-byte scattered store {user, value bits} into users_t
+            ((int2*)users_t)[slot] = make_int2(usr, __float_as_int(values_in[p]));
+            continue;
+        }
+        users_t[slot] = usr;
         if (perm_t) perm_t[slot] = (int32_t)p;
         if (values_in) values_out[slot] = values_in[p];
     }
@@ -187,7 +193,8 @@ extern "C" int trec_group_pairs_by_item(const int32_t* xu, const int32_t* xi, in
 {
     TREC_REQUIRE(xi && workspace_i32 && workspace_i64 && indptr_t && users_t, "trec_group_pairs_by_item: null pointer");
     TREC_REQUIRE(perm_t || (ranks && values_in), "trec_group_pairs_by_item: perm_t may be NULL only when values travel (ranked fill)");
-    TREC_REQUIRE(!values_in == !values_out && (!values_in || ranks), "trec_group_pairs_by_item: values_in/out come together, with ranks");
+    TREC_REQUIRE(!values_in || ranks, "trec_group_pairs_by_item: values travel only with ranks");
+    TREC_REQUIRE(values_in || !values_out, "trec_group_pairs_by_item: values_out without values_in");
     TREC_REQUIRE(xu || pairs_per_user >= 1, "trec_group_pairs_by_item: need xu or pairs_per_user");
     TREC_REQUIRE(n_pairs < ((int64_t)1 << 31) && n_items >= 1, "trec_group_pairs_by_item: n_pairs must fit int32");
     TREC_REQUIRE(!ranks || counts_given, "trec_group_pairs_by_item: ranks come with counts_given");

@@ -27,7 +27,9 @@ __device__ __forceinline__ float subgroup_sum(float v, int lpr) {
 // to out_inv (the bias gradient that accompanies a gradient gather: g summed per row, for free)
 // NT: non-temporal output stores (rows are written once); NTL: non-temporal weight-row loads as well (embedding-style
 // gathers where every weight row is referenced about once, so caching it only evicts useful lines)
-template <int ITERS, int R, int EPI, bool NT = false, bool NTL = false>
+// PACKED: `indices` points at int2 {column, value bits} entries (one 8-byte load per non-zero; values / val_perm unused)
+// -- the layout the counting sort of the fit step writes with ONE scattered store per pair
+template <int ITERS, int R, int EPI, bool NT = false, bool NTL = false, bool PACKED = false>
 __global__ __launch_bounds__(256) void spmm_csr_vec4_kernel(
     const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, const float* __restrict__ values,
     const int32_t* __restrict__ val_perm, int64_t n_rows, const float* __restrict__ W, int d, int lpr_log2,
@@ -70,8 +72,13 @@ __global__ __launch_bounds__(256) void spmm_csr_vec4_kernel(
     for (int r = 0; r < R; ++r) {
         c0[r] = 0; v0[r] = 0.f;
         if (s[r] < e[r]) {
-            c0[r] = indices[s[r]];
-            v0[r] = values[val_perm ? (int64_t)val_perm[s[r]] : s[r]];
+            if (PACKED) {
+                const int2 en = ((const int2*)indices)[s[r]];
+                c0[r] = en.x; v0[r] = __int_as_float(en.y);
+            } else {
+                c0[r] = indices[s[r]];
+                v0[r] = values[val_perm ? (int64_t)val_perm[s[r]] : s[r]];
+            }
         }
     }
     f32x4 x0[R][ITERS];
@@ -102,9 +109,16 @@ __global__ __launch_bounds__(256) void spmm_csr_vec4_kernel(
     for (int r = 0; r < R; ++r) {
         int64_t j = s[r] + 1;
         for (; j + 1 < e[r]; j += 2) {
-            const int32_t ca = indices[j], cb = indices[j + 1];
-            const float va = values[val_perm ? (int64_t)val_perm[j] : j];
-            const float vb = values[val_perm ? (int64_t)val_perm[j + 1] : j + 1];
+            int32_t ca, cb;
+            float va, vb;
+            if (PACKED) {
+                const int2 ea = ((const int2*)indices)[j], eb = ((const int2*)indices)[j + 1];
+                ca = ea.x; va = __int_as_float(ea.y); cb = eb.x; vb = __int_as_float(eb.y);
+            } else {
+                ca = indices[j]; cb = indices[j + 1];
+                va = values[val_perm ? (int64_t)val_perm[j] : j];
+                vb = values[val_perm ? (int64_t)val_perm[j + 1] : j + 1];
+            }
             if (EPI == 3) { vsum[r] += va; vsum[r] += vb; }
             f32x4 xa[ITERS], xb[ITERS];
 #pragma unroll
@@ -124,8 +138,15 @@ __global__ __launch_bounds__(256) void spmm_csr_vec4_kernel(
             }
         }
         if (j < e[r]) {
-            const int32_t ca = indices[j];
-            const float va = values[val_perm ? (int64_t)val_perm[j] : j];
+            int32_t ca;
+            float va;
+            if (PACKED) {
+                const int2 ea = ((const int2*)indices)[j];
+                ca = ea.x; va = __int_as_float(ea.y);
+            } else {
+                ca = indices[j];
+                va = values[val_perm ? (int64_t)val_perm[j] : j];
+            }
             if (EPI == 3) vsum[r] += va;
 #pragma unroll
             for (int it = 0; it < ITERS; ++it)
@@ -351,6 +372,32 @@ static int launch_vec4(const int64_t* indptr, const int32_t* indices, const floa
     }
 #undef TREC_SPMM_LAUNCH
     return trec_check_launch("trec_spmm_csr");
+}
+
+// out (+)= X . W for a CSR whose entries are packed int2 {column, value bits} (what trec_group_pairs_by_item writes in
+// packed mode); long rows (pairs grouped by item): one row per subgroup.  epilogue 0 or 3 (row sums of the values).
+extern "C" int trec_spmm_csr_packed(const int64_t* indptr, const void* entries, int64_t n_rows, const float* W, int32_t d,
+                                    int32_t epilogue, int32_t accumulate, float* out, float* out_rowsum, void* stream)
+{
+    TREC_REQUIRE(indptr && entries && W && out, "trec_spmm_csr_packed: null pointer");
+    TREC_REQUIRE(d >= 4 && d % 4 == 0 && d <= 1024, "trec_spmm_csr_packed: d must be a multiple of 4, <= 1024");
+    TREC_REQUIRE(epilogue == 0 || (epilogue == 3 && out_rowsum), "trec_spmm_csr_packed: epilogue 0 or 3 (+ row-sum output)");
+    if (n_rows == 0) return TREC_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int n4 = d / 4;
+    int lpr_log2 = pow2ceil_log2(n4);
+    if (lpr_log2 > 6) lpr_log2 = 6;
+    const int lpr = 1 << lpr_log2;
+    const int iters = (n4 + lpr - 1) / lpr;
+    const unsigned blocks = (unsigned)ceil_div64(n_rows * lpr, 256);
+    const int32_t* idx = (const int32_t*)entries;
+#define TREC_SPMM_PK(IT, EP)                                                                                          \
+    hipLaunchKernelGGL((spmm_csr_vec4_kernel<IT, 1, EP, false, false, true>), dim3(blocks), dim3(256), 0, st, indptr, idx, \
+                       nullptr, nullptr, n_rows, W, d, lpr_log2, nullptr, accumulate, out, out_rowsum)
+    if (epilogue == 3) { if (iters == 1) TREC_SPMM_PK(1, 3); else if (iters == 2) TREC_SPMM_PK(2, 3); else TREC_SPMM_PK(4, 3); }
+    else { if (iters == 1) TREC_SPMM_PK(1, 0); else if (iters == 2) TREC_SPMM_PK(2, 0); else TREC_SPMM_PK(4, 0); }
+#undef TREC_SPMM_PK
+    return trec_check_launch("trec_spmm_csr_packed");
 }
 
 extern "C" int trec_spmm_csr(const int64_t* indptr, const int32_t* indices, const float* values,

@@ -290,21 +290,26 @@ def group_pairs_by_item(xu32, xi32, pairs_per_user, n_items, workspace_with_coun
     ``workspace_with_counts``: an int32 [2 * n_items] workspace whose first half already holds the histogram of the
     items (counted by the kernel that consumed the pairs) -- the histogram pass is then skipped; ``ranks`` (with it): the
     values those histogram atomics returned, which makes the fill pass atomic-free; ``values`` (with ranks): per-pair
-    values to carry along -- the third result is then the values in bucket order instead of the permutation."""
+    values to carry along -- the result is then (indptr_t, entries int32 [n_pairs, 2] = {user, value bits}, None): one
+    8-byte scattered store per pair, consumed by trec_spmm_csr_packed."""
     dev = xi32.device
     n_pairs = xi32.numel()
     ws32 = workspace_with_counts if workspace_with_counts is not None else \
         torch.empty((2 * n_items,), dtype=torch.int32, device=dev)
     ws64 = torch.empty(((n_items + 1023) // 1024 + 1,), dtype=torch.int64, device=dev)
     indptr_t = torch.empty((n_items + 1,), dtype=torch.int64, device=dev)
-    users_t = torch.empty((n_pairs,), dtype=torch.int32, device=dev)
     carry = values is not None and ranks is not None
-    perm_t = None if carry else torch.empty((n_pairs,), dtype=torch.int32, device=dev)
-    values_t = torch.empty((n_pairs,), dtype=torch.float32, device=dev) if carry else None
+    users_t = None if carry else torch.empty((n_pairs,), dtype=torch.int32, device=dev)
+    if carry:      # packed: entries int2 {user, value bits}, one 8-byte scattered store per pair; (indptr, entries, None)
+        entries = torch.empty((n_pairs, 2), dtype=torch.int32, device=dev)
+        N.call("trec_group_pairs_by_item", N.ptr(xu32), N.ptr(xi32), n_pairs, pairs_per_user, n_items, N.ptr(ws32),
+               N.ptr(ws64), N.ptr(indptr_t), N.ptr(entries), None, 1, N.ptr(ranks), N.ptr(values), None)
+        return indptr_t, entries, None
+    perm_t = torch.empty((n_pairs,), dtype=torch.int32, device=dev)
     N.call("trec_group_pairs_by_item", N.ptr(xu32), N.ptr(xi32), n_pairs, pairs_per_user, n_items, N.ptr(ws32),
            N.ptr(ws64), N.ptr(indptr_t), N.ptr(users_t), N.ptr(perm_t), 1 if workspace_with_counts is not None else 0,
-           N.ptr(ranks), N.ptr(values) if carry else None, N.ptr(values_t))
-    return indptr_t, users_t, (values_t if carry else perm_t)
+           N.ptr(ranks), None, None)
+    return indptr_t, users_t, perm_t
 
 
 _ones_cache = {}
@@ -511,9 +516,11 @@ def wmrb_fused_step(user_in, item_in, user_bias, item_bias, interactions, sample
         indptr_t, users_t, perm_t = interactions.transposed()
         d_v = _spmm_rowsum(indptr_t, users_t, coef_p, perm_t, n_items, nnz, u, epi, False, None, d_ib)
     xs = samples.reshape(-1)
-    ind_s, users_s, coef_t = group_pairs_by_item(None, xs, S, n_items, workspace_with_counts=ws32, ranks=ranks.reshape(-1),
-                                                 values=coef_s.reshape(-1))
-    _spmm_rowsum(ind_s, users_s, coef_t, None, n_items, n_users * S, u, epi, True, d_v, d_ib)
+    ind_s, entries, _ = group_pairs_by_item(None, xs, S, n_items, workspace_with_counts=ws32, ranks=ranks.reshape(-1),
+                                            values=coef_s.reshape(-1))
+    with _timed("spmm_csr"):
+        N.call("trec_spmm_csr_packed", N.ptr(ind_s), N.ptr(entries), n_items, N.ptr(u), d, epi, 1, N.ptr(d_v),
+               N.ptr(d_ib) if epi == EPI_ROWSUM else None)
     return loss, pred, d_u, d_v, d_ub, d_ib
 
 
