@@ -60,6 +60,24 @@ int trec_spmm_csr_packed(const int64_t* indptr, const void* entries, int64_t n_r
  * rows are a user's / an item's pairs; 16 lanes share a row (coalesced), indices are not read.                  */
 int trec_spmv_csr(const int64_t* indptr, const int32_t* indices, const float* values, const int32_t* val_perm,
                   int64_t n_rows, const float* beta, float* out, void* stream);
+/* K1 for skewed row lengths (csrc/spmm_split.hip): the gradient gathers of the fit step run on transposed structures
+ * whose rows are items / feature columns, and real interaction data is Zipf-shaped (one MovieLens-20M item holds
+ * ~136,000 pairs).  Rows longer than the split threshold (2048 non-zeros) are cut into chunks that any subgroup of the
+ * chip can take; a row's chunk partials are added in chunk order, so the result is deterministic.  Rows at or below the
+ * threshold are the CSR-order fmaf chain of trec_spmm_csr, bit for bit.  Either (indices, values[, val_perm]) or
+ * packed_entries (int2 {column, value bits}) describes the non-zeros.  own (nullable, [n_rows, d]): gather
+ * (own[row,:] - W[col,:]) instead of W[col,:] -- the Euclidean pair gradient, prediction_graphs.py:105-117
+ * differentiated, with the coefficients of trec_pair_euclid_coef as values.  out_rowsum (nullable): sums of the rows'
+ * values.  accumulate != 0: out += (and out_rowsum +=).  workspace: trec_csr_split_workspace_bytes(nnz, d) bytes.   */
+int64_t trec_csr_split_workspace_bytes(int64_t nnz, int32_t d);
+int trec_spmm_csr_split(const int64_t* indptr, const int32_t* indices, const float* values, const int32_t* val_perm,
+                        const void* packed_entries, int64_t n_rows, int64_t nnz, const float* W, int32_t d,
+                        const float* own, int32_t accumulate, float* out, float* out_rowsum, void* workspace,
+                        int64_t workspace_bytes, void* stream);
+/* trec_spmv_csr with the same treatment of long rows (workspace: trec_csr_split_workspace_bytes(nnz, 1)) */
+int trec_spmv_csr_split(const int64_t* indptr, const int32_t* indices, const float* values, const int32_t* val_perm,
+                        int64_t n_rows, int64_t nnz, const float* beta, float* out, void* workspace,
+                        int64_t workspace_bytes, void* stream);
 /* tf.sparse_tensor_to_dense, representation_graphs.py:74 (FeaturePassThrough) */
 int trec_csr_to_dense(const int64_t* indptr, const int32_t* indices, const float* values, int64_t n_rows,
                       int32_t n_cols, float* out, void* stream);
@@ -69,11 +87,16 @@ int trec_row_l2norm_bwd(const float* y, const float* inv_norm, const float* dy, 
                         void* stream);
 /* gradient of tf.nn.relu (representation_graphs.py:119) and of the broadcast bias add (column sums) */
 int trec_relu_bwd(const float* out, const float* dout, int64_t n, float* dpre, void* stream);
-int trec_colsum(const float* x, int64_t n_rows, int32_t d, float* out, void* stream);
+/* n_slices > 1: the rows are summed as n_slices slices in parallel (workspace: n_slices * d floats) and the slice sums
+ * added in slice order -- deterministic; n_slices <= 1: one pass, d / 64 workgroups (short matrices) */
+int trec_colsum(const float* x, int64_t n_rows, int32_t d, float* out, float* workspace, int32_t n_slices, void* stream);
 /* tf.matmul(relu, linear_weights), representation_graphs.py:121, and its two gradients:
- * C[M,N] (+)= op(A) . op(B), fp32 on MFMA; trans flags select A^T / B^T (row-major storage, lda/ldb/ldc in elements) */
+ * C[M,N] (+)= op(A) . op(B), fp32 on MFMA; trans flags select A^T / B^T (row-major storage, lda/ldb/ldc in elements).
+ * splits > 1: K is cut into that many slices computed by separate workgroups (the weight gradient has a small output
+ * and K = all users) and added in slice order; workspace: splits * M * N floats (NULL with splits <= 1). */
 int trec_gemm_f32(int32_t trans_a, int32_t trans_b, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
-                  const float* B, int64_t ldb, float* C, int64_t ldc, int32_t accumulate, void* stream);
+                  const float* B, int64_t ldb, float* C, int64_t ldc, int32_t accumulate, float* workspace,
+                  int32_t splits, void* stream);
 
 /* ---- K2: user x item score contraction --------------------------------------------------------------------
  * tf.matmul(user_repr, item_repr, transpose_b=True): prediction_graphs.py:50 (DotProduct), :94 (Euclidean),
@@ -152,6 +175,12 @@ int trec_pair_score_fwd(const float* U, const float* V, const int32_t* xu, const
 int trec_pair_score_bwd(const float* U, const float* V, const int32_t* xu, const int32_t* xi, const float* grad,
                         int64_t n_pairs, int32_t pairs_per_user, int32_t d, int32_t mode, float* dU, float* dV,
                         float* d_user_bias, float* d_item_bias, void* stream);
+
+/* Euclidean pairs, backward: coef[p] = -grad[p] / sqrt(D_p), 0 where D_p < 1e-16 was clamped (tf.maximum passes no
+ * gradient there, prediction_graphs.py:113-115); dU[u] = sum_p coef[p] (U[u] - V[i_p]) and
+ * dV[i] = sum_p coef[p] (V[i] - U[u_p]) are then trec_spmm_csr_split gathers with `own` set. */
+int trec_pair_euclid_coef(const float* U, const float* V, const int32_t* xu, const int32_t* xi, const float* grad,
+                          int64_t n_pairs, int32_t pairs_per_user, int32_t d, float* coef, void* stream);
 
 /* Group a pair list by item (counting sort on the device; pairs with a negative item are skipped): writes the transposed structure (indptr_t[n_items+1],
  * users_t[n_pairs], perm_t[n_pairs]) so that the item-side gradient of sampled serial predictions is the trec_spmm_csr

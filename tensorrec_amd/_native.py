@@ -18,6 +18,8 @@ LIB_PATH = os.path.join(_HERE, "libtensorrec_hip.so")
 _vp, _i32, _i64, _u32, _u64, _f = (ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32,
                                    ctypes.c_uint64, ctypes.c_float)
 
+_RETURNS_I64 = ("trec_csr_split_workspace_bytes",)      # sizing queries that return a byte count
+
 # name -> argtypes, in the order of include/tensorrec_hip.h
 SIGNATURES = {
     "trec_abi_version": [],
@@ -27,12 +29,16 @@ SIGNATURES = {
     "trec_spmm_csr": [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp],
     "trec_spmm_csr_packed": [_vp, _vp, _i64, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
     "trec_spmv_csr": [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp],
+    "trec_csr_split_workspace_bytes": [_i64, _i32],
+    "trec_spmm_csr_split": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _i64, _vp],
+    "trec_spmv_csr_split": [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp],
+    "trec_pair_euclid_coef": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp],
     "trec_csr_to_dense": [_vp, _vp, _vp, _i64, _i32, _vp, _vp],
     "trec_row_l2norm_fwd": [_vp, _i64, _i32, _vp, _vp, _vp],
     "trec_row_l2norm_bwd": [_vp, _vp, _vp, _i64, _i32, _vp, _vp],
     "trec_relu_bwd": [_vp, _vp, _i64, _vp, _vp],
-    "trec_colsum": [_vp, _i64, _i32, _vp, _vp],
-    "trec_gemm_f32": [_i32, _i32, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp],
+    "trec_colsum": [_vp, _i64, _i32, _vp, _vp, _i32, _vp],
+    "trec_gemm_f32": [_i32, _i32, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp, _i32, _vp],
     "trec_score_kpad": [_i32],
     "trec_score_rows_per_workgroup": [_i32, _i32],
     "trec_score_tile_rows": [_i32, _i32],
@@ -101,7 +107,7 @@ def load():
         except AttributeError:
             raise NativeLibraryError("%s does not export %s (stale build?)" % (LIB_PATH, name))
         fn.argtypes = argtypes
-        fn.restype = ctypes.c_int
+        fn.restype = ctypes.c_int64 if name in _RETURNS_I64 else ctypes.c_int
     lib.trec_last_error.argtypes = []
     lib.trec_last_error.restype = ctypes.c_char_p
     _lib = lib

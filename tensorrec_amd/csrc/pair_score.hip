@@ -139,6 +139,28 @@ __global__ __launch_bounds__(256) void pair_score_bwd_kernel(
     }
 }
 
+// c_p = dS_p/dD-chain coefficient of a Euclidean pair: s = -sqrt(max(D, eps)), dS/du = -(u - v)/sqrt(D) -> with the
+// upstream gradient g_p:  dU[u] += c_p (u - v), dV[i] -= c_p (u - v), c_p = -g_p / sqrt(D_p) (0 where D_p was clamped).
+// Same arithmetic as pair_score_bwd_kernel; the accumulation itself then runs as a segmented gather (spmm_split.hip).
+__global__ __launch_bounds__(256) void pair_euclid_coef_kernel(
+    const float* __restrict__ U, const float* __restrict__ V, const int32_t* __restrict__ xu,
+    const int32_t* __restrict__ xi, const float* __restrict__ g, int64_t n_pairs, int32_t pairs_per_user, int d,
+    int lpr_log2, float* __restrict__ coef)
+{
+    const int lpr = 1 << lpr_log2;
+    const int sub_lane = threadIdx.x & (lpr - 1);
+    const int64_t p = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> lpr_log2;
+    if (p >= n_pairs) return;
+    const int64_t u = xu ? (int64_t)xu[p] : p / pairs_per_user;
+    const int64_t i = xi[p];
+    const float* a = U + u * d;
+    const float* b = V + i * d;
+    float acc = 0.f;
+    for (int c = sub_lane; c < d; c += lpr) { const float df = a[c] - b[c]; acc = fmaf(df, df, acc); }
+    for (int off = lpr >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (sub_lane == 0) coef[p] = (acc >= EUCLID_EPS) ? -g[p] / sqrtf(acc) : 0.f;
+}
+
 static void pair_geometry(int d, int& vec, int& lpr_log2)
 {
     vec = (d % 4 == 0) ? 4 : 1;
@@ -200,4 +222,18 @@ extern "C" int trec_pair_score_bwd(const float* U, const float* V, const int32_t
         hipLaunchKernelGGL((pair_score_bwd_kernel<1>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, U, V, xu, xi,
                            grad, n_pairs, pairs_per_user, d, l2, mode, dU, dV, d_user_bias, d_item_bias);
     return trec_check_launch("trec_pair_score_bwd");
+}
+
+extern "C" int trec_pair_euclid_coef(const float* U, const float* V, const int32_t* xu, const int32_t* xi,
+                                     const float* grad, int64_t n_pairs, int32_t pairs_per_user, int32_t d, float* coef,
+                                     void* stream)
+{
+    TREC_REQUIRE(U && V && xi && grad && coef, "trec_pair_euclid_coef: null pointer");
+    TREC_REQUIRE(xu || pairs_per_user >= 1, "trec_pair_euclid_coef: need xu or pairs_per_user");
+    TREC_REQUIRE(d >= 1, "trec_pair_euclid_coef: d must be >= 1");
+    if (n_pairs == 0) return TREC_OK;
+    int vec, l2; pair_geometry(d, vec, l2);
+    hipLaunchKernelGGL(pair_euclid_coef_kernel, dim3((unsigned)ceil_div64(n_pairs << l2, 256)), dim3(256), 0,
+                       (hipStream_t)stream, U, V, xu, xi, grad, n_pairs, pairs_per_user, d, l2, coef);
+    return trec_check_launch("trec_pair_euclid_coef");
 }

@@ -270,19 +270,34 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__
 }
 
 // column sums of a row-major [n_rows, d] matrix (gradient of the broadcast ReLU bias).
-// grid.x = column tiles of 64, each block walks rows with 4 waves then combines through LDS.
+// grid = (column tiles of 64, row slices): each block walks its slice of the rows with 4 waves and combines them through
+// LDS; with more than one slice the per-slice sums go to a workspace and colsum_finish_kernel adds them in slice order
+// (deterministic).  One slice (no workspace) is the whole job in one launch -- d / 64 workgroups, fine for short
+// matrices only: 16 workgroups took 8.7 ms over a 138k x 1024 matrix that the chip reads in 0.1 ms.
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int64_t n_rows, int d,
-                                                    float* __restrict__ out)
+                                                    int64_t rows_per_slice, float* __restrict__ out)
 {
     __shared__ float part[4][64];
     const int lane = lane_id(), w = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_slice;
+    const int64_t r1 = r0 + rows_per_slice < n_rows ? r0 + rows_per_slice : n_rows;
     float acc = 0.f;
     if (c < d)
-        for (int64_t r = w; r < n_rows; r += 4) acc += x[r * (int64_t)d + c];
+        for (int64_t r = r0 + w; r < r1; r += 4) acc += x[r * (int64_t)d + c];
     part[w][lane] = acc;
     __syncthreads();
-    if (w == 0 && c < d) out[c] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    if (w == 0 && c < d) out[(int64_t)blockIdx.y * d + c] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+}
+
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ partial, int n_slices, int d,
+                                                           float* __restrict__ out)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d) return;
+    float acc = 0.f;
+    for (int s = 0; s < n_slices; ++s) acc += partial[(int64_t)s * d + c];
+    out[c] = acc;
 }
 
 // b[r] = sum_j X[r,j] * beta[j]   (project_biases, recommendation_graphs.py:4-19), fmaf in CSR order
@@ -471,10 +486,21 @@ extern "C" int trec_relu_bwd(const float* out, const float* dout, int64_t n, flo
     return trec_check_launch("trec_relu_bwd");
 }
 
-extern "C" int trec_colsum(const float* x, int64_t n_rows, int32_t d, float* out, void* stream)
+extern "C" int trec_colsum(const float* x, int64_t n_rows, int32_t d, float* out, float* workspace, int32_t n_slices,
+                           void* stream)
 {
     TREC_REQUIRE(x && out && d >= 1, "trec_colsum: bad arguments");
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((d + 63) / 64)), dim3(256), 0, (hipStream_t)stream, x, n_rows, d,
+    TREC_REQUIRE(n_slices <= 1 || workspace, "trec_colsum: n_slices > 1 needs a workspace of n_slices * d floats");
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned tiles = (unsigned)((d + 63) / 64);
+    if (n_slices <= 1) {
+        hipLaunchKernelGGL(colsum_kernel, dim3(tiles), dim3(256), 0, st, x, n_rows, d, n_rows, out);
+        return trec_check_launch("trec_colsum");
+    }
+    const int64_t rows_per_slice = ceil_div64(n_rows, n_slices);
+    hipLaunchKernelGGL(colsum_kernel, dim3(tiles, (unsigned)n_slices), dim3(256), 0, st, x, n_rows, d, rows_per_slice,
+                       workspace);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, st, workspace, n_slices, d,
                        out);
     return trec_check_launch("trec_colsum");
 }

@@ -59,9 +59,63 @@ def spmm_raw(indptr, indices, values, perm, n_rows, nnz, w, col_bias=None, epilo
     return (out, inv) if want_inv else out
 
 
+# rows longer than this are cut into chunks by the split gathers (csrc/spmm_split.hip: SPLIT_T_DEFAULT)
+SPLIT_T = 2048
+# uniform samples: a bucket of mean m holds at most ~m + 4.5 sqrt(m) pairs; above this mean some bucket passes SPLIT_T
+_SPLIT_MEAN = 1700
+
+
+def _split_workspace(nnz, d, dev):
+    nbytes = N.query("trec_csr_split_workspace_bytes", int(nnz), int(d))
+    return torch.empty((nbytes,), dtype=torch.uint8, device=dev), nbytes
+
+
+def spmm_split(indptr, indices, values, perm, n_rows, nnz, w, own=None, accumulate=False, out=None, want_rowsum=False,
+               packed=None):
+    """K1 for skewed row lengths (trec_spmm_csr_split): rows of more than SPLIT_T non-zeros are summed as chunks by the
+    whole chip; ``own``: gather (own[row] - w[col]) -- the Euclidean pair gradient."""
+    w = _f32c(w)
+    d = w.shape[1]
+    if out is None:
+        out = torch.empty((n_rows, d), dtype=torch.float32, device=w.device)
+    rowsum = torch.empty((n_rows,), dtype=torch.float32, device=w.device) if want_rowsum is True else \
+        (want_rowsum if isinstance(want_rowsum, torch.Tensor) else None)
+    ws, nbytes = _split_workspace(nnz, d, w.device)
+    own = _f32c(own) if own is not None else None
+    with _timed("spmm_csr_split"):
+        N.call("trec_spmm_csr_split", N.ptr(indptr), N.ptr(indices), N.ptr(values), N.ptr(perm), N.ptr(packed), n_rows,
+               nnz, N.ptr(w), d, N.ptr(own), 1 if accumulate else 0, N.ptr(out), N.ptr(rowsum), N.ptr(ws), nbytes)
+    return (out, rowsum) if want_rowsum is True else out
+
+
+def spmv_raw(indptr, indices, values, perm, n_rows, nnz, beta, long_rows=False):
+    """out[r] = sum_j values[j] * beta[indices[j]] (beta None: plain segment sums); ``long_rows``: some row may exceed
+    SPLIT_T non-zeros -> the chunked form."""
+    out = torch.empty((n_rows,), dtype=torch.float32, device=indptr.device)
+    if long_rows:
+        ws, nbytes = _split_workspace(nnz, 1, indptr.device)
+        N.call("trec_spmv_csr_split", N.ptr(indptr), N.ptr(indices), N.ptr(values), N.ptr(perm), n_rows, nnz,
+               N.ptr(beta), N.ptr(out), N.ptr(ws), nbytes)
+    else:
+        N.call("trec_spmv_csr", N.ptr(indptr), N.ptr(indices), N.ptr(values), N.ptr(perm), n_rows, N.ptr(beta),
+               N.ptr(out))
+    return out
+
+
+def _sampled_buckets_long(n_pairs, n_items):
+    """pairs grouped by sampled item on the device: bucket sizes are not known to the host.  Uniform samples stay under
+    SPLIT_T up to a mean of _SPLIT_MEAN; large problems take the split form regardless (three small extra launches) so
+    that a skewed custom sampler does not serialise on its popular items."""
+    return n_pairs >= (1 << 20) or n_pairs > n_items * _SPLIT_MEAN
+
+
 def _spmm_t(feats: SparseFeatures, dout):
-    """dW[F, d] = X^T . dOut -- the same gather kernel on the transposed CSR."""
+    """dW[F, d] = X^T . dOut -- the same gather kernel on the transposed CSR (chunked where a feature column is long:
+    indicator columns of side features hold thousands of rows)."""
     indptr_t, rows_t, perm_t = feats.transposed()
+    d = dout.shape[1]
+    if feats.max_col_nnz > SPLIT_T and d % 4 == 0 and d <= 1024:
+        return spmm_split(indptr_t, rows_t, feats.values, perm_t, feats.shape[1], feats.nnz, dout)
     return spmm_raw(indptr_t, rows_t, feats.values, perm_t, feats.shape[1], feats.nnz, dout)
 
 
@@ -109,9 +163,18 @@ class _SpMMBiasRelu(torch.autograd.Function):
         (out,) = ctx.saved_tensors
         dpre = torch.empty_like(out)
         N.call("trec_relu_bwd", N.ptr(out), N.ptr(_f32c(dout)), out.numel(), N.ptr(dpre))
-        dbias = torch.empty((out.shape[1],), dtype=torch.float32, device=out.device)
-        N.call("trec_colsum", N.ptr(dpre), out.shape[0], out.shape[1], N.ptr(dbias))
-        return _spmm_t(ctx.feats, dpre), dbias.reshape(ctx.bias_shape), None
+        return _spmm_t(ctx.feats, dpre), colsum(dpre).reshape(ctx.bias_shape), None
+
+
+def colsum(x):
+    """Column sums of a [n_rows, d] matrix (gradient of a broadcast bias): row slices in parallel, added in slice order."""
+    x = _f32c(x)
+    n_rows, d = x.shape
+    out = torch.empty((d,), dtype=torch.float32, device=x.device)
+    n_slices = max(1, min(512, n_rows // 256))
+    ws = torch.empty((n_slices, d), dtype=torch.float32, device=x.device) if n_slices > 1 else None
+    N.call("trec_colsum", N.ptr(x), n_rows, d, N.ptr(out), N.ptr(ws), n_slices)
+    return out
 
 
 def sparse_dense_matmul(feats: SparseFeatures, w):
@@ -132,18 +195,15 @@ class _SpMV(torch.autograd.Function):
     def forward(ctx, beta, feats):
         ctx.feats = feats
         ctx.beta_shape = beta.shape
-        out = torch.empty((feats.shape[0],), dtype=torch.float32, device=beta.device)
-        N.call("trec_spmv_csr", N.ptr(feats.indptr), N.ptr(feats.indices), N.ptr(feats.values), None, feats.shape[0],
-               N.ptr(_f32c(beta).reshape(-1)), N.ptr(out))
-        return out
+        return spmv_raw(feats.indptr, feats.indices, feats.values, None, feats.shape[0], feats.nnz,
+                        _f32c(beta).reshape(-1), feats.max_row_nnz > SPLIT_T)
 
     @staticmethod
     def backward(ctx, dout):
         feats = ctx.feats
         indptr_t, rows_t, perm_t = feats.transposed()
-        dbeta = torch.empty((feats.shape[1],), dtype=torch.float32, device=dout.device)
-        N.call("trec_spmv_csr", N.ptr(indptr_t), N.ptr(rows_t), N.ptr(feats.values), N.ptr(perm_t), feats.shape[1],
-               N.ptr(_f32c(dout)), N.ptr(dbeta))
+        dbeta = spmv_raw(indptr_t, rows_t, feats.values, perm_t, feats.shape[1], feats.nnz, _f32c(dout),
+                         feats.max_col_nnz > SPLIT_T)
         return dbeta.reshape(ctx.beta_shape), None
 
 
@@ -187,8 +247,13 @@ def gemm_raw(a, b, trans_a=False, trans_b=False):
     k = a.shape[0] if trans_a else a.shape[1]
     n = b.shape[0] if trans_b else b.shape[1]
     c = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    # few output tiles and a long K (dW2 = Relu^T . dOut: [relu_size, n_components] over all users): split K so that the
+    # launch has ~1024 workgroups; the slices are added in order (deterministic)
+    tiles = ((m + 127) // 128) * ((n + 127) // 128)
+    splits = max(1, min(1024 // max(tiles, 1), k // 512)) if tiles < 512 else 1
+    ws = torch.empty((splits, m, n), dtype=torch.float32, device=a.device) if splits > 1 else None
     N.call("trec_gemm_f32", 1 if trans_a else 0, 1 if trans_b else 0, m, n, k, N.ptr(a), a.shape[1], N.ptr(b),
-           b.shape[1], N.ptr(c), n, 0)
+           b.shape[1], N.ptr(c), n, 0, N.ptr(ws), splits)
     return c
 
 
@@ -218,12 +283,15 @@ def _idx32(x):
 
 
 class _PairScore(torch.autograd.Function):
-    """Forward: K3.  Backward for dot products:
+    """Forward: K3.  Backward, for structured pair lists (a user's pairs are consecutive):
       * user side -- pairs are user-major (CSR over users: interactions, or S consecutive samples per user), so
         dU = G . V is the K1 gather kernel with the pair gradients as values: deterministic, no atomics;
-      * item side -- for interactions the transposed structure makes dV = G^T . U the same kernel; for sampled pairs
-        (random items, no structure) fp32 atomics (K3 bwd) remain.
-    Euclidean pairs and unstructured index tensors use the atomic kernel for both sides."""
+      * item side -- dV = G^T . U is the same kernel on the pairs grouped by item: interactions carry that structure,
+        sampled pairs (random items) are grouped by a counting sort on the device;
+      * Euclidean pairs: the values are c_p = -g_p / sqrt(D_p) (trec_pair_euclid_coef) and every gathered row is
+        (own - other), i.e. dU[u] = sum_p c_p (U[u] - V[i_p]), dV[i] = sum_p c_p (V[i] - U[u_p]);
+      * rows longer than SPLIT_T pairs (popular items of Zipf-shaped data) are summed as chunks (spmm_split.hip).
+    Unstructured index tensors use the atomic kernel for both sides."""
 
     @staticmethod
     def forward(ctx, u, v, ub, ib, xu32, xi32, pairs_per_user, mode, inter):
@@ -243,7 +311,8 @@ class _PairScore(torch.autograd.Function):
         g = _f32c(g)
         n_pairs = xi32.numel()
         n_users, n_items, dev = u.shape[0], v.shape[0], u.device
-        structured = mode == MODE_DOT and (ppu > 0 or inter is not None)
+        d = u.shape[1]
+        structured = (ppu > 0 or inter is not None) and (mode == MODE_DOT or (d % 4 == 0 and d <= 1024))
         if not structured:
             du, dv = torch.zeros_like(u), torch.zeros_like(v)
             dub = torch.zeros((n_users,), dtype=torch.float32, device=dev) if has_ub else None
@@ -251,36 +320,37 @@ class _PairScore(torch.autograd.Function):
             N.call("trec_pair_score_bwd", N.ptr(u), N.ptr(v), N.ptr(xu32), N.ptr(xi32), N.ptr(g), n_pairs, ppu,
                    u.shape[1], mode, N.ptr(du), N.ptr(dv), N.ptr(dub), N.ptr(dib))
             return du, dv, dub, dib, None, None, None, None, None
+        euclid = mode == MODE_EUCLIDEAN
+        vals = g
+        if euclid:       # dU[u] = sum_p c_p (U[u] - V[i_p]),  dV[i] = sum_p c_p (V[i] - U[u_p])
+            vals = torch.empty_like(g)
+            N.call("trec_pair_euclid_coef", N.ptr(u), N.ptr(v), N.ptr(xu32), N.ptr(xi32), N.ptr(g), n_pairs, ppu, d,
+                   N.ptr(vals))
+        can_split = d % 4 == 0 and d <= 1024
         # ---- user side: segmented gather over each user's pairs (K1 with values = g)
         if inter is not None:
-            indptr_u = inter.indptr
+            indptr_u, long_u = inter.indptr, inter.max_row_nnz > SPLIT_T
         else:
             indptr_u = torch.arange(0, (n_users + 1) * ppu, ppu, dtype=torch.int64, device=dev)
-        du = spmm_raw(indptr_u, xi32, g, None, n_users, n_pairs, v)
-        dub = None
-        if has_ub:
-            dub = torch.empty((n_users,), dtype=torch.float32, device=dev)
-            N.call("trec_spmv_csr", N.ptr(indptr_u), N.ptr(xi32), N.ptr(g), None, n_users,
-                   None, N.ptr(dub))
-        # ---- item side
+            long_u = ppu > SPLIT_T
+        if euclid or (long_u and can_split):
+            du = spmm_split(indptr_u, xi32, vals, None, n_users, n_pairs, v, own=u if euclid else None)
+        else:
+            du = spmm_raw(indptr_u, xi32, vals, None, n_users, n_pairs, v)
+        dub = spmv_raw(indptr_u, xi32, g, None, n_users, n_pairs, None, long_u) if has_ub else None
+        # ---- item side: interactions carry their transposed structure; sampled pairs (random items, no structure) are
+        # grouped by item on the device (counting sort) -- then the same segmented gather instead of n_pairs * d atomics
         if inter is not None:
             indptr_t, users_t, perm_t = inter.transposed()
-            dv = spmm_raw(indptr_t, users_t, g, perm_t, n_items, n_pairs, u)
-            dib = None
-            if has_ib:
-                dib = torch.empty((n_items,), dtype=torch.float32, device=dev)
-                N.call("trec_spmv_csr", N.ptr(indptr_t), N.ptr(users_t), N.ptr(g), N.ptr(perm_t), n_items,
-                       None, N.ptr(dib))
+            long_i = inter.max_col_nnz > SPLIT_T
         else:
-            # sampled pairs: items are random -> group the pairs by item on the device (counting sort), then the same
-            # segmented gather; replaces n_pairs * d fp32 atomics
             indptr_t, users_t, perm_t = group_pairs_by_item(xu32, xi32, ppu, n_items)
-            dv = spmm_raw(indptr_t, users_t, g, perm_t, n_items, n_pairs, u)
-            dib = None
-            if has_ib:
-                dib = torch.empty((n_items,), dtype=torch.float32, device=dev)
-                N.call("trec_spmv_csr", N.ptr(indptr_t), N.ptr(users_t), N.ptr(g), N.ptr(perm_t), n_items,
-                       None, N.ptr(dib))
+            long_i = _sampled_buckets_long(n_pairs, n_items)
+        if euclid or (long_i and can_split):
+            dv = spmm_split(indptr_t, users_t, vals, perm_t, n_items, n_pairs, u, own=v if euclid else None)
+        else:
+            dv = spmm_raw(indptr_t, users_t, vals, perm_t, n_items, n_pairs, u)
+        dib = spmv_raw(indptr_t, users_t, g, perm_t, n_items, n_pairs, None, long_i) if has_ib else None
         return du, dv, dub, dib, None, None, None, None, None
 
 
@@ -354,15 +424,13 @@ def _pair_bias_grads(g, xu32, xi32, ppu, inter, n_users, n_items, want_ub, want_
     if want_ub:
         indptr_u = inter.indptr if inter is not None else \
             torch.arange(0, (n_users + 1) * ppu, ppu, dtype=torch.int64, device=dev)
-        dub = torch.empty((n_users,), dtype=torch.float32, device=dev)
-        N.call("trec_spmv_csr", N.ptr(indptr_u), N.ptr(xi32), N.ptr(g), None, n_users, None,
-               N.ptr(dub))
+        long_u = (inter.max_row_nnz if inter is not None else ppu) > SPLIT_T
+        dub = spmv_raw(indptr_u, xi32, g, None, n_users, n_pairs, None, long_u)
     if want_ib:
         indptr_t, users_t, perm_t = inter.transposed() if inter is not None else \
             group_pairs_by_item(xu32, xi32, ppu, n_items)
-        dib = torch.empty((n_items,), dtype=torch.float32, device=dev)
-        N.call("trec_spmv_csr", N.ptr(indptr_t), N.ptr(users_t), N.ptr(g), N.ptr(perm_t), n_items,
-               None, N.ptr(dib))
+        long_i = inter.max_col_nnz > SPLIT_T if inter is not None else _sampled_buckets_long(n_pairs, n_items)
+        dib = spmv_raw(indptr_t, users_t, g, perm_t, n_items, n_pairs, None, long_i)
     return dub, dib
 
 
@@ -407,8 +475,7 @@ class _CollapseTastes(torch.autograd.Function):
             if n_ub is not None:
                 dub = gemm_raw(g2, _ones(span, g.device).reshape(span, 1)).reshape(-1)
             if n_ib is not None:
-                dib = torch.empty((span,), dtype=torch.float32, device=g.device)
-                N.call("trec_colsum", N.ptr(g2), g2.shape[0], span, N.ptr(dib))
+                dib = colsum(g2)
         return d_preds, d_attn, dub, dib, None
 
 
@@ -512,15 +579,23 @@ def wmrb_fused_step(user_in, item_in, user_bias, item_bias, interactions, sample
     d_ib = torch.zeros((n_items,), dtype=torch.float32, device=dev) if ib is not None else None
     # (epilogue 3 of K1: the row sums of the gathered coefficients = d b_i come out of the same pass)
     epi = EPI_ROWSUM if ib is not None else EPI_NONE
+    rowsum = d_ib if epi == EPI_ROWSUM else None
     if nnz:
         indptr_t, users_t, perm_t = interactions.transposed()
-        d_v = _spmm_rowsum(indptr_t, users_t, coef_p, perm_t, n_items, nnz, u, epi, False, None, d_ib)
+        if interactions.max_col_nnz > SPLIT_T:           # popular items: their pairs are summed as chunks
+            d_v = spmm_split(indptr_t, users_t, coef_p, perm_t, n_items, nnz, u, want_rowsum=rowsum)
+        else:
+            d_v = _spmm_rowsum(indptr_t, users_t, coef_p, perm_t, n_items, nnz, u, epi, False, None, d_ib)
     xs = samples.reshape(-1)
     ind_s, entries, _ = group_pairs_by_item(None, xs, S, n_items, workspace_with_counts=ws32, ranks=ranks.reshape(-1),
                                             values=coef_s.reshape(-1))
-    with _timed("spmm_csr"):
-        N.call("trec_spmm_csr_packed", N.ptr(ind_s), N.ptr(entries), n_items, N.ptr(u), d, epi, 1, N.ptr(d_v),
-               N.ptr(d_ib) if epi == EPI_ROWSUM else None)
+    if xs.numel() > n_items * _SPLIT_MEAN:               # few items: every bucket of samples is long
+        spmm_split(ind_s, None, None, None, n_items, xs.numel(), u, accumulate=True, out=d_v, want_rowsum=rowsum,
+                   packed=entries)
+    else:
+        with _timed("spmm_csr"):
+            N.call("trec_spmm_csr_packed", N.ptr(ind_s), N.ptr(entries), n_items, N.ptr(u), d, epi, 1, N.ptr(d_v),
+                   N.ptr(rowsum))
     return loss, pred, d_u, d_v, d_ub, d_ib
 
 

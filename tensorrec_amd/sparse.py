@@ -39,6 +39,9 @@ class SparseFeatures(object):
         self.indptr = _dev(m.indptr.astype(np.int64), self.device)
         self.indices = _dev(m.indices.astype(np.int32), self.device)
         self.values = _dev(m.data.astype(np.float32), self.device)
+        # longest row / column: the gathers switch to their chunked form above ops.SPLIT_T non-zeros
+        self.max_row_nnz = int(np.diff(m.indptr).max()) if m.shape[0] and m.nnz else 0
+        self.max_col_nnz = int(np.bincount(m.indices, minlength=1).max()) if m.nnz else 0
         self._t = None
 
     @property
@@ -101,6 +104,7 @@ class Interactions(object):
         pos_slot[pos] = np.arange(int(pos.sum()), dtype=np.int32)
         self.n_positive = int(pos.sum())
         self.max_row_nnz = int(np.diff(m.indptr).max()) if m.shape[0] and m.nnz else 0
+        self.max_col_nnz = int(np.bincount(m.indices, minlength=1).max()) if m.nnz else 0     # the most popular item
         self.indptr = _dev(indptr, self.device)
         self.x_user = _dev(coo_rows, self.device)
         self.x_item = _dev(m.indices.astype(np.int64), self.device)

@@ -1,0 +1,229 @@
+"""Skewed (Zipf-shaped) data: the chunked gathers of csrc/spmm_split.hip, the structured Euclidean pair gradient, the
+sliced column sums and the split-K GEMM -- the kernels a MovieLens-20M-shaped fit (BASELINE.json configs[4]) leans on.
+
+Bars: rows at or below the split threshold are the CSR-order fmaf chain bit for bit (== trec_spmm_csr == the oracle);
+longer rows are sums of chunk chains added in chunk order: deterministic (two runs agree bit for bit), and within 1e-5
+relative of the float64 result."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from tensorrec_amd import ops as _ops, _native
+    _native.require_gpu()
+    _native.load()
+    return _ops
+
+
+@pytest.fixture
+def small_split():
+    """split threshold 16 (chunks of 8) so that small matrices have long rows"""
+    from tensorrec_amd import _native
+    _native.set_tuning("split_t", 16)
+    yield 16
+    _native.set_tuning("split_t", 2048)
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def skewed_csr(n_rows, n_cols, seed, long_rows=(0, 7, 41), long_nnz=(17, 100, 1000)):
+    """short random rows, a few empty, and some rows far above the (small) split threshold"""
+    rng = np.random.default_rng(seed)
+    rows, cols, vals = [], [], []
+    for r in range(n_rows):
+        n = int(rng.integers(0, 12))
+        if r in long_rows:
+            n = min(n_cols, long_nnz[long_rows.index(r)])
+        if r in (3, n_rows - 1):
+            n = 0
+        c = rng.choice(n_cols, size=n, replace=False)
+        rows += [r] * n
+        cols += list(c)
+        vals += list(rng.standard_normal(n).astype(np.float32))
+    m = sp.csr_matrix((np.array(vals, np.float32), (rows, cols)), shape=(n_rows, n_cols))
+    m.sort_indices()
+    return m
+
+
+@pytest.mark.parametrize("d", [4, 64, 128, 256, 1024, 100])
+def test_split_spmm_short_rows_exact_long_rows_close_and_deterministic(ops, small_split, d):
+    rng = np.random.default_rng(d)
+    x = skewed_csr(120, 1500, seed=d)
+    w = rng.standard_normal((1500, d)).astype(np.float32)
+    indptr, idx, val = dev(x.indptr.astype(np.int64)), dev(x.indices.astype(np.int32)), dev(x.data)
+    wt = dev(w)
+    got, rs = ops.spmm_split(indptr, idx, val, None, 120, x.nnz, wt, want_rowsum=True)
+    again, rs2 = ops.spmm_split(indptr, idx, val, None, 120, x.nnz, wt, want_rowsum=True)
+    assert torch.equal(got, again) and torch.equal(rs, rs2)                      # no scheduling dependence
+    got, rs = got.cpu().numpy(), rs.cpu().numpy()
+    exact = O.spmm_exact(x, w)
+    nnz_row = np.diff(x.indptr)
+    short = nnz_row <= small_split
+    assert (~short).sum() == 3
+    assert np.array_equal(got[short], exact[short])                              # the fmaf chain of trec_spmm_csr
+    ref = (x.astype(np.float64) @ w.astype(np.float64))
+    assert np.allclose(got, ref, rtol=1e-5, atol=1e-4)
+    assert np.allclose(rs, np.asarray(x.sum(axis=1)).reshape(-1), rtol=1e-5, atol=1e-5)
+    # accumulate: out += result, rowsum += sums
+    base = rng.standard_normal((120, d)).astype(np.float32)
+    out, rsum = dev(base), dev(np.ones(120, np.float32))
+    ops.spmm_split(indptr, idx, val, None, 120, x.nnz, wt, accumulate=True, out=out, want_rowsum=rsum)
+    assert np.allclose(out.cpu().numpy(), base + ref, rtol=1e-5, atol=1e-4)
+    assert np.allclose(rsum.cpu().numpy(), 1.0 + np.asarray(x.sum(axis=1)).reshape(-1), rtol=1e-5, atol=1e-5)
+
+
+def test_split_spmm_permuted_values_packed_entries_and_own(ops, small_split):
+    rng = np.random.default_rng(5)
+    d = 128
+    x = skewed_csr(90, 700, seed=9, long_nnz=(17, 100, 700))
+    w = rng.standard_normal((700, d)).astype(np.float32)
+    own = rng.standard_normal((90, d)).astype(np.float32)
+    indptr, idx = dev(x.indptr.astype(np.int64)), dev(x.indices.astype(np.int32))
+    perm = rng.permutation(x.nnz).astype(np.int32)
+    scrambled = np.empty(x.nnz, np.float32)
+    scrambled[perm] = x.data                                                     # entry j carries values[perm[j]]
+    a = ops.spmm_split(indptr, idx, dev(x.data), None, 90, x.nnz, dev(w))
+    b = ops.spmm_split(indptr, idx, dev(scrambled), dev(perm), 90, x.nnz, dev(w))
+    entries = np.stack([x.indices.astype(np.int32), x.data.view(np.int32)], axis=1)
+    c = ops.spmm_split(indptr, None, None, None, 90, x.nnz, dev(w), packed=dev(entries))
+    assert torch.equal(a, b) and torch.equal(a, c)
+    # own: sum_j v_j (own[row] - w[col_j])
+    got = ops.spmm_split(indptr, idx, dev(x.data), None, 90, x.nnz, dev(w), own=dev(own)).cpu().numpy()
+    rowsum = np.asarray(x.astype(np.float64).sum(axis=1)).reshape(-1, 1)
+    l1 = np.asarray(abs(x).astype(np.float64).sum(axis=1)).reshape(-1, 1)
+    ref = rowsum * own.astype(np.float64) - x.astype(np.float64) @ w.astype(np.float64)
+    assert np.abs(got - ref).max() <= 1e-5 * (l1 * 8).max()
+
+
+def test_split_spmv_and_segment_sums(ops, small_split):
+    from tensorrec_amd import _native as N
+    rng = np.random.default_rng(2)
+    x = skewed_csr(150, 900, seed=1, long_nnz=(17, 200, 900))
+    beta = rng.standard_normal(900).astype(np.float32)
+    indptr, idx, val = dev(x.indptr.astype(np.int64)), dev(x.indices.astype(np.int32)), dev(x.data)
+    short = np.diff(x.indptr) <= small_split
+    for b in (dev(beta), None):
+        got = ops.spmv_raw(indptr, idx, val, None, 150, x.nnz, b, long_rows=True)
+        assert torch.equal(got, ops.spmv_raw(indptr, idx, val, None, 150, x.nnz, b, long_rows=True))
+        plain = ops.spmv_raw(indptr, idx, val, None, 150, x.nnz, b, long_rows=False).cpu().numpy()
+        got = got.cpu().numpy()
+        assert np.array_equal(got[short], plain[short])                          # the same chains as trec_spmv_csr
+        ref = x.astype(np.float64) @ beta.astype(np.float64) if b is not None else \
+            np.asarray(x.astype(np.float64).sum(axis=1)).reshape(-1)
+        assert np.allclose(got, ref, rtol=1e-5, atol=1e-4)
+    assert N.query("trec_csr_split_workspace_bytes", -1, 4) == -1
+
+
+def test_default_threshold_leaves_ordinary_matrices_bit_exact(ops):
+    """split threshold 2048: a matrix without long rows goes through the split entry point unchanged, bit for bit"""
+    rng = np.random.default_rng(0)
+    x = sp.random(300, 200, density=0.2, random_state=3, dtype=np.float32, format="csr")
+    w = rng.standard_normal((200, 64)).astype(np.float32)
+    got = ops.spmm_split(dev(x.indptr.astype(np.int64)), dev(x.indices.astype(np.int32)), dev(x.data), None, 300, x.nnz,
+                         dev(w)).cpu().numpy()
+    assert np.array_equal(got, O.spmm_exact(x, w))
+
+
+def test_transposed_feature_gradient_with_a_long_column(ops):
+    """dW = X^T . dOut where one indicator column holds 5000 rows (> 2048): the autograd path picks the chunked gather"""
+    from tensorrec_amd.sparse import SparseFeatures
+    rng = np.random.default_rng(4)
+    n, f, d = 6000, 50, 64
+    rows = np.concatenate([np.arange(n), rng.choice(n, 5000, replace=False)])
+    cols = np.concatenate([rng.integers(1, f, n), np.zeros(5000, np.int64)])
+    x = sp.csr_matrix((rng.standard_normal(rows.size).astype(np.float32), (rows, cols)), shape=(n, f))
+    x.sum_duplicates()
+    feats = SparseFeatures(x, "cuda")
+    assert feats.max_col_nnz >= 5000 and feats.max_row_nnz <= 2
+    w = dev(rng.standard_normal((f, d)).astype(np.float32)).requires_grad_(True)
+    beta = dev(rng.standard_normal(f).astype(np.float32)).requires_grad_(True)
+    g = rng.standard_normal((n, d)).astype(np.float32)
+    gb = rng.standard_normal(n).astype(np.float32)
+    ops.sparse_dense_matmul(feats, w).backward(dev(g))
+    ops.sparse_matvec(feats, beta).backward(dev(gb))
+    ref = x.T.astype(np.float64) @ g.astype(np.float64)
+    assert np.allclose(w.grad.cpu().numpy(), ref, rtol=1e-5, atol=1e-3)
+    assert np.allclose(beta.grad.cpu().numpy(), x.T.astype(np.float64) @ gb.astype(np.float64), rtol=1e-5, atol=1e-3)
+
+
+@pytest.mark.parametrize("d", [32, 128, 256])
+@pytest.mark.parametrize("layout", ["interactions", "samples"])
+def test_euclidean_pair_gradient_structured_equals_autograd(ops, d, layout):
+    """The structured Euclidean backward (coefficients + (own - other) gathers) against torch autograd on the CPU and
+    against the atomic kernel; one popular item holds more pairs than the split threshold."""
+    from tensorrec_amd.sparse import Interactions, PairIndex
+    from tensorrec_amd import _native as N
+    rng = np.random.default_rng(d)
+    nu, ni = 3000, 40
+    u = rng.standard_normal((nu, d)).astype(np.float32)
+    v = rng.standard_normal((ni, d)).astype(np.float32)
+    v[5] = u[7]                                                   # a clamped pair (distance 0): no gradient
+    ub, ib = rng.standard_normal(nu).astype(np.float32), rng.standard_normal(ni).astype(np.float32)
+    if layout == "interactions":
+        m = sp.random(nu, ni, density=0.1, random_state=1, dtype=np.float32, format="lil")
+        m[:, 0] = 1.0                                             # item 0: 3000 pairs > 2048
+        m[7, 5] = 1.0
+        m = sp.csr_matrix(m)
+        inter = Interactions(m, nu, ni, "cuda")
+        assert inter.max_col_nnz == nu
+        xu_np, xi_np = inter.x_user.cpu().numpy(), inter.x_item.cpu().numpy()
+        xu = PairIndex.make(inter.x_user, inter.x_user32, 0, inter)
+        xi = PairIndex.make(inter.x_item, inter.x_item32, 0, inter)
+    else:
+        S = 8
+        items = rng.integers(0, ni, (nu, S)).astype(np.int32)
+        items[:, 0] = 0
+        items[7, 1] = 5
+        flat = dev(items.reshape(-1))
+        xu = xi = PairIndex.make(flat, flat, S)
+        xu_np, xi_np = np.repeat(np.arange(nu), S), items.reshape(-1).astype(np.int64)
+    g = rng.standard_normal(xi_np.size).astype(np.float32)
+    ut, vt = dev(u).requires_grad_(True), dev(v).requires_grad_(True)
+    ubt, ibt = dev(ub).requires_grad_(True), dev(ib).requires_grad_(True)
+    ops.pair_score(ut, vt, xu, xi, ops.MODE_EUCLIDEAN, ubt, ibt).backward(dev(g))
+    uc, vc = torch.from_numpy(u).double().requires_grad_(True), torch.from_numpy(v).double().requires_grad_(True)
+    ubc, ibc = torch.from_numpy(ub).double().requires_grad_(True), torch.from_numpy(ib).double().requires_grad_(True)
+    dist = ((uc[xu_np] - vc[xi_np]) ** 2).sum(1)
+    sc = -torch.sqrt(torch.clamp(dist, min=1e-16)) + ubc[xu_np] + ibc[xi_np]
+    sc.backward(torch.from_numpy(g).double())
+    for a, b in ((ut, uc), (vt, vc), (ubt, ubc), (ibt, ibc)):
+        ref = b.grad.numpy()
+        assert np.abs(a.grad.cpu().numpy() - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
+    # the atomic kernel computes the same sums in an arbitrary order
+    du, dv = torch.zeros_like(ut), torch.zeros_like(vt)
+    u_d, v_d, xu_d, xi_d, g_d = ut.detach(), vt.detach(), dev(xu_np.astype(np.int32)), dev(xi_np.astype(np.int32)), dev(g)
+    N.call("trec_pair_score_bwd", N.ptr(u_d), N.ptr(v_d), N.ptr(xu_d), N.ptr(xi_d), N.ptr(g_d), g.size, 0, d,
+           ops.MODE_EUCLIDEAN, N.ptr(du), N.ptr(dv), None, None)
+    scale = max(1.0, float(dv.abs().max()))
+    assert float((du - ut.grad).abs().max()) <= 1e-4 * scale and float((dv - vt.grad).abs().max()) <= 1e-4 * scale
+
+
+@pytest.mark.parametrize("shape", [(100000, 1024), (5000, 100), (300, 7), (255, 64)])
+def test_colsum_slices(ops, shape):
+    rng = np.random.default_rng(shape[1])
+    x = rng.standard_normal(shape).astype(np.float32)
+    got = ops.colsum(dev(x))
+    assert torch.equal(got, ops.colsum(dev(x)))
+    ref = x.astype(np.float64).sum(0)
+    assert np.allclose(got.cpu().numpy(), ref, rtol=1e-5, atol=1e-5 * np.sqrt(shape[0]) * 4)
+
+
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("M,N,K", [(300, 260, 129), (1000, 256, 5000), (130, 70, 9000), (64, 1024, 33)])
+def test_gemm_f32_tiles_edges_and_split_k(ops, ta, tb, M, N, K):
+    rng = np.random.default_rng(M + K)
+    a = rng.standard_normal((K, M) if ta else (M, K)).astype(np.float32)
+    b = rng.standard_normal((N, K) if tb else (K, N)).astype(np.float32)
+    ref = (a.T if ta else a).astype(np.float64) @ (b.T if tb else b).astype(np.float64)
+    got = ops.gemm_raw(dev(a), dev(b), trans_a=ta, trans_b=tb)
+    assert torch.equal(got, ops.gemm_raw(dev(a), dev(b), trans_a=ta, trans_b=tb))       # split-K adds in slice order
+    assert np.allclose(got.cpu().numpy(), ref, rtol=1e-5, atol=1e-5 * np.sqrt(K) * 8)
