@@ -168,19 +168,23 @@ int trec_topk_merge(const float* part_vals, const int32_t* part_idx, int64_t n_u
 /* ---- K3: per-pair ("serial") scores -----------------------------------------------------------------------
  * prediction_graphs.py:52-55 (dot), :70-72 (cosine after l2norm), :105-117 (euclidean) fused with
  * bias_prediction_serial, recommendation_graphs.py:55-57.  xu == NULL: user of pair p is p / pairs_per_user
- * (the [U, S] sample layout of util.py:16-19).  bwd accumulates (+=) into dU / dV / d_*_bias (fp32 atomics). */
+ * (the [U, S] sample layout of util.py:16-19).  out_sqdist (nullable): the pair's accumulator before the epilogue --
+ * the squared distance in Euclidean mode, kept for the backward pass.  bwd accumulates (+=) into dU / dV / d_*_bias
+ * (fp32 atomics). */
 int trec_pair_score_fwd(const float* U, const float* V, const int32_t* xu, const int32_t* xi, int64_t n_pairs,
                         int32_t pairs_per_user, int32_t d, int32_t mode, const float* user_bias,
-                        const float* item_bias, float* out, void* stream);
+                        const float* item_bias, float* out, float* out_sqdist, void* stream);
 int trec_pair_score_bwd(const float* U, const float* V, const int32_t* xu, const int32_t* xi, const float* grad,
                         int64_t n_pairs, int32_t pairs_per_user, int32_t d, int32_t mode, float* dU, float* dV,
                         float* d_user_bias, float* d_item_bias, void* stream);
 
 /* Euclidean pairs, backward: coef[p] = -grad[p] / sqrt(D_p), 0 where D_p < 1e-16 was clamped (tf.maximum passes no
  * gradient there, prediction_graphs.py:113-115); dU[u] = sum_p coef[p] (U[u] - V[i_p]) and
- * dV[i] = sum_p coef[p] (V[i] - U[u_p]) are then trec_spmm_csr_split gathers with `own` set. */
+ * dV[i] = sum_p coef[p] (V[i] - U[u_p]) are then trec_spmm_csr_split gathers with `own` set.  sqdist (nullable): the
+ * squared distances the forward pass kept (out_sqdist) -- then an elementwise pass, U / V / xu / xi are not read. */
 int trec_pair_euclid_coef(const float* U, const float* V, const int32_t* xu, const int32_t* xi, const float* grad,
-                          int64_t n_pairs, int32_t pairs_per_user, int32_t d, float* coef, void* stream);
+                          const float* sqdist, int64_t n_pairs, int32_t pairs_per_user, int32_t d, float* coef,
+                          void* stream);
 
 /* Group a pair list by item (counting sort on the device; pairs with a negative item are skipped): writes the transposed structure (indptr_t[n_items+1],
  * users_t[n_pairs], perm_t[n_pairs]) so that the item-side gradient of sampled serial predictions is the trec_spmm_csr

@@ -32,7 +32,7 @@ SIGNATURES = {
     "trec_csr_split_workspace_bytes": [_i64, _i32],
     "trec_spmm_csr_split": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _i64, _vp],
     "trec_spmv_csr_split": [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp],
-    "trec_pair_euclid_coef": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp],
+    "trec_pair_euclid_coef": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp],
     "trec_csr_to_dense": [_vp, _vp, _vp, _i64, _i32, _vp, _vp],
     "trec_row_l2norm_fwd": [_vp, _i64, _i32, _vp, _vp, _vp],
     "trec_row_l2norm_bwd": [_vp, _vp, _vp, _i64, _i32, _vp, _vp],
@@ -59,7 +59,7 @@ SIGNATURES = {
     "trec_score_gemm_topk_grouped": [_vp, _vp, _i32, _i32, _i64, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp,
                                      _vp, _i32, _vp, _vp, _i32, _vp],
     "trec_topk_merge": [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp],
-    "trec_pair_score_fwd": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
+    "trec_pair_score_fwd": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
     "trec_pair_score_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
     "trec_group_pairs_by_item": [_vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp],
     "trec_rank_rows": [_vp, _i64, _i64, _i64, _vp, _i64, _vp],

@@ -28,7 +28,7 @@ template <int VEC, int PP, int UG = 0>
 __global__ __launch_bounds__(256) void pair_score_fwd_kernel(
     const float* __restrict__ U, const float* __restrict__ V, const int32_t* __restrict__ xu,
     const int32_t* __restrict__ xi, int64_t n_pairs, int32_t pairs_per_user, int d, int lpr_log2, int mode,
-    const float* __restrict__ ub, const float* __restrict__ ib, float* __restrict__ out)
+    const float* __restrict__ ub, const float* __restrict__ ib, float* __restrict__ out, float* __restrict__ out_acc)
 {
     const int lpr = 1 << lpr_log2;
     const int sub_lane = threadIdx.x & (lpr - 1);
@@ -85,6 +85,7 @@ __global__ __launch_bounds__(256) void pair_score_fwd_kernel(
         for (int r = 0; r < PP; ++r) {
             if (!ok[r]) continue;
             float s = acc[r];
+            if (out_acc) out_acc[p0 + r] = acc[r];           // squared distance: the backward pass needs it unclamped
             if (mode == MODE_EUCLID) s = -1.0f * sqrtf(fmaxf(acc[r], EUCLID_EPS));
             if (ub) s = s + ub[u[r]];
             if (ib) s = s + ib[i[r]];
@@ -171,7 +172,8 @@ static void pair_geometry(int d, int& vec, int& lpr_log2)
 
 extern "C" int trec_pair_score_fwd(const float* U, const float* V, const int32_t* xu, const int32_t* xi,
                                    int64_t n_pairs, int32_t pairs_per_user, int32_t d, int32_t mode,
-                                   const float* user_bias, const float* item_bias, float* out, void* stream)
+                                   const float* user_bias, const float* item_bias, float* out, float* out_sqdist,
+                                   void* stream)
 {
     TREC_REQUIRE(U && V && xi && out, "trec_pair_score_fwd: null pointer");
     TREC_REQUIRE(xu || pairs_per_user >= 1, "trec_pair_score_fwd: need xu or pairs_per_user");
@@ -186,15 +188,15 @@ extern "C" int trec_pair_score_fwd(const float* U, const float* V, const int32_t
     const unsigned blocks = (unsigned)ceil_div64(ceil_div64(n_pairs, pp) << l2, 256);
 #define TREC_PAIR_FWD(VECV, PPV)                                                                                    \
     hipLaunchKernelGGL((pair_score_fwd_kernel<VECV, PPV>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, U, V, xu, \
-                       xi, n_pairs, pairs_per_user, d, l2, mode, user_bias, item_bias, out)
+                       xi, n_pairs, pairs_per_user, d, l2, mode, user_bias, item_bias, out, out_sqdist)
     const int ug = trec_get_tuning("pair_fwd_user_group", 1);       // 1: share the user row inside a subgroup's pairs
     if (!xu && vec == 4 && ug && pp >= 2 && pairs_per_user % pp == 0) {
         if (pp == 4)
             hipLaunchKernelGGL((pair_score_fwd_kernel<4, 4, 4>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, U, V,
-                               xu, xi, n_pairs, pairs_per_user, d, l2, mode, user_bias, item_bias, out);
+                               xu, xi, n_pairs, pairs_per_user, d, l2, mode, user_bias, item_bias, out, out_sqdist);
         else
             hipLaunchKernelGGL((pair_score_fwd_kernel<4, 2, 2>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, U, V,
-                               xu, xi, n_pairs, pairs_per_user, d, l2, mode, user_bias, item_bias, out);
+                               xu, xi, n_pairs, pairs_per_user, d, l2, mode, user_bias, item_bias, out, out_sqdist);
     } else if (vec == 4 && pp == 4) TREC_PAIR_FWD(4, 4);
     else if (vec == 4 && pp == 2) TREC_PAIR_FWD(4, 2);
     else if (vec == 4) TREC_PAIR_FWD(4, 1);
@@ -224,11 +226,28 @@ extern "C" int trec_pair_score_bwd(const float* U, const float* V, const int32_t
     return trec_check_launch("trec_pair_score_bwd");
 }
 
-extern "C" int trec_pair_euclid_coef(const float* U, const float* V, const int32_t* xu, const int32_t* xi,
-                                     const float* grad, int64_t n_pairs, int32_t pairs_per_user, int32_t d, float* coef,
-                                     void* stream)
+__global__ __launch_bounds__(256) void euclid_coef_from_sqdist_kernel(const float* __restrict__ sqdist,
+                                                                     const float* __restrict__ g, int64_t n,
+                                                                     float* __restrict__ coef)
 {
-    TREC_REQUIRE(U && V && xi && grad && coef, "trec_pair_euclid_coef: null pointer");
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const float D = sqdist[p];
+    coef[p] = (D >= EUCLID_EPS) ? -g[p] / sqrtf(D) : 0.f;
+}
+
+extern "C" int trec_pair_euclid_coef(const float* U, const float* V, const int32_t* xu, const int32_t* xi,
+                                     const float* grad, const float* sqdist, int64_t n_pairs, int32_t pairs_per_user,
+                                     int32_t d, float* coef, void* stream)
+{
+    TREC_REQUIRE(grad && coef, "trec_pair_euclid_coef: null pointer");
+    if (sqdist) {            // the forward pass kept the squared distances (trec_pair_score_fwd out_sqdist)
+        if (n_pairs == 0) return TREC_OK;
+        hipLaunchKernelGGL(euclid_coef_from_sqdist_kernel, dim3((unsigned)ceil_div64(n_pairs, 256)), dim3(256), 0,
+                           (hipStream_t)stream, sqdist, grad, n_pairs, coef);
+        return trec_check_launch("trec_pair_euclid_coef");
+    }
+    TREC_REQUIRE(U && V && xi, "trec_pair_euclid_coef: null pointer");
     TREC_REQUIRE(xu || pairs_per_user >= 1, "trec_pair_euclid_coef: need xu or pairs_per_user");
     TREC_REQUIRE(d >= 1, "trec_pair_euclid_coef: d must be >= 1");
     if (n_pairs == 0) return TREC_OK;

@@ -298,8 +298,12 @@ class _PairScore(torch.autograd.Function):
         u, v = _f32c(u), _f32c(v)
         n_pairs = xi32.numel()
         out = torch.empty((n_pairs,), dtype=torch.float32, device=u.device)
+        # Euclidean pairs keep their squared distances: the backward coefficients -g / sqrt(D) need no second gather
+        keep = mode == MODE_EUCLIDEAN and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
+        sqdist = torch.empty((n_pairs,), dtype=torch.float32, device=u.device) if keep else None
         N.call("trec_pair_score_fwd", N.ptr(u), N.ptr(v), N.ptr(xu32), N.ptr(xi32), n_pairs, pairs_per_user, u.shape[1],
-               mode, N.ptr(ub), N.ptr(ib), N.ptr(out))
+               mode, N.ptr(ub), N.ptr(ib), N.ptr(out), N.ptr(sqdist))
+        ctx.sqdist = sqdist
         ctx.save_for_backward(u, v)
         ctx.meta = (xu32, xi32, pairs_per_user, mode, ub is not None, ib is not None, inter)
         return out
@@ -324,8 +328,8 @@ class _PairScore(torch.autograd.Function):
         vals = g
         if euclid:       # dU[u] = sum_p c_p (U[u] - V[i_p]),  dV[i] = sum_p c_p (V[i] - U[u_p])
             vals = torch.empty_like(g)
-            N.call("trec_pair_euclid_coef", N.ptr(u), N.ptr(v), N.ptr(xu32), N.ptr(xi32), N.ptr(g), n_pairs, ppu, d,
-                   N.ptr(vals))
+            N.call("trec_pair_euclid_coef", N.ptr(u), N.ptr(v), N.ptr(xu32), N.ptr(xi32), N.ptr(g), N.ptr(ctx.sqdist),
+                   n_pairs, ppu, d, N.ptr(vals))
         can_split = d % 4 == 0 and d <= 1024
         # ---- user side: segmented gather over each user's pairs (K1 with values = g)
         if inter is not None:

@@ -227,3 +227,22 @@ def test_gemm_f32_tiles_edges_and_split_k(ops, ta, tb, M, N, K):
     got = ops.gemm_raw(dev(a), dev(b), trans_a=ta, trans_b=tb)
     assert torch.equal(got, ops.gemm_raw(dev(a), dev(b), trans_a=ta, trans_b=tb))       # split-K adds in slice order
     assert np.allclose(got.cpu().numpy(), ref, rtol=1e-5, atol=1e-5 * np.sqrt(K) * 8)
+
+
+def test_euclid_coef_from_kept_squared_distances_equals_recomputed(ops):
+    from tensorrec_amd import _native as N
+    rng = np.random.default_rng(8)
+    nu, ni, d, P = 50, 70, 96, 4000
+    u, v = dev(rng.standard_normal((nu, d)).astype(np.float32)), dev(rng.standard_normal((ni, d)).astype(np.float32))
+    xu, xi = dev(rng.integers(0, nu, P).astype(np.int32)), dev(rng.integers(0, ni, P).astype(np.int32))
+    g = dev(rng.standard_normal(P).astype(np.float32))
+    out, sq = torch.empty(P, device="cuda"), torch.empty(P, device="cuda")
+    N.call("trec_pair_score_fwd", N.ptr(u), N.ptr(v), N.ptr(xu), N.ptr(xi), P, 0, d, ops.MODE_EUCLIDEAN, None, None,
+           N.ptr(out), N.ptr(sq))
+    assert torch.equal(out, -torch.sqrt(torch.clamp(sq, min=1e-16)))
+    a, b = torch.empty(P, device="cuda"), torch.empty(P, device="cuda")
+    N.call("trec_pair_euclid_coef", N.ptr(u), N.ptr(v), N.ptr(xu), N.ptr(xi), N.ptr(g), None, P, 0, d, N.ptr(a))
+    N.call("trec_pair_euclid_coef", None, None, None, None, N.ptr(g), N.ptr(sq), P, 0, d, N.ptr(b))
+    assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)
+    ref = -g.double() / torch.sqrt(((u.double()[xu.long()] - v.double()[xi.long()]) ** 2).sum(1))
+    assert torch.allclose(b.double(), ref, rtol=1e-5, atol=1e-7)
