@@ -91,7 +91,25 @@ def _adam_lr_t(lr, t):
     return float(np.float32(np.float32(lr) * np.sqrt(np.float32(1.0) - b2p) / (np.float32(1.0) - b1p)))
 
 
+def _fingerprint(matrix):
+    """Content key of a CSR matrix (shape, nnz, dtype, xxh3-128 of indptr / indices / data), or None when it cannot be
+    had cheaply (not CSR, or no xxhash module): such matrices are uploaded afresh."""
+    if not sp.isspmatrix_csr(matrix):
+        return None
+    try:
+        import xxhash
+    except ImportError:          # pragma: no cover
+        return None
+    h = xxhash.xxh3_128()
+    for a in (matrix.indptr, matrix.indices, matrix.data):
+        h.update(np.ascontiguousarray(a).view(np.uint8).data)
+    return (tuple(matrix.shape), int(matrix.nnz), str(matrix.data.dtype), h.hexdigest())
+
+
 class TensorRec(object):
+    cache_uploads = True          # defaults for objects unpickled from before these attributes existed
+    _upload_cache = {}
+
 
     def __init__(self,
                  n_components=100,
@@ -167,6 +185,8 @@ class TensorRec(object):
         self.data_parallel = bool(data_parallel)
         self.process_group = process_group
         self.hip_graphs = bool(hip_graphs)
+        self.cache_uploads = True          # reuse device copies of matrices whose content did not change between fit calls
+        self._upload_cache = {}
         if self.data_parallel and seed is None:
             raise ValueError("data_parallel=True needs seed= so that every rank starts from the same weights")
 
@@ -422,18 +442,35 @@ class TensorRec(object):
                 self.sampler = DeviceSampler(self.seed if self.seed is not None else 0)
 
         # upload once per call; the epoch loop below touches only device memory
+        # Matrices whose CONTENT was uploaded by the previous call are reused (xxh3 of the CSR arrays, ~20 ms for 20M
+        # interactions): the reference's idiom `for epoch: model.fit_partial(..., epochs=1); evaluate` would otherwise
+        # spend 0.3 s per call on the host-side transposition and upload of an ML-20M-sized matrix for a 15 ms epoch.
         dev_batches = []
         item_cache = {}
+        used = {}
+
+        def cached(kind, matrix, extra, build):
+            key = _fingerprint(matrix) if self.cache_uploads else None
+            if key is None:
+                return build()
+            key = (kind, str(device)) + extra + key
+            obj = used.get(key) or self._upload_cache.get(key) or build()
+            used[key] = obj
+            return obj
+
         for inter_m, uf_m, if_m in batches:
             if uf_m.shape[1] != self.n_user_features or if_m.shape[1] != self.n_item_features:
                 raise ValueError("feature matrices must keep the number of features the model was first fit with")
             if id(if_m) not in item_cache:
-                item_cache[id(if_m)] = SparseFeatures(if_m, device)
-            uf = SparseFeatures(uf_m, device)
+                item_cache[id(if_m)] = cached("features", if_m, (), lambda: SparseFeatures(if_m, device))
+            uf = cached("features", uf_m, (), lambda: SparseFeatures(uf_m, device))
             itf = item_cache[id(if_m)]
-            inter = Interactions(inter_m, n_users=uf.shape[0], n_items=itf.shape[0], device=device)
-            inter.user_base = int(user_offset) + sum(b[1].shape[0] for b in dev_batches)
+            user_base = int(user_offset) + sum(b[1].shape[0] for b in dev_batches)
+            inter = cached("interactions", inter_m, (uf.shape[0], itf.shape[0], user_base),
+                           lambda: Interactions(inter_m, n_users=uf.shape[0], n_items=itf.shape[0], device=device))
+            inter.user_base = user_base
             dev_batches.append((inter, uf, itf))
+        self._upload_cache = used          # only what this call used stays resident
 
         batched_alpha = calculate_batched_alpha(num_batches=len(dev_batches), alpha=alpha)
         if verbose:
@@ -553,8 +590,11 @@ class TensorRec(object):
                 else:
                     tf_prediction = self._dense_prediction(user_repr, item_repr, user_bias, item_bias,
                                                            differentiable=True)
+                # TF evaluates the rankings node only when a loss uses it, and no built-in loss does: the U * I^2 counting
+                # kernel runs for custom loss graphs only (50 ms of a 54 ms RMSEDense step at 20000 x 5000)
+                builtin = type(loss_graph).connect_loss_graph.__module__ == AbstractLossGraph.__module__
                 loss_kwargs.update({'tf_prediction': tf_prediction,
-                                    'tf_rankings': rank_predictions(tf_prediction)})
+                                    'tf_rankings': None if builtin else rank_predictions(tf_prediction)})
             if loss_graph.is_sample_based:
                 if samples is None:
                     samples = self._draw_samples(inter, n_sampled_items)
@@ -893,6 +933,7 @@ class TensorRec(object):
         state['_capture'] = None
         state['_schedule'] = None
         state['_schedule_mirror'] = None
+        state['_upload_cache'] = {}
         state['process_group'] = None
         return state
 

@@ -493,3 +493,28 @@ def test_hip_graph_is_actually_used(monkeypatch):
     calls.update(capture=0, run=0)
     T.TensorRec(n_components=16, seed=1, hip_graphs=False).fit(inter, uf, itf, epochs=8)
     assert calls == {"capture": 0, "run": 0}
+
+
+def test_uploads_are_reused_between_fit_calls_until_the_content_changes():
+    """fit_partial in a loop (the reference's evaluate-every-epoch idiom): the device copies of unchanged matrices are
+    reused, a changed matrix is uploaded again, and the weights equal those of a model that never caches."""
+    inter, uf, itf = T.util.generate_dummy_data(num_users=60, num_items=90, interaction_density=.2, random_state=1)
+    inter, uf, itf = sp.csr_matrix(inter), sp.csr_matrix(uf), sp.csr_matrix(itf)
+    a = T.TensorRec(n_components=8, seed=3)         # RMSE: every gather is deterministic
+    b = T.TensorRec(n_components=8, seed=3)         # RMSE: every gather is deterministic
+    b.cache_uploads = False
+    for m in (a, b):
+        m.fit_partial(inter, uf, itf, epochs=1)
+    first = {id(v) for v in a._upload_cache.values()}
+    assert len(first) == 3 and not b._upload_cache
+    for m in (a, b):
+        m.fit_partial(inter, uf, itf, epochs=2)
+    assert {id(v) for v in a._upload_cache.values()} == first              # nothing was rebuilt
+    changed = inter.copy()
+    changed.data[::3] *= -1.0                                              # same structure, other values
+    for m in (a, b):
+        m.fit_partial(changed, uf, itf, epochs=1)
+    now = {id(v) for v in a._upload_cache.values()}
+    assert len(now & first) == 2 and len(now) == 3                          # the features stayed, the interactions did not
+    for x, y in zip(a.predict(uf, itf), b.predict(uf, itf)):
+        assert np.array_equal(x, y)
