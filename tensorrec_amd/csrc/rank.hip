@@ -12,6 +12,14 @@
 // Tiles entirely below / above the block's target range need a single predicate (>= resp. >); only the diagonal
 // tiles evaluate the index tie-break.
 //
+// rank_rows_sorted_kernel (rows of at most 32768 items): the count above is a position in the sorted row.  One workgroup
+// per user maps the row to order-preserving 32-bit keys in LDS (128 KB at 32768), sorts them with an in-place bitonic
+// network, and every item finds  #{keys > its key} = NP - upper_bound  by binary search: O(I log^2 I) LDS work instead
+// of I^2 compares (26,744 items: 0.13 ms per row against 14 ms).  Ties need the index order the keys do not carry:
+// the (few) tied items go to a second list of (class, index) entries that is sorted as well -- an entry's offset from
+// the start of its class is #{j < i : s_j == s_i}.  A row with more than 2048 tied items (identical scores everywhere:
+// integer-valued predictions) is marked with rank -1 and recounted by rank_rows_kernel, which otherwise exits.
+//
 // rank_of_pairs_kernel: ranks for selected (user, item) pairs only, counting over a [begin, end) item range --
 // the item-shardable form used for evaluation at sizes where the [U, I] matrix cannot exist.
 #include "common.hpp"
@@ -19,6 +27,9 @@
 #define RANK_TGT 1024
 #define RANK_TILE 2048
 
+// FIXUP: only the rows the sorted kernel marked (rank -1 on every item) are counted; each block tests an element that
+// only it writes
+template <bool FIXUP>
 __global__ __launch_bounds__(256) void rank_rows_kernel(const float* __restrict__ scores, int64_t n_items,
                                                        int64_t ld, int32_t* __restrict__ ranks, int64_t ld_out)
 {
@@ -26,6 +37,7 @@ __global__ __launch_bounds__(256) void rank_rows_kernel(const float* __restrict_
     const int64_t u = blockIdx.y;
     const float* row = scores + u * ld;
     const int64_t tgt0 = (int64_t)blockIdx.x * RANK_TGT;
+    if (FIXUP && ranks[u * ld_out + tgt0] != -1) return;
     // thread t owns targets tgt0 + t + 256*e  (coalesced loads/stores)
     float tv[4];
     int64_t tix[4];
@@ -77,6 +89,84 @@ __global__ __launch_bounds__(256) void rank_rows_kernel(const float* __restrict_
         if (tix[e] < n_items) ranks[u * ld_out + tix[e]] = cnt[e] + 1;
 }
 
+#define RANK_SORT_MAX 32768      // keys of one row in LDS: 128 KB
+#define RANK_TIE_CAP 2048        // tied items handled by the (class, index) list: 16 KB
+
+// order-preserving map float -> uint32 (larger score = larger key); -0.0 ranks as +0.0 (they compare equal)
+__device__ __forceinline__ uint32_t rank_key(float f)
+{
+    uint32_t u = __float_as_uint(f);
+    if (u == 0x80000000u) u = 0u;
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+template <typename K>
+__device__ __forceinline__ void bitonic_sort_lds(K* a, int n, int tid, int nthreads)
+{
+    for (int k = 2; k <= n; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int idx = tid; idx < (n >> 1); idx += nthreads) {
+                const int i = ((idx & ~(j - 1)) << 1) | (idx & (j - 1));
+                const int p = i | j;
+                const K x = a[i], y = a[p];
+                if ((x > y) == ((i & k) == 0)) { a[i] = y; a[p] = x; }
+            }
+            __syncthreads();
+        }
+}
+
+__global__ __launch_bounds__(1024) void rank_rows_sorted_kernel(const float* __restrict__ scores, int n_items, int64_t ld,
+                                                               int32_t* __restrict__ ranks, int64_t ld_out, int NP)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t rank_sh[];
+    uint32_t* keys = rank_sh;                                    // [NP] ascending after the sort; padding = 0 in front
+    unsigned long long* ties = (unsigned long long*)(rank_sh + NP);      // [RANK_TIE_CAP] (class << 32) | item
+    int* n_ties = (int*)(ties + RANK_TIE_CAP);
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const float* row = scores + (int64_t)blockIdx.x * ld;
+    int32_t* out = ranks + (int64_t)blockIdx.x * ld_out;
+    for (int q = tid; q < NP; q += nt) keys[q] = q < n_items ? rank_key(row[q]) : 0u;
+    if (tid == 0) *n_ties = 0;
+    __syncthreads();
+    bitonic_sort_lds(keys, NP, tid, nt);
+    for (int i = tid; i < n_items; i += nt) {
+        const uint32_t k = rank_key(row[i]);
+        int lo = 0, hi = NP;                                     // upper bound: first position with keys[pos] > k
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (keys[mid] <= k) lo = mid + 1; else hi = mid;
+        }
+        if (lo >= 2 && keys[lo - 2] == k) {                      // another item has the same score
+            const int slot = atomicAdd(n_ties, 1);
+            if (slot < RANK_TIE_CAP) ties[slot] = ((unsigned long long)(uint32_t)lo << 32) | (uint32_t)i;
+        } else {
+            out[i] = 1 + NP - lo;
+        }
+    }
+    __syncthreads();
+    const int T = *n_ties;
+    if (T == 0) return;
+    if (T > RANK_TIE_CAP) {                                      // ties everywhere: recount the whole row (rank_rows_kernel<true>)
+        for (int i = tid; i < n_items; i += nt) out[i] = -1;
+        return;
+    }
+    int TP = 2;
+    while (TP < T) TP <<= 1;
+    for (int q = T + tid; q < TP; q += nt) ties[q] = ~0ull;
+    __syncthreads();
+    bitonic_sort_lds(ties, TP, tid, nt);
+    for (int p = tid; p < T; p += nt) {
+        const unsigned long long e = ties[p];
+        const unsigned long long cls = e & 0xffffffff00000000ull;
+        int lo = 0, hi = p;                                      // first entry of this class
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (ties[mid] < cls) lo = mid + 1; else hi = mid;
+        }
+        out[(uint32_t)e] = 1 + NP - (int)(e >> 32) + (p - lo);
+    }
+}
+
 // one wave per (user, item) pair; counts over items [begin, end) of the user's score row.
 // out[p] (+)= count  (+1 added by the caller once all shards are summed, or here when add_one != 0)
 __global__ __launch_bounds__(256) void rank_of_pairs_kernel(const float* __restrict__ scores, int64_t ld,
@@ -110,11 +200,31 @@ extern "C" int trec_rank_rows(const float* scores, int64_t n_users, int64_t n_it
     if (n_users == 0 || n_items == 0) return TREC_OK;
     hipStream_t st = (hipStream_t)stream;
     const unsigned bx = (unsigned)ceil_div64(n_items, RANK_TGT);
+    bool sorted = n_items >= 64 && n_items <= RANK_SORT_MAX && n_users < (1ll << 31) && trec_get_tuning("rank_sorted", 1);
+    if (sorted) {
+        int NP = 64;
+        while (NP < n_items) NP <<= 1;
+        const size_t lds = (size_t)NP * 4 + RANK_TIE_CAP * 8 + 16;
+        if (lds > 48 * 1024 &&
+            hipFuncSetAttribute((const void*)rank_rows_sorted_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess) {
+            (void)hipGetLastError();
+            sorted = false;                                      // cannot have the LDS: count instead
+        } else {
+            const int threads = NP / 2 < 1024 ? NP / 2 : 1024;
+            hipLaunchKernelGGL(rank_rows_sorted_kernel, dim3((unsigned)n_users), dim3(threads), lds, st, scores,
+                               (int)n_items, ld_scores, ranks, ld_ranks, NP);
+        }
+    }
     // gridDim.y is limited to 65535: launch in user slabs
     for (int64_t u0 = 0; u0 < n_users; u0 += 65535) {
         const unsigned by = (unsigned)((n_users - u0 < 65535) ? (n_users - u0) : 65535);
-        hipLaunchKernelGGL(rank_rows_kernel, dim3(bx, by), dim3(256), 0, st, scores + u0 * ld_scores, n_items,
-                           ld_scores, ranks + u0 * ld_ranks, ld_ranks);
+        if (sorted)
+            hipLaunchKernelGGL(rank_rows_kernel<true>, dim3(bx, by), dim3(256), 0, st, scores + u0 * ld_scores, n_items,
+                               ld_scores, ranks + u0 * ld_ranks, ld_ranks);
+        else
+            hipLaunchKernelGGL(rank_rows_kernel<false>, dim3(bx, by), dim3(256), 0, st, scores + u0 * ld_scores, n_items,
+                               ld_scores, ranks + u0 * ld_ranks, ld_ranks);
     }
     return trec_check_launch("trec_rank_rows");
 }

@@ -246,3 +246,24 @@ def test_euclid_coef_from_kept_squared_distances_equals_recomputed(ops):
     assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)
     ref = -g.double() / torch.sqrt(((u.double()[xu.long()] - v.double()[xi.long()]) ** 2).sum(1))
     assert torch.allclose(b.double(), ref, rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("n_items", [64, 100, 1682, 4096, 26744, 32768, 32769])
+def test_rank_rows_sorted_path_is_bit_exact(ops, n_items):
+    """K4 by sorting (rows up to 32768 items) against the counting definition: no ties, a few tied classes (the
+    (class, index) list), ties everywhere (marked rows recounted by the counting kernel), -0.0 == +0.0, infinities."""
+    from tensorrec_amd import _native as N
+    rng = np.random.default_rng(n_items)
+    n_users = 5 if n_items > 8192 else 9
+    s = rng.standard_normal((n_users, n_items)).astype(np.float32)
+    s[1, rng.choice(n_items, 40, replace=False)] = 0.25                    # one class of 40
+    s[2] = np.round(s[2] * 2000) / 2000                                    # many small classes
+    s[3] = rng.integers(0, 5, n_items).astype(np.float32)                  # five huge classes -> recount
+    s[4, :8] = [0.0, -0.0, np.inf, -np.inf, np.inf, -0.0, 0.0, -np.inf]
+    got = ops.rank_rows(dev(s)).cpu().numpy()
+    assert np.array_equal(got, O.rank_predictions_exact(s))
+    N.set_tuning("rank_sorted", 0)
+    try:
+        assert np.array_equal(ops.rank_rows(dev(s)).cpu().numpy(), got)    # the counting kernel alone agrees
+    finally:
+        N.set_tuning("rank_sorted", 1)
