@@ -518,3 +518,20 @@ def test_uploads_are_reused_between_fit_calls_until_the_content_changes():
     assert len(now & first) == 2 and len(now) == 3                          # the features stayed, the interactions did not
     for x, y in zip(a.predict(uf, itf), b.predict(uf, itf)):
         assert np.array_equal(x, y)
+
+
+def test_rank_of_interactions_with_many_positives_per_user_sorts_rows():
+    """>= 32 positives per user: the tile's rows are sorted once (K4 sorted form) and the pairs' ranks read off -- the
+    same integers as the counting path and as predict_rank()."""
+    _, uf, itf = dummy(90, 400, seed=4)
+    inter = sp.random(90, 400, density=0.2, random_state=5, dtype=np.float32, format="csr")
+    inter.data[:] = 1.0
+    inter.sort_indices()
+    model = T.TensorRec(n_components=16, seed=2)
+    model.fit(inter, uf, itf, epochs=2)
+    ranks = model.predict_rank(uf, itf)
+    coo = inter.tocoo()
+    for batch in (None, 32):
+        pr = model.predict_rank_of_interactions(uf, itf, inter, user_batch_size=batch)
+        assert len(pr.ranks) >= 32 * 90 and np.array_equal(pr.ranks, ranks[pr.rows, sp.csr_matrix(inter).tocoo().col])
+    assert np.array_equal(np.sort(coo.row, kind="stable"), pr.rows)
