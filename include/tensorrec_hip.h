@@ -68,7 +68,8 @@ int trec_spmv_csr(const int64_t* indptr, const int32_t* indices, const float* va
  * packed_entries (int2 {column, value bits}) describes the non-zeros.  own (nullable, [n_rows, d]): gather
  * (own[row,:] - W[col,:]) instead of W[col,:] -- the Euclidean pair gradient, prediction_graphs.py:105-117
  * differentiated, with the coefficients of trec_pair_euclid_coef as values.  out_rowsum (nullable): sums of the rows'
- * values.  accumulate != 0: out += (and out_rowsum +=).  workspace: trec_csr_split_workspace_bytes(nnz, d) bytes.   */
+ * values.  accumulate != 0: out += (and out_rowsum +=).  workspace: trec_csr_split_workspace_bytes(nnz, d) bytes.
+ * d: a multiple of 4 up to 1024 (float4 lanes), or any width up to 256 (single-column lanes).                     */
 int64_t trec_csr_split_workspace_bytes(int64_t nnz, int32_t d);
 int trec_spmm_csr_split(const int64_t* indptr, const int32_t* indices, const float* values, const int32_t* val_perm,
                         const void* packed_entries, int64_t n_rows, int64_t nnz, const float* W, int32_t d,

@@ -83,5 +83,14 @@ if __name__ == "__main__":
         res.append(timed_fit("j: 20000 x 5000, Linear d=64, SeparationDense", m, inter[:ns, :ni], uf[:ns], itf[:ni]))
         m = T.TensorRec(n_components=64, loss_graph=L.RMSEDenseLossGraph(), seed=0)
         res.append(timed_fit("j2: 20000 x 5000, Linear d=64, RMSEDense", m, inter[:ns, :ni], uf[:ns], itf[:ni]))
+    for dd in (10, 50, 100):
+        if on("k%d" % dd):
+            m = T.TensorRec(n_components=dd, loss_graph=L.WMRBLossGraph(), seed=0)
+            res.append(timed_fit("k%d: Linear d=%d, dot, WMRB S=100" % (dd, dd), m, inter, uf, itf, n_sampled_items=100))
+            m = T.TensorRec(n_components=dd, prediction_graph=P.EuclideanSimilarityPredictionGraph(),
+                            loss_graph=L.WMRBLossGraph(), seed=0)
+            res.append(timed_fit("k%d-euclid: Linear d=%d, euclidean, WMRB S=100" % (dd, dd), m, inter, uf, itf,
+                                 n_sampled_items=100))
+            res.append(timed("k%d: predict_top_k all users" % dd, lambda: m.predict_top_k(uf, itf, k=10), 1))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(res, open(os.path.join(ROOT, "gpurun_out", "bench_shapes.json"), "w"), indent=1)

@@ -72,6 +72,18 @@ __global__ __launch_bounds__(256) void split_plan_kernel(const int64_t* __restri
 
 struct Entry { int32_t col; float val; };
 
+// VEC = 4: a lane owns float4 column groups (d % 4 == 0, rows 16-byte aligned); VEC = 1: a lane owns single columns (any d)
+template <int VEC> struct VecOf { typedef f32x4 T; };
+template <> struct VecOf<1> { typedef float T; };
+__device__ __forceinline__ void vfma(f32x4& acc, float v, const f32x4& x)
+{
+    acc.x = fmaf(v, x.x, acc.x); acc.y = fmaf(v, x.y, acc.y); acc.z = fmaf(v, x.z, acc.z); acc.w = fmaf(v, x.w, acc.w);
+}
+__device__ __forceinline__ void vfma(float& acc, float v, const float& x) { acc = fmaf(v, x, acc); }
+template <typename T> __device__ __forceinline__ T vzero();
+template <> __device__ __forceinline__ f32x4 vzero<f32x4>() { return (f32x4){0.f, 0.f, 0.f, 0.f}; }
+template <> __device__ __forceinline__ float vzero<float>() { return 0.f; }
+
 template <bool PACKED>
 __device__ __forceinline__ Entry load_entry(const int32_t* __restrict__ indices, const float* __restrict__ values,
                                             const int32_t* __restrict__ val_perm, int64_t j)
@@ -89,34 +101,35 @@ __device__ __forceinline__ Entry load_entry(const int32_t* __restrict__ indices,
 
 // acc (+)= sum over non-zeros [j0, j1) of val * x(col), x = W row or (own - W row); CSR order, one fmaf per element;
 // four gathers in flight
-template <int ITERS, bool PACKED>
+template <int ITERS, bool PACKED, int VEC>
 __device__ __forceinline__ void gather_range(const int32_t* __restrict__ indices, const float* __restrict__ values,
                                              const int32_t* __restrict__ val_perm, int64_t j0, int64_t j1,
                                              const float* __restrict__ W, int d, const int (&col)[ITERS],
-                                             const bool (&cvalid)[ITERS], bool diff, const f32x4 (&ownv)[ITERS],
-                                             f32x4 (&acc)[ITERS], float& vsum)
+                                             const bool (&cvalid)[ITERS], bool diff,
+                                             const typename VecOf<VEC>::T (&ownv)[ITERS],
+                                             typename VecOf<VEC>::T (&acc)[ITERS], float& vsum)
 {
+    typedef typename VecOf<VEC>::T V;
     int64_t j = j0;
     for (; j + 3 < j1; j += 4) {
         Entry en[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) en[q] = load_entry<PACKED>(indices, values, val_perm, j + q);
-        f32x4 x[4][ITERS];
+        V x[4][ITERS];
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int it = 0; it < ITERS; ++it) {
-                x[q][it] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (cvalid[it]) x[q][it] = *(const f32x4*)(W + (int64_t)en[q].col * d + col[it]);
+                x[q][it] = vzero<V>();
+                if (cvalid[it]) x[q][it] = *(const V*)(W + (int64_t)en[q].col * d + col[it]);
             }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             vsum += en[q].val;
 #pragma unroll
             for (int it = 0; it < ITERS; ++it) {
-                const f32x4 xv = diff ? ownv[it] - x[q][it] : x[q][it];
-                acc[it].x = fmaf(en[q].val, xv.x, acc[it].x); acc[it].y = fmaf(en[q].val, xv.y, acc[it].y);
-                acc[it].z = fmaf(en[q].val, xv.z, acc[it].z); acc[it].w = fmaf(en[q].val, xv.w, acc[it].w);
+                const V xv = diff ? ownv[it] - x[q][it] : x[q][it];
+                vfma(acc[it], en[q].val, xv);
             }
         }
     }
@@ -126,21 +139,21 @@ __device__ __forceinline__ void gather_range(const int32_t* __restrict__ indices
 #pragma unroll
         for (int it = 0; it < ITERS; ++it)
             if (cvalid[it]) {
-                const f32x4 xr = *(const f32x4*)(W + (int64_t)en.col * d + col[it]);
-                const f32x4 xv = diff ? ownv[it] - xr : xr;
-                acc[it].x = fmaf(en.val, xv.x, acc[it].x); acc[it].y = fmaf(en.val, xv.y, acc[it].y);
-                acc[it].z = fmaf(en.val, xv.z, acc[it].z); acc[it].w = fmaf(en.val, xv.w, acc[it].w);
+                const V xr = *(const V*)(W + (int64_t)en.col * d + col[it]);
+                const V xv = diff ? ownv[it] - xr : xr;
+                vfma(acc[it], en.val, xv);
             }
     }
 }
 
 // rows of at most split_t non-zeros: one row per subgroup of lpr lanes (longer rows are left to the chunk kernels)
-template <int ITERS, bool PACKED>
+template <int ITERS, bool PACKED, int VEC>
 __global__ __launch_bounds__(256) void split_rows_kernel(
     const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, const float* __restrict__ values,
     const int32_t* __restrict__ val_perm, int64_t n_rows, const float* __restrict__ W, int d, int lpr_log2,
     const float* __restrict__ own, int accumulate, int split_t, float* __restrict__ out, float* __restrict__ out_rowsum)
 {
+    typedef typename VecOf<VEC>::T V;
     const int lpr = 1 << lpr_log2;
     const int sub_lane = threadIdx.x & (lpr - 1);
     const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> lpr_log2;
@@ -149,31 +162,32 @@ __global__ __launch_bounds__(256) void split_rows_kernel(
     if (e - s > split_t) return;
     int col[ITERS];
     bool cvalid[ITERS];
-    f32x4 acc[ITERS], ownv[ITERS];
+    V acc[ITERS], ownv[ITERS];
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
-        col[it] = (it * lpr + sub_lane) * 4;
+        col[it] = (it * lpr + sub_lane) * VEC;
         cvalid[it] = col[it] < d;
-        acc[it] = ownv[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        acc[it] = ownv[it] = vzero<V>();
         if (cvalid[it]) {
-            if (accumulate) acc[it] = *(const f32x4*)(out + row * (int64_t)d + col[it]);
-            if (own) ownv[it] = *(const f32x4*)(own + row * (int64_t)d + col[it]);
+            if (accumulate) acc[it] = *(const V*)(out + row * (int64_t)d + col[it]);
+            if (own) ownv[it] = *(const V*)(own + row * (int64_t)d + col[it]);
         }
     }
     float vsum = 0.f;
-    gather_range<ITERS, PACKED>(indices, values, val_perm, s, e, W, d, col, cvalid, own != nullptr, ownv, acc, vsum);
+    gather_range<ITERS, PACKED, VEC>(indices, values, val_perm, s, e, W, d, col, cvalid, own != nullptr, ownv, acc, vsum);
 #pragma unroll
     for (int it = 0; it < ITERS; ++it)
-        if (cvalid[it]) *(f32x4*)(out + row * (int64_t)d + col[it]) = acc[it];
+        if (cvalid[it]) *(V*)(out + row * (int64_t)d + col[it]) = acc[it];
     if (out_rowsum && sub_lane == 0) out_rowsum[row] = accumulate ? out_rowsum[row] + vsum : vsum;
 }
 
-template <int ITERS, bool PACKED>
+template <int ITERS, bool PACKED, int VEC>
 __global__ __launch_bounds__(256) void split_chunks_kernel(
     const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, const float* __restrict__ values,
     const int32_t* __restrict__ val_perm, const float* __restrict__ W, int d, int lpr_log2,
     const float* __restrict__ own, int split_t, SplitPlan p)
 {
+    typedef typename VecOf<VEC>::T V;
     const int lpr = 1 << lpr_log2;
     const int sub_lane = threadIdx.x & (lpr - 1);
     const int64_t n_sg = ((int64_t)gridDim.x * blockDim.x) >> lpr_log2;
@@ -182,31 +196,32 @@ __global__ __launch_bounds__(256) void split_chunks_kernel(
     int col[ITERS];
     bool cvalid[ITERS];
 #pragma unroll
-    for (int it = 0; it < ITERS; ++it) { col[it] = (it * lpr + sub_lane) * 4; cvalid[it] = col[it] < d; }
+    for (int it = 0; it < ITERS; ++it) { col[it] = (it * lpr + sub_lane) * VEC; cvalid[it] = col[it] < d; }
     for (int64_t c = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> lpr_log2; c < n_chunks; c += n_sg) {
         const int64_t row = p.chunk_row[c];
         const int64_t j0 = indptr[row] + (int64_t)p.chunk_k[c] * chunk;
         const int64_t re = indptr[row + 1];
         const int64_t j1 = j0 + chunk < re ? j0 + chunk : re;
-        f32x4 acc[ITERS], ownv[ITERS];
+        V acc[ITERS], ownv[ITERS];
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
-            acc[it] = ownv[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (own && cvalid[it]) ownv[it] = *(const f32x4*)(own + row * (int64_t)d + col[it]);
+            acc[it] = ownv[it] = vzero<V>();
+            if (own && cvalid[it]) ownv[it] = *(const V*)(own + row * (int64_t)d + col[it]);
         }
         float vsum = 0.f;
-        gather_range<ITERS, PACKED>(indices, values, val_perm, j0, j1, W, d, col, cvalid, own != nullptr, ownv, acc, vsum);
+        gather_range<ITERS, PACKED, VEC>(indices, values, val_perm, j0, j1, W, d, col, cvalid, own != nullptr, ownv, acc, vsum);
 #pragma unroll
         for (int it = 0; it < ITERS; ++it)
-            if (cvalid[it]) *(f32x4*)(p.partial + c * (int64_t)d + col[it]) = acc[it];
+            if (cvalid[it]) *(V*)(p.partial + c * (int64_t)d + col[it]) = acc[it];
         if (sub_lane == 0) p.psum[c] = vsum;
     }
 }
 
-template <int ITERS>
+template <int ITERS, int VEC>
 __global__ __launch_bounds__(256) void split_reduce_kernel(int d, int lpr_log2, int accumulate, SplitPlan p,
                                                           float* __restrict__ out, float* __restrict__ out_rowsum)
 {
+    typedef typename VecOf<VEC>::T V;
     const int lpr = 1 << lpr_log2;
     const int sub_lane = threadIdx.x & (lpr - 1);
     const int64_t n_sg = ((int64_t)gridDim.x * blockDim.x) >> lpr_log2;
@@ -216,12 +231,12 @@ __global__ __launch_bounds__(256) void split_reduce_kernel(int d, int lpr_log2, 
         const int base = p.long_base[li], nch = p.long_nch[li];
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
-            const int col = (it * lpr + sub_lane) * 4;
+            const int col = (it * lpr + sub_lane) * VEC;
             if (col >= d) continue;
-            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (accumulate) acc = *(const f32x4*)(out + row * (int64_t)d + col);
-            for (int k = 0; k < nch; ++k) acc += *(const f32x4*)(p.partial + (int64_t)(base + k) * d + col);
-            *(f32x4*)(out + row * (int64_t)d + col) = acc;
+            V acc = vzero<V>();
+            if (accumulate) acc = *(const V*)(out + row * (int64_t)d + col);
+            for (int k = 0; k < nch; ++k) acc += *(const V*)(p.partial + (int64_t)(base + k) * d + col);
+            *(V*)(out + row * (int64_t)d + col) = acc;
         }
         if (out_rowsum && sub_lane == 0) {
             float s = accumulate ? out_rowsum[row] : 0.f;
@@ -335,7 +350,8 @@ extern "C" int trec_spmm_csr_split(const int64_t* indptr, const int32_t* indices
 {
     TREC_REQUIRE(indptr && W && out, "trec_spmm_csr_split: null pointer");
     TREC_REQUIRE(nnz == 0 || packed_entries || (indices && values), "trec_spmm_csr_split: null indices/values with nnz != 0");
-    TREC_REQUIRE(d >= 4 && d % 4 == 0 && d <= 1024, "trec_spmm_csr_split: d must be a multiple of 4, <= 1024");
+    TREC_REQUIRE(d >= 1 && ((d % 4 == 0 && d <= 1024) || d <= 256),
+                 "trec_spmm_csr_split: d must be a multiple of 4 up to 1024, or any value up to 256");
     TREC_REQUIRE(n_rows >= 0 && nnz >= 0, "trec_spmm_csr_split: bad sizes");
     if (n_rows == 0) return TREC_OK;
     hipStream_t st = (hipStream_t)stream;
@@ -343,28 +359,35 @@ extern "C" int trec_spmm_csr_split(const int64_t* indptr, const int32_t* indices
     SplitPlan plan;
     int rc = make_plan(indptr, n_rows, nnz, d, workspace, workspace_bytes, split_t, &plan, st, "trec_spmm_csr_split(plan)");
     if (rc) return rc;
-    const int n4 = d / 4;
-    int lpr_log2 = pow2ceil_log2(n4);
+    const bool vec4 = d % 4 == 0;
+    const int per = vec4 ? d / 4 : d;                            // column groups a subgroup has to cover
+    int lpr_log2 = pow2ceil_log2(per);
     if (lpr_log2 > 6) lpr_log2 = 6;
     const int lpr = 1 << lpr_log2;
-    const int iters = (n4 + lpr - 1) / lpr;
+    const int iters = (per + lpr - 1) / lpr;
     const unsigned row_blocks = (unsigned)ceil_div64(n_rows * lpr, 256);
     const int64_t chunk_want = ceil_div64(plan.max_chunks * lpr, 256);
     const unsigned chunk_blocks = (unsigned)(chunk_want < 4096 ? chunk_want : 4096);
     const int64_t long_want = ceil_div64(plan.max_long * lpr, 256);
     const unsigned reduce_blocks = (unsigned)(long_want < 2048 ? long_want : 2048);
     const int32_t* idx = packed_entries ? (const int32_t*)packed_entries : indices;
-#define TREC_SPLIT_LAUNCH(IT, PK)                                                                                       \
+#define TREC_SPLIT_LAUNCH(IT, PK, VC)                                                                                   \
     do {                                                                                                                \
-        hipLaunchKernelGGL((split_rows_kernel<IT, PK>), dim3(row_blocks), dim3(256), 0, st, indptr, idx, values, val_perm, \
-                           n_rows, W, d, lpr_log2, own, accumulate, split_t, out, out_rowsum);                          \
-        hipLaunchKernelGGL((split_chunks_kernel<IT, PK>), dim3(chunk_blocks), dim3(256), 0, st, indptr, idx, values,     \
+        hipLaunchKernelGGL((split_rows_kernel<IT, PK, VC>), dim3(row_blocks), dim3(256), 0, st, indptr, idx, values,     \
+                           val_perm, n_rows, W, d, lpr_log2, own, accumulate, split_t, out, out_rowsum);                \
+        hipLaunchKernelGGL((split_chunks_kernel<IT, PK, VC>), dim3(chunk_blocks), dim3(256), 0, st, indptr, idx, values, \
                            val_perm, W, d, lpr_log2, own, split_t, plan);                                               \
-        hipLaunchKernelGGL((split_reduce_kernel<IT>), dim3(reduce_blocks), dim3(256), 0, st, d, lpr_log2, accumulate,    \
-                           plan, out, out_rowsum);                                                                      \
+        hipLaunchKernelGGL((split_reduce_kernel<IT, VC>), dim3(reduce_blocks), dim3(256), 0, st, d, lpr_log2,            \
+                           accumulate, plan, out, out_rowsum);                                                          \
     } while (0)
-    if (packed_entries) { if (iters == 1) TREC_SPLIT_LAUNCH(1, true); else if (iters == 2) TREC_SPLIT_LAUNCH(2, true); else TREC_SPLIT_LAUNCH(4, true); }
-    else { if (iters == 1) TREC_SPLIT_LAUNCH(1, false); else if (iters == 2) TREC_SPLIT_LAUNCH(2, false); else TREC_SPLIT_LAUNCH(4, false); }
+#define TREC_SPLIT_ITERS(PK, VC)                                                                                        \
+    do {                                                                                                                \
+        if (iters == 1) TREC_SPLIT_LAUNCH(1, PK, VC); else if (iters == 2) TREC_SPLIT_LAUNCH(2, PK, VC);                \
+        else TREC_SPLIT_LAUNCH(4, PK, VC);                                                                              \
+    } while (0)
+    if (vec4) { if (packed_entries) TREC_SPLIT_ITERS(true, 4); else TREC_SPLIT_ITERS(false, 4); }
+    else { if (packed_entries) TREC_SPLIT_ITERS(true, 1); else TREC_SPLIT_ITERS(false, 1); }
+#undef TREC_SPLIT_ITERS
 #undef TREC_SPLIT_LAUNCH
     return trec_check_launch("trec_spmm_csr_split");
 }

@@ -102,6 +102,17 @@ def spmv_raw(indptr, indices, values, perm, n_rows, nnz, beta, long_rows=False):
     return out
 
 
+def _split_ok(d):
+    """widths the chunked gathers cover: float4 lanes up to 1024 columns, single-column lanes (any d) up to 256"""
+    return (d % 4 == 0 and d <= 1024) or d <= 256
+
+
+def _prefer_split(d, nnz):
+    """d % 4 != 0 has no float4 kernel: K1's fallback walks a row with one load in flight per thread, the chunked form
+    keeps four -- worth its three extra launches on large gathers"""
+    return d % 4 != 0 and d <= 256 and nnz >= 65536
+
+
 def _sampled_buckets_long(n_pairs, n_items):
     """pairs grouped by sampled item on the device: bucket sizes are not known to the host.  Uniform samples stay under
     SPLIT_T up to a mean of _SPLIT_MEAN; large problems take the split form regardless (three small extra launches) so
@@ -114,7 +125,7 @@ def _spmm_t(feats: SparseFeatures, dout):
     indicator columns of side features hold thousands of rows)."""
     indptr_t, rows_t, perm_t = feats.transposed()
     d = dout.shape[1]
-    if feats.max_col_nnz > SPLIT_T and d % 4 == 0 and d <= 1024:
+    if (feats.max_col_nnz > SPLIT_T or _prefer_split(d, feats.nnz)) and _split_ok(d):
         return spmm_split(indptr_t, rows_t, feats.values, perm_t, feats.shape[1], feats.nnz, dout)
     return spmm_raw(indptr_t, rows_t, feats.values, perm_t, feats.shape[1], feats.nnz, dout)
 
@@ -316,7 +327,7 @@ class _PairScore(torch.autograd.Function):
         n_pairs = xi32.numel()
         n_users, n_items, dev = u.shape[0], v.shape[0], u.device
         d = u.shape[1]
-        structured = (ppu > 0 or inter is not None) and (mode == MODE_DOT or (d % 4 == 0 and d <= 1024))
+        structured = (ppu > 0 or inter is not None) and (mode == MODE_DOT or _split_ok(d))
         if not structured:
             du, dv = torch.zeros_like(u), torch.zeros_like(v)
             dub = torch.zeros((n_users,), dtype=torch.float32, device=dev) if has_ub else None
@@ -330,14 +341,15 @@ class _PairScore(torch.autograd.Function):
             vals = torch.empty_like(g)
             N.call("trec_pair_euclid_coef", N.ptr(u), N.ptr(v), N.ptr(xu32), N.ptr(xi32), N.ptr(g), N.ptr(ctx.sqdist),
                    n_pairs, ppu, d, N.ptr(vals))
-        can_split = d % 4 == 0 and d <= 1024
+        can_split = _split_ok(d)
+        prefer = _prefer_split(d, n_pairs)
         # ---- user side: segmented gather over each user's pairs (K1 with values = g)
         if inter is not None:
             indptr_u, long_u = inter.indptr, inter.max_row_nnz > SPLIT_T
         else:
             indptr_u = torch.arange(0, (n_users + 1) * ppu, ppu, dtype=torch.int64, device=dev)
             long_u = ppu > SPLIT_T
-        if euclid or (long_u and can_split):
+        if euclid or ((long_u or prefer) and can_split):
             du = spmm_split(indptr_u, xi32, vals, None, n_users, n_pairs, v, own=u if euclid else None)
         else:
             du = spmm_raw(indptr_u, xi32, vals, None, n_users, n_pairs, v)
@@ -350,7 +362,7 @@ class _PairScore(torch.autograd.Function):
         else:
             indptr_t, users_t, perm_t = group_pairs_by_item(xu32, xi32, ppu, n_items)
             long_i = _sampled_buckets_long(n_pairs, n_items)
-        if euclid or (long_i and can_split):
+        if euclid or ((long_i or prefer) and can_split):
             dv = spmm_split(indptr_t, users_t, vals, perm_t, n_items, n_pairs, u, own=v if euclid else None)
         else:
             dv = spmm_raw(indptr_t, users_t, vals, perm_t, n_items, n_pairs, u)

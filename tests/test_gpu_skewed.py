@@ -54,7 +54,7 @@ def skewed_csr(n_rows, n_cols, seed, long_rows=(0, 7, 41), long_nnz=(17, 100, 10
     return m
 
 
-@pytest.mark.parametrize("d", [4, 64, 128, 256, 1024, 100])
+@pytest.mark.parametrize("d", [4, 64, 128, 256, 1024, 100, 1, 5, 10, 50, 250])
 def test_split_spmm_short_rows_exact_long_rows_close_and_deterministic(ops, small_split, d):
     rng = np.random.default_rng(d)
     x = skewed_csr(120, 1500, seed=d)
@@ -155,7 +155,7 @@ def test_transposed_feature_gradient_with_a_long_column(ops):
     assert np.allclose(beta.grad.cpu().numpy(), x.T.astype(np.float64) @ gb.astype(np.float64), rtol=1e-5, atol=1e-3)
 
 
-@pytest.mark.parametrize("d", [32, 128, 256])
+@pytest.mark.parametrize("d", [32, 128, 256, 10, 50])
 @pytest.mark.parametrize("layout", ["interactions", "samples"])
 def test_euclidean_pair_gradient_structured_equals_autograd(ops, d, layout):
     """The structured Euclidean backward (coefficients + (own - other) gathers) against torch autograd on the CPU and
