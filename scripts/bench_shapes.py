@@ -92,5 +92,27 @@ if __name__ == "__main__":
             res.append(timed_fit("k%d-euclid: Linear d=%d, euclidean, WMRB S=100" % (dd, dd), m, inter, uf, itf,
                                  n_sampled_items=100))
             res.append(timed("k%d: predict_top_k all users" % dd, lambda: m.predict_top_k(uf, itf, k=10), 1))
+    if on("m"):
+        # the README / generate_dummy_data defaults: hashed features, 20 per row, 200 columns
+        di, du, dit = T.util.generate_dummy_data(num_users=15000, num_items=30000, interaction_density=.00045,
+                                                 random_state=0)
+        m = T.TensorRec(n_components=100, seed=0)
+        res.append(timed_fit("m1: README defaults 15000 x 30000, 200 features, d=100, RMSE", m, di, du, dit, epochs=5))
+        res.append(timed("m2: predict_rank 15000 x 30000 (to host)", lambda: m.predict_rank(du, dit), 1))
+        res.append(timed("m3: predict_similar_items, 100 items, n_similar=10",
+                         lambda: m.predict_similar_items(dit, item_ids=list(range(100)), n_similar=10), 1))
+        pr = m.predict_rank(du, dit)
+        res.append(timed("m4: recall/precision/ndcg @10 from the rank matrix (host)",
+                         lambda: (T.eval.recall_at_k(pr, di, 10), T.eval.precision_at_k(pr, di, 10), T.eval.ndcg_at_k(pr, di, 10)), 1))
+        m = T.TensorRec(n_components=100, loss_graph=L.WMRBLossGraph(), seed=0)
+        res.append(timed_fit("m5: same data, WMRB S=1000", m, di, du, dit, epochs=5, n_sampled_items=1000))
+    if on("n"):
+        m = T.TensorRec(n_components=64, n_tastes=3, attention_graph=R.LinearRepresentationGraph(),
+                        loss_graph=L.WMRBLossGraph(), seed=0)
+        res.append(timed_fit("n: 3 tastes + linear attention, d=64, WMRB S=100", m, inter, uf, itf, n_sampled_items=100))
+        bag = sp.random(N_ITEMS, 5000, density=0.06, random_state=3, dtype=np.float32, format="csr")      # 300 per row
+        m = T.TensorRec(n_components=128, loss_graph=L.WMRBLossGraph(), seed=0)
+        res.append(timed_fit("n2: item features = 5000-column bag, 300 per row, d=128, WMRB", m, inter, uf, bag,
+                             n_sampled_items=100))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(res, open(os.path.join(ROOT, "gpurun_out", "bench_shapes.json"), "w"), indent=1)
