@@ -305,6 +305,10 @@ def main():
                 write = [float(m) for m in re.findall(re.escape(key) + r"[^\n]*?WRITE_SIZE=([0-9.e+]+)", txt)]
                 if fetch and write:
                     break
+            k1f = re.findall(r"spmm_csr_vec4_kernel<1, 4, 0, true, true[^\n]*?FETCH_SIZE=([0-9.e+]+)", txt)
+            k1w = re.findall(r"spmm_csr_vec4_kernel<1, 4, 0, true, true[^\n]*?WRITE_SIZE=([0-9.e+]+)", txt)
+            if k1f and k1w and roofline_k1 is not None:          # per-dispatch averages over the user- and item-side launch
+                roofline_k1["traffic"] = (2.0 * float(k1f[0]) + float(k1w[0])) * 1024.0
             if fetch and write:
                 roofline["traffic"] = (2.0 * fetch[0] + write[0]) * 1024.0
                 roofline["traffic_note"] = ("bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KB from %s; fabric-side "
