@@ -183,3 +183,24 @@ def test_bench_cpu_baseline_leg_and_defaults(monkeypatch):
     a = bench.parse()
     assert (a.gpus, a.users, a.items, a.components, a.k, a.precision) == (1, 1_000_000, 1_000_000, 128, 10, "bf16")
     assert a.steps >= 1 and a.warmup >= 0
+
+
+def test_upload_fingerprint_and_split_policies():
+    """host-side keys of the upload cache and the dispatch rules of the chunked gathers (no GPU involved)"""
+    from tensorrec_amd.tensorrec import _fingerprint
+    from tensorrec_amd import ops
+    m = sp.random(50, 40, density=0.2, random_state=0, dtype=np.float32, format="csr")
+    same = sp.csr_matrix((m.data.copy(), m.indices.copy(), m.indptr.copy()), shape=m.shape)
+    assert _fingerprint(m) == _fingerprint(same) and _fingerprint(m) is not None
+    other = same.copy()
+    other.data[3] += 1.0
+    assert _fingerprint(other) != _fingerprint(m)
+    moved = sp.csr_matrix((m.data, (m.indices + 1) % 40, m.indptr), shape=m.shape)
+    assert _fingerprint(moved) != _fingerprint(m)
+    assert _fingerprint(m.tocoo()) is None and _fingerprint(sp.csr_matrix((50, 41), dtype=np.float32)) != \
+        _fingerprint(sp.csr_matrix((50, 40), dtype=np.float32))
+    assert ops._split_ok(128) and ops._split_ok(1024) and ops._split_ok(10) and ops._split_ok(250)
+    assert not ops._split_ok(1028) and not ops._split_ok(257)
+    assert ops._prefer_split(50, 1 << 20) and not ops._prefer_split(48, 1 << 20) and not ops._prefer_split(50, 1000)
+    assert ops._sampled_buckets_long(2_000_000, 10) and ops._sampled_buckets_long(1 << 20, 1 << 20)
+    assert not ops._sampled_buckets_long(100_000, 1000)
