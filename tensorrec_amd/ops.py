@@ -756,11 +756,11 @@ def score_topk_two_stage(users_op, items_op, dtype, kpad, k, user_bias=None, ite
     ksel = min(int(k), n_sb)
     rows_wg = N.query("trec_score_rows_per_workgroup", dtype, kpad)
     if n_chunks is None:
-        # Stage 1 has no per-chunk state, so item chunks only set the workgroup count: aim for >= 16 "rounds" of the
-        # 768 co-resident workgroups (3 per CU) so that the last, partially filled round costs < 6% (with one chunk,
-        # 1M users = 3907 workgroups = 5.09 rounds, i.e. 15% of the time is a nearly empty sixth round).
+        # Stage 1 has no per-chunk state, so item chunks only set the workgroup count: aim for ~50 "rounds" of the
+        # 512 co-resident workgroups (2 per CU) so that the last, partially filled round costs ~1% (measured at 1M x 1M:
+        # 7 chunks = 27 rounds 171.1 ms, 14 chunks 169.0, 28 chunks 169.3, 56 chunks 169.2).
         rblocks = (n_u + rows_wg - 1) // rows_wg
-        n_chunks = max(1, min(n_sb, -(-16 * 768 // rblocks)))
+        n_chunks = max(1, min(n_sb, -(-32 * 768 // rblocks)))
     # ---- stage 1: superblock maxima
     blockmax = torch.empty((n_sb, n_u), dtype=torch.float32, device=dev)
     with _timed("score_gemm_blockmax"):
