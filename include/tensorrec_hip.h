@@ -211,6 +211,12 @@ int trec_rank_rows(const float* scores, int64_t n_users, int64_t n_items, int64_
 int trec_rank_of_pairs(const float* scores, int64_t ld_scores, int64_t col_offset, int64_t begin, int64_t end,
                        const int32_t* xu, const int32_t* xi, const float* target_scores, int64_t n_pairs,
                        int32_t add_one, int32_t* out, void* stream);
+/* The same counts for pairs GROUPED BY USER (pair_indptr[n_users+1]: user u of the score slab owns pairs
+ * pair_indptr[u] .. pair_indptr[u+1]; xi / target_scores / out are indexed by pair): every slice of a user's row is read
+ * once for all of the user's targets instead of once per pair.  out is overwritten. */
+int trec_rank_of_pairs_by_user(const float* scores, int64_t ld_scores, int64_t col_offset, int64_t begin, int64_t end,
+                               const int64_t* pair_indptr, const int32_t* xi, const float* target_scores,
+                               int64_t n_users, int64_t n_pairs, int32_t add_one, int32_t* out, void* stream);
 
 /* ---- K6: losses ---------------------------------------------------------------------------------------------
  * WMRB / BalancedWMRB, loss_graphs.py:153-180 / :189-227.  Interactions are CSR over users (indptr[n_users+1]);

@@ -64,6 +64,7 @@ SIGNATURES = {
     "trec_group_pairs_by_item": [_vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp],
     "trec_rank_rows": [_vp, _i64, _i64, _i64, _vp, _i64, _vp],
     "trec_rank_of_pairs": [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _i32, _vp, _vp],
+    "trec_rank_of_pairs_by_user": [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp],
     "trec_wmrb_fwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp],
     "trec_wmrb_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp],
     "trec_wmrb_fused_lds_bytes": [_i32, _i32, _i32],

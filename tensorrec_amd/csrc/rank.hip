@@ -191,6 +191,58 @@ __global__ __launch_bounds__(256) void rank_of_pairs_kernel(const float* __restr
     if (lane == 0) out[p] = cnt + (add_one ? 1 : 0);
 }
 
+// Pairs grouped by user (pair_indptr[u] .. pair_indptr[u+1] are user u's pairs): a workgroup owns (user, item slice) and
+// reads the slice ONCE for all of the user's targets, eight at a time in registers -- the wave-per-pair kernel above
+// streams the user's row once per pair (20 positives per user over 1M items: 80 MB per user instead of 4).  Counts are
+// integers, so the slices' partial counts are added with atomics without losing exactness; out must be zeroed (the +1
+// is added by slice 0).
+#define RANK_BU_TGT 8
+__global__ __launch_bounds__(256) void rank_of_pairs_by_user_kernel(
+    const float* __restrict__ scores, int64_t ld, int64_t col_offset, int64_t begin, int64_t end, int64_t slice_len,
+    const int64_t* __restrict__ pair_indptr, const int32_t* __restrict__ xi, const float* __restrict__ target_scores,
+    int add_one, int32_t* __restrict__ out)
+{
+    __shared__ int part[4][RANK_BU_TGT];
+    const int64_t u = blockIdx.y;
+    const int64_t p0 = pair_indptr[u], p1 = pair_indptr[u + 1];
+    if (p0 == p1) return;
+    const int64_t b = begin + (int64_t)blockIdx.x * slice_len;
+    const int64_t e = b + slice_len < end ? b + slice_len : end;
+    if (b >= e && !(add_one && blockIdx.x == 0)) return;          // (an empty range still owes the +1)
+    const float* row = scores + u * ld - col_offset;              // row[j] valid for j in [begin, end)
+    const int lane = lane_id(), w = threadIdx.x >> 6;
+    for (int64_t q0 = p0; q0 < p1; q0 += RANK_BU_TGT) {
+        float tv[RANK_BU_TGT];
+        int64_t ti[RANK_BU_TGT];
+        int cnt[RANK_BU_TGT];
+#pragma unroll
+        for (int t = 0; t < RANK_BU_TGT; ++t) {
+            const bool v = q0 + t < p1;
+            tv[t] = v ? target_scores[q0 + t] : INFINITY;         // nothing beats +inf with index -1: count stays 0
+            ti[t] = v ? (int64_t)xi[q0 + t] : -1;
+            cnt[t] = 0;
+        }
+        for (int64_t j = b + threadIdx.x; j < e; j += 256) {
+            const float s = row[j];
+#pragma unroll
+            for (int t = 0; t < RANK_BU_TGT; ++t) cnt[t] += (s > tv[t]) || (s == tv[t] && j < ti[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < RANK_BU_TGT; ++t) {
+            int c = cnt[t];
+            for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+            if (lane == 0) part[w][t] = c;
+        }
+        __syncthreads();
+        if (threadIdx.x < RANK_BU_TGT && q0 + threadIdx.x < p1) {
+            const int t = threadIdx.x;
+            const int total = part[0][t] + part[1][t] + part[2][t] + part[3][t] + ((add_one && blockIdx.x == 0) ? 1 : 0);
+            if (total) atomicAdd(out + q0 + t, total);
+        }
+        __syncthreads();
+    }
+}
+
 extern "C" int trec_rank_rows(const float* scores, int64_t n_users, int64_t n_items, int64_t ld_scores,
                               int32_t* ranks, int64_t ld_ranks, void* stream)
 {
@@ -240,4 +292,36 @@ extern "C" int trec_rank_of_pairs(const float* scores, int64_t ld_scores, int64_
                        (hipStream_t)stream, scores, ld_scores, col_offset, begin, end, xu, xi, target_scores, n_pairs,
                        add_one, out);
     return trec_check_launch("trec_rank_of_pairs");
+}
+
+extern "C" int trec_rank_of_pairs_by_user(const float* scores, int64_t ld_scores, int64_t col_offset, int64_t begin,
+                                          int64_t end, const int64_t* pair_indptr, const int32_t* xi,
+                                          const float* target_scores, int64_t n_users, int64_t n_pairs, int32_t add_one,
+                                          int32_t* out, void* stream)
+{
+    TREC_REQUIRE(scores && pair_indptr && out, "trec_rank_of_pairs_by_user: null pointer");
+    TREC_REQUIRE(n_pairs == 0 || (xi && target_scores), "trec_rank_of_pairs_by_user: null pair arrays");
+    TREC_REQUIRE(begin <= end, "trec_rank_of_pairs_by_user: begin > end");
+    if (n_pairs == 0 || n_users == 0) return TREC_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(out, 0, sizeof(int32_t) * (size_t)n_pairs, st) != hipSuccess) {
+        trec_set_last_error("trec_rank_of_pairs_by_user: memset failed");
+        return TREC_ERR_LAUNCH;
+    }
+    if (begin == end && !add_one) return TREC_OK;                // an empty item range contributes only the +1
+    // enough (user, slice) workgroups to fill the chip, slices of at least 4096 items
+    const int64_t len = end - begin > 0 ? end - begin : 1;
+    int64_t n_slices = ceil_div64(4096, n_users);
+    const int64_t max_slices = ceil_div64(len, 4096);
+    if (n_slices > max_slices) n_slices = max_slices;
+    if (n_slices < 1) n_slices = 1;
+    const int64_t slice_len = ceil_div64(len, n_slices);
+    n_slices = ceil_div64(len, slice_len);
+    for (int64_t u0 = 0; u0 < n_users; u0 += 65535) {            // gridDim.y is limited to 65535
+        const unsigned by = (unsigned)((n_users - u0 < 65535) ? (n_users - u0) : 65535);
+        hipLaunchKernelGGL(rank_of_pairs_by_user_kernel, dim3((unsigned)n_slices, by), dim3(256), 0, st,
+                           scores + u0 * ld_scores, ld_scores, col_offset, begin, end, slice_len, pair_indptr + u0, xi,
+                           target_scores, add_one, out);
+    }
+    return trec_check_launch("trec_rank_of_pairs_by_user");
 }

@@ -834,6 +834,16 @@ def rank_of_pairs(scores, col_offset, begin, end, xu32, xi32, target_scores, add
     return out
 
 
+def rank_of_pairs_by_user(scores, col_offset, begin, end, pair_indptr, xi32, target_scores, add_one=True):
+    """rank_of_pairs for pairs grouped by user (pair_indptr int64 [n_users + 1] over the rows of ``scores``): a user's
+    row is read once for all of the user's targets."""
+    n_pairs = xi32.numel()
+    out = torch.empty((n_pairs,), dtype=torch.int32, device=scores.device)
+    N.call("trec_rank_of_pairs_by_user", N.ptr(scores), scores.stride(0), col_offset, begin, end, N.ptr(pair_indptr),
+           N.ptr(xi32), N.ptr(target_scores), scores.shape[0], n_pairs, 1 if add_one else 0, N.ptr(out))
+    return out
+
+
 def sample_items(n_users, n_items, n_sampled, replace, seed, step, device="cuda", user_base=0):
     out = torch.empty((n_users, n_sampled), dtype=torch.int32, device=device)
     N.call("trec_sample_items", n_users, int(user_base), n_items, n_sampled, 1 if replace else 0,

@@ -778,9 +778,10 @@ class TensorRec(object):
                     # and read the pairs' ranks off the tile, instead of one 26k-item count per pair
                     r = ops.rank_rows(slab)[xu, xi]
                 else:
+                    # (rows is sorted: the tile's pairs are grouped by user; one pass over a row serves all its targets)
                     target = slab[xu, xi].contiguous()
-                    r = ops.rank_of_pairs(slab, 0, 0, n_items, xu.to(torch.int32), xi.to(torch.int32), target,
-                                          add_one=True)
+                    tile_ptr = torch.from_numpy(np.searchsorted(rows[p0:p1], np.arange(s, e + 1)).astype(np.int64)).to(device)
+                    r = ops.rank_of_pairs_by_user(slab, 0, 0, n_items, tile_ptr, xi.to(torch.int32), target, add_one=True)
                 ranks[p0:p1] = r.cpu().numpy()
         return PairRanks(rows, ranks, vals, n_users)
 

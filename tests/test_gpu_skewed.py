@@ -267,3 +267,30 @@ def test_rank_rows_sorted_path_is_bit_exact(ops, n_items):
         assert np.array_equal(ops.rank_rows(dev(s)).cpu().numpy(), got)    # the counting kernel alone agrees
     finally:
         N.set_tuning("rank_sorted", 1)
+
+
+@pytest.mark.parametrize("n_items", [300, 5000, 70000])
+def test_rank_of_pairs_by_user_equals_wave_per_pair(ops, n_items):
+    """pairs grouped by user (one pass over a row for all of its targets, item slices added with integer atomics)
+    against the wave-per-pair kernel and the counting definition: ties, users without pairs, more than eight targets,
+    item sub-ranges with a column offset."""
+    rng = np.random.default_rng(n_items)
+    nu = 37
+    s = rng.integers(0, 60, (nu, n_items)).astype(np.float32)            # ties everywhere
+    per_user = rng.integers(0, 25, nu)
+    per_user[[0, 5, nu - 1]] = 0
+    xu = np.repeat(np.arange(nu), per_user).astype(np.int32)
+    xi = np.concatenate([np.sort(rng.choice(n_items, c, replace=False)) for c in per_user] + [np.zeros(0, np.int64)]).astype(np.int32)
+    indptr = np.concatenate([[0], np.cumsum(per_user)]).astype(np.int64)
+    st, tgt = dev(s), dev(s[xu, xi])
+    full = O.rank_predictions_exact(s)[xu, xi]
+    got = ops.rank_of_pairs_by_user(st, 0, 0, n_items, dev(indptr), dev(xi), tgt, add_one=True).cpu().numpy()
+    assert np.array_equal(got, full)
+    assert np.array_equal(got, ops.rank_of_pairs(st, 0, 0, n_items, dev(xu), dev(xi), tgt, add_one=True).cpu().numpy())
+    # an item sub-range of a slab that starts at global column 100
+    b, e = 100 + n_items // 5, 100 + n_items // 2
+    part = ops.rank_of_pairs_by_user(st, 100, b, e, dev(indptr), dev(xi + 100), tgt, add_one=False).cpu().numpy()
+    ref = ops.rank_of_pairs(st, 100, b, e, dev(xu), dev(xi + 100), tgt, add_one=False).cpu().numpy()
+    assert np.array_equal(part, ref)
+    empty = ops.rank_of_pairs_by_user(st, 0, 7, 7, dev(indptr), dev(xi), tgt, add_one=True).cpu().numpy()
+    assert (empty == 1).all()
