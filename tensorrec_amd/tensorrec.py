@@ -765,9 +765,12 @@ class TensorRec(object):
         m.sort_indices()
         if m.shape[0] > uf.shape[0] or m.shape[1] > itf.shape[0]:
             raise ValueError("interactions do not fit the feature matrices")
-        coo = m.tocoo()
-        pos = coo.data > 0
-        rows, cols, vals = coo.row[pos].astype(np.int64), coo.col[pos].astype(np.int64), coo.data[pos]
+        # serial (row-major) view of the positive entries, int32 throughout; the all-positive case copies nothing
+        rows = np.repeat(np.arange(m.shape[0], dtype=np.int32), np.diff(m.indptr))
+        cols, vals = m.indices.astype(np.int32, copy=False), m.data
+        pos = vals > 0
+        if not pos.all():
+            rows, cols, vals = rows[pos], cols[pos], vals[pos]
         n_users, n_items = uf.shape[0], itf.shape[0]
         if user_batch_size is None:
             user_batch_size = max(64, min(n_users, (1 << 29) // max(1, n_items)))       # <= 2 GB of fp32 scores
@@ -789,8 +792,9 @@ class TensorRec(object):
                 else:
                     slab = self._dense_prediction(user_reprs[0][s:e], item_repr, ub, item_bias)
                 slab = slab.contiguous()
-                xu = torch.from_numpy(rows[p0:p1] - s).to(device)
-                xi = torch.from_numpy(cols[p0:p1]).to(device)
+                xi32 = torch.from_numpy(cols[p0:p1]).to(device)
+                xu = (torch.from_numpy(rows[p0:p1]).to(device) - s).long()
+                xi = xi32.long()
                 if 64 <= n_items <= 32768 and (p1 - p0) >= 32 * (e - s):
                     # many positives per user: sort every row once (K4's sorted form, ~0.1 ms per 32768-item row and CU)
                     # and read the pairs' ranks off the tile, instead of one 26k-item count per pair
@@ -799,7 +803,7 @@ class TensorRec(object):
                     # (rows is sorted: the tile's pairs are grouped by user; one pass over a row serves all its targets)
                     target = slab[xu, xi].contiguous()
                     tile_ptr = torch.from_numpy(np.searchsorted(rows[p0:p1], np.arange(s, e + 1)).astype(np.int64)).to(device)
-                    r = ops.rank_of_pairs_by_user(slab, 0, 0, n_items, tile_ptr, xi.to(torch.int32), target, add_one=True)
+                    r = ops.rank_of_pairs_by_user(slab, 0, 0, n_items, tile_ptr, xi32, target, add_one=True)
                 ranks[p0:p1] = r.cpu().numpy()
         return PairRanks(rows, ranks, vals, n_users)
 
