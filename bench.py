@@ -42,7 +42,9 @@ def parse():
     ap.add_argument("--items", type=int, default=1_000_000)
     ap.add_argument("--components", type=int, default=128)
     ap.add_argument("--k", type=int, default=10)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="exact", choices=["exact", "bf16", "fp32"],
+                    help="exact (default): fp32 results, contraction on bf16 MFMA as an error-bounded filter + fp32 "
+                         "re-scoring of the survivors; bf16: approximate bf16 scores; fp32: fp32 MFMA throughout")
     ap.add_argument("--variant", type=int, default=int(os.environ.get("TREC_SCORE_VARIANT", "1")))
     ap.add_argument("--chunks", type=int, default=0, help="item chunks per user block (0 = auto)")
     ap.add_argument("--method", default="auto", choices=["auto", "direct", "two_stage"])
@@ -50,6 +52,8 @@ def parse():
     ap.add_argument("--no-fit", action="store_true", help="skip the fit epochs/sec measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-users", type=int, default=1024)
+    ap.add_argument("--parity-users", type=int, default=4096, help="users checked against the oracle in exact mode")
+    ap.add_argument("--no-fp32-mode", action="store_true", help="skip the all-fp32-MFMA record")
     ap.add_argument("--tune", action="append", default=[], metavar="NAME=INT",
                     help="diagnostic: set a kernel tuning knob (trec_set_tuning), e.g. blockmax_pipelined=0")
     return ap.parse_args()
@@ -173,7 +177,8 @@ def main():
         name, _, val = kv.partition("=")
         T._native.set_tuning(name, int(val))
     U, I, d, k = args.users, args.items, args.components, args.k
-    dtype = ops.DTYPE_BF16 if args.precision == "bf16" else ops.DTYPE_F32
+    dtype = ops.DTYPE_F32 if args.precision == "fp32" else ops.DTYPE_BF16     # arithmetic type of the MFMA stage
+    exact = args.precision == "exact"
     i_begin, i_end = sharding.shard_bounds(I, world, rank, align=64)
     n_local = i_end - i_begin
 
@@ -206,6 +211,18 @@ def main():
             item_repr = ops.spmm_raw(f_i.indptr, f_i.indices, f_i.values, None, n_local, f_i.nnz, w_i)    # K1
             ub = None if args.unbiased else ops.sparse_matvec(f_u, beta_u)
             ib = None if args.unbiased else ops.sparse_matvec(f_i, beta_i)
+            if exact and method == "two_stage":
+                # fp32-exact top-k: bf16 MFMA stage 1 as an error-bounded filter, survivors re-scored in fp32
+                u_f = ops.score_prep_filter(user_repr)
+                i_f = ops.score_prep_filter(item_repr, bias=ib, want_gstats=True)
+                vals, idx = ops.score_topk_filtered(
+                    u_f, i_f, k, ub, ib, item_index_base=i_begin, variant=args.variant,
+                    n_chunks=args.chunks if args.chunks > 0 else None,
+                    floor_exchange=sharding.shared_topk_floor if world > 1 else None,
+                    stats_exchange=sharding.all_reduce_max if world > 1 else None)
+                if world > 1:
+                    vals, idx = sharding.sharded_top_k(vals, idx, k)
+                return vals, idx, user_repr, item_repr
             u_op, _, _ = ops.score_prep(user_repr, dtype)
             i_op, _, _ = ops.score_prep(item_repr, dtype)
             if method == "direct":
@@ -268,11 +285,11 @@ def main():
     k2_name = "score_gemm_topk" if method == "direct" else "score_gemm_blockmax"
     k2_ms = float(np.mean(dur[k2_name]))
     k2_flops = 2.0 * U * n_local * kpad                    # algorithmic: 2*U*I*d per launch (d = kpad = 128 here)
-    peak = BF16_DENSE_PEAK_TFLOPS if args.precision == "bf16" else FP32_MFMA_PEAK_TFLOPS
+    peak = FP32_MFMA_PEAK_TFLOPS if args.precision == "fp32" else BF16_DENSE_PEAK_TFLOPS
     k2_tflops = k2_flops / (k2_ms * 1e-3) / 1e12
     k2_label = "score_gemm_kernel (fused top-k epilogue)" if method == "direct" else (
         "blockmax_pipe_kernel (superblock maxima, stage 1 of the two-stage top-k)"
-        if args.precision == "bf16" and kpad in (64, 128) and T._native.load().trec_get_tuning(b"blockmax_pipelined", 1)
+        if args.precision != "fp32" and kpad in (64, 128) and T._native.load().trec_get_tuning(b"blockmax_pipelined", 1)
         else "score_gemm_kernel (superblock-max epilogue)")
     roofline = {"kernel": k2_label,
                 "bound": "mfma", "achieved": k2_tflops,
@@ -317,34 +334,63 @@ def main():
     except Exception:
         pass
 
-    # ---- live parity check on a sample of users (oracle = checker only) ----
+    # ---- live parity check against the oracle (checker only): the timed step's own output, on sampled users ----
     parity = None
     try:
         from oracle import oracle as O
         vals, idx, user_repr, item_repr = out
-        sample = np.linspace(0, U - 1, 32).astype(np.int64)
-        if True:
-            us = user_repr[torch.from_numpy(sample).to(device)].cpu().numpy()
-            it = item_repr.cpu().numpy()
-            ref = us.astype(np.float32) @ it.T                               # fp32 sgemm reference scores
+        n_sample = args.parity_users if exact else 32
+        sample = np.unique(np.linspace(0, U - 1, n_sample).astype(np.int64))
+        sample_dev = torch.from_numpy(sample).to(device)
+        it = item_repr.cpu().numpy()
+        got_i = idx[sample_dev].cpu().numpy()
+        got_v = vals[sample_dev].cpu().numpy()
+        us_all = user_repr[sample_dev].cpu().numpy()
+        ids_equal = vals_equal = True
+        overlap, max_rel = [], 0.0
+        t_par = time.perf_counter()
+        for s0 in range(0, len(sample), 512):                       # 512 x 1M fp32 scores = 2 GB per tile on the host
+            us = us_all[s0:s0 + 512]
+            ref = O.score_dense_exact(us, it)                        # fp32 k-ordered fmaf chain (tr_oracle.c), zero biases
             rv, ri = O.topk_rows(ref, k)
-            got_i = idx[torch.from_numpy(sample).to(device)].cpu().numpy()
-            got_v = vals[torch.from_numpy(sample).to(device)].cpu().numpy()
-            overlap = float(np.mean([len(set(a) & set(b)) / float(k) for a, b in zip(got_i, ri)]))
-            # exact mode on the same users through the same kernel family
-            u32, _, _ = ops.score_prep(user_repr[torch.from_numpy(sample).to(device)].contiguous(), ops.DTYPE_F32)
-            i32, _, _ = ops.score_prep(item_repr, ops.DTYPE_F32)
-            ev, ei = ops.score_topk(u32, i32, ops.DTYPE_F32, kpad, k)
-            exact_ref = O.topk_rows(O.score_dense_exact(us, it), k)
-            parity = {"sample_users": len(sample),
-                      "topk_overlap_%s_vs_fp32_oracle" % args.precision: overlap,
-                      "max_rel_score_err_%s" % args.precision:
-                          float(np.max(np.abs(got_v - np.take_along_axis(ref, got_i.astype(np.int64), 1)))
-                                / np.abs(ref).max()),
-                      "fp32_mode_topk_bit_exact_vs_oracle": bool(np.array_equal(ei.cpu().numpy(), exact_ref[1])
-                                                                 and np.array_equal(ev.cpu().numpy(), exact_ref[0]))}
+            gi, gv = got_i[s0:s0 + 512], got_v[s0:s0 + 512]
+            ids_equal = ids_equal and bool(np.array_equal(gi, ri))
+            vals_equal = vals_equal and bool(np.array_equal(gv, rv))
+            overlap += [len(set(a) & set(b)) / float(k) for a, b in zip(gi, ri)]
+            max_rel = max(max_rel, float(np.max(np.abs(gv - np.take_along_axis(ref, gi.astype(np.int64), 1)))
+                                         / np.abs(ref).max()))
+        parity = {"sample_users": int(len(sample)), "mode": args.precision,
+                  "topk_overlap_vs_fp32_oracle": float(np.mean(overlap)),
+                  "topk_ids_bit_exact_vs_oracle": ids_equal, "topk_values_bit_exact_vs_oracle": vals_equal,
+                  "max_rel_score_err": max_rel, "oracle_seconds": time.perf_counter() - t_par}
+        if exact:
+            parity["filter"] = dict(ops.LAST_FILTER_STATS)
     except Exception as exc:      # the measurement stands on its own; report why the check could not run
         parity = {"error": repr(exc)}
+
+    # ---- the all-fp32-MFMA form of the same top-k (v_mfma_f32_32x32x2_f32 throughout), as a driver-run record ----
+    fp32_mode = None
+    if exact and world == 1 and not args.no_fp32_mode:
+        try:
+            vals, idx, user_repr, item_repr = out
+            n32 = min(U, 65536)
+            u32, _, _ = ops.score_prep(user_repr[:n32].contiguous(), ops.DTYPE_F32)
+            i32, _, _ = ops.score_prep(item_repr, ops.DTYPE_F32)
+            ops.score_topk_two_stage(u32, i32, ops.DTYPE_F32, kpad, k)                    # warm-up
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            reps = 3
+            for _ in range(reps):
+                ev, ei = ops.score_topk_two_stage(u32, i32, ops.DTYPE_F32, kpad, k)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / reps
+            fp32_mode = {"workload": "%d users x %d items, whole two-stage top-%d on fp32 MFMA" % (n32, n_local, k),
+                         "ms": 1e3 * dt, "predictions_per_s": n32 * float(n_local) / dt,
+                         "tflops": 2.0 * n32 * n_local * kpad / dt / 1e12,
+                         "frac_of_fp32_mfma_peak": 2.0 * n32 * n_local * kpad / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                         "equals_timed_exact_mode_output": bool(torch.equal(ei, idx[:n32]) and torch.equal(ev, vals[:n32]))}
+        except Exception as exc:
+            fp32_mode = {"error": repr(exc)}
 
     cpu = None
     if not args.no_cpu_baseline and world == 1:
@@ -353,14 +399,19 @@ def main():
     line = {
         "metric": "user-item predictions/sec", "value": value, "unit": "predictions/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-        "scaling": "strong", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+        "scaling": "strong", "vs_baseline": None,
+        "dtype": "fp32" if args.precision == "fp32" else "bf16",      # arithmetic type of the dominant (MFMA) kernel
+        "result_precision": "fp32-exact (bf16 MFMA filter with a proven error bound + fp32 re-scoring of the survivors)"
+                            if exact else args.precision,
+        "data": "synthetic",
         "config": {"workload": "synthetic %d users x %d items, identity features, d=%d, LinearRepresentation + "
                                "DotProduct, biased, fused top-%d (BASELINE.json configs[2])" % (U, I, d, k),
                    "users": U, "items": I, "n_components": d, "top_k": k,
                    "parallelism": "items sharded x%d, users replicated" % world,
                    "topk_method": method,
                    "score_kernel_variant": "global_load_lds" if args.variant & 1 else "register-staged"},
-        "roofline": roofline, "roofline_k1": roofline_k1, "cpu_baseline": cpu, "parity": parity, "fit": fit,
+        "roofline": roofline, "roofline_k1": roofline_k1, "cpu_baseline": cpu, "parity": parity,
+        "fp32_mfma_mode": fp32_mode, "fit": fit,
     }
     print(json.dumps(line))
     if world > 1:

@@ -51,6 +51,11 @@ SIGNATURES = {
     "trec_score_gemm_blockmax": [_vp, _vp, _i32, _i32, _i64, _i64, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _i64, _i32,
                                  _vp],
     "trec_topk_select_blocks": [_vp, _i32, _i64, _i64, _i32, _vp, _vp, _vp, _vp],
+    "trec_topk_select_blocks_ex": [_vp, _i32, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp],
+    "trec_score_prep_filter": [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
+    "trec_topk_filter_floor": [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i64, _vp, _vp, _vp, _vp],
+    "trec_topk_filter_finish": [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _i32, _i64,
+                                _i32, _vp, _vp, _vp, _vp, _vp],
     "trec_topk_group_keys": [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp],
     "trec_topk_pad_counts": [_vp, _i32, _i32, _vp, _vp],
     "trec_exclusive_scan_i32": [_vp, _i64, _vp, _vp, _vp],

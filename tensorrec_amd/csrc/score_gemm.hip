@@ -22,6 +22,7 @@
 // in k order, bit-identical to oracle/tr_oracle.c:orc_score_dense; 1 = bf16 operands on
 // v_mfma_f32_32x32x16_bf16 with fp32 accumulate (the throughput mode named by BASELINE.json).
 #include "score_common.hpp"
+#include "topk_common.hpp"
 #include <math.h>
 
 #define EPI_STORE 0
@@ -70,15 +71,6 @@ __device__ __forceinline__ int opaque_uniform(int x)
 }
 
 __device__ __forceinline__ bool wave_any(bool x) { return __builtin_amdgcn_ballot_w64(x) != 0ull; }
-
-// largest float strictly below x (x finite or -inf, never NaN): v >= x  <=>  v > float_pred(x)
-__device__ __forceinline__ float float_pred(float x)
-{
-    const unsigned int u = __float_as_uint(x);
-    if (x == -INFINITY) return x;
-    if ((u << 1) == 0u) return __uint_as_float(0x80000001u);
-    return __uint_as_float(x > 0.f ? u - 1u : u + 1u);
-}
 
 __device__ __forceinline__ int cd_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }  // 32x32 C/D row of reg r
 
@@ -454,7 +446,10 @@ __global__ __launch_bounds__(256, WPS) void score_gemm_kernel(ScoreParams p)
                                 }
                             }
                         }
-                        tau_pp[cb] = fmaxf(tau_pp[cb], float_pred(__shfl_xor(tv[cb][KTOP - 1], 32, 64)));
+                        // (independent lists -- the bf16 FILTER of the exact top-k, topk_filter.hip -- keep every score
+                        // >= the row's floor that fits: what a list drops is then below ITS OWN last entry only)
+                        if (!p.independent_lists)
+                            tau_pp[cb] = fmaxf(tau_pp[cb], float_pred(__shfl_xor(tv[cb][KTOP - 1], 32, 64)));
                         thr[cb] = fmaxf(tv[cb][KTOP - 1], tau_pp[cb]);
                     }
                 }
@@ -533,37 +528,6 @@ __global__ __launch_bounds__(256, WPS) void score_gemm_kernel(ScoreParams p)
 // mapped monotonically onto unsigned, low word: ~index -- so "best" is an unsigned 64-bit maximum, taken across the
 // wave with DPP row rotations + row broadcasts (VALU-only; the ds_bpermute butterflies this replaces cost ~1200 cycles
 // per round, 10 rounds per user).
-__device__ __forceinline__ unsigned long long merge_key(float v, int32_t id)
-{
-    const unsigned int u = (v == 0.f) ? 0u : __float_as_uint(v);            // -0.0 and +0.0 compare equal: one key
-    const unsigned int hi = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-    return ((unsigned long long)hi << 32) | (unsigned int)(~id);
-}
-
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ unsigned long long dpp_max_u64(unsigned long long x)
-{
-    const int lo = (int)(unsigned int)x, hi = (int)(unsigned int)(x >> 32);
-    const unsigned int tlo = (unsigned int)__builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
-    const unsigned int thi = (unsigned int)__builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
-    const unsigned long long t = ((unsigned long long)thi << 32) | tlo;
-    return t > x ? t : x;
-}
-
-// maximum over the 64 lanes, returned in every lane
-__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long x)
-{
-    x = dpp_max_u64<0x128, 0xf>(x);      // row_ror:8
-    x = dpp_max_u64<0x124, 0xf>(x);      // row_ror:4
-    x = dpp_max_u64<0x122, 0xf>(x);      // row_ror:2
-    x = dpp_max_u64<0x121, 0xf>(x);      // row_ror:1   -> every lane: maximum of its 16-lane row
-    x = dpp_max_u64<0x142, 0xa>(x);      // row_bcast15 -> rows 1, 3 also cover rows 0, 2
-    x = dpp_max_u64<0x143, 0xc>(x);      // row_bcast31 -> row 3 covers all four rows
-    const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)x, 63);
-    const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(x >> 32), 63);
-    return ((unsigned long long)hi << 32) | lo;
-}
-
 template <int CPL>
 __global__ __launch_bounds__(256) void topk_merge_kernel(const float* __restrict__ pv, const int32_t* __restrict__ pi,
                                                         int64_t n_users, int n_cand, int k, float* __restrict__ ov,
@@ -868,6 +832,7 @@ extern "C" int trec_score_gemm_topk_grouped(const void* users_g, const void* ite
     p.rblock_chunk = rblock_chunk; p.row_pair = row_pair; p.row_floor = row_floor;
     p.part_vals = part_vals; p.part_idx = part_idx; p.n_parts = 2; p.t_index_base = item_index_base;
     p.capacity = capacity;
+    p.independent_lists = (variant >> 4) & 1;
     if (capacity == 8) return dispatch_score<EPI_TOPK, 8>(dtype, kpad, variant & 1, p, (hipStream_t)stream);
     if (capacity == 12) return dispatch_score<EPI_TOPK, 12>(dtype, kpad, variant & 1, p, (hipStream_t)stream);
     return dispatch_score<EPI_TOPK, 16>(dtype, kpad, variant & 1, p, (hipStream_t)stream);

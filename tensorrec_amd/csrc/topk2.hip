@@ -31,7 +31,7 @@ __device__ __forceinline__ void sel_insert(float (&tv)[KSEL], int32_t (&ti)[KSEL
 // one lane per user; blockmax is [n_sb][stride] so a wave reads 64 consecutive users per superblock (coalesced)
 template <int KSEL>
 __global__ __launch_bounds__(256) void select_blocks_kernel(const float* __restrict__ blockmax, int32_t n_sb,
-                                                           int64_t n_users, int64_t stride, int32_t k,
+                                                           int64_t n_users, int64_t stride, int32_t k, int32_t k_tau,
                                                            int32_t* __restrict__ sel, float* __restrict__ sel_max,
                                                            float* __restrict__ tau)
 {
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void select_blocks_kernel(const float* __restr
     int32_t ti[KSEL];
 #pragma unroll
     for (int j = 0; j < KSEL; ++j) { tv[j] = -INFINITY; ti[j] = -1; }
-    // slot k-1 (not KSEL-1) is the threshold: lists longer than k are never needed
+    // the list holds the KSEL best; tau = entry k_tau - 1 (the k-th largest maximum: a floor of the final k-th best score)
     for (int32_t s = 0; s < n_sb; ++s) {
         const float v = ok ? blockmax[(int64_t)s * stride + u] : -INFINITY;
         const bool hit = (v > tv[KSEL - 1]) || (ti[KSEL - 1] < 0 && ok);      // strict: earlier superblocks win ties
@@ -56,7 +56,13 @@ __global__ __launch_bounds__(256) void select_blocks_kernel(const float* __restr
             }
         // k superblocks have a maximum >= tv[k-1], i.e. k items score >= it: a valid floor for the final k-th best score
         // (-inf while fewer than k superblocks exist).  The re-scoring pass starts its lists from this threshold.
-        if (tau) tau[u] = (ti[KSEL - 1] >= 0) ? tv[KSEL - 1] : -INFINITY;
+        if (tau) {
+            float t = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < KSEL; ++j)
+                if (j == k_tau - 1 && ti[j] >= 0) t = tv[j];
+            tau[u] = t;
+        }
     }
 }
 
@@ -68,7 +74,7 @@ __global__ __launch_bounds__(256) void select_blocks_kernel(const float* __restr
 #define SEL_TS 8
 template <int KSEL>
 __global__ __launch_bounds__(256) void select_blocks_tiled_kernel(const float* __restrict__ blockmax, int32_t n_sb,
-                                                                 int64_t n_users, int64_t stride, int32_t k,
+                                                                 int64_t n_users, int64_t stride, int32_t k, int32_t k_tau,
                                                                  int32_t* __restrict__ sel, float* __restrict__ sel_max,
                                                                  float* __restrict__ tau)
 {
@@ -121,7 +127,13 @@ __global__ __launch_bounds__(256) void select_blocks_tiled_kernel(const float* _
                 sel[u * k + j] = ti[j];
                 if (sel_max) sel_max[(int64_t)j * n_users + u] = tv[j];
             }
-        if (tau) tau[u] = (ti[KSEL - 1] >= 0) ? tv[KSEL - 1] : -INFINITY;
+        if (tau) {
+            float t = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < KSEL; ++j)
+                if (j == k_tau - 1 && ti[j] >= 0) t = tv[j];
+            tau[u] = t;
+        }
     }
 }
 
@@ -210,32 +222,48 @@ __global__ __launch_bounds__(256) void fill_groups_kernel(
     }
 }
 
-extern "C" int trec_topk_select_blocks(const float* blockmax, int32_t n_sb, int64_t n_users, int64_t stride, int32_t k,
-                                       int32_t* sel, float* sel_max, float* tau, void* stream)
+// k = entries kept per user (list length, <= 64), k_tau <= k = which entry is reported as tau
+extern "C" int trec_topk_select_blocks_ex(const float* blockmax, int32_t n_sb, int64_t n_users, int64_t stride, int32_t k,
+                                          int32_t k_tau, int32_t* sel, float* sel_max, float* tau, void* stream)
 {
     TREC_REQUIRE(blockmax && sel, "trec_topk_select_blocks: null pointer");
-    TREC_REQUIRE(k >= 1 && k <= 16 && n_sb >= 1, "trec_topk_select_blocks: need 1 <= k <= 16, n_sb >= 1");
+    TREC_REQUIRE(k >= 1 && k <= 64 && n_sb >= 1 && k_tau >= 1 && k_tau <= k, "trec_topk_select_blocks: need 1 <= k_tau <= k <= 64, n_sb >= 1");
     if (n_users == 0) return TREC_OK;
     const unsigned blocks = (unsigned)ceil_div64(n_users, 256);
     hipStream_t st = (hipStream_t)stream;
-    // the list length IS k here (threshold = k-th best): instantiate the lengths in use
     const bool tiled = stride % 4 == 0 && ((uintptr_t)blockmax % 16) == 0 && n_sb >= 4 * SEL_TS &&
                        trec_get_tuning("select_tiled", 1);
 #define TREC_SEL(KS)                                                                                                   \
     do {                                                                                                               \
         if (tiled) hipLaunchKernelGGL((select_blocks_tiled_kernel<KS>), dim3(blocks), dim3(256), 0, st, blockmax, n_sb, \
-                                      n_users, stride, k, sel, sel_max, tau);                                          \
+                                      n_users, stride, k, k_tau, sel, sel_max, tau);                                   \
         else hipLaunchKernelGGL((select_blocks_kernel<KS>), dim3(blocks), dim3(256), 0, st, blockmax, n_sb, n_users,    \
-                                stride, k, sel, sel_max, tau);                                                         \
+                                stride, k, k_tau, sel, sel_max, tau);                                                  \
     } while (0)
+    // the list length is a template parameter (registers): exact for k <= 16, rounded up above (entries beyond k unused)
     switch (k) {
         case 1: TREC_SEL(1); break;   case 2: TREC_SEL(2); break;   case 3: TREC_SEL(3); break;   case 4: TREC_SEL(4); break;
         case 5: TREC_SEL(5); break;   case 6: TREC_SEL(6); break;   case 7: TREC_SEL(7); break;   case 8: TREC_SEL(8); break;
         case 9: TREC_SEL(9); break;   case 10: TREC_SEL(10); break; case 11: TREC_SEL(11); break; case 12: TREC_SEL(12); break;
-        case 13: TREC_SEL(13); break; case 14: TREC_SEL(14); break; case 15: TREC_SEL(15); break; default: TREC_SEL(16); break;
+        case 13: TREC_SEL(13); break; case 14: TREC_SEL(14); break; case 15: TREC_SEL(15); break; case 16: TREC_SEL(16); break;
+        default:
+            if (k <= 20) TREC_SEL(20);
+            else if (k <= 24) TREC_SEL(24);
+            else if (k <= 32) TREC_SEL(32);
+            else if (k <= 40) TREC_SEL(40);
+            else if (k <= 48) TREC_SEL(48);
+            else TREC_SEL(64);
+            break;
     }
 #undef TREC_SEL
     return trec_check_launch("trec_topk_select_blocks");
+}
+
+extern "C" int trec_topk_select_blocks(const float* blockmax, int32_t n_sb, int64_t n_users, int64_t stride, int32_t k,
+                                       int32_t* sel, float* sel_max, float* tau, void* stream)
+{
+    TREC_REQUIRE(k >= 1 && k <= 16, "trec_topk_select_blocks: need 1 <= k <= 16");
+    return trec_topk_select_blocks_ex(blockmax, n_sb, n_users, stride, k, k, sel, sel_max, tau, stream);
 }
 
 extern "C" int trec_topk_group_keys(const int32_t* sel, const float* sel_max, const float* floor_, int64_t n, int32_t k,

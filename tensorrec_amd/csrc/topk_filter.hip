@@ -1,0 +1,301 @@
+// tensorrec_amd/csrc/topk_filter.hip -- K2f: the EXACT fp32 top-k at bf16-MFMA speed.
+//
+// The reference contracts user x item scores in float32 (tf.matmul, tensorrec/prediction_graphs.py:49-50; operands are
+// float32, tensorrec/input_utils.py:16) and ranks them with tf.nn.top_k (tensorrec/recommendation_graphs.py:80).  The
+// bf16 MFMA stage-1 kernel is 16x faster than the fp32 MFMA one but its scores differ from the fp32 ones by ~1e-3
+// relative, so on its own it misses ~0.6% of the top-10 slots.  Here it is used as a FILTER with a proven error bound,
+// and the survivors are re-scored exactly:
+//
+//   prep     trec_score_prep_filter: per operand row x (fp32, optionally l2-normalised) the bf16 image xh = bf16(x),
+//            |x| = ||x||_2 and |dx| = ||x - xh||_2 (the ACTUAL rounding error of this row, not the worst case), and
+//            device-side maxima of |x|, |dx|, |bias| over the item rows;
+//   stage 1  bf16 superblock maxima  Mh[s][u]  (score_blockmax.hip, unchanged);
+//   stage 2  trec_topk_select_blocks with a list of KSEL >= k entries;  tau_u = k-th largest Mh[.][u];
+//            trec_topk_filter_floor:   eps_u >= |sh(u,i) - s(u,i)| for EVERY item i (bound below);
+//                                      floor_u = tau_u - 2 eps_u;  superblocks with Mh >= floor_u are kept;
+//   stage 3  grouped bf16 re-scoring (score_gemm.hip, lists made independent): every item with sh >= floor_u;
+//   stage 4  trec_topk_filter_finish: the surviving items are re-scored in fp32 by the k-ordered fmaf chain of
+//            oracle/tr_oracle.c:orc_score_dense (+ biases in the reference's order (s + b_u) + b_i) and the k best by
+//            (value desc, index asc) are written -- bit-identical to the fp32 MFMA path and to the oracle.
+//
+// Why nothing of the true top-k is lost.  Let s = the fp32 score the reference order gives, sh = the bf16-path score,
+// |sh - s| <= eps for all items of user u.  k superblocks have Mh >= tau, each holds an item with sh >= tau, hence
+// s >= tau - eps: k distinct items, so the true k-th best t_k >= tau - eps.  An item of the true top-k (ties included:
+// the order is total) has s >= t_k, hence sh >= s - eps >= tau - 2 eps = floor: it sits in a kept superblock and passes
+// the stage-3 threshold.  Its exact fp32 score is then computed in stage 4 together with every other survivor, and the
+// exact order among the survivors is the exact order among all items for the first k places.
+// Capacity limits (KSEL superblocks per user, `capacity` entries per (user, superblock, half-wave) list, 64 survivors
+// per user) cannot lose an item silently: a saturated selection list whose last entry still passes the floor, a full
+// stage-3 list, more than 64 survivors, or a non-finite bound set flag[u], and the host re-does flagged users on the
+// exact fp32 MFMA path (ops.score_topk_filtered).
+//
+// The bound.  x = user operand row, y = item operand row (fp32), xh / yh their bf16 images, X = sum_k x_k y_k in real
+// arithmetic.  |sum xh yh - X| = |<xh - x, yh> + <x, yh - y>| <= |dx| |yh| + |x| |dy|  (Cauchy-Schwarz).  The fp32
+// reference chain errs by <= (K+2) 2^-24 (|x||y| + |b_u| + |b_i|) from X + b_u + b_i; the MFMA chain (bf16 products are
+// exact in fp32; K/16 chained 16-term blocks + the bias accumulator + one add) is charged 2^-22 per addition -- four
+// times round-to-nearest, covering truncating adders.  Every norm is computed in fp32 (relative error < K 2^-23) and
+// the sum is inflated by 2^-9; 1e-30 absorbs flushed denormals.  tests/test_gpu_filter.py measures max |sh - s| / eps
+// on random, adversarially aligned and near-tied inputs.
+#include "topk_common.hpp"
+
+#define FILTER_CMAX 64          // survivors per user the finish kernel can re-score (one per lane)
+
+__device__ __forceinline__ void atomic_max_nonneg(float* addr, float v)
+{
+    // v >= 0 (or NaN, which must win: it poisons the bound and flags every user): uint order == float order
+    // read first: after the first few waves almost nobody raises the maximum, and 500k same-address atomics would cost
+    // milliseconds (a stale L1 line only means one unnecessary atomic)
+    if (__float_as_uint(v) > *(volatile unsigned int*)addr) atomicMax((unsigned int*)addr, __float_as_uint(v));
+}
+
+// G lanes own one row; a lane handles float4 chunks (kt <= 256 = 2 * 32 lanes * 4).  Same normalisation arithmetic
+// as score_prep_vec4_kernel (score_gemm.hip), so out_f32 / out_bf16 are bit-identical to trec_score_prep's outputs.
+template <int G>
+__global__ __launch_bounds__(256) void prep_filter_kernel(const float* __restrict__ x, int64_t n, int d, int kt,
+                                                         int normalize, const float* __restrict__ bias,
+                                                         float* __restrict__ out_f32, unsigned short* __restrict__ out_bf16,
+                                                         float2* __restrict__ row_stats, float* __restrict__ gstats)
+{
+    const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const bool ok = row < n;
+    const int sub = threadIdx.x % G;
+    const float* xr = x + (ok ? row : 0) * (int64_t)d;
+    f32x4 v[2];
+    float ss = 0.f;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int c = (it * G + sub) * 4;
+        v[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (ok && c < d) {
+            if ((d & 3) == 0) v[it] = *(const f32x4*)(xr + c);
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (c + e < d) v[it][e] = xr[c + e];
+            }
+        }
+        ss = fmaf(v[it][0], v[it][0], ss); ss = fmaf(v[it][1], v[it][1], ss);
+        ss = fmaf(v[it][2], v[it][2], ss); ss = fmaf(v[it][3], v[it][3], ss);
+    }
+    float scale = 1.0f;
+    if (normalize) {
+        for (int off = G / 2; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+        scale = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
+    }
+    float sw = 0.f, se = 0.f;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int c = (it * G + sub) * 4;
+        f32x4 w = v[it];
+        if (normalize) { w[0] *= scale; w[1] *= scale; w[2] *= scale; w[3] *= scale; }
+        unsigned short h[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            h[e] = f32_to_bf16_rne(w[e]);
+            const float err = w[e] - bf16_bits_to_f32(h[e]);        // exact: the discarded low bits of w
+            sw = fmaf(w[e], w[e], sw);
+            se = fmaf(err, err, se);
+        }
+        if (ok && c < kt) {
+            if (out_f32) *(f32x4*)(out_f32 + row * (int64_t)kt + c) = w;
+            uint2 pk;
+            pk.x = (unsigned int)h[0] | ((unsigned int)h[1] << 16);
+            pk.y = (unsigned int)h[2] | ((unsigned int)h[3] << 16);
+            *(uint2*)(out_bf16 + row * (int64_t)kt + c) = pk;
+        }
+    }
+    for (int off = G / 2; off > 0; off >>= 1) { sw += __shfl_xor(sw, off, 64); se += __shfl_xor(se, off, 64); }
+    if (sub == 0 && ok) row_stats[row] = make_float2(sqrtf(sw), sqrtf(se));
+    if (gstats) {
+        float nw = (sub == 0 && ok) ? sqrtf(sw) : 0.f, ne = (sub == 0 && ok) ? sqrtf(se) : 0.f;
+        float ab = (sub == 0 && ok && bias) ? fabsf(bias[row]) : 0.f;
+        // (one atomic per wave, not per row)  NaN must poison the bound, and fmaxf would drop it: turn it into +inf
+        if (nw != nw) nw = INFINITY;
+        if (ne != ne) ne = INFINITY;
+        if (ab != ab) ab = INFINITY;
+        for (int off = 32; off > 0; off >>= 1) {
+            nw = fmaxf(nw, __shfl_xor(nw, off, 64));
+            ne = fmaxf(ne, __shfl_xor(ne, off, 64));
+            ab = fmaxf(ab, __shfl_xor(ab, off, 64));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomic_max_nonneg(gstats + 0, nw);
+            atomic_max_nonneg(gstats + 1, ne);
+            atomic_max_nonneg(gstats + 2, ab);
+        }
+    }
+}
+
+// floor_u = tau_u - 2 eps_u (rounded DOWN twice), eps2_u = 2 eps_u, flag_u |= 1 when the bound is unusable or the
+// selection list may have been too short.
+__global__ __launch_bounds__(256) void filter_floor_kernel(const float* __restrict__ tau, const float2* __restrict__ ustats,
+                                                          const float* __restrict__ user_bias,
+                                                          const float* __restrict__ gstats, int kdim,
+                                                          const int32_t* __restrict__ sel, const float* __restrict__ sel_max,
+                                                          int ksel, int n_sb, int64_t n_users, float* __restrict__ floor_,
+                                                          int32_t* __restrict__ flag, int32_t* __restrict__ n_flagged)
+{
+    const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (u >= n_users) return;
+    const float ni = gstats[0], ai = gstats[1], bi = gstats[2];
+    const float2 st = ustats[u];
+    const float bu = user_bias ? fabsf(user_bias[u]) : 0.f;
+    const float ck = (float)(kdim + 2) * 2.98023224e-07f;                       // (K + 2) (2^-24 + 2^-22)
+    float eps = st.y * (ni * 1.00390625f) + st.x * ai + ck * (st.x * ni * 1.0078125f + bu + bi);
+    eps = eps * 1.001953125f + 1e-30f;
+    const float t = tau[u];
+    float f = t - 2.0f * eps;
+    bool bad = !(eps < INFINITY);                                               // inf or NaN
+    if (t == -INFINITY) f = -INFINITY;                                          // fewer than k superblocks: keep all
+    else if (!(f == f)) bad = true;
+    else f = float_pred(float_pred(f));
+    if (bad) f = -INFINITY;
+    floor_[u] = f;
+    // a saturated selection whose last entry still passes the floor may hide further superblocks >= floor
+    if (!bad && n_sb > ksel && sel[u * ksel + ksel - 1] >= 0 && !(sel_max[(int64_t)(ksel - 1) * n_users + u] < f)) bad = true;
+    flag[u] = bad ? 1 : 0;
+    if (bad) atomicAdd(n_flagged, 1);
+}
+
+// One wave per user.  The user's kept superblocks are slots [0, c_u) of its selection list (maxima are sorted, the
+// floor cuts a prefix), so its stage-3 lists are the first c_u * 2 * cap entries of its slice of part_vals / part_idx.
+template <int CPL>
+__global__ __launch_bounds__(256) void filter_finish_kernel(
+    const float* __restrict__ pv, const int32_t* __restrict__ pi, int cap, int ksel, const int32_t* __restrict__ sel,
+    const float* __restrict__ sel_max, const float* __restrict__ floor_, const float* __restrict__ U,
+    const float* __restrict__ V, int64_t ld_u, int64_t ld_v, int kdim, const float* __restrict__ user_bias,
+    const float* __restrict__ item_bias, int32_t item_index_base, int64_t n_users, int k, float* __restrict__ ov,
+    int32_t* __restrict__ oi, int32_t* __restrict__ flag, int32_t* __restrict__ n_flagged)
+{
+    __shared__ int32_t cand_lds[4][FILTER_CMAX];
+    const int wave = threadIdx.x >> 6;
+    const int64_t u = (int64_t)blockIdx.x * 4 + wave;
+    if (u >= n_users) return;
+    const int lane = lane_id();
+    // ---- kept slots: a prefix of the selection list
+    const float fl = floor_[u];
+    bool kept = false;
+    if (lane < ksel) kept = sel[u * ksel + lane] >= 0 && !(sel_max[(int64_t)lane * n_users + u] < fl);
+    const int c_u = __builtin_popcountll(__builtin_amdgcn_ballot_w64(kept));
+    const int n_ent = c_u * 2 * cap;
+    const int64_t base = u * (int64_t)ksel * 2 * cap;
+    // ---- survivors: every valid list entry; a full list may have dropped items above the floor
+    int32_t id[CPL];
+    bool lossy = false;
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+        const int j = c * 64 + lane;
+        id[c] = -1;
+        if (j < n_ent) {
+            id[c] = pi[base + j];
+            if (id[c] >= 0 && (j % cap) == cap - 1) lossy = true;
+        }
+    }
+    int total = 0;
+    int32_t* cand = cand_lds[wave];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(id[c] >= 0);
+        const int pos = total + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+        if (id[c] >= 0 && pos < FILTER_CMAX) cand[pos] = id[c];
+        total += __builtin_popcountll(m);
+    }
+    const bool over = __builtin_amdgcn_ballot_w64(lossy) != 0ull || total > FILTER_CMAX;
+    if (over && lane == 0 && flag[u] == 0) { flag[u] = 1; atomicAdd(n_flagged, 1); }
+    if (total > FILTER_CMAX) total = FILTER_CMAX;
+    __builtin_amdgcn_wave_barrier();              // cand[] is private to this wave and DS operations of a wave execute in order
+    // ---- exact fp32 scores of the survivors: the reference's k-ordered fmaf chain, then (s + b_u) + b_i
+    const unsigned long long EMPTY = merge_key(-INFINITY, 0x7fffffff);
+    unsigned long long key = EMPTY;
+    if (lane < total) {
+        const int32_t item = cand[lane];
+        const float* a = U + u * ld_u;
+        const float* b = V + (int64_t)(item - item_index_base) * ld_v;
+        float acc = 0.0f;
+        int kk = 0;
+        if (((ld_u | ld_v) & 3) == 0) {
+            for (; kk + 4 <= kdim; kk += 4) {
+                const f32x4 a4 = *(const f32x4*)(a + kk);
+                const f32x4 b4 = *(const f32x4*)(b + kk);
+                acc = __fmaf_rn(a4[0], b4[0], acc); acc = __fmaf_rn(a4[1], b4[1], acc);
+                acc = __fmaf_rn(a4[2], b4[2], acc); acc = __fmaf_rn(a4[3], b4[3], acc);
+            }
+        }
+        for (; kk < kdim; ++kk) acc = __fmaf_rn(a[kk], b[kk], acc);
+        if (user_bias) acc = acc + user_bias[u];
+        if (item_bias) acc = acc + item_bias[item - item_index_base];
+        key = merge_key(acc, item);
+    }
+    // ---- the k best by (value desc, index asc)
+    for (int t = 0; t < k; ++t) {
+        const unsigned long long best = wave_max_u64(key);
+        if (key == best && best != EMPTY) key = EMPTY;
+        if (lane == 0) {
+            const unsigned int hi = (unsigned int)(best >> 32);
+            const unsigned int bits = (hi & 0x80000000u) ? (hi & 0x7fffffffu) : ~hi;
+            ov[u * k + t] = (best == EMPTY) ? -INFINITY : __uint_as_float(bits);
+            oi[u * k + t] = (best == EMPTY) ? -1 : (int32_t)(~(unsigned int)best);
+        }
+    }
+}
+
+extern "C" int trec_score_prep_filter(const float* repr, int64_t n, int32_t d, int32_t kpad, int32_t normalize,
+                                      const float* bias, float* out_f32, void* out_bf16, float* row_stats, float* gstats,
+                                      void* stream)
+{
+    TREC_REQUIRE(repr && out_bf16 && row_stats, "trec_score_prep_filter: null pointer");
+    TREC_REQUIRE(d >= 1 && kpad >= d && kpad % 4 == 0 && kpad <= 256, "trec_score_prep_filter: need d <= kpad <= 256, kpad % 4 == 0");
+    TREC_REQUIRE(((uintptr_t)repr % 16) == 0 || (d & 3) != 0, "trec_score_prep_filter: repr must be 16-byte aligned");
+    if (n == 0) return TREC_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int g = kpad >= 128 ? 32 : kpad / 4;              // 8, 16 or 32 lanes per row
+    const unsigned blocks = (unsigned)ceil_div64(n * g, 256);
+#define TREC_PF(GV) hipLaunchKernelGGL(prep_filter_kernel<GV>, dim3(blocks), dim3(256), 0, st, repr, n, d, kpad, normalize, bias, out_f32, (unsigned short*)out_bf16, (float2*)row_stats, gstats)
+    if (g == 32) TREC_PF(32);
+    else if (g == 16) TREC_PF(16);
+    else TREC_PF(8);
+#undef TREC_PF
+    return trec_check_launch("trec_score_prep_filter");
+}
+
+extern "C" int trec_topk_filter_floor(const float* tau, const float* user_stats, const float* user_bias,
+                                      const float* item_gstats, int32_t kdim, const int32_t* sel, const float* sel_max,
+                                      int32_t ksel, int32_t n_sb, int64_t n_users, float* floor_, int32_t* flag,
+                                      int32_t* n_flagged, void* stream)
+{
+    TREC_REQUIRE(tau && user_stats && item_gstats && sel && sel_max && floor_ && flag && n_flagged,
+                 "trec_topk_filter_floor: null pointer");
+    TREC_REQUIRE(ksel >= 1 && kdim >= 1, "trec_topk_filter_floor: bad sizes");
+    if (n_users == 0) return TREC_OK;
+    hipLaunchKernelGGL(filter_floor_kernel, dim3((unsigned)ceil_div64(n_users, 256)), dim3(256), 0, (hipStream_t)stream,
+                       tau, (const float2*)user_stats, user_bias, item_gstats, kdim, sel, sel_max, ksel, n_sb, n_users,
+                       floor_, flag, n_flagged);
+    return trec_check_launch("trec_topk_filter_floor");
+}
+
+extern "C" int trec_topk_filter_finish(const float* part_vals, const int32_t* part_idx, int32_t capacity, int32_t ksel,
+                                       const int32_t* sel, const float* sel_max, const float* floor_, const float* users_f32,
+                                       const float* items_f32, int64_t ld_users, int64_t ld_items, int32_t kdim,
+                                       const float* user_bias, const float* item_bias, int32_t item_index_base,
+                                       int64_t n_users, int32_t k, float* out_vals, int32_t* out_idx, int32_t* flag,
+                                       int32_t* n_flagged, void* stream)
+{
+    TREC_REQUIRE(part_vals && part_idx && sel && sel_max && floor_ && users_f32 && items_f32 && out_vals && out_idx && flag &&
+                     n_flagged, "trec_topk_filter_finish: null pointer");
+    TREC_REQUIRE(ksel >= 1 && ksel <= 64 && k >= 1 && k <= FILTER_CMAX, "trec_topk_filter_finish: need ksel <= 64, k <= 64");
+    TREC_REQUIRE(capacity >= 1 && ksel * 2 * capacity <= 64 * 32, "trec_topk_filter_finish: ksel * 2 * capacity <= 2048");
+    if (n_users == 0) return TREC_OK;
+    const unsigned blocks = (unsigned)ceil_div64(n_users, 4);
+    hipStream_t st = (hipStream_t)stream;
+    const int cpl = (ksel * 2 * capacity + 63) / 64;
+#define TREC_FF(CPLV)                                                                                                  \
+    hipLaunchKernelGGL((filter_finish_kernel<CPLV>), dim3(blocks), dim3(256), 0, st, part_vals, part_idx, capacity, ksel, sel, \
+                       sel_max, floor_, users_f32, items_f32, ld_users, ld_items, kdim, user_bias, item_bias,          \
+                       item_index_base, n_users, k, out_vals, out_idx, flag, n_flagged)
+    if (cpl <= 4) TREC_FF(4);
+    else if (cpl <= 8) TREC_FF(8);
+    else if (cpl <= 12) TREC_FF(12);
+    else if (cpl <= 16) TREC_FF(16);
+    else TREC_FF(32);
+#undef TREC_FF
+    return trec_check_launch("trec_topk_filter_finish");
+}

@@ -20,18 +20,25 @@ KERNEL_EVENTS = None
 
 
 class _timed(object):
+    """Brackets a launch (or a group of launches) with HIP events; brackets nested inside another one are not recorded,
+    so a composite step (e.g. the exact fallback of the filtered top-k) does not pollute its inner kernels' statistics."""
+    depth = 0
+
     def __init__(self, name):
         self.name = name
 
     def __enter__(self):
-        if KERNEL_EVENTS is not None:
+        self.on = KERNEL_EVENTS is not None and _timed.depth == 0
+        _timed.depth += 1
+        if self.on:
             self.s = torch.cuda.Event(enable_timing=True)
             self.e = torch.cuda.Event(enable_timing=True)
             self.s.record()
         return self
 
     def __exit__(self, *exc):
-        if KERNEL_EVENTS is not None:
+        _timed.depth -= 1
+        if self.on and KERNEL_EVENTS is not None:
             self.e.record()
             KERNEL_EVENTS.append((self.name, self.s, self.e))
         return False
@@ -809,6 +816,134 @@ def score_topk_two_stage(users_op, items_op, dtype, kpad, k, user_bias=None, ite
                N.ptr(row_pair), N.ptr(g_tau), cap, N.ptr(pv), N.ptr(pi), variant & 1)
     # ---- stage 4: merge the ksel * 2 lists of every user
     return topk_merge(pv.reshape(n_u, ksel * 2 * cap), pi.reshape(n_u, ksel * 2 * cap), k)
+
+
+# ------------------------------------------------------------------------------------------------ K2f: exact top-k, bf16 filter
+FILTER_KSEL = 32          # superblocks a user may keep (1M x 1M, d = 128, k = 10: 15 on average; more -> exact fallback)
+LAST_FILTER_STATS = {}    # diagnostics of the most recent score_topk_filtered call (bench.py reports them)
+
+
+class FilterOperand(object):
+    """One side of the filtered top-k (trec_score_prep_filter): ``bf16`` [n, kpad] stage-1 / stage-3 operand, ``f32``
+    [n, kpad] exact operand (the representation itself when it needs neither padding nor normalising), ``stats`` [n, 2]
+    = {||x||, ||x - bf16(x)||} per row, ``gstats`` [3] = maxima of both and of |bias| over the rows (item side)."""
+    __slots__ = ("bf16", "f32", "n", "d", "kpad", "stats", "gstats")
+
+
+def score_prep_filter(repr_, normalize=False, bias=None, want_gstats=False):
+    x = _f32c(repr_.detach())
+    n, d = x.shape
+    kpad = score_kpad(d)
+    op = FilterOperand()
+    op.n, op.d, op.kpad = n, d, kpad
+    own_f32 = normalize or kpad != d
+    op.f32 = torch.empty((n, kpad), dtype=torch.float32, device=x.device) if own_f32 else x
+    op.bf16 = torch.empty((n, kpad), dtype=torch.bfloat16, device=x.device)
+    op.stats = torch.empty((n, 2), dtype=torch.float32, device=x.device)
+    op.gstats = torch.zeros((3,), dtype=torch.float32, device=x.device) if want_gstats else None
+    with _timed("score_prep_filter"):
+        N.call("trec_score_prep_filter", N.ptr(x), n, d, kpad, 1 if normalize else 0, N.ptr(bias),
+               N.ptr(op.f32) if own_f32 else None, N.ptr(op.bf16), N.ptr(op.stats), N.ptr(op.gstats))
+    return op
+
+
+def score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index_base=0, sb_rows=None, variant=1,
+                        n_chunks=None, floor_exchange=None, stats_exchange=None, ksel=None):
+    """EXACT fp32 top-k (values and ids bit-identical to ``score_topk(..., DTYPE_F32)`` and to the oracle) with the
+    score matrix contracted ONCE on bf16 MFMA: the bf16 stage-1 maxima and the bf16 re-scoring act as a filter with a
+    proven error bound (csrc/topk_filter.hip), the survivors (~15 items per user at 1M x 1M) are re-scored by the
+    reference's k-ordered fp32 chain.  ``uop`` / ``iop``: FilterOperand (iop with gstats).  Dot / cosine scores.
+    Item shards: ``floor_exchange`` as in score_topk_two_stage, ``stats_exchange(gstats) -> gstats`` = all-reduce MAX of
+    the item-side maxima (the bound must cover every shard's items).  Users the filter cannot certify (its capacity
+    limits, non-finite bounds) are re-done on the exact fp32 MFMA path; their number is in LAST_FILTER_STATS."""
+    cap = N.query("trec_score_topk_capacity", int(k))
+    if cap < 0:
+        raise ValueError("fused top-k supports k <= 16 (got %d)" % k)
+    dev = uop.bf16.device
+    n_u, n_i, kpad = uop.n, iop.n, uop.kpad
+    if iop.kpad != kpad or iop.gstats is None:
+        raise ValueError("score_topk_filtered: operands must share kpad and the item side needs gstats")
+    sb_rows = int(sb_rows or SUPERBLOCK_ROWS)
+    n_sb = (n_i + sb_rows - 1) // sb_rows
+    if n_sb < int(k):
+        raise ValueError("score_topk_filtered needs at least k superblocks of items")
+    ksel = min(int(ksel or FILTER_KSEL), n_sb)
+    ksel = max(ksel, int(k))
+    rows_wg = N.query("trec_score_rows_per_workgroup", DTYPE_BF16, kpad)
+    if n_chunks is None:
+        rblocks = (n_u + rows_wg - 1) // rows_wg
+        n_chunks = max(1, min(n_sb, -(-32 * 768 // rblocks)))
+    # ---- stage 1: bf16 superblock maxima
+    blockmax = torch.empty((n_sb, n_u), dtype=torch.float32, device=dev)
+    with _timed("score_gemm_blockmax"):
+        N.call("trec_score_gemm_blockmax", N.ptr(uop.bf16), N.ptr(iop.bf16), DTYPE_BF16, kpad, n_u, n_i,
+               N.ptr(user_bias), N.ptr(item_bias), MODE_DOT, None, None, sb_rows, n_chunks, N.ptr(blockmax), n_u, variant)
+    # ---- stage 2: the ksel best superblocks, tau = k-th largest maximum, floor = tau - 2 eps
+    sel = torch.empty((n_u, ksel), dtype=torch.int32, device=dev)
+    sel_max = torch.empty((ksel, n_u), dtype=torch.float32, device=dev)
+    tau = torch.empty((n_u,), dtype=torch.float32, device=dev)
+    with _timed("topk_select_blocks"):
+        N.call("trec_topk_select_blocks_ex", N.ptr(blockmax), n_sb, n_u, n_u, ksel, int(k), N.ptr(sel), N.ptr(sel_max),
+               N.ptr(tau))
+    del blockmax
+    gstats = iop.gstats
+    if floor_exchange is not None:                  # item shards: the k-th largest maximum over ALL shards
+        tau = floor_exchange(sel_max[:int(k)].contiguous()).contiguous()
+    if stats_exchange is not None:
+        gstats = stats_exchange(gstats).contiguous()
+    floor = torch.empty((n_u,), dtype=torch.float32, device=dev)
+    flag = torch.empty((n_u,), dtype=torch.int32, device=dev)
+    n_flagged = torch.zeros((1,), dtype=torch.int32, device=dev)
+    N.call("trec_topk_filter_floor", N.ptr(tau), N.ptr(uop.stats), N.ptr(user_bias), N.ptr(gstats), kpad, N.ptr(sel),
+           N.ptr(sel_max), ksel, n_sb, n_u, N.ptr(floor), N.ptr(flag), N.ptr(n_flagged))
+    # ---- stage 3a: group the kept (user, slot) pairs by superblock, pad groups to whole workgroups, gather bf16 rows
+    n_pairs = n_u * ksel
+    keys = torch.empty((n_pairs,), dtype=torch.int32, device=dev)
+    N.call("trec_topk_group_keys", N.ptr(sel), N.ptr(sel_max), N.ptr(floor), n_pairs, ksel, n_sb, N.ptr(keys))
+    indptr_t, users_t, perm_t = group_pairs_by_item(None, keys, ksel, n_sb + 1)
+    cnt_pad = torch.empty((n_sb + 1,), dtype=torch.int32, device=dev)
+    N.call("trec_topk_pad_counts", N.ptr(indptr_t), n_sb, rows_wg, N.ptr(cnt_pad))
+    pstart = torch.empty((n_sb + 2,), dtype=torch.int64, device=dev)
+    ws64 = torch.empty(((n_sb + 1 + 1023) // 1024 + 1,), dtype=torch.int64, device=dev)
+    N.call("trec_exclusive_scan_i32", N.ptr(cnt_pad), n_sb + 1, N.ptr(ws64), N.ptr(pstart))
+    max_rows = (n_pairs + min(n_sb, n_pairs) * (rows_wg - 1) + rows_wg - 1) // rows_wg * rows_wg
+    g_op = torch.empty((max_rows, kpad), dtype=torch.bfloat16, device=dev)
+    g_bias = torch.empty((max_rows,), dtype=torch.float32, device=dev) if user_bias is not None else None
+    g_tau = torch.empty((max_rows,), dtype=torch.float32, device=dev)
+    row_pair = torch.empty((max_rows,), dtype=torch.int32, device=dev)
+    rblock_chunk = torch.empty((max_rows // rows_wg,), dtype=torch.int32, device=dev)
+    with _timed("topk_fill_groups"):
+        N.call("trec_topk_fill_groups", N.ptr(pstart), N.ptr(indptr_t), N.ptr(users_t), N.ptr(perm_t), n_sb, rows_wg,
+               max_rows, N.ptr(uop.bf16), kpad * 2, N.ptr(user_bias), None, N.ptr(floor), N.ptr(g_op), N.ptr(g_bias),
+               None, N.ptr(g_tau), N.ptr(row_pair), N.ptr(rblock_chunk))
+    # ---- stage 3b: bf16 re-scoring of the kept superblocks, every item >= floor listed (independent lists: bit 4)
+    pv = torch.empty((n_pairs * 2, cap), dtype=torch.float32, device=dev)      # only the kept pairs' lists are touched
+    pi = torch.empty((n_pairs * 2, cap), dtype=torch.int32, device=dev)
+    with _timed("score_gemm_topk_grouped"):
+        N.call("trec_score_gemm_topk_grouped", N.ptr(g_op), N.ptr(iop.bf16), DTYPE_BF16, kpad, max_rows, n_i,
+               item_index_base, N.ptr(g_bias), N.ptr(item_bias), MODE_DOT, None, None, sb_rows, N.ptr(rblock_chunk),
+               N.ptr(row_pair), N.ptr(g_tau), cap, N.ptr(pv), N.ptr(pi), (variant & 1) | 16)
+    # ---- stage 4: exact fp32 scores of the survivors, exact top-k
+    ov = torch.empty((n_u, int(k)), dtype=torch.float32, device=dev)
+    oi = torch.empty((n_u, int(k)), dtype=torch.int32, device=dev)
+    with _timed("topk_filter_finish"):
+        N.call("trec_topk_filter_finish", N.ptr(pv), N.ptr(pi), cap, ksel, N.ptr(sel), N.ptr(sel_max), N.ptr(floor),
+               N.ptr(uop.f32), N.ptr(iop.f32), kpad, kpad, uop.d, N.ptr(user_bias), N.ptr(item_bias), item_index_base,
+               n_u, int(k), N.ptr(ov), N.ptr(oi), N.ptr(flag), N.ptr(n_flagged))
+    del pv, pi
+    # ---- users the filter could not certify: the exact fp32 MFMA path (one host read of a counter)
+    n_bad = int(n_flagged.item())
+    LAST_FILTER_STATS.clear()
+    LAST_FILTER_STATS.update({"users": n_u, "flagged_users": n_bad, "ksel": ksel})
+    if n_bad:
+        bad = torch.nonzero(flag, as_tuple=False).reshape(-1)
+        ub = user_bias[bad].contiguous() if user_bias is not None else None
+        with _timed("topk_filter_fallback"):
+            fv, fi = score_topk(uop.f32[bad].contiguous(), iop.f32, DTYPE_F32, kpad, int(k), ub, item_bias, MODE_DOT,
+                                item_index_base=item_index_base, method="two_stage" if n_i >= TWO_STAGE_MIN_ITEMS else "direct")
+        ov[bad] = fv
+        oi[bad] = fi
+    return ov, oi
 
 
 def topk_merge(cand_vals, cand_idx, k):

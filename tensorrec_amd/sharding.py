@@ -105,6 +105,15 @@ def shared_topk_floor(sel_max, group=None):
     return kth_largest_block_max(gathered, k)
 
 
+def all_reduce_max(t, group=None):
+    """MAX all-reduce of a small float tensor (the item-side maxima behind the bf16 filter's error bound: the bound must
+    cover the items of EVERY shard, ops.score_topk_filtered)."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        t = t.clone()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return t
+
+
 def all_reduce_scalar(value, device, group=None):
     t = torch.tensor([int(value)], dtype=torch.int64, device=device)
     if dist.is_initialized() and dist.get_world_size(group) > 1:

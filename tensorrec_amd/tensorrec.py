@@ -842,16 +842,32 @@ class TensorRec(object):
                 floor_exchange = lambda sel_max: sharding.shared_topk_floor(sel_max, self.process_group)  # noqa: E731
             else:
                 method = "direct"
+        # precision='fp32' on a large catalogue: the same exact fp32 result, with the contraction done once on bf16 MFMA
+        # as an error-bounded filter and only the survivors re-scored in fp32 (ops.score_topk_filtered)
+        n_items_min = int(smallest.item()) if sharded else itf.shape[0]
+        filtered = (dtype == ops.DTYPE_F32 and graph.engine_mode == ops.MODE_DOT and 1 <= k <= 16 and
+                    n_items_min >= ops.TWO_STAGE_MIN_ITEMS and self.n_components <= 256 and
+                    ops.N.load().trec_get_tuning(b"topk_bf16_filter", 1) != 0)
+        stats_exchange = (lambda g: sharding.all_reduce_max(g, self.process_group)) if sharded else None
         vals, idx = [], []
         with torch.no_grad(), variable_scope(self._store):
             user_reprs, _, item_repr, user_bias, item_bias, _ = self._representations(uf, itf)
-            i_op, i_sq, kpad = ops.score_prep(item_repr, dtype, normalize=graph.engine_normalize, want_sqnorm=want_sq)
             ib = item_bias.contiguous() if self.biased else None
+            if filtered:
+                i_f = ops.score_prep_filter(item_repr, normalize=graph.engine_normalize, bias=ib, want_gstats=True)
+            else:
+                i_op, i_sq, kpad = ops.score_prep(item_repr, dtype, normalize=graph.engine_normalize, want_sqnorm=want_sq)
             for s in range(0, uf.shape[0], user_batch_size):
                 e = min(s + user_batch_size, uf.shape[0])
                 ub = user_bias[s:e].contiguous() if self.biased else None
                 per_taste = []
                 for user_repr in user_reprs:
+                    if filtered:
+                        u_f = ops.score_prep_filter(user_repr[s:e], normalize=graph.engine_normalize)
+                        per_taste.append(ops.score_topk_filtered(u_f, i_f, k, ub, ib, item_index_base=int(item_offset),
+                                                                 floor_exchange=floor_exchange,
+                                                                 stats_exchange=stats_exchange))
+                        continue
                     u_op, u_sq, _ = ops.score_prep(user_repr[s:e], dtype, normalize=graph.engine_normalize,
                                                    want_sqnorm=want_sq)
                     per_taste.append(ops.score_topk(u_op, i_op, dtype, kpad, k, ub, ib, graph.engine_mode, u_sq, i_sq,

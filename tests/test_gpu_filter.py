@@ -1,0 +1,248 @@
+"""K2f -- the exact fp32 top-k through the bf16 filter (csrc/topk_filter.hip, ops.score_topk_filtered).
+
+Bar: values AND item ids bit-identical to the oracle's fp32 restatement of tf.matmul + tf.nn.top_k
+(tensorrec/prediction_graphs.py:49-50, tensorrec/recommendation_graphs.py:80: oracle/tr_oracle.c:orc_score_dense +
+O.topk_rows) and to the fp32 MFMA path, on random, tied, near-tied and adversarially aligned inputs; the proven bound
+eps_u must dominate every observed |bf16 score - fp32 score|."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from tensorrec_amd import ops as _ops, _native
+    _native.require_gpu()
+    _native.load()
+    return _ops
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def run_filtered(ops, u, v, k, ub=None, ib=None, normalize=False, **kw):
+    du, dv = dev(u), dev(v)
+    dub = dev(ub) if ub is not None else None
+    dib = dev(ib) if ib is not None else None
+    uop = ops.score_prep_filter(du, normalize=normalize)
+    iop = ops.score_prep_filter(dv, normalize=normalize, bias=dib, want_gstats=True)
+    vals, idx = ops.score_topk_filtered(uop, iop, k, dub, dib, **kw)
+    return vals.cpu().numpy(), idx.cpu().numpy(), dict(ops.LAST_FILTER_STATS), uop, iop
+
+
+def exact_reference(u, v, k, ub=None, ib=None):
+    return O.topk_rows(O.score_dense_exact(u, v, ub, ib), k)
+
+
+@pytest.mark.parametrize("d,biased", [(128, True), (128, False), (64, True), (100, True), (32, False), (256, True)])
+def test_filtered_topk_bit_exact_vs_oracle(ops, d, biased):
+    rng = np.random.default_rng(d + biased)
+    n_u, n_i, k = 700, 40000 + 77, 10
+    u = rng.standard_normal((n_u, d)).astype(np.float32)
+    v = rng.standard_normal((n_i, d)).astype(np.float32)
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    ub = (0.1 * rng.standard_normal(n_u)).astype(np.float32) if biased else None
+    ib = (0.1 * rng.standard_normal(n_i)).astype(np.float32) if biased else None
+    vals, idx, stats, _, _ = run_filtered(ops, u, v, k, ub, ib)
+    rv, ri = exact_reference(u, v, k, ub, ib)
+    assert np.array_equal(idx, ri)
+    assert np.array_equal(vals, rv)
+    assert stats["flagged_users"] <= n_u // 20           # the filter itself must carry (almost) everybody
+
+
+def test_filtered_equals_fp32_mfma_path_cosine_unnormalised_inputs(ops):
+    """cosine: operands are normalised by the prep kernel exactly as trec_score_prep does, so the filtered result must
+    equal the fp32 two-stage path bit for bit (and the oracle's cosine scores within 1e-6 -- l2-normalise rounding)."""
+    rng = np.random.default_rng(5)
+    n_u, n_i, d, k = 300, 50000, 128, 10
+    u = (rng.standard_normal((n_u, d)) * rng.uniform(0.1, 30, (n_u, 1))).astype(np.float32)
+    v = (rng.standard_normal((n_i, d)) * rng.uniform(0.1, 30, (n_i, 1))).astype(np.float32)
+    vals, idx, stats, uop, iop = run_filtered(ops, u, v, k, normalize=True)
+    u32, _, kpad = ops.score_prep(dev(u), ops.DTYPE_F32, normalize=True)
+    v32, _, _ = ops.score_prep(dev(v), ops.DTYPE_F32, normalize=True)
+    assert torch.equal(u32, uop.f32) and torch.equal(v32, iop.f32)
+    vb, _, _ = ops.score_prep(dev(v), ops.DTYPE_BF16, normalize=True)
+    assert torch.equal(vb, iop.bf16)
+    ev, ei = ops.score_topk(u32, v32, ops.DTYPE_F32, kpad, k, method="two_stage")
+    assert np.array_equal(idx, ei.cpu().numpy()) and np.array_equal(vals, ev.cpu().numpy())
+    ref = O.cosine_dense(u, v)
+    np.testing.assert_allclose(vals, np.take_along_axis(ref, idx.astype(np.int64), 1), rtol=0, atol=1e-6)
+
+
+def _eps_of(ops, uop, iop, ub, kpad):
+    """eps_u as the floor kernel computes it: floor = pred(pred(0 - 2 eps))."""
+    n_u = uop.n
+    tau = torch.zeros((n_u,), dtype=torch.float32, device="cuda")
+    sel = torch.zeros((n_u, 1), dtype=torch.int32, device="cuda")
+    sel_max = torch.full((1, n_u), -np.inf, dtype=torch.float32, device="cuda")
+    floor = torch.empty((n_u,), dtype=torch.float32, device="cuda")
+    flag = torch.empty((n_u,), dtype=torch.int32, device="cuda")
+    nf = torch.zeros((1,), dtype=torch.int32, device="cuda")
+    N = ops.N
+    N.call("trec_topk_filter_floor", N.ptr(tau), N.ptr(uop.stats), N.ptr(ub), N.ptr(iop.gstats), kpad, N.ptr(sel),
+           N.ptr(sel_max), 1, 1, n_u, N.ptr(floor), N.ptr(flag), N.ptr(nf))
+    return (-floor / 2).cpu().numpy()
+
+
+@pytest.mark.parametrize("case", ["random", "aligned_rounding", "large_magnitude", "biased"])
+def test_error_bound_dominates_observed_error(ops, case):
+    """max |bf16-path score - fp32 score| / eps_u <= 1 on every pair; 'aligned_rounding' makes the rounding errors of the
+    user row parallel to the item rows, the case in which the Cauchy-Schwarz step is tight."""
+    rng = np.random.default_rng(11)
+    n_u, n_i, d = 256, 4096, 128
+    ub = ib = None
+    if case == "aligned_rounding":
+        # every component rounds DOWN by almost half a bf16 ulp; items are the all-ones direction: <dx, y> = |dx||y|
+        u = (np.float32(2.0) ** rng.integers(-1, 3, (n_u, 1)).astype(np.float32)) * \
+            np.full((n_u, d), 1.0 + 2.0 ** -8 - 2.0 ** -20, np.float32)
+        v = np.ones((n_i, d), np.float32) * (np.float32(2.0) ** rng.integers(-2, 3, (n_i, 1)).astype(np.float32))
+    elif case == "large_magnitude":
+        u = (rng.standard_normal((n_u, d)) * 1e3).astype(np.float32)
+        v = (rng.standard_normal((n_i, d)) * 1e2).astype(np.float32)
+    else:
+        u = rng.standard_normal((n_u, d)).astype(np.float32)
+        v = rng.standard_normal((n_i, d)).astype(np.float32)
+    if case == "biased":
+        ub = (3 * rng.standard_normal(n_u)).astype(np.float32)
+        ib = (3 * rng.standard_normal(n_i)).astype(np.float32)
+    dub = dev(ub) if ub is not None else None
+    dib = dev(ib) if ib is not None else None
+    uop = ops.score_prep_filter(dev(u))
+    iop = ops.score_prep_filter(dev(v), bias=dib, want_gstats=True)
+    kpad = uop.kpad
+    eps = _eps_of(ops, uop, iop, dub, kpad)
+    s_bf = ops.score_store(uop.bf16, iop.bf16, ops.DTYPE_BF16, kpad, dub, dib).cpu().numpy()
+    s_32 = O.score_dense_exact(u, v, ub, ib)
+    err = np.abs(s_bf.astype(np.float64) - s_32.astype(np.float64))
+    ratio = (err / eps[:, None]).max()
+    print("case %s: max |err| / eps = %.3f (eps mean %.3g)" % (case, ratio, eps.mean()))
+    assert ratio <= 1.0
+    if case == "aligned_rounding":
+        assert ratio > 0.5                  # the bound is not slack by construction in its tight case
+
+
+def test_near_ties_within_the_bf16_error(ops):
+    """Scores spaced far below 2^-9 relative: bf16 cannot order them, the filter must keep them all and the fp32
+    re-scoring must produce the exact order (ties by index).  40 near-copies of each user's best item are scattered
+    over distinct superblocks."""
+    rng = np.random.default_rng(3)
+    n_u, n_i, d, k = 128, 60000, 128, 10
+    u = rng.standard_normal((n_u, d)).astype(np.float32)
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    v = (0.3 * rng.standard_normal((n_i, d))).astype(np.float32)
+    # items aligned with a few users, perturbed at the 1e-5 level, placed in different superblocks
+    for j, uu in enumerate(range(0, 24)):
+        slots = (np.arange(20) * 2557 + 31 * j) % n_i
+        v[slots] = u[uu] * 2.0 + (1e-5 * rng.standard_normal((20, d))).astype(np.float32)
+    vals, idx, stats, _, _ = run_filtered(ops, u, v, k)
+    rv, ri = exact_reference(u, v, k)
+    assert np.array_equal(idx, ri) and np.array_equal(vals, rv)
+    assert stats["flagged_users"] < n_u             # handled by the filter, not only by the fallback
+
+
+def test_exact_ties_keep_index_order(ops):
+    """Small-integer embeddings are exact in bf16: thousands of exactly tied scores; order = (value desc, index asc)."""
+    rng = np.random.default_rng(4)
+    n_u, n_i, d, k = 200, 33000, 64, 10
+    u = rng.integers(-2, 3, (n_u, d)).astype(np.float32)
+    v = rng.integers(-2, 3, (n_i, d)).astype(np.float32)
+    vals, idx, stats, _, _ = run_filtered(ops, u, v, k)
+    rv, ri = exact_reference(u, v, k)
+    assert np.array_equal(idx, ri) and np.array_equal(vals, rv)
+
+
+def test_degenerate_all_scores_within_the_bound_falls_back_exactly(ops):
+    """Every item within 2 eps of the best (near-identical item rows): no filter can certify anything -- every user is
+    flagged and re-done on the fp32 MFMA path; the result is still the oracle's."""
+    rng = np.random.default_rng(6)
+    n_u, n_i, d, k = 96, 20000, 128, 10
+    u = rng.standard_normal((n_u, d)).astype(np.float32)
+    base = rng.standard_normal((1, d)).astype(np.float32)
+    v = base + (1e-6 * rng.standard_normal((n_i, d))).astype(np.float32)
+    vals, idx, stats, _, _ = run_filtered(ops, u, v, k)
+    rv, ri = exact_reference(u, v, k)
+    assert np.array_equal(idx, ri) and np.array_equal(vals, rv)
+    assert stats["flagged_users"] == n_u
+
+
+def test_full_list_in_one_superblock_is_flagged_not_truncated(ops):
+    """More near-tied items inside ONE (superblock, half-wave) than a stage-3 list holds: the user must be flagged (a
+    full list may have dropped survivors) and come out exact."""
+    rng = np.random.default_rng(7)
+    n_u, n_i, d, k = 64, 30000, 128, 10
+    u = rng.standard_normal((n_u, d)).astype(np.float32)
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    v = (0.2 * rng.standard_normal((n_i, d))).astype(np.float32)
+    v[1024:1024 + 40] = u[5] * 3.0 + (1e-6 * rng.standard_normal((40, d))).astype(np.float32)   # 40 survivors, one block
+    vals, idx, stats, _, _ = run_filtered(ops, u, v, k)
+    rv, ri = exact_reference(u, v, k)
+    assert np.array_equal(idx, ri) and np.array_equal(vals, rv)
+    assert stats["flagged_users"] >= 1
+
+
+def test_item_shards_with_shared_floor_and_stats(ops):
+    """Two item shards on one GPU: tau = k-th largest maximum over both shards, item maxima all-reduced (MAX); the merge
+    of the per-shard lists is the whole-catalogue exact top-k."""
+    rng = np.random.default_rng(8)
+    n_u, n_i, d, k = 300, 70000, 128, 10
+    u = rng.standard_normal((n_u, d)).astype(np.float32)
+    v = rng.standard_normal((n_i, d)).astype(np.float32)
+    ub = rng.standard_normal(n_u).astype(np.float32)
+    ib = rng.standard_normal(n_i).astype(np.float32)
+    cut = 36864
+    du, dub = dev(u), dev(ub)
+    shards = [(0, cut), (cut, n_i)]
+    iops = [ops.score_prep_filter(dev(v[a:b]), bias=dev(ib[a:b]), want_gstats=True) for a, b in shards]
+    gmax = torch.maximum(iops[0].gstats, iops[1].gstats)
+    # pass 1: every shard's k largest maxima (what sharding.shared_topk_floor all-gathers)
+    captured = []
+
+    def capture(sel_max):
+        captured.append(sel_max.clone())
+        return torch.full((n_u,), -np.inf, device="cuda")
+
+    uop = ops.score_prep_filter(du)
+    for (a, b), iop in zip(shards, iops):
+        ops.score_topk_filtered(uop, iop, k, dub, dev(ib[a:b]), item_index_base=a, floor_exchange=capture,
+                                stats_exchange=lambda g: gmax)
+    both = torch.cat(captured, dim=0)                                   # [2k, n_u]
+    tau_glob = torch.sort(both, dim=0, descending=True).values[k - 1].contiguous()
+    parts_v, parts_i = [], []
+    for (a, b), iop in zip(shards, iops):
+        pv, pi = ops.score_topk_filtered(uop, iop, k, dub, dev(ib[a:b]), item_index_base=a,
+                                         floor_exchange=lambda sm: tau_glob, stats_exchange=lambda g: gmax)
+        parts_v.append(pv)
+        parts_i.append(pi)
+    mv, mi = ops.topk_merge(torch.cat(parts_v, 1).contiguous(), torch.cat(parts_i, 1).contiguous(), k)
+    rv, ri = exact_reference(u, v, k, ub, ib)
+    assert np.array_equal(mi.cpu().numpy(), ri) and np.array_equal(mv.cpu().numpy(), rv)
+
+
+def test_model_predict_top_k_uses_the_filter_and_is_exact(ops):
+    """Through the public API: precision='fp32' top-k on a catalogue above the two-stage threshold takes the filter and
+    equals the oracle's top-k of the fp32 score matrix."""
+    import scipy.sparse as sp
+    import tensorrec_amd as T
+    rng = np.random.default_rng(9)
+    n_u, n_i, d, k = 257, 20000, 64, 10
+    uf = sp.identity(n_u, dtype=np.float32, format="csr")
+    itf = sp.identity(n_i, dtype=np.float32, format="csr")
+    inter = sp.csr_matrix((np.ones(n_u, np.float32), (np.arange(n_u), rng.integers(0, n_i, n_u))), shape=(n_u, n_i))
+    model = T.TensorRec(n_components=d, seed=1)
+    model.fit(inter, uf, itf, epochs=1)
+    w = model.get_weights()
+    uu = O.spmm_exact(uf, w["linear_weights_user_0"])
+    vv = O.spmm_exact(itf, w["linear_weights_item"])
+    ub = O.spmm_exact(uf, w["user_feature_biases"]).reshape(-1)
+    ib = O.spmm_exact(itf, w["item_feature_biases"]).reshape(-1)
+    ops.LAST_FILTER_STATS.clear()
+    vals, idx = model.predict_top_k(uf, itf, k=k)
+    assert ops.LAST_FILTER_STATS.get("users") == n_u            # the filtered path ran
+    rv, ri = exact_reference(uu, vv, k, ub, ib)
+    assert np.array_equal(idx, ri) and np.array_equal(vals, rv)
