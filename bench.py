@@ -94,6 +94,45 @@ def cpu_baseline(n_items, d, k, n_users_sample, seed=0):
                       "d=%d, top-%d, %.1f s" % (n_users_sample, n_items, d, k, dt)}
 
 
+def cpu_baseline_fit(n_users_total, n_items, d, per_user=20, n_sampled=100, shard_sizes=(2048, 8192), seed=0):
+    """CPU leg of the fit half of the metric: ONE optimiser step of the oracle's model (oracle/model.py -- the restated
+    _build_tf_graph + TF-form Adam, torch-CPU autograd, float32, all host cores) on user shards of the same 1M-item,
+    d = 128, WMRB workload.  A step costs a + b * users (a: the item-side dense work -- 1M x 128 weights, their Adam
+    update; b: per-user pairs), so two shard sizes are timed and the full epoch (one step over ALL users, as on the GPU)
+    is a + b * n_users_total."""
+    import scipy.sparse as sp
+    import torch
+    from oracle import oracle as O
+    from oracle.model import OracleTensorRec
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    itf = sp.identity(n_items, dtype=np.float32, format="csr")
+    times = []
+    for n_u in (64,) + tuple(shard_sizes):                # the first, tiny step pays the one-time costs and is dropped
+        rng = np.random.default_rng(seed)
+        cols = rng.integers(0, n_items, size=(n_u, per_user), dtype=np.int64)
+        inter = sp.csr_matrix((np.ones(n_u * per_user, np.float32), cols.reshape(-1),
+                               np.arange(0, (n_u + 1) * per_user, per_user, dtype=np.int64)), shape=(n_u, n_items))
+        inter.sum_duplicates()
+        uf = sp.identity(n_u, dtype=np.float32, format="csr")
+        model = OracleTensorRec(d, "linear", "linear", "dot", "wmrb", True)
+        model.init_weights(n_u, n_items, rng)
+        samples = rng.integers(0, n_items, size=(n_u, n_sampled), dtype=np.int64)   # (cost only: distinctness is irrelevant)
+        t0 = time.perf_counter()
+        model.step(inter, uf, itf, 0.1, 1e-5, samples)
+        times.append(time.perf_counter() - t0)
+        del model
+    (u1, u2), (t1, t2) = shard_sizes, times[1:]
+    b = max(0.0, (t2 - t1) / float(u2 - u1))
+    a = max(0.0, t1 - b * u1)
+    epoch = a + b * n_users_total
+    return {"value": 1.0 / epoch, "unit": "epochs/s", "cores": cores, "kind": "port",
+            "sample": "oracle/model.py (torch-CPU autograd + NumPy TF-form Adam, fp32): one optimiser step on %d and %d users "
+                      "x %d items, d=%d, WMRB, %d interactions + %d samples per user: %.2f s and %.2f s -> step = %.2f s + "
+                      "%.3g s/user, extrapolated to one step over %d users = %.1f s"
+                      % (u1, u2, n_items, d, per_user, n_sampled, t1, t2, a, b, n_users_total, epoch)}
+
+
 def fit_epochs_per_sec(n_users, n_items, d, per_user=20, n_sampled=100, epochs=3, rank=0, world=1):
     """Second half of BASELINE.json's metric: fit epochs/sec on the same 1M x 1M, d=128 shape.  One epoch = one
     optimiser step over all users (user_batch_size=None) through the public API: K1 fwd (user + item), K7 sampling,
@@ -134,7 +173,51 @@ def fit_epochs_per_sec(n_users, n_items, d, per_user=20, n_sampled=100, epochs=3
     one = run(1)
     per_epoch = (run(1 + epochs) - one) / epochs                     # removes the per-call upload of the inputs
     nnz = sharding.all_reduce_scalar(int(inter.nnz), device)
+    # ---- roofline of the dominant fit kernel: HIP events around every launch of two more epochs ----
+    from tensorrec_amd import ops
+    ops.KERNEL_EVENTS = []
+    run(2)
+    events, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
+    dur = {}
+    for name, s_, e_ in events:
+        dur.setdefault(name, []).append(s_.elapsed_time(e_))
+    roofline_fit = None
+    if "wmrb_fused_step" in dur:
+        ms = float(np.mean(dur["wmrb_fused_step"]))
+        pairs_s, pairs_p = float(n_loc) * n_sampled, float(inter.nnz)
+        # item rows gathered once per pair; user rows read, dU written; per pair: sample id + coefficient + bucket rank
+        # (samples) / item id + prediction + coefficient + loss (interactions)
+        alg = (pairs_s + pairs_p) * d * 4 + 2.0 * n_loc * d * 4 + pairs_s * 12 + pairs_p * 16
+        gbs = alg / (ms * 1e-3) / 1e9
+        roofline_fit = {"kernel": "wmrb_user_fused_kernel (one-pass WMRB step, user side: every pair's item row gathered once)",
+                        "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                        "traffic": None, "avg_launch_ms": ms, "launches": len(dur["wmrb_fused_step"]),
+                        "algorithmic_bytes_per_launch": alg,
+                        "bound_note": "random 512-byte row gathers from a 512 MB item table: 16x the aggregate L2 (32 MB) "
+                                      "and 2x the Infinity Cache, so the rows cross the memory-side fabric (TCC hit rate "
+                                      "and FETCH_SIZE of this kernel: profiles/r02_fit_pmc_summary.txt); priced against "
+                                      "the HBM peak",
+                        "other_kernels_avg_ms": {n: float(np.mean(v)) for n, v in dur.items() if n != "wmrb_fused_step"},
+                        "other_kernels_launches_per_epoch": {n: len(v) / 2.0 for n, v in dur.items() if n != "wmrb_fused_step"}}
+        try:
+            import glob, re
+            files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*fit_pmc_summary.txt")))
+            if files and world == 1 and (n_users, n_items, d) == (1_000_000, 1_000_000, 128):
+                txt = open(files[-1]).read()
+                f_ = re.findall(r"wmrb_user_fused_kernel[^\n]*?FETCH_SIZE=([0-9.e+]+)", txt)
+                w_ = re.findall(r"wmrb_user_fused_kernel[^\n]*?WRITE_SIZE=([0-9.e+]+)", txt)
+                h_ = re.findall(r"wmrb_user_fused_kernel[^\n]*?TCC_HIT=([0-9.e+]+)", txt)
+                m_ = re.findall(r"wmrb_user_fused_kernel[^\n]*?TCC_MISS=([0-9.e+]+)", txt)
+                if f_ and w_:
+                    # 512-byte rows are fetched as 16-byte-per-lane loads: FETCH_SIZE is doubled as the guide prescribes
+                    roofline_fit["traffic"] = (2.0 * float(f_[0]) + float(w_[0])) * 1024.0
+                if h_ and m_:
+                    roofline_fit["l2_hit_rate"] = float(h_[0]) / (float(h_[0]) + float(m_[0]))
+                roofline_fit["traffic_note"] = "(2*FETCH_SIZE + WRITE_SIZE) KB per launch from %s" % os.path.basename(files[-1])
+        except Exception:
+            pass
     return {"fit_epochs_per_sec": 1.0 / per_epoch, "sec_per_epoch": per_epoch, "epochs_timed": epochs,
+            "roofline_fit": roofline_fit,
             "workload": "%d users x %d items, identity features, d=%d, Linear + DotProduct + WMRB, biased, %d "
                         "interactions, n_sampled_items=%d, device sampler, 1 optimiser step per epoch"
                         % (n_users, n_items, d, nnz, n_sampled),
@@ -392,9 +475,14 @@ def main():
         except Exception as exc:
             fp32_mode = {"error": repr(exc)}
 
-    cpu = None
+    cpu = cpu_fit = None
     if not args.no_cpu_baseline and world == 1:
         cpu = cpu_baseline(I, d, k, args.cpu_users)
+        if fit is not None and "error" not in fit:
+            try:
+                cpu_fit = cpu_baseline_fit(U, I, d)
+            except Exception as exc:
+                cpu_fit = {"error": repr(exc)}
 
     line = {
         "metric": "user-item predictions/sec", "value": value, "unit": "predictions/s", "n_gpus": world,
@@ -412,6 +500,7 @@ def main():
                    "score_kernel_variant": "global_load_lds" if args.variant & 1 else "register-staged"},
         "roofline": roofline, "roofline_k1": roofline_k1, "cpu_baseline": cpu, "parity": parity,
         "fp32_mfma_mode": fp32_mode, "fit": fit,
+        "roofline_fit": (fit or {}).get("roofline_fit"), "cpu_baseline_fit": cpu_fit,
     }
     print(json.dumps(line))
     if world > 1:

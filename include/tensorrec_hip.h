@@ -159,7 +159,13 @@ int trec_score_gemm_topk_grouped(const void* users_g, const void* items, int32_t
                                  const float* item_bias, int32_t mode, const float* user_sqnorm_g,
                                  const float* item_sqnorm, int32_t sb_rows, const int32_t* rblock_chunk,
                                  const int32_t* row_pair, const float* row_floor, int32_t capacity, float* part_vals,
-                                 int32_t* part_idx, int32_t variant, void* stream);
+                                 int32_t* part_idx, int32_t variant, const int32_t* row_index, void* stream);
+/* The index form of trec_topk_fill_groups: no operand copy -- row_user[v] = the operand row of grouped row v (-1 =
+ * padding), to be passed to trec_score_gemm_topk_grouped as row_index together with the UNgathered users / user_bias /
+ * user_sqnorm / row_floor arrays (part_vals may then be NULL: only the item ids are listed). */
+int trec_topk_fill_groups_index(const int64_t* pstart, const int64_t* indptr_t, const int32_t* users_t,
+                                const int32_t* perm_t, int32_t n_sb, int32_t rows_wg, int64_t max_rows, int32_t* row_user,
+                                int32_t* row_pair, int32_t* rblock_chunk, void* stream);
 
 /* trec_topk_select_blocks with a list of k <= 64 entries per user and tau = entry k_tau - 1 (k_tau <= k). */
 int trec_topk_select_blocks_ex(const float* blockmax, int32_t n_sb, int64_t n_users, int64_t stride, int32_t k,
@@ -175,24 +181,29 @@ int trec_topk_select_blocks_ex(const float* blockmax, int32_t n_sb, int64_t n_us
  *     out_f32 [n, kpad] (nullable; what trec_score_prep(dtype fp32) writes), row_stats [n][2] = {||x||, ||x - bf16(x)||}
  *     of the (normalised) row, and -- gstats non-NULL, zero-initialised by the caller -- running maxima
  *     gstats[0..2] = {max ||x||, max ||x - bf16(x)||, max |bias|} (the item side; item shards all-reduce them with MAX).
- *   trec_topk_filter_floor: floor[u] = tau[u] - 2 eps_u rounded down; flag[u] = 1 (and *n_flagged += 1) when the bound
- *     is not finite or the ksel-entry selection list is saturated with its last entry still >= floor.
- *   (then trec_topk_group_keys(sel, sel_max, floor, ...), the grouping entry points above with user_tau = floor, and
- *     trec_score_gemm_topk_grouped with variant bit 4 set: lists independent of each other)
- *   trec_topk_filter_finish: part_vals / part_idx are [n_users * ksel * 2, capacity] lists (pair = user * ksel + slot);
+ *   trec_topk_filter_floor: floor[u] = tau[u] - 2 eps_u rounded down (tau = the k-th largest superblock maximum from
+ *     trec_topk_select_blocks; with item shards the k-th largest over all shards); flag[u] = 1 and *n_flagged += 1 when
+ *     the bound is not finite.
+ *   trec_topk_collect_blocks: second pass over the superblock maxima -- keys[u * ksel + c] = the c-th superblock (in
+ *     index order) whose maximum is >= floor[u], -1 in unused slots, count[u] = min(c, ksel); users with more than ksel
+ *     such superblocks are flagged.  keys go straight to trec_group_pairs_by_item (pair = u * ksel + c), then the
+ *     grouping entry points above with user_tau = floor, and trec_score_gemm_topk_grouped with variant bit 4 set (lists
+ *     independent of each other).
+ *   trec_topk_filter_finish: part_idx is the [n_users * ksel * 2, capacity] item-id lists of the grouped pass;
  *     users_f32 / items_f32 the fp32 operands (row strides ld_*, contraction length kdim); writes the exact top-k and
  *     flags users whose lists were full or who had more than 64 survivors.  Flagged users must be re-done on the exact
  *     path by the caller (ops.score_topk_filtered does). */
 int trec_score_prep_filter(const float* repr, int64_t n, int32_t d, int32_t kpad, int32_t normalize, const float* bias,
                            float* out_f32, void* out_bf16, float* row_stats, float* gstats, void* stream);
 int trec_topk_filter_floor(const float* tau, const float* user_stats, const float* user_bias, const float* item_gstats,
-                           int32_t kdim, const int32_t* sel, const float* sel_max, int32_t ksel, int32_t n_sb,
-                           int64_t n_users, float* floor, int32_t* flag, int32_t* n_flagged, void* stream);
-int trec_topk_filter_finish(const float* part_vals, const int32_t* part_idx, int32_t capacity, int32_t ksel,
-                            const int32_t* sel, const float* sel_max, const float* floor, const float* users_f32,
-                            const float* items_f32, int64_t ld_users, int64_t ld_items, int32_t kdim,
-                            const float* user_bias, const float* item_bias, int32_t item_index_base, int64_t n_users,
-                            int32_t k, float* out_vals, int32_t* out_idx, int32_t* flag, int32_t* n_flagged, void* stream);
+                           int32_t kdim, int64_t n_users, float* floor, int32_t* flag, int32_t* n_flagged, void* stream);
+int trec_topk_collect_blocks(const float* blockmax, int32_t n_sb, int64_t n_users, int64_t stride, const float* floor,
+                             int32_t ksel, int32_t* keys, int32_t* count, int32_t* flag, int32_t* n_flagged, void* stream);
+int trec_topk_filter_finish(const int32_t* part_idx, int32_t capacity, int32_t ksel, const int32_t* count,
+                            const float* users_f32, const float* items_f32, int64_t ld_users, int64_t ld_items,
+                            int32_t kdim, const float* user_bias, const float* item_bias, int32_t item_index_base,
+                            int64_t n_users, int32_t k, float* out_vals, int32_t* out_idx, int32_t* flag,
+                            int32_t* n_flagged, void* stream);
 
 /* k best of n_cand candidates per user, ordered (value desc, index asc) = tf.nn.top_k tie rule; also the merge
  * step after the all-gather of per-shard lists */

@@ -53,16 +53,18 @@ SIGNATURES = {
     "trec_topk_select_blocks": [_vp, _i32, _i64, _i64, _i32, _vp, _vp, _vp, _vp],
     "trec_topk_select_blocks_ex": [_vp, _i32, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp],
     "trec_score_prep_filter": [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
-    "trec_topk_filter_floor": [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i64, _vp, _vp, _vp, _vp],
-    "trec_topk_filter_finish": [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _i32, _i64,
-                                _i32, _vp, _vp, _vp, _vp, _vp],
+    "trec_topk_filter_floor": [_vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp],
+    "trec_topk_collect_blocks": [_vp, _i32, _i64, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
+    "trec_topk_filter_finish": [_vp, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _i32, _i64, _i32, _vp, _vp,
+                                _vp, _vp, _vp],
     "trec_topk_group_keys": [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp],
     "trec_topk_pad_counts": [_vp, _i32, _i32, _vp, _vp],
     "trec_exclusive_scan_i32": [_vp, _i64, _vp, _vp, _vp],
     "trec_topk_fill_groups": [_vp, _vp, _vp, _vp, _i32, _i32, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                               _vp],
     "trec_score_gemm_topk_grouped": [_vp, _vp, _i32, _i32, _i64, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp,
-                                     _vp, _i32, _vp, _vp, _i32, _vp],
+                                     _vp, _i32, _vp, _vp, _i32, _vp, _vp],
+    "trec_topk_fill_groups_index": [_vp, _vp, _vp, _vp, _i32, _i32, _i64, _vp, _vp, _vp, _vp],
     "trec_topk_merge": [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp],
     "trec_pair_score_fwd": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
     "trec_pair_score_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
@@ -134,10 +136,15 @@ def ptr(t):
         raise NativeLibraryError("expected a GPU tensor, got device=%s" % t.device)
     if not t.is_contiguous():
         raise NativeLibraryError("expected a contiguous tensor")
+    if t.device.index != torch.cuda.current_device():
+        raise NativeLibraryError("tensor lives on %s but the current device (whose stream the kernels are launched on) "
+                                 "is cuda:%d -- call through the model's public methods or use torch.cuda.device(...)"
+                                 % (t.device, torch.cuda.current_device()))
     return ctypes.c_void_p(t.data_ptr())
 
 
 def stream():
+    """The current stream of the current device (ptr() checks that every tensor of the call lives on that device)."""
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

@@ -30,6 +30,7 @@ struct ScoreParams {
     const int32_t* rblock_chunk;   // nullable [n_rblocks]: chunk (= superblock) index of this resident block, -1 = idle
     const int32_t* row_pair;       // nullable [n_r]: output list id of a resident row, -1 = padding row
     const float* row_floor;        // nullable [n_r]: a known lower bound of the row's final k-th best score (lists start there)
+    const int32_t* row_index;      // grouped TOPK: nullable [n_r], resident row r is R[row_index[r]] (bias / sqnorm / floor too)
     int independent_lists;         // grouped TOPK: a list's threshold never rises from the partner half-wave's list (variant bit 4)
 };
 

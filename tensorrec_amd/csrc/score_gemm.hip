@@ -133,10 +133,21 @@ __global__ __launch_bounds__(256, WPS) void score_gemm_kernel(ScoreParams p)
     // ---- resident fragments: straight from global into registers, once ----
     bf16x8 rfb[(DT == 1) ? NCB : 1][(DT == 1) ? KS : 1];
     float rff[(DT == 0) ? NCB : 1][(DT == 0) ? KS : 1];
+    // grouped TOPK through an index (stage 3 of the filtered top-k): resident row r is operand row row_index[r] -- the
+    // user rows are gathered by these loads instead of by a separate copy pass; -1 = padding row (reads row 0, never lists)
+    int64_t src_row[NCB];
+    bool pad_row[NCB];
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
         int64_t row = r_base + cb * 32 + l31;
         if (row >= p.n_r) row = p.n_r - 1;                                   // clamped rows are never written
+        pad_row[cb] = false;
+        if (EPI == EPI_TOPK && p.row_index) {
+            const int32_t s = p.row_index[row];
+            pad_row[cb] = s < 0;
+            row = s < 0 ? 0 : s;
+        }
+        src_row[cb] = row;
         const char* src = (const char*)p.R + row * (int64_t)RB;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -152,8 +163,7 @@ __global__ __launch_bounds__(256, WPS) void score_gemm_kernel(ScoreParams p)
     if (LANEUSER) {
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
-            int64_t u = r_base + cb * 32 + l31;
-            if (u >= p.n_r) u = p.n_r - 1;
+            const int64_t u = src_row[cb];
             r_bias_col[cb] = (BIAS && p.r_bias) ? p.r_bias[u] : 0.f;
             r_sq_col[cb] = EUCLID ? p.r_sqnorm[u] : 0.f;
         }
@@ -178,9 +188,7 @@ __global__ __launch_bounds__(256, WPS) void score_gemm_kernel(ScoreParams p)
         for (int cb = 0; cb < NCB; ++cb) {
             thr[cb] = -INFINITY; tau_pp[cb] = -INFINITY;
             if (p.row_floor) {          // grouped re-scoring: scores below the floor cannot be in the final top-k
-                int64_t u = r_base + cb * 32 + l31;
-                if (u >= p.n_r) u = p.n_r - 1;
-                tau_pp[cb] = float_pred(p.row_floor[u]);
+                tau_pp[cb] = pad_row[cb] ? INFINITY : float_pred(p.row_floor[src_row[cb]]);
                 thr[cb] = tau_pp[cb];
             }
 #pragma unroll
@@ -509,9 +517,14 @@ __global__ __launch_bounds__(256, WPS) void score_gemm_kernel(ScoreParams p)
                 if (KTOP % 4 == 0 && p.capacity == KTOP) {
 #pragma unroll
                     for (int j = 0; j + 3 < KTOP; j += 4) {
-                        *(f32x4*)(p.part_vals + o + j) = (f32x4){tv[cb][j], tv[cb][j + 1], tv[cb][j + 2], tv[cb][j + 3]};
+                        if (p.part_vals)      // (the filtered top-k re-scores the listed ids exactly: bf16 values unused)
+                            *(f32x4*)(p.part_vals + o + j) = (f32x4){tv[cb][j], tv[cb][j + 1], tv[cb][j + 2], tv[cb][j + 3]};
                         *(int4*)(p.part_idx + o + j) = make_int4(ti[cb][j], ti[cb][j + 1], ti[cb][j + 2], ti[cb][j + 3]);
                     }
+                } else if (!p.part_vals) {
+#pragma unroll
+                    for (int j = 0; j < KTOP; ++j) p.part_idx[o + j] = ti[cb][j];
+                    for (int j = KTOP; j < p.capacity; ++j) p.part_idx[o + j] = -1;
                 } else {
 #pragma unroll
                     for (int j = 0; j < KTOP; ++j) { p.part_vals[o + j] = tv[cb][j]; p.part_idx[o + j] = ti[cb][j]; }
@@ -810,7 +823,8 @@ extern "C" int trec_score_gemm_blockmax(const void* users, const void* items, in
 }
 
 // users_g: operand rows gathered by trec_topk_fill_groups ([n_rows_g, kpad], n_rows_g a multiple of the rows per
-// workgroup); workgroup w re-scores superblock rblock_chunk[w] (rows [s*sb_rows, (s+1)*sb_rows) of `items`) for its
+// workgroup) -- or, with row_index (int32 [n_rows_g], -1 = padding row), the UNgathered operand: grouped row r is
+// users_g[row_index[r]] and user_bias_g / user_sqnorm_g / row_floor are indexed the same way; workgroup w re-scores superblock rblock_chunk[w] (rows [s*sb_rows, (s+1)*sb_rows) of `items`) for its
 // rows and writes the two half-wave lists of row r to list ids 2*row_pair[r], 2*row_pair[r]+1 of part_vals / part_idx.
 extern "C" int trec_score_gemm_topk_grouped(const void* users_g, const void* items, int32_t dtype, int32_t kpad,
                                             int64_t n_rows_g, int64_t n_items, int32_t item_index_base,
@@ -818,10 +832,10 @@ extern "C" int trec_score_gemm_topk_grouped(const void* users_g, const void* ite
                                             const float* user_sqnorm_g, const float* item_sqnorm, int32_t sb_rows,
                                             const int32_t* rblock_chunk, const int32_t* row_pair,
                                             const float* row_floor, int32_t capacity, float* part_vals,
-                                            int32_t* part_idx, int32_t variant, void* stream)
+                                            int32_t* part_idx, int32_t variant, const int32_t* row_index, void* stream)
 {
     ScoreParams p = {};
-    TREC_REQUIRE(part_vals && part_idx && rblock_chunk && row_pair, "trec_score_gemm_topk_grouped: null pointer");
+    TREC_REQUIRE(part_idx && rblock_chunk && row_pair, "trec_score_gemm_topk_grouped: null pointer");
     TREC_REQUIRE(capacity == 8 || capacity == 12 || capacity == 16, "trec_score_gemm_topk_grouped: capacity must be 8, 12 or 16");
     TREC_REQUIRE(sb_rows >= 128 && sb_rows % 128 == 0, "trec_score_gemm_topk_grouped: sb_rows must be a multiple of 128");
     if (n_rows_g == 0) return TREC_OK;
@@ -833,6 +847,7 @@ extern "C" int trec_score_gemm_topk_grouped(const void* users_g, const void* ite
     p.part_vals = part_vals; p.part_idx = part_idx; p.n_parts = 2; p.t_index_base = item_index_base;
     p.capacity = capacity;
     p.independent_lists = (variant >> 4) & 1;
+    p.row_index = row_index;
     if (capacity == 8) return dispatch_score<EPI_TOPK, 8>(dtype, kpad, variant & 1, p, (hipStream_t)stream);
     if (capacity == 12) return dispatch_score<EPI_TOPK, 12>(dtype, kpad, variant & 1, p, (hipStream_t)stream);
     return dispatch_score<EPI_TOPK, 16>(dtype, kpad, variant & 1, p, (hipStream_t)stream);

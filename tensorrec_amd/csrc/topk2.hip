@@ -137,6 +137,65 @@ __global__ __launch_bounds__(256) void select_blocks_tiled_kernel(const float* _
     }
 }
 
+// Pass 2 of the filtered selection (topk_filter.hip): every superblock whose maximum reaches the user's floor, in
+// superblock order -- keys[u * ksel + c] = s for the c-th such superblock (c < ksel), -1 in the unused slots;
+// count[u] = min(c, ksel).  More than ksel qualifying superblocks: flag[u] = 1 (the caller re-does the user exactly).
+// Same tiling as select_blocks_tiled_kernel (16-byte loads through LDS, register prefetch of the next tile).
+__global__ __launch_bounds__(256) void collect_blocks_tiled_kernel(const float* __restrict__ blockmax, int32_t n_sb,
+                                                                  int64_t n_users, int64_t stride,
+                                                                  const float* __restrict__ floor_, int32_t ksel,
+                                                                  int32_t* __restrict__ keys, int32_t* __restrict__ count,
+                                                                  int32_t* __restrict__ flag, int32_t* __restrict__ n_flagged)
+{
+    __shared__ __attribute__((aligned(16))) float tile[2][SEL_TS][256];
+    const int t = threadIdx.x;
+    const int64_t u0 = (int64_t)blockIdx.x * 256;
+    const int64_t u = u0 + t;
+    const bool ok = u < n_users;
+    const int lrow = t >> 6, lcol = (t & 63) * 4;
+    const bool vec = (stride % 4 == 0) && (((uintptr_t)blockmax % 16) == 0) && (u0 + lcol + 3 < stride);
+    const float fl = ok ? floor_[u] : INFINITY;
+    int32_t c = 0;
+    auto fetch = [&](int32_t s0, f32x4 (&r)[2]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int32_t srow = s0 + lrow + 4 * i;
+            r[i] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            if (srow < n_sb && vec) r[i] = *(const f32x4*)(blockmax + (int64_t)srow * stride + u0 + lcol);
+            else if (srow < n_sb) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (u0 + lcol + e < stride) r[i][e] = blockmax[(int64_t)srow * stride + u0 + lcol + e];
+            }
+        }
+    };
+    f32x4 cur[2], nxt[2];
+    fetch(0, cur);
+    int buf = 0;
+    for (int32_t s0 = 0; s0 < n_sb; s0 += SEL_TS) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *(f32x4*)(&tile[buf][lrow + 4 * i][lcol]) = cur[i];
+        if (s0 + SEL_TS < n_sb) fetch(s0 + SEL_TS, nxt);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < SEL_TS; ++r) {
+            const int32_t s = s0 + r;
+            const float v = tile[buf][r][t];
+            if (ok && s < n_sb && !(v < fl)) {
+                if (c < ksel) keys[u * ksel + c] = s;
+                ++c;
+            }
+        }
+        cur[0] = nxt[0]; cur[1] = nxt[1];
+        buf ^= 1;
+    }
+    if (ok) {
+        for (int32_t j = c; j < ksel; ++j) keys[u * ksel + j] = -1;
+        count[u] = c < ksel ? c : ksel;
+        if (c > ksel && flag[u] == 0) { flag[u] = 1; atomicAdd(n_flagged, 1); }
+    }
+}
+
 // keys for the counting sort: superblock id, or -1 (skipped by the sort) for empty slots and for superblocks whose
 // maximum lies below the user's floor.  The floor is any lower bound of the user's final k-th best score -- with item
 // shards, the MAX over ranks of the per-shard tau (every shard's k-th best is a floor of the global k-th best): a
@@ -223,6 +282,59 @@ __global__ __launch_bounds__(256) void fill_groups_kernel(
 }
 
 // k = entries kept per user (list length, <= 64), k_tau <= k = which entry is reported as tau
+// fill_groups without the operand copy: one thread per grouped row writes row_user[v] (the operand row the grouped score
+// kernel loads through its row_index; -1 = padding), row_pair[v] and, for the first row of a workgroup, rblock_chunk.
+__global__ __launch_bounds__(256) void fill_groups_index_kernel(
+    const int64_t* __restrict__ pstart, const int64_t* __restrict__ indptr_t, const int32_t* __restrict__ users_t,
+    const int32_t* __restrict__ perm_t, int32_t n_sb, int32_t rows_wg, int64_t max_rows, int32_t* __restrict__ row_user,
+    int32_t* __restrict__ row_pair, int32_t* __restrict__ rblock_chunk)
+{
+    __shared__ int64_t l_pstart[FILL_LDS_SB + 1];
+    const bool in_lds = n_sb <= FILL_LDS_SB;
+    if (in_lds) {
+        for (int i = threadIdx.x; i <= n_sb; i += 256) l_pstart[i] = pstart[i];
+        __syncthreads();
+    }
+    const int64_t* ps = in_lds ? l_pstart : pstart;
+    const int64_t total = ps[n_sb];
+    const int64_t row0 = (int64_t)blockIdx.x * FILL_ROWS;
+    const int64_t row1 = (row0 + FILL_ROWS < max_rows) ? row0 + FILL_ROWS : max_rows;
+    for (int64_t v = row0 + threadIdx.x; v < row1; v += 256) {
+        int32_t sb = -1, user = -1, pair = -1;
+        if (v < total) {
+            int lo = 0, hi = n_sb - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (ps[mid] <= v) lo = mid; else hi = mid - 1;
+            }
+            sb = lo;
+            const int64_t o = v - ps[sb];
+            if (o < indptr_t[sb + 1] - indptr_t[sb]) {
+                const int64_t e = indptr_t[sb] + o;
+                user = users_t[e];
+                pair = perm_t[e];
+            }
+        }
+        row_user[v] = user;
+        row_pair[v] = pair;
+        if (v % rows_wg == 0) rblock_chunk[v / rows_wg] = sb;
+    }
+}
+
+extern "C" int trec_topk_fill_groups_index(const int64_t* pstart, const int64_t* indptr_t, const int32_t* users_t,
+                                           const int32_t* perm_t, int32_t n_sb, int32_t rows_wg, int64_t max_rows,
+                                           int32_t* row_user, int32_t* row_pair, int32_t* rblock_chunk, void* stream)
+{
+    TREC_REQUIRE(pstart && indptr_t && users_t && perm_t && row_user && row_pair && rblock_chunk,
+                 "trec_topk_fill_groups_index: null pointer");
+    TREC_REQUIRE(rows_wg >= 1 && max_rows % rows_wg == 0, "trec_topk_fill_groups_index: max_rows % rows_wg");
+    if (max_rows == 0) return TREC_OK;
+    hipLaunchKernelGGL(fill_groups_index_kernel, dim3((unsigned)ceil_div64(max_rows, FILL_ROWS)), dim3(256), 0,
+                       (hipStream_t)stream, pstart, indptr_t, users_t, perm_t, n_sb, rows_wg, max_rows, row_user, row_pair,
+                       rblock_chunk);
+    return trec_check_launch("trec_topk_fill_groups_index");
+}
+
 extern "C" int trec_topk_select_blocks_ex(const float* blockmax, int32_t n_sb, int64_t n_users, int64_t stride, int32_t k,
                                           int32_t k_tau, int32_t* sel, float* sel_max, float* tau, void* stream)
 {
@@ -264,6 +376,18 @@ extern "C" int trec_topk_select_blocks(const float* blockmax, int32_t n_sb, int6
 {
     TREC_REQUIRE(k >= 1 && k <= 16, "trec_topk_select_blocks: need 1 <= k <= 16");
     return trec_topk_select_blocks_ex(blockmax, n_sb, n_users, stride, k, k, sel, sel_max, tau, stream);
+}
+
+extern "C" int trec_topk_collect_blocks(const float* blockmax, int32_t n_sb, int64_t n_users, int64_t stride,
+                                        const float* floor_, int32_t ksel, int32_t* keys, int32_t* count, int32_t* flag,
+                                        int32_t* n_flagged, void* stream)
+{
+    TREC_REQUIRE(blockmax && floor_ && keys && count && flag && n_flagged, "trec_topk_collect_blocks: null pointer");
+    TREC_REQUIRE(ksel >= 1 && ksel <= 64 && n_sb >= 1 && stride >= n_users, "trec_topk_collect_blocks: need 1 <= ksel <= 64");
+    if (n_users == 0) return TREC_OK;
+    hipLaunchKernelGGL(collect_blocks_tiled_kernel, dim3((unsigned)ceil_div64(n_users, 256)), dim3(256), 0,
+                       (hipStream_t)stream, blockmax, n_sb, n_users, stride, floor_, ksel, keys, count, flag, n_flagged);
+    return trec_check_launch("trec_topk_collect_blocks");
 }
 
 extern "C" int trec_topk_group_keys(const int32_t* sel, const float* sel_max, const float* floor_, int64_t n, int32_t k,

@@ -125,14 +125,12 @@ __global__ __launch_bounds__(256) void prep_filter_kernel(const float* __restric
     }
 }
 
-// floor_u = tau_u - 2 eps_u (rounded DOWN twice), eps2_u = 2 eps_u, flag_u |= 1 when the bound is unusable or the
-// selection list may have been too short.
+// floor_u = tau_u - 2 eps_u (rounded DOWN twice); flag_u = 1 when the bound is unusable (then floor_u = -inf).
 __global__ __launch_bounds__(256) void filter_floor_kernel(const float* __restrict__ tau, const float2* __restrict__ ustats,
                                                           const float* __restrict__ user_bias,
-                                                          const float* __restrict__ gstats, int kdim,
-                                                          const int32_t* __restrict__ sel, const float* __restrict__ sel_max,
-                                                          int ksel, int n_sb, int64_t n_users, float* __restrict__ floor_,
-                                                          int32_t* __restrict__ flag, int32_t* __restrict__ n_flagged)
+                                                          const float* __restrict__ gstats, int kdim, int64_t n_users,
+                                                          float* __restrict__ floor_, int32_t* __restrict__ flag,
+                                                          int32_t* __restrict__ n_flagged)
 {
     const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (u >= n_users) return;
@@ -150,48 +148,50 @@ __global__ __launch_bounds__(256) void filter_floor_kernel(const float* __restri
     else f = float_pred(float_pred(f));
     if (bad) f = -INFINITY;
     floor_[u] = f;
-    // a saturated selection whose last entry still passes the floor may hide further superblocks >= floor
-    if (!bad && n_sb > ksel && sel[u * ksel + ksel - 1] >= 0 && !(sel_max[(int64_t)(ksel - 1) * n_users + u] < f)) bad = true;
     flag[u] = bad ? 1 : 0;
     if (bad) atomicAdd(n_flagged, 1);
 }
 
-// One wave per user.  The user's kept superblocks are slots [0, c_u) of its selection list (maxima are sorted, the
-// floor cuts a prefix), so its stage-3 lists are the first c_u * 2 * cap entries of its slice of part_vals / part_idx.
+// One wave per user.  Only the first count[u] slots of a user have stage-3 lists.  Survivors are re-scored FILTER_RB at a time: their fp32
+// rows are fetched with coalesced 16-byte loads (a row = KT/4 consecutive lanes) into LDS, then lane r walks row r with
+// the reference's k-ordered fmaf chain (a row per lane straight from global memory is a 16-byte access per 512-byte
+// row per load: 4.6 ms at 1M users, ~15 survivors each; staged: see DESIGN.md).
+#define FILTER_RB 16
 template <int CPL>
 __global__ __launch_bounds__(256) void filter_finish_kernel(
-    const float* __restrict__ pv, const int32_t* __restrict__ pi, int cap, int ksel, const int32_t* __restrict__ sel,
-    const float* __restrict__ sel_max, const float* __restrict__ floor_, const float* __restrict__ U,
+    const int32_t* __restrict__ pi, int cap, int ksel, const int32_t* __restrict__ count, const float* __restrict__ U,
     const float* __restrict__ V, int64_t ld_u, int64_t ld_v, int kdim, const float* __restrict__ user_bias,
     const float* __restrict__ item_bias, int32_t item_index_base, int64_t n_users, int k, float* __restrict__ ov,
     int32_t* __restrict__ oi, int32_t* __restrict__ flag, int32_t* __restrict__ n_flagged)
 {
-    __shared__ int32_t cand_lds[4][FILTER_CMAX];
+    extern __shared__ __attribute__((aligned(16))) char fsmem[];
     const int wave = threadIdx.x >> 6;
     const int64_t u = (int64_t)blockIdx.x * 4 + wave;
     if (u >= n_users) return;
     const int lane = lane_id();
-    // ---- kept slots: a prefix of the selection list
-    const float fl = floor_[u];
-    bool kept = false;
-    if (lane < ksel) kept = sel[u * ksel + lane] >= 0 && !(sel_max[(int64_t)lane * n_users + u] < fl);
-    const int c_u = __builtin_popcountll(__builtin_amdgcn_ballot_w64(kept));
-    const int n_ent = c_u * 2 * cap;
+    const int kd4 = (kdim + 3) & ~3;                         // floats staged per row (operand rows are padded to kpad >= kd4)
+    const int rstride = kd4 + 4;                             // +4 floats: lanes r = 0..15 start on distinct 4-bank groups
+    int32_t* cand = (int32_t*)fsmem + wave * FILTER_CMAX;
+    float* urow = (float*)(fsmem + 4 * FILTER_CMAX * 4) + (size_t)wave * kd4;
+    float* rows = (float*)(fsmem + 4 * FILTER_CMAX * 4) + (size_t)4 * kd4 + (size_t)wave * FILTER_RB * rstride;
+    // ---- kept slots: the first count[u] of the user's ksel slots (trec_topk_collect_blocks)
+    const int c_u = count[u];
+    const unsigned long long keptmask = c_u >= 64 ? ~0ull : ((1ull << c_u) - 1ull);
     const int64_t base = u * (int64_t)ksel * 2 * cap;
-    // ---- survivors: every valid list entry; a full list may have dropped items above the floor
+    // ---- survivors: every valid entry of a kept slot's two lists; a full list may have dropped items above the floor
     int32_t id[CPL];
     bool lossy = false;
+    const int n_ent = ksel * 2 * cap;
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
         const int j = c * 64 + lane;
         id[c] = -1;
-        if (j < n_ent) {
+        if (j < n_ent && ((keptmask >> (j / (2 * cap))) & 1ull)) {
             id[c] = pi[base + j];
             if (id[c] >= 0 && (j % cap) == cap - 1) lossy = true;
         }
     }
     int total = 0;
-    int32_t* cand = cand_lds[wave];
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
         const unsigned long long m = __builtin_amdgcn_ballot_w64(id[c] >= 0);
@@ -202,33 +202,71 @@ __global__ __launch_bounds__(256) void filter_finish_kernel(
     const bool over = __builtin_amdgcn_ballot_w64(lossy) != 0ull || total > FILTER_CMAX;
     if (over && lane == 0 && flag[u] == 0) { flag[u] = 1; atomicAdd(n_flagged, 1); }
     if (total > FILTER_CMAX) total = FILTER_CMAX;
-    __builtin_amdgcn_wave_barrier();              // cand[] is private to this wave and DS operations of a wave execute in order
+    __builtin_amdgcn_wave_barrier();              // cand[] / rows[] are private to this wave; a wave's DS operations execute in order
     // ---- exact fp32 scores of the survivors: the reference's k-ordered fmaf chain, then (s + b_u) + b_i
     const unsigned long long EMPTY = merge_key(-INFINITY, 0x7fffffff);
-    unsigned long long key = EMPTY;
-    if (lane < total) {
-        const int32_t item = cand[lane];
-        const float* a = U + u * ld_u;
-        const float* b = V + (int64_t)(item - item_index_base) * ld_v;
-        float acc = 0.0f;
-        int kk = 0;
-        if (((ld_u | ld_v) & 3) == 0) {
-            for (; kk + 4 <= kdim; kk += 4) {
-                const f32x4 a4 = *(const f32x4*)(a + kk);
-                const f32x4 b4 = *(const f32x4*)(b + kk);
-                acc = __fmaf_rn(a4[0], b4[0], acc); acc = __fmaf_rn(a4[1], b4[1], acc);
-                acc = __fmaf_rn(a4[2], b4[2], acc); acc = __fmaf_rn(a4[3], b4[3], acc);
-            }
+    unsigned long long key = EMPTY;                // lane r ends up holding survivor (round * FILTER_RB + r)'s key ...
+    unsigned long long mine = EMPTY;               // ... moved to lane (round * FILTER_RB + r) here
+    const float bu = user_bias ? user_bias[u] : 0.f;
+    const int chunks = kd4 >> 2;
+    const bool vec = ((ld_v & 3) == 0) && ((ld_u & 3) == 0);
+    // the user's row: one coalesced read into LDS, broadcast from there by every chain step
+    for (int ch = lane; ch < chunks; ch += 64) {
+        const float* src = U + u * ld_u + ch * 4;
+        f32x4 w;
+        if (vec) w = *(const f32x4*)src;
+        else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[e] = (ch * 4 + e < kdim) ? src[e] : 0.f;
         }
-        for (; kk < kdim; ++kk) acc = __fmaf_rn(a[kk], b[kk], acc);
-        if (user_bias) acc = acc + user_bias[u];
-        if (item_bias) acc = acc + item_bias[item - item_index_base];
-        key = merge_key(acc, item);
+        *(f32x4*)(urow + ch * 4) = w;
+    }
+    const float* a = urow;
+    for (int r0 = 0; r0 < total; r0 += FILTER_RB) {
+        const int nr = (total - r0 < FILTER_RB) ? total - r0 : FILTER_RB;
+        for (int idx = lane; idx < nr * chunks; idx += 64) {
+            const int r = idx / chunks, ch = idx - r * chunks;
+            const float* src = V + (int64_t)(cand[r0 + r] - item_index_base) * ld_v + ch * 4;
+            f32x4 w;
+            if (vec) w = *(const f32x4*)src;
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[e] = (ch * 4 + e < kdim) ? src[e] : 0.f;
+            }
+            *(f32x4*)(rows + r * rstride + ch * 4) = w;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < nr) {
+            const int32_t item = cand[r0 + lane];
+            const float* b = rows + lane * rstride;
+            float acc = 0.0f;
+            int kk = 0;
+            {
+                for (; kk + 4 <= kdim; kk += 4) {
+                    const f32x4 a4 = *(const f32x4*)(a + kk);
+                    const f32x4 b4 = *(const f32x4*)(b + kk);
+                    acc = __fmaf_rn(a4[0], b4[0], acc); acc = __fmaf_rn(a4[1], b4[1], acc);
+                    acc = __fmaf_rn(a4[2], b4[2], acc); acc = __fmaf_rn(a4[3], b4[3], acc);
+                }
+            }
+            for (; kk < kdim; ++kk) acc = __fmaf_rn(a[kk], b[kk], acc);
+            if (user_bias) acc = acc + bu;
+            if (item_bias) acc = acc + item_bias[item - item_index_base];
+            key = merge_key(acc, item);
+        } else key = EMPTY;
+        __builtin_amdgcn_wave_barrier();
+        // lane r0 + r takes over lane r's key (r0 is a multiple of 16: a fixed rotation per round)
+        {
+            const int srcl = (lane - r0) & 63;
+            const unsigned int lo = (unsigned int)__shfl((int)(unsigned int)key, srcl, 64);
+            const unsigned int hi = (unsigned int)__shfl((int)(unsigned int)(key >> 32), srcl, 64);
+            if (lane >= r0 && lane < r0 + nr) mine = ((unsigned long long)hi << 32) | lo;
+        }
     }
     // ---- the k best by (value desc, index asc)
     for (int t = 0; t < k; ++t) {
-        const unsigned long long best = wave_max_u64(key);
-        if (key == best && best != EMPTY) key = EMPTY;
+        const unsigned long long best = wave_max_u64(mine);
+        if (mine == best && best != EMPTY) mine = EMPTY;
         if (lane == 0) {
             const unsigned int hi = (unsigned int)(best >> 32);
             const unsigned int bits = (hi & 0x80000000u) ? (hi & 0x7fffffffu) : ~hi;
@@ -258,44 +296,46 @@ extern "C" int trec_score_prep_filter(const float* repr, int64_t n, int32_t d, i
 }
 
 extern "C" int trec_topk_filter_floor(const float* tau, const float* user_stats, const float* user_bias,
-                                      const float* item_gstats, int32_t kdim, const int32_t* sel, const float* sel_max,
-                                      int32_t ksel, int32_t n_sb, int64_t n_users, float* floor_, int32_t* flag,
+                                      const float* item_gstats, int32_t kdim, int64_t n_users, float* floor_, int32_t* flag,
                                       int32_t* n_flagged, void* stream)
 {
-    TREC_REQUIRE(tau && user_stats && item_gstats && sel && sel_max && floor_ && flag && n_flagged,
-                 "trec_topk_filter_floor: null pointer");
-    TREC_REQUIRE(ksel >= 1 && kdim >= 1, "trec_topk_filter_floor: bad sizes");
+    TREC_REQUIRE(tau && user_stats && item_gstats && floor_ && flag && n_flagged, "trec_topk_filter_floor: null pointer");
+    TREC_REQUIRE(kdim >= 1, "trec_topk_filter_floor: bad sizes");
     if (n_users == 0) return TREC_OK;
     hipLaunchKernelGGL(filter_floor_kernel, dim3((unsigned)ceil_div64(n_users, 256)), dim3(256), 0, (hipStream_t)stream,
-                       tau, (const float2*)user_stats, user_bias, item_gstats, kdim, sel, sel_max, ksel, n_sb, n_users,
-                       floor_, flag, n_flagged);
+                       tau, (const float2*)user_stats, user_bias, item_gstats, kdim, n_users, floor_, flag, n_flagged);
     return trec_check_launch("trec_topk_filter_floor");
 }
 
-extern "C" int trec_topk_filter_finish(const float* part_vals, const int32_t* part_idx, int32_t capacity, int32_t ksel,
-                                       const int32_t* sel, const float* sel_max, const float* floor_, const float* users_f32,
+extern "C" int trec_topk_filter_finish(const int32_t* part_idx, int32_t capacity, int32_t ksel, const int32_t* count,
+                                       const float* users_f32,
                                        const float* items_f32, int64_t ld_users, int64_t ld_items, int32_t kdim,
                                        const float* user_bias, const float* item_bias, int32_t item_index_base,
                                        int64_t n_users, int32_t k, float* out_vals, int32_t* out_idx, int32_t* flag,
                                        int32_t* n_flagged, void* stream)
 {
-    TREC_REQUIRE(part_vals && part_idx && sel && sel_max && floor_ && users_f32 && items_f32 && out_vals && out_idx && flag &&
-                     n_flagged, "trec_topk_filter_finish: null pointer");
+    TREC_REQUIRE(part_idx && count && users_f32 && items_f32 && out_vals && out_idx && flag && n_flagged,
+                 "trec_topk_filter_finish: null pointer");
     TREC_REQUIRE(ksel >= 1 && ksel <= 64 && k >= 1 && k <= FILTER_CMAX, "trec_topk_filter_finish: need ksel <= 64, k <= 64");
     TREC_REQUIRE(capacity >= 1 && ksel * 2 * capacity <= 64 * 32, "trec_topk_filter_finish: ksel * 2 * capacity <= 2048");
+    TREC_REQUIRE(kdim >= 1 && kdim <= 1024 && ld_users >= kdim && ld_items >= ((kdim + 3) & ~3),
+                 "trec_topk_filter_finish: need kdim <= 1024 and item rows padded to a multiple of 4");
     if (n_users == 0) return TREC_OK;
     const unsigned blocks = (unsigned)ceil_div64(n_users, 4);
     hipStream_t st = (hipStream_t)stream;
     const int cpl = (ksel * 2 * capacity + 63) / 64;
+    const int kd4 = (kdim + 3) & ~3;
+    const size_t lds = 4 * FILTER_CMAX * 4 + (size_t)4 * kd4 * 4 + (size_t)4 * FILTER_RB * (kd4 + 4) * 4;
 #define TREC_FF(CPLV)                                                                                                  \
-    hipLaunchKernelGGL((filter_finish_kernel<CPLV>), dim3(blocks), dim3(256), 0, st, part_vals, part_idx, capacity, ksel, sel, \
-                       sel_max, floor_, users_f32, items_f32, ld_users, ld_items, kdim, user_bias, item_bias,          \
+    (void)hipFuncSetAttribute((const void*)filter_finish_kernel<CPLV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((filter_finish_kernel<CPLV>), dim3(blocks), dim3(256), lds, st, part_idx, capacity, ksel, count, \
+                       users_f32, items_f32, ld_users, ld_items, kdim, user_bias, item_bias,          \
                        item_index_base, n_users, k, out_vals, out_idx, flag, n_flagged)
-    if (cpl <= 4) TREC_FF(4);
-    else if (cpl <= 8) TREC_FF(8);
-    else if (cpl <= 12) TREC_FF(12);
-    else if (cpl <= 16) TREC_FF(16);
-    else TREC_FF(32);
+    if (cpl <= 4) { TREC_FF(4); }
+    else if (cpl <= 8) { TREC_FF(8); }
+    else if (cpl <= 12) { TREC_FF(12); }
+    else if (cpl <= 16) { TREC_FF(16); }
+    else { TREC_FF(32); }
 #undef TREC_FF
     return trec_check_launch("trec_topk_filter_finish");
 }

@@ -21,12 +21,33 @@ import torch
 _state = threading.local()
 
 
+def resolve_device(device):
+    """torch.device with an explicit index ('cuda' -> the current device), so that devices compare and guard reliably
+    (torch.device('cuda') != torch.device('cuda:0'))."""
+    dev = torch.device(device)
+    if dev.type == 'cuda' and dev.index is None and torch.cuda.is_available():
+        dev = torch.device('cuda', torch.cuda.current_device())
+    return dev
+
+
 class VariableStore(object):
-    def __init__(self, device):
-        self.device = torch.device(device)
+    def __init__(self, device, seed=None):
+        self.device = resolve_device(device)
         self.variables = {}          # name -> leaf tensor (requires_grad)
         self.order = []
         self._anon = 0
+        # ONE generator per model, created once: successive initialiser draws continue one seeded stream, so equally
+        # shaped weights (the tastes, equal user / item feature counts) start different.  seed=None: torch's global RNG.
+        self.seed = _generator.get("seed") if seed is None else int(seed)
+        self._gen = None
+
+    def generator(self):
+        if self.seed is None:
+            return None
+        if self._gen is None:
+            self._gen = torch.Generator(device=self.device)
+            self._gen.manual_seed(self.seed)
+        return self._gen
 
     def get(self, name, init):
         if name is None:
@@ -76,24 +97,17 @@ _generator = {}
 
 
 def set_seed(seed):
-    """The reference exposes no seed; this is an extension used by tests and benchmarks."""
-    _generator["seed"] = int(seed)
-    _generator.pop("gen", None)
-
-
-def _gen(dev):
-    if "seed" not in _generator:
-        return None
-    if "gen" not in _generator or _generator["gen"].device != dev:
-        g = torch.Generator(device=dev)
-        g.manual_seed(_generator["seed"])
-        _generator["gen"] = g
-    return _generator["gen"]
+    """Default seed of models created afterwards without one (``None`` clears it).  The reference exposes no seed
+    (SURVEY.md 3.4); TensorRec(seed=...) is the per-model form and takes precedence."""
+    if seed is None:
+        _generator.pop("seed", None)
+    else:
+        _generator["seed"] = int(seed)
 
 
 def random_normal(shape, stddev=1.0):
-    dev = device()
-    return torch.randn(tuple(shape), dtype=torch.float32, device=dev, generator=_gen(dev)) * stddev
+    store = current_store()
+    return torch.randn(tuple(shape), dtype=torch.float32, device=store.device, generator=store.generator()) * stddev
 
 
 def zeros(shape):

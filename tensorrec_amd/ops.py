@@ -769,10 +769,11 @@ def score_topk_two_stage(users_op, items_op, dtype, kpad, k, user_bias=None, ite
         rblocks = (n_u + rows_wg - 1) // rows_wg
         n_chunks = max(1, min(n_sb, -(-32 * 768 // rblocks)))
     # ---- stage 1: superblock maxima
-    blockmax = torch.empty((n_sb, n_u), dtype=torch.float32, device=dev)
+    stride = (n_u + 3) // 4 * 4                     # 16-byte aligned rows: the tiled selection kernel's float4 loads
+    blockmax = torch.empty((n_sb, stride), dtype=torch.float32, device=dev)
     with _timed("score_gemm_blockmax"):
         N.call("trec_score_gemm_blockmax", N.ptr(users_op), N.ptr(items_op), dtype, kpad, n_u, n_i, N.ptr(user_bias),
-               N.ptr(item_bias), mode, N.ptr(user_sq), N.ptr(item_sq), sb_rows, n_chunks, N.ptr(blockmax), n_u, variant)
+               N.ptr(item_bias), mode, N.ptr(user_sq), N.ptr(item_sq), sb_rows, n_chunks, N.ptr(blockmax), stride, variant)
     # ---- stage 2: the ksel best superblocks of every user
     sel = torch.empty((n_u, ksel), dtype=torch.int32, device=dev)
     tau = torch.empty((n_u,), dtype=torch.float32, device=dev) if ksel == int(k) else None   # floor needs k superblocks
@@ -780,7 +781,7 @@ def score_topk_two_stage(users_op, items_op, dtype, kpad, k, user_bias=None, ite
     if floor_exchange is not None:                  # rows >= ksel stay -inf (a shard with fewer than k superblocks)
         sel_max = torch.full((int(k), n_u), float('-inf'), dtype=torch.float32, device=dev)
     with _timed("topk_select_blocks"):
-        N.call("trec_topk_select_blocks", N.ptr(blockmax), n_sb, n_u, n_u, ksel, N.ptr(sel), N.ptr(sel_max), N.ptr(tau))
+        N.call("trec_topk_select_blocks", N.ptr(blockmax), n_sb, n_u, stride, ksel, N.ptr(sel), N.ptr(sel_max), N.ptr(tau))
     del blockmax
     floor = None
     if floor_exchange is not None:
@@ -813,7 +814,7 @@ def score_topk_two_stage(users_op, items_op, dtype, kpad, k, user_bias=None, ite
     with _timed("score_gemm_topk_grouped"):
         N.call("trec_score_gemm_topk_grouped", N.ptr(g_op), N.ptr(items_op), dtype, kpad, max_rows, n_i, item_index_base,
                N.ptr(g_bias), N.ptr(item_bias), mode, N.ptr(g_sq), N.ptr(item_sq), sb_rows, N.ptr(rblock_chunk),
-               N.ptr(row_pair), N.ptr(g_tau), cap, N.ptr(pv), N.ptr(pi), variant & 1)
+               N.ptr(row_pair), N.ptr(g_tau), cap, N.ptr(pv), N.ptr(pi), variant & 1, None)
     # ---- stage 4: merge the ksel * 2 lists of every user
     return topk_merge(pv.reshape(n_u, ksel * 2 * cap), pi.reshape(n_u, ksel * 2 * cap), k)
 
@@ -856,9 +857,9 @@ def score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index_
     Item shards: ``floor_exchange`` as in score_topk_two_stage, ``stats_exchange(gstats) -> gstats`` = all-reduce MAX of
     the item-side maxima (the bound must cover every shard's items).  Users the filter cannot certify (its capacity
     limits, non-finite bounds) are re-done on the exact fp32 MFMA path; their number is in LAST_FILTER_STATS."""
-    cap = N.query("trec_score_topk_capacity", int(k))
-    if cap < 0:
+    if not 1 <= int(k) <= 16:
         raise ValueError("fused top-k supports k <= 16 (got %d)" % k)
+    cap = 8              # stage-3 lists hold survivors of ONE (user, superblock, half-wave): 0-2 typically; full -> exact fallback
     dev = uop.bf16.device
     n_u, n_i, kpad = uop.n, iop.n, uop.kpad
     if iop.kpad != kpad or iop.gstats is None:
@@ -878,28 +879,32 @@ def score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index_
     with _timed("score_gemm_blockmax"):
         N.call("trec_score_gemm_blockmax", N.ptr(uop.bf16), N.ptr(iop.bf16), DTYPE_BF16, kpad, n_u, n_i,
                N.ptr(user_bias), N.ptr(item_bias), MODE_DOT, None, None, sb_rows, n_chunks, N.ptr(blockmax), n_u, variant)
-    # ---- stage 2: the ksel best superblocks, tau = k-th largest maximum, floor = tau - 2 eps
-    sel = torch.empty((n_u, ksel), dtype=torch.int32, device=dev)
-    sel_max = torch.empty((ksel, n_u), dtype=torch.float32, device=dev)
+    # ---- stage 2, pass 1: tau = k-th largest superblock maximum (a floor of the k-th best bf16 score)
+    kk = int(k)
+    sel = torch.empty((n_u, kk), dtype=torch.int32, device=dev)
+    sel_max = torch.empty((kk, n_u), dtype=torch.float32, device=dev) if floor_exchange is not None else None
     tau = torch.empty((n_u,), dtype=torch.float32, device=dev)
     with _timed("topk_select_blocks"):
-        N.call("trec_topk_select_blocks_ex", N.ptr(blockmax), n_sb, n_u, n_u, ksel, int(k), N.ptr(sel), N.ptr(sel_max),
-               N.ptr(tau))
-    del blockmax
+        N.call("trec_topk_select_blocks", N.ptr(blockmax), n_sb, n_u, n_u, kk, N.ptr(sel), N.ptr(sel_max), N.ptr(tau))
     gstats = iop.gstats
     if floor_exchange is not None:                  # item shards: the k-th largest maximum over ALL shards
-        tau = floor_exchange(sel_max[:int(k)].contiguous()).contiguous()
+        tau = floor_exchange(sel_max).contiguous()
     if stats_exchange is not None:
         gstats = stats_exchange(gstats).contiguous()
+    # ---- floor = tau - 2 eps (proven bound, csrc/topk_filter.hip); pass 2: every superblock reaching the floor
     floor = torch.empty((n_u,), dtype=torch.float32, device=dev)
     flag = torch.empty((n_u,), dtype=torch.int32, device=dev)
     n_flagged = torch.zeros((1,), dtype=torch.int32, device=dev)
-    N.call("trec_topk_filter_floor", N.ptr(tau), N.ptr(uop.stats), N.ptr(user_bias), N.ptr(gstats), kpad, N.ptr(sel),
-           N.ptr(sel_max), ksel, n_sb, n_u, N.ptr(floor), N.ptr(flag), N.ptr(n_flagged))
-    # ---- stage 3a: group the kept (user, slot) pairs by superblock, pad groups to whole workgroups, gather bf16 rows
+    N.call("trec_topk_filter_floor", N.ptr(tau), N.ptr(uop.stats), N.ptr(user_bias), N.ptr(gstats), kpad, n_u,
+           N.ptr(floor), N.ptr(flag), N.ptr(n_flagged))
     n_pairs = n_u * ksel
     keys = torch.empty((n_pairs,), dtype=torch.int32, device=dev)
-    N.call("trec_topk_group_keys", N.ptr(sel), N.ptr(sel_max), N.ptr(floor), n_pairs, ksel, n_sb, N.ptr(keys))
+    count = torch.empty((n_u,), dtype=torch.int32, device=dev)
+    with _timed("topk_collect_blocks"):
+        N.call("trec_topk_collect_blocks", N.ptr(blockmax), n_sb, n_u, n_u, N.ptr(floor), ksel, N.ptr(keys), N.ptr(count),
+               N.ptr(flag), N.ptr(n_flagged))
+    del blockmax
+    # ---- stage 3a: group the kept (user, slot) pairs by superblock, pad groups to whole workgroups, gather bf16 rows
     indptr_t, users_t, perm_t = group_pairs_by_item(None, keys, ksel, n_sb + 1)
     cnt_pad = torch.empty((n_sb + 1,), dtype=torch.int32, device=dev)
     N.call("trec_topk_pad_counts", N.ptr(indptr_t), n_sb, rows_wg, N.ptr(cnt_pad))
@@ -907,34 +912,32 @@ def score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index_
     ws64 = torch.empty(((n_sb + 1 + 1023) // 1024 + 1,), dtype=torch.int64, device=dev)
     N.call("trec_exclusive_scan_i32", N.ptr(cnt_pad), n_sb + 1, N.ptr(ws64), N.ptr(pstart))
     max_rows = (n_pairs + min(n_sb, n_pairs) * (rows_wg - 1) + rows_wg - 1) // rows_wg * rows_wg
-    g_op = torch.empty((max_rows, kpad), dtype=torch.bfloat16, device=dev)
-    g_bias = torch.empty((max_rows,), dtype=torch.float32, device=dev) if user_bias is not None else None
-    g_tau = torch.empty((max_rows,), dtype=torch.float32, device=dev)
+    row_user = torch.empty((max_rows,), dtype=torch.int32, device=dev)
     row_pair = torch.empty((max_rows,), dtype=torch.int32, device=dev)
     rblock_chunk = torch.empty((max_rows // rows_wg,), dtype=torch.int32, device=dev)
     with _timed("topk_fill_groups"):
-        N.call("trec_topk_fill_groups", N.ptr(pstart), N.ptr(indptr_t), N.ptr(users_t), N.ptr(perm_t), n_sb, rows_wg,
-               max_rows, N.ptr(uop.bf16), kpad * 2, N.ptr(user_bias), None, N.ptr(floor), N.ptr(g_op), N.ptr(g_bias),
-               None, N.ptr(g_tau), N.ptr(row_pair), N.ptr(rblock_chunk))
-    # ---- stage 3b: bf16 re-scoring of the kept superblocks, every item >= floor listed (independent lists: bit 4)
-    pv = torch.empty((n_pairs * 2, cap), dtype=torch.float32, device=dev)      # only the kept pairs' lists are touched
-    pi = torch.empty((n_pairs * 2, cap), dtype=torch.int32, device=dev)
+        N.call("trec_topk_fill_groups_index", N.ptr(pstart), N.ptr(indptr_t), N.ptr(users_t), N.ptr(perm_t), n_sb, rows_wg,
+               max_rows, N.ptr(row_user), N.ptr(row_pair), N.ptr(rblock_chunk))
+    # ---- stage 3b: bf16 re-scoring of the kept superblocks, every item >= floor listed (independent lists: bit 4);
+    # the user rows / biases / floors are fetched through row_user, only item ids are written
+    pi = torch.empty((n_pairs * 2, cap), dtype=torch.int32, device=dev)        # only the kept pairs' lists are touched
     with _timed("score_gemm_topk_grouped"):
-        N.call("trec_score_gemm_topk_grouped", N.ptr(g_op), N.ptr(iop.bf16), DTYPE_BF16, kpad, max_rows, n_i,
-               item_index_base, N.ptr(g_bias), N.ptr(item_bias), MODE_DOT, None, None, sb_rows, N.ptr(rblock_chunk),
-               N.ptr(row_pair), N.ptr(g_tau), cap, N.ptr(pv), N.ptr(pi), (variant & 1) | 16)
+        N.call("trec_score_gemm_topk_grouped", N.ptr(uop.bf16), N.ptr(iop.bf16), DTYPE_BF16, kpad, max_rows, n_i,
+               item_index_base, N.ptr(user_bias), N.ptr(item_bias), MODE_DOT, None, None, sb_rows, N.ptr(rblock_chunk),
+               N.ptr(row_pair), N.ptr(floor), cap, None, N.ptr(pi), (variant & 1) | 16, N.ptr(row_user))
     # ---- stage 4: exact fp32 scores of the survivors, exact top-k
     ov = torch.empty((n_u, int(k)), dtype=torch.float32, device=dev)
     oi = torch.empty((n_u, int(k)), dtype=torch.int32, device=dev)
     with _timed("topk_filter_finish"):
-        N.call("trec_topk_filter_finish", N.ptr(pv), N.ptr(pi), cap, ksel, N.ptr(sel), N.ptr(sel_max), N.ptr(floor),
-               N.ptr(uop.f32), N.ptr(iop.f32), kpad, kpad, uop.d, N.ptr(user_bias), N.ptr(item_bias), item_index_base,
-               n_u, int(k), N.ptr(ov), N.ptr(oi), N.ptr(flag), N.ptr(n_flagged))
-    del pv, pi
+        N.call("trec_topk_filter_finish", N.ptr(pi), cap, ksel, N.ptr(count), N.ptr(uop.f32), N.ptr(iop.f32), kpad, kpad,
+               uop.d, N.ptr(user_bias), N.ptr(item_bias), item_index_base, n_u, int(k), N.ptr(ov), N.ptr(oi), N.ptr(flag),
+               N.ptr(n_flagged))
+    del pi
     # ---- users the filter could not certify: the exact fp32 MFMA path (one host read of a counter)
     n_bad = int(n_flagged.item())
     LAST_FILTER_STATS.clear()
-    LAST_FILTER_STATS.update({"users": n_u, "flagged_users": n_bad, "ksel": ksel})
+    LAST_FILTER_STATS.update({"users": n_u, "flagged_users": n_bad, "ksel": ksel,
+                              "kept_superblocks_per_user": float(count.sum().item()) / max(1, n_u)})
     if n_bad:
         bad = torch.nonzero(flag, as_tuple=False).reshape(-1)
         ub = user_bias[bad].contiguous() if user_bias is not None else None

@@ -140,22 +140,26 @@ class Interactions(object):
 
     def balanced_weight(self):
         """value_p / (sum of positive values of p's item)  -- loss_graphs.py:197-202, 222-224; 0 for non-positives.
-        Under a user-sharded (data-parallel) fit the per-item sums are all-reduced so they cover every user."""
-        if self._balanced_weight is None:
+        Under a user-sharded (data-parallel) fit the trainer sets ``self.dp_group = (True, group)`` and the per-item
+        sums are all-reduced over THAT group so they cover every user; in every other situation -- including item-sharded
+        inference processes that each fit the full data -- the sums are local.  Cached per mode."""
+        active, group = getattr(self, "dp_group", (False, None))
+        key = (bool(active), id(group) if active else None)
+        if self._balanced_weight is None or self._balanced_weight[0] != key:
             m = self._host
             vals = m.data.astype(np.float32)
             pos = vals > 0.0
             per_item = np.zeros(self.shape[1], np.float32)
             np.add.at(per_item, m.indices[pos], vals[pos])
-            import torch.distributed as dist
-            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            if active:
+                import torch.distributed as dist
                 t = _dev(per_item, self.device)
-                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
                 per_item = t.cpu().numpy()
             w = np.zeros(m.nnz, np.float32)
             w[pos] = vals[pos] / per_item[m.indices[pos]]
-            self._balanced_weight = _dev(w, self.device)
-        return self._balanced_weight
+            self._balanced_weight = (key, _dev(w, self.device))
+        return self._balanced_weight[1]
 
     def to_scipy(self):
         return self._host

@@ -30,8 +30,9 @@ from . import _native as N
 from .errors import (
     ModelNotBiasedException, ModelNotFitException, ModelWithoutAttentionException, BatchNonSparseInputException
 )
-from .framework import VariableStore, variable_scope, set_seed
-from .loss_graphs import AbstractLossGraph, RMSELossGraph, WMRBLossGraph, BalancedWMRBLossGraph
+from .framework import VariableStore, variable_scope, resolve_device
+from .loss_graphs import (AbstractLossGraph, RMSELossGraph, RMSEDenseLossGraph, WMRBLossGraph,
+                          BalancedWMRBLossGraph)
 from .prediction_graphs import AbstractPredictionGraph, DotProductPredictionGraph
 from .recommendation_graphs import (
     project_biases, bias_prediction_dense, bias_prediction_serial, rank_predictions,
@@ -60,6 +61,13 @@ class HostSampler(object):
 
     def __init__(self, rng=None):
         self.rng = rng if rng is not None else np.random
+
+    def __getstate__(self):
+        # the default rng is the np.random MODULE, which cannot be pickled (save_model pickles the model object)
+        return {"rng": None if self.rng is np.random else self.rng}
+
+    def __setstate__(self, state):
+        self.rng = state["rng"] if state.get("rng") is not None else np.random
 
     def sample(self, n_items, n_users, n_sampled_items, replace, step, device, user_base=0):
         pairs = sample_items(n_items, n_users, n_sampled_items, replace, rng=self.rng)
@@ -122,6 +130,24 @@ def _fingerprint(matrix):
     for a in (matrix.indptr, matrix.indices, matrix.data):
         h.update(np.ascontiguousarray(a).view(np.uint8).data)
     return (tuple(matrix.shape), int(matrix.nnz), str(matrix.data.dtype), h.hexdigest())
+
+
+def _on_model_device(method):
+    """Run a public method with the MODEL's GPU as the current device: every kernel is launched with raw pointers on
+    ``torch.cuda.current_stream()``, which belongs to the current device -- a model on cuda:1 in a process whose current
+    device is cuda:0 would otherwise launch on GPU 0 with GPU 1's pointers."""
+    import functools
+
+    @functools.wraps(method)
+    def guarded(self, *args, **kwargs):
+        if self._store is None and not torch.cuda.is_available():
+            return method(self, *args, **kwargs)            # the method itself raises (not fit / no GPU)
+        dev = self._store.device if self._store is not None else self._device()
+        if dev.type != 'cuda':
+            return method(self, *args, **kwargs)
+        with torch.cuda.device(dev):
+            return method(self, *args, **kwargs)
+    return guarded
 
 
 class TensorRec(object):
@@ -209,6 +235,7 @@ class TensorRec(object):
             raise ValueError("data_parallel=True needs seed= so that every rank starts from the same weights")
 
         self._store = None
+        self._graph_pool_owner = []
         self._capture = None          # tests set this to a dict to receive the last step's loss and raw gradients
         self._adam = {}
         self._opt_step = 0
@@ -232,7 +259,7 @@ class TensorRec(object):
     def _device(self):
         N.require_gpu()
         N.load()
-        return torch.device(self.device if self.device is not None else 'cuda')
+        return resolve_device(self.device if self.device is not None else 'cuda')
 
     @staticmethod
     def _as_list(raw_input):
@@ -431,6 +458,7 @@ class TensorRec(object):
                          epochs=epochs, learning_rate=learning_rate, alpha=alpha, verbose=verbose,
                          user_batch_size=user_batch_size, n_sampled_items=n_sampled_items, user_offset=user_offset)
 
+    @_on_model_device
     def fit_partial(self, interactions, user_features, item_features, epochs=1, learning_rate=0.1,
                     alpha=0.00001, verbose=False, user_batch_size=None, n_sampled_items=None, user_offset=0):
         """One or more epochs; one optimiser step per user batch (tensorrec/tensorrec.py:539-634).
@@ -452,10 +480,8 @@ class TensorRec(object):
             # numbers of features are learned from the first batch and cannot change (tensorrec.py:598-605)
             n_user_features = batches[0][1].shape[1]
             n_item_features = batches[0][2].shape[1]
-            if self.seed is not None:
-                set_seed(self.seed)
             self.n_user_features, self.n_item_features = int(n_user_features), int(n_item_features)
-            self._store = VariableStore(device)
+            self._store = VariableStore(device, seed=self.seed)
             if self.sampler is None:
                 self.sampler = DeviceSampler(self.seed if self.seed is not None else 0)
 
@@ -487,6 +513,7 @@ class TensorRec(object):
             inter = cached("interactions", inter_m, (uf.shape[0], itf.shape[0], user_base),
                            lambda: Interactions(inter_m, n_users=uf.shape[0], n_items=itf.shape[0], device=device))
             inter.user_base = user_base
+            inter.dp_group = (self._dp_active(), self.process_group)
             dev_batches.append((inter, uf, itf))
         self._upload_cache = used          # only what this call used stays resident
 
@@ -497,6 +524,7 @@ class TensorRec(object):
         # launch-bound steps (small batches: ~60 kernels of a few microseconds each) are captured in a HIP graph after one
         # eager execution and replayed; see _GraphedStep
         graphed = {}
+        self._graph_pool_owner = []          # graphs captured by this call (they share the first one's memory pool)
         for epoch in range(epochs):
             for batch, (inter, uf, itf) in enumerate(dev_batches):
                 step = graphed.get(batch)
@@ -541,6 +569,13 @@ class TensorRec(object):
 
     def _graph_eligible(self, inter, n_sampled_items, verbose):
         if not self.hip_graphs or self._dp_active() or self._capture is not None:
+            return False
+        # only steps made of the library's own launches are captured: the built-in capturable losses on built-in
+        # graphs.  Separation* losses index with boolean masks (a host sync inside the step) and user-defined torch
+        # graphs / losses may do anything -- capturing them would fail, warn and fall back on every fit call.
+        if type(self.loss_graph_factory) not in _GRAPH_CAPTURABLE_LOSSES or not self._is_engine_graph():
+            return False
+        if len(self._graph_pool_owner) >= MAX_GRAPHED_BATCHES:
             return False
         pairs = inter.nnz + inter.shape[0] * int(n_sampled_items or 0)
         dense = self.loss_graph_factory.is_dense
@@ -740,17 +775,20 @@ class TensorRec(object):
                 return self._dense_multi(user_reprs, attn_reprs, item_repr, user_bias, item_bias)
             return self._dense_prediction(user_reprs[0], item_repr, user_bias, item_bias)
 
+    @_on_model_device
     def predict(self, user_features, item_features):
         """Recommendation scores, ndarray [n_users, n_items] float32 (tensorrec.py:636-664)."""
         self._check_fit('predict')
         return _to_host(self._predict_device(user_features, item_features))
 
+    @_on_model_device
     def predict_rank(self, user_features, item_features):
         """Recommendation ranks, ndarray [n_users, n_items] int32, 1 = best (tensorrec.py:705-733)."""
         self._check_fit('predict_rank')
         pred = self._predict_device(user_features, item_features)
         return _to_host(rank_predictions(pred))
 
+    @_on_model_device
     def predict_rank_of_interactions(self, user_features, item_features, interactions, user_batch_size=None):
         """EXTENSION: the ranks ``predict_rank`` would give, but only at the positive entries of ``interactions`` --
         all the evaluation metrics need (eval.py multiplies the [n_users, n_items] rank matrix by the positive mask).
@@ -807,6 +845,7 @@ class TensorRec(object):
                 ranks[p0:p1] = r.cpu().numpy()
         return PairRanks(rows, ranks, vals, n_users)
 
+    @_on_model_device
     def predict_top_k(self, user_features, item_features, k=10, user_batch_size=65536, return_device=False,
                       item_sharded=False, item_offset=0):
         """EXTENSION: the k best items per user -- (scores [n_users, k] float32, item ids [n_users, k] int32),
@@ -883,6 +922,7 @@ class TensorRec(object):
             return vals, idx
         return _to_host(vals), _to_host(idx)
 
+    @_on_model_device
     def predict_similar_items(self, item_features, item_ids, n_similar):
         """Most similar items, list of lists of (item_id, score) (tensorrec.py:666-703); the query item itself is
         included, as in the reference."""
@@ -901,6 +941,7 @@ class TensorRec(object):
             results.append(item_results)
         return results
 
+    @_on_model_device
     def predict_user_representation(self, user_features):
         """ndarray [n_users, n_components], or [n_tastes, n_users, n_components] when n_tastes > 1
         (tensorrec.py:735-762)."""
@@ -911,6 +952,7 @@ class TensorRec(object):
         user_repr = _to_host(torch.stack(user_reprs))
         return user_repr[0] if self.n_tastes == 1 else user_repr
 
+    @_on_model_device
     def predict_user_attention_representation(self, user_features):
         """ndarray [n_tastes, n_users, n_components] (tensorrec.py:764-793)."""
         self._check_fit('predict_user_attention_representation')
@@ -921,6 +963,7 @@ class TensorRec(object):
             _, attn_reprs, _ = self._user_representations(uf)
         return _to_host(torch.stack(attn_reprs))
 
+    @_on_model_device
     def predict_item_representation(self, item_features):
         """ndarray [n_items, n_components] (tensorrec.py:795-816)."""
         self._check_fit('predict_item_representation')
@@ -931,6 +974,7 @@ class TensorRec(object):
                 node_name_ending='item')
         return _to_host(item_repr)
 
+    @_on_model_device
     def predict_user_bias(self, user_features):
         """ndarray [n_users] (tensorrec.py:818-842)."""
         self._check_fit('predict_user_bias')
@@ -941,6 +985,7 @@ class TensorRec(object):
             _, proj = project_biases(uf, self.n_user_features, name='user_feature_biases')
         return proj.cpu().numpy()
 
+    @_on_model_device
     def predict_item_bias(self, item_features):
         """ndarray [n_items] (tensorrec.py:844-868)."""
         self._check_fit('predict_item_bias')
@@ -952,12 +997,14 @@ class TensorRec(object):
         return proj.cpu().numpy()
 
     # ------------------------------------------------------------------------------------------ weights access
+    @_on_model_device
     def get_weights(self):
         """name -> ndarray copy of every variable (EXTENSION; used by the parity tests to share weights with the
         oracle, since the reference exposes no seed)."""
         self._check_fit('get_weights')
         return {k: v.detach().cpu().numpy().copy() for k, v in self._store.variables.items()}
 
+    @_on_model_device
     def set_weights(self, weights, reset_optimizer=True):
         self._check_fit('set_weights')
         for k, arr in weights.items():
@@ -976,12 +1023,14 @@ class TensorRec(object):
         state['_store'] = None
         state['_adam'] = {}
         state['_capture'] = None
+        state['_graph_pool_owner'] = []
         state['_schedule'] = None
         state['_schedule_mirror'] = None
         state['_upload_cache'] = {}
         state['process_group'] = None
         return state
 
+    @_on_model_device
     def save_model(self, directory_path):
         """Saves the model to files in the given directory (tensorrec.py:869-893): ``tensorrec.pkl`` (the python
         object: hyper-parameters and graph objects) and ``tensorrec_session.npz`` (every variable, its Adam slots and
@@ -1009,9 +1058,10 @@ class TensorRec(object):
         with open(os.path.join(directory_path, 'tensorrec.pkl'), 'rb') as file:
             model = pickle.load(file=file)
         device = model._device()
-        with np.load(os.path.join(directory_path, 'tensorrec_session.npz'), allow_pickle=False) as ckpt:
+        with np.load(os.path.join(directory_path, 'tensorrec_session.npz'), allow_pickle=False) as ckpt, \
+                torch.cuda.device(device):
             names = [str(n) for n in ckpt['names']]
-            model._store = VariableStore(device)
+            model._store = VariableStore(device, seed=model.seed)
             for i, name in enumerate(names):
                 model._store.get(name, ckpt['var/%d' % i])
                 if 'adam_m/%d' % i in ckpt.files:
@@ -1020,15 +1070,14 @@ class TensorRec(object):
             model._opt_step, model._sample_step = (int(c) for c in ckpt['counters'])
         return model
 
+    @_on_model_device
     def build(self, n_user_features, n_item_features):
         """EXTENSION: create the variables without a training step (weights then come from set_weights or the
         initialisers); fit_partial does this implicitly on its first call."""
         device = self._device()
         if self._store is None:
-            if self.seed is not None:
-                set_seed(self.seed)
             self.n_user_features, self.n_item_features = int(n_user_features), int(n_item_features)
-            self._store = VariableStore(device)
+            self._store = VariableStore(device, seed=self.seed)
             if self.sampler is None:
                 self.sampler = DeviceSampler(self.seed if self.seed is not None else 0)
             uf = SparseFeatures(sp.csr_matrix((1, n_user_features), dtype=np.float32), device)
@@ -1036,6 +1085,10 @@ class TensorRec(object):
             with torch.no_grad(), variable_scope(self._store):
                 self._representations(uf, itf)
         return self
+
+
+_GRAPH_CAPTURABLE_LOSSES = (RMSELossGraph, RMSEDenseLossGraph, WMRBLossGraph, BalancedWMRBLossGraph)
+MAX_GRAPHED_BATCHES = 64        # graphs kept alive by one fit call; further batches run eagerly
 
 
 class _GraphedStep(object):
@@ -1064,7 +1117,11 @@ class _GraphedStep(object):
                 var.grad = None
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            # every graph of one fit call shares ONE memory pool (the batches run one after the other, so their
+            # temporaries can alias) instead of pinning a private copy of every forward/backward temporary per batch
+            owner = model._graph_pool_owner
+            pool = owner[0].pool() if owner else None
+            with torch.cuda.graph(self.graph, pool=pool):
                 ops.adam_schedule_advance(state, learning_rate, ADAM_BETA1, ADAM_BETA2, bump_sample_step=sample_based)
                 samples = self.samples
                 if self.device_sampler:
@@ -1087,6 +1144,7 @@ class _GraphedStep(object):
             for var in store.variables.values():
                 var.grad = None
             self.sample_based = sample_based
+            owner.append(self.graph)
             return self
         except Exception as exc:      # capture is an optimisation: fall back to eager steps for this batch
             logging.warning('HIP graph capture of the training step failed (%r); running eagerly', exc)

@@ -79,14 +79,12 @@ def _eps_of(ops, uop, iop, ub, kpad):
     """eps_u as the floor kernel computes it: floor = pred(pred(0 - 2 eps))."""
     n_u = uop.n
     tau = torch.zeros((n_u,), dtype=torch.float32, device="cuda")
-    sel = torch.zeros((n_u, 1), dtype=torch.int32, device="cuda")
-    sel_max = torch.full((1, n_u), -np.inf, dtype=torch.float32, device="cuda")
     floor = torch.empty((n_u,), dtype=torch.float32, device="cuda")
     flag = torch.empty((n_u,), dtype=torch.int32, device="cuda")
     nf = torch.zeros((1,), dtype=torch.int32, device="cuda")
     N = ops.N
-    N.call("trec_topk_filter_floor", N.ptr(tau), N.ptr(uop.stats), N.ptr(ub), N.ptr(iop.gstats), kpad, N.ptr(sel),
-           N.ptr(sel_max), 1, 1, n_u, N.ptr(floor), N.ptr(flag), N.ptr(nf))
+    N.call("trec_topk_filter_floor", N.ptr(tau), N.ptr(uop.stats), N.ptr(ub), N.ptr(iop.gstats), kpad, n_u, N.ptr(floor),
+           N.ptr(flag), N.ptr(nf))
     return (-floor / 2).cpu().numpy()
 
 

@@ -8,6 +8,7 @@ import torch
 
 from oracle import oracle as O
 from oracle.model import OracleTensorRec
+from parity_util import check_weights_after_adam
 
 pytestmark = pytest.mark.gpu
 
@@ -110,14 +111,16 @@ def test_fit_steps_match_oracle(user_repr, item_repr, pred, loss, biased, d):
                 assert got_g is not None and got_g.shape == ref.shape, k
                 assert np.abs(got_g - ref).max() <= 1e-4 * gmax, "%s: grad diff %g (gmax %g)" % (
                     k, np.abs(got_g - ref).max(), gmax)
+            grads0_gpu, grads0_ref = dict(cap['grads']), grads
         oracle.step(inter, uf, itf, 0.05, 1e-4, tables[t] if tables else None)
     got = model.get_weights()
-    for k, ref in _rename(oracle.weights).items():
-        assert got[k].shape == ref.shape, k
-        # Adam turns a gradient into a step of ~lr whatever its size, so zero-in-exact-arithmetic gradients move by
-        # lr * noise/|noise|-like amounts; 10% of one step (0.1 * lr) is the bar after 3 steps, an upstream sign or
-        # scale error would show up as O(lr) = 0.05 per step
-        assert np.allclose(got[k], ref, rtol=2e-3, atol=5e-3), "%s: max abs diff %g" % (k, np.abs(got[k] - ref).max())
+    # tests/parity_util.py: 1e-4 * lr per step wherever the first-step gradient stands clear of the fp32 summation
+    # noise, proportionally looser below (Adam steps by ~lr * g / |g|).  Exempt -- gradient provably ZERO in exact
+    # arithmetic: user_feature_biases under WMRB / BalancedWMRB (b_u cancels inside every hinge 1 - y_ui + y_us).
+    exempt = ("user_feature_biases",) if "wmrb" in loss else ()
+    rep = check_weights_after_adam(got, _rename(oracle.weights), grads0_gpu, _rename(grads0_ref), 0.05, steps,
+                                   exempt=exempt, label="%s/%s/%s/%s" % (user_repr, item_repr, pred, loss))
+    print("weights after %d steps (max |dw|, share beyond 1e-4 lr/step): %s" % (steps, rep))
     p_gpu = model.predict(uf, itf)
     p_ref = oracle.predict(uf, itf)
     assert np.abs(p_gpu - p_ref).max() <= 2e-2 * max(1.0, np.abs(p_ref).max())

@@ -173,7 +173,8 @@ def test_no_oracle_in_product():
 
 def test_bench_cpu_baseline_leg_and_defaults(monkeypatch):
     """bench.py's cpu_baseline leg (the oracle timed on the host cores) on a tiny sample: the keys the measurement
-    contract names; the argument defaults are the BASELINE.json configuration (1M x 1M, d = 128, bf16, top-10, N = 1)."""
+    contract names; the argument defaults are the BASELINE.json configuration (1M x 1M, d = 128, top-10, N = 1) in the
+    exact mode (fp32 results through the bf16 MFMA filter)."""
     import sys
     import bench
     out = bench.cpu_baseline(n_items=3000, d=16, k=5, n_users_sample=64)
@@ -181,7 +182,7 @@ def test_bench_cpu_baseline_leg_and_defaults(monkeypatch):
     assert out["kind"] == "port" and out["unit"] == "predictions/s" and out["value"] > 0 and out["cores"] >= 1
     monkeypatch.setattr(sys, "argv", ["bench.py"])
     a = bench.parse()
-    assert (a.gpus, a.users, a.items, a.components, a.k, a.precision) == (1, 1_000_000, 1_000_000, 128, 10, "bf16")
+    assert (a.gpus, a.users, a.items, a.components, a.k, a.precision) == (1, 1_000_000, 1_000_000, 128, 10, "exact")
     assert a.steps >= 1 and a.warmup >= 0
 
 
@@ -204,3 +205,26 @@ def test_upload_fingerprint_and_split_policies():
     assert ops._prefer_split(50, 1 << 20) and not ops._prefer_split(48, 1 << 20) and not ops._prefer_split(50, 1000)
     assert ops._sampled_buckets_long(2_000_000, 10) and ops._sampled_buckets_long(1 << 20, 1 << 20)
     assert not ops._sampled_buckets_long(100_000, 1000)
+
+
+def test_seeded_store_draws_one_stream_per_model():
+    """every initialiser draw of a seeded model continues ONE generator (equally shaped weights must start
+    different), two models with the same seed start identical, and a seed never leaks into an unseeded model."""
+    import torch
+    from tensorrec_amd import framework as F
+    a, b = F.VariableStore("cpu", seed=3), F.VariableStore("cpu", seed=3)
+    with F.variable_scope(a):
+        a1, a2 = F.random_normal([7, 5]), F.random_normal([7, 5])
+    with F.variable_scope(b):
+        b1 = F.random_normal([7, 5])
+    assert not torch.equal(a1, a2) and torch.equal(a1, b1)
+    assert F.VariableStore("cpu").generator() is None
+    assert F.resolve_device("cpu") == torch.device("cpu")
+
+
+def test_host_sampler_pickles():
+    import pickle
+    s = pickle.loads(pickle.dumps(T.HostSampler()))
+    assert s.rng is np.random
+    r = pickle.loads(pickle.dumps(T.HostSampler(np.random.RandomState(5))))
+    assert isinstance(r.rng, np.random.RandomState)
