@@ -250,6 +250,31 @@ int trec_group_pairs_by_item(const int32_t* xu, const int32_t* xi, int64_t n_pai
  * rank_predictions, recommendation_graphs.py:73-82 (double tf.nn.top_k) as an exact count; int32, 1 = best. */
 int trec_rank_rows(const float* scores, int64_t n_users, int64_t n_items, int64_t ld_scores, int32_t* ranks,
                    int64_t ld_ranks, void* stream);
+/* The same ranks for rows of more than 32768 items: the row is sorted in 32768-item chunks (one workgroup each, LDS) and
+ * every item adds, for each OTHER chunk, the number of that chunk's items that beat it -- a binary search in the chunk's
+ * sorted keys (ties go to the lower chunk, so no index data is needed across chunks).  workspace:
+ * trec_rank_rows_workspace_bytes(n_users, n_items) bytes, 16-byte aligned; n_users <= 65535 per call. */
+int64_t trec_rank_rows_workspace_bytes(int64_t n_users, int64_t n_items);
+int trec_rank_rows_chunked(const float* scores, int64_t n_users, int64_t n_items, int64_t ld_scores, int32_t* ranks,
+                           int64_t ld_ranks, void* workspace, int64_t workspace_bytes, void* stream);
+/* K2r -- ranks of selected pairs WITHOUT a score slab (csrc/score_rank.hip): the count of rank_predictions
+ * (recommendation_graphs.py:73-82) as the epilogue of the fp32 MFMA score kernel.  users_f32 / items_f32: fp32 operands
+ * [n, kpad] (trec_score_prep, dtype fp32).  Resident row r scores operand row row_user[r] and counts, for each of its
+ * row_tn[r] <= trec_score_rankcount_max_targets() targets (tgt_item / tgt_score [row_t0[r] ...]; item ids are global:
+ * local row + item_index_base), the items of THIS call's item range that beat it: counts[t] += #{j : s_j > t or
+ * (s_j == t and j < item_t)}.  counts must be zero-initialised; item shards add their counts (all-reduce SUM) and the
+ * rank is count + 1.  tgt_score must be the exact score of the pair: trec_pair_score_exact (the same k-ordered fmaf
+ * chain, (s + b_u) + b_i, Euclidean transform of prediction_graphs.py:84-100 in mode 1).  n_chunks <= 0: automatic. */
+int trec_score_rankcount_max_targets(void);
+int trec_pair_score_exact(const float* users_f32, const float* items_f32, int64_t ld, int32_t kdim, const int32_t* xu,
+                          const int32_t* xi, int64_t n_pairs, const float* user_bias, const float* item_bias,
+                          int32_t mode, const float* user_sqnorm, const float* item_sqnorm, int32_t item_index_base,
+                          float* out, void* stream);
+int trec_score_gemm_rankcount(const float* users_f32, const float* items_f32, int32_t kpad, int64_t n_rows,
+                              int64_t n_items, int32_t item_index_base, const float* user_bias, const float* item_bias,
+                              int32_t mode, const float* user_sqnorm, const float* item_sqnorm, const int32_t* row_user,
+                              const int32_t* row_t0, const int32_t* row_tn, const int32_t* tgt_item,
+                              const float* tgt_score, int32_t n_chunks, int32_t* counts, void* stream);
 /* partial rank counts of selected (user, item) pairs over item columns [begin, end) of a score slab whose first
  * column is global item `col_offset`; item shards sum their counts (add_one on exactly one of them) */
 int trec_rank_of_pairs(const float* scores, int64_t ld_scores, int64_t col_offset, int64_t begin, int64_t end,

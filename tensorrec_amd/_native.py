@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libtensorrec_hip.so")
 _vp, _i32, _i64, _u32, _u64, _f = (ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32,
                                    ctypes.c_uint64, ctypes.c_float)
 
-_RETURNS_I64 = ("trec_csr_split_workspace_bytes",)      # sizing queries that return a byte count
+_RETURNS_I64 = ("trec_csr_split_workspace_bytes", "trec_rank_rows_workspace_bytes")      # sizing queries that return a byte count
 
 # name -> argtypes, in the order of include/tensorrec_hip.h
 SIGNATURES = {
@@ -70,6 +70,12 @@ SIGNATURES = {
     "trec_pair_score_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
     "trec_group_pairs_by_item": [_vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp],
     "trec_rank_rows": [_vp, _i64, _i64, _i64, _vp, _i64, _vp],
+    "trec_rank_rows_workspace_bytes": [_i64, _i64],
+    "trec_rank_rows_chunked": [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp],
+    "trec_score_rankcount_max_targets": [],
+    "trec_pair_score_exact": [_vp, _vp, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp],
+    "trec_score_gemm_rankcount": [_vp, _vp, _i32, _i64, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                  _i32, _vp, _vp],
     "trec_rank_of_pairs": [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _i32, _vp, _vp],
     "trec_rank_of_pairs_by_user": [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp],
     "trec_wmrb_fwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp],

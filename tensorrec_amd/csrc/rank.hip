@@ -167,6 +167,140 @@ __global__ __launch_bounds__(1024) void rank_rows_sorted_kernel(const float* __r
     }
 }
 
+// ---- rows longer than RANK_SORT_MAX: sorted CHUNKS ---------------------------------------------------------------
+// rank[i] - 1 = sum over chunks c of #{j in c : j beats i}.  Inside i's own chunk that is the sorted-chunk position
+// (ties through the (class, index) list, as above).  For another chunk the index order is decided by the chunk order
+// alone -- every item of a LOWER chunk wins a tie, none of a HIGHER chunk does -- so the count is NP_c - lower_bound(k)
+// resp. NP_c - upper_bound(k) in that chunk's sorted keys: no index data, no 64-bit keys.
+//   pass A  rank_chunk_sort_kernel   grid (chunks, users): sort the chunk's keys in LDS, write the in-chunk ranks and the
+//           sorted keys (workspace [users][chunks][RANK_SORT_MAX]); a chunk with > RANK_TIE_CAP tied items flags its row;
+//   pass B  rank_chunk_merge_kernel  grid (chunks, users): the chunk's items (32 per thread, keys in registers) binary-
+//           search every OTHER chunk of the row, staged through LDS one chunk at a time; flagged rows are set to -1
+//           and recounted by rank_rows_kernel<true>.
+__device__ __forceinline__ int rank_chunk_np(int64_t n_items, int c)
+{
+    const int64_t left = n_items - (int64_t)c * RANK_SORT_MAX;
+    const int len = left < RANK_SORT_MAX ? (int)left : RANK_SORT_MAX;
+    int NP = 64;
+    while (NP < len) NP <<= 1;
+    return NP;
+}
+
+__global__ __launch_bounds__(1024) void rank_chunk_sort_kernel(const float* __restrict__ scores, int64_t n_items, int64_t ld,
+                                                              int32_t* __restrict__ ranks, int64_t ld_out,
+                                                              uint32_t* __restrict__ ws_keys, int n_chunks,
+                                                              int32_t* __restrict__ heavy)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t rank_sh[];
+    const int c = blockIdx.x;
+    const int64_t u = blockIdx.y;
+    const int NP = rank_chunk_np(n_items, c);
+    const int64_t i0 = (int64_t)c * RANK_SORT_MAX;
+    const int len = (n_items - i0 < RANK_SORT_MAX) ? (int)(n_items - i0) : RANK_SORT_MAX;
+    uint32_t* keys = rank_sh;
+    unsigned long long* ties = (unsigned long long*)(rank_sh + RANK_SORT_MAX);
+    int* n_ties = (int*)(ties + RANK_TIE_CAP);
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const float* row = scores + u * ld + i0;
+    int32_t* out = ranks + u * ld_out + i0;
+    for (int q = tid; q < NP; q += nt) keys[q] = q < len ? rank_key(row[q]) : 0u;
+    if (tid == 0) *n_ties = 0;
+    __syncthreads();
+    bitonic_sort_lds(keys, NP, tid, nt);
+    uint32_t* wsk = ws_keys + ((int64_t)u * n_chunks + c) * RANK_SORT_MAX;
+    for (int q = tid; q < NP; q += nt) wsk[q] = keys[q];
+    for (int i = tid; i < len; i += nt) {
+        const uint32_t k = rank_key(row[i]);
+        int lo = 0, hi = NP;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (keys[mid] <= k) lo = mid + 1; else hi = mid;
+        }
+        if (lo >= 2 && keys[lo - 2] == k) {
+            const int slot = atomicAdd(n_ties, 1);
+            if (slot < RANK_TIE_CAP) ties[slot] = ((unsigned long long)(uint32_t)lo << 32) | (uint32_t)i;
+        } else {
+            out[i] = 1 + NP - lo;
+        }
+    }
+    __syncthreads();
+    const int T = *n_ties;
+    if (T == 0) return;
+    if (T > RANK_TIE_CAP) {
+        if (tid == 0) heavy[u] = 1;
+        return;
+    }
+    int TP = 2;
+    while (TP < T) TP <<= 1;
+    for (int q = T + tid; q < TP; q += nt) ties[q] = ~0ull;
+    __syncthreads();
+    bitonic_sort_lds(ties, TP, tid, nt);
+    for (int p = tid; p < T; p += nt) {
+        const unsigned long long e = ties[p];
+        const unsigned long long cls = e & 0xffffffff00000000ull;
+        int lo = 0, hi = p;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (ties[mid] < cls) lo = mid + 1; else hi = mid;
+        }
+        out[(uint32_t)e] = 1 + NP - (int)(e >> 32) + (p - lo);
+    }
+}
+
+#define RANK_MERGE_Q (RANK_SORT_MAX / 1024)      // query items per thread
+__global__ __launch_bounds__(1024) void rank_chunk_merge_kernel(const float* __restrict__ scores, int64_t n_items,
+                                                               int64_t ld, int32_t* __restrict__ ranks, int64_t ld_out,
+                                                               const uint32_t* __restrict__ ws_keys, int n_chunks,
+                                                               const int32_t* __restrict__ heavy)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t rank_sh[];
+    const int own = blockIdx.x;
+    const int64_t u = blockIdx.y;
+    const int64_t i0 = (int64_t)own * RANK_SORT_MAX;
+    const int len = (n_items - i0 < RANK_SORT_MAX) ? (int)(n_items - i0) : RANK_SORT_MAX;
+    const int tid = threadIdx.x;
+    int32_t* out = ranks + u * ld_out + i0;
+    if (heavy[u]) {                                           // recounted by rank_rows_kernel<true>
+        for (int i = tid; i < len; i += 1024) out[i] = -1;
+        return;
+    }
+    const float* row = scores + u * ld + i0;
+    uint32_t qk[RANK_MERGE_Q];
+    int add[RANK_MERGE_Q];
+#pragma unroll
+    for (int e = 0; e < RANK_MERGE_Q; ++e) {
+        const int i = tid + 1024 * e;
+        qk[e] = i < len ? rank_key(row[i]) : 0xffffffffu;
+        add[e] = 0;
+    }
+    for (int c = 0; c < n_chunks; ++c) {
+        if (c == own) continue;
+        const int NP = rank_chunk_np(n_items, c);
+        const uint32_t* wsk = ws_keys + ((int64_t)u * n_chunks + c) * RANK_SORT_MAX;
+        __syncthreads();
+        for (int q = tid * 4; q < NP; q += 4096) *(u32x4*)(rank_sh + q) = *(const u32x4*)(wsk + q);
+        __syncthreads();
+        const bool lower = c < own;                           // items of a lower chunk win ties
+#pragma unroll
+        for (int e = 0; e < RANK_MERGE_Q; ++e) {
+            const uint32_t k = qk[e];
+            int lo = 0, hi = NP;                              // lower: first pos with key >= k;  else: first pos with key > k
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                const uint32_t v = rank_sh[mid];
+                const bool right = lower ? (v < k) : (v <= k);
+                if (right) lo = mid + 1; else hi = mid;
+            }
+            add[e] += NP - lo;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < RANK_MERGE_Q; ++e) {
+        const int i = tid + 1024 * e;
+        if (i < len) out[i] += add[e];
+    }
+}
+
 // one wave per (user, item) pair; counts over items [begin, end) of the user's score row.
 // out[p] (+)= count  (+1 added by the caller once all shards are summed, or here when add_one != 0)
 __global__ __launch_bounds__(256) void rank_of_pairs_kernel(const float* __restrict__ scores, int64_t ld,
@@ -279,6 +413,50 @@ extern "C" int trec_rank_rows(const float* scores, int64_t n_users, int64_t n_it
                                ld_scores, ranks + u0 * ld_ranks, ld_ranks);
     }
     return trec_check_launch("trec_rank_rows");
+}
+
+// workspace of trec_rank_rows_chunked for a slab of n_users rows: sorted keys of every chunk + one flag per row
+extern "C" int64_t trec_rank_rows_workspace_bytes(int64_t n_users, int64_t n_items)
+{
+    if (n_items <= RANK_SORT_MAX) return 0;
+    const int64_t n_chunks = ceil_div64(n_items, RANK_SORT_MAX);
+    return n_users * n_chunks * RANK_SORT_MAX * 4 + n_users * 4;
+}
+
+// rows of more than RANK_SORT_MAX items: sorted chunks + cross-chunk binary searches (see above)
+extern "C" int trec_rank_rows_chunked(const float* scores, int64_t n_users, int64_t n_items, int64_t ld_scores,
+                                      int32_t* ranks, int64_t ld_ranks, void* workspace, int64_t workspace_bytes,
+                                      void* stream)
+{
+    TREC_REQUIRE(scores && ranks && workspace, "trec_rank_rows_chunked: null pointer");
+    TREC_REQUIRE(ld_scores >= n_items && ld_ranks >= n_items, "trec_rank_rows_chunked: leading dimension < n_items");
+    TREC_REQUIRE(n_items > RANK_SORT_MAX && n_users <= 65535, "trec_rank_rows_chunked: need n_items > 32768, n_users <= 65535");
+    TREC_REQUIRE(workspace_bytes >= trec_rank_rows_workspace_bytes(n_users, n_items), "trec_rank_rows_chunked: workspace too small");
+    TREC_REQUIRE(((uintptr_t)workspace % 16) == 0, "trec_rank_rows_chunked: workspace must be 16-byte aligned");
+    if (n_users == 0) return TREC_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int n_chunks = (int)ceil_div64(n_items, RANK_SORT_MAX);
+    uint32_t* ws_keys = (uint32_t*)workspace;
+    int32_t* heavy = (int32_t*)(ws_keys + n_users * n_chunks * (int64_t)RANK_SORT_MAX);
+    if (hipMemsetAsync(heavy, 0, sizeof(int32_t) * (size_t)n_users, st) != hipSuccess) {
+        trec_set_last_error("trec_rank_rows_chunked: memset failed");
+        return TREC_ERR_LAUNCH;
+    }
+    const size_t lds_a = (size_t)RANK_SORT_MAX * 4 + RANK_TIE_CAP * 8 + 16, lds_b = (size_t)RANK_SORT_MAX * 4;
+    if (hipFuncSetAttribute((const void*)rank_chunk_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a) != hipSuccess ||
+        hipFuncSetAttribute((const void*)rank_chunk_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b) != hipSuccess) {
+        (void)hipGetLastError();
+        trec_set_last_error("trec_rank_rows_chunked: cannot reserve the LDS");
+        return TREC_ERR_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL(rank_chunk_sort_kernel, dim3((unsigned)n_chunks, (unsigned)n_users), dim3(1024), lds_a, st, scores,
+                       n_items, ld_scores, ranks, ld_ranks, ws_keys, n_chunks, heavy);
+    hipLaunchKernelGGL(rank_chunk_merge_kernel, dim3((unsigned)n_chunks, (unsigned)n_users), dim3(1024), lds_b, st, scores,
+                       n_items, ld_scores, ranks, ld_ranks, ws_keys, n_chunks, heavy);
+    const unsigned bx = (unsigned)ceil_div64(n_items, RANK_TGT);
+    hipLaunchKernelGGL(rank_rows_kernel<true>, dim3(bx, (unsigned)n_users), dim3(256), 0, st, scores, n_items, ld_scores,
+                       ranks, ld_ranks);
+    return trec_check_launch("trec_rank_rows_chunked");
 }
 
 extern "C" int trec_rank_of_pairs(const float* scores, int64_t ld_scores, int64_t col_offset, int64_t begin,

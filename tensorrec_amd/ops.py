@@ -957,12 +957,78 @@ def topk_merge(cand_vals, cand_idx, k):
     return ov, oi
 
 
+RANK_SORT_MAX = 32768            # csrc/rank.hip: the longest row one workgroup sorts in LDS
+
+
 def rank_rows(scores):
+    """rank_predictions (recommendation_graphs.py:73-82) of a score slab [n_users, n_items] -> int32 ranks, 1 = best,
+    ties to the lower index.  Rows up to 32768 items are sorted in LDS by one workgroup; longer rows are sorted in
+    32768-item chunks and every item binary-searches the other chunks (trec_rank_rows_chunked)."""
     scores = _f32c(scores)
+    n_u, n_i = scores.shape
     ranks = torch.empty(scores.shape, dtype=torch.int32, device=scores.device)
-    N.call("trec_rank_rows", N.ptr(scores), scores.shape[0], scores.shape[1], scores.stride(0), N.ptr(ranks),
-           ranks.stride(0))
+    if n_i > RANK_SORT_MAX and n_u > 0 and N.load().trec_get_tuning(b"rank_chunked", 1):
+        per_user = N.query("trec_rank_rows_workspace_bytes", 1, n_i)
+        slab = int(max(1, min(65535, (4 << 30) // per_user, n_u)))
+        nbytes = N.query("trec_rank_rows_workspace_bytes", slab, n_i)
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=scores.device)
+        for s in range(0, n_u, slab):
+            e = min(s + slab, n_u)
+            with _timed("rank_rows_chunked"):
+                N.call("trec_rank_rows_chunked", N.ptr(scores[s:e]), e - s, n_i, scores.stride(0), N.ptr(ranks[s:e]),
+                       ranks.stride(0), N.ptr(ws), nbytes)
+        return ranks
+    N.call("trec_rank_rows", N.ptr(scores), n_u, n_i, scores.stride(0), N.ptr(ranks), ranks.stride(0))
     return ranks
+
+
+def pair_scores_exact(users_f32, items_f32, kpad, d, xu32, xi32, user_bias=None, item_bias=None, mode=MODE_DOT,
+                      user_sq=None, item_sq=None, item_index_base=0):
+    """Exact fp32 scores of (user row, GLOBAL item id) pairs: the k-ordered fmaf chain of the fp32 MFMA kernels and of the
+    oracle, biases / Euclidean transform in the reference's order (trec_pair_score_exact)."""
+    n_pairs = int(xi32.numel())
+    out = torch.empty((n_pairs,), dtype=torch.float32, device=users_f32.device)
+    N.call("trec_pair_score_exact", N.ptr(users_f32), N.ptr(items_f32), kpad, int(d), N.ptr(xu32), N.ptr(xi32), n_pairs,
+           N.ptr(user_bias), N.ptr(item_bias), mode, N.ptr(user_sq), N.ptr(item_sq), int(item_index_base), N.ptr(out))
+    return out
+
+
+def rank_counts_fused(users_f32, items_f32, kpad, d, pair_indptr, xi32, user_bias=None, item_bias=None, mode=MODE_DOT,
+                      user_sq=None, item_sq=None, item_index_base=0, n_chunks=0, target_scores=None):
+    """Partial rank counts of pairs grouped by user, with NO score slab (csrc/score_rank.hip): the exact fp32 MFMA score
+    tile is compared with the users' targets in registers.  ``users_f32`` / ``items_f32``: fp32 operands [n, kpad] from
+    score_prep; ``pair_indptr``: host int64 [n_users + 1]; ``xi32``: device int32 [n_pairs] GLOBAL item ids of the pairs,
+    sorted by user.  Returns int32 [n_pairs] counts over this call's items (rank = count + 1 once every item shard's
+    counts are summed).  Users with more than 32 targets occupy several resident rows.  ``target_scores``: the pairs'
+    exact scores when this call's items are a shard that does not hold every target (the owning shard computes them
+    with pair_scores_exact); default: computed here from the operands."""
+    import numpy as np
+    dev = users_f32.device
+    n_pairs = int(xi32.numel())
+    counts = torch.zeros((n_pairs,), dtype=torch.int32, device=dev)
+    if n_pairs == 0:
+        return counts
+    qmax = N.query("trec_score_rankcount_max_targets")
+    indptr = np.asarray(pair_indptr, dtype=np.int64)
+    per_user = np.diff(indptr)
+    rows_per_user = -(-per_user // qmax)
+    row_user = np.repeat(np.arange(len(per_user), dtype=np.int64), rows_per_user)
+    first_row = np.concatenate([[0], np.cumsum(rows_per_user)[:-1]])
+    j = np.arange(len(row_user), dtype=np.int64) - first_row[row_user]            # group number inside the user
+    row_t0 = indptr[row_user] + qmax * j
+    row_tn = np.minimum(qmax, per_user[row_user] - qmax * j)
+    xu32 = torch.from_numpy(np.repeat(np.arange(len(per_user), dtype=np.int32), per_user)).to(dev)
+    row_user_d = torch.from_numpy(row_user.astype(np.int32)).to(dev)
+    row_t0_d = torch.from_numpy(row_t0.astype(np.int32)).to(dev)
+    row_tn_d = torch.from_numpy(row_tn.astype(np.int32)).to(dev)
+    tgt = target_scores if target_scores is not None else \
+        pair_scores_exact(users_f32, items_f32, kpad, d, xu32, xi32, user_bias, item_bias, mode, user_sq, item_sq,
+                          item_index_base)
+    with _timed("score_gemm_rankcount"):
+        N.call("trec_score_gemm_rankcount", N.ptr(users_f32), N.ptr(items_f32), kpad, len(row_user), items_f32.shape[0],
+               int(item_index_base), N.ptr(user_bias), N.ptr(item_bias), mode, N.ptr(user_sq), N.ptr(item_sq),
+               N.ptr(row_user_d), N.ptr(row_t0_d), N.ptr(row_tn_d), N.ptr(xi32), N.ptr(tgt), int(n_chunks), N.ptr(counts))
+    return counts
 
 
 def rank_of_pairs(scores, col_offset, begin, end, xu32, xi32, target_scores, add_one=True):

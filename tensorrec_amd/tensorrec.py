@@ -815,8 +815,28 @@ class TensorRec(object):
         device = self._store.device
         ranks = np.zeros(len(rows), np.int32)
         bounds = np.searchsorted(rows, np.arange(0, n_users + user_batch_size, user_batch_size))
+        # one taste, built-in prediction graph, fp32: no slab at all -- the count is the epilogue of the fp32 MFMA score
+        # kernel (csrc/score_rank.hip), the targets' exact scores come from the same fmaf chain
+        fused = (self._is_engine_graph() and not self._multi() and self.precision == 'fp32' and len(rows) > 0 and
+                 self.n_components <= 256 and N.load().trec_get_tuning(b"rank_fused", 1) != 0)
         with torch.no_grad(), variable_scope(self._store):
             user_reprs, attn_reprs, item_repr, user_bias, item_bias, _ = self._representations(uf, itf)
+            if fused:
+                graph = self.prediction_graph_factory
+                want_sq = graph.engine_mode == ops.MODE_EUCLIDEAN
+                u_op, u_sq, kpad = ops.score_prep(user_reprs[0], ops.DTYPE_F32, normalize=graph.engine_normalize,
+                                                  want_sqnorm=want_sq)
+                i_op, i_sq, _ = ops.score_prep(item_repr, ops.DTYPE_F32, normalize=graph.engine_normalize,
+                                               want_sqnorm=want_sq)
+                if want_sq and u_op.shape[1] != kpad:          # (score_prep returns the representation itself when d == kpad)
+                    raise RuntimeError("score_prep returned an unpadded operand")
+                pair_indptr = np.searchsorted(rows, np.arange(n_users + 1)).astype(np.int64)
+                counts = ops.rank_counts_fused(u_op, i_op, kpad, user_reprs[0].shape[1], pair_indptr,
+                                               torch.from_numpy(np.ascontiguousarray(cols)).to(device),
+                                               user_bias.contiguous() if self.biased else None,
+                                               item_bias.contiguous() if self.biased else None, graph.engine_mode,
+                                               u_sq, i_sq)
+                return PairRanks(rows, (counts + 1).cpu().numpy(), vals, n_users)
             for b, s in enumerate(range(0, n_users, user_batch_size)):
                 p0, p1 = bounds[b], bounds[b + 1]
                 if p0 == p1:

@@ -175,11 +175,11 @@ def test_config4_movielens20m_tile_relu_euclidean_matches_oracle():
         if ref is None:
             continue
         dg = np.abs(cap['grads'][k] - ref) / gmax
-        worst[k] = (float(dg.max()), float((dg > 1e-4).mean()))
-    print("config4 raw-gradient error / gmax per tensor (max, share beyond 1e-4): %s" % worst)
+        worst[k] = (float(dg.max()), int((dg > 1e-4).sum()), dg.size)
+    print("config4 raw-gradient error / gmax per tensor (max, entries beyond 1e-4, entries): %s" % worst)
     # 1e-4 of the largest gradient entry, as in tests/test_gpu_model.py -- with room for the kinks: ~31M hidden ReLU
     # pre-activations and ~48M hinge terms are evaluated here, a handful of them within 1e-7 of zero on one side and not
     # on the other; each such switch changes a few gradient entries by one term.  Observed: max 1.2e-4 on the ReLU
-    # tensors, everything else <= 6e-5.  Bar: no entry beyond 2e-4, at most 1e-5 of a tensor's entries beyond 1e-4.
-    for k, (mx, share) in worst.items():
-        assert mx <= 2e-4 and share <= 1e-5, "%s: %g / %g" % (k, mx, share)
+    # tensors, everything else <= 6e-5.  Bar: no entry beyond 2e-4; beyond 1e-4 at most 8 entries or 1e-5 of the tensor.
+    for k, (mx, n_beyond, size) in worst.items():
+        assert mx <= 2e-4 and n_beyond <= max(8, 1e-5 * size), "%s: %g / %d of %d" % (k, mx, n_beyond, size)
