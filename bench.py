@@ -288,6 +288,15 @@ def main():
     ws = (torch.empty((U, n_parts, cap), dtype=torch.float32, device=device),
           torch.empty((U, n_parts, cap), dtype=torch.int32, device=device))
 
+    # item shards exchange per-user data partitioned by user (all-to-all: every rank receives 1/world of what an
+    # all-gather would deliver); the all-gather forms remain for backends without device all-to-all (gloo tests)
+    selfcheck = None
+    floor_fn, topk_fn = sharding.shared_topk_floor, sharding.sharded_top_k
+    if world > 1:
+        selfcheck = sharding.collective_selfcheck(device)
+        if sharding.a2a_available(w_u):
+            floor_fn, topk_fn = sharding.shared_topk_floor_a2a, sharding.sharded_top_k_a2a
+
     def step():
         with torch.no_grad():
             user_repr = ops.spmm_raw(f_u.indptr, f_u.indices, f_u.values, None, U, f_u.nnz, w_u)          # K1
@@ -301,10 +310,10 @@ def main():
                 vals, idx = ops.score_topk_filtered(
                     u_f, i_f, k, ub, ib, item_index_base=i_begin, variant=args.variant,
                     n_chunks=args.chunks if args.chunks > 0 else None,
-                    floor_exchange=sharding.shared_topk_floor if world > 1 else None,
+                    floor_exchange=floor_fn if world > 1 else None,
                     stats_exchange=sharding.all_reduce_max if world > 1 else None)
                 if world > 1:
-                    vals, idx = sharding.sharded_top_k(vals, idx, k)
+                    vals, idx = topk_fn(vals, idx, k)              # every rank finalises ITS users (all-to-all + merge)
                 return vals, idx, user_repr, item_repr
             u_op, _, _ = ops.score_prep(user_repr, dtype)
             i_op, _, _ = ops.score_prep(item_repr, dtype)
@@ -315,9 +324,9 @@ def main():
                 # item shards share ONE top-k floor per user (all-gather of k superblock maxima) before re-scoring
                 vals, idx = ops.score_topk_two_stage(u_op, i_op, dtype, kpad, k, ub, ib, item_index_base=i_begin,
                                                      variant=args.variant, n_chunks=args.chunks if args.chunks > 0 else None,
-                                                     floor_exchange=sharding.shared_topk_floor if world > 1 else None)
+                                                     floor_exchange=floor_fn if world > 1 else None)
             if world > 1:
-                vals, idx = sharding.sharded_top_k(vals, idx, k)                                          # 1 all-gather
+                vals, idx = topk_fn(vals, idx, k)
             return vals, idx, user_repr, item_repr
 
     def sync():
@@ -423,7 +432,8 @@ def main():
         from oracle import oracle as O
         vals, idx, user_repr, item_repr = out
         n_sample = args.parity_users if exact else 32
-        sample = np.unique(np.linspace(0, U - 1, n_sample).astype(np.int64))
+        n_have = int(vals.shape[0])               # rank 0 holds all users (N = 1) or its own slice [0, n_have) (N > 1)
+        sample = np.unique(np.linspace(0, n_have - 1, min(n_sample, n_have)).astype(np.int64))
         sample_dev = torch.from_numpy(sample).to(device)
         it = item_repr.cpu().numpy()
         got_i = idx[sample_dev].cpu().numpy()
@@ -496,6 +506,9 @@ def main():
                                "DotProduct, biased, fused top-%d (BASELINE.json configs[2])" % (U, I, d, k),
                    "users": U, "items": I, "n_components": d, "top_k": k,
                    "parallelism": "items sharded x%d, users replicated" % world,
+                   "exchange": None if world == 1 else ("all-to-all by user (floor + lists)" if topk_fn is sharding.sharded_top_k_a2a
+                                                        else "all-gather (floor + lists)"),
+                   "collective_selfcheck": selfcheck,
                    "topk_method": method,
                    "score_kernel_variant": "global_load_lds" if args.variant & 1 else "register-staged"},
         "roofline": roofline, "roofline_k1": roofline_k1, "cpu_baseline": cpu, "parity": parity,

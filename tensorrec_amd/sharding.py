@@ -105,6 +105,131 @@ def shared_topk_floor(sel_max, group=None):
     return kth_largest_block_max(gathered, k)
 
 
+# ---- exchanges partitioned by USER ------------------------------------------------------------------------------
+# The all-gather forms above leave every rank with every user's result: each rank RECEIVES (world - 1) x the payload
+# (8 ranks, 1M users, k = 10: 7 x 40 MB of superblock maxima + 7 x 80 MB of lists per rank).  A rank only has to
+# FINALISE its share of the users, so the same information can travel as all-to-all slices -- per rank (world - 1) / world
+# of ONE payload (35 MB + 70 MB) -- followed, where every rank needs the result, by an all-gather of the final values
+# only (4 bytes per user for the floor, k * 8 bytes per user for the lists).  xGMI is point-to-point, so received bytes
+# per rank are what the exchange costs.
+def user_slice(n_users, world_size, rank):
+    """Contiguous, equal-sized (padded) user ranges: rank r finalises users [r * per, min((r + 1) * per, n_users))."""
+    per = -(-n_users // world_size)
+    return min(rank * per, n_users), min((rank + 1) * per, n_users), per
+
+
+def _all_to_all_user_slices(t, user_dim, group):
+    """t has all users along ``user_dim``; returns [world, ...] where entry s is rank s's data for THIS rank's users
+    (user axis cut to the padded slice length)."""
+    world = dist.get_world_size(group)
+    n_users = t.shape[user_dim]
+    per = -(-n_users // world)
+    t = t.movedim(user_dim, 0)
+    if per * world != n_users:
+        pad = torch.zeros((per * world - n_users,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        t = torch.cat([t, pad], dim=0)
+    send = t.contiguous()                                         # [world * per, ...]: destination-major
+    recv = torch.empty_like(send)
+    dist.all_to_all_single(recv, send, group=group)
+    return recv.reshape((world, per) + tuple(send.shape[1:]))
+
+
+def exchange_floor_table_a2a(sel_max, group=None):
+    """[k, n_users] maxima of this rank's k selected superblocks -> ([world * k, per] table of ALL ranks' maxima for this
+    rank's users, (begin, end) of those users)."""
+    k, n_users = sel_max.shape
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    got = _all_to_all_user_slices(sel_max, 1, group)              # [world, per, k]
+    per = got.shape[1]
+    b, e, _ = user_slice(n_users, world, rank)
+    return got.permute(0, 2, 1).reshape(world * k, per).contiguous(), (b, e)
+
+
+def shared_topk_floor_a2a(sel_max, group=None, kth_fn=None):
+    """shared_topk_floor with user-partitioned traffic: every rank receives the other ranks' k maxima for ITS users only
+    (all-to-all), takes the k-th largest of the world * k values (``kth_fn``, default the stage-2 HIP kernel), and the
+    [n_users] floor is completed by an all-gather of the slices (4 bytes per user)."""
+    kth_fn = kth_fn or kth_largest_block_max
+    k, n_users = sel_max.shape
+    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+        return kth_fn(sel_max, k)
+    world = dist.get_world_size(group)
+    table, (b, e) = exchange_floor_table_a2a(sel_max, group)
+    per = table.shape[1]
+    mine = kth_fn(table, k) if per else table.new_empty((0,))
+    mine[e - b:] = float('-inf')                                  # padded users
+    out = torch.empty((world * per,), dtype=sel_max.dtype, device=sel_max.device)
+    dist.all_gather_into_tensor(out, mine.contiguous(), group=group)
+    return out[:n_users].contiguous()
+
+
+def exchange_topk_a2a(local_vals, local_idx, group=None):
+    """Per-shard [n_users, k] lists -> candidate tables [per, world * k] for THIS rank's users (one all-to-all each for
+    values / ids) and the (begin, end) of those users."""
+    n_users, k = local_vals.shape
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    gv = _all_to_all_user_slices(local_vals, 0, group)            # [world, per, k]
+    gi = _all_to_all_user_slices(local_idx, 0, group)
+    per = gv.shape[1]
+    b, e, _ = user_slice(n_users, world, rank)
+    if e - b < per:                                               # padded users: empty candidates
+        gi[:, e - b:] = -1
+        gv[:, e - b:] = float('-inf')
+    return (gv.permute(1, 0, 2).reshape(per, world * k).contiguous(),
+            gi.permute(1, 0, 2).reshape(per, world * k).contiguous(), (b, e))
+
+
+def sharded_top_k_a2a(local_vals, local_idx, k, group=None, replicate=False, merge_fn=None):
+    """Per-shard [n_users, k] lists (global item ids) -> the exact global top-k of THIS rank's users
+    (user_slice(n_users, world, rank)): one all-to-all of list slices + a local merge (``merge_fn``, default the HIP merge
+    kernel).  ``replicate``: finish with an all-gather of the merged lists so that every rank holds all users (what
+    sharded_top_k returns)."""
+    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+        return local_vals, local_idx
+    merge_fn = merge_fn or merge_topk
+    n_users = local_vals.shape[0]
+    world = dist.get_world_size(group)
+    cv, ci, (b, e) = exchange_topk_a2a(local_vals, local_idx, group)
+    per = cv.shape[0]
+    mv, mi = merge_fn(cv, ci, k)
+    if not replicate:
+        return mv[:e - b], mi[:e - b]
+    ov = torch.empty((world * per, k), dtype=mv.dtype, device=mv.device)
+    oi = torch.empty((world * per, k), dtype=mi.dtype, device=mi.device)
+    dist.all_gather_into_tensor(ov, mv.contiguous(), group=group)
+    dist.all_gather_into_tensor(oi, mi.contiguous(), group=group)
+    return ov[:n_users], oi[:n_users]
+
+
+def a2a_available(t, group=None):
+    """All-to-all of device tensors needs RCCL ("nccl"); gloo carries CUDA tensors only for the gather / reduce
+    collectives (the one-GPU functional tests).  CPU tensors: gloo has all_to_all_single."""
+    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+        return False
+    return (not t.is_cuda) or dist.get_backend(group) == "nccl"
+
+
+def collective_selfcheck(device, group=None):
+    """Tiny known-answer run of every collective the scoring / training path uses (all-gather, all-to-all, all-reduce SUM
+    / MAX): the first thing bench.py does on a multi-GPU launch, so a broken RCCL / xGMI setup fails loudly before any
+    number is reported.  Returns 'ok'."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    x = torch.arange(world * 3, dtype=torch.float32, device=device) + 100.0 * rank
+    g = all_gather_cat(x.reshape(1, -1), group, dim=0)
+    want = torch.stack([torch.arange(world * 3, dtype=torch.float32) + 100.0 * r for r in range(world)]).to(device)
+    assert torch.equal(g, want), "all-gather self-check failed"
+    if a2a_available(x, group):
+        got = _all_to_all_user_slices(x, 0, group)                # [world, 3]: entry s = rank s's values for my slice
+        want = torch.stack([torch.arange(rank * 3, rank * 3 + 3, dtype=torch.float32) + 100.0 * s for s in range(world)])
+        assert torch.equal(got.cpu(), want), "all-to-all self-check failed"
+    s = torch.tensor([rank + 1.0, 10.0], device=device)
+    dist.all_reduce(s, op=dist.ReduceOp.SUM, group=group)
+    assert s.tolist() == [world * (world + 1) / 2.0, 10.0 * world], "all-reduce(SUM) self-check failed"
+    m = all_reduce_max(torch.tensor([float(rank)], device=device), group)
+    assert m.item() == world - 1.0, "all-reduce(MAX) self-check failed"
+    return "ok"
+
+
 def all_reduce_max(t, group=None):
     """MAX all-reduce of a small float tensor (the item-side maxima behind the bf16 filter's error bound: the bound must
     cover the items of EVERY shard, ops.score_topk_filtered)."""

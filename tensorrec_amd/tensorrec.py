@@ -898,7 +898,10 @@ class TensorRec(object):
             dist.all_reduce(smallest, op=dist.ReduceOp.MIN, group=self.process_group)
             if int(smallest.item()) >= ops.TWO_STAGE_MIN_ITEMS:
                 method = "two_stage"
-                floor_exchange = lambda sel_max: sharding.shared_topk_floor(sel_max, self.process_group)  # noqa: E731
+                # RCCL: user-partitioned all-to-all (each rank receives 1/world of an all-gather's bytes); else all-gather
+                a2a = sharding.a2a_available(smallest, self.process_group)
+                floor_fn = sharding.shared_topk_floor_a2a if a2a else sharding.shared_topk_floor
+                floor_exchange = lambda sel_max: floor_fn(sel_max, self.process_group)  # noqa: E731
             else:
                 method = "direct"
         # precision='fp32' on a large catalogue: the same exact fp32 result, with the contraction done once on bf16 MFMA
@@ -934,7 +937,10 @@ class TensorRec(object):
                                                     floor_exchange=floor_exchange))
                 v, i = per_taste[0] if len(per_taste) == 1 else _merge_taste_topk(per_taste, k)
                 if sharded:
-                    v, i = sharding.sharded_top_k(v, i, k, self.process_group)
+                    if sharding.a2a_available(v, self.process_group):
+                        v, i = sharding.sharded_top_k_a2a(v, i, k, self.process_group, replicate=True)
+                    else:
+                        v, i = sharding.sharded_top_k(v, i, k, self.process_group)
                 vals.append(v)
                 idx.append(i)
         vals, idx = torch.cat(vals), torch.cat(idx)

@@ -86,6 +86,66 @@ def test_exchange_and_reduce_over_gloo(world):
     assert dict(ret) == {r: "ok" for r in range(world)}
 
 
+def _a2a_worker(rank, world, port, ret):
+    """User-partitioned exchanges (sharding.*_a2a): the all-to-all forms must give every rank exactly its users' slice of
+    what the all-gather forms give everybody; the merge / k-th-largest kernels are replaced by NumPy here."""
+    from oracle import oracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(1)
+        n_users, n_items, d, k = 29, 1200, 16, 10          # 29 users: not a multiple of the world size (padding path)
+        u = rng.integers(-2, 3, (n_users, d)).astype(np.float32)
+        v = rng.integers(-2, 3, (n_items, d)).astype(np.float32)
+        full = O.score_dense_exact(u, v)
+        b, e = sharding.shard_bounds(n_items, world, rank, align=64)
+        lv, li = O.topk_rows(np.ascontiguousarray(full[:, b:e]), k)
+        li = np.where(li >= 0, li + b, -1).astype(np.int32)
+
+        def merge_np(cv, ci, kk):
+            cv, ci = cv.numpy(), ci.numpy()
+            ov = np.full((cv.shape[0], kk), -np.inf, np.float32)
+            oi = np.full((cv.shape[0], kk), -1, np.int32)
+            for r in range(cv.shape[0]):
+                cand = sorted((-cv[r, j], ci[r, j]) for j in range(cv.shape[1]) if ci[r, j] >= 0)[:kk]
+                for j, (nv, idx) in enumerate(cand):
+                    ov[r, j], oi[r, j] = -nv, idx
+            return torch.from_numpy(ov), torch.from_numpy(oi)
+
+        def kth_np(table, kk):
+            t = np.sort(table.numpy(), axis=0)[::-1]
+            return torch.from_numpy(np.ascontiguousarray(t[kk - 1]))
+
+        gv, gi = O.topk_rows(full, k)
+        ub, ue, _ = sharding.user_slice(n_users, world, rank)
+        mv, mi = sharding.sharded_top_k_a2a(torch.from_numpy(lv), torch.from_numpy(li), k, merge_fn=merge_np)
+        assert np.array_equal(mi.numpy(), gi[ub:ue]) and np.array_equal(mv.numpy(), gv[ub:ue])
+        rv, ri = sharding.sharded_top_k_a2a(torch.from_numpy(lv), torch.from_numpy(li), k, replicate=True, merge_fn=merge_np)
+        assert np.array_equal(ri.numpy(), gi) and np.array_equal(rv.numpy(), gv)
+        # floor: k-th largest of all ranks' per-shard top-k "superblock maxima" (here: the shard's k best scores per user)
+        sel_max = torch.from_numpy(np.ascontiguousarray(lv.T))                 # [k, n_users]
+        floor = sharding.shared_topk_floor_a2a(sel_max, kth_fn=kth_np).numpy()
+        gathered = sharding.all_gather_cat(sel_max, dim=0).numpy()             # the all-gather form's table
+        assert np.array_equal(floor, np.sort(gathered, axis=0)[::-1][k - 1])
+        assert np.array_equal(floor, gv[:, k - 1])                             # = the global k-th best score here
+        # item-side maxima of the bf16 filter's bound: MAX all-reduce
+        g = sharding.all_reduce_max(torch.tensor([1.0 + rank, 5.0 - rank, 0.5]))
+        assert g.tolist() == [float(world), 5.0, 0.5]
+        ret[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_user_partitioned_exchanges_over_gloo(world):
+    port = _free_port()
+    mgr = mp.get_context("spawn").Manager()
+    ret = mgr.dict()
+    mp.spawn(_a2a_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert dict(ret) == {r: "ok" for r in range(world)}
+
+
 def _dp_worker(rank, world, port, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
