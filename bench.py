@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--cpu-users", type=int, default=1024)
     ap.add_argument("--parity-users", type=int, default=4096, help="users checked against the oracle in exact mode")
     ap.add_argument("--no-fp32-mode", action="store_true", help="skip the all-fp32-MFMA record")
+    ap.add_argument("--no-k1-multi", action="store_true", help="skip the multi-nnz K1 roofline")
     ap.add_argument("--tune", action="append", default=[], metavar="NAME=INT",
                     help="diagnostic: set a kernel tuning knob (trec_set_tuning), e.g. blockmax_pipelined=0")
     return ap.parse_args()
@@ -400,12 +401,52 @@ def main():
                        "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                        "traffic": None, "avg_launch_ms": k1_user_ms, "algorithmic_bytes_per_launch": bytes_user}
 
+    # ---- K1 on features that are NOT the identity: 20 non-zeros per row over 1M feature columns, d = 128 -- the 512 MB
+    # weight table is 16x the L2 and 2x the Infinity Cache, so (unlike a small table) every gathered row is memory
+    # traffic and nnz * d * 4 is an honest algorithmic byte count (checked against PMC: profiles/*k1_multi_pmc*.txt)
+    roofline_k1_multi = None
+    if world == 1 and not args.no_k1_multi:
+        try:
+            nnz_row, F = 20, 1_000_000
+            n_rows = min(U, 1_000_000)
+            rng = np.random.default_rng(5)
+            cols = rng.integers(0, F, size=(n_rows, nnz_row), dtype=np.int32)
+            cols.sort(axis=1)
+            m = sp.csr_matrix((rng.random(n_rows * nnz_row, dtype=np.float32), cols.reshape(-1),
+                               np.arange(0, (n_rows + 1) * nnz_row, nnz_row, dtype=np.int64)), shape=(n_rows, F))
+            f_m = SparseFeatures(m, device)
+            w_m = torch.randn((F, d), device=device, generator=gen)
+            ops.spmm_raw(f_m.indptr, f_m.indices, f_m.values, None, n_rows, f_m.nnz, w_m)
+            ops.KERNEL_EVENTS = []
+            for _ in range(5):
+                ops.spmm_raw(f_m.indptr, f_m.indices, f_m.values, None, n_rows, f_m.nnz, w_m)
+            torch.cuda.synchronize()
+            ev, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
+            ms = float(np.mean([s_.elapsed_time(e_) for n_, s_, e_ in ev if n_ == "spmm_csr"]))
+            alg = f_m.nnz * (4 + 4) + (n_rows + 1) * 8 + float(f_m.nnz) * d * 4 + float(n_rows) * d * 4
+            gbs = alg / (ms * 1e-3) / 1e9
+            roofline_k1_multi = {"kernel": "spmm_csr_vec4_kernel, %d rows x %d non-zeros over %d feature columns, d=%d" % (n_rows, nnz_row, F, d),
+                                 "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                 "traffic": None, "avg_launch_ms": ms, "algorithmic_bytes_per_launch": alg}
+            import glob as _g, re as _re
+            files = sorted(_g.glob(os.path.join(ROOT, "profiles", "*k1_multi_pmc*.txt")))
+            if files and n_rows == 1_000_000 and d == 128:
+                txt = open(files[-1]).read()
+                f_ = _re.findall(r"spmm_csr[^\n]*?FETCH_SIZE=([0-9.e+]+)", txt)
+                w_ = _re.findall(r"spmm_csr[^\n]*?WRITE_SIZE=([0-9.e+]+)", txt)
+                if f_ and w_:
+                    roofline_k1_multi["traffic"] = (2.0 * float(f_[0]) + float(w_[0])) * 1024.0
+                    roofline_k1_multi["traffic_note"] = "(2*FETCH_SIZE + WRITE_SIZE) KB per launch from %s" % os.path.basename(files[-1])
+            del f_m, w_m, m, cols
+        except Exception as exc:
+            roofline_k1_multi = {"error": repr(exc)}
+
     # ---- HBM-side traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the figure
     # comes from the committed rocprofv3 --pmc passes of this same command (profiles/*_pmc_summary.txt), corrected as
     # MI355X_MICROARCH.md prescribes (gfx950 FETCH_SIZE counts wide coalesced reads at half their size) ----
     try:
         import glob, re
-        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.txt")))
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_summary.txt")))
         if files and world == 1 and (U, I, d) == (1_000_000, 1_000_000, 128) and method == "two_stage":
             txt = open(files[-1]).read()
             fetch = write = None
@@ -511,7 +552,7 @@ def main():
                    "collective_selfcheck": selfcheck,
                    "topk_method": method,
                    "score_kernel_variant": "global_load_lds" if args.variant & 1 else "register-staged"},
-        "roofline": roofline, "roofline_k1": roofline_k1, "cpu_baseline": cpu, "parity": parity,
+        "roofline": roofline, "roofline_k1": roofline_k1, "roofline_k1_multi_nnz": roofline_k1_multi, "cpu_baseline": cpu, "parity": parity,
         "fp32_mfma_mode": fp32_mode, "fit": fit,
         "roofline_fit": (fit or {}).get("roofline_fit"), "cpu_baseline_fit": cpu_fit,
     }
