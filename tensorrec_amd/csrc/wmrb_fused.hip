@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256, (ITERS == 1 && RMAX == 16) ? 4 : 1) void wmrb_
     const float* __restrict__ pos_weight, const int32_t* __restrict__ samples, int64_t n_users, int32_t S, int d,
     float ratio, int32_t max_rows, float* __restrict__ loss, float* __restrict__ pred_serial, float* __restrict__ dU,
     float* __restrict__ dub, float* __restrict__ coef_samples, float* __restrict__ coef_pairs,
-    int32_t* __restrict__ sample_hist, int32_t* __restrict__ sample_rank)
+    int32_t* __restrict__ sample_hist, int32_t* __restrict__ sample_rank, int ablate)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // y [max_rows4] | coef [max_rows4] | c [max_rows4] | base [max_rows4] | tmp [16 * max_rows4] | partial dU [8][d]
@@ -67,6 +67,11 @@ __global__ __launch_bounds__(256, (ITERS == 1 && RMAX == 16) ? 4 : 1) void wmrb_
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int sub = tid & 31, sg = tid >> 5;             // 8 subgroups of 32 lanes
+    // the sampled item ids do not depend on the user's interaction range: their loads leave together with indptr's
+    // (one round trip of the index -> row chain less for S of the S + n_pos rows)
+    int32_t item[RMAX];
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) item[r] = (sg + 8 * r < S) ? samples[u * S + sg + 8 * r] : 0;
     const int64_t b = indptr[u], e = indptr[u + 1];
     const int n_pos = (int)(e - b);
     const int R = S + n_pos;                             // rows of this user: samples first, then interactions
@@ -99,17 +104,26 @@ __global__ __launch_bounds__(256, (ITERS == 1 && RMAX == 16) ? 4 : 1) void wmrb_
     const float bu = ub ? ub[u] : 0.f;
 
     // ---- (b) every subgroup gathers its rows j = sg + 8 r (r < RMAX) in ONE batch and keeps them ----
-    int32_t item[RMAX];
     f32x4 y[RMAX][ITERS];
 #pragma unroll
     for (int r = 0; r < RMAX; ++r) {
         const int j = sg + 8 * r;
-        item[r] = (j < R) ? ((j < S) ? samples[u * S + j] : xi[b + (j - S)]) : 0;
+        if (j >= S) item[r] = (j < R) ? xi[b + (j - S)] : 0;
     }
-    float bi[RMAX];                                       // item biases ride in the same batch of loads as the rows
+    // Lane 16 + (r & 15) of a subgroup OWNS the subgroup's row r (lanes 16..31 are where the DPP reduction leaves the
+    // 32-lane dot product): it fetches the row's item bias -- in the same batch of loads as the rows --, issues the row's
+    // histogram atomic and writes its prediction; none of that costs RMAX registers in every lane.
+    constexpr int H = RMAX / 16;
+    const int own = sub - 16;
+    float my_bi[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+        const int j = sg + 8 * (own + 16 * h);
+        my_bi[h] = 0.f;
+        if (ib && own >= 0 && j < R) my_bi[h] = ib[(j < S) ? samples[u * S + j] : xi[b + (j - S)]];
+    }
 #pragma unroll
     for (int r = 0; r < RMAX; ++r) {
-        bi[r] = (ib && sg + 8 * r < R) ? ib[item[r]] : 0.f;
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
             const int c = (it * 32 + sub) * 4;
@@ -117,19 +131,16 @@ __global__ __launch_bounds__(256, (ITERS == 1 && RMAX == 16) ? 4 : 1) void wmrb_
                                                  : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
     }
-    if (sample_hist && sub == 0) {
-        // histogram of the counting sort to come; the value each atomic returns is the pair's rank inside its item's
-        // bucket, which makes the sort's fill pass atomic-free (issued after the row loads, consumed before the dots)
-        int32_t rk[RMAX];
+    // histogram of the counting sort to come, by the owner lanes: ONE atomic instruction per subgroup and 16 rows instead
+    // of RMAX from lane 0.  The value an atomic returns is the pair's rank inside its item's bucket, which makes the sort's
+    // fill pass atomic-free; it is stored at the very end of the kernel, so nothing in between waits for the atomics.
+    int32_t rk[H];
 #pragma unroll
-        for (int r = 0; r < RMAX; ++r)
-            rk[r] = (sg + 8 * r < S) ? __hip_atomic_fetch_add(sample_hist + item[r], 1, __ATOMIC_RELAXED,
-                                                               __HIP_MEMORY_SCOPE_AGENT) : 0;
-        if (sample_rank) {
-#pragma unroll
-            for (int r = 0; r < RMAX; ++r)
-                if (sg + 8 * r < S) sample_rank[u * S + sg + 8 * r] = rk[r];
-        }
+    for (int h = 0; h < H; ++h) {
+        const int j = sg + 8 * (own + 16 * h);
+        rk[h] = 0;
+        if (sample_hist && own >= 0 && j < S && !(ablate & 1))
+            rk[h] = __hip_atomic_fetch_add(sample_hist + samples[u * S + j], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // predictions: no per-row branch (a wave holds two subgroups with different rows), so the RMAX reduction chains
     // interleave; rows past R are zeros and are simply not written
@@ -150,17 +161,18 @@ __global__ __launch_bounds__(256, (ITERS == 1 && RMAX == 16) ? 4 : 1) void wmrb_
         t = dpp_add(t, 8); t = dpp_add(t, 4); t = dpp_add(t, 2); t = dpp_add(t, 1);
         dot[r] = dpp_add(t, 0);                            // lanes 16..31 of the subgroup: the 32-lane total
     }
-    if (sub == 31) {
 #pragma unroll
-        for (int r = 0; r < RMAX; ++r) {
-            const int j = sg + 8 * r;
-            if (j < R) {
-                float s = dot[r];
-                if (ub) s = s + bu;
-                if (ib) s = s + bi[r];
-                l_y[j] = s;
-                if (j >= S) pred_serial[b + (j - S)] = s;
-            }
+    for (int h = 0; h < H; ++h) {
+        float mine = 0.f;
+#pragma unroll
+        for (int r16 = 0; r16 < 16; ++r16) mine = (own == r16) ? dot[r16 + 16 * h] : mine;
+        const int j = sg + 8 * (own + 16 * h);
+        if (own >= 0 && j < R) {
+            float s = mine;
+            if (ub) s = s + bu;
+            if (ib) s = s + my_bi[h];
+            l_y[j] = s;
+            if (j >= S) pred_serial[b + (j - S)] = s;
         }
     }
     __syncthreads();
@@ -169,7 +181,7 @@ __global__ __launch_bounds__(256, (ITERS == 1 && RMAX == 16) ? 4 : 1) void wmrb_
     //      first threads = interactions, each walking the S sample predictions (LDS broadcast reads) for its hinge sum
     //      and active count; then threads = samples, each walking the interactions for its coefficient ----
     // (c1) hinge sum and active count of interaction q, 8 threads per interaction, each over every 8th float4 of samples
-    for (int q0 = 0; q0 < n_pos; q0 += 32) {
+    for (int q0 = 0; q0 < ((ablate & 2) ? 0 : n_pos); q0 += 32) {
         const int q = q0 + (tid >> 3), k = tid & 7;
         float acc = 0.f;
         int cnt = 0;
@@ -215,7 +227,7 @@ __global__ __launch_bounds__(256, (ITERS == 1 && RMAX == 16) ? 4 : 1) void wmrb_
     for (int s = tid; s < S; s += 256) {
         const float ys = l_y[s];
         float g = 0.f;
-        for (int q = 0; q < n_pos; ++q) g += (l_base[q] + ys >= 0.f) ? l_c[q] : 0.f;     // l_c = 0 for non-positives
+        for (int q = 0; q < ((ablate & 2) ? 0 : n_pos); ++q) g += (l_base[q] + ys >= 0.f) ? l_c[q] : 0.f;     // l_c = 0 for non-positives
         l_coef[s] = g;
         coef_samples[u * S + s] = g;
     }
@@ -229,7 +241,7 @@ __global__ __launch_bounds__(256, (ITERS == 1 && RMAX == 16) ? 4 : 1) void wmrb_
 #pragma unroll
         for (int r = 0; r < RMAX; ++r) {
             const int j = sg + 8 * r;
-            if (j < R) {
+            if (j < R && !(ablate & 4)) {
                 const float cf = l_coef[j];
 #pragma unroll
                 for (int it = 0; it < ITERS; ++it) {
@@ -256,6 +268,13 @@ __global__ __launch_bounds__(256, (ITERS == 1 && RMAX == 16) ? 4 : 1) void wmrb_
         for (int j = lane; j < R; j += 64) acc += l_coef[j];
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
         if (lane == 0) dub[u] = acc;
+    }
+    if (sample_hist && sample_rank && own >= 0 && !(ablate & 1)) {
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            const int j = sg + 8 * (own + 16 * h);
+            if (j < S) sample_rank[u * S + j] = rk[h];
+        }
     }
 }
 
@@ -299,7 +318,8 @@ extern "C" int trec_wmrb_fused_step(const float* U, const float* V, const float*
 #define TREC_FUSED(IT, RM)                                                                                             \
     hipLaunchKernelGGL((wmrb_user_fused_kernel<IT, RM>), dim3((unsigned)n_users), dim3(256), lds, st, U, V, user_bias,  \
                        item_bias, indptr, x_item, pos_slot, pos_weight, samples, n_users, n_sampled, d, ratio, max_rows, \
-                       loss, pred_serial, dU, d_user_bias, coef_samples, coef_pairs, sample_hist, sample_rank)
+                       loss, pred_serial, dU, d_user_bias, coef_samples, coef_pairs, sample_hist, sample_rank,    \
+                       trec_get_tuning("wmrb_ablate", 0))
     if (d <= 128 && max_rows <= 128) TREC_FUSED(1, 16);
     else if (d <= 128) TREC_FUSED(1, 32);
     else TREC_FUSED(2, 16);

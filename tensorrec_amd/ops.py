@@ -820,7 +820,9 @@ def score_topk_two_stage(users_op, items_op, dtype, kpad, k, user_bias=None, ite
 
 
 # ------------------------------------------------------------------------------------------------ K2f: exact top-k, bf16 filter
-FILTER_KSEL = 32          # superblocks a user may keep (1M x 1M, d = 128, k = 10: 15 on average; more -> exact fallback)
+# superblocks a user may keep (1M x 1M, d = 128, k = 10: 15.5 on average; 19 users of 1M need more than 32, none more than
+# 48 -- a user beyond the limit goes to the exact fp32 fallback, whose launch chain costs ~1.2 ms however few users)
+FILTER_KSEL = 48
 LAST_FILTER_STATS = {}    # diagnostics of the most recent score_topk_filtered call (bench.py reports them)
 
 
