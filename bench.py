@@ -55,6 +55,10 @@ def parse():
     ap.add_argument("--parity-users", type=int, default=4096, help="users checked against the oracle in exact mode")
     ap.add_argument("--no-fp32-mode", action="store_true", help="skip the all-fp32-MFMA record")
     ap.add_argument("--no-k1-multi", action="store_true", help="skip the multi-nnz K1 roofline")
+    ap.add_argument("--fused-k1", action="store_true",
+                    help="K1 emits the filter's operands in its epilogue (trec_spmm_csr_filter) instead of a separate prep "
+                         "pass: 0.1 ms per side less in total, but the gather kernel itself then runs at 0.49 of the HBM "
+                         "roofline instead of 0.68 (DESIGN.md section 8)")
     ap.add_argument("--tune", action="append", default=[], metavar="NAME=INT",
                     help="diagnostic: set a kernel tuning knob (trec_set_tuning), e.g. blockmax_pipelined=0")
     return ap.parse_args()
@@ -300,6 +304,20 @@ def main():
 
     def step():
         with torch.no_grad():
+            if exact and method == "two_stage" and d in (32, 64, 128, 256) and args.fused_k1:
+                # K1 emits the filter's operands itself (fp32 representation + bf16 image + error norms): no prep pass
+                ub = None if args.unbiased else ops.sparse_matvec(f_u, beta_u)
+                ib = None if args.unbiased else ops.sparse_matvec(f_i, beta_i)
+                u_f = ops.spmm_filter_operand(f_u, w_u)
+                i_f = ops.spmm_filter_operand(f_i, w_i, bias=ib, want_gstats=True)
+                vals, idx = ops.score_topk_filtered(
+                    u_f, i_f, k, ub, ib, item_index_base=i_begin, variant=args.variant,
+                    n_chunks=args.chunks if args.chunks > 0 else None,
+                    floor_exchange=floor_fn if world > 1 else None,
+                    stats_exchange=sharding.all_reduce_max if world > 1 else None)
+                if world > 1:
+                    vals, idx = topk_fn(vals, idx, k)
+                return vals, idx, u_f.f32, i_f.f32
             user_repr = ops.spmm_raw(f_u.indptr, f_u.indices, f_u.values, None, U, f_u.nnz, w_u)          # K1
             item_repr = ops.spmm_raw(f_i.indptr, f_i.indices, f_i.values, None, n_local, f_i.nnz, w_i)    # K1
             ub = None if args.unbiased else ops.sparse_matvec(f_u, beta_u)
@@ -396,8 +414,12 @@ def main():
         # user-side launches are the even ones (U rows), item-side the odd ones (n_local rows)
         k1_user_ms = float(np.mean(k1[0::2]))
         bytes_user = U * (4 + 4) + (U + 1) * 8 + U * d * 4 + U * d * 4      # idx int32 + val, indptr int64, gather, store
+        fused_k1 = exact and method == "two_stage" and d in (32, 64, 128, 256) and args.fused_k1
+        if fused_k1:
+            bytes_user += U * d * 2 + U * 8                                 # + the bf16 image and the two norms per row
         gbs = bytes_user / (k1_user_ms * 1e-3) / 1e9
-        roofline_k1 = {"kernel": "spmm_csr_vec4_kernel (user side, identity features)", "bound": "hbm",
+        roofline_k1 = {"kernel": "spmm_csr_vec4_kernel (user side, identity features%s)"
+                                 % (", filter-operand epilogue: fp32 + bf16 rows + error norms" if fused_k1 else ""), "bound": "hbm",
                        "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                        "traffic": None, "avg_launch_ms": k1_user_ms, "algorithmic_bytes_per_launch": bytes_user}
 

@@ -51,6 +51,14 @@ int trec_get_tuning(const char* name, int dflt);
 int trec_spmm_csr(const int64_t* indptr, const int32_t* indices, const float* values, const int32_t* val_perm,
                   int64_t n_rows, int64_t nnz, const float* W, int32_t d, const float* col_bias, int32_t epilogue,
                   int32_t accumulate, float* out, float* out_inv_norm, void* stream);
+/* K1 with the operand of the filtered top-k (K2f) as its epilogue: out = X . W in fp32 AND its bf16 image [n_rows, d],
+ * row_stats [n_rows][2] = {||row||, ||row - bf16(row)||} and (gstats non-NULL, zero-initialised) their running maxima --
+ * what trec_score_prep_filter computes in a separate pass.  d = 32 / 64 / 128 / 256 (no padding), dot products (no
+ * normalisation).  trec_absmax: running maximum of |x| into *out (the |bias| term of the bound, gstats[2]). */
+int trec_spmm_csr_filter(const int64_t* indptr, const int32_t* indices, const float* values, int64_t n_rows, int64_t nnz,
+                         const float* W, int32_t d, float* out, void* out_bf16, float* row_stats, float* gstats,
+                         void* stream);
+int trec_absmax(const float* x, int64_t n, float* out, void* stream);
 /* The same gather over a CSR with packed entries int2 {column, value bits} (trec_group_pairs_by_item, packed mode);
  * epilogue 0 or 3 (out_rowsum[r] = sum of the row's values); accumulate != 0: out += (and out_rowsum +=).            */
 int trec_spmm_csr_packed(const int64_t* indptr, const void* entries, int64_t n_rows, const float* W, int32_t d,

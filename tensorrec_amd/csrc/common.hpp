@@ -50,5 +50,13 @@ __device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
     return (unsigned short)(u >> 16);
 }
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short h) { return __uint_as_float(((unsigned int)h) << 16); }
+// two fp32 -> packed bf16 pair (low half = a) in ONE instruction: v_cvt_pk_bf16_f32 (round-to-nearest-even, the same
+// bits as f32_to_bf16_rne for every non-NaN input)
+typedef __bf16 trec_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float trec_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned int f32x2_to_bf16x2_bits(float a, float b) {
+    const trec_f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, trec_bf16x2));
+}
 
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }

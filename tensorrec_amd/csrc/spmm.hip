@@ -29,11 +29,21 @@ __device__ __forceinline__ float subgroup_sum(float v, int lpr) {
 // gathers where every weight row is referenced about once, so caching it only evicts useful lines)
 // PACKED: `indices` points at int2 {column, value bits} entries (one 8-byte load per non-zero; values / val_perm unused)
 // -- the layout the counting sort of the fit step writes with ONE scattered store per pair
+// EPI 4 (the operand of the filtered top-k straight from the gather, csrc/topk_filter.hip): besides the fp32 row, its
+// bf16 image [n_rows, d], {||row||, ||row - bf16(row)||} and the running maxima of both (what trec_score_prep_filter
+// computes in a separate pass over the representation)
+struct SpmmFilterOut {
+    unsigned short* bf16;
+    float2* row_stats;
+    float* gstats;
+};
+
 template <int ITERS, int R, int EPI, bool NT = false, bool NTL = false, bool PACKED = false>
 __global__ __launch_bounds__(256) void spmm_csr_vec4_kernel(
     const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, const float* __restrict__ values,
     const int32_t* __restrict__ val_perm, int64_t n_rows, const float* __restrict__ W, int d, int lpr_log2,
-    const float* __restrict__ col_bias, int accumulate, float* __restrict__ out, float* __restrict__ out_inv)
+    const float* __restrict__ col_bias, int accumulate, float* __restrict__ out, float* __restrict__ out_inv,
+    SpmmFilterOut fo = SpmmFilterOut{nullptr, nullptr, nullptr})
 {
     const int lpr = 1 << lpr_log2;
     const int sub_lane = threadIdx.x & (lpr - 1);
@@ -178,6 +188,56 @@ __global__ __launch_bounds__(256) void spmm_csr_vec4_kernel(
             if (out_inv && sub_lane == 0) out_inv[row] = inv;
         } else if (EPI == 3) {
             if (out_inv && sub_lane == 0) out_inv[row] = accumulate ? out_inv[row] + vsum[r] : vsum[r];
+        } else if (EPI == 4) {
+            float sw = 0.f, se = 0.f;
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it)
+                if (cvalid[it]) {
+                    uint2 pk;
+                    pk.x = f32x2_to_bf16x2_bits(acc[r][it][0], acc[r][it][1]);
+                    pk.y = f32x2_to_bf16x2_bits(acc[r][it][2], acc[r][it][3]);
+#pragma unroll
+                    for (int e4 = 0; e4 < 4; ++e4) {
+                        const float w = acc[r][it][e4];
+                        const unsigned int word = (e4 < 2) ? pk.x : pk.y;
+                        const float back = __uint_as_float((e4 & 1) ? (word & 0xffff0000u) : (word << 16));
+                        const float err = w - back;                         // exact: the discarded low bits
+                        sw = fmaf(w, w, sw);
+                        se = fmaf(err, err, se);
+                    }
+                    if (NT) __builtin_nontemporal_store(pk.x | ((unsigned long long)pk.y << 32),
+                                                        (unsigned long long*)(fo.bf16 + row * (int64_t)d + col[it]));
+                    else *(uint2*)(fo.bf16 + row * (int64_t)d + col[it]) = pk;
+                }
+            int writer = 0;
+            if (lpr == 32) {
+                // 32-lane rows (d = 128): DPP adds -- four rotations inside the 16-lane rows, then row_bcast15 carries the
+                // first row's total into the second; the sum is complete in lane 31 (no LDS crossbar, cf. wmrb_fused.hip)
+                auto dpp_sum32 = [](float x) {
+                    int v, r;
+                    v = __float_as_int(x); r = __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, false); x += __int_as_float(r);
+                    v = __float_as_int(x); r = __builtin_amdgcn_update_dpp(0, v, 0x124, 0xf, 0xf, false); x += __int_as_float(r);
+                    v = __float_as_int(x); r = __builtin_amdgcn_update_dpp(0, v, 0x122, 0xf, 0xf, false); x += __int_as_float(r);
+                    v = __float_as_int(x); r = __builtin_amdgcn_update_dpp(0, v, 0x121, 0xf, 0xf, false); x += __int_as_float(r);
+                    v = __float_as_int(x); r = __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false); x += __int_as_float(r);
+                    return x;
+                };
+                sw = dpp_sum32(sw);
+                se = dpp_sum32(se);
+                writer = 31;
+            } else {
+                sw = subgroup_sum<0>(sw, lpr);
+                se = subgroup_sum<0>(se, lpr);
+            }
+            if (sub_lane == writer) {
+                const float nw = sqrtf(sw), ne = sqrtf(se);
+                fo.row_stats[row] = make_float2(nw, ne);
+                if (fo.gstats) {      // guarded atomic max (non-negative floats order like their bit patterns; NaN -> +inf)
+                    const unsigned int bw = __float_as_uint(nw == nw ? nw : INFINITY), be = __float_as_uint(ne == ne ? ne : INFINITY);
+                    if (bw > *(volatile unsigned int*)(fo.gstats + 0)) atomicMax((unsigned int*)(fo.gstats + 0), bw);
+                    if (be > *(volatile unsigned int*)(fo.gstats + 1)) atomicMax((unsigned int*)(fo.gstats + 1), be);
+                }
+            }
         } else if (EPI == 2) {
 #pragma unroll
             for (int it = 0; it < ITERS; ++it)
@@ -351,7 +411,8 @@ static int pow2ceil_log2(int x) { int l = 0; while ((1 << l) < x) ++l; return l;
 template <int EPI>
 static int launch_vec4(const int64_t* indptr, const int32_t* indices, const float* values, const int32_t* val_perm,
                        int64_t n_rows, const float* W, int d, const float* col_bias, int accumulate, float* out,
-                       float* out_inv, int64_t nnz_hint, hipStream_t st)
+                       float* out_inv, int64_t nnz_hint, hipStream_t st,
+                       SpmmFilterOut fo = SpmmFilterOut{nullptr, nullptr, nullptr})
 {
     const int n4 = d / 4;
     int lpr_log2 = pow2ceil_log2(n4);
@@ -372,10 +433,10 @@ static int launch_vec4(const int64_t* indptr, const int32_t* indices, const floa
     const unsigned blocks = (unsigned)ceil_div64(threads, 256);
 #define TREC_SPMM_LAUNCH(IT, RR)                                                                                   \
     hipLaunchKernelGGL((spmm_csr_vec4_kernel<IT, RR, EPI>), dim3(blocks), dim3(256), 0, st, indptr, indices, values, \
-                       val_perm, n_rows, W, d, lpr_log2, col_bias, accumulate, out, out_inv)
+                       val_perm, n_rows, W, d, lpr_log2, col_bias, accumulate, out, out_inv, fo)
     if (R == 4 && iters == 1 && tune_nt && !accumulate) {
-        if (tune_ntl) hipLaunchKernelGGL((spmm_csr_vec4_kernel<1, 4, EPI, true, true>), dim3(blocks), dim3(256), 0, st, indptr, indices, values, val_perm, n_rows, W, d, lpr_log2, col_bias, accumulate, out, out_inv);
-        else hipLaunchKernelGGL((spmm_csr_vec4_kernel<1, 4, EPI, true, false>), dim3(blocks), dim3(256), 0, st, indptr, indices, values, val_perm, n_rows, W, d, lpr_log2, col_bias, accumulate, out, out_inv);
+        if (tune_ntl) hipLaunchKernelGGL((spmm_csr_vec4_kernel<1, 4, EPI, true, true>), dim3(blocks), dim3(256), 0, st, indptr, indices, values, val_perm, n_rows, W, d, lpr_log2, col_bias, accumulate, out, out_inv, fo);
+        else hipLaunchKernelGGL((spmm_csr_vec4_kernel<1, 4, EPI, true, false>), dim3(blocks), dim3(256), 0, st, indptr, indices, values, val_perm, n_rows, W, d, lpr_log2, col_bias, accumulate, out, out_inv, fo);
     } else if (R >= 4) {
         if (iters == 1) TREC_SPMM_LAUNCH(1, 4);
         else if (iters == 2) TREC_SPMM_LAUNCH(2, 4);
@@ -456,6 +517,45 @@ extern "C" int trec_spmm_csr(const int64_t* indptr, const int32_t* indices, cons
         return trec_check_launch("trec_spmm_csr(bias_relu)");
     }
     return TREC_OK;
+}
+
+// K1 with the filtered top-k's operand as its epilogue (EPI 4): out = X . W (fp32, the exact operand) AND its bf16 image,
+// the per-row {||row||, ||row - bf16(row)||} and -- gstats non-NULL, zero-initialised -- their running maxima.  For
+// representations that go into the score kernels as they are (dot products, d = 32 / 64 / 128 / 256: no padding, no
+// normalisation); everything else takes trec_score_prep_filter.
+extern "C" int trec_spmm_csr_filter(const int64_t* indptr, const int32_t* indices, const float* values, int64_t n_rows,
+                                    int64_t nnz, const float* W, int32_t d, float* out, void* out_bf16, float* row_stats,
+                                    float* gstats, void* stream)
+{
+    TREC_REQUIRE(indptr && W && out && out_bf16 && row_stats, "trec_spmm_csr_filter: null pointer");
+    TREC_REQUIRE(nnz == 0 || (indices && values), "trec_spmm_csr_filter: null indices/values with nnz != 0");
+    TREC_REQUIRE(d == 32 || d == 64 || d == 128 || d == 256, "trec_spmm_csr_filter: d must be 32, 64, 128 or 256");
+    if (n_rows == 0) return TREC_OK;
+    return launch_vec4<4>(indptr, indices, values, nullptr, n_rows, W, d, nullptr, 0, out, nullptr, nnz, (hipStream_t)stream,
+                          SpmmFilterOut{(unsigned short*)out_bf16, (float2*)row_stats, gstats});
+}
+
+// running maximum of |x| into *out (non-negative float, zero-initialised by the caller): the |bias| term of the filter's bound
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out)
+{
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float a = fabsf(x[i]);
+        m = fmaxf(m, a == a ? a : INFINITY);
+    }
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0 && __float_as_uint(m) > *(volatile unsigned int*)out)
+        atomicMax((unsigned int*)out, __float_as_uint(m));
+}
+
+extern "C" int trec_absmax(const float* x, int64_t n, float* out, void* stream)
+{
+    TREC_REQUIRE(x && out, "trec_absmax: null pointer");
+    if (n == 0) return TREC_OK;
+    unsigned blocks = (unsigned)ceil_div64(n, 256 * 8);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, n, out);
+    return trec_check_launch("trec_absmax");
 }
 
 extern "C" int trec_row_l2norm_fwd(const float* x, int64_t n_rows, int32_t d, float* y, float* inv_norm, void* stream)

@@ -87,19 +87,19 @@ __global__ __launch_bounds__(256) void prep_filter_kernel(const float* __restric
         const int c = (it * G + sub) * 4;
         f32x4 w = v[it];
         if (normalize) { w[0] *= scale; w[1] *= scale; w[2] *= scale; w[3] *= scale; }
-        unsigned short h[4];
+        uint2 pk;                                                   // v_cvt_pk_bf16_f32: round-to-nearest-even
+        pk.x = f32x2_to_bf16x2_bits(w[0], w[1]);
+        pk.y = f32x2_to_bf16x2_bits(w[2], w[3]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            h[e] = f32_to_bf16_rne(w[e]);
-            const float err = w[e] - bf16_bits_to_f32(h[e]);        // exact: the discarded low bits of w
+            const unsigned int word = (e < 2) ? pk.x : pk.y;
+            const float back = __uint_as_float((e & 1) ? (word & 0xffff0000u) : (word << 16));
+            const float err = w[e] - back;                          // exact: the discarded low bits of w
             sw = fmaf(w[e], w[e], sw);
             se = fmaf(err, err, se);
         }
         if (ok && c < kt) {
             if (out_f32) *(f32x4*)(out_f32 + row * (int64_t)kt + c) = w;
-            uint2 pk;
-            pk.x = (unsigned int)h[0] | ((unsigned int)h[1] << 16);
-            pk.y = (unsigned int)h[2] | ((unsigned int)h[3] << 16);
             *(uint2*)(out_bf16 + row * (int64_t)kt + c) = pk;
         }
     }

@@ -850,6 +850,28 @@ def score_prep_filter(repr_, normalize=False, bias=None, want_gstats=False):
     return op
 
 
+def spmm_filter_operand(features, w, bias=None, want_gstats=False):
+    """K1 with the filtered top-k's operand as its epilogue (trec_spmm_csr_filter): representation = features . w in fp32
+    (the exact operand) together with its bf16 image and rounding-error norms -- no separate pass over the representation.
+    For representations that enter the score kernels unchanged: n_components in (32, 64, 128, 256), dot products."""
+    w = _f32c(w)
+    d = w.shape[1]
+    n = features.shape[0]
+    op = FilterOperand()
+    op.n, op.d, op.kpad = n, d, d
+    op.f32 = torch.empty((n, d), dtype=torch.float32, device=w.device)
+    op.bf16 = torch.empty((n, d), dtype=torch.bfloat16, device=w.device)
+    op.stats = torch.empty((n, 2), dtype=torch.float32, device=w.device)
+    op.gstats = torch.zeros((3,), dtype=torch.float32, device=w.device) if want_gstats else None
+    with _timed("spmm_csr"):
+        N.call("trec_spmm_csr_filter", N.ptr(features.indptr), N.ptr(features.indices), N.ptr(features.values), n,
+               features.nnz, N.ptr(w), d, N.ptr(op.f32), N.ptr(op.bf16), N.ptr(op.stats), N.ptr(op.gstats))
+    if want_gstats and bias is not None:
+        import ctypes
+        N.call("trec_absmax", N.ptr(bias), bias.numel(), ctypes.c_void_p(op.gstats.data_ptr() + 8))
+    return op
+
+
 def score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index_base=0, sb_rows=None, variant=1,
                         n_chunks=None, floor_exchange=None, stats_exchange=None, ksel=None):
     """EXACT fp32 top-k (values and ids bit-identical to ``score_topk(..., DTYPE_F32)`` and to the oracle) with the

@@ -244,3 +244,31 @@ def test_model_predict_top_k_uses_the_filter_and_is_exact(ops):
     assert ops.LAST_FILTER_STATS.get("users") == n_u            # the filtered path ran
     rv, ri = exact_reference(uu, vv, k, ub, ib)
     assert np.array_equal(idx, ri) and np.array_equal(vals, rv)
+
+
+def test_k1_filter_epilogue_equals_gather_plus_prep(ops):
+    """trec_spmm_csr_filter (K1 emitting the filter's operand) == trec_spmm_csr followed by trec_score_prep_filter: the fp32
+    rows and their bf16 images bit for bit, the norms to fp32 summation order, and the same exact top-k."""
+    import scipy.sparse as sp
+    from tensorrec_amd.sparse import SparseFeatures
+    rng = np.random.default_rng(12)
+    n_u, n_i, F, d, k = 400, 30000, 5000, 128, 10
+    xu = sp.random(n_u, F, density=0.004, random_state=1, dtype=np.float32, format="csr")
+    xi = sp.random(n_i, F, density=0.002, random_state=2, dtype=np.float32, format="csr")
+    w_u = dev(rng.standard_normal((F, d)).astype(np.float32))
+    w_i = dev(rng.standard_normal((F, d)).astype(np.float32))
+    ib = dev(rng.standard_normal(n_i).astype(np.float32))
+    fu, fi = SparseFeatures(xu, "cuda"), SparseFeatures(xi, "cuda")
+    a_u = ops.spmm_filter_operand(fu, w_u)
+    a_i = ops.spmm_filter_operand(fi, w_i, bias=ib, want_gstats=True)
+    r_u = ops.spmm_raw(fu.indptr, fu.indices, fu.values, None, n_u, fu.nnz, w_u)
+    r_i = ops.spmm_raw(fi.indptr, fi.indices, fi.values, None, n_i, fi.nnz, w_i)
+    b_u = ops.score_prep_filter(r_u)
+    b_i = ops.score_prep_filter(r_i, bias=ib, want_gstats=True)
+    for a, b in ((a_u, b_u), (a_i, b_i)):
+        assert torch.equal(a.f32, b.f32) and torch.equal(a.bf16, b.bf16)
+        assert torch.allclose(a.stats, b.stats, rtol=1e-5, atol=1e-30)
+    assert torch.allclose(a_i.gstats, b_i.gstats, rtol=1e-5)
+    va, ia = ops.score_topk_filtered(a_u, a_i, k, None, ib)
+    vb, ib_ = ops.score_topk_filtered(b_u, b_i, k, None, ib)
+    assert torch.equal(va, vb) and torch.equal(ia, ib_)
