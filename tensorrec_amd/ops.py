@@ -512,7 +512,28 @@ def collapse_tastes(tastes_predictions, tastes_attentions=None, user_bias=None, 
     preds = stacked(tastes_predictions)
     attn = stacked(tastes_attentions) if tastes_attentions is not None else None
     if preds.shape[0] > 16:
-        raise ValueError("n_tastes = %d is beyond the collapse kernel's limit of 16" % preds.shape[0])
+        # the collapse kernel holds <= 16 tastes: a maximum is a maximum of group maxima (exact, bias add on the last
+        # call only); the attention form (softmax over ALL tastes) is composed from torch ops -- same arithmetic order as
+        # recommendation_graphs.py:96-105 (stack, softmax, multiply, reduce_sum), then the bias adds
+        if attn is None:
+            groups = [collapse_tastes(preds[g:g + 16]) if preds[g:g + 16].shape[0] > 1 else preds[g]
+                      for g in range(0, preds.shape[0], 16)]
+            return collapse_tastes(torch.stack(groups), None, user_bias, item_bias, x_user, x_item)
+        out = (preds * torch.softmax(attn, dim=0)).sum(dim=0)
+        if user_bias is None and item_bias is None:
+            return out
+        if x_item is not None:
+            xu, xi = x_user.long(), x_item.long()
+            if user_bias is not None:
+                out = out + user_bias[xu]
+            if item_bias is not None:
+                out = out + item_bias[xi]
+            return out
+        if user_bias is not None:
+            out = out + user_bias.reshape(-1, 1)
+        if item_bias is not None:
+            out = out + item_bias.reshape(1, -1)
+        return out
     ub = _f32c(user_bias) if user_bias is not None else None
     ib = _f32c(item_bias) if item_bias is not None else None
     if ub is None and ib is None:
@@ -683,6 +704,52 @@ def score_prep(repr_, dtype=DTYPE_F32, normalize=False, want_sqnorm=False):
     sq = torch.empty((n,), dtype=torch.float32, device=x.device) if want_sqnorm else None
     N.call("trec_score_prep", N.ptr(x), n, d, kpad, 1 if normalize else 0, dtype, N.ptr(out), N.ptr(sq))
     return out, sq, kpad
+
+
+SCORE_KMAX = 256          # the MFMA score kernels keep one operand resident in registers: n_components <= 256
+
+
+def dense_scores(user_repr, item_repr, dtype, normalize=False, mode=MODE_DOT, user_bias=None, item_bias=None, out=None):
+    """[n_users, n_items] scores of a built-in prediction graph (+ biases) from the two representations: the MFMA score
+    kernel with its fused epilogue for n_components <= 256; wider models take the K-looped fp32 MFMA GEMM
+    (trec_gemm_f32) followed by elementwise passes -- slower per score, same fp32 semantics
+    (prediction_graphs.py:49-50, :64-69, :84-100; recommendation_graphs.py:41)."""
+    d = user_repr.shape[1]
+    if d <= SCORE_KMAX:
+        want_sq = mode == MODE_EUCLIDEAN
+        u_op, u_sq, kpad = score_prep(user_repr, dtype, normalize=normalize, want_sqnorm=want_sq)
+        i_op, i_sq, _ = score_prep(item_repr, dtype, normalize=normalize, want_sqnorm=want_sq)
+        return score_store(u_op, i_op, dtype, kpad, user_bias, item_bias, mode, u_sq, i_sq, out=out)
+    u, v = _f32c(user_repr.detach()), _f32c(item_repr.detach())
+    if normalize:
+        u, v = l2_normalize_rows(u).detach(), l2_normalize_rows(v).detach()
+    s = gemm_raw(u, v, trans_b=True)
+    if mode == MODE_EUCLIDEAN:
+        r_u, r_v = (u * u).sum(dim=1, keepdim=True), (v * v).sum(dim=1, keepdim=True)
+        s = -1.0 * torch.sqrt(torch.clamp((r_u - 2.0 * s) + r_v.t(), min=1e-16))
+    if user_bias is not None:
+        s = s + user_bias.reshape(-1, 1)
+    if item_bias is not None:
+        s = s + item_bias.reshape(1, -1)
+    if out is not None:
+        out.copy_(s)
+        return out
+    return s
+
+
+def topk_from_scores(scores, k):
+    """(values [n_users, k], item ids int32 [n_users, k]) of a score slab in rank_predictions' order (value desc, index
+    asc): exact ranks (rank_rows) select the entries -- the route of models the fused top-k kernels do not cover."""
+    n_u, n_i = scores.shape
+    kk = min(int(k), n_i)
+    ranks = rank_rows(scores)
+    rows, cols = torch.nonzero(ranks <= kk, as_tuple=True)
+    pos = (ranks[rows, cols] - 1).long()
+    vals = torch.full((n_u, int(k)), float('-inf'), dtype=torch.float32, device=scores.device)
+    idx = torch.full((n_u, int(k)), -1, dtype=torch.int32, device=scores.device)
+    vals[rows, pos] = scores[rows, cols]
+    idx[rows, pos] = cols.to(torch.int32)
+    return vals, idx
 
 
 def score_store(users_op, items_op, dtype, kpad, user_bias=None, item_bias=None, mode=MODE_DOT, user_sq=None,

@@ -34,10 +34,7 @@ class AbstractPredictionGraph(object):
 
 def _dense(user_repr, item_repr, mode, normalize, precision):
     dtype = ops.DTYPE_BF16 if precision == 'bf16' else ops.DTYPE_F32
-    want_sq = mode == ops.MODE_EUCLIDEAN
-    u_op, u_sq, kpad = ops.score_prep(user_repr, dtype, normalize=normalize, want_sqnorm=want_sq)
-    i_op, i_sq, _ = ops.score_prep(item_repr, dtype, normalize=normalize, want_sqnorm=want_sq)
-    return ops.score_store(u_op, i_op, dtype, kpad, mode=mode, user_sq=u_sq, item_sq=i_sq)
+    return ops.dense_scores(user_repr, item_repr, dtype, normalize, mode)
 
 
 class DotProductPredictionGraph(AbstractPredictionGraph):

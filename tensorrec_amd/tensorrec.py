@@ -390,12 +390,17 @@ class TensorRec(object):
         if self._is_engine_graph() and not differentiable:
             dtype = ops.DTYPE_BF16 if self.precision == 'bf16' else ops.DTYPE_F32
             want_sq = graph.engine_mode == ops.MODE_EUCLIDEAN
-            i_op, i_sq, kpad = ops.score_prep(item_repr, dtype, normalize=graph.engine_normalize, want_sqnorm=want_sq)
+            wide = item_repr.shape[1] > ops.SCORE_KMAX
+            if not wide:
+                i_op, i_sq, kpad = ops.score_prep(item_repr, dtype, normalize=graph.engine_normalize, want_sqnorm=want_sq)
             n_u, n_i = user_reprs[0].shape[0], item_repr.shape[0]
 
             def stack(reprs):
                 out = torch.empty((len(reprs), n_u, n_i), dtype=torch.float32, device=item_repr.device)
                 for t, r in enumerate(reprs):
+                    if wide:
+                        ops.dense_scores(r, item_repr, dtype, graph.engine_normalize, graph.engine_mode, out=out[t])
+                        continue
                     u_op, u_sq, _ = ops.score_prep(r, dtype, normalize=graph.engine_normalize, want_sqnorm=want_sq)
                     ops.score_store(u_op, i_op, dtype, kpad, None, None, graph.engine_mode, u_sq, i_sq, out=out[t])
                 return out
@@ -435,12 +440,9 @@ class TensorRec(object):
         graph = self.prediction_graph_factory
         if self._is_engine_graph() and not differentiable:
             dtype = ops.DTYPE_BF16 if self.precision == 'bf16' else ops.DTYPE_F32
-            want_sq = graph.engine_mode == ops.MODE_EUCLIDEAN
-            u_op, u_sq, kpad = ops.score_prep(user_repr, dtype, normalize=graph.engine_normalize, want_sqnorm=want_sq)
-            i_op, i_sq, _ = ops.score_prep(item_repr, dtype, normalize=graph.engine_normalize, want_sqnorm=want_sq)
             ub = user_bias.detach().contiguous() if self.biased else None
             ib = item_bias.detach().contiguous() if self.biased else None
-            return ops.score_store(u_op, i_op, dtype, kpad, ub, ib, graph.engine_mode, u_sq, i_sq)
+            return ops.dense_scores(user_repr, item_repr, dtype, graph.engine_normalize, graph.engine_mode, ub, ib)
         if self._is_engine_graph() and differentiable:
             pred = _differentiable_dense(graph, user_repr, item_repr)
         else:
@@ -912,6 +914,25 @@ class TensorRec(object):
                     ops.N.load().trec_get_tuning(b"topk_bf16_filter", 1) != 0)
         stats_exchange = (lambda g: sharding.all_reduce_max(g, self.process_group)) if sharded else None
         vals, idx = [], []
+        if self.n_components > ops.SCORE_KMAX:
+            # wider than the fused kernels' resident operand: score slabs (K-looped fp32 GEMM) + exact ranks pick the top-k
+            if sharded:
+                raise NotImplementedError("item-sharded predict_top_k needs n_components <= %d" % ops.SCORE_KMAX)
+            step = max(1, min(int(user_batch_size), (1 << 28) // max(1, itf.shape[0])))
+            with torch.no_grad(), variable_scope(self._store):
+                user_reprs, attn_reprs, item_repr, user_bias, item_bias, _ = self._representations(uf, itf)
+                for s in range(0, uf.shape[0], step):
+                    e = min(s + step, uf.shape[0])
+                    ub = user_bias[s:e] if user_bias is not None else None
+                    if self._multi():
+                        slab = self._dense_multi([u[s:e] for u in user_reprs], None, item_repr, ub, item_bias)
+                    else:
+                        slab = self._dense_prediction(user_reprs[0][s:e], item_repr, ub, item_bias)
+                    v, i = ops.topk_from_scores(slab.contiguous(), k)
+                    vals.append(v)
+                    idx.append(i + int(item_offset))
+            vals, idx = torch.cat(vals), torch.cat(idx)
+            return (vals, idx) if return_device else (_to_host(vals), _to_host(idx))
         with torch.no_grad(), variable_scope(self._store):
             user_reprs, _, item_repr, user_bias, item_bias, _ = self._representations(uf, itf)
             ib = item_bias.contiguous() if self.biased else None
@@ -1227,10 +1248,8 @@ class _DenseDot(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, u, v):
-        u_op, _, kpad = ops.score_prep(u, ops.DTYPE_F32)
-        v_op, _, _ = ops.score_prep(v, ops.DTYPE_F32)
         ctx.save_for_backward(u, v)
-        return ops.score_store(u_op, v_op, ops.DTYPE_F32, kpad)
+        return ops.dense_scores(u, v, ops.DTYPE_F32)
 
     @staticmethod
     def backward(ctx, g):

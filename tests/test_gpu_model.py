@@ -538,3 +538,26 @@ def test_rank_of_interactions_with_many_positives_per_user_sorts_rows():
         pr = model.predict_rank_of_interactions(uf, itf, inter, user_batch_size=batch)
         assert len(pr.ranks) >= 32 * 90 and np.array_equal(pr.ranks, ranks[pr.rows, sp.csr_matrix(inter).tocoo().col])
     assert np.array_equal(np.sort(coo.row, kind="stable"), pr.rows)
+
+
+def test_wide_models_and_many_tastes_take_the_fallbacks():
+    """fit accepted n_components > 256 and n_tastes > 16 but predict* raised.  Wider models score through the
+    K-looped fp32 GEMM, more tastes collapse in groups of 16 (max) or through the composed softmax form (attention);
+    results against the oracle model from the same weights, top-k / ranks consistent with predict."""
+    inter, uf, itf = dummy(40, 70, seed=8)
+    for d, n_tastes, pred in ((300, 1, "dot"), (260, 1, "euclidean"), (24, 18, "dot")):
+        oracle = OracleTensorRec(d, "linear", "linear", pred, "rmse", True, n_tastes=n_tastes)
+        oracle.init_weights(uf.shape[1], itf.shape[1], np.random.default_rng(3))
+        model = T.TensorRec(n_components=d, n_tastes=n_tastes, prediction_graph=PRED[pred](), seed=1)
+        model.build(uf.shape[1], itf.shape[1])
+        w = dict(oracle.weights)
+        if n_tastes == 1:
+            w = _rename(w)
+        model.set_weights(w)
+        p_gpu, p_ref = model.predict(uf, itf), oracle.predict(uf, itf)
+        assert np.abs(p_gpu - p_ref).max() <= 1e-4 * np.abs(p_ref).max()
+        assert np.array_equal(model.predict_rank(uf, itf), O.rank_predictions_exact(p_gpu))
+        vals, idx = model.predict_top_k(uf, itf, k=5)
+        rv, ri = O.topk_rows(p_gpu, 5)
+        assert np.array_equal(idx, ri) and np.array_equal(vals, rv)
+        model.fit_partial(inter, uf, itf, epochs=1)                  # and training still runs
