@@ -51,7 +51,8 @@ def parse():
     ap.add_argument("--unbiased", action="store_true", help="diagnostic: model built with biased=False")
     ap.add_argument("--no-fit", action="store_true", help="skip the fit epochs/sec measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-users", type=int, default=1024)
+    ap.add_argument("--cpu-users", type=int, default=4096,
+                    help="user tile of the CPU baseline (SURVEY.md 8d: 4,096 users x all items)")
     ap.add_argument("--parity-users", type=int, default=4096, help="users checked against the oracle in exact mode")
     ap.add_argument("--no-fp32-mode", action="store_true", help="skip the all-fp32-MFMA record")
     ap.add_argument("--no-k1-multi", action="store_true", help="skip the multi-nnz K1 roofline")

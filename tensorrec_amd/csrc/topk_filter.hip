@@ -156,7 +156,8 @@ __global__ __launch_bounds__(256) void filter_floor_kernel(const float* __restri
 // rows are fetched with coalesced 16-byte loads (a row = KT/4 consecutive lanes) into LDS, then lane r walks row r with
 // the reference's k-ordered fmaf chain (a row per lane straight from global memory is a 16-byte access per 512-byte
 // row per load: 4.6 ms at 1M users, ~15 survivors each; staged: see DESIGN.md).
-#define FILTER_RB 16
+#define FILTER_RB 8
+#define FILTER_SPEC 24       // slots whose id lists are fetched before the user's slot count is known
 template <int CPL>
 __global__ __launch_bounds__(256) void filter_finish_kernel(
     const int32_t* __restrict__ pi, int cap, int ksel, const int32_t* __restrict__ count, const float* __restrict__ U,
@@ -174,22 +175,48 @@ __global__ __launch_bounds__(256) void filter_finish_kernel(
     int32_t* cand = (int32_t*)fsmem + wave * FILTER_CMAX;
     float* urow = (float*)(fsmem + 4 * FILTER_CMAX * 4) + (size_t)wave * kd4;
     float* rows = (float*)(fsmem + 4 * FILTER_CMAX * 4) + (size_t)4 * kd4 + (size_t)wave * FILTER_RB * rstride;
-    // ---- kept slots: the first count[u] of the user's ksel slots (trec_topk_collect_blocks)
+    // ---- everything that does not depend on anything else leaves at once: the user's count, its row and bias, and --
+    // speculatively, before the count is known -- the id lists of its first FILTER_SPEC slots (their entries are masked
+    // by the count afterwards; a user with more kept slots pays one more round trip).  The wave is latency-bound: every
+    // dependent load round costs ~1-2 us and a CU holds 16 of these waves.
     const int c_u = count[u];
-    const unsigned long long keptmask = c_u >= 64 ? ~0ull : ((1ull << c_u) - 1ull);
     const int64_t base = u * (int64_t)ksel * 2 * cap;
-    // ---- survivors: every valid entry of a kept slot's two lists; a full list may have dropped items above the floor
-    int32_t id[CPL];
-    bool lossy = false;
     const int n_ent = ksel * 2 * cap;
+    const int n_spec = (n_ent < FILTER_SPEC * 2 * cap) ? n_ent : FILTER_SPEC * 2 * cap;
+    const int chunks = kd4 >> 2;
+    const bool vec = ((ld_v & 3) == 0) && ((ld_u & 3) == 0);
+    int32_t id[CPL];
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
         const int j = c * 64 + lane;
-        id[c] = -1;
-        if (j < n_ent && ((keptmask >> (j / (2 * cap))) & 1ull)) {
-            id[c] = pi[base + j];
-            if (id[c] >= 0 && (j % cap) == cap - 1) lossy = true;
+        id[c] = (j < n_spec) ? pi[base + j] : -1;
+    }
+    f32x4 uw[4];                                            // the user's row: kd4 <= 1024 floats = 4 float4 per lane
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int ch = q * 64 + lane;
+        uw[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (ch < chunks) {
+            const float* src = U + u * ld_u + ch * 4;
+            if (vec) uw[q] = *(const f32x4*)src;
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) uw[q][e] = (ch * 4 + e < kdim) ? src[e] : 0.f;
+            }
         }
+    }
+    const float bu = user_bias ? user_bias[u] : 0.f;
+    // ---- kept slots: the first count[u] of the user's ksel slots (trec_topk_collect_blocks)
+    const unsigned long long keptmask = c_u >= 64 ? ~0ull : ((1ull << c_u) - 1ull);
+    // ---- survivors: every valid entry of a kept slot's two lists; a full list may have dropped items above the floor
+    bool lossy = false;
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+        const int j = c * 64 + lane;
+        const bool keep = j < n_ent && ((keptmask >> (j / (2 * cap))) & 1ull);
+        if (keep && j >= n_spec) id[c] = pi[base + j];            // beyond the speculated slots (rare)
+        if (!keep) id[c] = -1;
+        if (id[c] >= 0 && (j % cap) == cap - 1) lossy = true;
     }
     int total = 0;
 #pragma unroll
@@ -207,19 +234,10 @@ __global__ __launch_bounds__(256) void filter_finish_kernel(
     const unsigned long long EMPTY = merge_key(-INFINITY, 0x7fffffff);
     unsigned long long key = EMPTY;                // lane r ends up holding survivor (round * FILTER_RB + r)'s key ...
     unsigned long long mine = EMPTY;               // ... moved to lane (round * FILTER_RB + r) here
-    const float bu = user_bias ? user_bias[u] : 0.f;
-    const int chunks = kd4 >> 2;
-    const bool vec = ((ld_v & 3) == 0) && ((ld_u & 3) == 0);
-    // the user's row: one coalesced read into LDS, broadcast from there by every chain step
-    for (int ch = lane; ch < chunks; ch += 64) {
-        const float* src = U + u * ld_u + ch * 4;
-        f32x4 w;
-        if (vec) w = *(const f32x4*)src;
-        else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) w[e] = (ch * 4 + e < kdim) ? src[e] : 0.f;
-        }
-        *(f32x4*)(urow + ch * 4) = w;
+    for (int q = 0; q < 4; ++q) {
+        const int ch = q * 64 + lane;
+        if (ch < chunks) *(f32x4*)(urow + ch * 4) = uw[q];        // broadcast from LDS by every chain step
     }
     const float* a = urow;
     for (int r0 = 0; r0 < total; r0 += FILTER_RB) {
@@ -235,9 +253,10 @@ __global__ __launch_bounds__(256) void filter_finish_kernel(
             }
             *(f32x4*)(rows + r * rstride + ch * 4) = w;
         }
+        const int32_t item = (lane < nr) ? cand[r0 + lane] : item_index_base;
+        const float ibv = (item_bias && lane < nr) ? item_bias[item - item_index_base] : 0.f;   // rides with the row loads
         __builtin_amdgcn_wave_barrier();
         if (lane < nr) {
-            const int32_t item = cand[r0 + lane];
             const float* b = rows + lane * rstride;
             float acc = 0.0f;
             int kk = 0;
@@ -251,7 +270,7 @@ __global__ __launch_bounds__(256) void filter_finish_kernel(
             }
             for (; kk < kdim; ++kk) acc = __fmaf_rn(a[kk], b[kk], acc);
             if (user_bias) acc = acc + bu;
-            if (item_bias) acc = acc + item_bias[item - item_index_base];
+            if (item_bias) acc = acc + ibv;
             key = merge_key(acc, item);
         } else key = EMPTY;
         __builtin_amdgcn_wave_barrier();

@@ -132,6 +132,8 @@ def _a2a_worker(rank, world, port, ret):
         # item-side maxima of the bf16 filter's bound: MAX all-reduce
         g = sharding.all_reduce_max(torch.tensor([1.0 + rank, 5.0 - rank, 0.5]))
         assert g.tolist() == [float(world), 5.0, 0.5]
+        # the known-answer run bench.py starts a multi-GPU launch with (all-gather, all-to-all, all-reduce SUM / MAX)
+        assert sharding.a2a_available(torch.zeros(1)) and sharding.collective_selfcheck(torch.device("cpu")) == "ok"
         ret[rank] = "ok"
     finally:
         dist.destroy_process_group()
