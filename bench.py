@@ -100,12 +100,13 @@ def cpu_baseline(n_items, d, k, n_users_sample, seed=0):
                       "d=%d, top-%d, %.1f s" % (n_users_sample, n_items, d, k, dt)}
 
 
-def cpu_baseline_fit(n_users_total, n_items, d, per_user=20, n_sampled=100, shard_sizes=(2048, 8192), seed=0):
+def cpu_baseline_fit(n_users_total, n_items, d, per_user=20, n_sampled=100, shard_sizes=(4096, 49152), seed=0):
     """CPU leg of the fit half of the metric: ONE optimiser step of the oracle's model (oracle/model.py -- the restated
     _build_tf_graph + TF-form Adam, torch-CPU autograd, float32, all host cores) on user shards of the same 1M-item,
     d = 128, WMRB workload.  A step costs a + b * users (a: the item-side dense work -- 1M x 128 weights, their Adam
     update; b: per-user pairs), so two shard sizes are timed and the full epoch (one step over ALL users, as on the GPU)
-    is a + b * n_users_total."""
+    is a + b * n_users_total.  (The shards are 12x apart: with 2,048 / 8,192 users the slope was the difference of two
+    ~22 s measurements 0.2-0.9 s apart and the extrapolation moved between 46 s and 130 s from run to run.)"""
     import scipy.sparse as sp
     import torch
     from oracle import oracle as O

@@ -13,7 +13,8 @@ import os
 import torch  # noqa: F401  (must be imported first: it loads the HIP runtime that the library binds to)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtensorrec_hip.so")
+# TREC_HIP_LIB: another build of the same library (A/B runs of kernel variants on one box); default: the in-tree build
+LIB_PATH = os.environ.get("TREC_HIP_LIB") or os.path.join(_HERE, "libtensorrec_hip.so")
 
 _vp, _i32, _i64, _u32, _u64, _f = (ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32,
                                    ctypes.c_uint64, ctypes.c_float)

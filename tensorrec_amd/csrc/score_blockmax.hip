@@ -34,7 +34,7 @@ __device__ __forceinline__ int swz16(int row, int ch) {
 // one workgroup per CU -- half the LDS reads, tile loads and barriers per flop, the wave hides its own latencies)
 // OVL: two accumulator sets, the epilogue of a block under the next block's MFMAs (false: one set, the epilogue right
 // after the block -- the register plan that lets a wave own 96 users)
-template <int KT, bool BIAS, int NCB, int WPS, bool OVL = true>
+template <int KT, bool BIAS, int NCB, int WPS, bool OVL = true, int NBUF = 2>
 __global__ __launch_bounds__(256, WPS) void blockmax_pipe_kernel(ScoreParams p)
 {
     constexpr int RB = KT * 2;               // bytes per operand row
@@ -47,8 +47,10 @@ __global__ __launch_bounds__(256, WPS) void blockmax_pipe_kernel(ScoreParams p)
     constexpr int OPS = (NOPS + KS - 4) / (KS - 3);     // ops per step: the epilogue runs in local steps 1 .. KS-3
     static_assert(KT == 64 || KT == 128, "pipelined BLOCKMAX covers K = 64 / 128");
 
-    extern __shared__ __attribute__((aligned(16))) char smem[];    // [2][TILE_BYTES] item tiles | [2][BN] item biases
-    float* side = (float*)(smem + 2 * TILE_BYTES);
+    // NBUF LDS buffers: tile t is computed while tiles t+1 .. t+NBUF-1 are in flight (global_load_lds).  Two is the
+    // shipped form: a third buffer (two tiles of MFMAs for a tile's loads to land) measured 1.2% SLOWER.
+    extern __shared__ __attribute__((aligned(16))) char smem[];    // [NBUF][TILE_BYTES] item tiles | [NBUF][BN] item biases
+    float* side = (float*)(smem + NBUF * TILE_BYTES);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -83,14 +85,20 @@ __global__ __launch_bounds__(256, WPS) void blockmax_pipe_kernel(ScoreParams p)
         slot_off[i] = row * RB + ((pc ^ swz16(row, CH)) * 16);
     }
     const char* t_chunk = (const char*)p.T + t_begin * (int64_t)RB;
-    float side_b = 0.f;
+    // the item-bias row of a tile travels like the tile itself: wave 0 issues ONE 4-byte-per-lane global_load_lds (no
+    // staging register, no commit store); a NULL item bias (user biases only) is a row of zeros
     auto stage_issue = [&](int tile, int buf) {
         const int64_t row0 = t_begin + (int64_t)tile * BN;
         const bool clamp = row0 + BN > p.n_t;                    // wave-uniform: only the very last tile
-        if (BIAS && tid < BN) {
-            int64_t g = row0 + tid;
+        if (BIAS && wave == 0) {
+            int64_t g = row0 + lane;
             if (g >= p.n_t) g = p.n_t - 1;                       // duplicate of the last valid item: max unchanged
-            side_b = p.t_bias ? p.t_bias[g] : 0.f;
+            if (p.t_bias) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.t_bias + g),
+                                                 (__attribute__((address_space(3))) void*)(side + buf * BN), 4, 0, 0);
+            } else {
+                side[buf * BN + lane] = 0.f;
+            }
         }
         const char* tile_base = t_chunk + (int64_t)tile * (BN * RB);
 #pragma unroll
@@ -106,9 +114,17 @@ __global__ __launch_bounds__(256, WPS) void blockmax_pipe_kernel(ScoreParams p)
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         }
     };
-    auto stage_commit = [&](int buf) {
-        if (BIAS && tid < BN) side[buf * BN + tid] = side_b;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // wait until the OLDEST tile in flight has landed, leaving `younger` newer tiles' loads outstanding (loads retire in
+    // issue order; wave 0 carries one more load per tile: the bias row)
+    auto stage_wait = [&](int younger) {
+        if (younger == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (younger == 1) {
+            if (BIAS && p.t_bias && wave == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSLOT + 1) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSLOT) : "memory");
+        } else {
+            if (BIAS && p.t_bias && wave == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NSLOT + 2) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NSLOT) : "memory");
+        }
     };
 
     // ---- per-lane LDS read offsets of the KS operand chunks of "my" item row (row l31 of a 32-row block) ----
@@ -241,19 +257,27 @@ __global__ __launch_bounds__(256, WPS) void blockmax_pipe_kernel(ScoreParams p)
         }
     };
 
-    stage_issue(0, 0);
-    stage_commit(0);
+    // prologue: NBUF - 1 tiles in flight, tile 0 landed
+#pragma unroll
+    for (int i = 0; i < NBUF - 1; ++i)
+        if (i < n_tiles) stage_issue(i, i);
+    {
+        const int inflight = (n_tiles < NBUF - 1 ? n_tiles : NBUF - 1) - 1;        // tiles issued after tile 0
+        stage_wait(inflight);
+    }
     __syncthreads();
 
+    int buf = 0;
     for (int t = 0; t < n_tiles; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < n_tiles) stage_issue(t + 1, buf ^ 1);
+        if (t + NBUF - 1 < n_tiles) stage_issue(t + NBUF - 1, (buf + NBUF - 1) % NBUF);
         if (OVL) {
             if (buf == 0) tile_body(std::integral_constant<int, 0>{});
-            else tile_body(std::integral_constant<int, 1>{});
+            else if (buf == 1 || NBUF == 2) tile_body(std::integral_constant<int, 1>{});
+            else tile_body(std::integral_constant<int, NBUF - 1>{});
         } else {
             if (buf == 0) tile_body_single(std::integral_constant<int, 0>{});
-            else tile_body_single(std::integral_constant<int, 1>{});
+            else if (buf == 1 || NBUF == 2) tile_body_single(std::integral_constant<int, 1>{});
+            else tile_body_single(std::integral_constant<int, NBUF - 1>{});
         }
 
         if (((t + 1) % p.sb_tiles) == 0 || t + 1 == n_tiles) {
@@ -272,8 +296,14 @@ __global__ __launch_bounds__(256, WPS) void blockmax_pipe_kernel(ScoreParams p)
                 for (int r = 0; r < 16; ++r) accB[cb][r] = -INFINITY;        // the deferred epilogue becomes a no-op
             }
         }
-        if (t + 1 < n_tiles) stage_commit(buf ^ 1);
+        if (t + 1 < n_tiles) {
+            // tile t + 1 must have landed; tiles t + 2 .. min(t + NBUF - 1, n_tiles - 1) stay in flight
+            int younger = n_tiles - 2 - t;
+            if (younger > NBUF - 2) younger = NBUF - 2;
+            stage_wait(younger);
+        }
         __syncthreads();
+        buf = (buf + 1 == NBUF) ? 0 : buf + 1;
     }
 }
 
@@ -452,11 +482,11 @@ int launch_f32(ScoreParams p, int sb_rows, hipStream_t st)
     return trec_check_launch("trec_score_gemm_blockmax (pipelined fp32)");
 }
 
-template <int KT, bool BIAS, int NCB, int WPS, bool OVL = true>
-int launch_one(ScoreParams p, hipStream_t st)
+template <int KT, bool BIAS, int NCB, int WPS, bool OVL, int NBUF>
+int launch_one_nbuf(ScoreParams p, hipStream_t st)
 {
-    constexpr int LDS = 2 * BN * KT * 2 + 2 * BN * 4;
-    auto kern = blockmax_pipe_kernel<KT, BIAS, NCB, WPS, OVL>;
+    constexpr int LDS = NBUF * BN * KT * 2 + NBUF * BN * 4;
+    auto kern = blockmax_pipe_kernel<KT, BIAS, NCB, WPS, OVL, NBUF>;
     static bool attr_set = false;
     if (!attr_set && LDS > 32 * 1024) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -466,6 +496,17 @@ int launch_one(ScoreParams p, hipStream_t st)
     const unsigned blocks = (unsigned)p.n_rblocks * (unsigned)p.n_chunks;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), LDS, st, p);
     return trec_check_launch("trec_score_gemm_blockmax (pipelined)");
+}
+
+// Two LDS buffers by default; "blockmax_nbuf" = 3 selects the triple-buffered form.  Measured on one box, 1M x 1M x 128,
+// biased (profiles/r02_stage1_ab.txt): round-1 kernel 165.7 ms | 2 buffers with the bias row through global_load_lds
+// (no staging register, no commit store) 164.6 ms | 3 buffers 166.7 ms -- a tile's loads already land within one tile of
+// MFMAs; the third buffer only costs LDS.
+template <int KT, bool BIAS, int NCB, int WPS, bool OVL = true>
+int launch_one(ScoreParams p, hipStream_t st)
+{
+    if (trec_get_tuning("blockmax_nbuf", 2) == 3) return launch_one_nbuf<KT, BIAS, NCB, WPS, OVL, 3>(p, st);
+    return launch_one_nbuf<KT, BIAS, NCB, WPS, OVL, 2>(p, st);
 }
 
 }  // namespace
