@@ -301,7 +301,7 @@ def main():
     floor_fn, topk_fn = sharding.shared_topk_floor, sharding.sharded_top_k
     if world > 1:
         selfcheck = sharding.collective_selfcheck(device)
-        if sharding.a2a_available(w_u):
+        if sharding.a2a_available(w_u) and selfcheck == "ok":
             floor_fn, topk_fn = sharding.shared_topk_floor_a2a, sharding.sharded_top_k_a2a
 
     def step():

@@ -212,16 +212,24 @@ def a2a_available(t, group=None):
 def collective_selfcheck(device, group=None):
     """Tiny known-answer run of every collective the scoring / training path uses (all-gather, all-to-all, all-reduce SUM
     / MAX): the first thing bench.py does on a multi-GPU launch, so a broken RCCL / xGMI setup fails loudly before any
-    number is reported.  Returns 'ok'."""
+    number is reported.  Returns 'ok', or -- identically on every rank -- a message when only the all-to-all answer is
+    wrong (the caller then keeps the all-gather forms of the exchanges)."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     x = torch.arange(world * 3, dtype=torch.float32, device=device) + 100.0 * rank
     g = all_gather_cat(x.reshape(1, -1), group, dim=0)
     want = torch.stack([torch.arange(world * 3, dtype=torch.float32) + 100.0 * r for r in range(world)]).to(device)
     assert torch.equal(g, want), "all-gather self-check failed"
     if a2a_available(x, group):
-        got = _all_to_all_user_slices(x, 0, group)                # [world, 3]: entry s = rank s's values for my slice
         want = torch.stack([torch.arange(rank * 3, rank * 3 + 3, dtype=torch.float32) + 100.0 * s for s in range(world)])
-        assert torch.equal(got.cpu(), want), "all-to-all self-check failed"
+        try:
+            got = _all_to_all_user_slices(x, 0, group)            # [world, 3]: entry s = rank s's values for my slice
+            good = torch.equal(got.cpu(), want)
+        except RuntimeError:                                      # (a backend without all_to_all raises on every rank alike)
+            good = False
+        ok = torch.tensor([1.0 if good else 0.0], device=device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)    # every rank must take the same exchange form
+        if ok.item() != 1.0:
+            return "all-to-all self-check failed: falling back to the all-gather exchange"
     s = torch.tensor([rank + 1.0, 10.0], device=device)
     dist.all_reduce(s, op=dist.ReduceOp.SUM, group=group)
     assert s.tolist() == [world * (world + 1) / 2.0, 10.0 * world], "all-reduce(SUM) self-check failed"
