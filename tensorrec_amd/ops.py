@@ -377,6 +377,9 @@ class _PairScore(torch.autograd.Function):
         return du, dv, dub, dib, None, None, None, None, None
 
 
+DETERMINISTIC_GROUPING = False      # set by TensorRec(deterministic=True) for the duration of a fit call
+
+
 def group_pairs_by_item(xu32, xi32, pairs_per_user, n_items, workspace_with_counts=None, ranks=None, values=None):
     """(indptr_t int64 [n_items+1], users_t int32 [n_pairs], perm_t int32 [n_pairs]) for a pair list, built on the
     device; the order of pairs inside an item's bucket is not fixed (atomic slot assignment).
@@ -387,6 +390,18 @@ def group_pairs_by_item(xu32, xi32, pairs_per_user, n_items, workspace_with_coun
     8-byte scattered store per pair, consumed by trec_spmm_csr_packed."""
     dev = xi32.device
     n_pairs = xi32.numel()
+    if DETERMINISTIC_GROUPING and n_pairs:
+        # bit-reproducible fits (TensorRec(deterministic=True)): a STABLE sort by item keeps the pairs of a bucket in pair
+        # order, so the fp32 sums over a bucket are added in the same order every run (the counting sort below orders a
+        # bucket by atomic arrival).  Negative keys sort to the front and fall before indptr[0].
+        order = torch.sort(xi32, stable=True).indices
+        sorted_keys = xi32[order]
+        indptr_t = torch.searchsorted(sorted_keys, torch.arange(n_items + 1, dtype=torch.int32, device=dev)).to(torch.int64)
+        users = xu32[order] if xu32 is not None else torch.div(order, pairs_per_user, rounding_mode="floor").to(torch.int32)
+        if values is not None and ranks is not None:
+            entries = torch.stack([users.to(torch.int32), values[order].contiguous().view(torch.int32)], dim=1).contiguous()
+            return indptr_t, entries, None
+        return indptr_t, users.to(torch.int32).contiguous(), order.to(torch.int32).contiguous()
     ws32 = workspace_with_counts if workspace_with_counts is not None else \
         torch.empty((2 * n_items,), dtype=torch.int32, device=dev)
     ws64 = torch.empty(((n_items + 1023) // 1024 + 1,), dtype=torch.int64, device=dev)

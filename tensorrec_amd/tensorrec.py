@@ -171,11 +171,16 @@ class TensorRec(object):
                  seed=None,
                  data_parallel=False,
                  process_group=None,
-                 hip_graphs=True):
+                 hip_graphs=True,
+                 deterministic=False):
         """
         A TensorRec recommendation model (arguments as tensorrec/tensorrec.py:28-61).
-        :param precision: 'fp32' (default; exact fp32 MFMA, bit-stable ranks) or 'bf16' (bf16 operands, fp32
-        accumulate) for the dense score contraction in predict / predict_rank / predict_top_k.
+        :param precision: 'fp32' (default; exact float32 results: fp32 MFMA, or -- top-k on large catalogues -- the bf16
+        MFMA contraction as an error-bounded filter with fp32 re-scoring of the survivors, same bits) or 'bf16' (bf16
+        operands, fp32 accumulate, approximate) for predict / predict_rank / predict_top_k.
+        :param deterministic: if True, the item-side sums of sample-based fits are added in pair order (a stable sort
+        of the sampled pairs instead of the atomic counting sort): fits are bit-reproducible run to run, ~25% slower
+        at 1M x 1M.  Default False: reproducible up to fp32 summation order, like TF's own GPU kernels.
         :param device: torch device; default 'cuda' (there is no CPU execution path).
         :param sampler: object with ``sample(n_items, n_users, n_sampled_items, replace, step, device)``;
         default DeviceSampler(seed).
@@ -229,6 +234,7 @@ class TensorRec(object):
         self.data_parallel = bool(data_parallel)
         self.process_group = process_group
         self.hip_graphs = bool(hip_graphs)
+        self.deterministic = bool(deterministic)
         self.cache_uploads = True          # reuse device copies of matrices whose content did not change between fit calls
         self._upload_cache = {}
         if self.data_parallel and seed is None:
@@ -527,6 +533,13 @@ class TensorRec(object):
         # eager execution and replayed; see _GraphedStep
         graphed = {}
         self._graph_pool_owner = []          # graphs captured by this call (they share the first one's memory pool)
+        ops.DETERMINISTIC_GROUPING = bool(getattr(self, "deterministic", False))
+        try:
+            self._run_epochs(epochs, dev_batches, graphed, learning_rate, alpha, batched_alpha, n_sampled_items, verbose)
+        finally:
+            ops.DETERMINISTIC_GROUPING = False
+
+    def _run_epochs(self, epochs, dev_batches, graphed, learning_rate, alpha, batched_alpha, n_sampled_items, verbose):
         for epoch in range(epochs):
             for batch, (inter, uf, itf) in enumerate(dev_batches):
                 step = graphed.get(batch)
@@ -570,7 +583,7 @@ class TensorRec(object):
         self._schedule_mirror = (self._opt_step, self._sample_step)
 
     def _graph_eligible(self, inter, n_sampled_items, verbose):
-        if not self.hip_graphs or self._dp_active() or self._capture is not None:
+        if not self.hip_graphs or self._dp_active() or self._capture is not None or getattr(self, 'deterministic', False):
             return False
         # only steps made of the library's own launches are captured: the built-in capturable losses on built-in
         # graphs.  Separation* losses index with boolean masks (a host sync inside the step) and user-defined torch
