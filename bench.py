@@ -320,8 +320,10 @@ def main():
                 if world > 1:
                     vals, idx = topk_fn(vals, idx, k)
                 return vals, idx, u_f.f32, i_f.f32
-            user_repr = ops.spmm_raw(f_u.indptr, f_u.indices, f_u.values, None, U, f_u.nnz, w_u)          # K1
-            item_repr = ops.spmm_raw(f_i.indptr, f_i.indices, f_i.values, None, n_local, f_i.nnz, w_i)    # K1
+            user_repr = ops.spmm_raw(f_u.indptr, f_u.indices, f_u.values, None, U, f_u.nnz, w_u,          # K1
+                                     one_per_row=f_u.one_per_row)
+            item_repr = ops.spmm_raw(f_i.indptr, f_i.indices, f_i.values, None, n_local, f_i.nnz, w_i,    # K1
+                                     one_per_row=f_i.one_per_row)
             ub = None if args.unbiased else ops.sparse_matvec(f_u, beta_u)
             ib = None if args.unbiased else ops.sparse_matvec(f_i, beta_i)
             if exact and method == "two_stage":
@@ -415,13 +417,15 @@ def main():
     if k1:
         # user-side launches are the even ones (U rows), item-side the odd ones (n_local rows)
         k1_user_ms = float(np.mean(k1[0::2]))
-        bytes_user = U * (4 + 4) + (U + 1) * 8 + U * d * 4 + U * d * 4      # idx int32 + val, indptr int64, gather, store
+        # idx int32 + val, gather, store (+ the int64 row pointer unless every row has exactly one non-zero: not read then)
+        bytes_user = U * (4 + 4) + (0 if f_u.one_per_row else (U + 1) * 8) + U * d * 4 + U * d * 4
         fused_k1 = exact and method == "two_stage" and d in (32, 64, 128, 256) and args.fused_k1
         if fused_k1:
             bytes_user += U * d * 2 + U * 8                                 # + the bf16 image and the two norms per row
         gbs = bytes_user / (k1_user_ms * 1e-3) / 1e9
-        roofline_k1 = {"kernel": "spmm_csr_vec4_kernel (user side, identity features%s)"
-                                 % (", filter-operand epilogue: fp32 + bf16 rows + error norms" if fused_k1 else ""), "bound": "hbm",
+        roofline_k1 = {"kernel": "%s (user side, identity features%s)"
+                                 % ("spmm_one_per_row_kernel" if f_u.one_per_row and not fused_k1 else "spmm_csr_vec4_kernel",
+                                    ", filter-operand epilogue: fp32 + bf16 rows + error norms" if fused_k1 else ""), "bound": "hbm",
                        "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                        "traffic": None, "avg_launch_ms": k1_user_ms, "algorithmic_bytes_per_launch": bytes_user}
 
@@ -479,8 +483,9 @@ def main():
                 write = [float(m) for m in re.findall(re.escape(key) + r"[^\n]*?WRITE_SIZE=([0-9.e+]+)", txt)]
                 if fetch and write:
                     break
-            k1f = re.findall(r"spmm_csr_vec4_kernel<1, 4, 0, true, true[^\n]*?FETCH_SIZE=([0-9.e+]+)", txt)
-            k1w = re.findall(r"spmm_csr_vec4_kernel<1, 4, 0, true, true[^\n]*?WRITE_SIZE=([0-9.e+]+)", txt)
+            k1_pat = "spmm_one_per_row_kernel" if f_u.one_per_row else "spmm_csr_vec4_kernel<1, 4, 0, true, true"
+            k1f = re.findall(re.escape(k1_pat) + r"[^\n]*?FETCH_SIZE=([0-9.e+]+)", txt)
+            k1w = re.findall(re.escape(k1_pat) + r"[^\n]*?WRITE_SIZE=([0-9.e+]+)", txt)
             if k1f and k1w and roofline_k1 is not None:          # per-dispatch averages over the user- and item-side launch
                 roofline_k1["traffic"] = (2.0 * float(k1f[0]) + float(k1w[0])) * 1024.0
             if fetch and write:

@@ -51,6 +51,11 @@ int trec_get_tuning(const char* name, int dflt);
 int trec_spmm_csr(const int64_t* indptr, const int32_t* indices, const float* values, const int32_t* val_perm,
                   int64_t n_rows, int64_t nnz, const float* W, int32_t d, const float* col_bias, int32_t epilogue,
                   int32_t accumulate, float* out, float* out_inv_norm, void* stream);
+/* K1 for matrices with exactly ONE non-zero per row (identity / indicator features -- every user or item is its own
+ * feature, the case of BASELINE configs[2]): out[r] = values[r] * W[indices[r]].  The row pointer is the identity and is
+ * not read.  d % 4 == 0, d <= 1024; indices / values 16-byte aligned. */
+int trec_spmm_one_per_row(const int32_t* indices, const float* values, int64_t n_rows, const float* W, int32_t d, float* out,
+                          void* stream);
 /* K1 with the operand of the filtered top-k (K2f) as its epilogue: out = X . W in fp32 AND its bf16 image [n_rows, d],
  * row_stats [n_rows][2] = {||row||, ||row - bf16(row)||} and (gstats non-NULL, zero-initialised) their running maxima --
  * what trec_score_prep_filter computes in a separate pass.  d = 32 / 64 / 128 / 256 (no padding), dot products (no

@@ -15,6 +15,8 @@ def t(fn, n=20):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / n
 plain = t(lambda: ops.spmm_raw(f.indptr, f.indices, f.values, None, U, f.nnz, w))
+one = t(lambda: ops.spmm_raw(f.indptr, f.indices, f.values, None, U, f.nnz, w, one_per_row=True))
+print("one-per-row kernel %.4f ms %.0f GB/s" % (one, (U * 8 + 2 * U * d * 4) / one / 1e6))
 fused = t(lambda: ops.spmm_filter_operand(f, w, want_gstats=True))
 r = ops.spmm_raw(f.indptr, f.indices, f.values, None, U, f.nnz, w)
 prep = t(lambda: ops.score_prep_filter(r, want_gstats=True))

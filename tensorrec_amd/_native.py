@@ -28,6 +28,7 @@ SIGNATURES = {
     "trec_set_tuning": [ctypes.c_char_p, _i32],
     "trec_get_tuning": [ctypes.c_char_p, ctypes.c_int],
     "trec_spmm_csr": [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp],
+    "trec_spmm_one_per_row": [_vp, _vp, _i64, _vp, _i32, _vp, _vp],
     "trec_spmm_csr_filter": [_vp, _vp, _vp, _i64, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
     "trec_absmax": [_vp, _i64, _vp, _vp],
     "trec_spmm_csr_packed": [_vp, _vp, _i64, _vp, _i32, _i32, _i32, _vp, _vp, _vp],

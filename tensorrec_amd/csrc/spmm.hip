@@ -519,6 +519,80 @@ extern "C" int trec_spmm_csr(const int64_t* indptr, const int32_t* indices, cons
     return TREC_OK;
 }
 
+// ---- exactly ONE non-zero per row (identity / indicator features: every user or item is its own feature) -------------
+// out[r] = values[r] * W[indices[r]]: the CSR row pointer is the identity, so it is neither read (8 bytes per row and one
+// hop of the indptr -> index -> row load chain less) nor needed.  A 32-lane group (d = 128; d / 4 lanes in general, ITERS
+// float4 per lane) owns 4 consecutive rows: ONE 16-byte load fetches their four column indices, one their four values.
+template <int ITERS>
+__global__ __launch_bounds__(256) void spmm_one_per_row_kernel(const int32_t* __restrict__ indices,
+                                                              const float* __restrict__ values, int64_t n_rows,
+                                                              const float* __restrict__ W, int d, int lpr_log2,
+                                                              float* __restrict__ out)
+{
+    const int lpr = 1 << lpr_log2;
+    const int sub_lane = threadIdx.x & (lpr - 1);
+    const int64_t sg = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> lpr_log2;
+    const int64_t row0 = sg * 4;
+    if (row0 >= n_rows) return;
+    int32_t c[4];
+    float v[4];
+    if (row0 + 3 < n_rows) {
+        const int4 c4 = *(const int4*)(indices + row0);
+        const f32x4 v4 = *(const f32x4*)(values + row0);
+        c[0] = c4.x; c[1] = c4.y; c[2] = c4.z; c[3] = c4.w;
+        v[0] = v4[0]; v[1] = v4[1]; v[2] = v4[2]; v[3] = v4[3];
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool ok = row0 + r < n_rows;
+            c[r] = ok ? indices[row0 + r] : 0;
+            v[r] = ok ? values[row0 + r] : 0.f;
+        }
+    }
+    f32x4 x[4][ITERS];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int col = (it * lpr + sub_lane) * 4;
+            x[r][it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (col < d && row0 + r < n_rows)
+                x[r][it] = __builtin_nontemporal_load((const f32x4*)(W + (int64_t)c[r] * d + col));
+        }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int col = (it * lpr + sub_lane) * 4;
+            if (col < d && row0 + r < n_rows) {
+                f32x4 o;                                   // fmaf(v, w, 0) of the oracle's chain == v * w
+                o[0] = v[r] * x[r][it][0]; o[1] = v[r] * x[r][it][1]; o[2] = v[r] * x[r][it][2]; o[3] = v[r] * x[r][it][3];
+                __builtin_nontemporal_store(o, (f32x4*)(out + (row0 + r) * (int64_t)d + col));
+            }
+        }
+}
+
+extern "C" int trec_spmm_one_per_row(const int32_t* indices, const float* values, int64_t n_rows, const float* W, int32_t d,
+                                     float* out, void* stream)
+{
+    TREC_REQUIRE(indices && values && W && out, "trec_spmm_one_per_row: null pointer");
+    TREC_REQUIRE(d >= 4 && d % 4 == 0 && d <= 1024, "trec_spmm_one_per_row: d must be a multiple of 4 up to 1024");
+    TREC_REQUIRE(((uintptr_t)indices % 16) == 0 && ((uintptr_t)values % 16) == 0, "trec_spmm_one_per_row: 16-byte aligned index / value arrays");
+    if (n_rows == 0) return TREC_OK;
+    const int n4 = d / 4;
+    int lpr_log2 = pow2ceil_log2(n4);
+    if (lpr_log2 > 6) lpr_log2 = 6;
+    const int lpr = 1 << lpr_log2;
+    const int iters = (n4 + lpr - 1) / lpr;
+    const int64_t threads = ceil_div64(n_rows, 4) * lpr;
+    const unsigned blocks = (unsigned)ceil_div64(threads, 256);
+    hipStream_t st = (hipStream_t)stream;
+    if (iters == 1) hipLaunchKernelGGL(spmm_one_per_row_kernel<1>, dim3(blocks), dim3(256), 0, st, indices, values, n_rows, W, d, lpr_log2, out);
+    else if (iters == 2) hipLaunchKernelGGL(spmm_one_per_row_kernel<2>, dim3(blocks), dim3(256), 0, st, indices, values, n_rows, W, d, lpr_log2, out);
+    else hipLaunchKernelGGL(spmm_one_per_row_kernel<4>, dim3(blocks), dim3(256), 0, st, indices, values, n_rows, W, d, lpr_log2, out);
+    return trec_check_launch("trec_spmm_one_per_row");
+}
+
 // K1 with the filtered top-k's operand as its epilogue (EPI 4): out = X . W (fp32, the exact operand) AND its bf16 image,
 // the per-row {||row||, ||row - bf16(row)||} and -- gstats non-NULL, zero-initialised -- their running maxima.  For
 // representations that go into the score kernels as they are (dot products, d = 32 / 64 / 128 / 256: no padding, no

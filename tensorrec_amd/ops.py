@@ -54,11 +54,17 @@ def _f32c(t):
 
 # ------------------------------------------------------------------------------------------------ K1
 def spmm_raw(indptr, indices, values, perm, n_rows, nnz, w, col_bias=None, epilogue=EPI_NONE, accumulate=False,
-             out=None, want_inv=False):
+             out=None, want_inv=False, one_per_row=False):
     w = _f32c(w)
     d = w.shape[1]
     if out is None:
         out = torch.empty((n_rows, d), dtype=torch.float32, device=w.device)
+    if one_per_row and perm is None and epilogue == EPI_NONE and not accumulate and not want_inv and d % 4 == 0 \
+            and d <= 1024 and nnz == n_rows and N.load().trec_get_tuning(b"spmm_one_per_row", 1):
+        # identity / indicator features (SparseFeatures.one_per_row): the row pointer is the identity and is not read
+        with _timed("spmm_csr"):
+            N.call("trec_spmm_one_per_row", N.ptr(indices), N.ptr(values), n_rows, N.ptr(w), d, N.ptr(out))
+        return out
     inv = torch.empty((n_rows,), dtype=torch.float32, device=w.device) if want_inv else None
     with _timed("spmm_csr"):
         N.call("trec_spmm_csr", N.ptr(indptr), N.ptr(indices), N.ptr(values), N.ptr(perm), n_rows, nnz, N.ptr(w), d,
@@ -141,7 +147,8 @@ class _SpMM(torch.autograd.Function):
     @staticmethod
     def forward(ctx, w, feats):
         ctx.feats = feats
-        return spmm_raw(feats.indptr, feats.indices, feats.values, None, feats.shape[0], feats.nnz, w)
+        return spmm_raw(feats.indptr, feats.indices, feats.values, None, feats.shape[0], feats.nnz, w,
+                        one_per_row=getattr(feats, 'one_per_row', False))
 
     @staticmethod
     def backward(ctx, dout):

@@ -42,6 +42,9 @@ class SparseFeatures(object):
         # longest row / column: the gathers switch to their chunked form above ops.SPLIT_T non-zeros
         self.max_row_nnz = int(np.diff(m.indptr).max()) if m.shape[0] and m.nnz else 0
         self.max_col_nnz = int(np.bincount(m.indices, minlength=1).max()) if m.nnz else 0
+        # exactly one non-zero in every row (identity / indicator features): K1 then skips the row pointer
+        self.one_per_row = bool(m.shape[0] > 0 and m.nnz == m.shape[0] and
+                                np.array_equal(m.indptr, np.arange(m.shape[0] + 1)))
         self._t = None
 
     @property

@@ -50,6 +50,23 @@ def test_spmm_bit_exact(ops, d):
     assert np.array_equal(got, O.spmm_exact(x, w))
 
 
+@pytest.mark.parametrize("n,d", [(5003, 128), (4096, 64), (7, 4), (1001, 256), (130, 1024)])
+def test_spmm_one_per_row_bit_exact(ops, n, d):
+    """identity / indicator features (exactly one non-zero per row): the kernel that skips the row pointer."""
+    rng = np.random.default_rng(n + d)
+    cols = rng.integers(0, 977, n)
+    x = sp.csr_matrix((rng.standard_normal(n).astype(np.float32), (np.arange(n), cols)), shape=(n, 977))
+    w = rng.standard_normal((977, d)).astype(np.float32)
+    f = feats(x)
+    assert f.one_per_row
+    got = ops.spmm_raw(f.indptr, f.indices, f.values, None, n, f.nnz, dev(w), one_per_row=True).cpu().numpy()
+    assert np.array_equal(got, O.spmm_exact(x, w))
+    generic = ops.spmm_raw(f.indptr, f.indices, f.values, None, n, f.nnz, dev(w)).cpu().numpy()
+    assert np.array_equal(got, generic)
+    two = sp.csr_matrix(([1.0, 2.0, 3.0], ([0, 0, 1], [1, 2, 0])), shape=(2, 3), dtype=np.float32)
+    assert not feats(two).one_per_row
+
+
 def test_spmm_identity_rows_batched_path(ops):
     """identity-style features (1 nnz per row) take the 4-rows-per-subgroup path (n_rows >= 4096)."""
     rng = np.random.default_rng(0)
