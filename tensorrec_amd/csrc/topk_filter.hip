@@ -48,6 +48,19 @@ __device__ __forceinline__ void atomic_max_nonneg(float* addr, float v)
     if (__float_as_uint(v) > *(volatile unsigned int*)addr) atomicMax((unsigned int*)addr, __float_as_uint(v));
 }
 
+// sum over an aligned 32-lane group with DPP adds (no LDS crossbar): four rotations inside the 16-lane rows, then
+// row_bcast15 carries the first row's total into the second -- complete in lanes 16..31 of the group (cf. wmrb_fused.hip)
+__device__ __forceinline__ float dpp_sum32_upper(float x)
+{
+    int v, r;
+    v = __float_as_int(x); r = __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, false); x += __int_as_float(r);
+    v = __float_as_int(x); r = __builtin_amdgcn_update_dpp(0, v, 0x124, 0xf, 0xf, false); x += __int_as_float(r);
+    v = __float_as_int(x); r = __builtin_amdgcn_update_dpp(0, v, 0x122, 0xf, 0xf, false); x += __int_as_float(r);
+    v = __float_as_int(x); r = __builtin_amdgcn_update_dpp(0, v, 0x121, 0xf, 0xf, false); x += __int_as_float(r);
+    v = __float_as_int(x); r = __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false); x += __int_as_float(r);
+    return x;
+}
+
 // G lanes own one row; a lane handles float4 chunks (kt <= 256 = 2 * 32 lanes * 4).  Same normalisation arithmetic
 // as score_prep_vec4_kernel (score_gemm.hip), so out_f32 / out_bf16 are bit-identical to trec_score_prep's outputs.
 template <int G>
@@ -103,11 +116,13 @@ __global__ __launch_bounds__(256) void prep_filter_kernel(const float* __restric
             *(uint2*)(out_bf16 + row * (int64_t)kt + c) = pk;
         }
     }
-    for (int off = G / 2; off > 0; off >>= 1) { sw += __shfl_xor(sw, off, 64); se += __shfl_xor(se, off, 64); }
-    if (sub == 0 && ok) row_stats[row] = make_float2(sqrtf(sw), sqrtf(se));
+    int writer = 0;                                        // the lane of the group that ends up with the sums
+    if (G == 32) { sw = dpp_sum32_upper(sw); se = dpp_sum32_upper(se); writer = 31; }
+    else for (int off = G / 2; off > 0; off >>= 1) { sw += __shfl_xor(sw, off, 64); se += __shfl_xor(se, off, 64); }
+    if (sub == writer && ok) row_stats[row] = make_float2(sqrtf(sw), sqrtf(se));
     if (gstats) {
-        float nw = (sub == 0 && ok) ? sqrtf(sw) : 0.f, ne = (sub == 0 && ok) ? sqrtf(se) : 0.f;
-        float ab = (sub == 0 && ok && bias) ? fabsf(bias[row]) : 0.f;
+        float nw = (sub == writer && ok) ? sqrtf(sw) : 0.f, ne = (sub == writer && ok) ? sqrtf(se) : 0.f;
+        float ab = (sub == writer && ok && bias) ? fabsf(bias[row]) : 0.f;
         // (one atomic per wave, not per row)  NaN must poison the bound, and fmaxf would drop it: turn it into +inf
         if (nw != nw) nw = INFINITY;
         if (ne != ne) ne = INFINITY;
