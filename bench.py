@@ -29,6 +29,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 BF16_DENSE_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+INT8_DENSE_PEAK_TOPS = 5000.0       # MI355X_MICROARCH.md: I8 MFMA "~2x bf16 rate" (no spec row; its ubench ceiling is >= 3944 TOPS)
 FP32_MFMA_PEAK_TFLOPS = 157.3
 HBM_PEAK_GBS = 8000.0
 
@@ -45,6 +46,8 @@ def parse():
     ap.add_argument("--precision", default="exact", choices=["exact", "bf16", "fp32"],
                     help="exact (default): fp32 results, contraction on bf16 MFMA as an error-bounded filter + fp32 "
                          "re-scoring of the survivors; bf16: approximate bf16 scores; fp32: fp32 MFMA throughout")
+    ap.add_argument("--prefilter", default="int8", choices=["int8", "none"],
+                    help="exact mode: int8 MFMA pre-filter in front of the bf16 stage (the cascade of csrc/topk_cascade.hip)")
     ap.add_argument("--variant", type=int, default=int(os.environ.get("TREC_SCORE_VARIANT", "1")))
     ap.add_argument("--chunks", type=int, default=0, help="item chunks per user block (0 = auto)")
     ap.add_argument("--method", default="auto", choices=["auto", "direct", "two_stage"])
@@ -304,6 +307,8 @@ def main():
         if sharding.a2a_available(w_u) and selfcheck == "ok":
             floor_fn, topk_fn = sharding.shared_topk_floor_a2a, sharding.sharded_top_k_a2a
 
+    prefilter = "int8" if exact and args.prefilter == "int8" and kpad in (64, 128) else None
+
     def step():
         with torch.no_grad():
             if exact and method == "two_stage" and d in (32, 64, 128, 256) and args.fused_k1:
@@ -316,7 +321,7 @@ def main():
                     u_f, i_f, k, ub, ib, item_index_base=i_begin, variant=args.variant,
                     n_chunks=args.chunks if args.chunks > 0 else None,
                     floor_exchange=floor_fn if world > 1 else None,
-                    stats_exchange=sharding.all_reduce_max if world > 1 else None)
+                    stats_exchange=sharding.all_reduce_max if world > 1 else None, prefilter=prefilter)
                 if world > 1:
                     vals, idx = topk_fn(vals, idx, k)
                 return vals, idx, u_f.f32, i_f.f32
@@ -334,7 +339,7 @@ def main():
                     u_f, i_f, k, ub, ib, item_index_base=i_begin, variant=args.variant,
                     n_chunks=args.chunks if args.chunks > 0 else None,
                     floor_exchange=floor_fn if world > 1 else None,
-                    stats_exchange=sharding.all_reduce_max if world > 1 else None)
+                    stats_exchange=sharding.all_reduce_max if world > 1 else None, prefilter=prefilter)
                 if world > 1:
                     vals, idx = topk_fn(vals, idx, k)              # every rank finalises ITS users (all-to-all + merge)
                 return vals, idx, user_repr, item_repr
@@ -397,15 +402,28 @@ def main():
     dur = {}
     for name, s, e in events:
         dur.setdefault(name, []).append(s.elapsed_time(e))
-    k2_name = "score_gemm_topk" if method == "direct" else "score_gemm_blockmax"
+    cascade = "score_gemm_blockmax_i8" in dur and "score_gemm_blockmax" not in dur
+    k2_name = "score_gemm_topk" if method == "direct" else ("score_gemm_blockmax_i8" if cascade else "score_gemm_blockmax")
     k2_ms = float(np.mean(dur[k2_name]))
     k2_flops = 2.0 * U * n_local * kpad                    # algorithmic: 2*U*I*d per launch (d = kpad = 128 here)
-    peak = FP32_MFMA_PEAK_TFLOPS if args.precision == "fp32" else BF16_DENSE_PEAK_TFLOPS
+    peak = FP32_MFMA_PEAK_TFLOPS if args.precision == "fp32" else (INT8_DENSE_PEAK_TOPS if cascade else BF16_DENSE_PEAK_TFLOPS)
     k2_tflops = k2_flops / (k2_ms * 1e-3) / 1e12
     k2_label = "score_gemm_kernel (fused top-k epilogue)" if method == "direct" else (
+        "blockmax_i8_kernel (int8 superblock maxima over every (user, item): stage 0 of the int8 -> bf16 -> fp32 cascade; "
+        "int8 multiply-adds counted as 2 ops, peak = 2x the dense bf16 peak)" if cascade else
         "blockmax_pipe_kernel (superblock maxima, stage 1 of the two-stage top-k)"
         if args.precision != "fp32" and kpad in (64, 128) and T._native.load().trec_get_tuning(b"blockmax_pipelined", 1)
         else "score_gemm_kernel (superblock-max epilogue)")
+    roofline_bf16_stage = None
+    if cascade and "score_gemm_blockmax_grouped" in dur:
+        rows = float(ops.LAST_FILTER_STATS.get("refined_rows", 0))
+        g_ms = float(np.mean(dur["score_gemm_blockmax_grouped"]))
+        g_tf = 2.0 * rows * ops.SUPERBLOCK_ROWS * kpad / (g_ms * 1e-3) / 1e12
+        roofline_bf16_stage = {"kernel": "blockmax_pipe_kernel, grouped form (bf16 maxima of the (superblock, user) pairs "
+                                         "the int8 bound cannot rule out)", "bound": "mfma", "achieved": g_tf,
+                               "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": g_tf / BF16_DENSE_PEAK_TFLOPS,
+                               "avg_launch_ms": g_ms, "resident_rows": rows,
+                               "refined_fraction_of_pairs": rows / (float(U) * ((n_local + ops.SUPERBLOCK_ROWS - 1) // ops.SUPERBLOCK_ROWS))}
     roofline = {"kernel": k2_label,
                 "bound": "mfma", "achieved": k2_tflops,
                 "peak": peak, "unit": "TFLOP/s", "frac": k2_tflops / peak, "traffic": None,
@@ -478,7 +496,8 @@ def main():
         if files and world == 1 and (U, I, d) == (1_000_000, 1_000_000, 128) and method == "two_stage":
             txt = open(files[-1]).read()
             fetch = write = None
-            for key in ("blockmax_pipe_kernel<128", "score_gemm_kernel<1, 128, 64, 2, 2"):     # stage-1 kernel names
+            for key in (("blockmax_i8_kernel<128",) if cascade else
+                        ("blockmax_pipe_kernel<128", "score_gemm_kernel<1, 128, 64, 2, 2")):     # stage-1 kernel names
                 fetch = [float(m) for m in re.findall(re.escape(key) + r"[^\n]*?FETCH_SIZE=([0-9.e+]+)", txt)]
                 write = [float(m) for m in re.findall(re.escape(key) + r"[^\n]*?WRITE_SIZE=([0-9.e+]+)", txt)]
                 if fetch and write:
@@ -492,7 +511,8 @@ def main():
                 roofline["traffic"] = (2.0 * fetch[0] + write[0]) * 1024.0
                 roofline["traffic_note"] = ("bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KB from %s; fabric-side "
                                             "reads incl. Infinity-Cache hits; algorithmic minimum is %.3g bytes"
-                                            % (os.path.basename(files[-1]), (U + n_local) * kpad * 2.0 + U * 4.0 * (n_local // 512)))
+                                            % (os.path.basename(files[-1]),
+                                               (U + n_local) * kpad * (1.0 if cascade else 2.0) + U * 4.0 * (n_local // 512)))
     except Exception:
         pass
 
@@ -568,8 +588,11 @@ def main():
         "metric": "user-item predictions/sec", "value": value, "unit": "predictions/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None,
-        "dtype": "fp32" if args.precision == "fp32" else "bf16",      # arithmetic type of the dominant (MFMA) kernel
-        "result_precision": "fp32-exact (bf16 MFMA filter with a proven error bound + fp32 re-scoring of the survivors)"
+        # arithmetic type of the dominant (MFMA) kernel
+        "dtype": "fp32" if args.precision == "fp32" else ("i8" if cascade else "bf16"),
+        "result_precision": ("fp32-exact (int8 MFMA pre-filter -> bf16 MFMA filter, both with proven error bounds -> fp32 "
+                             "re-scoring of the survivors)" if cascade else
+                             "fp32-exact (bf16 MFMA filter with a proven error bound + fp32 re-scoring of the survivors)")
                             if exact else args.precision,
         "data": "synthetic",
         "config": {"workload": "synthetic %d users x %d items, identity features, d=%d, LinearRepresentation + "
@@ -581,7 +604,7 @@ def main():
                    "collective_selfcheck": selfcheck,
                    "topk_method": method,
                    "score_kernel_variant": "global_load_lds" if args.variant & 1 else "register-staged"},
-        "roofline": roofline, "roofline_k1": roofline_k1, "roofline_k1_multi_nnz": roofline_k1_multi, "cpu_baseline": cpu, "parity": parity,
+        "roofline": roofline, "roofline_bf16_stage": roofline_bf16_stage, "roofline_k1": roofline_k1, "roofline_k1_multi_nnz": roofline_k1_multi, "cpu_baseline": cpu, "parity": parity,
         "fp32_mfma_mode": fp32_mode, "fit": fit,
         "roofline_fit": (fit or {}).get("roofline_fit"), "cpu_baseline_fit": cpu_fit,
     }

@@ -34,7 +34,10 @@ __device__ __forceinline__ int swz16(int row, int ch) {
 // one workgroup per CU -- half the LDS reads, tile loads and barriers per flop, the wave hides its own latencies)
 // OVL: two accumulator sets, the epilogue of a block under the next block's MFMAs (false: one set, the epilogue right
 // after the block -- the register plan that lets a wave own 96 users)
-template <int KT, bool BIAS, int NCB, int WPS, bool OVL = true, int NBUF = 2>
+// GRP (grouped form, stage 2 of the int8 cascade): workgroup w owns superblock rblock_chunk[w] only; its resident rows are
+// users row_index[w * rows + r] (-1 = padding row) and each maximum goes to blockmax[superblock][that user] -- the refined
+// entries of the table the int8 stage wrote.
+template <int KT, bool BIAS, int NCB, int WPS, bool OVL = true, int NBUF = 2, bool GRP = false>
 __global__ __launch_bounds__(256, WPS) void blockmax_pipe_kernel(ScoreParams p)
 {
     constexpr int RB = KT * 2;               // bytes per operand row
@@ -56,8 +59,9 @@ __global__ __launch_bounds__(256, WPS) void blockmax_pipe_kernel(ScoreParams p)
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
-    const int rblock = blockIdx.x % p.n_rblocks;
-    const int chunk = blockIdx.x / p.n_rblocks;
+    const int rblock = GRP ? (int)blockIdx.x : (int)(blockIdx.x % p.n_rblocks);
+    const int chunk = GRP ? p.rblock_chunk[rblock] : (int)(blockIdx.x / p.n_rblocks);
+    if (GRP && chunk < 0) return;                                // idle workgroup of the grouped launch
     const int64_t r_base = ((int64_t)rblock * 4 + wave) * (NCB * 32);
     const int64_t t_begin = (int64_t)chunk * p.chunk_len;
     const int64_t t_end = (t_begin + p.chunk_len < p.n_t) ? t_begin + p.chunk_len : p.n_t;
@@ -66,10 +70,15 @@ __global__ __launch_bounds__(256, WPS) void blockmax_pipe_kernel(ScoreParams p)
     // ---- resident user fragments, straight from global, once ----
     bf16x8 rfb[NCB][KS];
     float r_bias[NCB];
+    int32_t dst_user[GRP ? NCB : 1];
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
         int64_t row = r_base + cb * 32 + l31;
         if (row >= p.n_r) row = p.n_r - 1;                       // clamped rows are never written
+        if (GRP) {
+            dst_user[cb] = p.row_index[row];
+            row = dst_user[cb] < 0 ? 0 : dst_user[cb];           // padding rows compute on user 0, never written
+        }
         const char* src = (const char*)p.R + row * (int64_t)RB;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) rfb[cb][ks] = *(const bf16x8*)(src + (ks * 2 + half) * 16);
@@ -290,7 +299,9 @@ __global__ __launch_bounds__(256, WPS) void blockmax_pipe_kernel(ScoreParams p)
                 float v = fmaxf(bm[cb], __shfl_xor(bm[cb], 32, 64));
                 if (BIAS) v = v + r_bias[cb];
                 const int64_t u = r_base + cb * 32 + l31;
-                if (half == 0 && u < p.n_r) p.blockmax[sb * p.bm_stride + u] = v;
+                if (GRP) {
+                    if (half == 0 && dst_user[cb] >= 0) p.blockmax[(int64_t)chunk * p.bm_stride + dst_user[cb]] = v;
+                } else if (half == 0 && u < p.n_r) p.blockmax[sb * p.bm_stride + u] = v;
                 bm[cb] = -INFINITY;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) accB[cb][r] = -INFINITY;        // the deferred epilogue becomes a no-op
@@ -510,6 +521,31 @@ int launch_one(ScoreParams p, hipStream_t st)
 }
 
 }  // namespace
+
+// grouped form: p.n_r padded resident rows (a multiple of 512), p.rblock_chunk [n_r / 512], p.row_index [n_r],
+// p.chunk_len = the superblock height
+template <int KT, bool BIAS>
+int launch_grouped(ScoreParams p, hipStream_t st)
+{
+    constexpr int LDS = 2 * BN * KT * 2 + 2 * BN * 4;
+    auto kern = blockmax_pipe_kernel<KT, BIAS, 4, 2, false, 2, true>;
+    static bool attr_set = false;
+    if (!attr_set && LDS > 32 * 1024) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    p.n_rblocks = (int)(p.n_r / 512);
+    hipLaunchKernelGGL(kern, dim3((unsigned)p.n_rblocks), dim3(256), LDS, st, p);
+    return trec_check_launch("trec_score_gemm_blockmax_grouped");
+}
+
+int launch_blockmax_pipelined_grouped(const ScoreParams& p, int kt, hipStream_t st)
+{
+    const bool bias = p.r_bias || p.t_bias;
+    if (kt == 128) return bias ? launch_grouped<128, true>(p, st) : launch_grouped<128, false>(p, st);
+    if (kt == 64) return bias ? launch_grouped<64, true>(p, st) : launch_grouped<64, false>(p, st);
+    return TREC_ERR_UNSUPPORTED;
+}
 
 int launch_blockmax_pipelined(const ScoreParams& p, int kt, hipStream_t st)
 {

@@ -32,10 +32,13 @@ struct ScoreParams {
     const float* row_floor;        // nullable [n_r]: a known lower bound of the row's final k-th best score (lists start there)
     const int32_t* row_index;      // grouped TOPK: nullable [n_r], resident row r is R[row_index[r]] (bias / sqnorm / floor too)
     int independent_lists;         // grouped TOPK: a list's threshold never rises from the partner half-wave's list (variant bit 4)
+    const float* scales;           // int8 BLOCKMAX (score_blockmax_i8.hip): device float[3], [2] = integer score units -> float
 };
 
 // software-pipelined BLOCKMAX kernel (score_blockmax.hip): bf16 dot / cosine, kpad 64 or 128.  Returns
 // TREC_ERR_UNSUPPORTED when the configuration is not covered (the caller then uses the generic kernel).
 int launch_blockmax_pipelined(const ScoreParams& p, int kt, hipStream_t stream);
+// grouped bf16 form (stage 2 of the int8 cascade): see score_blockmax.hip
+int launch_blockmax_pipelined_grouped(const ScoreParams& p, int kt, hipStream_t stream);
 // the exact fp32 form (kpad 64 or 128, dot / cosine); sb_rows = superblock height in item rows
 int launch_blockmax_pipelined_f32(const ScoreParams& p, int kt, int sb_rows, hipStream_t stream);

@@ -918,8 +918,13 @@ LAST_FILTER_STATS = {}    # diagnostics of the most recent score_topk_filtered c
 class FilterOperand(object):
     """One side of the filtered top-k (trec_score_prep_filter): ``bf16`` [n, kpad] stage-1 / stage-3 operand, ``f32``
     [n, kpad] exact operand (the representation itself when it needs neither padding nor normalising), ``stats`` [n, 2]
-    = {||x||, ||x - bf16(x)||} per row, ``gstats`` [3] = maxima of both and of |bias| over the rows (item side)."""
-    __slots__ = ("bf16", "f32", "n", "d", "kpad", "stats", "gstats")
+    = {||x||, ||x - bf16(x)||} per row, ``gstats`` [3] = maxima of both and of |bias| over the rows (item side).
+    The int8 pre-filter (score_prep_i8_pair) adds ``i8`` [n, kpad] int8, ``stats8`` [n, 2] = {||x||, ||x - scale q||},
+    and on the item side ``bias_q`` int32 [n], ``gstats8`` [4], ``scales`` [3] = {user scale, item scale, product}."""
+    __slots__ = ("bf16", "f32", "n", "d", "kpad", "stats", "gstats", "i8", "stats8", "bias_q", "gstats8", "scales")
+
+    def __init__(self):
+        self.i8 = self.stats8 = self.bias_q = self.gstats8 = self.scales = None
 
 
 def score_prep_filter(repr_, normalize=False, bias=None, want_gstats=False):
@@ -961,15 +966,113 @@ def spmm_filter_operand(features, w, bias=None, want_gstats=False):
     return op
 
 
+I8_USER_CLIP_SIGMAS = 5.0        # user rows clip at 5 rms (a clipped user only widens ITS bound); item rows never clip
+CASCADE_MAX_REFINED = 0.30       # refine at most this fraction of the (superblock, user) pairs; beyond it bf16 does it all
+CASCADE_MIN_ITEMS = 262144       # below ~512 superblocks the k-th largest maximum is not selective enough for int8 to pay
+
+
+def cascade_prefilter_for(n_components, n_items_total):
+    """"int8" when the int8 pre-filter is worth trying for this shape (tuning ``topk_int8_prefilter``, default on), else None."""
+    if N.load().trec_get_tuning(b"topk_int8_prefilter", 1) == 0:
+        return None
+    return "int8" if score_kpad(n_components) in (64, 128) and n_items_total >= CASCADE_MIN_ITEMS else None
+
+
+def score_prep_i8_pair(uop, iop, item_bias=None):
+    """int8 operands of both sides for the cascade's pre-filter (trec_score_prep_i8), from the fp32 operands of
+    FilterOperand (already normalised / padded).  One scale per side: users min(5 rms, max |x|) / 127, items max |x| / 127.
+    The item rows are quantised once per ``iop``; a new batch of users (its own scale) only re-derives the scale product
+    and the item biases in units of it."""
+    if uop.kpad > 128:
+        raise ValueError("int8 pre-filter covers kpad <= 128")
+    dev = uop.f32.device
+    ws = torch.empty((2,), dtype=torch.float64, device=dev)
+    clip = N.load().trec_get_tuning(b"i8_user_clip_x10", int(I8_USER_CLIP_SIGMAS * 10)) / 10.0
+    with _timed("score_prep_i8"):
+        fresh_items = iop.i8 is None
+        if fresh_items:
+            iop.scales = torch.zeros((3,), dtype=torch.float32, device=dev)
+            iop.gstats8 = torch.zeros((4,), dtype=torch.float32, device=dev)
+            iop.i8 = torch.empty((iop.n, iop.kpad), dtype=torch.int8, device=dev)
+            iop.stats8 = torch.empty((iop.n, 2), dtype=torch.float32, device=dev)
+        else:
+            iop.gstats8[2:].zero_()
+        iop.bias_q = torch.empty((iop.n,), dtype=torch.int32, device=dev) if item_bias is not None else None
+        uop.i8 = torch.empty((uop.n, uop.kpad), dtype=torch.int8, device=dev)
+        uop.stats8 = torch.empty((uop.n, 2), dtype=torch.float32, device=dev)
+        N.call("trec_score_prep_i8", N.ptr(uop.f32), uop.n, uop.f32.shape[1], uop.kpad, 0, float(clip), None,
+               N.ptr(iop.scales), N.ptr(ws), N.ptr(uop.i8), N.ptr(uop.stats8), None, None)
+        if fresh_items:
+            N.call("trec_score_prep_i8", N.ptr(iop.f32), iop.n, iop.f32.shape[1], iop.kpad, 1, 0.0, N.ptr(item_bias),
+                   N.ptr(iop.scales), N.ptr(ws), N.ptr(iop.i8), N.ptr(iop.stats8), N.ptr(iop.bias_q), N.ptr(iop.gstats8))
+        else:
+            N.call("trec_score_prep_i8", None, iop.n, iop.f32.shape[1], iop.kpad, 2, 0.0, N.ptr(item_bias),
+                   N.ptr(iop.scales), None, None, None, N.ptr(iop.bias_q), N.ptr(iop.gstats8))
+    return uop, iop
+
+
+def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, floor_exchange, stats_exchange):
+    """Stages 0-1 of the int8 -> bf16 -> fp32 cascade (csrc/topk_cascade.hip): the [n_sb, n_users] table of superblock
+    maxima whose entries are bf16 maxima wherever a top-k item can be and int8 maxima elsewhere.  Returns None when the
+    int8 bound is too loose for this data to pay (more than CASCADE_MAX_REFINED of the pairs would be refined)."""
+    dev = uop.bf16.device
+    n_u, n_i, kpad = uop.n, iop.n, uop.kpad
+    if uop.i8 is None or iop.i8 is None:
+        score_prep_i8_pair(uop, iop, item_bias)
+    stride = (n_u + 3) // 4 * 4
+    table = torch.empty((n_sb, stride), dtype=torch.float32, device=dev)
+    with _timed("score_gemm_blockmax_i8"):
+        N.call("trec_score_gemm_blockmax_i8", N.ptr(uop.i8), N.ptr(iop.i8), kpad, n_u, n_i, N.ptr(user_bias),
+               N.ptr(iop.bias_q), N.ptr(iop.scales), sb_rows, n_chunks, N.ptr(table), stride)
+    kk = int(k)
+    sel = torch.empty((n_u, kk), dtype=torch.int32, device=dev)
+    sel_max = torch.empty((kk, n_u), dtype=torch.float32, device=dev) if floor_exchange is not None else None
+    tau = torch.empty((n_u,), dtype=torch.float32, device=dev)
+    with _timed("topk_select_blocks"):
+        N.call("trec_topk_select_blocks", N.ptr(table), n_sb, n_u, stride, kk, N.ptr(sel), N.ptr(sel_max), N.ptr(tau))
+    gstats8 = iop.gstats8
+    if floor_exchange is not None:
+        tau = floor_exchange(sel_max).contiguous()
+    if stats_exchange is not None:
+        gstats8 = stats_exchange(gstats8).contiguous()
+    floor8 = torch.empty((n_u,), dtype=torch.float32, device=dev)
+    N.call("trec_topk_filter_floor_i8", N.ptr(tau), N.ptr(uop.stats8), N.ptr(user_bias), N.ptr(gstats8), kpad, n_u,
+           N.ptr(floor8), None, None)
+    n_ublk = N.query("trec_topk_rows_user_blocks", n_u)
+    block_off = torch.empty((n_sb * n_ublk,), dtype=torch.int32, device=dev)
+    row_total = torch.empty((n_sb,), dtype=torch.int32, device=dev)
+    row_pad = torch.empty((n_sb,), dtype=torch.int32, device=dev)
+    pstart = torch.empty((n_sb + 1,), dtype=torch.int64, device=dev)
+    with _timed("topk_rows_compact"):
+        N.call("trec_topk_rows_count", N.ptr(table), n_sb, n_u, stride, N.ptr(floor8), N.ptr(block_off), N.ptr(row_total),
+               N.ptr(row_pad), N.ptr(pstart))
+    n_rows_g = int(pstart[n_sb].item())             # the one host read of the cascade: sizes the grouped launch
+    LAST_FILTER_STATS["refined_rows"] = n_rows_g
+    if n_rows_g > CASCADE_MAX_REFINED * n_sb * n_u + 512 * n_sb:
+        return None, stride
+    if n_rows_g:
+        row_user = torch.empty((n_rows_g,), dtype=torch.int32, device=dev)
+        rblock_chunk = torch.empty((n_rows_g // 512,), dtype=torch.int32, device=dev)
+        with _timed("topk_rows_compact"):
+            N.call("trec_topk_rows_fill", N.ptr(table), n_sb, n_u, stride, N.ptr(floor8), N.ptr(block_off), N.ptr(row_total),
+                   N.ptr(pstart), N.ptr(row_user), N.ptr(rblock_chunk))
+        with _timed("score_gemm_blockmax_grouped"):
+            N.call("trec_score_gemm_blockmax_grouped", N.ptr(uop.bf16), N.ptr(iop.bf16), kpad, n_rows_g, n_i,
+                   N.ptr(user_bias), N.ptr(item_bias), sb_rows, N.ptr(rblock_chunk), N.ptr(row_user), N.ptr(table), stride)
+    return table, stride
+
+
 def score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index_base=0, sb_rows=None, variant=1,
-                        n_chunks=None, floor_exchange=None, stats_exchange=None, ksel=None):
+                        n_chunks=None, floor_exchange=None, stats_exchange=None, ksel=None, prefilter=None):
     """EXACT fp32 top-k (values and ids bit-identical to ``score_topk(..., DTYPE_F32)`` and to the oracle) with the
     score matrix contracted ONCE on bf16 MFMA: the bf16 stage-1 maxima and the bf16 re-scoring act as a filter with a
     proven error bound (csrc/topk_filter.hip), the survivors (~15 items per user at 1M x 1M) are re-scored by the
     reference's k-ordered fp32 chain.  ``uop`` / ``iop``: FilterOperand (iop with gstats).  Dot / cosine scores.
     Item shards: ``floor_exchange`` as in score_topk_two_stage, ``stats_exchange(gstats) -> gstats`` = all-reduce MAX of
     the item-side maxima (the bound must cover every shard's items).  Users the filter cannot certify (its capacity
-    limits, non-finite bounds) are re-done on the exact fp32 MFMA path; their number is in LAST_FILTER_STATS."""
+    limits, non-finite bounds) are re-done on the exact fp32 MFMA path; their number is in LAST_FILTER_STATS.
+    ``prefilter="int8"``: stage 1 becomes the cascade of csrc/topk_cascade.hip -- an exact-integer int8 MFMA pass over
+    everything, the bf16 kernel only on the (superblock, user) pairs the int8 bound cannot rule out (kpad 64 / 128)."""
     if not 1 <= int(k) <= 16:
         raise ValueError("fused top-k supports k <= 16 (got %d)" % k)
     cap = 8              # stage-3 lists hold survivors of ONE (user, superblock, half-wave): 0-2 typically; full -> exact fallback
@@ -987,18 +1090,31 @@ def score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index_
     if n_chunks is None:
         rblocks = (n_u + rows_wg - 1) // rows_wg
         n_chunks = max(1, min(n_sb, -(-32 * 768 // rblocks)))
-    # ---- stage 1: bf16 superblock maxima
-    blockmax = torch.empty((n_sb, n_u), dtype=torch.float32, device=dev)
-    with _timed("score_gemm_blockmax"):
-        N.call("trec_score_gemm_blockmax", N.ptr(uop.bf16), N.ptr(iop.bf16), DTYPE_BF16, kpad, n_u, n_i,
-               N.ptr(user_bias), N.ptr(item_bias), MODE_DOT, None, None, sb_rows, n_chunks, N.ptr(blockmax), n_u, variant)
+    LAST_FILTER_STATS.clear()
+    blockmax, bm_stride = None, n_u
+    if prefilter == "int8" and kpad in (64, 128) and sb_rows % 128 == 0:
+        # ---- stages 0 + 1: int8 maxima everywhere, bf16 maxima where a top-k item can be
+        blockmax, bm_stride = _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, floor_exchange,
+                                              stats_exchange)
+        LAST_FILTER_STATS["prefilter"] = "int8" if blockmax is not None else "int8 (too loose: bf16 stage 1 instead)"
+    elif prefilter not in (None, "int8"):
+        raise ValueError("unknown prefilter %r" % (prefilter,))
+    if blockmax is None:
+        # ---- stage 1: bf16 superblock maxima
+        bm_stride = n_u
+        blockmax = torch.empty((n_sb, n_u), dtype=torch.float32, device=dev)
+        with _timed("score_gemm_blockmax"):
+            N.call("trec_score_gemm_blockmax", N.ptr(uop.bf16), N.ptr(iop.bf16), DTYPE_BF16, kpad, n_u, n_i,
+                   N.ptr(user_bias), N.ptr(item_bias), MODE_DOT, None, None, sb_rows, n_chunks, N.ptr(blockmax), n_u,
+                   variant)
     # ---- stage 2, pass 1: tau = k-th largest superblock maximum (a floor of the k-th best bf16 score)
     kk = int(k)
     sel = torch.empty((n_u, kk), dtype=torch.int32, device=dev)
     sel_max = torch.empty((kk, n_u), dtype=torch.float32, device=dev) if floor_exchange is not None else None
     tau = torch.empty((n_u,), dtype=torch.float32, device=dev)
     with _timed("topk_select_blocks"):
-        N.call("trec_topk_select_blocks", N.ptr(blockmax), n_sb, n_u, n_u, kk, N.ptr(sel), N.ptr(sel_max), N.ptr(tau))
+        N.call("trec_topk_select_blocks", N.ptr(blockmax), n_sb, n_u, bm_stride, kk, N.ptr(sel), N.ptr(sel_max),
+               N.ptr(tau))
     gstats = iop.gstats
     if floor_exchange is not None:                  # item shards: the k-th largest maximum over ALL shards
         tau = floor_exchange(sel_max).contiguous()
@@ -1014,8 +1130,8 @@ def score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index_
     keys = torch.empty((n_pairs,), dtype=torch.int32, device=dev)
     count = torch.empty((n_u,), dtype=torch.int32, device=dev)
     with _timed("topk_collect_blocks"):
-        N.call("trec_topk_collect_blocks", N.ptr(blockmax), n_sb, n_u, n_u, N.ptr(floor), ksel, N.ptr(keys), N.ptr(count),
-               N.ptr(flag), N.ptr(n_flagged))
+        N.call("trec_topk_collect_blocks", N.ptr(blockmax), n_sb, n_u, bm_stride, N.ptr(floor), ksel, N.ptr(keys),
+               N.ptr(count), N.ptr(flag), N.ptr(n_flagged))
     del blockmax
     # ---- stage 3a: group the kept (user, slot) pairs by superblock, pad groups to whole workgroups, gather bf16 rows
     indptr_t, users_t, perm_t = group_pairs_by_item(None, keys, ksel, n_sb + 1)
@@ -1048,7 +1164,6 @@ def score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index_
     del pi
     # ---- users the filter could not certify: the exact fp32 MFMA path (one host read of a counter)
     n_bad = int(n_flagged.item())
-    LAST_FILTER_STATS.clear()
     LAST_FILTER_STATS.update({"users": n_u, "flagged_users": n_bad, "ksel": ksel,
                               "kept_superblocks_per_user": float(count.sum().item()) / max(1, n_u)})
     if n_bad:

@@ -926,6 +926,10 @@ class TensorRec(object):
                     n_items_min >= ops.TWO_STAGE_MIN_ITEMS and self.n_components <= 256 and
                     ops.N.load().trec_get_tuning(b"topk_bf16_filter", 1) != 0)
         stats_exchange = (lambda g: sharding.all_reduce_max(g, self.process_group)) if sharded else None
+        # ... and on a catalogue of >= 262,144 items an int8 MFMA pass (exact integer arithmetic, proven bound) first decides
+        # which (superblock, user) pairs the bf16 stage has to look at at all (csrc/topk_cascade.hip)
+        prefilter = ops.cascade_prefilter_for(self.n_components, n_items_min * (dist.get_world_size(self.process_group) if sharded else 1)) \
+            if filtered else None
         vals, idx = [], []
         if self.n_components > ops.SCORE_KMAX:
             # wider than the fused kernels' resident operand: score slabs (K-looped fp32 GEMM) + exact ranks pick the top-k
@@ -962,7 +966,7 @@ class TensorRec(object):
                         u_f = ops.score_prep_filter(user_repr[s:e], normalize=graph.engine_normalize)
                         per_taste.append(ops.score_topk_filtered(u_f, i_f, k, ub, ib, item_index_base=int(item_offset),
                                                                  floor_exchange=floor_exchange,
-                                                                 stats_exchange=stats_exchange))
+                                                                 stats_exchange=stats_exchange, prefilter=prefilter))
                         continue
                     u_op, u_sq, _ = ops.score_prep(user_repr[s:e], dtype, normalize=graph.engine_normalize,
                                                    want_sqnorm=want_sq)
