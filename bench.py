@@ -575,6 +575,40 @@ def main():
         except Exception as exc:
             fp32_mode = {"error": repr(exc)}
 
+    # ---- the bf16-filter form of the same exact top-k (no int8 stage): north_star's bf16 MFMA score kernel, dense, as a
+    # driver-run record beside the cascade that is timed above ----
+    bf16_mode = None
+    if cascade and world == 1 and not args.no_fp32_mode:
+        try:
+            vals, idx, user_repr, item_repr = out
+            ub2 = None if args.unbiased else ops.sparse_matvec(f_u, beta_u)
+            ib2 = None if args.unbiased else ops.sparse_matvec(f_i, beta_i)
+
+            def bf16_step():
+                u_f = ops.score_prep_filter(user_repr)
+                i_f = ops.score_prep_filter(item_repr, bias=ib2, want_gstats=True)
+                return ops.score_topk_filtered(u_f, i_f, k, ub2, ib2, item_index_base=i_begin, variant=args.variant)
+            bf16_step()
+            torch.cuda.synchronize()
+            ops.KERNEL_EVENTS = []
+            t0 = time.perf_counter()
+            reps = 2
+            for _ in range(reps):
+                bv, bi_ = bf16_step()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / reps
+            ev2, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
+            s1 = float(np.mean([a.elapsed_time(b) for n_, a, b in ev2 if n_ == "score_gemm_blockmax"]))
+            bf16_mode = {"workload": "the same %d users x %d items, exact top-%d through the bf16 filter alone (--prefilter none), "
+                                     "operands given" % (U, n_local, k),
+                         "ms": 1e3 * dt, "stage1_kernel": "blockmax_pipe_kernel (dense bf16 superblock maxima)",
+                         "stage1_avg_launch_ms": s1, "stage1_tflops": k2_flops / (s1 * 1e-3) / 1e12,
+                         "stage1_frac_of_bf16_mfma_peak": k2_flops / (s1 * 1e-3) / 1e12 / BF16_DENSE_PEAK_TFLOPS,
+                         "equals_timed_cascade_output": bool(torch.equal(bi_, idx) and torch.equal(bv, vals))}
+        except Exception as exc:
+            ops.KERNEL_EVENTS = None
+            bf16_mode = {"error": repr(exc)}
+
     cpu = cpu_fit = None
     if not args.no_cpu_baseline and world == 1:
         cpu = cpu_baseline(I, d, k, args.cpu_users)
@@ -605,7 +639,7 @@ def main():
                    "topk_method": method,
                    "score_kernel_variant": "global_load_lds" if args.variant & 1 else "register-staged"},
         "roofline": roofline, "roofline_bf16_stage": roofline_bf16_stage, "roofline_k1": roofline_k1, "roofline_k1_multi_nnz": roofline_k1_multi, "cpu_baseline": cpu, "parity": parity,
-        "fp32_mfma_mode": fp32_mode, "fit": fit,
+        "fp32_mfma_mode": fp32_mode, "bf16_filter_mode": bf16_mode, "fit": fit,
         "roofline_fit": (fit or {}).get("roofline_fit"), "cpu_baseline_fit": cpu_fit,
     }
     print(json.dumps(line))

@@ -227,8 +227,10 @@ int trec_score_prep_filter(const float* repr, int64_t n, int32_t d, int32_t kpad
  *   trec_topk_rows_count / trec_topk_rows_fill: the pairs with table[s][u] >= floor[u], grouped by superblock by a
  *     row-wise stream compaction (the table is superblock-major: no sort).  count: block_off [n_sb *
  *     trec_topk_rows_user_blocks(n_users)], row_total / row_pad [n_sb], pstart int64 [n_sb + 1] -- pstart[n_sb] is the
- *     number of resident rows (a multiple of 512), read by the host to size row_user [pstart[n_sb]] and rblock_chunk
- *     [pstart[n_sb] / 512] for fill (user ids ascending inside a superblock, -1 = padding).
+ *     number of resident rows (a multiple of 512); status int64[2] = {pstart[n_sb], 1 if it exceeds cap_rows}.  fill:
+ *     row_user [cap_rows] (user ids ascending inside a superblock, -1 = padding), rblock_chunk [cap_rows / 512] (-1 for
+ *     the idle workgroups beyond the kept pairs; all of them after an overflow, which the caller reads from status when
+ *     the pipeline has drained and answers with the dense bf16 stage 1).  No host round trip between the stages.
  *   trec_score_gemm_blockmax_grouped: the hand-scheduled bf16 stage-1 kernel over those pairs only; workgroup w re-scores
  *     superblock rblock_chunk[w] for its 512 rows and writes blockmax[rblock_chunk[w] * bm_stride + row_user[r]]. */
 int trec_score_prep_i8(const float* repr, int64_t n, int32_t d, int32_t kpad, int32_t side, float clip_sigmas,
@@ -241,10 +243,11 @@ int trec_topk_filter_floor_i8(const float* tau, const float* user_stats, const f
                               int32_t kdim, int64_t n_users, float* floor, int32_t* flag, int32_t* n_flagged, void* stream);
 int32_t trec_topk_rows_user_blocks(int64_t n_users);
 int trec_topk_rows_count(const float* table, int32_t n_sb, int64_t n_users, int64_t stride, const float* floor,
-                         int32_t* block_off, int32_t* row_total, int32_t* row_pad, int64_t* pstart, void* stream);
+                         int32_t* block_off, int32_t* row_total, int32_t* row_pad, int64_t* pstart, int64_t cap_rows,
+                         int64_t* status, void* stream);
 int trec_topk_rows_fill(const float* table, int32_t n_sb, int64_t n_users, int64_t stride, const float* floor,
-                        const int32_t* block_off, const int32_t* row_total, const int64_t* pstart, int32_t* row_user,
-                        int32_t* rblock_chunk, void* stream);
+                        const int32_t* block_off, const int32_t* row_total, const int64_t* pstart, int64_t cap_rows,
+                        const int64_t* status, int32_t* row_user, int32_t* rblock_chunk, void* stream);
 int trec_score_gemm_blockmax_grouped(const void* users_bf16, const void* items_bf16, int32_t kpad, int64_t n_rows_g,
                                      int64_t n_items, const float* user_bias, const float* item_bias, int32_t sb_rows,
                                      const int32_t* rblock_chunk, const int32_t* row_user, float* blockmax,

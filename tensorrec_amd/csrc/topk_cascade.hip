@@ -146,8 +146,11 @@ __global__ __launch_bounds__(256) void rows_scan_kernel(int32_t* __restrict__ bl
 }
 
 // single workgroup: pstart[s] = sum of the padded sizes of rows < s, pstart[n_sb] = the grouped launch's resident rows
+// status[0] = pstart[n_sb], status[1] = 1 when that exceeds cap_rows (the caller's row_user capacity): pass 2 and the grouped
+// launch then do nothing and the caller falls back to the dense bf16 stage 1
 __global__ __launch_bounds__(256) void rows_pstart_kernel(const int32_t* __restrict__ row_pad, int32_t n_sb,
-                                                         int64_t* __restrict__ pstart)
+                                                         int64_t* __restrict__ pstart, int64_t cap_rows,
+                                                         int64_t* __restrict__ status)
 {
     __shared__ long long wsum[4];
     __shared__ long long carry_s;
@@ -170,7 +173,20 @@ __global__ __launch_bounds__(256) void rows_pstart_kernel(const int32_t* __restr
         if (threadIdx.x == 255) carry_s = base + inc;
         __syncthreads();
     }
-    if (threadIdx.x == 0) pstart[n_sb] = carry_s;
+    if (threadIdx.x == 0) {
+        pstart[n_sb] = carry_s;
+        status[0] = carry_s;
+        status[1] = carry_s > cap_rows ? 1 : 0;
+    }
+}
+
+// workgroups of the grouped launch beyond the kept pairs (all of them after an overflow) are idle: superblock id -1
+__global__ __launch_bounds__(256) void rows_tail_kernel(const int64_t* __restrict__ status, int64_t cap_wgs,
+                                                       int32_t* __restrict__ rblock_chunk)
+{
+    const int64_t first = status[1] ? 0 : status[0] / GROUP_ROWS;
+    for (int64_t w = first + (int64_t)blockIdx.x * 256 + threadIdx.x; w < cap_wgs; w += (int64_t)gridDim.x * 256)
+        rblock_chunk[w] = -1;
 }
 
 __global__ __launch_bounds__(256) void rows_fill_kernel(const float* __restrict__ table, int32_t n_sb, int64_t n_users,
@@ -178,9 +194,10 @@ __global__ __launch_bounds__(256) void rows_fill_kernel(const float* __restrict_
                                                        const int32_t* __restrict__ blockoff,
                                                        const int32_t* __restrict__ row_total,
                                                        const int64_t* __restrict__ pstart, int32_t* __restrict__ row_user,
-                                                       int32_t* __restrict__ rblock_chunk)
+                                                       int32_t* __restrict__ rblock_chunk, const int64_t* __restrict__ status)
 {
     __shared__ int wsum[CROWS][4];
+    if (status[1]) return;                                       // more pairs than row_user holds: nothing is refined
     const int32_t s0 = blockIdx.y * CROWS;
     const int64_t u = (int64_t)blockIdx.x * CUSERS + threadIdx.x * 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -236,34 +253,44 @@ extern "C" int trec_topk_filter_floor_i8(const float* tau, const float* user_sta
 extern "C" int32_t trec_topk_rows_user_blocks(int64_t n_users) { return (int32_t)ceil_div64(n_users, CUSERS); }
 
 // pass 1 of the row-wise compaction: block_off [n_sb][trec_topk_rows_user_blocks(n_users)] (scratch for pass 2),
-// row_total [n_sb], pstart [n_sb + 1] (int64; pstart[n_sb] = resident rows of the grouped launch, a multiple of 512)
+// row_total [n_sb], pstart [n_sb + 1] (int64; pstart[n_sb] = resident rows of the grouped launch, a multiple of 512),
+// status int64[2] = {pstart[n_sb], overflow: it exceeds cap_rows} -- nothing here needs the host
 extern "C" int trec_topk_rows_count(const float* table, int32_t n_sb, int64_t n_users, int64_t stride, const float* floor_,
-                                    int32_t* block_off, int32_t* row_total, int32_t* row_pad, int64_t* pstart, void* stream)
+                                    int32_t* block_off, int32_t* row_total, int32_t* row_pad, int64_t* pstart,
+                                    int64_t cap_rows, int64_t* status, void* stream)
 {
-    TREC_REQUIRE(table && floor_ && block_off && row_total && row_pad && pstart, "trec_topk_rows_count: null pointer");
+    TREC_REQUIRE(table && floor_ && block_off && row_total && row_pad && pstart && status, "trec_topk_rows_count: null pointer");
+    TREC_REQUIRE(cap_rows >= 0 && cap_rows % GROUP_ROWS == 0, "trec_topk_rows_count: cap_rows must be a multiple of 512");
     TREC_REQUIRE(n_sb >= 1 && n_users >= 1 && stride >= n_users, "trec_topk_rows_count: bad sizes");
     hipStream_t st = (hipStream_t)stream;
     const int n_ublk = (int)ceil_div64(n_users, CUSERS);
     hipLaunchKernelGGL(rows_count_kernel, dim3((unsigned)n_ublk, (unsigned)((n_sb + CROWS - 1) / CROWS)), dim3(256), 0, st,
                        table, n_sb, n_users, stride, floor_, n_ublk, block_off);
     hipLaunchKernelGGL(rows_scan_kernel, dim3((unsigned)n_sb), dim3(256), 0, st, block_off, n_ublk, row_total, row_pad);
-    hipLaunchKernelGGL(rows_pstart_kernel, dim3(1), dim3(256), 0, st, row_pad, n_sb, pstart);
+    hipLaunchKernelGGL(rows_pstart_kernel, dim3(1), dim3(256), 0, st, row_pad, n_sb, pstart, cap_rows, status);
     return trec_check_launch("trec_topk_rows_count");
 }
 
-// pass 2: row_user [pstart[n_sb]] = the kept users of superblock 0, padding (-1), those of superblock 1, ... (ascending
-// user ids inside a superblock); rblock_chunk [pstart[n_sb] / 512] = the superblock of each 512-row workgroup
+// pass 2: row_user [cap_rows], first pstart[n_sb] entries = the kept users of superblock 0, padding (-1), those of
+// superblock 1, ... (ascending user ids inside a superblock); rblock_chunk [cap_rows / 512] = the superblock of each
+// 512-row workgroup, -1 for the workgroups beyond pstart[n_sb] / 512 (all of them when status[1] is set)
 extern "C" int trec_topk_rows_fill(const float* table, int32_t n_sb, int64_t n_users, int64_t stride, const float* floor_,
                                    const int32_t* block_off, const int32_t* row_total, const int64_t* pstart,
-                                   int32_t* row_user, int32_t* rblock_chunk, void* stream)
+                                   int64_t cap_rows, const int64_t* status, int32_t* row_user, int32_t* rblock_chunk,
+                                   void* stream)
 {
-    TREC_REQUIRE(table && floor_ && block_off && row_total && pstart && row_user && rblock_chunk,
+    TREC_REQUIRE(table && floor_ && block_off && row_total && pstart && status && row_user && rblock_chunk,
                  "trec_topk_rows_fill: null pointer");
+    TREC_REQUIRE(cap_rows >= GROUP_ROWS && cap_rows % GROUP_ROWS == 0, "trec_topk_rows_fill: cap_rows must be a multiple of 512");
     TREC_REQUIRE(n_sb >= 1 && n_users >= 1 && stride >= n_users, "trec_topk_rows_fill: bad sizes");
     const int n_ublk = (int)ceil_div64(n_users, CUSERS);
     hipLaunchKernelGGL(rows_fill_kernel, dim3((unsigned)n_ublk, (unsigned)((n_sb + CROWS - 1) / CROWS)), dim3(256), 0,
                        (hipStream_t)stream, table, n_sb, n_users, stride, floor_, n_ublk, block_off, row_total, pstart,
-                       row_user, rblock_chunk);
+                       row_user, rblock_chunk, status);
+    const int64_t cap_wgs = cap_rows / GROUP_ROWS;
+    unsigned tb = (unsigned)ceil_div64(cap_wgs, 256);
+    if (tb > 1024) tb = 1024;
+    hipLaunchKernelGGL(rows_tail_kernel, dim3(tb), dim3(256), 0, (hipStream_t)stream, status, cap_wgs, rblock_chunk);
     return trec_check_launch("trec_topk_rows_fill");
 }
 

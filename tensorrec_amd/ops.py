@@ -968,7 +968,7 @@ def spmm_filter_operand(features, w, bias=None, want_gstats=False):
 
 I8_USER_CLIP_SIGMAS = 4.0        # user rows clip at 4 rms (a clipped user only widens ITS bound; measured at 1M x 1M: refined
                                  # pairs 139M at 5.0, 125M at 4.5, 114M at 4.0, 119M at 3.5); item rows never clip
-CASCADE_MAX_REFINED = 0.30       # refine at most this fraction of the (superblock, user) pairs; beyond it bf16 does it all
+CASCADE_MAX_REFINED = 0.20       # refine at most this fraction of the (superblock, user) pairs; beyond it bf16 does it all
 CASCADE_MIN_ITEMS = 262144       # below ~512 superblocks the k-th largest maximum is not selective enough for int8 to pay
 
 
@@ -1014,8 +1014,11 @@ def score_prep_i8_pair(uop, iop, item_bias=None):
 
 def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, floor_exchange, stats_exchange):
     """Stages 0-1 of the int8 -> bf16 -> fp32 cascade (csrc/topk_cascade.hip): the [n_sb, n_users] table of superblock
-    maxima whose entries are bf16 maxima wherever a top-k item can be and int8 maxima elsewhere.  Returns None when the
-    int8 bound is too loose for this data to pay (more than CASCADE_MAX_REFINED of the pairs would be refined)."""
+    maxima whose entries are bf16 maxima wherever a top-k item can be and int8 maxima elsewhere, its row stride, and the
+    device int64[2] ``status`` = {resident rows of the grouped launch, overflow}.  No host round trip: the grouped launch is
+    sized for CASCADE_MAX_REFINED of the pairs (workgroups beyond the kept pairs exit at once); when the int8 bound is too
+    loose for the data and more pairs reach the floor, ``status[1]`` is set, nothing is refined, and the caller -- who reads
+    it when the pipeline has drained -- runs the dense bf16 stage 1 instead."""
     dev = uop.bf16.device
     n_u, n_i, kpad = uop.n, iop.n, uop.kpad
     if uop.i8 is None or iop.i8 is None:
@@ -1044,23 +1047,19 @@ def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, 
     row_total = torch.empty((n_sb,), dtype=torch.int32, device=dev)
     row_pad = torch.empty((n_sb,), dtype=torch.int32, device=dev)
     pstart = torch.empty((n_sb + 1,), dtype=torch.int64, device=dev)
+    cap_rows = (int(CASCADE_MAX_REFINED * n_sb * n_u) + 511) // 512 * 512 + 512 * n_sb
+    status = torch.empty((2,), dtype=torch.int64, device=dev)
+    row_user = torch.empty((cap_rows,), dtype=torch.int32, device=dev)          # only the kept pairs' part is touched
+    rblock_chunk = torch.empty((cap_rows // 512,), dtype=torch.int32, device=dev)
     with _timed("topk_rows_compact"):
         N.call("trec_topk_rows_count", N.ptr(table), n_sb, n_u, stride, N.ptr(floor8), N.ptr(block_off), N.ptr(row_total),
-               N.ptr(row_pad), N.ptr(pstart))
-    n_rows_g = int(pstart[n_sb].item())             # the one host read of the cascade: sizes the grouped launch
-    LAST_FILTER_STATS["refined_rows"] = n_rows_g
-    if n_rows_g > CASCADE_MAX_REFINED * n_sb * n_u + 512 * n_sb:
-        return None, stride
-    if n_rows_g:
-        row_user = torch.empty((n_rows_g,), dtype=torch.int32, device=dev)
-        rblock_chunk = torch.empty((n_rows_g // 512,), dtype=torch.int32, device=dev)
-        with _timed("topk_rows_compact"):
-            N.call("trec_topk_rows_fill", N.ptr(table), n_sb, n_u, stride, N.ptr(floor8), N.ptr(block_off), N.ptr(row_total),
-                   N.ptr(pstart), N.ptr(row_user), N.ptr(rblock_chunk))
-        with _timed("score_gemm_blockmax_grouped"):
-            N.call("trec_score_gemm_blockmax_grouped", N.ptr(uop.bf16), N.ptr(iop.bf16), kpad, n_rows_g, n_i,
-                   N.ptr(user_bias), N.ptr(item_bias), sb_rows, N.ptr(rblock_chunk), N.ptr(row_user), N.ptr(table), stride)
-    return table, stride
+               N.ptr(row_pad), N.ptr(pstart), cap_rows, N.ptr(status))
+        N.call("trec_topk_rows_fill", N.ptr(table), n_sb, n_u, stride, N.ptr(floor8), N.ptr(block_off), N.ptr(row_total),
+               N.ptr(pstart), cap_rows, N.ptr(status), N.ptr(row_user), N.ptr(rblock_chunk))
+    with _timed("score_gemm_blockmax_grouped"):
+        N.call("trec_score_gemm_blockmax_grouped", N.ptr(uop.bf16), N.ptr(iop.bf16), kpad, cap_rows, n_i,
+               N.ptr(user_bias), N.ptr(item_bias), sb_rows, N.ptr(rblock_chunk), N.ptr(row_user), N.ptr(table), stride)
+    return table, stride, status
 
 
 def score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index_base=0, sb_rows=None, variant=1,
@@ -1092,12 +1091,11 @@ def score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index_
         rblocks = (n_u + rows_wg - 1) // rows_wg
         n_chunks = max(1, min(n_sb, -(-32 * 768 // rblocks)))
     LAST_FILTER_STATS.clear()
-    blockmax, bm_stride = None, n_u
+    blockmax, bm_stride, cascade_status = None, n_u, None
     if prefilter == "int8" and kpad in (64, 128) and sb_rows % 128 == 0:
         # ---- stages 0 + 1: int8 maxima everywhere, bf16 maxima where a top-k item can be
-        blockmax, bm_stride = _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, floor_exchange,
-                                              stats_exchange)
-        LAST_FILTER_STATS["prefilter"] = "int8" if blockmax is not None else "int8 (too loose: bf16 stage 1 instead)"
+        blockmax, bm_stride, cascade_status = _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks,
+                                                              floor_exchange, stats_exchange)
     elif prefilter not in (None, "int8"):
         raise ValueError("unknown prefilter %r" % (prefilter,))
     if blockmax is None:
@@ -1165,6 +1163,19 @@ def score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index_
     del pi
     # ---- users the filter could not certify: the exact fp32 MFMA path (one host read of a counter)
     n_bad = int(n_flagged.item())
+    if cascade_status is not None:
+        rows, overflow = cascade_status.tolist()
+        if stats_exchange is not None:                  # item shards: every rank takes the same path (collectives inside)
+            overflow = float(stats_exchange(torch.tensor([float(overflow)], device=dev)).item())
+        if overflow:
+            # the int8 bound was too loose for this data: nothing was refined and the lists above mean nothing
+            r = score_topk_filtered(uop, iop, k, user_bias, item_bias, item_index_base, sb_rows, variant, n_chunks,
+                                    floor_exchange, stats_exchange, ksel, None)
+            LAST_FILTER_STATS["prefilter"] = "int8 (too loose: bf16 stage 1 instead)"
+            LAST_FILTER_STATS["refined_rows"] = int(rows)
+            return r
+        LAST_FILTER_STATS["prefilter"] = "int8"
+        LAST_FILTER_STATS["refined_rows"] = int(rows)
     LAST_FILTER_STATS.update({"users": n_u, "flagged_users": n_bad, "ksel": ksel,
                               "kept_superblocks_per_user": float(count.sum().item()) / max(1, n_u)})
     if n_bad:

@@ -177,23 +177,30 @@ def test_rows_compaction_lists_exactly_the_pairs_at_or_above_the_floor(ops):
         row_total = torch.empty((n_sb,), dtype=torch.int32, device="cuda")
         row_pad = torch.empty((n_sb,), dtype=torch.int32, device="cuda")
         pstart = torch.empty((n_sb + 1,), dtype=torch.int64, device="cuda")
-        N.call("trec_topk_rows_count", N.ptr(dt), n_sb, n_u, stride, N.ptr(df), N.ptr(block_off), N.ptr(row_total),
-               N.ptr(row_pad), N.ptr(pstart))
         keep = table[:, :n_u] >= floor[None, :]
-        assert np.array_equal(row_total.cpu().numpy(), keep.sum(1))
-        ps = pstart.cpu().numpy()
-        assert np.array_equal(np.diff(ps), (keep.sum(1) + 511) // 512 * 512)
-        n_rows = int(ps[-1])
-        row_user = torch.full((n_rows,), -7, dtype=torch.int32, device="cuda")
-        rblock_chunk = torch.full((n_rows // 512,), -7, dtype=torch.int32, device="cuda")
-        N.call("trec_topk_rows_fill", N.ptr(dt), n_sb, n_u, stride, N.ptr(df), N.ptr(block_off), N.ptr(row_total),
-               N.ptr(pstart), N.ptr(row_user), N.ptr(rblock_chunk))
-        ru, rc = row_user.cpu().numpy(), rblock_chunk.cpu().numpy()
-        for s in range(n_sb):
-            users = np.nonzero(keep[s])[0]
-            seg = ru[ps[s]:ps[s + 1]]
-            assert np.array_equal(seg[:len(users)], users) and np.all(seg[len(users):] == -1)
-            assert np.all(rc[ps[s] // 512:ps[s + 1] // 512] == s)
+        want_rows = int(((keep.sum(1) + 511) // 512 * 512).sum())
+        for cap_rows in (want_rows + 1024, want_rows, want_rows - 512):          # roomy, exact fit, one workgroup short
+            status = torch.full((2,), -5, dtype=torch.int64, device="cuda")
+            N.call("trec_topk_rows_count", N.ptr(dt), n_sb, n_u, stride, N.ptr(df), N.ptr(block_off), N.ptr(row_total),
+                   N.ptr(row_pad), N.ptr(pstart), cap_rows, N.ptr(status))
+            assert np.array_equal(row_total.cpu().numpy(), keep.sum(1))
+            ps = pstart.cpu().numpy()
+            assert np.array_equal(np.diff(ps), (keep.sum(1) + 511) // 512 * 512)
+            assert status.tolist() == [want_rows, int(want_rows > cap_rows)]
+            row_user = torch.full((cap_rows,), -7, dtype=torch.int32, device="cuda")
+            rblock_chunk = torch.full((cap_rows // 512,), -7, dtype=torch.int32, device="cuda")
+            N.call("trec_topk_rows_fill", N.ptr(dt), n_sb, n_u, stride, N.ptr(df), N.ptr(block_off), N.ptr(row_total),
+                   N.ptr(pstart), cap_rows, N.ptr(status), N.ptr(row_user), N.ptr(rblock_chunk))
+            ru, rc = row_user.cpu().numpy(), rblock_chunk.cpu().numpy()
+            if want_rows > cap_rows:                                              # overflow: every workgroup idle, no row written
+                assert np.all(rc == -1) and np.all(ru == -7)
+                continue
+            for s in range(n_sb):
+                users = np.nonzero(keep[s])[0]
+                seg = ru[ps[s]:ps[s + 1]]
+                assert np.array_equal(seg[:len(users)], users) and np.all(seg[len(users):] == -1)
+                assert np.all(rc[ps[s] // 512:ps[s + 1] // 512] == s)
+            assert np.all(rc[want_rows // 512:] == -1)
 
 
 def test_grouped_bf16_blockmax_equals_the_full_kernel_on_the_listed_pairs(ops):

@@ -106,14 +106,14 @@ def _initial(name):
 
 
 # ---- item-sharded predict_top_k through the public API (BASELINE.json configs[3] in miniature) ---------------------------
-def _topk_case(n_items, n_tastes):
+def _topk_case(n_items, n_tastes, d=32):
     import tensorrec_amd as T
     rng = np.random.RandomState(1)
     n_u = 150
     uf = sp.random(n_u, 30, density=0.2, random_state=rng, format="csr", dtype=np.float32)
     itf = sp.hstack([sp.identity(n_items, format="csr", dtype=np.float32),
                      sp.random(n_items, 5, density=0.3, random_state=rng, format="csr", dtype=np.float32)], format="csr")
-    model = T.TensorRec(n_components=32, n_tastes=n_tastes, seed=11,
+    model = T.TensorRec(n_components=d, n_tastes=n_tastes, seed=11,
                         prediction_graph=T.prediction_graphs.CosineSimilarityPredictionGraph())
     model.build(uf.shape[1], itf.shape[1])
     w = model.get_weights()
@@ -123,29 +123,30 @@ def _topk_case(n_items, n_tastes):
     return model, uf, itf
 
 
-def _topk_worker(rank, world, port, n_items, n_tastes, ret):
+def _topk_worker(rank, world, port, n_items, n_tastes, ret, d=32):
     import torch.distributed as dist
     from tensorrec_amd import sharding
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        model, uf, itf = _topk_case(n_items, n_tastes)
+        model, uf, itf = _topk_case(n_items, n_tastes, d)
         b, e = sharding.shard_bounds(n_items, world, rank)
         ret[rank] = model.predict_top_k(uf, itf[b:e], k=10, item_sharded=True, item_offset=b)
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_items,n_tastes", [(40000, 1), (3000, 1), (40000, 2)])
-def test_item_sharded_predict_top_k_equals_single_process(n_items, n_tastes):
+@pytest.mark.parametrize("n_items,n_tastes,d", [(40000, 1, 32), (3000, 1, 32), (40000, 2, 32), (300000, 1, 64)])
+def test_item_sharded_predict_top_k_equals_single_process(n_items, n_tastes, d):
     """Cosine similarity, biased, items sharded over two ranks: both ranks return the single-process result exactly
-    (two-stage path with the shared floor for 20,000-item shards, direct fused path for small ones)."""
-    model, uf, itf = _topk_case(n_items, n_tastes)
+    (two-stage path with the shared floor for 20,000-item shards, direct fused path for small ones; 300,000 items at
+    d = 64: the int8 -> bf16 -> fp32 cascade with both of its floors shared between the shards)."""
+    model, uf, itf = _topk_case(n_items, n_tastes, d)
     ref_v, ref_i = model.predict_top_k(uf, itf, k=10)
     mgr = mp.get_context("spawn").Manager()
     ret = mgr.dict()
-    mp.spawn(_topk_worker, args=(2, _free_port(), n_items, n_tastes, ret), nprocs=2, join=True)
+    mp.spawn(_topk_worker, args=(2, _free_port(), n_items, n_tastes, ret, d), nprocs=2, join=True)
     for r in (0, 1):
         v, i = ret[r]
         assert np.array_equal(i, ref_i) and np.array_equal(v, ref_v), "rank %d" % r
