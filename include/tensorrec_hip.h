@@ -211,22 +211,25 @@ int trec_score_prep_filter(const float* repr, int64_t n, int32_t d, int32_t kpad
 /* ---- K2q / K2c: the int8 -> bf16 -> fp32 cascade of the exact top-k (csrc/score_blockmax_i8.hip, csrc/topk_cascade.hip;
  * same place in the reference as K2f: prediction_graphs.py:49-50 + recommendation_graphs.py:80) ------------------------
  * The bf16 stage-1 kernel runs at the chip's power limit; the int8 MFMA contracts twice the elements per cycle and is
- * exact on integers.  Operand rows are quantised with ONE scale per side; the quantisation error of every row is
- * measured, which gives a proven bound eps8_u >= |int8 score - fp32 score|.  Only (superblock, user) pairs whose int8
- * maximum reaches tau8_u - 2 eps8_u are re-scored in bf16; the bf16 maxima replace those entries of the table and the
- * bf16 filter above runs unchanged on it (proof: csrc/topk_cascade.hip).
- *   trec_score_prep_i8: repr [n, d] fp32 -> out_q int8 [n, kpad]; scales[side] = min(clip_sigmas * rms, max |x|) / 127
- *     (clip_sigmas <= 0: max |x| / 127, nothing clips); side 1 (items) also writes scales[2] = the product -- prepare the
- *     users first; row_stats [n][2] = {||x||, ||x - scale q||}; for the items bias_q = rint(bias / scales[2]) and
- *     gstats[0..3] = running maxima {||x|| + ||dx||, ||dx||, |bias|, |bias - scales[2] bias_q|} (zero-initialised by the
- *     caller; item shards all-reduce them with MAX).  workspace: 16 bytes.  kpad <= 128.
- *   trec_score_gemm_blockmax_i8: blockmax[s * bm_stride + u] = scales[2] * max over the items of superblock s of
+ * exact on integers.  Operand rows are quantised (users: one scale; items: one scale per superblock, so that a
+ * superblock's maximum stays an integer maximum); the quantisation error of every row is measured, which gives a proven
+ * bound e(u, s) >= |int8 score - fp32 score| per user and superblock.  Only (superblock, user) pairs whose int8 maximum + e
+ * reaches the k-th largest (int8 maximum - e) are re-scored in bf16; the bf16 maxima replace those entries of the table and
+ * the bf16 filter above runs unchanged on it (proof: csrc/topk_cascade.hip).
+ *   trec_score_prep_i8: repr [n, d] fp32 -> out_q int8 [n, kpad], row_stats [n][2] = {||x||, ||x - scale q||}.
+ *     side 0 (users): scales[0] = min(clip_sigmas * rms, max |x|) / 127 (clip_sigmas <= 0: nothing clips); workspace 16 B.
+ *     side 1 (items): sb_stats [n_sb][4], zero-initialised = {b_s = max |y| / 127 over superblock s (sb_rows rows), max
+ *       ||y|| + ||dy||, max ||dy||, max |bias - scales[0] b_s bias_q|}; with a bias also side 2 (users first).
+ *     side 2: bias_q = rint(bias / (scales[0] b_s)), sb_stats[s][3] and gstats[2] = max |bias| (both zeroed by the caller)
+ *       for the current user scale; the item rows are quantised once per catalogue.  kpad <= 128.
+ *   trec_score_user_err_i8: r_err [n_users][3] = {||x||, ||x - a q||, ck (|b_u| + gstats[2])}, the users' part of e(u, s).
+ *   trec_score_gemm_blockmax_i8: blockmax[s * bm_stride + u] = scales[0] * b_s * max over the items of superblock s of
  *     (q_u . q_i + bias_q[i]) + user_bias[u]; exact integer arithmetic on v_mfma_i32_32x32x32_i8.  kpad 64 / 128.
- *   trec_topk_filter_floor_i8: floor[u] = tau[u] - 2 eps8_u rounded down (tau from trec_topk_select_blocks on the int8
- *     table); -inf (every superblock refined) when the bound is not finite; flag / n_flagged nullable.
- *   trec_topk_rows_count / trec_topk_rows_fill: the pairs with table[s][u] >= floor[u], grouped by superblock by a
- *     row-wise stream compaction (the table is superblock-major: no sort).  count: block_off [n_sb *
- *     trec_topk_rows_user_blocks(n_users)], row_total / row_pad [n_sb], pstart int64 [n_sb + 1] -- pstart[n_sb] is the
+ *     With user_err / chunk_top / top_k (10 or 16): chunk_top [n_chunks_eff * top_k][bm_stride] = per chunk of superblocks
+ *     and user the top_k largest lower bounds (sorted, -inf padded); trec_topk_select_blocks over it gives tau.
+ *   trec_topk_rows_count / trec_topk_rows_fill: the pairs with table[s][u] + e(u, s) >= thr[u] (two floats below),
+ *     grouped by superblock by a row-wise stream compaction (the table is superblock-major: no sort).  count: block_off
+ *     [n_sb * trec_topk_rows_user_blocks(n_users)], row_total / row_pad [n_sb], pstart int64 [n_sb + 1] -- pstart[n_sb] is the
  *     number of resident rows (a multiple of 512); status int64[2] = {pstart[n_sb], 1 if it exceeds cap_rows}.  fill:
  *     row_user [cap_rows] (user ids ascending inside a superblock, -1 = padding), rblock_chunk [cap_rows / 512] (-1 for
  *     the idle workgroups beyond the kept pairs; all of them after an overflow, which the caller reads from status when
@@ -234,20 +237,23 @@ int trec_score_prep_filter(const float* repr, int64_t n, int32_t d, int32_t kpad
  *   trec_score_gemm_blockmax_grouped: the hand-scheduled bf16 stage-1 kernel over those pairs only; workgroup w re-scores
  *     superblock rblock_chunk[w] for its 512 rows and writes blockmax[rblock_chunk[w] * bm_stride + row_user[r]]. */
 int trec_score_prep_i8(const float* repr, int64_t n, int32_t d, int32_t kpad, int32_t side, float clip_sigmas,
-                       const float* bias, float* scales, double* workspace, void* out_q, float* row_stats,
-                       int32_t* bias_q, float* gstats, void* stream);
+                       int32_t sb_rows, const float* bias, float* scales, double* workspace, void* out_q,
+                       float* row_stats, int32_t* bias_q, float* sb_stats, float* gstats, void* stream);
+int trec_score_user_err_i8(const float* user_stats, const float* user_bias, const float* gstats, int32_t kdim,
+                           int64_t n_users, float* r_err, void* stream);
 int trec_score_gemm_blockmax_i8(const void* users_q, const void* items_q, int32_t kpad, int64_t n_users, int64_t n_items,
-                                const float* user_bias, const int32_t* item_bias_q, const float* scales, int32_t sb_rows,
-                                int32_t n_chunks, float* blockmax, int64_t bm_stride, void* stream);
-int trec_topk_filter_floor_i8(const float* tau, const float* user_stats, const float* user_bias, const float* item_gstats,
-                              int32_t kdim, int64_t n_users, float* floor, int32_t* flag, int32_t* n_flagged, void* stream);
+                                const float* user_bias, const int32_t* item_bias_q, const float* scales,
+                                const float* sb_stats, int32_t sb_rows, int32_t n_chunks, float* blockmax,
+                                int64_t bm_stride, const float* user_err, float* chunk_top, int32_t top_k, void* stream);
 int32_t trec_topk_rows_user_blocks(int64_t n_users);
-int trec_topk_rows_count(const float* table, int32_t n_sb, int64_t n_users, int64_t stride, const float* floor,
-                         int32_t* block_off, int32_t* row_total, int32_t* row_pad, int64_t* pstart, int64_t cap_rows,
-                         int64_t* status, void* stream);
-int trec_topk_rows_fill(const float* table, int32_t n_sb, int64_t n_users, int64_t stride, const float* floor,
-                        const int32_t* block_off, const int32_t* row_total, const int64_t* pstart, int64_t cap_rows,
-                        const int64_t* status, int32_t* row_user, int32_t* rblock_chunk, void* stream);
+int trec_topk_rows_count(const float* table, int32_t n_sb, int64_t n_users, int64_t stride, const float* thr,
+                         const float* user_err, const float* sb_stats, int32_t kdim, int32_t* block_off,
+                         int32_t* row_total, int32_t* row_pad, int64_t* pstart, int64_t cap_rows, int64_t* status,
+                         void* stream);
+int trec_topk_rows_fill(const float* table, int32_t n_sb, int64_t n_users, int64_t stride, const float* thr,
+                        const float* user_err, const float* sb_stats, int32_t kdim, const int32_t* block_off,
+                        const int32_t* row_total, const int64_t* pstart, int64_t cap_rows, const int64_t* status,
+                        int32_t* row_user, int32_t* rblock_chunk, void* stream);
 int trec_score_gemm_blockmax_grouped(const void* users_bf16, const void* items_bf16, int32_t kpad, int64_t n_rows_g,
                                      int64_t n_items, const float* user_bias, const float* item_bias, int32_t sb_rows,
                                      const int32_t* rblock_chunk, const int32_t* row_user, float* blockmax,

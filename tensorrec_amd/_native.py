@@ -57,12 +57,13 @@ SIGNATURES = {
     "trec_topk_select_blocks": [_vp, _i32, _i64, _i64, _i32, _vp, _vp, _vp, _vp],
     "trec_topk_select_blocks_ex": [_vp, _i32, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp],
     "trec_score_prep_filter": [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
-    "trec_score_prep_i8": [_vp, _i64, _i32, _i32, _i32, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
-    "trec_score_gemm_blockmax_i8": [_vp, _vp, _i32, _i64, _i64, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _vp],
-    "trec_topk_filter_floor_i8": [_vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp],
+    "trec_score_prep_i8": [_vp, _i64, _i32, _i32, _i32, _f, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "trec_score_user_err_i8": [_vp, _vp, _vp, _i32, _i64, _vp, _vp],
+    "trec_score_gemm_blockmax_i8": [_vp, _vp, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp, _i32,
+                                    _vp],
     "trec_topk_rows_user_blocks": [_i64],
-    "trec_topk_rows_count": [_vp, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
-    "trec_topk_rows_fill": [_vp, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp],
+    "trec_topk_rows_count": [_vp, _i32, _i64, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
+    "trec_topk_rows_fill": [_vp, _i32, _i64, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp],
     "trec_score_gemm_blockmax_grouped": [_vp, _vp, _i32, _i64, _i64, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _vp],
     "trec_topk_filter_floor": [_vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp],
     "trec_topk_collect_blocks": [_vp, _i32, _i64, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp],

@@ -33,7 +33,10 @@ typedef int v16i32 __attribute__((ext_vector_type(16)));
 
 constexpr int BNQ = 128;        // item rows per tile (four 32-row MFMA blocks)
 
-template <int KT, bool BIAS, int NCB, int WPS>
+// TK > 0: the kernel also keeps, per user, the TK largest LOWER bounds M - e(u, s) of the superblocks of its chunk (sorted
+// registers, one insertion per superblock end) and writes them to chunk_top: the k-th largest over the chunks' lists is
+// tau8 -- no pass over the 7.8 GB table for it.
+template <int KT, bool BIAS, int NCB, int WPS, int TK>
 __global__ __launch_bounds__(256, WPS) void blockmax_i8_kernel(ScoreParams p)
 {
     constexpr int RB = KT;                   // bytes per operand row
@@ -124,6 +127,18 @@ __global__ __launch_bounds__(256, WPS) void blockmax_i8_kernel(ScoreParams p)
     int bm[NCB];
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) bm[cb] = INT_MIN;
+    float top[TK ? NCB : 1][TK ? TK : 1];
+    float e_nx[TK ? NCB : 1], e_ex[TK ? NCB : 1], e_cu[TK ? NCB : 1];
+    if (TK) {
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            int64_t row = r_base + cb * 32 + l31;
+            if (row >= p.n_r) row = p.n_r - 1;
+            e_nx[cb] = p.r_err[row * 3]; e_ex[cb] = p.r_err[row * 3 + 1]; e_cu[cb] = p.r_err[row * 3 + 2];
+#pragma unroll
+            for (int j = 0; j < TK; ++j) top[cb][j] = -INFINITY;
+        }
+    }
 
     auto read_c0 = [&](v16i32& c, const int* sdi) {           // integer item biases of the block's 16 rows of this half-wave
 #pragma unroll
@@ -181,16 +196,25 @@ __global__ __launch_bounds__(256, WPS) void blockmax_i8_kernel(ScoreParams p)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    const float scale = p.scales[2];             // a b: integer score units -> float
+    const float a_user = p.scales[0];            // integer score units -> float: a_user * (item scale of the superblock)
+    // the NEXT superblock's statistics are fetched while the first tile of the current one is computed: issued at a
+    // superblock end they would sit, fresh, in front of the s_waitcnt vmcnt(0) that closes every tile
+    const int64_t sb0 = t_begin / ((int64_t)p.sb_tiles * BNQ);
+    f32x4 ss_cur = *(const f32x4*)(p.sb_stats + sb0 * 4), ss_next = ss_cur;
     for (int t = 0; t < n_tiles; ++t) {
         const int buf = t & 1;
         if (t + 1 < n_tiles) stage_issue(t + 1, buf ^ 1);
+        if ((t % p.sb_tiles) == 0 && t + p.sb_tiles < n_tiles)
+            ss_next = *(const f32x4*)(p.sb_stats + (sb0 + t / p.sb_tiles + 1) * 4);
         if (buf == 0) tile_body(std::integral_constant<int, 0>{});
         else tile_body(std::integral_constant<int, 1>{});
 
         if (((t + 1) % p.sb_tiles) == 0 || t + 1 == n_tiles) {
             // end of a superblock: combine the two half-wave maxima of each user, convert, add the user bias, store, reset
-            const int64_t sb = t_begin / ((int64_t)p.sb_tiles * BNQ) + t / p.sb_tiles;
+            const int64_t sb = sb0 + t / p.sb_tiles;
+            const float scale = a_user * ss_cur[0];
+            const float yh = TK ? ss_cur[1] : 0.f, dy = TK ? ss_cur[2] : 0.f, db = TK ? ss_cur[3] : 0.f;
+            ss_cur = ss_next;
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) {
                 const int o = __shfl_xor(bm[cb], 32, 64);
@@ -200,18 +224,37 @@ __global__ __launch_bounds__(256, WPS) void blockmax_i8_kernel(ScoreParams p)
                 const int64_t u = r_base + cb * 32 + l31;
                 if (half == 0 && u < p.n_r) p.blockmax[sb * p.bm_stride + u] = v;
                 bm[cb] = INT_MIN;
+                if (TK) {
+                    float lb = v - i8_pair_err(e_nx[cb], e_ex[cb], e_cu[cb], yh, dy, db, KT);
+                    lb = (lb == lb) ? lb : -INFINITY;          // a NaN certifies nothing
+                    // sorted insertion into a descending list, one v_med3 per slot: new t_j = median(t_j, t_{j-1}, lb)
+                    // (lb <= t_j: t_j stays | t_j < lb <= t_{j-1}: lb lands here | lb > t_{j-1}: t_{j-1} moves down)
+#pragma unroll
+                    for (int j = TK - 1; j >= 1; --j) top[cb][j] = __builtin_amdgcn_fmed3f(top[cb][j], top[cb][j - 1], lb);
+                    top[cb][0] = fmaxf(top[cb][0], lb);
+                }
             }
         }
         if (t + 1 < n_tiles) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
+    if (TK) {
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            const int64_t u = r_base + cb * 32 + l31;
+            if (half == 0 && u < p.n_r) {
+#pragma unroll
+                for (int j = 0; j < TK; ++j) p.chunk_top[((int64_t)chunk * TK + j) * p.bm_stride + u] = top[cb][j];
+            }
+        }
+    }
 }
 
-template <int KT, bool BIAS, int NCB, int WPS>
+template <int KT, bool BIAS, int NCB, int WPS, int TK>
 int launch_i8(ScoreParams p, int sb_rows, hipStream_t st)
 {
     constexpr int LDS = 2 * BNQ * KT + 2 * BNQ * 4;
-    auto kern = blockmax_i8_kernel<KT, BIAS, NCB, WPS>;
+    auto kern = blockmax_i8_kernel<KT, BIAS, NCB, WPS, TK>;
     static bool attr_set = false;
     if (!attr_set && LDS > 32 * 1024) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -224,18 +267,21 @@ int launch_i8(ScoreParams p, int sb_rows, hipStream_t st)
     return trec_check_launch("trec_score_gemm_blockmax_i8");
 }
 
-// fp32 rows -> int8 rows [n, kpad] (zero padded) with ONE scale for the whole side, + what the bound needs per row:
-// {||x||, ||x - scale q||} (the actual quantisation error of this row, clipping included); items also get their bias in
-// integer units of scale_prod and the maxima over rows of ||x|| + ||dx||, ||dx||, |bias|, |bias - scale_prod bq|.
+// fp32 rows -> int8 rows [n, kpad] (zero padded), q = clamp(rint(x / scale), +-127), + what the bound needs per row:
+// {||x||, ||x - scale q||} (the actual quantisation error of this row, clipping included).  Users: ONE scale (*scale_ptr).
+// Items: one scale per superblock of sb_rows rows, sb_stats[s][0] (= the superblock's max |y| / 127: no item clips), and the
+// running maxima sb_stats[s][1] = max ||y|| + ||dy|| (>= ||scale q||), sb_stats[s][2] = max ||dy|| over the superblock's rows.
 template <int G>
 __global__ __launch_bounds__(256) void prep_i8_kernel(const float* __restrict__ x, int64_t n, int d, int kt,
-                                                     const float* __restrict__ scale_ptr, signed char* __restrict__ out_q,
-                                                     float2* __restrict__ row_stats, float* __restrict__ gstats)
+                                                     const float* __restrict__ scale_ptr, int sb_rows,
+                                                     float* __restrict__ sb_stats, signed char* __restrict__ out_q,
+                                                     float2* __restrict__ row_stats)
 {
     const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
     const bool ok = row < n;
     const int sub = threadIdx.x % G;
-    const float scale = *scale_ptr;
+    const int64_t sb = sb_rows ? (ok ? row : n - 1) / sb_rows : 0;
+    const float scale = sb_rows ? sb_stats[sb * 4] : *scale_ptr;
     const float inv = 1.0f / scale;
     const float* xr = x + (ok ? row : 0) * (int64_t)d;
     float sw = 0.f, se = 0.f;
@@ -255,7 +301,7 @@ __global__ __launch_bounds__(256) void prep_i8_kernel(const float* __restrict__ 
         for (int e = 0; e < 4; ++e) {
             float q = rintf(v[e] * inv);
             q = fminf(fmaxf(q, -127.f), 127.f);
-            if (!(q == q)) q = 0.f;                                     // NaN input: the error norm below turns NaN and flags the user
+            if (!(q == q)) q = 0.f;                                     // NaN input: the error norm below turns NaN -> the bound turns inf
             const float err = v[e] - q * scale;
             sw = fmaf(v[e], v[e], sw);
             se = fmaf(err, err, se);
@@ -266,53 +312,112 @@ __global__ __launch_bounds__(256) void prep_i8_kernel(const float* __restrict__ 
     for (int off = G / 2; off > 0; off >>= 1) { sw += __shfl_xor(sw, off, 64); se += __shfl_xor(se, off, 64); }
     float nw = sqrtf(sw), ne = sqrtf(se);
     if (sub == 0 && ok) row_stats[row] = make_float2(nw, ne);
-    if (gstats) {
-        float g0 = (sub == 0 && ok) ? nw + ne : 0.f, g1 = (sub == 0 && ok) ? ne : 0.f;
-        if (g0 != g0) g0 = INFINITY;
-        if (g1 != g1) g1 = INFINITY;
-        for (int off = 32; off > 0; off >>= 1) {
-            g0 = fmaxf(g0, __shfl_xor(g0, off, 64)); g1 = fmaxf(g1, __shfl_xor(g1, off, 64));
-        }
-        if ((threadIdx.x & 63) == 0) {
-            const float g[2] = {g0, g1};
-#pragma unroll
-            for (int e = 0; e < 2; ++e)
-                if (__float_as_uint(g[e]) > *(volatile unsigned int*)(gstats + e)) atomicMax((unsigned int*)(gstats + e), __float_as_uint(g[e]));
-        }
+}
+
+// one workgroup per superblock: sb_stats[s][1] = max ||y|| + ||dy||, sb_stats[s][2] = max ||dy|| over its rows (NaN -> inf)
+__global__ __launch_bounds__(256) void sb_reduce_kernel(const float2* __restrict__ row_stats, int64_t n, int sb_rows,
+                                                       float* __restrict__ sb_stats)
+{
+    const int64_t s = blockIdx.x;
+    const int64_t r0 = s * sb_rows, r1 = (r0 + sb_rows < n) ? r0 + sb_rows : n;
+    float g0 = 0.f, g1 = 0.f;
+    for (int64_t r = r0 + threadIdx.x; r < r1; r += 256) {
+        const float2 st = row_stats[r];
+        float a = st.x + st.y, b = st.y;
+        if (a != a) a = INFINITY;
+        if (b != b) b = INFINITY;
+        g0 = fmaxf(g0, a); g1 = fmaxf(g1, b);
+    }
+    for (int off = 32; off > 0; off >>= 1) { g0 = fmaxf(g0, __shfl_xor(g0, off, 64)); g1 = fmaxf(g1, __shfl_xor(g1, off, 64)); }
+    __shared__ float w0[4], w1[4];
+    if ((threadIdx.x & 63) == 0) { w0[threadIdx.x >> 6] = g0; w1[threadIdx.x >> 6] = g1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        sb_stats[s * 4 + 1] = fmaxf(fmaxf(w0[0], w0[1]), fmaxf(w0[2], w0[3]));
+        sb_stats[s * 4 + 2] = fmaxf(fmaxf(w1[0], w1[1]), fmaxf(w1[2], w1[3]));
     }
 }
 
-__global__ void scale_prod_kernel(float* __restrict__ scales) { scales[2] = scales[0] * scales[1]; }
-
-// item biases in integer units of the scale product (scales[0] * scales[1], also written to scales[2]):
-// bias_q = rint(bias / product), gstats[2] = max |bias|, gstats[3] = max |bias - product * bias_q|
-__global__ __launch_bounds__(256) void bias_i8_kernel(const float* __restrict__ bias, int64_t n, float* __restrict__ scales,
-                                                     int* __restrict__ bias_q, float* __restrict__ gstats)
+// sb_stats[s][0] = (max |y| over the rows of superblock s) / 127 -- 1.0 for an all-zero or non-finite superblock
+__global__ __launch_bounds__(1024) void sb_scale_kernel(const float* __restrict__ x, int64_t n, int d, int sb_rows,
+                                                       float* __restrict__ sb_stats)
 {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const float sp = scales[0] * scales[1];
-    if (i == 0) scales[2] = sp;
+    const int64_t s = blockIdx.x;
+    const int64_t r0 = s * sb_rows;
+    const int64_t r1 = (r0 + sb_rows < n) ? r0 + sb_rows : n;
+    const int64_t n_elem = (r1 - r0) * d;
+    const float* xs = x + r0 * (int64_t)d;
+    float am = 0.f;
+    if ((d & 3) == 0) {
+        for (int64_t i = (int64_t)threadIdx.x * 4; i < n_elem; i += 4096) {
+            const f32x4 v = *(const f32x4*)(xs + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float a = fabsf(v[e]); am = (a > am || a != a) ? a : am; }     // NaN sticks
+        }
+    } else {
+        for (int64_t i = threadIdx.x; i < n_elem; i += 1024) { const float a = fabsf(xs[i]); am = (a > am || a != a) ? a : am; }
+    }
+    if (am != am) am = INFINITY;
+    for (int off = 32; off > 0; off >>= 1) am = fmaxf(am, __shfl_xor(am, off, 64));
+    __shared__ float wmax[16];
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = am;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        am = 0.f;
+        for (int w = 0; w < 16; ++w) am = fmaxf(am, wmax[w]);
+        float sc = am / 127.0f;
+        if (!(sc > 0.f) || !(sc < INFINITY)) sc = 1.0f;
+        sb_stats[s * 4] = sc;
+    }
+}
+
+// item biases in integer units of the superblock's scale product a_user * b_s: bias_q = rint(bias / product),
+// gstats[2] = max |bias| (all items), sb_stats[s][3] = max |bias - product * bias_q| (superblock s).  One workgroup per superblock.
+__global__ __launch_bounds__(256) void bias_i8_kernel(const float* __restrict__ bias, int64_t n, const float* __restrict__ scales,
+                                                     int sb_rows, float* __restrict__ sb_stats, int* __restrict__ bias_q,
+                                                     float* __restrict__ gstats)
+{
+    const int64_t s = blockIdx.x;
+    const int64_t r0 = s * sb_rows, r1 = (r0 + sb_rows < n) ? r0 + sb_rows : n;
+    const float sp = scales[0] * sb_stats[s * 4];                       // the same product the score kernel forms
     float g2 = 0.f, g3 = 0.f;
-    if (i < n) {
+    for (int64_t i = r0 + threadIdx.x; i < r1; i += 256) {
         const float b = bias[i];
         float bq = rintf(b / sp);
         bq = fminf(fmaxf(bq, -4194304.f), 4194304.f);                   // |bq| <= 2^22: accumulators stay below 2^24
         if (!(bq == bq)) bq = 0.f;
         bias_q[i] = (int)bq;
-        g2 = fabsf(b);
-        g3 = fabsf(b - bq * sp);
-        if (g2 != g2) g2 = INFINITY;
-        if (g3 != g3) g3 = INFINITY;
+        float a2 = fabsf(b), a3 = fabsf(b - bq * sp);
+        if (a2 != a2) a2 = INFINITY;
+        if (a3 != a3) a3 = INFINITY;
+        g2 = fmaxf(g2, a2); g3 = fmaxf(g3, a3);
     }
     for (int off = 32; off > 0; off >>= 1) { g2 = fmaxf(g2, __shfl_xor(g2, off, 64)); g3 = fmaxf(g3, __shfl_xor(g3, off, 64)); }
-    if ((threadIdx.x & 63) == 0) {
+    __shared__ float w2[4], w3[4];
+    if ((threadIdx.x & 63) == 0) { w2[threadIdx.x >> 6] = g2; w3[threadIdx.x >> 6] = g3; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        g2 = fmaxf(fmaxf(w2[0], w2[1]), fmaxf(w2[2], w2[3]));
+        sb_stats[s * 4 + 3] = fmaxf(fmaxf(w3[0], w3[1]), fmaxf(w3[2], w3[3]));
         if (__float_as_uint(g2) > *(volatile unsigned int*)(gstats + 2)) atomicMax((unsigned int*)(gstats + 2), __float_as_uint(g2));
-        if (__float_as_uint(g3) > *(volatile unsigned int*)(gstats + 3)) atomicMax((unsigned int*)(gstats + 3), __float_as_uint(g3));
     }
 }
 
+// r_err[u] = {||x_u||, ||x_u - a q_u||, ck (|b_u| + max |b_i|)}: the user's part of i8_pair_err
+__global__ __launch_bounds__(256) void user_err_i8_kernel(const float2* __restrict__ ustats, const float* __restrict__ user_bias,
+                                                         const float* __restrict__ gstats, int kdim, int64_t n_users,
+                                                         float* __restrict__ r_err)
+{
+    const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (u >= n_users) return;
+    const float2 st = ustats[u];
+    const float bu = user_bias ? fabsf(user_bias[u]) : 0.f;
+    const float ck = (float)(kdim + 4) * 2.98023224e-07f;
+    r_err[u * 3] = st.x; r_err[u * 3 + 1] = st.y; r_err[u * 3 + 2] = ck * (bu + gstats[2]);
+}
+
 // sum of squares (double) and maximum magnitude (float bits) of a [n, d] matrix into ws[0] / the low word of ws[1]
-// (zero-initialised by the caller): the scale of a side is derived from them
+// (zero-initialised by the caller): the users' scale is derived from them
 __global__ __launch_bounds__(256) void sumsq_absmax_kernel(const float* __restrict__ x, int64_t n_elem, double* __restrict__ ws)
 {
     double acc = 0.0;
@@ -337,10 +442,8 @@ __global__ __launch_bounds__(256) void sumsq_absmax_kernel(const float* __restri
     }
 }
 
-// scales[side] = min(clip_sigmas * rms, max |x|) / 127 (clip_sigmas <= 0: max |x| / 127, nothing clips); side 1 also
-// writes scales[2] = scales[0] * scales[1]
-__global__ void scale_from_stats_kernel(const double* __restrict__ ws, double n_elem, float clip_sigmas, int side,
-                                        float* __restrict__ scales)
+// scales[0] = min(clip_sigmas * rms, max |x|) / 127 (clip_sigmas <= 0: max |x| / 127, nothing clips)
+__global__ void scale_from_stats_kernel(const double* __restrict__ ws, double n_elem, float clip_sigmas, float* __restrict__ scales)
 {
     const double rms = sqrt(ws[0] / n_elem);
     const float am = __uint_as_float(*(const unsigned int*)(ws + 1));
@@ -348,81 +451,103 @@ __global__ void scale_from_stats_kernel(const double* __restrict__ ws, double n_
     if (clip_sigmas > 0.f && (float)(clip_sigmas * rms) < top) top = (float)(clip_sigmas * rms);
     float s = top / 127.0f;
     if (!(s > 0.f) || !(s < INFINITY)) s = 1.0f;                        // all-zero or non-finite input: any scale is as good
-    scales[side] = s;
-    if (side == 1) scales[2] = scales[0] * s;
+    scales[0] = s;
 }
 
 }  // namespace
 
-// int8 operands for the pre-filter.  scales: float[3] on the device = {user-side scale, item-side scale, their product}.
-// side 0: users (scales[0]); side 1: items (scales[1], gstats[0..1]) and -- with a bias -- what side 2 does; side 2: no
-// quantisation (repr / out_q / row_stats unused): scales[2] and the item biases in units of the CURRENT product, gstats[2..3]
-// (the item rows are quantised once; a new batch of users with its own scale only needs side 2 again).
-// workspace: 16 bytes (zeroed here).  row_stats [n][2]; gstats (items) float[4], zero-initialised by the caller.
+// int8 operands for the pre-filter.
+// side 0, users: ONE scale, scales[0] = min(clip_sigmas * rms, max |x|) / 127; out_q [n, kpad], row_stats [n][2]; workspace 16 B.
+// side 1, items: one scale per superblock of sb_rows rows -- sb_stats [n_sb][4] (zero-initialised by the caller) =
+//   {b_s = max |y| / 127 over the superblock, max ||y|| + ||dy||, max ||dy||, max |bias - a b_s bias_q|}; with a bias also what
+//   side 2 does (the users must have been prepared: it needs scales[0]).
+// side 2, item biases for the CURRENT user scale (repr / out_q / row_stats unused): bias_q = rint(bias / (scales[0] b_s)),
+//   sb_stats[s][3], gstats[2] = max |bias| -- both zeroed by the caller; the item rows are quantised once, a new batch of users
+//   with its own scale only needs side 2 again.
 extern "C" int trec_score_prep_i8(const float* repr, int64_t n, int32_t d, int32_t kpad, int32_t side, float clip_sigmas,
-                                  const float* bias, float* scales, double* workspace, void* out_q, float* row_stats,
-                                  int32_t* bias_q, float* gstats, void* stream)
+                                  int32_t sb_rows, const float* bias, float* scales, double* workspace, void* out_q,
+                                  float* row_stats, int32_t* bias_q, float* sb_stats, float* gstats, void* stream)
 {
     TREC_REQUIRE(scales && (side == 0 || side == 1 || side == 2), "trec_score_prep_i8: side must be 0 (users), 1 (items) or 2 (item biases)");
     TREC_REQUIRE(!bias || (bias_q && gstats && side >= 1), "trec_score_prep_i8: a bias needs bias_q, gstats and side 1 / 2");
+    TREC_REQUIRE(side == 0 || (sb_stats && sb_rows >= 1), "trec_score_prep_i8: the item side needs sb_stats and sb_rows");
     if (n == 0) return TREC_OK;
     hipStream_t st = (hipStream_t)stream;
     if (side != 2) {
-        TREC_REQUIRE(repr && workspace && out_q && row_stats, "trec_score_prep_i8: null pointer");
+        TREC_REQUIRE(repr && out_q && row_stats, "trec_score_prep_i8: null pointer");
         TREC_REQUIRE(d >= 1 && kpad >= d && kpad % 4 == 0 && kpad <= 128, "trec_score_prep_i8: need d <= kpad <= 128, kpad % 4 == 0");
-        TREC_REQUIRE(side == 0 || gstats, "trec_score_prep_i8: the item side needs gstats");
         TREC_REQUIRE(((uintptr_t)repr % 16) == 0, "trec_score_prep_i8: repr must be 16-byte aligned");
-        if (hipMemsetAsync(workspace, 0, 2 * sizeof(double), st) != hipSuccess) {
-            trec_set_last_error("trec_score_prep_i8: memset failed");
-            return TREC_ERR_LAUNCH;
+        if (side == 0) {
+            TREC_REQUIRE(workspace, "trec_score_prep_i8: the user side needs the 16-byte workspace");
+            if (hipMemsetAsync(workspace, 0, 2 * sizeof(double), st) != hipSuccess) {
+                trec_set_last_error("trec_score_prep_i8: memset failed");
+                return TREC_ERR_LAUNCH;
+            }
+            const int64_t n_elem = n * (int64_t)d;
+            unsigned sb = (unsigned)ceil_div64(n_elem, 1024 * 8);
+            if (sb > 4096) sb = 4096;
+            if (sb < 1) sb = 1;
+            hipLaunchKernelGGL(sumsq_absmax_kernel, dim3(sb), dim3(256), 0, st, repr, n_elem, workspace);
+            hipLaunchKernelGGL(scale_from_stats_kernel, dim3(1), dim3(1), 0, st, workspace, (double)n_elem, clip_sigmas, scales);
+        } else {
+            hipLaunchKernelGGL(sb_scale_kernel, dim3((unsigned)ceil_div64(n, sb_rows)), dim3(1024), 0, st, repr, n, d, sb_rows, sb_stats);
         }
-        const int64_t n_elem = n * (int64_t)d;
-        unsigned sb = (unsigned)ceil_div64(n_elem, 1024 * 8);
-        if (sb > 4096) sb = 4096;
-        if (sb < 1) sb = 1;
-        hipLaunchKernelGGL(sumsq_absmax_kernel, dim3(sb), dim3(256), 0, st, repr, n_elem, workspace);
-        hipLaunchKernelGGL(scale_from_stats_kernel, dim3(1), dim3(1), 0, st, workspace, (double)n_elem, clip_sigmas, side, scales);
         const int g = kpad >= 128 ? 32 : kpad / 4;
         const unsigned blocks = (unsigned)ceil_div64(n * g, 256);
-#define TREC_PQ(GV) hipLaunchKernelGGL(prep_i8_kernel<GV>, dim3(blocks), dim3(256), 0, st, repr, n, d, kpad, scales + side, (signed char*)out_q, (float2*)row_stats, side == 1 ? gstats : (float*)nullptr)
+#define TREC_PQ(GV) hipLaunchKernelGGL(prep_i8_kernel<GV>, dim3(blocks), dim3(256), 0, st, repr, n, d, kpad, scales, side == 1 ? sb_rows : 0, sb_stats, (signed char*)out_q, (float2*)row_stats)
         if (g == 32) TREC_PQ(32);
         else if (g == 16) TREC_PQ(16);
         else TREC_PQ(8);
 #undef TREC_PQ
+        if (side == 1)
+            hipLaunchKernelGGL(sb_reduce_kernel, dim3((unsigned)ceil_div64(n, sb_rows)), dim3(256), 0, st, (const float2*)row_stats, n, sb_rows, sb_stats);
     }
     if (side >= 1 && bias)
-        hipLaunchKernelGGL(bias_i8_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, st, bias, n, scales, bias_q, gstats);
-    else if (side == 2)
-        hipLaunchKernelGGL(scale_prod_kernel, dim3(1), dim3(1), 0, st, scales);
+        hipLaunchKernelGGL(bias_i8_kernel, dim3((unsigned)ceil_div64(n, sb_rows)), dim3(256), 0, st, bias, n, scales, sb_rows, sb_stats, bias_q, gstats);
     return trec_check_launch("trec_score_prep_i8");
 }
 
-// blockmax[s * bm_stride + u] = scale_prod * max over the items of superblock s of (sum_k q_u q_i + bq_i) + user_bias[u]
-// (users_q / items_q: int8 [n, kpad]; item_bias_q: int32 [n_items] or NULL; scales: the device array of trec_score_prep_i8)
+// r_err [n_users][3] = the users' part of the int8 bound ({||x||, ||x - a q||, ck (|b_u| + gstats[2])}); gstats[2] = max |item
+// bias| over ALL items (item shards all-reduce it with MAX first)
+extern "C" int trec_score_user_err_i8(const float* user_stats, const float* user_bias, const float* gstats, int32_t kdim,
+                                      int64_t n_users, float* r_err, void* stream)
+{
+    TREC_REQUIRE(user_stats && gstats && r_err && kdim >= 1, "trec_score_user_err_i8: bad arguments");
+    if (n_users == 0) return TREC_OK;
+    hipLaunchKernelGGL(user_err_i8_kernel, dim3((unsigned)ceil_div64(n_users, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float2*)user_stats, user_bias, gstats, kdim, n_users, r_err);
+    return trec_check_launch("trec_score_user_err_i8");
+}
+
+// blockmax[s * bm_stride + u] = scales[0] * b_s * max over the items of superblock s of (q_u . q_i + bq_i) + user_bias[u]
+// (users_q / items_q: int8 [n, kpad]; item_bias_q: int32 [n_items] or NULL; scales / sb_stats: trec_score_prep_i8).
+// user_err + chunk_top + top_k (all or none): chunk_top [n_chunks_eff * top_k][bm_stride] receives, per chunk of superblocks
+// and user, the top_k largest lower bounds M - e(u, s), sorted descending, -inf padded; top_k = 10 or 16;
+// n_chunks_eff = ceil(n_items / chunk_len), chunk_len = ceil(ceil(n_items / n_chunks) / sb_rows) * sb_rows.
 extern "C" int trec_score_gemm_blockmax_i8(const void* users_q, const void* items_q, int32_t kpad, int64_t n_users,
                                            int64_t n_items, const float* user_bias, const int32_t* item_bias_q,
-                                           const float* scales, int32_t sb_rows, int32_t n_chunks, float* blockmax,
-                                           int64_t bm_stride, void* stream)
+                                           const float* scales, const float* sb_stats, int32_t sb_rows, int32_t n_chunks,
+                                           float* blockmax, int64_t bm_stride, const float* user_err, float* chunk_top,
+                                           int32_t top_k, void* stream)
 {
-    TREC_REQUIRE(users_q && items_q && scales && blockmax && bm_stride >= n_users, "trec_score_gemm_blockmax_i8: bad arguments");
+    TREC_REQUIRE(users_q && items_q && scales && sb_stats && blockmax && bm_stride >= n_users, "trec_score_gemm_blockmax_i8: bad arguments");
     TREC_REQUIRE(kpad == 64 || kpad == 128, "trec_score_gemm_blockmax_i8: kpad must be 64 or 128");
     TREC_REQUIRE(sb_rows >= BNQ && sb_rows % BNQ == 0, "trec_score_gemm_blockmax_i8: sb_rows must be a multiple of 128");
     TREC_REQUIRE(n_users >= 1 && n_items >= 1 && n_chunks >= 1, "trec_score_gemm_blockmax_i8: empty operand");
     TREC_REQUIRE(n_items < (int64_t)1 << 31 && n_users < (int64_t)1 << 31, "trec_score_gemm_blockmax_i8: sizes must fit int32");
+    TREC_REQUIRE((chunk_top != nullptr) == (user_err != nullptr) && (chunk_top ? (top_k == 10 || top_k == 16) : top_k == 0),
+                 "trec_score_gemm_blockmax_i8: user_err, chunk_top and top_k (10 or 16) come together");
     ScoreParams p = {};
     p.R = users_q; p.T = items_q; p.n_r = n_users; p.n_t = n_items;
     p.chunk_len = ceil_div64(ceil_div64(n_items, n_chunks), sb_rows) * sb_rows;        // chunks are whole superblocks
     p.n_chunks = (int)ceil_div64(n_items, p.chunk_len);
     p.r_bias = user_bias; p.t_bias = (const float*)item_bias_q;
     p.blockmax = blockmax; p.bm_stride = bm_stride;
-    p.scales = scales;
+    p.scales = scales; p.sb_stats = sb_stats; p.r_err = user_err; p.chunk_top = chunk_top; p.top_k = top_k;
     hipStream_t st = (hipStream_t)stream;
     const bool bias = user_bias || item_bias_q;
-    const int shape = trec_get_tuning("blockmax_i8_shape", 0);
-    if (kpad == 128) {
-        if (shape == 1) return bias ? launch_i8<128, true, 4, 3>(p, sb_rows, st) : launch_i8<128, false, 4, 3>(p, sb_rows, st);
-        if (shape == 2) return bias ? launch_i8<128, true, 2, 3>(p, sb_rows, st) : launch_i8<128, false, 2, 3>(p, sb_rows, st);
-        return bias ? launch_i8<128, true, 4, 2>(p, sb_rows, st) : launch_i8<128, false, 4, 2>(p, sb_rows, st);
-    }
-    return bias ? launch_i8<64, true, 4, 2>(p, sb_rows, st) : launch_i8<64, false, 4, 2>(p, sb_rows, st);
+#define TREC_I8(KTV, TKV) (bias ? launch_i8<KTV, true, 4, 2, TKV>(p, sb_rows, st) : launch_i8<KTV, false, 4, 2, TKV>(p, sb_rows, st))
+    if (kpad == 128) return top_k == 0 ? TREC_I8(128, 0) : (top_k == 10 ? TREC_I8(128, 10) : TREC_I8(128, 16));
+    return top_k == 0 ? TREC_I8(64, 0) : (top_k == 10 ? TREC_I8(64, 10) : TREC_I8(64, 16));
+#undef TREC_I8
 }

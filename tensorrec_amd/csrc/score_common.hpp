@@ -32,8 +32,22 @@ struct ScoreParams {
     const float* row_floor;        // nullable [n_r]: a known lower bound of the row's final k-th best score (lists start there)
     const int32_t* row_index;      // grouped TOPK: nullable [n_r], resident row r is R[row_index[r]] (bias / sqnorm / floor too)
     int independent_lists;         // grouped TOPK: a list's threshold never rises from the partner half-wave's list (variant bit 4)
-    const float* scales;           // int8 BLOCKMAX (score_blockmax_i8.hip): device float[3], [2] = integer score units -> float
+    const float* scales;           // int8 BLOCKMAX (score_blockmax_i8.hip): device float[3] = {user scale, unused, unused}
+    const float* sb_stats;         // int8 BLOCKMAX: [n_sb][4] = {item scale b_s, max ||y|| + ||dy||, max ||dy||, max |bias - a b_s bq|}
+    const float* r_err;            // int8 BLOCKMAX: nullable [n_r][3] = {||x||, ||x - a q||, ck (|b_u| + max |b_i|)} -> per-chunk top lists
+    float* chunk_top;              // int8 BLOCKMAX: [n_chunks * top_k][bm_stride]: the top_k largest LOWER BOUNDS of a chunk per user
+    int top_k;
 };
+
+// |int8 score - fp32 score| <= i8_pair_err for every item of a superblock with statistics (yh, dy, db) and a user with
+// (nx, ex, cu) -- the bound of csrc/topk_cascade.hip; ONE definition, evaluated identically (no contraction) by the int8
+// kernel (lower bounds M - e) and by the compaction (upper bounds M + e)
+__device__ __forceinline__ float i8_pair_err(float nx, float ex, float cu, float yh, float dy, float db, int kdim)
+{
+    const float ck = (float)(kdim + 4) * 2.98023224e-07f;                       // (K + 4) (2^-24 + 2^-22)
+    const float e = nx * (dy + ck * yh) + ex * yh + db + cu;
+    return e * 1.001953125f + 1e-30f;
+}
 
 // software-pipelined BLOCKMAX kernel (score_blockmax.hip): bf16 dot / cosine, kpad 64 or 128.  Returns
 // TREC_ERR_UNSUPPORTED when the configuration is not covered (the caller then uses the generic kernel).

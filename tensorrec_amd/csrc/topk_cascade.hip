@@ -1,25 +1,26 @@
 // tensorrec_amd/csrc/topk_cascade.hip -- K2c: the glue of the int8 -> bf16 -> fp32 cascade of the exact top-k.
 //
-//   stage 0  trec_score_gemm_blockmax_i8 (score_blockmax_i8.hip): table[s][u] = int8 maximum of superblock s for user u
-//   select   trec_topk_select_blocks: tau8_u = the k-th largest entry of column u
-//   floor    trec_topk_filter_floor_i8 (here): floor8_u = tau8_u - 2 eps8_u, eps8_u >= |int8 score - fp32 score| proven
-//            from the MEASURED quantisation error norms of trec_score_prep_i8
-//   compact  trec_topk_rows_count / trec_topk_rows_fill (here): the (superblock, user) pairs with table >= floor8, already
-//            grouped by superblock -- the table is superblock-major, so a row-wise stream compaction IS the grouping
-//            (no sort): per superblock a run of user ids padded with -1 to whole 512-row workgroups
+//   stage 0  trec_score_gemm_blockmax_i8 (score_blockmax_i8.hip): table[s][u] = M8 = int8 maximum of superblock s for user u,
+//            and -- kept in registers, written once per chunk of superblocks -- the k largest LOWER bounds M8 - e(u, s)
+//   select   trec_topk_select_blocks over the chunks' lists (k rows per chunk, not the table): tauLB_u = the k-th largest
+//            lower bound.  e(u, s) >= |int8 score - fp32 score| for every item of superblock s: proven from the MEASURED
+//            quantisation error norms of trec_score_prep_i8, per user and per superblock (i8_pair_err, score_common.hpp)
+//   compact  trec_topk_rows_count / trec_topk_rows_fill (here): the (superblock, user) pairs whose UPPER bound M8 + e(u, s)
+//            reaches tauLB_u, already grouped by superblock -- the table is superblock-major, so a row-wise stream
+//            compaction IS the grouping (no sort): per superblock a run of user ids padded with -1 to whole 512-row workgroups
 //   stage 1  trec_score_gemm_blockmax_grouped (here + score_blockmax.hip): the hand-scheduled bf16 kernel on the kept pairs
-//            only (~3% of them at 1M x 1M); each bf16 maximum REPLACES the int8 entry of the table
+//            only (~4% of them at 1M x 1M); each bf16 maximum REPLACES the int8 entry of the table
 //   then the bf16 filter of topk_filter.hip runs unchanged on the mixed table (select, floor16, collect, bf16 lists, fp32).
 //
-// Why the mixed table is sound (eps16 <= eps8 is NOT needed): every entry of column u -- int8 or bf16 -- certifies an item
-// of its superblock with fp32 score >= entry - eps_kind >= entry - max(eps8, eps16).  (1) A superblock holding a true
-// top-k item has int8 maximum >= tau8 - 2 eps8, so it was refined and its entry is a bf16 maximum M16 >= that item's
-// fp32 score - eps16.  (2) With eps16 <= eps8 the k largest entries of the mixed column are all refined ones (k refined
-// entries have M16 >= tau8 - eps8 - eps16 >= floor8 > every unrefined entry), so tau16 and floor16 = tau16 - 2 eps16 are
-// exactly what the bf16 filter computes from a pure bf16 table restricted to the refined superblocks; with eps16 > eps8
-// an unrefined entry among the k largest still certifies an item with fp32 score >= entry - eps8 >= entry - eps16, and
-// the argument of topk_filter.hip goes through verbatim.  Unrefined entries that pass floor16 are false positives: their
-// superblocks are re-scored like any other.
+// Nothing is lost: k superblocks have M8 - e >= tauLB, each holds an item with fp32 score >= tauLB, so the true k-th best
+// t_k >= tauLB.  A top-k item has fp32 score >= t_k >= tauLB and int8 score >= fp32 - e, so its superblock has
+// M8 + e >= tauLB: it is refined, and its table entry becomes a bf16 maximum M16 >= that item's fp32 score - eps16.
+// The mixed table is sound for the bf16 filter: an UNrefined entry has M8 < tauLB - e(u, s).  The k certifying
+// superblocks above are refined with M16 >= tauLB - eps16, so an unrefined entry with e(u, s) >= eps16 lies strictly below
+// k refined entries and is never among the k largest of its column; one with e(u, s) < eps16 certifies an item with fp32
+// score >= M8 - e > M8 - eps16 like a bf16 entry would.  Either way every one of the k largest entries certifies an item
+// with fp32 score >= entry - eps16, which is all the argument of topk_filter.hip uses for tau16 and floor16 = tau16 - 2 eps16.
+// Unrefined entries that pass floor16 are false positives: their superblocks are re-scored like any other.
 //
 // Replaces (as a filter) tf.matmul of tensorrec/prediction_graphs.py:49-50 + tf.nn.top_k of
 // tensorrec/recommendation_graphs.py:80; the results come from the fp32 finish of topk_filter.hip, bit-identical to the oracle.
@@ -28,54 +29,47 @@
 
 namespace {
 
-constexpr int CROWS = 8;          // table rows (superblocks) per workgroup
+constexpr int CROWS = 8;          // table rows (superblocks) per group: one float4 load per row and thread in flight
+constexpr int CGROUPS = 4;        // groups of rows per workgroup
 constexpr int CUSERS = 1024;      // users per workgroup: one float4 per thread
 constexpr int GROUP_ROWS = 512;   // resident rows per workgroup of the grouped bf16 kernel
 
-__global__ __launch_bounds__(256) void filter_floor_i8_kernel(const float* __restrict__ tau, const float2* __restrict__ ustats,
-                                                             const float* __restrict__ user_bias,
-                                                             const float* __restrict__ gstats, int kdim, int64_t n_users,
-                                                             float* __restrict__ floor_, int32_t* __restrict__ flag,
-                                                             int32_t* __restrict__ n_flagged)
+// table rows s0 .. s0 + CROWS - 1, users u .. u + 3 of this thread: bit (4 r + e) of the result = the superblock's UPPER
+// bound table[s0 + r][u + e] + e8 reaches thr[u + e] (the k-th largest LOWER bound, two floats down).  e8 here is
+// nx A_s + ex B_s + C_s + cu with the inflation of i8_pair_err folded into the per-row / per-user constants (rounded up):
+// it need not equal the int8 kernel's evaluation bit for bit, both only have to dominate the true error.
+struct UserConsts { float f[4], nx[4], ex[4]; };
+
+__device__ __forceinline__ UserConsts load_user_consts(const float* __restrict__ thr, const float* __restrict__ user_err,
+                                                       int64_t n_users, int64_t u)
 {
-    const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (u >= n_users) return;
-    // gstats: max over items of {||y|| + ||dy||  (>= ||b q_i||),  ||dy||,  |bias|,  |bias - scale_prod bias_q|}
-    const float ni = gstats[0], ai = gstats[1], bi = gstats[2], db = gstats[3];
-    const float2 st = ustats[u];                                                // {||x||, ||x - a q_u||}
-    const float bu = user_bias ? fabsf(user_bias[u]) : 0.f;
-    // int8 score (real arithmetic) = a b (q_u . q_i + bq_i) + b_u;  fp32 score = fl-chain(x . y) + b_u + b_i:
-    //   |x . y - a b q_u . q_i| = |<x - a q_u, b q_i> + <x, y - b q_i>| <= ||dx|| ||b q_i|| + ||x|| ||dy||
-    //   the reference's chain and its two bias adds, the table's conversion and add: (K + 4) roundings of terms bounded by
-    //   ||x|| ||y|| + |b_u| + |b_i|, covered by ck below with room to spare; the bias quantisation adds db.
-    const float ck = (float)(kdim + 4) * 2.98023224e-07f;                       // (K + 4) (2^-24 + 2^-22)
-    float eps = st.y * ni + st.x * ai + ck * (st.x * ni + bu + bi) + db;
-    eps = eps * 1.001953125f + 1e-30f;
-    const float t = tau[u];
-    float f = t - 2.0f * eps;
-    bool bad = !(eps < INFINITY);
-    if (t == -INFINITY) f = -INFINITY;                                          // fewer than k superblocks: keep all
-    else if (!(f == f)) bad = true;
-    else f = float_pred(float_pred(f));
-    if (bad) f = -INFINITY;                                                     // every superblock of this user is refined
-    floor_[u] = f;
-    if (flag) flag[u] = bad ? 1 : 0;
-    if (bad && n_flagged) atomicAdd(n_flagged, 1);
+    const float infl = 1.0029296875f;                      // 1 + 3 * 2^-10 > (1 + 2^-9) (1 + 2^-12): covers the re-association
+    UserConsts c;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const bool in = u + e < n_users;
+        c.nx[e] = in ? user_err[(u + e) * 3] : 0.f;
+        c.ex[e] = in ? user_err[(u + e) * 3 + 1] : 0.f;
+        const float cu = in ? user_err[(u + e) * 3 + 2] * infl + 2e-30f : 0.f;
+        c.f[e] = in ? float_pred(float_pred(thr[u + e])) - cu : INFINITY;        // v + nx A + ex B + C >= thr - cu
+        if (in) c.f[e] = float_pred(c.f[e]);                                      // the subtraction may have rounded up
+    }
+    return c;
 }
 
-// table rows s0 .. s0 + CROWS - 1, users u .. u + 3 of this thread: bit (4 r + e) of the result = table[s0 + r][u + e] >= floor
 __device__ __forceinline__ unsigned int tile_bits(const float* __restrict__ table, int32_t n_sb, int64_t n_users, int64_t stride,
-                                                  const float* __restrict__ floor_, int32_t s0, int64_t u)
+                                                  const UserConsts& c, const float* __restrict__ sb_stats, int kdim,
+                                                  int32_t s0, int64_t u)
 {
-    float f[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) f[e] = (u + e < n_users) ? floor_[u + e] : INFINITY;
+    const float infl = 1.0029296875f;
+    const float ck = (float)(kdim + 4) * 2.98023224e-07f;
     const bool vec = (stride % 4 == 0) && (((uintptr_t)table % 16) == 0) && (u + 3 < stride);
     unsigned int bits = 0;
 #pragma unroll
     for (int r = 0; r < CROWS; ++r) {
         const int32_t s = s0 + r;
         f32x4 v = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        float A = 0.f, B = 0.f, C = 0.f;
         if (s < n_sb) {
             const float* src = table + (int64_t)s * stride + u;
             if (vec) v = __builtin_nontemporal_load((const f32x4*)src);
@@ -83,33 +77,46 @@ __device__ __forceinline__ unsigned int tile_bits(const float* __restrict__ tabl
 #pragma unroll
                 for (int e = 0; e < 4; ++e) if (u + e < n_users) v[e] = src[e];
             }
+            const f32x4 ss = *(const f32x4*)(sb_stats + (int64_t)s * 4);
+            A = (ss[2] + ck * ss[1]) * infl; B = ss[1] * infl; C = ss[3] * infl;
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            if (s < n_sb && u + e < n_users && !(v[e] < f[e])) bits |= 1u << (4 * r + e);
+            if (s < n_sb && u + e < n_users && !(__fmaf_rn(c.nx[e], A, __fmaf_rn(c.ex[e], B, v[e] + C)) < c.f[e]))
+                bits |= 1u << (4 * r + e);
     }
     return bits;
 }
 
+// A workgroup owns 1024 users x CGROUPS groups of CROWS table rows: the users' constants are loaded once (per 8-row group
+// they were half as many bytes again as the table itself).
 __global__ __launch_bounds__(256) void rows_count_kernel(const float* __restrict__ table, int32_t n_sb, int64_t n_users,
-                                                        int64_t stride, const float* __restrict__ floor_, int32_t n_ublk,
+                                                        int64_t stride, const float* __restrict__ thr,
+                                                        const float* __restrict__ user_err,
+                                                        const float* __restrict__ sb_stats, int kdim, int32_t n_ublk,
                                                         int32_t* __restrict__ blockcnt)
 {
-    __shared__ int cnt[CROWS];
-    if (threadIdx.x < CROWS) cnt[threadIdx.x] = 0;
+    __shared__ int cnt[CGROUPS][CROWS];
+    if (threadIdx.x < CGROUPS * CROWS) (&cnt[0][0])[threadIdx.x] = 0;
     __syncthreads();
-    const int32_t s0 = blockIdx.y * CROWS;
     const int64_t u = (int64_t)blockIdx.x * CUSERS + threadIdx.x * 4;
-    const unsigned int bits = tile_bits(table, n_sb, n_users, stride, floor_, s0, u);
+    const UserConsts c = load_user_consts(thr, user_err, n_users, u);
+    for (int g = 0; g < CGROUPS; ++g) {
+        const int32_t s0 = (blockIdx.y * CGROUPS + g) * CROWS;
+        if (s0 >= n_sb) break;
+        const unsigned int bits = tile_bits(table, n_sb, n_users, stride, c, sb_stats, kdim, s0, u);
 #pragma unroll
-    for (int r = 0; r < CROWS; ++r) {
-        int c = __builtin_popcount((bits >> (4 * r)) & 15u);
-        for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
-        if ((threadIdx.x & 63) == 0 && c) atomicAdd(&cnt[r], c);
+        for (int r = 0; r < CROWS; ++r) {
+            int k = __builtin_popcount((bits >> (4 * r)) & 15u);
+            for (int off = 32; off > 0; off >>= 1) k += __shfl_xor(k, off, 64);
+            if ((threadIdx.x & 63) == 0 && k) atomicAdd(&cnt[g][r], k);
+        }
     }
     __syncthreads();
-    if (threadIdx.x < CROWS && s0 + threadIdx.x < n_sb)
-        blockcnt[(int64_t)(s0 + threadIdx.x) * n_ublk + blockIdx.x] = cnt[threadIdx.x];
+    if (threadIdx.x < CGROUPS * CROWS) {
+        const int32_t s = blockIdx.y * CGROUPS * CROWS + threadIdx.x;
+        if (s < n_sb) blockcnt[(int64_t)s * n_ublk + blockIdx.x] = (&cnt[0][0])[threadIdx.x];
+    }
 }
 
 // one workgroup per table row: exclusive scan of the row's block counts in place, the row's total and its padded size
@@ -190,82 +197,78 @@ __global__ __launch_bounds__(256) void rows_tail_kernel(const int64_t* __restric
 }
 
 __global__ __launch_bounds__(256) void rows_fill_kernel(const float* __restrict__ table, int32_t n_sb, int64_t n_users,
-                                                       int64_t stride, const float* __restrict__ floor_, int32_t n_ublk,
+                                                       int64_t stride, const float* __restrict__ thr,
+                                                       const float* __restrict__ user_err,
+                                                       const float* __restrict__ sb_stats, int kdim, int32_t n_ublk,
                                                        const int32_t* __restrict__ blockoff,
                                                        const int32_t* __restrict__ row_total,
                                                        const int64_t* __restrict__ pstart, int32_t* __restrict__ row_user,
                                                        int32_t* __restrict__ rblock_chunk, const int64_t* __restrict__ status)
 {
-    __shared__ int wsum[CROWS][4];
+    __shared__ int wsum[2][CROWS][4];
     if (status[1]) return;                                       // more pairs than row_user holds: nothing is refined
-    const int32_t s0 = blockIdx.y * CROWS;
     const int64_t u = (int64_t)blockIdx.x * CUSERS + threadIdx.x * 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned int bits = tile_bits(table, n_sb, n_users, stride, floor_, s0, u);
-    int pre[CROWS];
+    const UserConsts c = load_user_consts(thr, user_err, n_users, u);
+    for (int g = 0; g < CGROUPS; ++g) {
+        const int32_t s0 = (blockIdx.y * CGROUPS + g) * CROWS;
+        if (s0 >= n_sb) break;
+        const unsigned int bits = tile_bits(table, n_sb, n_users, stride, c, sb_stats, kdim, s0, u);
+        int pre[CROWS];
 #pragma unroll
-    for (int r = 0; r < CROWS; ++r) {
-        const int c = __builtin_popcount((bits >> (4 * r)) & 15u);
-        int inc = c;
-        for (int off = 1; off < 64; off <<= 1) {
-            const int t = __shfl_up(inc, off, 64);
-            if (lane >= off) inc += t;
+        for (int r = 0; r < CROWS; ++r) {
+            const int k = __builtin_popcount((bits >> (4 * r)) & 15u);
+            int inc = k;
+            for (int off = 1; off < 64; off <<= 1) {
+                const int t = __shfl_up(inc, off, 64);
+                if (lane >= off) inc += t;
+            }
+            pre[r] = inc - k;
+            if (lane == 63) wsum[g & 1][r][wave] = inc;
         }
-        pre[r] = inc - c;
-        if (lane == 63) wsum[r][wave] = inc;
-    }
-    __syncthreads();
+        __syncthreads();                                         // (two alternating buffers: one barrier per group is enough)
 #pragma unroll
-    for (int r = 0; r < CROWS; ++r) {
-        const int32_t s = s0 + r;
-        if (s >= n_sb) break;
-        const unsigned int m = (bits >> (4 * r)) & 15u;
-        if (m) {
-            int base = pre[r];
-            for (int w = 0; w < wave; ++w) base += wsum[r][w];
-            int64_t dst = pstart[s] + blockoff[(int64_t)s * n_ublk + blockIdx.x] + base;
+        for (int r = 0; r < CROWS; ++r) {
+            const int32_t s = s0 + r;
+            if (s >= n_sb) break;
+            const unsigned int m = (bits >> (4 * r)) & 15u;
+            if (m) {
+                int base = pre[r];
+                for (int w = 0; w < wave; ++w) base += wsum[g & 1][r][w];
+                int64_t dst = pstart[s] + blockoff[(int64_t)s * n_ublk + blockIdx.x] + base;
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if ((m >> e) & 1u) row_user[dst++] = (int32_t)(u + e);
-        }
-        if (blockIdx.x == 0) {                                   // the row's padding entries and its workgroups' superblock ids
-            const int64_t p0 = pstart[s], p1 = pstart[s + 1];
-            for (int64_t j = p0 + row_total[s] + threadIdx.x; j < p1; j += 256) row_user[j] = -1;
-            for (int64_t w = p0 / GROUP_ROWS + threadIdx.x; w < p1 / GROUP_ROWS; w += 256) rblock_chunk[w] = s;
+                for (int e = 0; e < 4; ++e)
+                    if ((m >> e) & 1u) row_user[dst++] = (int32_t)(u + e);
+            }
+            if (blockIdx.x == 0) {                               // the row's padding entries and its workgroups' superblock ids
+                const int64_t p0 = pstart[s], p1 = pstart[s + 1];
+                for (int64_t j = p0 + row_total[s] + threadIdx.x; j < p1; j += 256) row_user[j] = -1;
+                for (int64_t w = p0 / GROUP_ROWS + threadIdx.x; w < p1 / GROUP_ROWS; w += 256) rblock_chunk[w] = s;
+            }
         }
     }
 }
 
 }  // namespace
 
-extern "C" int trec_topk_filter_floor_i8(const float* tau, const float* user_stats, const float* user_bias,
-                                         const float* item_gstats, int32_t kdim, int64_t n_users, float* floor_,
-                                         int32_t* flag, int32_t* n_flagged, void* stream)
-{
-    TREC_REQUIRE(tau && user_stats && item_gstats && floor_, "trec_topk_filter_floor_i8: null pointer");
-    TREC_REQUIRE(kdim >= 1, "trec_topk_filter_floor_i8: bad sizes");
-    if (n_users == 0) return TREC_OK;
-    hipLaunchKernelGGL(filter_floor_i8_kernel, dim3((unsigned)ceil_div64(n_users, 256)), dim3(256), 0, (hipStream_t)stream,
-                       tau, (const float2*)user_stats, user_bias, item_gstats, kdim, n_users, floor_, flag, n_flagged);
-    return trec_check_launch("trec_topk_filter_floor_i8");
-}
-
 extern "C" int32_t trec_topk_rows_user_blocks(int64_t n_users) { return (int32_t)ceil_div64(n_users, CUSERS); }
 
 // pass 1 of the row-wise compaction: block_off [n_sb][trec_topk_rows_user_blocks(n_users)] (scratch for pass 2),
 // row_total [n_sb], pstart [n_sb + 1] (int64; pstart[n_sb] = resident rows of the grouped launch, a multiple of 512),
 // status int64[2] = {pstart[n_sb], overflow: it exceeds cap_rows} -- nothing here needs the host
-extern "C" int trec_topk_rows_count(const float* table, int32_t n_sb, int64_t n_users, int64_t stride, const float* floor_,
-                                    int32_t* block_off, int32_t* row_total, int32_t* row_pad, int64_t* pstart,
-                                    int64_t cap_rows, int64_t* status, void* stream)
+extern "C" int trec_topk_rows_count(const float* table, int32_t n_sb, int64_t n_users, int64_t stride, const float* thr,
+                                    const float* user_err, const float* sb_stats, int32_t kdim, int32_t* block_off,
+                                    int32_t* row_total, int32_t* row_pad, int64_t* pstart, int64_t cap_rows,
+                                    int64_t* status, void* stream)
 {
-    TREC_REQUIRE(table && floor_ && block_off && row_total && row_pad && pstart && status, "trec_topk_rows_count: null pointer");
+    TREC_REQUIRE(table && thr && user_err && sb_stats && block_off && row_total && row_pad && pstart && status,
+                 "trec_topk_rows_count: null pointer");
     TREC_REQUIRE(cap_rows >= 0 && cap_rows % GROUP_ROWS == 0, "trec_topk_rows_count: cap_rows must be a multiple of 512");
     TREC_REQUIRE(n_sb >= 1 && n_users >= 1 && stride >= n_users, "trec_topk_rows_count: bad sizes");
     hipStream_t st = (hipStream_t)stream;
     const int n_ublk = (int)ceil_div64(n_users, CUSERS);
-    hipLaunchKernelGGL(rows_count_kernel, dim3((unsigned)n_ublk, (unsigned)((n_sb + CROWS - 1) / CROWS)), dim3(256), 0, st,
-                       table, n_sb, n_users, stride, floor_, n_ublk, block_off);
+    hipLaunchKernelGGL(rows_count_kernel, dim3((unsigned)n_ublk, (unsigned)((n_sb + CROWS * CGROUPS - 1) / (CROWS * CGROUPS))), dim3(256), 0, st,
+                       table, n_sb, n_users, stride, thr, user_err, sb_stats, kdim, n_ublk, block_off);
     hipLaunchKernelGGL(rows_scan_kernel, dim3((unsigned)n_sb), dim3(256), 0, st, block_off, n_ublk, row_total, row_pad);
     hipLaunchKernelGGL(rows_pstart_kernel, dim3(1), dim3(256), 0, st, row_pad, n_sb, pstart, cap_rows, status);
     return trec_check_launch("trec_topk_rows_count");
@@ -274,19 +277,19 @@ extern "C" int trec_topk_rows_count(const float* table, int32_t n_sb, int64_t n_
 // pass 2: row_user [cap_rows], first pstart[n_sb] entries = the kept users of superblock 0, padding (-1), those of
 // superblock 1, ... (ascending user ids inside a superblock); rblock_chunk [cap_rows / 512] = the superblock of each
 // 512-row workgroup, -1 for the workgroups beyond pstart[n_sb] / 512 (all of them when status[1] is set)
-extern "C" int trec_topk_rows_fill(const float* table, int32_t n_sb, int64_t n_users, int64_t stride, const float* floor_,
-                                   const int32_t* block_off, const int32_t* row_total, const int64_t* pstart,
-                                   int64_t cap_rows, const int64_t* status, int32_t* row_user, int32_t* rblock_chunk,
-                                   void* stream)
+extern "C" int trec_topk_rows_fill(const float* table, int32_t n_sb, int64_t n_users, int64_t stride, const float* thr,
+                                   const float* user_err, const float* sb_stats, int32_t kdim, const int32_t* block_off,
+                                   const int32_t* row_total, const int64_t* pstart, int64_t cap_rows, const int64_t* status,
+                                   int32_t* row_user, int32_t* rblock_chunk, void* stream)
 {
-    TREC_REQUIRE(table && floor_ && block_off && row_total && pstart && status && row_user && rblock_chunk,
+    TREC_REQUIRE(table && thr && user_err && sb_stats && block_off && row_total && pstart && status && row_user && rblock_chunk,
                  "trec_topk_rows_fill: null pointer");
     TREC_REQUIRE(cap_rows >= GROUP_ROWS && cap_rows % GROUP_ROWS == 0, "trec_topk_rows_fill: cap_rows must be a multiple of 512");
     TREC_REQUIRE(n_sb >= 1 && n_users >= 1 && stride >= n_users, "trec_topk_rows_fill: bad sizes");
     const int n_ublk = (int)ceil_div64(n_users, CUSERS);
-    hipLaunchKernelGGL(rows_fill_kernel, dim3((unsigned)n_ublk, (unsigned)((n_sb + CROWS - 1) / CROWS)), dim3(256), 0,
-                       (hipStream_t)stream, table, n_sb, n_users, stride, floor_, n_ublk, block_off, row_total, pstart,
-                       row_user, rblock_chunk, status);
+    hipLaunchKernelGGL(rows_fill_kernel, dim3((unsigned)n_ublk, (unsigned)((n_sb + CROWS * CGROUPS - 1) / (CROWS * CGROUPS))), dim3(256), 0,
+                       (hipStream_t)stream, table, n_sb, n_users, stride, thr, user_err, sb_stats, kdim, n_ublk, block_off,
+                       row_total, pstart, row_user, rblock_chunk, status);
     const int64_t cap_wgs = cap_rows / GROUP_ROWS;
     unsigned tb = (unsigned)ceil_div64(cap_wgs, 256);
     if (tb > 1024) tb = 1024;

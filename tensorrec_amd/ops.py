@@ -920,11 +920,13 @@ class FilterOperand(object):
     [n, kpad] exact operand (the representation itself when it needs neither padding nor normalising), ``stats`` [n, 2]
     = {||x||, ||x - bf16(x)||} per row, ``gstats`` [3] = maxima of both and of |bias| over the rows (item side).
     The int8 pre-filter (score_prep_i8_pair) adds ``i8`` [n, kpad] int8, ``stats8`` [n, 2] = {||x||, ||x - scale q||},
-    and on the item side ``bias_q`` int32 [n], ``gstats8`` [4], ``scales`` [3] = {user scale, item scale, product}."""
-    __slots__ = ("bf16", "f32", "n", "d", "kpad", "stats", "gstats", "i8", "stats8", "bias_q", "gstats8", "scales")
+    and on the item side ``bias_q`` int32 [n], ``sb_stats`` [n_sb, 4] = per superblock of ``sb_rows`` items {scale, max
+    ||y|| + ||dy||, max ||dy||, max bias quantisation error}, ``gstats8`` [4] ([2] = max |bias|), ``scales`` [3] ([0] = user scale)."""
+    __slots__ = ("bf16", "f32", "n", "d", "kpad", "stats", "gstats", "i8", "stats8", "bias_q", "gstats8", "scales",
+                 "sb_stats", "sb_rows")
 
     def __init__(self):
-        self.i8 = self.stats8 = self.bias_q = self.gstats8 = self.scales = None
+        self.i8 = self.stats8 = self.bias_q = self.gstats8 = self.scales = self.sb_stats = self.sb_rows = None
 
 
 def score_prep_filter(repr_, normalize=False, bias=None, want_gstats=False):
@@ -979,37 +981,50 @@ def cascade_prefilter_for(n_components, n_items_total):
     return "int8" if score_kpad(n_components) in (64, 128) and n_items_total >= CASCADE_MIN_ITEMS else None
 
 
-def score_prep_i8_pair(uop, iop, item_bias=None):
+def score_prep_i8_pair(uop, iop, item_bias=None, sb_rows=None):
     """int8 operands of both sides for the cascade's pre-filter (trec_score_prep_i8), from the fp32 operands of
-    FilterOperand (already normalised / padded).  One scale per side: users min(4 rms, max |x|) / 127, items max |x| / 127.
-    The item rows are quantised once per ``iop``; a new batch of users (its own scale) only re-derives the scale product
-    and the item biases in units of it."""
+    FilterOperand (already normalised / padded).  Users: one scale, min(4 rms, max |x|) / 127.  Items: one scale per
+    superblock of ``sb_rows`` rows (max |y| / 127 over the superblock: no item clips), with the superblock's error maxima
+    in ``iop.sb_stats`` [n_sb, 4].  The item rows are quantised once per ``iop``; a new batch of users (its own scale) only
+    re-derives the item biases in units of the new scale products."""
     if uop.kpad > 128:
         raise ValueError("int8 pre-filter covers kpad <= 128")
+    sb_rows = int(sb_rows or SUPERBLOCK_ROWS)
     dev = uop.f32.device
     ws = torch.empty((2,), dtype=torch.float64, device=dev)
     clip = N.load().trec_get_tuning(b"i8_user_clip_x10", int(I8_USER_CLIP_SIGMAS * 10)) / 10.0
     with _timed("score_prep_i8"):
-        fresh_items = iop.i8 is None
+        fresh_items = iop.i8 is None or iop.sb_rows != sb_rows
+        n_sb = (iop.n + sb_rows - 1) // sb_rows
         if fresh_items:
             iop.scales = torch.zeros((3,), dtype=torch.float32, device=dev)
             iop.gstats8 = torch.zeros((4,), dtype=torch.float32, device=dev)
+            iop.sb_stats = torch.zeros((n_sb, 4), dtype=torch.float32, device=dev)
+            iop.sb_rows = sb_rows
             iop.i8 = torch.empty((iop.n, iop.kpad), dtype=torch.int8, device=dev)
             iop.stats8 = torch.empty((iop.n, 2), dtype=torch.float32, device=dev)
         else:
             iop.gstats8[2:].zero_()
+            iop.sb_stats[:, 3].zero_()
         iop.bias_q = torch.empty((iop.n,), dtype=torch.int32, device=dev) if item_bias is not None else None
         uop.i8 = torch.empty((uop.n, uop.kpad), dtype=torch.int8, device=dev)
         uop.stats8 = torch.empty((uop.n, 2), dtype=torch.float32, device=dev)
-        N.call("trec_score_prep_i8", N.ptr(uop.f32), uop.n, uop.f32.shape[1], uop.kpad, 0, float(clip), None,
-               N.ptr(iop.scales), N.ptr(ws), N.ptr(uop.i8), N.ptr(uop.stats8), None, None)
+        N.call("trec_score_prep_i8", N.ptr(uop.f32), uop.n, uop.f32.shape[1], uop.kpad, 0, float(clip), 0, None,
+               N.ptr(iop.scales), N.ptr(ws), N.ptr(uop.i8), N.ptr(uop.stats8), None, None, None)
         if fresh_items:
-            N.call("trec_score_prep_i8", N.ptr(iop.f32), iop.n, iop.f32.shape[1], iop.kpad, 1, 0.0, N.ptr(item_bias),
-                   N.ptr(iop.scales), N.ptr(ws), N.ptr(iop.i8), N.ptr(iop.stats8), N.ptr(iop.bias_q), N.ptr(iop.gstats8))
-        else:
-            N.call("trec_score_prep_i8", None, iop.n, iop.f32.shape[1], iop.kpad, 2, 0.0, N.ptr(item_bias),
-                   N.ptr(iop.scales), None, None, None, N.ptr(iop.bias_q), N.ptr(iop.gstats8))
+            N.call("trec_score_prep_i8", N.ptr(iop.f32), iop.n, iop.f32.shape[1], iop.kpad, 1, 0.0, sb_rows,
+                   N.ptr(item_bias), N.ptr(iop.scales), None, N.ptr(iop.i8), N.ptr(iop.stats8), N.ptr(iop.bias_q),
+                   N.ptr(iop.sb_stats), N.ptr(iop.gstats8))
+        elif item_bias is not None:
+            N.call("trec_score_prep_i8", None, iop.n, iop.f32.shape[1], iop.kpad, 2, 0.0, sb_rows, N.ptr(item_bias),
+                   N.ptr(iop.scales), None, None, None, N.ptr(iop.bias_q), N.ptr(iop.sb_stats), N.ptr(iop.gstats8))
     return uop, iop
+
+
+def blockmax_i8_chunks(n_items, n_chunks, sb_rows):
+    """(chunk length in items, number of chunks) trec_score_gemm_blockmax_i8 uses for a requested chunk count."""
+    chunk_len = -(-(-(-n_items // n_chunks)) // sb_rows) * sb_rows
+    return chunk_len, -(-n_items // chunk_len)
 
 
 def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, floor_exchange, stats_exchange):
@@ -1017,31 +1032,36 @@ def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, 
     maxima whose entries are bf16 maxima wherever a top-k item can be and int8 maxima elsewhere, its row stride, and the
     device int64[2] ``status`` = {resident rows of the grouped launch, overflow}.  No host round trip: the grouped launch is
     sized for CASCADE_MAX_REFINED of the pairs (workgroups beyond the kept pairs exit at once); when the int8 bound is too
-    loose for the data and more pairs reach the floor, ``status[1]`` is set, nothing is refined, and the caller -- who reads
-    it when the pipeline has drained -- runs the dense bf16 stage 1 instead."""
+    loose for the data and more pairs reach the threshold, ``status[1]`` is set, nothing is refined, and the caller -- who
+    reads it when the pipeline has drained -- runs the dense bf16 stage 1 instead."""
     dev = uop.bf16.device
     n_u, n_i, kpad = uop.n, iop.n, uop.kpad
-    if uop.i8 is None or iop.i8 is None:
-        score_prep_i8_pair(uop, iop, item_bias)
+    if uop.i8 is None or iop.i8 is None or iop.sb_rows != sb_rows:
+        score_prep_i8_pair(uop, iop, item_bias, sb_rows)
+    gstats8 = iop.gstats8
+    if stats_exchange is not None:                  # max |item bias| over ALL shards enters every user's bound
+        gstats8 = stats_exchange(gstats8).contiguous()
+    user_err = torch.empty((n_u, 3), dtype=torch.float32, device=dev)
+    N.call("trec_score_user_err_i8", N.ptr(uop.stats8), N.ptr(user_bias), N.ptr(gstats8), kpad, n_u, N.ptr(user_err))
     stride = (n_u + 3) // 4 * 4
+    kk = int(k)
+    top_k = 10 if kk <= 10 else 16
+    _, n_ch = blockmax_i8_chunks(n_i, n_chunks, sb_rows)
     table = torch.empty((n_sb, stride), dtype=torch.float32, device=dev)
+    chunk_top = torch.empty((n_ch * top_k, stride), dtype=torch.float32, device=dev)
     with _timed("score_gemm_blockmax_i8"):
         N.call("trec_score_gemm_blockmax_i8", N.ptr(uop.i8), N.ptr(iop.i8), kpad, n_u, n_i, N.ptr(user_bias),
-               N.ptr(iop.bias_q), N.ptr(iop.scales), sb_rows, n_chunks, N.ptr(table), stride)
-    kk = int(k)
+               N.ptr(iop.bias_q), N.ptr(iop.scales), N.ptr(iop.sb_stats), sb_rows, n_chunks, N.ptr(table), stride,
+               N.ptr(user_err), N.ptr(chunk_top), top_k)
+    # tau = the k-th largest LOWER bound: from the chunks' lists (k rows per chunk), not from the 7.8 GB table
     sel = torch.empty((n_u, kk), dtype=torch.int32, device=dev)
     sel_max = torch.empty((kk, n_u), dtype=torch.float32, device=dev) if floor_exchange is not None else None
     tau = torch.empty((n_u,), dtype=torch.float32, device=dev)
     with _timed("topk_select_blocks"):
-        N.call("trec_topk_select_blocks", N.ptr(table), n_sb, n_u, stride, kk, N.ptr(sel), N.ptr(sel_max), N.ptr(tau))
-    gstats8 = iop.gstats8
+        N.call("trec_topk_select_blocks", N.ptr(chunk_top), n_ch * top_k, n_u, stride, kk, N.ptr(sel), N.ptr(sel_max),
+               N.ptr(tau))
     if floor_exchange is not None:
         tau = floor_exchange(sel_max).contiguous()
-    if stats_exchange is not None:
-        gstats8 = stats_exchange(gstats8).contiguous()
-    floor8 = torch.empty((n_u,), dtype=torch.float32, device=dev)
-    N.call("trec_topk_filter_floor_i8", N.ptr(tau), N.ptr(uop.stats8), N.ptr(user_bias), N.ptr(gstats8), kpad, n_u,
-           N.ptr(floor8), None, None)
     n_ublk = N.query("trec_topk_rows_user_blocks", n_u)
     block_off = torch.empty((n_sb * n_ublk,), dtype=torch.int32, device=dev)
     row_total = torch.empty((n_sb,), dtype=torch.int32, device=dev)
@@ -1052,10 +1072,11 @@ def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, 
     row_user = torch.empty((cap_rows,), dtype=torch.int32, device=dev)          # only the kept pairs' part is touched
     rblock_chunk = torch.empty((cap_rows // 512,), dtype=torch.int32, device=dev)
     with _timed("topk_rows_compact"):
-        N.call("trec_topk_rows_count", N.ptr(table), n_sb, n_u, stride, N.ptr(floor8), N.ptr(block_off), N.ptr(row_total),
-               N.ptr(row_pad), N.ptr(pstart), cap_rows, N.ptr(status))
-        N.call("trec_topk_rows_fill", N.ptr(table), n_sb, n_u, stride, N.ptr(floor8), N.ptr(block_off), N.ptr(row_total),
-               N.ptr(pstart), cap_rows, N.ptr(status), N.ptr(row_user), N.ptr(rblock_chunk))
+        N.call("trec_topk_rows_count", N.ptr(table), n_sb, n_u, stride, N.ptr(tau), N.ptr(user_err), N.ptr(iop.sb_stats),
+               kpad, N.ptr(block_off), N.ptr(row_total), N.ptr(row_pad), N.ptr(pstart), cap_rows, N.ptr(status))
+        N.call("trec_topk_rows_fill", N.ptr(table), n_sb, n_u, stride, N.ptr(tau), N.ptr(user_err), N.ptr(iop.sb_stats),
+               kpad, N.ptr(block_off), N.ptr(row_total), N.ptr(pstart), cap_rows, N.ptr(status), N.ptr(row_user),
+               N.ptr(rblock_chunk))
     with _timed("score_gemm_blockmax_grouped"):
         N.call("trec_score_gemm_blockmax_grouped", N.ptr(uop.bf16), N.ptr(iop.bf16), kpad, cap_rows, n_i,
                N.ptr(user_bias), N.ptr(item_bias), sb_rows, N.ptr(rblock_chunk), N.ptr(row_user), N.ptr(table), stride)

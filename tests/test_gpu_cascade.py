@@ -121,76 +121,130 @@ def test_cascade_non_finite_rows_fall_back(ops):
     assert np.array_equal(vals, ev.cpu().numpy(), equal_nan=True)
 
 
+def _pair_err(nx, ex, cu, yh, dy, db, kdim):
+    """i8_pair_err (csrc/score_common.hpp) in float32, operation for operation."""
+    f = np.float32
+    ck = f(kdim + 4) * f(2.98023224e-07)
+    e = nx * (dy + ck * yh) + ex * yh + db + cu
+    return e * f(1.001953125) + f(1e-30)
+
+
 def test_int8_table_is_exact_integer_arithmetic_and_bound_holds(ops):
     from tensorrec_amd import _native as N
     rng = np.random.default_rng(8)
     n_u, n_i, d, sb = 640, 30000 + 5, 128, 512
     u = rng.standard_normal((n_u, d)).astype(np.float32) * rng.uniform(0.5, 2, (n_u, 1)).astype(np.float32)
-    v = rng.standard_normal((n_i, d)).astype(np.float32)
+    v = rng.standard_normal((n_i, d)).astype(np.float32) * rng.uniform(0.3, 3, (n_i, 1)).astype(np.float32)
     ub = rng.standard_normal(n_u).astype(np.float32) * 0.3
     ib = rng.standard_normal(n_i).astype(np.float32) * 0.3
     uop = ops.score_prep_filter(dev(u))
     iop = ops.score_prep_filter(dev(v), bias=dev(ib), want_gstats=True)
-    ops.score_prep_i8_pair(uop, iop, dev(ib))
-    a, b, ab = iop.scales.cpu().numpy()
-    assert ab == np.float32(a) * np.float32(b)
+    ops.score_prep_i8_pair(uop, iop, dev(ib), sb)
+    n_sb = (n_i + sb - 1) // sb
+    a = iop.scales.cpu().numpy()[0]
+    sbs = iop.sb_stats.cpu().numpy()
+    b_row = np.repeat(sbs[:, 0], sb)[:n_i]                                    # one item scale per superblock
     uq, iq = uop.i8.cpu().numpy().astype(np.int64), iop.i8.cpu().numpy().astype(np.int64)
     # quantisation as documented, error norms as measured
-    assert np.array_equal(iq, np.clip(np.rint(v * (np.float32(1) / b)), -127, 127).astype(np.int64))
-    assert np.abs(iq).max() == 127                                           # item scale = max |x| / 127: nothing clips
-    np.testing.assert_allclose(iop.stats8.cpu().numpy()[:, 1], np.linalg.norm(v - iq * b, axis=1), rtol=1e-4)
+    for s in range(n_sb):
+        blk = v[s * sb:(s + 1) * sb]
+        assert sbs[s, 0] == np.abs(blk).max() / np.float32(127)
+    assert np.array_equal(iq, np.clip(np.rint(v * (np.float32(1) / b_row)[:, None]), -127, 127).astype(np.int64))
+    assert all(np.abs(iq[s * sb:(s + 1) * sb]).max() == 127 for s in range(n_sb))          # every superblock uses its full range
+    dy = np.linalg.norm(v - iq * b_row[:, None], axis=1)
+    np.testing.assert_allclose(iop.stats8.cpu().numpy()[:, 1], dy, rtol=1e-4)
     np.testing.assert_allclose(uop.stats8.cpu().numpy()[:, 1], np.linalg.norm(u - uq * a, axis=1), rtol=1e-4)
+    st8 = iop.stats8.cpu().numpy()
+    for s in (0, 7, n_sb - 1):
+        rows = slice(s * sb, min(n_i, (s + 1) * sb))
+        assert sbs[s, 1] == (st8[rows, 0] + st8[rows, 1]).max() and sbs[s, 2] == st8[rows, 1].max()
+    sp_row = np.float32(a) * b_row
     bq = iop.bias_q.cpu().numpy().astype(np.int64)
-    assert np.array_equal(bq, np.rint(ib / ab).astype(np.int64))
-    n_sb = (n_i + sb - 1) // sb
+    assert np.array_equal(bq, np.rint(ib / sp_row).astype(np.int64))
+    # the table: exact integer arithmetic, converted once per (user, superblock); the chunks' lists: the 10 largest lower bounds
+    dub = dev(ub)
+    uerr = torch.empty((n_u, 3), dtype=torch.float32, device="cuda")
+    N.call("trec_score_user_err_i8", N.ptr(uop.stats8), N.ptr(dub), N.ptr(iop.gstats8), d, n_u, N.ptr(uerr))
+    n_chunks = 3
+    chunk_len, n_ch = ops.blockmax_i8_chunks(n_i, n_chunks, sb)
     table = torch.empty((n_sb, n_u), dtype=torch.float32, device="cuda")
-    N.call("trec_score_gemm_blockmax_i8", N.ptr(uop.i8), N.ptr(iop.i8), d, n_u, n_i, N.ptr(dev(ub)), N.ptr(iop.bias_q),
-           N.ptr(iop.scales), sb, 3, N.ptr(table), n_u)
+    ctop = torch.empty((n_ch * 10, n_u), dtype=torch.float32, device="cuda")
+    N.call("trec_score_gemm_blockmax_i8", N.ptr(uop.i8), N.ptr(iop.i8), d, n_u, n_i, N.ptr(dub), N.ptr(iop.bias_q),
+           N.ptr(iop.scales), N.ptr(iop.sb_stats), sb, n_chunks, N.ptr(table), n_u, N.ptr(uerr), N.ptr(ctop), 10)
     s_int = uq @ iq.T + bq[None, :]
     pad = n_sb * sb - n_i
-    s_pad = np.concatenate([s_int, np.full((n_u, pad), np.iinfo(np.int64).min)], 1).reshape(n_u, n_sb, sb).max(2)
-    want = (s_pad.astype(np.float32) * np.float32(ab) + ub[:, None]).T
-    assert np.array_equal(table.cpu().numpy(), want)
-    # the bound: eps8_u = (tau - floor) / 2 with tau = 0, against the observed |int8 score - fp32 score|
-    floor8 = torch.empty((n_u,), dtype=torch.float32, device="cuda")
-    N.call("trec_topk_filter_floor_i8", N.ptr(torch.zeros(n_u, device="cuda")), N.ptr(uop.stats8), N.ptr(dev(ub)),
-           N.ptr(iop.gstats8), d, n_u, N.ptr(floor8), None, None)
-    eps8 = -floor8.cpu().numpy().astype(np.float64) / 2
-    s8 = s_int.astype(np.float64) * float(ab) + ub[:, None]
+    m_int = np.concatenate([s_int, np.full((n_u, pad), np.iinfo(np.int64).min)], 1).reshape(n_u, n_sb, sb).max(2)
+    sp_sb = np.float32(a) * sbs[:, 0]
+    want = (m_int.astype(np.float32) * sp_sb[None, :] + ub[:, None]).T
+    got = table.cpu().numpy()
+    assert np.array_equal(got, want)
+    ue = uerr.cpu().numpy()
+    e = _pair_err(ue[:, 0][None, :], ue[:, 1][None, :], ue[:, 2][None, :], sbs[:, 1][:, None], sbs[:, 2][:, None],
+                  sbs[:, 3][:, None], d)                                      # [n_sb, n_u]
+    lb = got - e
+    spc = chunk_len // sb
+    ct = ctop.cpu().numpy().reshape(n_ch, 10, n_u)
+    for c in range(n_ch):
+        ref = -np.sort(-lb[c * spc:(c + 1) * spc], axis=0)[:10]
+        assert np.array_equal(ct[c][:ref.shape[0]], ref) and np.all(ct[c][ref.shape[0]:] == -np.inf)
+    # the bound: e(u, s) against the observed |int8 score - fp32 score| of every item of the superblock
+    s8 = s_int.astype(np.float64) * sp_row[None, :].astype(np.float64) + ub[:, None]
     s32 = O.score_dense_exact(u, v, ub, ib).astype(np.float64)
-    worst = np.abs(s8 - s32).max(1)
-    assert np.all(worst <= eps8)
-    assert np.median(eps8 / worst) < 40                                       # ... and is not absurdly loose
+    diff = np.concatenate([np.abs(s8 - s32), np.zeros((n_u, pad))], 1).reshape(n_u, n_sb, sb).max(2).T    # [n_sb, n_u]
+    assert np.all(diff <= e)
+    assert np.median(e / np.maximum(diff, 1e-12)) < 40                        # ... and is not absurdly loose
 
 
-def test_rows_compaction_lists_exactly_the_pairs_at_or_above_the_floor(ops):
+def test_rows_compaction_lists_exactly_the_pairs_whose_upper_bound_reaches_the_threshold(ops):
     from tensorrec_amd import _native as N
     rng = np.random.default_rng(2)
     for n_sb, n_u, stride in ((37, 5000, 5000), (9, 1023, 1024), (130, 2050, 2051)):
         table = rng.standard_normal((n_sb, stride)).astype(np.float32)
-        floor = rng.uniform(0.5, 2.5, n_u).astype(np.float32)
-        floor[5] = -np.inf                                                     # a user that keeps every superblock
-        floor[6] = np.inf
-        dt, df = dev(table), dev(floor)
+        thr = rng.uniform(0.5, 2.5, n_u).astype(np.float32)
+        thr[5] = -np.inf                                                       # a user that keeps every superblock
+        thr[6] = np.inf
+        uerr = rng.uniform(0.0, 0.3, (n_u, 3)).astype(np.float32)
+        sbs = rng.uniform(0.0, 1.0, (n_sb, 4)).astype(np.float32)
+        sbs[3, 2] = np.inf                                                     # a superblock with an unusable bound: always kept
+        dt, dth, due, dsb = dev(table), dev(thr), dev(uerr), dev(sbs)
         n_ublk = N.query("trec_topk_rows_user_blocks", n_u)
         block_off = torch.empty((n_sb * n_ublk,), dtype=torch.int32, device="cuda")
         row_total = torch.empty((n_sb,), dtype=torch.int32, device="cuda")
         row_pad = torch.empty((n_sb,), dtype=torch.int32, device="cuda")
         pstart = torch.empty((n_sb + 1,), dtype=torch.int64, device="cuda")
-        keep = table[:, :n_u] >= floor[None, :]
+        with np.errstate(invalid="ignore", over="ignore"):
+            # tile_bits (csrc/topk_cascade.hip), operation for operation in float32 (fma through float64: exact product)
+            f32, f64 = np.float32, np.float64
+            infl, ck = f32(1.0029296875), f32(128 + 4) * f32(2.98023224e-07)
+            A = ((sbs[:, 2] + ck * sbs[:, 1]) * infl)[:, None]
+            B = (sbs[:, 1] * infl)[:, None]
+            C = (sbs[:, 3] * infl)[:, None]
+            cu = uerr[:, 2] * infl + f32(2e-30)
+
+            def pred(x):
+                y = np.nextafter(x, f32(-np.inf))
+                y[x == -np.inf] = -np.inf
+                return y
+            f = pred(pred(pred(thr.copy())) - cu)
+            fma = lambda a, b, c: (a.astype(f64) * b.astype(f64) + c.astype(f64)).astype(f32)
+            tv = table[:, :n_u]
+            lhs = fma(np.broadcast_to(uerr[:, 0][None, :], tv.shape), np.broadcast_to(A, tv.shape),
+                      fma(np.broadcast_to(uerr[:, 1][None, :], tv.shape), np.broadcast_to(B, tv.shape), tv + C))
+            keep = ~(lhs < f[None, :])
         want_rows = int(((keep.sum(1) + 511) // 512 * 512).sum())
         for cap_rows in (want_rows + 1024, want_rows, want_rows - 512):          # roomy, exact fit, one workgroup short
             status = torch.full((2,), -5, dtype=torch.int64, device="cuda")
-            N.call("trec_topk_rows_count", N.ptr(dt), n_sb, n_u, stride, N.ptr(df), N.ptr(block_off), N.ptr(row_total),
-                   N.ptr(row_pad), N.ptr(pstart), cap_rows, N.ptr(status))
+            N.call("trec_topk_rows_count", N.ptr(dt), n_sb, n_u, stride, N.ptr(dth), N.ptr(due), N.ptr(dsb), 128,
+                   N.ptr(block_off), N.ptr(row_total), N.ptr(row_pad), N.ptr(pstart), cap_rows, N.ptr(status))
             assert np.array_equal(row_total.cpu().numpy(), keep.sum(1))
             ps = pstart.cpu().numpy()
             assert np.array_equal(np.diff(ps), (keep.sum(1) + 511) // 512 * 512)
             assert status.tolist() == [want_rows, int(want_rows > cap_rows)]
             row_user = torch.full((cap_rows,), -7, dtype=torch.int32, device="cuda")
             rblock_chunk = torch.full((cap_rows // 512,), -7, dtype=torch.int32, device="cuda")
-            N.call("trec_topk_rows_fill", N.ptr(dt), n_sb, n_u, stride, N.ptr(df), N.ptr(block_off), N.ptr(row_total),
-                   N.ptr(pstart), cap_rows, N.ptr(status), N.ptr(row_user), N.ptr(rblock_chunk))
+            N.call("trec_topk_rows_fill", N.ptr(dt), n_sb, n_u, stride, N.ptr(dth), N.ptr(due), N.ptr(dsb), 128,
+                   N.ptr(block_off), N.ptr(row_total), N.ptr(pstart), cap_rows, N.ptr(status), N.ptr(row_user),
+                   N.ptr(rblock_chunk))
             ru, rc = row_user.cpu().numpy(), rblock_chunk.cpu().numpy()
             if want_rows > cap_rows:                                              # overflow: every workgroup idle, no row written
                 assert np.all(rc == -1) and np.all(ru == -7)
