@@ -96,6 +96,22 @@ def test_cascade_user_batches_share_the_item_operand(ops):
     assert "int8" in used                                                    # 586 superblocks: the cascade itself ran
 
 
+@pytest.mark.parametrize("k,d", [(16, 64), (12, 128), (1, 128)])
+def test_cascade_other_k_on_a_selective_catalogue(ops, k, d):
+    """k = 11..16 takes the 16-slot form of the int8 kernel's register lists, k = 1 the 10-slot one with a single live
+    slot; 300,000 items = 586 superblocks: the cascade itself runs (no fall-back)."""
+    rng = np.random.default_rng(100 + k)
+    n_u, n_i = 260, 300_000
+    u = rng.standard_normal((n_u, d)).astype(np.float32)
+    v = rng.standard_normal((n_i, d)).astype(np.float32)
+    ub = rng.standard_normal(n_u).astype(np.float32) * 0.5
+    ib = rng.standard_normal(n_i).astype(np.float32) * 0.5
+    vals, idx, stats, _, _ = run_cascade(ops, u, v, k, ub, ib)
+    rv, ri = O.topk_rows(O.score_dense_exact(u, v, ub, ib), k)
+    assert np.array_equal(idx, ri) and np.array_equal(vals, rv)
+    assert stats["prefilter"] == "int8" and stats["flagged_users"] <= 13
+
+
 def test_cascade_ties_and_integer_data(ops):
     """Small-integer operands: int8 quantisation is exact only by luck of the scale, every score ties with many others;
     ids must follow tf.nn.top_k's lower-index-first order."""
