@@ -211,6 +211,46 @@ def test_int8_table_is_exact_integer_arithmetic_and_bound_holds(ops):
     assert np.median(e / np.maximum(diff, 1e-12)) < 40                        # ... and is not absurdly loose
 
 
+def test_int8_bound_is_tight_but_holds_on_aligned_quantisation_errors(ops):
+    """Cauchy-Schwarz is tight when the rounding errors are parallel to the other operand.  Users x = a0 (q + 0.49 s) and
+    items y = b0 (r + 0.49 t) with power-of-two scales planted through the rows' largest elements (so the prep kernels
+    derive exactly a0 / b0) quantise to q / r with error 0.49 a0 s / 0.49 b0 t; s and t follow the signs of chosen partner
+    rows, so the two error terms add up coherently.  The bound must still dominate, with little room to spare."""
+    from tensorrec_amd import _native as N
+    rng = np.random.default_rng(21)
+    n_u, n_i, d, sb = 256, 2048, 128, 512
+    a0, b0 = np.float32(2.0 ** -8), np.float32(2.0 ** -9)
+    q = rng.integers(-100, 101, (n_u, d)).astype(np.float32)
+    r = rng.integers(-100, 101, (n_i, d)).astype(np.float32)
+    r[r == 0] = 1
+    q[q == 0] = 1
+    partner = rng.integers(0, n_i, n_u)                                      # user u's errors follow item partner[u] ...
+    s_ = np.sign(r[partner])
+    t_ = np.sign(q[rng.integers(0, n_u, n_i)])                               # ... item i's errors some user's row
+    t_[partner] = np.sign(q)                                                 # (the partner's own errors follow ITS user: both terms add)
+    x = a0 * (q + np.float32(0.49) * s_)
+    y = b0 * (r + np.float32(0.49) * t_)
+    x[:, 0] = 127 * a0                                                       # max |x| = 127 a0 < 4 rms: the user scale is a0
+    for s in range(n_i // sb):
+        y[s * sb, 1] = 127 * b0                                              # every superblock's scale is b0
+    uop = ops.score_prep_filter(dev(x))
+    iop = ops.score_prep_filter(dev(y), want_gstats=True)
+    ops.score_prep_i8_pair(uop, iop, None, sb)
+    assert iop.scales.cpu().numpy()[0] == a0 and np.all(iop.sb_stats.cpu().numpy()[:, 0] == b0)
+    uq, iq = uop.i8.cpu().numpy().astype(np.int64), iop.i8.cpu().numpy().astype(np.int64)
+    s8 = (uq @ iq.T).astype(np.float64) * float(a0) * float(b0)
+    s32 = O.score_dense_exact(x, y).astype(np.float64)
+    uerr = torch.empty((n_u, 3), dtype=torch.float32, device="cuda")
+    N.call("trec_score_user_err_i8", N.ptr(uop.stats8), None, N.ptr(iop.gstats8), d, n_u, N.ptr(uerr))
+    ue, sbs = uerr.cpu().numpy(), iop.sb_stats.cpu().numpy()
+    e = _pair_err(ue[:, 0][None, :], ue[:, 1][None, :], ue[:, 2][None, :], sbs[:, 1][:, None], sbs[:, 2][:, None],
+                  sbs[:, 3][:, None], d)                                      # [n_sb, n_u]
+    diff = np.abs(s8 - s32).reshape(n_u, n_i // sb, sb).max(2).T
+    assert np.all(diff <= e)
+    at_partner = np.abs(s8 - s32)[np.arange(n_u), partner] / e[partner // sb, np.arange(n_u)]
+    assert np.median(at_partner) > 0.6                                        # coherent errors use most of the bound
+
+
 def test_rows_compaction_lists_exactly_the_pairs_whose_upper_bound_reaches_the_threshold(ops):
     from tensorrec_amd import _native as N
     rng = np.random.default_rng(2)
