@@ -250,6 +250,229 @@ __global__ __launch_bounds__(256, WPS) void blockmax_i8_kernel(ScoreParams p)
     }
 }
 
+// ---- the same stage on v_mfma_i32_16x16x64_i8 ------------------------------------------------------------------------
+// Bare MFMA streams on random operands, ~1 s each at the 1.3 kW cap (scripts/probe/mfma_stream.hip): i8 32x32x32 3.45 Pop/s,
+// i8 16x16x64 4.05 Pop/s (bf16 32x32x16: 1.80 PF).  The 16x16x64 form does the same work per operand byte (a 16-item x 64-k
+// fragment, one ds_read_b128, feeds 8 MFMAs of 16 users each = the 128 users of a wave) and needs half the accumulator
+// registers (8 x 4).  Lane = (k-group g = lane >> 4 of the operands | row-group g of the result, user / item row lane & 15):
+// the maxima of the four row-groups are combined by two shuffles at a superblock end, after which row-group g owns NUB / 4
+// of the user blocks (their table stores, bound constants and top-k register lists: NUB / 4 x TK registers, not NUB x TK).
+template <int KT, bool BIAS, int TK, int NUB>        // NUB: 16-user blocks per wave (8: 128 users, 12: 192 users)
+__global__ __launch_bounds__(256, 2) void blockmax_i8x16_kernel(ScoreParams p)
+{
+    constexpr int OW = NUB / 4;              // user blocks a row-group owns at superblock ends
+    static_assert(NUB % 4 == 0, "user blocks per wave must split over the four row-groups");
+    constexpr int RB = KT;                   // bytes per operand row
+    constexpr int CH = RB / 16;              // 16-byte chunks per row (8 at K = 128, 4 at K = 64)
+    constexpr int KS = KT / 64;              // MFMA k-steps per block
+    constexpr int TILE_BYTES = BNQ * RB;
+    constexpr int NSLOT = BNQ * CH / 256;
+    constexpr int NBLK = BNQ / 16;           // 16-item blocks per tile
+    constexpr int NSTEP = NBLK * KS;
+    static_assert(KT == 64 || KT == 128, "int8 16x16x64 BLOCKMAX covers K = 64 / 128");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];    // [2][TILE_BYTES] item tiles | [2][BNQ] integer item biases
+    int* side = (int*)(smem + 2 * TILE_BYTES);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, lu = lane & 15;
+    const int rblock = blockIdx.x % p.n_rblocks;
+    const int chunk = blockIdx.x / p.n_rblocks;
+    const int64_t r_base = ((int64_t)rblock * 4 + wave) * (NUB * 16);
+    const int64_t t_begin = (int64_t)chunk * p.chunk_len;
+    const int64_t t_end = (t_begin + p.chunk_len < p.n_t) ? t_begin + p.chunk_len : p.n_t;
+    const int n_tiles = (int)((t_end - t_begin + BNQ - 1) / BNQ);
+    // physical 16-byte chunk = logical chunk ^ swz(row): 8 consecutive rows of one logical chunk (what 8 consecutive lanes
+    // read) land on 8 distinct chunk positions = all 32 banks
+    auto swz = [](int row) { return CH == 8 ? (row & 7) : ((row >> 1) & 3); };
+
+    // ---- resident user fragments: lane holds k = 64 ks + 16 g + 0..15 of user lu of each block ----
+    v4i32 rfq[NUB][KS];
+#pragma unroll
+    for (int ub = 0; ub < NUB; ++ub) {
+        int64_t row = r_base + ub * 16 + lu;
+        if (row >= p.n_r) row = p.n_r - 1;                       // clamped rows are never written
+        const char* src = (const char*)p.R + row * (int64_t)RB;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) rfq[ub][ks] = *(const v4i32*)(src + (ks * 4 + g) * 16);
+    }
+    // the OW users this lane owns at superblock ends
+    int64_t own_u[OW];
+    float own_bias[OW], e_nx[OW], e_ex[OW], e_cu[OW];
+    float top[TK ? OW : 1][TK ? TK : 1];
+#pragma unroll
+    for (int o = 0; o < OW; ++o) {
+        own_u[o] = r_base + (OW * g + o) * 16 + lu;
+        const int64_t row = own_u[o] < p.n_r ? own_u[o] : p.n_r - 1;
+        own_bias[o] = (BIAS && p.r_bias) ? p.r_bias[row] : 0.f;
+        if (TK) {
+            e_nx[o] = p.r_err[row * 3]; e_ex[o] = p.r_err[row * 3 + 1]; e_cu[o] = p.r_err[row * 3 + 2];
+#pragma unroll
+            for (int j = 0; j < TK; ++j) top[o][j] = -INFINITY;
+        }
+    }
+
+    int slot_off[NSLOT];
+#pragma unroll
+    for (int i = 0; i < NSLOT; ++i) {
+        const int q = i * 256 + tid;
+        const int row = q / CH, pc = q % CH;
+        slot_off[i] = row * RB + ((pc ^ swz(row)) * 16);
+    }
+    const char* t_chunk = (const char*)p.T + t_begin * (int64_t)RB;
+    const int* t_bias_q = (const int*)p.t_bias;
+    auto stage_issue = [&](int tile, int buf) {
+        const int64_t row0 = t_begin + (int64_t)tile * BNQ;
+        const bool clamp = row0 + BNQ > p.n_t;                   // wave-uniform: only the very last tile
+        if (BIAS && wave < 2) {
+            int64_t gi = row0 + wave * 64 + lane;
+            if (gi >= p.n_t) gi = p.n_t - 1;                     // duplicate of the last valid item: max unchanged
+            if (t_bias_q) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(t_bias_q + gi),
+                                                 (__attribute__((address_space(3))) void*)(side + buf * BNQ + wave * 64), 4, 0, 0);
+            } else {
+                side[buf * BNQ + wave * 64 + lane] = 0;
+            }
+        }
+        const char* tile_base = t_chunk + (int64_t)tile * (BNQ * RB);
+#pragma unroll
+        for (int i = 0; i < NSLOT; ++i) {
+            int off = slot_off[i];
+            if (clamp) {
+                const int last = (int)(p.n_t - 1 - row0);
+                const int row = (i * 256 + tid) / CH;
+                if (row > last) off -= (row - last) * RB;
+            }
+            char* dst = smem + buf * TILE_BYTES + (i * 256 + wave * 64) * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tile_base + off),
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
+
+    // per-lane LDS offsets of the KS operand chunks of item row lu of a 16-row block (rows lu + 16 b share the swizzle)
+    int koff[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) koff[ks] = lu * RB + (((ks * 4 + g) ^ swz(lu)) * 16);
+
+    v4i32 acc[NUB];
+    int bm[NUB];
+#pragma unroll
+    for (int ub = 0; ub < NUB; ++ub) bm[ub] = INT_MIN;
+
+    auto tile_body = [&](auto bufc) __attribute__((always_inline)) {
+        constexpr int buf = decltype(bufc)::value;
+        const char* tb = smem + buf * TILE_BYTES;
+        const int* sd = side + buf * BNQ + 4 * g;                // the block's integer biases of result rows 4 g .. 4 g + 3
+        v4i32 tf[3];
+        v4i32 c0 = {0, 0, 0, 0};
+        if (BIAS) c0 = *(const v4i32*)sd;
+        tf[0] = *(const v4i32*)(tb + koff[0]);
+        tf[1] = *(const v4i32*)(tb + (KS > 1 ? koff[1 % KS] : 16 * RB + koff[0]));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) {
+            const int blk = s / KS, ks = s % KS;
+            if (s + 2 < NSTEP)
+                tf[(s + 2) % 3] = *(const v4i32*)(tb + ((s + 2) / KS) * 16 * RB + koff[(s + 2) % KS]);
+            if (ks == 0) {
+#pragma unroll
+                for (int ub = 0; ub < NUB; ++ub)
+                    acc[ub] = __builtin_amdgcn_mfma_i32_16x16x64_i8(tf[s % 3], rfq[ub][0], c0, 0, 0, 0);
+                if (BIAS && blk + 1 < NBLK) c0 = *(const v4i32*)(sd + 16 * (blk + 1));     // lands under this block's MFMAs
+            } else {
+#pragma unroll
+                for (int ub = 0; ub < NUB; ++ub)
+                    acc[ub] = __builtin_amdgcn_mfma_i32_16x16x64_i8(tf[s % 3], rfq[ub][ks], acc[ub], 0, 0, 0);
+            }
+            if (ks == KS - 1) {
+#pragma unroll
+                for (int ub = 0; ub < NUB; ++ub) {
+                    bm[ub] = max(max(bm[ub], acc[ub][0]), acc[ub][1]);
+                    bm[ub] = max(max(bm[ub], acc[ub][2]), acc[ub][3]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    stage_issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const float a_user = p.scales[0];
+    const int64_t sb0 = t_begin / ((int64_t)p.sb_tiles * BNQ);
+    f32x4 ss_cur = *(const f32x4*)(p.sb_stats + sb0 * 4), ss_next = ss_cur;
+    for (int t = 0; t < n_tiles; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < n_tiles) stage_issue(t + 1, buf ^ 1);
+        if ((t % p.sb_tiles) == 0 && t + p.sb_tiles < n_tiles)
+            ss_next = *(const f32x4*)(p.sb_stats + (sb0 + t / p.sb_tiles + 1) * 4);
+        if (buf == 0) tile_body(std::integral_constant<int, 0>{});
+        else tile_body(std::integral_constant<int, 1>{});
+
+        if (((t + 1) % p.sb_tiles) == 0 || t + 1 == n_tiles) {
+            // end of a superblock: combine the four row-groups' maxima of every user; row-group g then finishes its OW blocks
+            const int64_t sb = sb0 + t / p.sb_tiles;
+            const float scale = a_user * ss_cur[0];
+            const float yh = TK ? ss_cur[1] : 0.f, dy = TK ? ss_cur[2] : 0.f, db = TK ? ss_cur[3] : 0.f;
+            ss_cur = ss_next;
+            int m[NUB];
+#pragma unroll
+            for (int ub = 0; ub < NUB; ++ub) {
+                int x = bm[ub];
+                const int o1 = __shfl_xor(x, 16, 64);
+                x = x > o1 ? x : o1;
+                const int o2 = __shfl_xor(x, 32, 64);
+                m[ub] = x > o2 ? x : o2;
+                bm[ub] = INT_MIN;
+            }
+#pragma unroll
+            for (int o = 0; o < OW; ++o) {
+                const int mo = g == 0 ? m[o] : (g == 1 ? m[OW + o] : (g == 2 ? m[2 * OW + o] : m[3 * OW + o]));
+                float v = (float)mo * scale;                  // |m| < 2^24: the conversion is exact
+                if (BIAS) v = v + own_bias[o];
+                if (own_u[o] < p.n_r) p.blockmax[sb * p.bm_stride + own_u[o]] = v;
+                if (TK) {
+                    float lb = v - i8_pair_err(e_nx[o], e_ex[o], e_cu[o], yh, dy, db, KT);
+                    lb = (lb == lb) ? lb : -INFINITY;          // a NaN certifies nothing
+#pragma unroll
+                    for (int j = TK - 1; j >= 1; --j) top[o][j] = __builtin_amdgcn_fmed3f(top[o][j], top[o][j - 1], lb);
+                    top[o][0] = fmaxf(top[o][0], lb);
+                }
+            }
+        }
+        if (t + 1 < n_tiles) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    if (TK) {
+#pragma unroll
+        for (int o = 0; o < OW; ++o)
+            if (own_u[o] < p.n_r) {
+#pragma unroll
+                for (int j = 0; j < TK; ++j) p.chunk_top[((int64_t)chunk * TK + j) * p.bm_stride + own_u[o]] = top[o][j];
+            }
+    }
+}
+
+template <int KT, bool BIAS, int TK, int NUB>
+int launch_i8x16(ScoreParams p, int sb_rows, hipStream_t st)
+{
+    constexpr int LDS = 2 * BNQ * KT + 2 * BNQ * 4;
+    auto kern = blockmax_i8x16_kernel<KT, BIAS, TK, NUB>;
+    static bool attr_set = false;
+    if (!attr_set && LDS > 32 * 1024) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    p.n_rblocks = (int)ceil_div64(p.n_r, 4 * NUB * 16);
+    p.sb_tiles = sb_rows / BNQ;
+    const unsigned blocks = (unsigned)p.n_rblocks * (unsigned)p.n_chunks;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), LDS, st, p);
+    return trec_check_launch("trec_score_gemm_blockmax_i8 (16x16x64)");
+}
+
 template <int KT, bool BIAS, int NCB, int WPS, int TK>
 int launch_i8(ScoreParams p, int sb_rows, hipStream_t st)
 {
@@ -546,6 +769,17 @@ extern "C" int trec_score_gemm_blockmax_i8(const void* users_q, const void* item
     p.scales = scales; p.sb_stats = sb_stats; p.r_err = user_err; p.chunk_top = chunk_top; p.top_k = top_k;
     hipStream_t st = (hipStream_t)stream;
     const bool bias = user_bias || item_bias_q;
+    // "blockmax_i8_mfma": 1 (default) = v_mfma_i32_16x16x64_i8, 0 = v_mfma_i32_32x32x32_i8 (A/B runs)
+    if (trec_get_tuning("blockmax_i8_mfma", 1) != 0) {
+#define TREC_I8X(KTV, TKV) (users == 192 ? (bias ? launch_i8x16<KTV, true, TKV, 12>(p, sb_rows, st) : launch_i8x16<KTV, false, TKV, 12>(p, sb_rows, st)) \
+                                       : (bias ? launch_i8x16<KTV, true, TKV, 8>(p, sb_rows, st) : launch_i8x16<KTV, false, TKV, 8>(p, sb_rows, st)))
+        // users per wave: 192 (12 blocks of 16: a third fewer LDS reads and tile streams per flop; 78.8 vs 81.9 ms at 1M x 1M
+        // with the 10-slot lists, profiles/r02_power_trace_i8.txt) unless the 16-slot lists need the registers
+        const int users = trec_get_tuning("blockmax_i8_users", top_k > 10 ? 128 : 192);
+        if (kpad == 128) return top_k == 0 ? TREC_I8X(128, 0) : (top_k == 10 ? TREC_I8X(128, 10) : TREC_I8X(128, 16));
+        return top_k == 0 ? TREC_I8X(64, 0) : (top_k == 10 ? TREC_I8X(64, 10) : TREC_I8X(64, 16));
+#undef TREC_I8X
+    }
 #define TREC_I8(KTV, TKV) (bias ? launch_i8<KTV, true, 4, 2, TKV>(p, sb_rows, st) : launch_i8<KTV, false, 4, 2, TKV>(p, sb_rows, st))
     if (kpad == 128) return top_k == 0 ? TREC_I8(128, 0) : (top_k == 10 ? TREC_I8(128, 10) : TREC_I8(128, 16));
     return top_k == 0 ? TREC_I8(64, 0) : (top_k == 10 ? TREC_I8(64, 10) : TREC_I8(64, 16));
