@@ -146,7 +146,10 @@ int trec_score_gemm_topk(const void* users, const void* items, int32_t dtype, in
  *   3. trec_topk_group_keys + trec_group_pairs_by_item + trec_topk_pad_counts + trec_exclusive_scan_i32 +
  *      trec_topk_fill_groups: (user, slot) pairs grouped by superblock, padded to whole workgroups, operand rows gathered;
  *      trec_score_gemm_topk_grouped: every workgroup re-scores one superblock for its gathered rows (fused lists);
- *   4. trec_topk_merge over the k*2 lists of each user. */
+ *   4. trec_topk_merge over the k*2 lists of each user.
+ * trec_score_gemm_blockmax, variant bit 5 (32): the caller is a FILTER (K2f / K2c) -- the bf16 maxima only have to obey the
+ * error bound, not equal another kernel's scores bit for bit: the v_mfma_f32_16x16x32_bf16 form of the kernel is used
+ * (bf16 dot / cosine, kpad 64 / 128; more work per joule at the chip's power cap). */
 int trec_score_gemm_blockmax(const void* users, const void* items, int32_t dtype, int32_t kpad, int64_t n_users,
                              int64_t n_items, const float* user_bias, const float* item_bias, int32_t mode,
                              const float* user_sqnorm, const float* item_sqnorm, int32_t sb_rows, int32_t n_chunks,

@@ -25,9 +25,9 @@ def run():
                N.ptr(ctop) if TK else None, TK)
     else:
         N.call("trec_score_gemm_blockmax", N.ptr(uop.bf16), N.ptr(iop.bf16), ops.DTYPE_BF16, d, U, I, N.ptr(ub), N.ptr(ib),
-               ops.MODE_DOT, None, None, 512, 13, N.ptr(table), U, 1)
+               ops.MODE_DOT, None, None, 512, 13, N.ptr(table), U, int(os.environ.get("VARIANT", 1)))
 run(); torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(n): run()
 torch.cuda.synchronize()
-print("%s (TK=%d, MFMA=%s): %.2f ms per launch over %d launches" % (which, TK, os.environ.get("MFMA", "1") + " USERS=" + os.environ.get("USERS", "128"), (time.perf_counter() - t0) / n * 1e3, n))
+print("%s (TK=%d, MFMA=%s): %.2f ms per launch over %d launches" % (which, TK, os.environ.get("MFMA", "1") + " VARIANT=" + os.environ.get("VARIANT", "1") + " USERS=" + os.environ.get("USERS", "128"), (time.perf_counter() - t0) / n * 1e3, n))

@@ -39,6 +39,19 @@ __global__ __launch_bounds__(256, 2) void stream(const int* __restrict__ src, in
         int s = 0;
         for (int i = 0; i < 8; ++i) for (int e = 0; e < 4; ++e) s += c[i][e];
         out[l] = s;
+    } else if (MODE == 3) {
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        v4f c[8] = {};
+        bf16x8 fa[4], fb[4];
+        for (int i = 0; i < 4; ++i) { fa[i] = __builtin_bit_cast(bf16x8, a[i]); fb[i] = __builtin_bit_cast(bf16x8, b[i]); }
+        for (int it = 0; it < iters; ++it)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) c[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[j], fb[i & 3], c[i], 0, 0, 0);
+        float s = 0;
+        for (int i = 0; i < 8; ++i) for (int e = 0; e < 4; ++e) s += c[i][e];
+        out[l] = (int)s;
     } else {
         v16f c[4] = {};
         bf16x8 fa[4], fb[4];
@@ -69,6 +82,9 @@ int main(int argc, char** argv)
         {0, "i8 32x32x32, operands masked to +-31 (0x1f1f1f1f)", 65536.0 * 16, 0x1f1f1f1f},
         {1, "i8 16x16x64, full-range operands", 32768.0 * 32, -1},
         {2, "bf16 32x32x16, random bit patterns masked to finite (0x3fff3fff)", 32768.0 * 16, 0x3fff3fff},
+        {3, "bf16 16x16x32, random bit patterns masked to finite (0x3fff3fff)", 16384.0 * 32, 0x3fff3fff},
+        {2, "bf16 32x32x16, again", 32768.0 * 16, 0x3fff3fff},
+        {1, "i8 16x16x64, again", 32768.0 * 32, -1},
     };
     for (auto& c : cases) {
         const int iters = argc > 1 ? atoi(argv[1]) : 60000;
@@ -76,6 +92,7 @@ int main(int argc, char** argv)
             hipEventRecord(e0);
             if (c.mode == 0) hipLaunchKernelGGL(stream<0>, dim3(blocks), dim3(256), 0, 0, src, out, iters, c.mask);
             else if (c.mode == 1) hipLaunchKernelGGL(stream<1>, dim3(blocks), dim3(256), 0, 0, src, out, iters, c.mask);
+            else if (c.mode == 3) hipLaunchKernelGGL(stream<3>, dim3(blocks), dim3(256), 0, 0, src, out, iters, c.mask);
             else hipLaunchKernelGGL(stream<2>, dim3(blocks), dim3(256), 0, 0, src, out, iters, c.mask);
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);

@@ -318,6 +318,200 @@ __global__ __launch_bounds__(256, WPS) void blockmax_pipe_kernel(ScoreParams p)
     }
 }
 
+// ---- the filter form on v_mfma_f32_16x16x32_bf16 -----------------------------------------------------------------------
+// Bare MFMA streams at the 1.3 kW cap (scripts/probe/mfma_stream.hip): bf16 32x32x16 1.80 PF, bf16 16x16x32 2.10 PF -- the
+// 16x16 shapes do 17% more work per joule.  Same plan as the int8 16x16x64 kernel (score_blockmax_i8.hip): lane = (k-group /
+// result row-group g = lane >> 4, user / item row lane & 15); a wave owns 8 blocks of 16 users (128 VGPRs of fragments at
+// K = 128); a 16-item x 32-k fragment (one ds_read_b128) feeds 8 MFMAs; 2 v_max3_f32 per 4-register accumulator; the item
+// bias is the initial accumulator; the four row-groups' maxima meet by two shuffles at a superblock end and row-group g
+// stores user blocks 2g, 2g + 1.  The partial sums of a score are added in a different order than in the 32x32x16 kernels:
+// this form serves the FILTERS only (K2f / K2c: their bound charges every addition of the chain, in any order); the plain
+// bf16 two-stage top-k, whose stage 3 must reproduce stage 1's maxima bit for bit, keeps the 32x32x16 kernel.
+// GRP: the grouped launch of the cascade (one superblock per workgroup, rows through row_index), as in blockmax_pipe_kernel.
+template <int KT, bool BIAS, bool GRP>
+__global__ __launch_bounds__(256, 2) void blockmax_bf16x16_kernel(ScoreParams p)
+{
+    constexpr int NUB = 8;                   // 16-user blocks per wave
+    constexpr int OW = NUB / 4;
+    constexpr int RB = KT * 2;               // bytes per operand row
+    constexpr int CH = RB / 16;              // 16-byte chunks per row (16 at K = 128, 8 at K = 64)
+    constexpr int KS = KT / 32;              // MFMA k-steps per block
+    constexpr int TILE_BYTES = BN * RB;
+    constexpr int NSLOT = BN * CH / 256;
+    constexpr int NBLK = BN / 16;            // 16-item blocks per tile
+    constexpr int NSTEP = NBLK * KS;
+    static_assert(KT == 64 || KT == 128, "bf16 16x16x32 BLOCKMAX covers K = 64 / 128");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];    // [2][TILE_BYTES] item tiles | [2][BN] item biases
+    float* side = (float*)(smem + 2 * TILE_BYTES);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, lu = lane & 15;
+    const int rblock = GRP ? (int)blockIdx.x : (int)(blockIdx.x % p.n_rblocks);
+    const int chunk = GRP ? p.rblock_chunk[rblock] : (int)(blockIdx.x / p.n_rblocks);
+    if (GRP && chunk < 0) return;                                // idle workgroup of the grouped launch
+    const int64_t r_base = ((int64_t)rblock * 4 + wave) * (NUB * 16);
+    const int64_t t_begin = (int64_t)chunk * p.chunk_len;
+    const int64_t t_end = (t_begin + p.chunk_len < p.n_t) ? t_begin + p.chunk_len : p.n_t;
+    const int n_tiles = (int)((t_end - t_begin + BN - 1) / BN);
+    // physical chunk = logical chunk ^ (row & (CH - 1)): 8 consecutive rows of one logical chunk (8 consecutive lanes) hit 8
+    // distinct 16-byte positions modulo 128 bytes = all 32 banks
+    auto swz = [](int row) { return row & (CH - 1); };
+
+    // ---- resident user fragments: lane holds k = 32 ks + 8 g + 0..7 of user lu of each block ----
+    bf16x8 rfb[NUB][KS];
+#pragma unroll
+    for (int ub = 0; ub < NUB; ++ub) {
+        int64_t row = r_base + ub * 16 + lu;
+        if (row >= p.n_r) row = p.n_r - 1;                       // clamped rows are never written
+        if (GRP) { const int32_t s = p.row_index[row]; row = s < 0 ? 0 : s; }     // padding rows compute on user 0
+        const char* src = (const char*)p.R + row * (int64_t)RB;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) rfb[ub][ks] = *(const bf16x8*)(src + (ks * 4 + g) * 16);
+    }
+    // the users this lane stores at superblock ends
+    int64_t own_u[OW];
+    float own_bias[OW];
+#pragma unroll
+    for (int o = 0; o < OW; ++o) {
+        const int64_t row = r_base + (OW * g + o) * 16 + lu;
+        if (GRP) own_u[o] = p.row_index[row];                    // -1: padding row, never written
+        else own_u[o] = row < p.n_r ? row : -1;
+        own_bias[o] = (BIAS && p.r_bias && own_u[o] >= 0) ? p.r_bias[own_u[o]] : 0.f;
+    }
+
+    int slot_off[NSLOT];
+#pragma unroll
+    for (int i = 0; i < NSLOT; ++i) {
+        const int q = i * 256 + tid;
+        const int row = q / CH, pc = q % CH;
+        slot_off[i] = row * RB + ((pc ^ swz(row)) * 16);
+    }
+    const char* t_chunk = (const char*)p.T + t_begin * (int64_t)RB;
+    auto stage_issue = [&](int tile, int buf) {
+        const int64_t row0 = t_begin + (int64_t)tile * BN;
+        const bool clamp = row0 + BN > p.n_t;                    // wave-uniform: only the very last tile
+        if (BIAS && wave == 0) {
+            int64_t gi = row0 + lane;
+            if (gi >= p.n_t) gi = p.n_t - 1;                     // duplicate of the last valid item: max unchanged
+            if (p.t_bias) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.t_bias + gi),
+                                                 (__attribute__((address_space(3))) void*)(side + buf * BN), 4, 0, 0);
+            } else {
+                side[buf * BN + lane] = 0.f;
+            }
+        }
+        const char* tile_base = t_chunk + (int64_t)tile * (BN * RB);
+#pragma unroll
+        for (int i = 0; i < NSLOT; ++i) {
+            int off = slot_off[i];
+            if (clamp) {
+                const int last = (int)(p.n_t - 1 - row0);
+                const int row = (i * 256 + tid) / CH;
+                if (row > last) off -= (row - last) * RB;
+            }
+            char* dst = smem + buf * TILE_BYTES + (i * 256 + wave * 64) * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tile_base + off),
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
+
+    int koff[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) koff[ks] = lu * RB + (((ks * 4 + g) ^ swz(lu)) * 16);      // rows lu + 16 b: same swizzle
+
+    f32x4 acc[NUB];
+    float bm[NUB];
+#pragma unroll
+    for (int ub = 0; ub < NUB; ++ub) bm[ub] = -INFINITY;
+
+    auto tile_body = [&](auto bufc) __attribute__((always_inline)) {
+        constexpr int buf = decltype(bufc)::value;
+        const char* tb = smem + buf * TILE_BYTES;
+        const float* sd = side + buf * BN + 4 * g;               // the block's item biases of result rows 4 g .. 4 g + 3
+        bf16x8 tf[3];
+        f32x4 c0 = {0.f, 0.f, 0.f, 0.f};
+        if (BIAS) c0 = *(const f32x4*)sd;
+        tf[0] = *(const bf16x8*)(tb + koff[0]);
+        tf[1] = *(const bf16x8*)(tb + koff[1 % KS]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) {
+            const int blk = s / KS, ks = s % KS;
+            if (s + 2 < NSTEP)
+                tf[(s + 2) % 3] = *(const bf16x8*)(tb + ((s + 2) / KS) * 16 * RB + koff[(s + 2) % KS]);
+            if (ks == 0) {
+#pragma unroll
+                for (int ub = 0; ub < NUB; ++ub)
+                    acc[ub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tf[s % 3], rfb[ub][0], c0, 0, 0, 0);
+                if (BIAS && blk + 1 < NBLK) c0 = *(const f32x4*)(sd + 16 * (blk + 1));      // lands under this block's MFMAs
+            } else {
+#pragma unroll
+                for (int ub = 0; ub < NUB; ++ub)
+                    acc[ub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tf[s % 3], rfb[ub][ks], acc[ub], 0, 0, 0);
+            }
+            if (ks == KS - 1) {
+#pragma unroll
+                for (int ub = 0; ub < NUB; ++ub) {
+                    bm[ub] = fmaxf(fmaxf(bm[ub], acc[ub][0]), acc[ub][1]);
+                    bm[ub] = fmaxf(fmaxf(bm[ub], acc[ub][2]), acc[ub][3]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    stage_issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int t = 0; t < n_tiles; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < n_tiles) stage_issue(t + 1, buf ^ 1);
+        if (buf == 0) tile_body(std::integral_constant<int, 0>{});
+        else tile_body(std::integral_constant<int, 1>{});
+
+        if (((t + 1) % p.sb_tiles) == 0 || t + 1 == n_tiles) {
+            // end of a superblock: the four row-groups' maxima of every user meet; row-group g stores blocks OW g .. OW g + OW - 1
+            const int64_t sb = GRP ? (int64_t)chunk : t_begin / ((int64_t)p.sb_tiles * BN) + t / p.sb_tiles;
+            float m[NUB];
+#pragma unroll
+            for (int ub = 0; ub < NUB; ++ub) {
+                float x = bm[ub];
+                x = fmaxf(x, __shfl_xor(x, 16, 64));
+                m[ub] = fmaxf(x, __shfl_xor(x, 32, 64));
+                bm[ub] = -INFINITY;
+            }
+#pragma unroll
+            for (int o = 0; o < OW; ++o) {
+                float v = g == 0 ? m[o] : (g == 1 ? m[OW + o] : (g == 2 ? m[2 * OW + o] : m[3 * OW + o]));
+                if (BIAS) v = v + own_bias[o];
+                if (own_u[o] >= 0) p.blockmax[sb * p.bm_stride + own_u[o]] = v;
+            }
+        }
+        if (t + 1 < n_tiles) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+}
+
+template <int KT, bool BIAS, bool GRP>
+int launch_bf16x16(ScoreParams p, hipStream_t st)
+{
+    constexpr int LDS = 2 * BN * KT * 2 + 2 * BN * 4;
+    auto kern = blockmax_bf16x16_kernel<KT, BIAS, GRP>;
+    static bool attr_set = false;
+    if (!attr_set && LDS > 32 * 1024) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    p.n_rblocks = GRP ? (int)(p.n_r / 512) : (int)ceil_div64(p.n_r, 512);
+    const unsigned blocks = GRP ? (unsigned)p.n_rblocks : (unsigned)p.n_rblocks * (unsigned)p.n_chunks;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), LDS, st, p);
+    return trec_check_launch(GRP ? "trec_score_gemm_blockmax_grouped (16x16x32)" : "trec_score_gemm_blockmax (16x16x32)");
+}
+
 // ---- the exact (fp32) form --------------------------------------------------------------------------------------------
 // Same stage 1 on v_mfma_f32_32x32x2_f32 -- an exact k-ordered fmaf chain, bit-identical to oracle/tr_oracle.c -- with
 // the reference's bias order (s + b_u) + b_i per element before the maximum.  An fp32 MFMA occupies the pipe for 64
@@ -542,8 +736,22 @@ int launch_grouped(ScoreParams p, hipStream_t st)
 int launch_blockmax_pipelined_grouped(const ScoreParams& p, int kt, hipStream_t st)
 {
     const bool bias = p.r_bias || p.t_bias;
+    if (trec_get_tuning("blockmax_bf16_mfma16", 1) != 0) {       // the 16x16x32 form (filters only: see blockmax_bf16x16_kernel)
+        if (kt == 128) return bias ? launch_bf16x16<128, true, true>(p, st) : launch_bf16x16<128, false, true>(p, st);
+        if (kt == 64) return bias ? launch_bf16x16<64, true, true>(p, st) : launch_bf16x16<64, false, true>(p, st);
+    }
     if (kt == 128) return bias ? launch_grouped<128, true>(p, st) : launch_grouped<128, false>(p, st);
     if (kt == 64) return bias ? launch_grouped<64, true>(p, st) : launch_grouped<64, false>(p, st);
+    return TREC_ERR_UNSUPPORTED;
+}
+
+// filter use (variant bit 5 of trec_score_gemm_blockmax): the 16x16x32 form, any summation order
+int launch_blockmax_filter16(const ScoreParams& p, int kt, hipStream_t st)
+{
+    if (p.euclid || trec_get_tuning("blockmax_bf16_mfma16", 1) == 0) return TREC_ERR_UNSUPPORTED;
+    const bool bias = p.r_bias || p.t_bias;
+    if (kt == 128) return bias ? launch_bf16x16<128, true, false>(p, st) : launch_bf16x16<128, false, false>(p, st);
+    if (kt == 64) return bias ? launch_bf16x16<64, true, false>(p, st) : launch_bf16x16<64, false, false>(p, st);
     return TREC_ERR_UNSUPPORTED;
 }
 

@@ -52,6 +52,8 @@ __device__ __forceinline__ float i8_pair_err(float nx, float ex, float cu, float
 // software-pipelined BLOCKMAX kernel (score_blockmax.hip): bf16 dot / cosine, kpad 64 or 128.  Returns
 // TREC_ERR_UNSUPPORTED when the configuration is not covered (the caller then uses the generic kernel).
 int launch_blockmax_pipelined(const ScoreParams& p, int kt, hipStream_t stream);
+// the 16x16x32 bf16 form for the filters (any summation order): TREC_ERR_UNSUPPORTED when switched off / not covered
+int launch_blockmax_filter16(const ScoreParams& p, int kt, hipStream_t stream);
 // grouped bf16 form (stage 2 of the int8 cascade): see score_blockmax.hip
 int launch_blockmax_pipelined_grouped(const ScoreParams& p, int kt, hipStream_t stream);
 // the exact fp32 form (kpad 64 or 128, dot / cosine); sb_rows = superblock height in item rows

@@ -811,6 +811,12 @@ extern "C" int trec_score_gemm_blockmax(const void* users, const void* items, in
     p.blockmax = blockmax; p.bm_stride = bm_stride; p.sb_tiles = sb_rows / c.bn;
     // the hot configuration (bf16 dot / cosine, K = 64 / 128) has a hand-scheduled kernel; "blockmax_pipelined" = 0
     // selects the generic one (A/B runs and tests)
+    // variant bit 5: the caller is a FILTER (K2f): the maxima need not equal any other kernel's scores bit for bit, only obey
+    // the bound -> the 16x16x32 form (17% more work per joule at the power cap)
+    if (dtype == 1 && !mode && (kpad == 64 || kpad == 128) && c.bn == 64 && (variant & 32)) {
+        rc = launch_blockmax_filter16(p, kpad, (hipStream_t)stream);
+        if (rc != TREC_ERR_UNSUPPORTED) return rc;
+    }
     if (dtype == 1 && !mode && (kpad == 64 || kpad == 128) && c.bn == 64 && trec_get_tuning("blockmax_pipelined", 1)) {
         rc = launch_blockmax_pipelined(p, kpad, (hipStream_t)stream);
         if (rc != TREC_ERR_UNSUPPORTED) return rc;

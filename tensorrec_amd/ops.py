@@ -1126,7 +1126,7 @@ def score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index_
         with _timed("score_gemm_blockmax"):
             N.call("trec_score_gemm_blockmax", N.ptr(uop.bf16), N.ptr(iop.bf16), DTYPE_BF16, kpad, n_u, n_i,
                    N.ptr(user_bias), N.ptr(item_bias), MODE_DOT, None, None, sb_rows, n_chunks, N.ptr(blockmax), n_u,
-                   variant)
+                   variant | 32)          # bit 5: filter use -> the 16x16x32 MFMA form (any summation order obeys the bound)
     # ---- stage 2, pass 1: tau = k-th largest superblock maximum (a floor of the k-th best bf16 score)
     kk = int(k)
     sel = torch.empty((n_u, kk), dtype=torch.int32, device=dev)

@@ -325,7 +325,7 @@ def test_grouped_bf16_blockmax_equals_the_full_kernel_on_the_listed_pairs(ops):
     n_sb = (n_i + sb - 1) // sb
     full = torch.empty((n_sb, n_u), dtype=torch.float32, device="cuda")
     N.call("trec_score_gemm_blockmax", N.ptr(uop.bf16), N.ptr(iop.bf16), ops.DTYPE_BF16, d, n_u, n_i, N.ptr(ub), N.ptr(ib),
-           ops.MODE_DOT, None, None, sb, 2, N.ptr(full), n_u, 1)
+           ops.MODE_DOT, None, None, sb, 2, N.ptr(full), n_u, 1 | 32)        # bit 5: the filters' 16x16x32 form, as the grouped launch
     keep = rng.random((n_sb, n_u)) < 0.3
     rows, chunks = [], []
     for s in range(n_sb):
