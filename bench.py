@@ -409,8 +409,8 @@ def main():
     peak = FP32_MFMA_PEAK_TFLOPS if args.precision == "fp32" else (INT8_DENSE_PEAK_TOPS if cascade else BF16_DENSE_PEAK_TFLOPS)
     k2_tflops = k2_flops / (k2_ms * 1e-3) / 1e12
     k2_label = "score_gemm_kernel (fused top-k epilogue)" if method == "direct" else (
-        "blockmax_i8_kernel (int8 superblock maxima over every (user, item): stage 0 of the int8 -> bf16 -> fp32 cascade; "
-        "int8 multiply-adds counted as 2 ops, peak = 2x the dense bf16 peak)" if cascade else
+        "blockmax_i8x16_kernel (v_mfma_i32_16x16x64_i8: int8 superblock maxima over every (user, item), stage 0 of the "
+        "int8 -> bf16 -> fp32 cascade; int8 multiply-adds counted as 2 ops, peak = 2x the dense bf16 peak)" if cascade else
         "blockmax_pipe_kernel (superblock maxima, stage 1 of the two-stage top-k)"
         if args.precision != "fp32" and kpad in (64, 128) and T._native.load().trec_get_tuning(b"blockmax_pipelined", 1)
         else "score_gemm_kernel (superblock-max epilogue)")
@@ -419,8 +419,8 @@ def main():
         rows = float(ops.LAST_FILTER_STATS.get("refined_rows", 0))
         g_ms = float(np.mean(dur["score_gemm_blockmax_grouped"]))
         g_tf = 2.0 * rows * ops.SUPERBLOCK_ROWS * kpad / (g_ms * 1e-3) / 1e12
-        roofline_bf16_stage = {"kernel": "blockmax_pipe_kernel, grouped form (bf16 maxima of the (superblock, user) pairs "
-                                         "the int8 bound cannot rule out)", "bound": "mfma", "achieved": g_tf,
+        roofline_bf16_stage = {"kernel": "blockmax_bf16x16_kernel, grouped form (v_mfma_f32_16x16x32_bf16: bf16 maxima of the "
+                                         "(superblock, user) pairs the int8 bound cannot rule out)", "bound": "mfma", "achieved": g_tf,
                                "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": g_tf / BF16_DENSE_PEAK_TFLOPS,
                                "avg_launch_ms": g_ms, "resident_rows": rows,
                                "refined_fraction_of_pairs": rows / (float(U) * ((n_local + ops.SUPERBLOCK_ROWS - 1) // ops.SUPERBLOCK_ROWS))}
@@ -496,7 +496,7 @@ def main():
         if files and world == 1 and (U, I, d) == (1_000_000, 1_000_000, 128) and method == "two_stage":
             txt = open(files[-1]).read()
             fetch = write = None
-            for key in (("blockmax_i8_kernel<128",) if cascade else
+            for key in (("blockmax_i8x16_kernel<128", "blockmax_i8_kernel<128") if cascade else
                         ("blockmax_pipe_kernel<128", "score_gemm_kernel<1, 128, 64, 2, 2")):     # stage-1 kernel names
                 fetch = [float(m) for m in re.findall(re.escape(key) + r"[^\n]*?FETCH_SIZE=([0-9.e+]+)", txt)]
                 write = [float(m) for m in re.findall(re.escape(key) + r"[^\n]*?WRITE_SIZE=([0-9.e+]+)", txt)]
@@ -601,7 +601,7 @@ def main():
             s1 = float(np.mean([a.elapsed_time(b) for n_, a, b in ev2 if n_ == "score_gemm_blockmax"]))
             bf16_mode = {"workload": "the same %d users x %d items, exact top-%d through the bf16 filter alone (--prefilter none), "
                                      "operands given" % (U, n_local, k),
-                         "ms": 1e3 * dt, "stage1_kernel": "blockmax_pipe_kernel (dense bf16 superblock maxima)",
+                         "ms": 1e3 * dt, "stage1_kernel": "blockmax_bf16x16_kernel (v_mfma_f32_16x16x32_bf16, dense bf16 superblock maxima)",
                          "stage1_avg_launch_ms": s1, "stage1_tflops": k2_flops / (s1 * 1e-3) / 1e12,
                          "stage1_frac_of_bf16_mfma_peak": k2_flops / (s1 * 1e-3) / 1e12 / BF16_DENSE_PEAK_TFLOPS,
                          "equals_timed_cascade_output": bool(torch.equal(bi_, idx) and torch.equal(bv, vals))}
