@@ -12,7 +12,9 @@ ub = torch.zeros(U, device="cuda"); ib = torch.zeros(I, device="cuda")
 uop = ops.score_prep_filter(u); iop = ops.score_prep_filter(v, bias=ib, want_gstats=True)
 ops.score_prep_i8_pair(uop, iop, ib)
 N.load().trec_set_tuning(b"blockmax_i8_mfma", int(os.environ.get("MFMA", 1)))
-N.load().trec_set_tuning(b"blockmax_i8_users", int(os.environ.get("USERS", 128)))
+N.load().trec_set_tuning(b"blockmax_i8_users", int(os.environ.get("USERS", 192)))
+N.load().trec_set_tuning(b"blockmax_i8_waves", int(os.environ.get("WAVES", 4)))
+N.load().trec_set_tuning(b"blockmax_i8_tile", int(os.environ.get("TILE", 128)))
 n_sb = (I + 511) // 512
 table = torch.empty((n_sb, U), dtype=torch.float32, device="cuda")
 uerr = torch.empty((U, 3), device="cuda")
@@ -30,4 +32,4 @@ run(); torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(n): run()
 torch.cuda.synchronize()
-print("%s (TK=%d, MFMA=%s): %.2f ms per launch over %d launches" % (which, TK, os.environ.get("MFMA", "1") + " VARIANT=" + os.environ.get("VARIANT", "1") + " USERS=" + os.environ.get("USERS", "128"), (time.perf_counter() - t0) / n * 1e3, n))
+print("%s (TK=%d, MFMA=%s): %.2f ms per launch over %d launches" % (which, TK, os.environ.get("MFMA", "1") + " VARIANT=" + os.environ.get("VARIANT", "1") + " USERS=" + os.environ.get("USERS", "192") + " WAVES=" + os.environ.get("WAVES", "4") + " TILE=" + os.environ.get("TILE", "128"), (time.perf_counter() - t0) / n * 1e3, n))

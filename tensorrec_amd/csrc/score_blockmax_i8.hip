@@ -257,21 +257,25 @@ __global__ __launch_bounds__(256, WPS) void blockmax_i8_kernel(ScoreParams p)
 // registers (8 x 4).  Lane = (k-group g = lane >> 4 of the operands | row-group g of the result, user / item row lane & 15):
 // the maxima of the four row-groups are combined by two shuffles at a superblock end, after which row-group g owns NUB / 4
 // of the user blocks (their table stores, bound constants and top-k register lists: NUB / 4 x TK registers, not NUB x TK).
-template <int KT, bool BIAS, int TK, int NUB>        // NUB: 16-user blocks per wave (8: 128 users, 12: 192 users)
-__global__ __launch_bounds__(256, 2) void blockmax_i8x16_kernel(ScoreParams p)
+// NUB: 16-user blocks per wave (8: 128 users, 12: 192 users); NW: waves per workgroup sharing one item tile stream (4: two
+// workgroups per CU, 8: one)
+// BT: item rows per tile (one barrier per tile)
+template <int KT, bool BIAS, int TK, int NUB, int NW, int BT>
+__global__ __launch_bounds__(NW * 64, 8 / NW) void blockmax_i8x16_kernel(ScoreParams p)
 {
+    constexpr int NT = NW * 64;              // threads per workgroup
     constexpr int OW = NUB / 4;              // user blocks a row-group owns at superblock ends
     static_assert(NUB % 4 == 0, "user blocks per wave must split over the four row-groups");
     constexpr int RB = KT;                   // bytes per operand row
     constexpr int CH = RB / 16;              // 16-byte chunks per row (8 at K = 128, 4 at K = 64)
     constexpr int KS = KT / 64;              // MFMA k-steps per block
-    constexpr int TILE_BYTES = BNQ * RB;
-    constexpr int NSLOT = BNQ * CH / 256;
-    constexpr int NBLK = BNQ / 16;           // 16-item blocks per tile
+    constexpr int TILE_BYTES = BT * RB;
+    constexpr int NSLOT = BT * CH / NT;
+    constexpr int NBLK = BT / 16;           // 16-item blocks per tile
     constexpr int NSTEP = NBLK * KS;
     static_assert(KT == 64 || KT == 128, "int8 16x16x64 BLOCKMAX covers K = 64 / 128");
 
-    extern __shared__ __attribute__((aligned(16))) char smem[];    // [2][TILE_BYTES] item tiles | [2][BNQ] integer item biases
+    extern __shared__ __attribute__((aligned(16))) char smem[];    // [2][TILE_BYTES] item tiles | [2][BT] integer item biases
     int* side = (int*)(smem + 2 * TILE_BYTES);
 
     const int tid = threadIdx.x;
@@ -280,10 +284,10 @@ __global__ __launch_bounds__(256, 2) void blockmax_i8x16_kernel(ScoreParams p)
     const int g = lane >> 4, lu = lane & 15;
     const int rblock = blockIdx.x % p.n_rblocks;
     const int chunk = blockIdx.x / p.n_rblocks;
-    const int64_t r_base = ((int64_t)rblock * 4 + wave) * (NUB * 16);
+    const int64_t r_base = ((int64_t)rblock * NW + wave) * (NUB * 16);
     const int64_t t_begin = (int64_t)chunk * p.chunk_len;
     const int64_t t_end = (t_begin + p.chunk_len < p.n_t) ? t_begin + p.chunk_len : p.n_t;
-    const int n_tiles = (int)((t_end - t_begin + BNQ - 1) / BNQ);
+    const int n_tiles = (int)((t_end - t_begin + BT - 1) / BT);
     // physical 16-byte chunk = logical chunk ^ swz(row): 8 consecutive rows of one logical chunk (what 8 consecutive lanes
     // read) land on 8 distinct chunk positions = all 32 banks
     auto swz = [](int row) { return CH == 8 ? (row & 7) : ((row >> 1) & 3); };
@@ -317,35 +321,35 @@ __global__ __launch_bounds__(256, 2) void blockmax_i8x16_kernel(ScoreParams p)
     int slot_off[NSLOT];
 #pragma unroll
     for (int i = 0; i < NSLOT; ++i) {
-        const int q = i * 256 + tid;
+        const int q = i * NT + tid;
         const int row = q / CH, pc = q % CH;
         slot_off[i] = row * RB + ((pc ^ swz(row)) * 16);
     }
     const char* t_chunk = (const char*)p.T + t_begin * (int64_t)RB;
     const int* t_bias_q = (const int*)p.t_bias;
     auto stage_issue = [&](int tile, int buf) {
-        const int64_t row0 = t_begin + (int64_t)tile * BNQ;
-        const bool clamp = row0 + BNQ > p.n_t;                   // wave-uniform: only the very last tile
-        if (BIAS && wave < 2) {
+        const int64_t row0 = t_begin + (int64_t)tile * BT;
+        const bool clamp = row0 + BT > p.n_t;                   // wave-uniform: only the very last tile
+        if (BIAS && wave < BT / 64) {
             int64_t gi = row0 + wave * 64 + lane;
             if (gi >= p.n_t) gi = p.n_t - 1;                     // duplicate of the last valid item: max unchanged
             if (t_bias_q) {
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(t_bias_q + gi),
-                                                 (__attribute__((address_space(3))) void*)(side + buf * BNQ + wave * 64), 4, 0, 0);
+                                                 (__attribute__((address_space(3))) void*)(side + buf * BT + wave * 64), 4, 0, 0);
             } else {
-                side[buf * BNQ + wave * 64 + lane] = 0;
+                side[buf * BT + wave * 64 + lane] = 0;
             }
         }
-        const char* tile_base = t_chunk + (int64_t)tile * (BNQ * RB);
+        const char* tile_base = t_chunk + (int64_t)tile * (BT * RB);
 #pragma unroll
         for (int i = 0; i < NSLOT; ++i) {
             int off = slot_off[i];
             if (clamp) {
                 const int last = (int)(p.n_t - 1 - row0);
-                const int row = (i * 256 + tid) / CH;
+                const int row = (i * NT + tid) / CH;
                 if (row > last) off -= (row - last) * RB;
             }
-            char* dst = smem + buf * TILE_BYTES + (i * 256 + wave * 64) * 16;
+            char* dst = smem + buf * TILE_BYTES + (i * NT + wave * 64) * 16;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tile_base + off),
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         }
@@ -364,7 +368,7 @@ __global__ __launch_bounds__(256, 2) void blockmax_i8x16_kernel(ScoreParams p)
     auto tile_body = [&](auto bufc) __attribute__((always_inline)) {
         constexpr int buf = decltype(bufc)::value;
         const char* tb = smem + buf * TILE_BYTES;
-        const int* sd = side + buf * BNQ + 4 * g;                // the block's integer biases of result rows 4 g .. 4 g + 3
+        const int* sd = side + buf * BT + 4 * g;                // the block's integer biases of result rows 4 g .. 4 g + 3
         v4i32 tf[3];
         v4i32 c0 = {0, 0, 0, 0};
         if (BIAS) c0 = *(const v4i32*)sd;
@@ -402,7 +406,7 @@ __global__ __launch_bounds__(256, 2) void blockmax_i8x16_kernel(ScoreParams p)
     __syncthreads();
 
     const float a_user = p.scales[0];
-    const int64_t sb0 = t_begin / ((int64_t)p.sb_tiles * BNQ);
+    const int64_t sb0 = t_begin / ((int64_t)p.sb_tiles * BT);
     f32x4 ss_cur = *(const f32x4*)(p.sb_stats + sb0 * 4), ss_next = ss_cur;
     for (int t = 0; t < n_tiles; ++t) {
         const int buf = t & 1;
@@ -456,20 +460,20 @@ __global__ __launch_bounds__(256, 2) void blockmax_i8x16_kernel(ScoreParams p)
     }
 }
 
-template <int KT, bool BIAS, int TK, int NUB>
+template <int KT, bool BIAS, int TK, int NUB, int NW, int BT>
 int launch_i8x16(ScoreParams p, int sb_rows, hipStream_t st)
 {
-    constexpr int LDS = 2 * BNQ * KT + 2 * BNQ * 4;
-    auto kern = blockmax_i8x16_kernel<KT, BIAS, TK, NUB>;
+    constexpr int LDS = 2 * BT * KT + 2 * BT * 4;
+    auto kern = blockmax_i8x16_kernel<KT, BIAS, TK, NUB, NW, BT>;
     static bool attr_set = false;
     if (!attr_set && LDS > 32 * 1024) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
-    p.n_rblocks = (int)ceil_div64(p.n_r, 4 * NUB * 16);
-    p.sb_tiles = sb_rows / BNQ;
+    p.n_rblocks = (int)ceil_div64(p.n_r, NW * NUB * 16);
+    p.sb_tiles = sb_rows / BT;
     const unsigned blocks = (unsigned)p.n_rblocks * (unsigned)p.n_chunks;
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), LDS, st, p);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(NW * 64), LDS, st, p);
     return trec_check_launch("trec_score_gemm_blockmax_i8 (16x16x64)");
 }
 
@@ -771,14 +775,20 @@ extern "C" int trec_score_gemm_blockmax_i8(const void* users_q, const void* item
     const bool bias = user_bias || item_bias_q;
     // "blockmax_i8_mfma": 1 (default) = v_mfma_i32_16x16x64_i8, 0 = v_mfma_i32_32x32x32_i8 (A/B runs)
     if (trec_get_tuning("blockmax_i8_mfma", 1) != 0) {
-#define TREC_I8X(KTV, TKV) (users == 192 ? (bias ? launch_i8x16<KTV, true, TKV, 12>(p, sb_rows, st) : launch_i8x16<KTV, false, TKV, 12>(p, sb_rows, st)) \
-                                       : (bias ? launch_i8x16<KTV, true, TKV, 8>(p, sb_rows, st) : launch_i8x16<KTV, false, TKV, 8>(p, sb_rows, st)))
+#define TREC_I8X3(KTV, TKV, NUBV, NWV, BTV) (bias ? launch_i8x16<KTV, true, TKV, NUBV, NWV, BTV>(p, sb_rows, st) : launch_i8x16<KTV, false, TKV, NUBV, NWV, BTV>(p, sb_rows, st))
+#define TREC_I8X2(KTV, TKV, NUBV, NWV) (tile == 256 && sb_rows % 256 == 0 ? TREC_I8X3(KTV, TKV, NUBV, NWV, 256) : TREC_I8X3(KTV, TKV, NUBV, NWV, 128))
+#define TREC_I8X(KTV, TKV) (users == 192 ? (waves == 8 ? TREC_I8X2(KTV, TKV, 12, 8) : TREC_I8X2(KTV, TKV, 12, 4)) \
+                                       : (waves == 8 ? TREC_I8X2(KTV, TKV, 8, 8) : TREC_I8X2(KTV, TKV, 8, 4)))
+        const int tile = trec_get_tuning("blockmax_i8_tile", 128);             // item rows per tile: 128 or 256
+        const int waves = trec_get_tuning("blockmax_i8_waves", 4);             // waves per workgroup: 4 or 8
         // users per wave: 192 (12 blocks of 16: a third fewer LDS reads and tile streams per flop; 78.8 vs 81.9 ms at 1M x 1M
         // with the 10-slot lists, profiles/r02_power_trace_i8.txt) unless the 16-slot lists need the registers
         const int users = trec_get_tuning("blockmax_i8_users", top_k > 10 ? 128 : 192);
         if (kpad == 128) return top_k == 0 ? TREC_I8X(128, 0) : (top_k == 10 ? TREC_I8X(128, 10) : TREC_I8X(128, 16));
         return top_k == 0 ? TREC_I8X(64, 0) : (top_k == 10 ? TREC_I8X(64, 10) : TREC_I8X(64, 16));
 #undef TREC_I8X
+#undef TREC_I8X2
+#undef TREC_I8X3
     }
 #define TREC_I8(KTV, TKV) (bias ? launch_i8<KTV, true, 4, 2, TKV>(p, sb_rows, st) : launch_i8<KTV, false, 4, 2, TKV>(p, sb_rows, st))
     if (kpad == 128) return top_k == 0 ? TREC_I8(128, 0) : (top_k == 10 ? TREC_I8(128, 10) : TREC_I8(128, 16));
