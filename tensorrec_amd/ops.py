@@ -923,10 +923,11 @@ class FilterOperand(object):
     and on the item side ``bias_q`` int32 [n], ``sb_stats`` [n_sb, 4] = per superblock of ``sb_rows`` items {scale, max
     ||y|| + ||dy||, max ||dy||, max bias quantisation error}, ``gstats8`` [4] ([2] = max |bias|), ``scales`` [3] ([0] = user scale)."""
     __slots__ = ("bf16", "f32", "n", "d", "kpad", "stats", "gstats", "i8", "stats8", "bias_q", "gstats8", "scales",
-                 "sb_stats", "sb_rows")
+                 "sb_stats", "sb_rows", "cascade_too_loose")
 
     def __init__(self):
         self.i8 = self.stats8 = self.bias_q = self.gstats8 = self.scales = self.sb_stats = self.sb_rows = None
+        self.cascade_too_loose = False      # set on the item side when the int8 bound did not pay for this catalogue
 
 
 def score_prep_filter(repr_, normalize=False, bias=None, want_gstats=False):
@@ -1113,7 +1114,8 @@ def score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index_
         n_chunks = max(1, min(n_sb, -(-32 * 768 // rblocks)))
     LAST_FILTER_STATS.clear()
     blockmax, bm_stride, cascade_status = None, n_u, None
-    if prefilter == "int8" and kpad in (64, 128) and sb_rows % 128 == 0:
+    if prefilter == "int8" and kpad in (64, 128) and sb_rows % 128 == 0 and not (iop.cascade_too_loose and
+                                                                                 floor_exchange is None):
         # ---- stages 0 + 1: int8 maxima everywhere, bf16 maxima where a top-k item can be
         blockmax, bm_stride, cascade_status = _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks,
                                                               floor_exchange, stats_exchange)
@@ -1194,6 +1196,9 @@ def score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index_
                                     floor_exchange, stats_exchange, ksel, None)
             LAST_FILTER_STATS["prefilter"] = "int8 (too loose: bf16 stage 1 instead)"
             LAST_FILTER_STATS["refined_rows"] = int(rows)
+            # the next user batches against this catalogue skip the attempt (item shards keep trying: every rank must take
+            # the same path and the flag is local)
+            iop.cascade_too_loose = True
             return r
         LAST_FILTER_STATS["prefilter"] = "int8"
         LAST_FILTER_STATS["refined_rows"] = int(rows)

@@ -112,6 +112,24 @@ def test_cascade_other_k_on_a_selective_catalogue(ops, k, d):
     assert stats["prefilter"] == "int8" and stats["flagged_users"] <= 13
 
 
+def test_cascade_remembers_a_catalogue_it_is_too_loose_for(ops):
+    """A small catalogue (78 superblocks) is not selective enough: the first call tries the int8 stage, falls back, and
+    marks the item operand; the next user batch goes straight to the bf16 filter.  Both exact."""
+    rng = np.random.default_rng(77)
+    n_u, n_i, d, k = 200, 40000, 128, 10
+    u = rng.standard_normal((2 * n_u, d)).astype(np.float32)
+    v = rng.standard_normal((n_i, d)).astype(np.float32)
+    iop = ops.score_prep_filter(dev(v), want_gstats=True)
+    seen = []
+    for b in range(2):
+        uop = ops.score_prep_filter(dev(u[b * n_u:(b + 1) * n_u]))
+        vals, idx = ops.score_topk_filtered(uop, iop, k, prefilter="int8")
+        seen.append(ops.LAST_FILTER_STATS.get("prefilter"))
+        rv, ri = O.topk_rows(O.score_dense_exact(u[b * n_u:(b + 1) * n_u], v), k)
+        assert np.array_equal(idx.cpu().numpy(), ri) and np.array_equal(vals.cpu().numpy(), rv)
+    assert seen[0] == "int8 (too loose: bf16 stage 1 instead)" and seen[1] is None and iop.cascade_too_loose
+
+
 def test_cascade_ties_and_integer_data(ops):
     """Small-integer operands: int8 quantisation is exact only by luck of the scale, every score ties with many others;
     ids must follow tf.nn.top_k's lower-index-first order."""
