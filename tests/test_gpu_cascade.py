@@ -113,10 +113,10 @@ def test_cascade_other_k_on_a_selective_catalogue(ops, k, d):
 
 
 def test_cascade_remembers_a_catalogue_it_is_too_loose_for(ops):
-    """A small catalogue (78 superblocks) is not selective enough: the first call tries the int8 stage, falls back, and
+    """A small catalogue (16 superblocks, k = 10) is not selective at all: the first call tries the int8 stage, falls back, and
     marks the item operand; the next user batch goes straight to the bf16 filter.  Both exact."""
     rng = np.random.default_rng(77)
-    n_u, n_i, d, k = 200, 40000, 128, 10
+    n_u, n_i, d, k = 200, 8192, 128, 10
     u = rng.standard_normal((2 * n_u, d)).astype(np.float32)
     v = rng.standard_normal((n_i, d)).astype(np.float32)
     iop = ops.score_prep_filter(dev(v), want_gstats=True)
