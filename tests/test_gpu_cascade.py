@@ -116,7 +116,7 @@ def test_cascade_remembers_a_catalogue_it_is_too_loose_for(ops):
     """A small catalogue (16 superblocks, k = 10) is not selective at all: the first call tries the int8 stage, falls back, and
     marks the item operand; the next user batch goes straight to the bf16 filter.  Both exact."""
     rng = np.random.default_rng(77)
-    n_u, n_i, d, k = 200, 8192, 128, 10
+    n_u, n_i, d, k = 3000, 8192, 128, 10                     # (few users never overflow: the list has room for padding)
     u = rng.standard_normal((2 * n_u, d)).astype(np.float32)
     v = rng.standard_normal((n_i, d)).astype(np.float32)
     iop = ops.score_prep_filter(dev(v), want_gstats=True)
