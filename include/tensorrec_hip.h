@@ -237,8 +237,14 @@ int trec_score_prep_filter(const float* repr, int64_t n, int32_t d, int32_t kpad
  *     row_user [cap_rows] (user ids ascending inside a superblock, -1 = padding), rblock_chunk [cap_rows / 512] (-1 for
  *     the idle workgroups beyond the kept pairs; all of them after an overflow, which the caller reads from status when
  *     the pipeline has drained and answers with the dense bf16 stage 1).  No host round trip between the stages.
+ *   trec_topk_rows_collect: the same compaction in ONE pass -- row_user [n_sb][rcap] with a fixed capacity per superblock
+ *     (rcap % 512 == 0), slots handed out by one atomicAdd per (workgroup, row) on row_count [n_sb] (zero-initialised;
+ *     ends as the number of users kept, possibly above rcap: status[1]); the order of a superblock's users follows the
+ *     atomics (no result depends on it).
  *   trec_score_gemm_blockmax_grouped: the hand-scheduled bf16 stage-1 kernel over those pairs only; workgroup w re-scores
- *     superblock rblock_chunk[w] for its 512 rows and writes blockmax[rblock_chunk[w] * bm_stride + row_user[r]]. */
+ *     superblock rblock_chunk[w] for its 512 rows and writes blockmax[rblock_chunk[w] * bm_stride + row_user[r]];
+ *     wgs_per_row > 0: the layout of trec_topk_rows_collect (rblock_chunk = row_count, superblock = w / wgs_per_row,
+ *     n_rows_g = n_sb * wgs_per_row * 512). */
 int trec_score_prep_i8(const float* repr, int64_t n, int32_t d, int32_t kpad, int32_t side, float clip_sigmas,
                        int32_t sb_rows, const float* bias, float* scales, double* workspace, void* out_q,
                        float* row_stats, int32_t* bias_q, float* sb_stats, float* gstats, void* stream);
@@ -257,10 +263,13 @@ int trec_topk_rows_fill(const float* table, int32_t n_sb, int64_t n_users, int64
                         const float* user_err, const float* sb_stats, int32_t kdim, const int32_t* block_off,
                         const int32_t* row_total, const int64_t* pstart, int64_t cap_rows, const int64_t* status,
                         int32_t* row_user, int32_t* rblock_chunk, void* stream);
+int trec_topk_rows_collect(const float* table, int32_t n_sb, int64_t n_users, int64_t stride, const float* thr,
+                           const float* user_err, const float* sb_stats, int32_t kdim, int32_t rcap, int32_t* row_count,
+                           int32_t* row_user, int64_t* status, void* stream);
 int trec_score_gemm_blockmax_grouped(const void* users_bf16, const void* items_bf16, int32_t kpad, int64_t n_rows_g,
                                      int64_t n_items, const float* user_bias, const float* item_bias, int32_t sb_rows,
                                      const int32_t* rblock_chunk, const int32_t* row_user, float* blockmax,
-                                     int64_t bm_stride, void* stream);
+                                     int64_t bm_stride, int32_t wgs_per_row, void* stream);
 int trec_topk_filter_floor(const float* tau, const float* user_stats, const float* user_bias, const float* item_gstats,
                            int32_t kdim, int64_t n_users, float* floor, int32_t* flag, int32_t* n_flagged, void* stream);
 int trec_topk_collect_blocks(const float* blockmax, int32_t n_sb, int64_t n_users, int64_t stride, const float* floor,

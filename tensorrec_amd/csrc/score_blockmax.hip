@@ -350,8 +350,17 @@ __global__ __launch_bounds__(256, 2) void blockmax_bf16x16_kernel(ScoreParams p)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, lu = lane & 15;
     const int rblock = GRP ? (int)blockIdx.x : (int)(blockIdx.x % p.n_rblocks);
-    const int chunk = GRP ? p.rblock_chunk[rblock] : (int)(blockIdx.x / p.n_rblocks);
-    if (GRP && chunk < 0) return;                                // idle workgroup of the grouped launch
+    // grouped launch, two layouts: a list (rblock_chunk[w] = the superblock of workgroup w, -1 = idle, padding rows -1 in
+    // row_index) or fixed capacity (p.capacity workgroups per superblock, rblock_chunk = the superblocks' row counts)
+    const bool fixed = GRP && p.capacity > 0;
+    const int chunk = !GRP ? (int)(blockIdx.x / p.n_rblocks) : (fixed ? rblock / p.capacity : p.rblock_chunk[rblock]);
+    int rows_here = 512;                                         // fixed layout: valid rows of this workgroup
+    if (fixed) {
+        int cnt = p.rblock_chunk[chunk];
+        if (cnt > p.capacity * 512) cnt = p.capacity * 512;
+        rows_here = cnt - (rblock % p.capacity) * 512;
+    }
+    if (GRP && (chunk < 0 || rows_here <= 0)) return;            // idle workgroup of the grouped launch
     const int64_t r_base = ((int64_t)rblock * 4 + wave) * (NUB * 16);
     const int64_t t_begin = (int64_t)chunk * p.chunk_len;
     const int64_t t_end = (t_begin + p.chunk_len < p.n_t) ? t_begin + p.chunk_len : p.n_t;
@@ -366,7 +375,11 @@ __global__ __launch_bounds__(256, 2) void blockmax_bf16x16_kernel(ScoreParams p)
     for (int ub = 0; ub < NUB; ++ub) {
         int64_t row = r_base + ub * 16 + lu;
         if (row >= p.n_r) row = p.n_r - 1;                       // clamped rows are never written
-        if (GRP) { const int32_t s = p.row_index[row]; row = s < 0 ? 0 : s; }     // padding rows compute on user 0
+        if (GRP) {                                               // padding rows compute on user 0
+            const bool pad = fixed && wave * (NUB * 16) + ub * 16 + lu >= rows_here;
+            const int32_t s = pad ? -1 : p.row_index[row];
+            row = s < 0 ? 0 : s;
+        }
         const char* src = (const char*)p.R + row * (int64_t)RB;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) rfb[ub][ks] = *(const bf16x8*)(src + (ks * 4 + g) * 16);
@@ -377,7 +390,7 @@ __global__ __launch_bounds__(256, 2) void blockmax_bf16x16_kernel(ScoreParams p)
 #pragma unroll
     for (int o = 0; o < OW; ++o) {
         const int64_t row = r_base + (OW * g + o) * 16 + lu;
-        if (GRP) own_u[o] = p.row_index[row];                    // -1: padding row, never written
+        if (GRP) own_u[o] = (fixed && wave * (NUB * 16) + (OW * g + o) * 16 + lu >= rows_here) ? -1 : p.row_index[row];   // -1: padding
         else own_u[o] = row < p.n_r ? row : -1;
         own_bias[o] = (BIAS && p.r_bias && own_u[o] >= 0) ? p.r_bias[own_u[o]] : 0.f;
     }
@@ -739,6 +752,10 @@ int launch_blockmax_pipelined_grouped(const ScoreParams& p, int kt, hipStream_t 
     if (trec_get_tuning("blockmax_bf16_mfma16", 1) != 0) {       // the 16x16x32 form (filters only: see blockmax_bf16x16_kernel)
         if (kt == 128) return bias ? launch_bf16x16<128, true, true>(p, st) : launch_bf16x16<128, false, true>(p, st);
         if (kt == 64) return bias ? launch_bf16x16<64, true, true>(p, st) : launch_bf16x16<64, false, true>(p, st);
+    }
+    if (p.capacity > 0) {
+        trec_set_last_error("trec_score_gemm_blockmax_grouped: the fixed-capacity layout needs the 16x16x32 form (tuning blockmax_bf16_mfma16 = 1)");
+        return TREC_ERR_UNSUPPORTED;
     }
     if (kt == 128) return bias ? launch_grouped<128, true>(p, st) : launch_grouped<128, false>(p, st);
     if (kt == 64) return bias ? launch_grouped<64, true>(p, st) : launch_grouped<64, false>(p, st);

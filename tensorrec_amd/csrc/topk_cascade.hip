@@ -249,6 +249,87 @@ __global__ __launch_bounds__(256) void rows_fill_kernel(const float* __restrict_
     }
 }
 
+// ---- the same compaction in ONE pass over the table: fixed capacity per superblock --------------------------------------
+// row_user is [n_sb][rcap]; a workgroup (1024 users x 32 rows) takes, per row, a run of slots with ONE atomicAdd on the row's
+// counter and writes its kept users there (ascending inside the run; the order of the runs of different workgroups follows
+// the atomics -- which users share a workgroup of the bf16 stage changes from run to run, no result does).  Slots beyond
+// rcap are dropped and row_count[s] > rcap tells (rows_status_kernel) that the call must fall back.
+__global__ __launch_bounds__(256) void rows_collect_kernel(const float* __restrict__ table, int32_t n_sb, int64_t n_users,
+                                                          int64_t stride, const float* __restrict__ thr,
+                                                          const float* __restrict__ user_err,
+                                                          const float* __restrict__ sb_stats, int kdim, int32_t rcap,
+                                                          int32_t* __restrict__ row_count, int32_t* __restrict__ row_user)
+{
+    __shared__ int wsum[2][CROWS][4];
+    __shared__ int base_s[2][CROWS];
+    const int64_t u = (int64_t)blockIdx.x * CUSERS + threadIdx.x * 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const UserConsts c = load_user_consts(thr, user_err, n_users, u);
+    for (int g = 0; g < CGROUPS; ++g) {
+        const int32_t s0 = (blockIdx.y * CGROUPS + g) * CROWS;
+        if (s0 >= n_sb) break;
+        const unsigned int bits = tile_bits(table, n_sb, n_users, stride, c, sb_stats, kdim, s0, u);
+        int pre[CROWS];
+#pragma unroll
+        for (int r = 0; r < CROWS; ++r) {
+            const int k = __builtin_popcount((bits >> (4 * r)) & 15u);
+            int inc = k;
+            for (int off = 1; off < 64; off <<= 1) {
+                const int t = __shfl_up(inc, off, 64);
+                if (lane >= off) inc += t;
+            }
+            pre[r] = inc - k;
+            if (lane == 63) wsum[g & 1][r][wave] = inc;
+        }
+        __syncthreads();
+        if (threadIdx.x < CROWS && s0 + threadIdx.x < n_sb) {
+            const int total = wsum[g & 1][threadIdx.x][0] + wsum[g & 1][threadIdx.x][1] + wsum[g & 1][threadIdx.x][2] +
+                              wsum[g & 1][threadIdx.x][3];
+            base_s[g & 1][threadIdx.x] = total ? atomicAdd(&row_count[s0 + threadIdx.x], total) : 0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < CROWS; ++r) {
+            const int32_t s = s0 + r;
+            if (s >= n_sb) break;
+            const unsigned int m = (bits >> (4 * r)) & 15u;
+            if (m) {
+                int idx = base_s[g & 1][r] + pre[r];
+                for (int w = 0; w < wave; ++w) idx += wsum[g & 1][r][w];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if ((m >> e) & 1u) {
+                        if (idx < rcap) row_user[(int64_t)s * rcap + idx] = (int32_t)(u + e);
+                        ++idx;
+                    }
+            }
+        }
+    }
+}
+
+// status[0] = resident rows the grouped launch works on (every row's count, capped, rounded up to whole workgroups),
+// status[1] = 1 when some superblock kept more users than rcap
+__global__ __launch_bounds__(256) void rows_status_kernel(const int32_t* __restrict__ row_count, int32_t n_sb, int32_t rcap,
+                                                         int64_t* __restrict__ status)
+{
+    __shared__ long long tot[4];
+    __shared__ int over[4];
+    long long t = 0;
+    int o = 0;
+    for (int s = threadIdx.x; s < n_sb; s += 256) {
+        const int c = row_count[s];
+        o |= c > rcap;
+        t += ((c < rcap ? c : rcap) + GROUP_ROWS - 1) / GROUP_ROWS * GROUP_ROWS;
+    }
+    for (int off = 32; off > 0; off >>= 1) { t += __shfl_xor(t, off, 64); o |= __shfl_xor(o, off, 64); }
+    if ((threadIdx.x & 63) == 0) { tot[threadIdx.x >> 6] = t; over[threadIdx.x >> 6] = o; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        status[0] = tot[0] + tot[1] + tot[2] + tot[3];
+        status[1] = (over[0] | over[1] | over[2] | over[3]) ? 1 : 0;
+    }
+}
+
 }  // namespace
 
 extern "C" int32_t trec_topk_rows_user_blocks(int64_t n_users) { return (int32_t)ceil_div64(n_users, CUSERS); }
@@ -297,13 +378,35 @@ extern "C" int trec_topk_rows_fill(const float* table, int32_t n_sb, int64_t n_u
     return trec_check_launch("trec_topk_rows_fill");
 }
 
+// The one-pass form of the compaction: row_user [n_sb][rcap] (rcap a multiple of 512), row_count [n_sb] zero-initialised by
+// the caller (ends as the number of users kept per superblock, possibly above rcap), status int64[2] = {resident rows,
+// overflow}.  The order of a superblock's users is not deterministic (runs of ascending ids in atomic order).
+extern "C" int trec_topk_rows_collect(const float* table, int32_t n_sb, int64_t n_users, int64_t stride, const float* thr,
+                                      const float* user_err, const float* sb_stats, int32_t kdim, int32_t rcap,
+                                      int32_t* row_count, int32_t* row_user, int64_t* status, void* stream)
+{
+    TREC_REQUIRE(table && thr && user_err && sb_stats && row_count && row_user && status, "trec_topk_rows_collect: null pointer");
+    TREC_REQUIRE(n_sb >= 1 && n_users >= 1 && stride >= n_users, "trec_topk_rows_collect: bad sizes");
+    TREC_REQUIRE(rcap >= GROUP_ROWS && rcap % GROUP_ROWS == 0, "trec_topk_rows_collect: rcap must be a multiple of 512");
+    hipStream_t st = (hipStream_t)stream;
+    const int n_ublk = (int)ceil_div64(n_users, CUSERS);
+    hipLaunchKernelGGL(rows_collect_kernel, dim3((unsigned)n_ublk, (unsigned)((n_sb + CROWS * CGROUPS - 1) / (CROWS * CGROUPS))),
+                       dim3(256), 0, st, table, n_sb, n_users, stride, thr, user_err, sb_stats, kdim, rcap, row_count, row_user);
+    hipLaunchKernelGGL(rows_status_kernel, dim3(1), dim3(256), 0, st, row_count, n_sb, rcap, status);
+    return trec_check_launch("trec_topk_rows_collect");
+}
+
 // bf16 superblock maxima of the kept (superblock, user) pairs, written over the table's entries:
 // blockmax[rblock_chunk[w] * bm_stride + row_user[r]] for every resident row r of workgroup w = r / 512 with row_user[r] >= 0
 extern "C" int trec_score_gemm_blockmax_grouped(const void* users_bf16, const void* items_bf16, int32_t kpad, int64_t n_rows_g,
                                                 int64_t n_items, const float* user_bias, const float* item_bias,
                                                 int32_t sb_rows, const int32_t* rblock_chunk, const int32_t* row_user,
-                                                float* blockmax, int64_t bm_stride, void* stream)
+                                                float* blockmax, int64_t bm_stride, int32_t wgs_per_row, void* stream)
 {
+    // wgs_per_row > 0: the fixed-capacity layout of trec_topk_rows_collect -- row_user is [n_sb][wgs_per_row * 512],
+    // rblock_chunk is row_count [n_sb]; workgroup w works on superblock w / wgs_per_row and exits when its 512 rows lie beyond
+    // the superblock's count
+    TREC_REQUIRE(wgs_per_row >= 0, "trec_score_gemm_blockmax_grouped: wgs_per_row < 0");
     TREC_REQUIRE(users_bf16 && items_bf16 && rblock_chunk && row_user && blockmax, "trec_score_gemm_blockmax_grouped: null pointer");
     TREC_REQUIRE(kpad == 64 || kpad == 128, "trec_score_gemm_blockmax_grouped: kpad must be 64 or 128");
     TREC_REQUIRE(n_rows_g % GROUP_ROWS == 0 && n_rows_g < ((int64_t)1 << 40), "trec_score_gemm_blockmax_grouped: n_rows_g % 512 != 0");
@@ -315,6 +418,6 @@ extern "C" int trec_score_gemm_blockmax_grouped(const void* users_bf16, const vo
     p.chunk_len = sb_rows; p.n_chunks = 1;
     p.r_bias = user_bias; p.t_bias = item_bias;
     p.blockmax = blockmax; p.bm_stride = bm_stride; p.sb_tiles = sb_rows / 64;
-    p.rblock_chunk = rblock_chunk; p.row_index = row_user;
+    p.rblock_chunk = rblock_chunk; p.row_index = row_user; p.capacity = wgs_per_row;
     return launch_blockmax_pipelined_grouped(p, kpad, (hipStream_t)stream);
 }

@@ -1063,13 +1063,26 @@ def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, 
                N.ptr(tau))
     if floor_exchange is not None:
         tau = floor_exchange(sel_max).contiguous()
+    status = torch.empty((2,), dtype=torch.int64, device=dev)
+    if N.load().trec_get_tuning(b"cascade_rows_onepass", 1) != 0 and N.load().trec_get_tuning(b"blockmax_bf16_mfma16", 1) != 0:
+        # one pass over the table: a fixed capacity per superblock, slots handed out by atomics (csrc/topk_cascade.hip)
+        rcap = (int(CASCADE_MAX_REFINED * n_u) + 511) // 512 * 512 + 512
+        row_count = torch.zeros((n_sb,), dtype=torch.int32, device=dev)
+        row_user = torch.empty((n_sb * rcap,), dtype=torch.int32, device=dev)      # only the kept pairs' part is touched
+        with _timed("topk_rows_compact"):
+            N.call("trec_topk_rows_collect", N.ptr(table), n_sb, n_u, stride, N.ptr(tau), N.ptr(user_err),
+                   N.ptr(iop.sb_stats), kpad, rcap, N.ptr(row_count), N.ptr(row_user), N.ptr(status))
+        with _timed("score_gemm_blockmax_grouped"):
+            N.call("trec_score_gemm_blockmax_grouped", N.ptr(uop.bf16), N.ptr(iop.bf16), kpad, n_sb * rcap, n_i,
+                   N.ptr(user_bias), N.ptr(item_bias), sb_rows, N.ptr(row_count), N.ptr(row_user), N.ptr(table), stride,
+                   rcap // 512)
+        return table, stride, status
     n_ublk = N.query("trec_topk_rows_user_blocks", n_u)
     block_off = torch.empty((n_sb * n_ublk,), dtype=torch.int32, device=dev)
     row_total = torch.empty((n_sb,), dtype=torch.int32, device=dev)
     row_pad = torch.empty((n_sb,), dtype=torch.int32, device=dev)
     pstart = torch.empty((n_sb + 1,), dtype=torch.int64, device=dev)
     cap_rows = (int(CASCADE_MAX_REFINED * n_sb * n_u) + 511) // 512 * 512 + 512 * n_sb
-    status = torch.empty((2,), dtype=torch.int64, device=dev)
     row_user = torch.empty((cap_rows,), dtype=torch.int32, device=dev)          # only the kept pairs' part is touched
     rblock_chunk = torch.empty((cap_rows // 512,), dtype=torch.int32, device=dev)
     with _timed("topk_rows_compact"):
@@ -1080,7 +1093,7 @@ def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, 
                N.ptr(rblock_chunk))
     with _timed("score_gemm_blockmax_grouped"):
         N.call("trec_score_gemm_blockmax_grouped", N.ptr(uop.bf16), N.ptr(iop.bf16), kpad, cap_rows, n_i,
-               N.ptr(user_bias), N.ptr(item_bias), sb_rows, N.ptr(rblock_chunk), N.ptr(row_user), N.ptr(table), stride)
+               N.ptr(user_bias), N.ptr(item_bias), sb_rows, N.ptr(rblock_chunk), N.ptr(row_user), N.ptr(table), stride, 0)
     return table, stride, status
 
 

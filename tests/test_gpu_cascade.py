@@ -331,6 +331,55 @@ def test_rows_compaction_lists_exactly_the_pairs_whose_upper_bound_reaches_the_t
             assert np.all(rc[want_rows // 512:] == -1)
 
 
+def test_rows_collect_one_pass_keeps_the_same_pairs(ops):
+    """trec_topk_rows_collect: per superblock the same SET of users as the two-pass compaction (the order follows the
+    atomics), the counts, the overflow flag when a superblock keeps more than the capacity."""
+    from tensorrec_amd import _native as N
+    rng = np.random.default_rng(12)
+    for n_sb, n_u, stride, rcap in ((37, 5000, 5000, 2048), (130, 2050, 2051, 1024), (9, 3000, 3000, 512)):
+        table = rng.standard_normal((n_sb, stride)).astype(np.float32)
+        thr = rng.uniform(0.5, 2.5, n_u).astype(np.float32)
+        thr[5] = -np.inf
+        uerr = rng.uniform(0.0, 0.3, (n_u, 3)).astype(np.float32)
+        sbs = rng.uniform(0.0, 1.0, (n_sb, 4)).astype(np.float32)
+        with np.errstate(invalid="ignore", over="ignore"):
+            f32, f64 = np.float32, np.float64
+            infl, ck = f32(1.0029296875), f32(128 + 4) * f32(2.98023224e-07)
+            A = ((sbs[:, 2] + ck * sbs[:, 1]) * infl)[:, None]
+            B = (sbs[:, 1] * infl)[:, None]
+            C = (sbs[:, 3] * infl)[:, None]
+            cu = uerr[:, 2] * infl + f32(2e-30)
+
+            def pred(x):
+                y = np.nextafter(x, f32(-np.inf))
+                y[x == -np.inf] = -np.inf
+                return y
+            f = pred(pred(pred(thr.copy())) - cu)
+            fma = lambda a, b, c: (a.astype(f64) * b.astype(f64) + c.astype(f64)).astype(f32)
+            tv = table[:, :n_u]
+            lhs = fma(np.broadcast_to(uerr[:, 0][None, :], tv.shape), np.broadcast_to(A, tv.shape),
+                      fma(np.broadcast_to(uerr[:, 1][None, :], tv.shape), np.broadcast_to(B, tv.shape), tv + C))
+            keep = ~(lhs < f[None, :])
+        row_count = torch.zeros((n_sb,), dtype=torch.int32, device="cuda")
+        row_user = torch.full((n_sb * rcap,), -7, dtype=torch.int32, device="cuda")
+        status = torch.full((2,), -5, dtype=torch.int64, device="cuda")
+        dt, dth, due, dsb = dev(table), dev(thr), dev(uerr), dev(sbs)           # (kept alive across the launch)
+        N.call("trec_topk_rows_collect", N.ptr(dt), n_sb, n_u, stride, N.ptr(dth), N.ptr(due), N.ptr(dsb), 128, rcap,
+               N.ptr(row_count), N.ptr(row_user), N.ptr(status))
+        cnt = row_count.cpu().numpy()
+        assert np.array_equal(cnt, keep.sum(1))
+        ru = row_user.cpu().numpy().reshape(n_sb, rcap)
+        over = bool((cnt > rcap).any())
+        assert status.tolist() == [int(((np.minimum(cnt, rcap) + 511) // 512 * 512).sum()), int(over)]
+        for s in range(n_sb):
+            users = np.nonzero(keep[s])[0]
+            got = ru[s, :min(cnt[s], rcap)]
+            if cnt[s] <= rcap:
+                assert np.array_equal(np.sort(got), users) and np.all(ru[s, cnt[s]:] == -7)
+            else:
+                assert len(np.unique(got)) == rcap and np.all(np.isin(got, users))
+
+
 def test_grouped_bf16_blockmax_equals_the_full_kernel_on_the_listed_pairs(ops):
     from tensorrec_amd import _native as N
     rng = np.random.default_rng(6)
@@ -355,7 +404,19 @@ def test_grouped_bf16_blockmax_equals_the_full_kernel_on_the_listed_pairs(ops):
     rblock_chunk = dev(np.asarray(chunks, np.int32))
     table = torch.full((n_sb, n_u), -123.0, dtype=torch.float32, device="cuda")
     N.call("trec_score_gemm_blockmax_grouped", N.ptr(uop.bf16), N.ptr(iop.bf16), d, row_user.numel(), n_i, N.ptr(ub),
-           N.ptr(ib), sb, N.ptr(rblock_chunk), N.ptr(row_user), N.ptr(table), n_u)
+           N.ptr(ib), sb, N.ptr(rblock_chunk), N.ptr(row_user), N.ptr(table), n_u, 0)
     got, want = table.cpu().numpy(), full.cpu().numpy()
     assert np.array_equal(got[keep], want[keep])
     assert np.all(got[~keep] == -123.0)
+    # the fixed-capacity layout (trec_topk_rows_collect): [n_sb][rcap] with per-superblock counts, users in any order
+    rcap = 1024
+    counts = keep.sum(1).astype(np.int32)
+    assert counts.max() <= rcap
+    ru = np.full((n_sb, rcap), -77, np.int32)
+    for s in range(n_sb):
+        ru[s, :counts[s]] = rng.permutation(np.nonzero(keep[s])[0])
+    table2 = torch.full((n_sb, n_u), -123.0, dtype=torch.float32, device="cuda")
+    dcounts, dru = dev(counts), dev(ru.reshape(-1))
+    N.call("trec_score_gemm_blockmax_grouped", N.ptr(uop.bf16), N.ptr(iop.bf16), d, n_sb * rcap, n_i, N.ptr(ub),
+           N.ptr(ib), sb, N.ptr(dcounts), N.ptr(dru), N.ptr(table2), n_u, rcap // 512)
+    assert np.array_equal(table2.cpu().numpy(), got)
