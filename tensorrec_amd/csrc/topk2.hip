@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void select_blocks_tiled_kernel(const float* _
         for (int i = 0; i < 2; ++i) {
             const int32_t srow = s0 + lrow + 4 * i;
             r[i] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-            if (srow < n_sb && colok) r[i] = *(const f32x4*)(blockmax + (int64_t)srow * stride + u0 + lcol);
+            if (srow < n_sb && colok) r[i] = __builtin_nontemporal_load((const f32x4*)(blockmax + (int64_t)srow * stride + u0 + lcol));
             else if (srow < n_sb) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void collect_blocks_tiled_kernel(const float* 
         for (int i = 0; i < 2; ++i) {
             const int32_t srow = s0 + lrow + 4 * i;
             r[i] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-            if (srow < n_sb && vec) r[i] = *(const f32x4*)(blockmax + (int64_t)srow * stride + u0 + lcol);
+            if (srow < n_sb && vec) r[i] = __builtin_nontemporal_load((const f32x4*)(blockmax + (int64_t)srow * stride + u0 + lcol));
             else if (srow < n_sb) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
