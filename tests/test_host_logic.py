@@ -228,3 +228,22 @@ def test_host_sampler_pickles():
     assert s.rng is np.random
     r = pickle.loads(pickle.dumps(T.HostSampler(np.random.RandomState(5))))
     assert isinstance(r.rng, np.random.RandomState)
+
+
+def test_cascade_host_helpers():
+    """Host-side arithmetic of the int8 cascade: the chunking the int8 kernel uses for its per-chunk lists (must match
+    csrc/score_blockmax_i8.hip: chunks are whole superblocks) and the shapes the pre-filter is offered for."""
+    from tensorrec_amd import ops
+    for n_items, n_chunks, sb in ((1_000_000, 13, 512), (40_077, 3, 512), (512, 7, 512), (600_000, 64, 512), (5200, 1, 512)):
+        chunk_len, n_ch = ops.blockmax_i8_chunks(n_items, n_chunks, sb)
+        assert chunk_len % sb == 0 and chunk_len * n_ch >= n_items > chunk_len * (n_ch - 1) and n_ch <= n_chunks
+    assert ops.cascade_prefilter_for(128, 1_000_000) == "int8" and ops.cascade_prefilter_for(64, 262_144) == "int8"
+    assert ops.cascade_prefilter_for(100, 300_000) == "int8"            # d = 100 pads to kpad 128
+    assert ops.cascade_prefilter_for(128, 200_000) is None              # too few superblocks to be selective
+    assert ops.cascade_prefilter_for(32, 1_000_000) is None and ops.cascade_prefilter_for(256, 1_000_000) is None
+    from tensorrec_amd import _native
+    _native.set_tuning("topk_int8_prefilter", 0)
+    try:
+        assert ops.cascade_prefilter_for(128, 1_000_000) is None
+    finally:
+        _native.set_tuning("topk_int8_prefilter", 1)
