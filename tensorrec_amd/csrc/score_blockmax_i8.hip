@@ -1,25 +1,27 @@
 // tensorrec_amd/csrc/score_blockmax_i8.hip -- K2q: stage 0 of the cascaded exact top-k, the int8 pre-filter.
 //
-// The bf16 stage-1 kernel (score_blockmax.hip) sits at the chip's power limit (0.61 of the bf16 MFMA peak), so the way to
-// make the exact top-k faster is to do FEWER bf16 flops.  v_mfma_i32_32x32x32_i8 contracts twice as many elements per
-// cycle as the bf16 MFMA and its arithmetic is EXACT (int8 x int8 products, int32 accumulation: no rounding at all).
-// Operand rows are quantised to int8 with ONE scale per side (trec_score_prep_i8: q = clamp(rint(x / scale), +-127)),
-// so that for a user u   score(u, i) ~ a b (sum_k q_u[k] q_i[k] + bq_i) + b_u   and the maximum over the items of a
-// superblock is an INTEGER maximum of the raw accumulators: the same one-v_max3-per-MFMA epilogue as the bf16 kernel, with
-// the item bias (in integer units of a b) as the initial accumulator.  The quantisation error of every row is measured,
-// not assumed (|x - a q| per row, clipping included), which gives a proven bound eps8_u >= |int8 score - fp32 score|
-// exactly like the bf16 filter's (csrc/topk_filter.hip); superblocks whose int8 maximum is below
-// (k-th largest int8 maximum) - 2 eps8_u cannot hold a top-k item and never reach the bf16 stage.  At 1M x 1M, d = 128,
-// normalised rows: eps8 ~ 0.018, ~3% of the superblocks survive.
+// The bf16 stage-1 kernel (score_blockmax.hip) sits at the chip's power limit, so the way to make the exact top-k faster is
+// to do FEWER bf16 flops.  The int8 MFMA contracts twice as many elements per cycle as the bf16 one and its arithmetic is
+// EXACT (int8 x int8 products, int32 accumulation: no rounding at all).  Operand rows are quantised to int8
+// (trec_score_prep_i8: q = clamp(rint(x / scale), +-127); users: ONE scale a, items: one scale b_s per superblock), so that
+// for a user u   score(u, i) ~ a b_s (sum_k q_u[k] q_i[k] + bq_i) + b_u   and the maximum over the items of a superblock is an
+// INTEGER maximum of the raw accumulators: the same one-v_max3-per-accumulator-pair epilogue as the bf16 kernel, with the
+// item bias (in integer units of a b_s) as the initial accumulator.  The quantisation error of every row is measured, not
+// assumed (|x - scale q| per row, clipping included), which gives a proven bound e(u, s) >= |int8 score - fp32 score| per
+// user and superblock (i8_pair_err, score_common.hpp); superblocks whose upper bound M8 + e lies below the user's k-th
+// largest lower bound M8 - e cannot hold a top-k item and never reach the bf16 stage (csrc/topk_cascade.hip).  At
+// 1M x 1M, d = 128, normalised rows: e ~ 0.021, 4.3% of the (superblock, user) pairs survive.
 //
 // Replaces (as a filter in front of them) tf.matmul of tensorrec/prediction_graphs.py:49-50 + the first tf.nn.top_k of
 // tensorrec/recommendation_graphs.py:80; nothing it computes is returned to the caller -- survivors are re-scored in bf16
 // (bounded again) and finally in fp32, bit-identical to the oracle.
 //
-// Kernel plan (K = 128 bytes per row): a wave owns NCB x 32 users whose int8 fragments stay in registers (NCB x 4 k-steps x
-// 4 VGPRs); item tiles of 128 rows x 128 B = 16 KB are double-buffered in LDS through global_load_lds with the 16-byte-chunk
-// XOR swizzle of score_gemm.hip; a 32-item block is 4 k-steps of NCB MFMAs fed by ONE ds_read_b128 each; the block's
-// epilogue (8 v_max3_i32 per accumulator) runs right after its last k-step, the next block's bias row is read straight
+// Two forms of the kernel: blockmax_i8_kernel on v_mfma_i32_32x32x32_i8 (the first one; tuning blockmax_i8_mfma = 0) and
+// blockmax_i8x16_kernel on v_mfma_i32_16x16x64_i8 (the default: 17% more work per joule at the power cap, see its header).
+// Plan of the first form (K = 128 bytes per row): a wave owns NCB x 32 users whose int8 fragments stay in registers (NCB x 4
+// k-steps x 4 VGPRs); item tiles of 128 rows x 128 B = 16 KB are double-buffered in LDS through global_load_lds with the
+// 16-byte-chunk XOR swizzle of score_gemm.hip; a 32-item block is 4 k-steps of NCB MFMAs fed by ONE ds_read_b128 each; the
+// block's epilogue (8 v_max3_i32 per accumulator) runs right after its last k-step, the next block's bias row is read straight
 // into accumulator 0.  Lane & 31 is the user (acc = mfma(items, users)), exactly the orientation of the bf16 kernel.
 #include "score_common.hpp"
 #include <math.h>

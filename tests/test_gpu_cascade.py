@@ -4,7 +4,7 @@ ops.score_topk_filtered(prefilter="int8")).
 Bar: values AND item ids bit-identical to the oracle's fp32 restatement of tf.matmul + tf.nn.top_k
 (tensorrec/prediction_graphs.py:49-50, tensorrec/recommendation_graphs.py:80) -- the int8 stage only decides which
 (superblock, user) pairs the bf16 stage looks at; the int8 maxima are exact integer arithmetic (checked against an integer
-reference), the bound eps8_u must dominate every observed |int8 score - fp32 score|, and the row-wise compaction must
+reference), the bound e(u, s) must dominate every observed |int8 score - fp32 score|, and the row-wise compaction must
 list exactly the pairs at or above the floor."""
 import numpy as np
 import pytest
