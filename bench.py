@@ -623,7 +623,9 @@ def main():
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None,
         # arithmetic type of the dominant (MFMA) kernel
-        "dtype": "fp32" if args.precision == "fp32" else ("i8" if cascade else "bf16"),
+        # (the cascade computes in all three: int8 MFMA over every pair, bf16 MFMA over the ~4% it cannot rule out, fp32
+        # chains over the survivors; what comes out is fp32-exact: "result_precision" and the "parity" block)
+        "dtype": "fp32" if args.precision == "fp32" else ("i8/bf16/fp32" if cascade else "bf16"),
         "result_precision": ("fp32-exact (int8 MFMA pre-filter -> bf16 MFMA filter, both with proven error bounds -> fp32 "
                              "re-scoring of the survivors)" if cascade else
                              "fp32-exact (bf16 MFMA filter with a proven error bound + fp32 re-scoring of the survivors)")
