@@ -270,6 +270,18 @@ int trec_score_gemm_blockmax_grouped(const void* users_bf16, const void* items_b
                                      int64_t n_items, const float* user_bias, const float* item_bias, int32_t sb_rows,
                                      const int32_t* rblock_chunk, const int32_t* row_user, float* blockmax,
                                      int64_t bm_stride, int32_t wgs_per_row, void* stream);
+/* Skewed catalogues (fitted models, Zipf popularity: a few superblocks are wanted by most users although only 2-3% of all
+ * pairs are kept).  trec_topk_rows_hot, after trec_topk_rows_collect: superblocks with row_count > rcap are listed in hot_list
+ * [hot_cap] (ascending, -1 padded) and their row_count is zeroed -- the fixed-capacity grouped launch skips them;
+ * status = {resident rows of both launches, 1 when more than hot_cap superblocks are hot or the rows exceed max_rows: the
+ * caller falls back to the dense bf16 stage 1}.  trec_score_gemm_blockmax_hot: the dense bf16 filter kernel over the listed superblocks only, EVERY user,
+ * maxima written over the table's entries (same arithmetic as tf.matmul of tensorrec/prediction_graphs.py:49-50 in bf16,
+ * used as a bounded filter like the grouped form). */
+int trec_topk_rows_hot(int32_t* row_count, int32_t n_sb, int32_t rcap, int64_t n_users, int32_t* hot_list, int32_t hot_cap,
+                       int64_t max_rows, int64_t* status, void* stream);
+int trec_score_gemm_blockmax_hot(const void* users_bf16, const void* items_bf16, int32_t kpad, int64_t n_users,
+                                 int64_t n_items, const float* user_bias, const float* item_bias, int32_t sb_rows,
+                                 const int32_t* hot_list, int32_t hot_cap, float* blockmax, int64_t bm_stride, void* stream);
 int trec_topk_filter_floor(const float* tau, const float* user_stats, const float* user_bias, const float* item_gstats,
                            int32_t kdim, int64_t n_users, float* floor, int32_t* flag, int32_t* n_flagged, void* stream);
 int trec_topk_collect_blocks(const float* blockmax, int32_t n_sb, int64_t n_users, int64_t stride, const float* floor,

@@ -352,15 +352,18 @@ __global__ __launch_bounds__(256, 2) void blockmax_bf16x16_kernel(ScoreParams p)
     const int rblock = GRP ? (int)blockIdx.x : (int)(blockIdx.x % p.n_rblocks);
     // grouped launch, two layouts: a list (rblock_chunk[w] = the superblock of workgroup w, -1 = idle, padding rows -1 in
     // row_index) or fixed capacity (p.capacity workgroups per superblock, rblock_chunk = the superblocks' row counts)
+    // dense launch over a LIST of superblocks (the cascade's "hot" superblocks -- kept by more users than the fixed capacity
+    // holds -- are refined for every user: trec_score_gemm_blockmax_hot): p.rblock_chunk[blockIdx.x / n_rblocks], -1 = idle
     const bool fixed = GRP && p.capacity > 0;
-    const int chunk = !GRP ? (int)(blockIdx.x / p.n_rblocks) : (fixed ? rblock / p.capacity : p.rblock_chunk[rblock]);
+    const int chunk = !GRP ? (p.rblock_chunk ? p.rblock_chunk[blockIdx.x / p.n_rblocks] : (int)(blockIdx.x / p.n_rblocks))
+                           : (fixed ? rblock / p.capacity : p.rblock_chunk[rblock]);
     int rows_here = 512;                                         // fixed layout: valid rows of this workgroup
     if (fixed) {
         int cnt = p.rblock_chunk[chunk];
         if (cnt > p.capacity * 512) cnt = p.capacity * 512;
         rows_here = cnt - (rblock % p.capacity) * 512;
     }
-    if (GRP && (chunk < 0 || rows_here <= 0)) return;            // idle workgroup of the grouped launch
+    if (chunk < 0 || (GRP && rows_here <= 0)) return;            // idle workgroup of a grouped / listed launch
     const int64_t r_base = ((int64_t)rblock * 4 + wave) * (NUB * 16);
     const int64_t t_begin = (int64_t)chunk * p.chunk_len;
     const int64_t t_end = (t_begin + p.chunk_len < p.n_t) ? t_begin + p.chunk_len : p.n_t;
@@ -762,10 +765,11 @@ int launch_blockmax_pipelined_grouped(const ScoreParams& p, int kt, hipStream_t 
     return TREC_ERR_UNSUPPORTED;
 }
 
-// filter use (variant bit 5 of trec_score_gemm_blockmax): the 16x16x32 form, any summation order
+// filter use (variant bit 5 of trec_score_gemm_blockmax): the 16x16x32 form, any summation order.  With p.rblock_chunk set
+// (trec_score_gemm_blockmax_hot) chunk c of the launch is superblock p.rblock_chunk[c] (-1: idle), p.chunk_len = sb_rows.
 int launch_blockmax_filter16(const ScoreParams& p, int kt, hipStream_t st)
 {
-    if (p.euclid || trec_get_tuning("blockmax_bf16_mfma16", 1) == 0) return TREC_ERR_UNSUPPORTED;
+    if (p.euclid || (trec_get_tuning("blockmax_bf16_mfma16", 1) == 0 && !p.rblock_chunk)) return TREC_ERR_UNSUPPORTED;
     const bool bias = p.r_bias || p.t_bias;
     if (kt == 128) return bias ? launch_bf16x16<128, true, false>(p, st) : launch_bf16x16<128, false, false>(p, st);
     if (kt == 64) return bias ? launch_bf16x16<64, true, false>(p, st) : launch_bf16x16<64, false, false>(p, st);

@@ -330,6 +330,55 @@ __global__ __launch_bounds__(256) void rows_status_kernel(const int32_t* __restr
     }
 }
 
+// "Hot" superblocks: rows kept by more users than the fixed capacity holds (a few very popular items are wanted by most
+// users although only 2-3% of ALL pairs are kept: fitted models, Zipf catalogues).  They are listed -- ascending, -1 padded --
+// for a dense pass over every user (trec_score_gemm_blockmax_hot) and their counts are zeroed so that the fixed-capacity
+// grouped launch skips them; the call only fails (status[1]) when there are more than hot_cap of them or when both launches
+// together would work on more than max_rows resident rows (the int8 bound is too loose to pay).
+// status[0] = resident rows both launches work on.  Single workgroup.
+__global__ __launch_bounds__(256) void rows_hot_kernel(int32_t* __restrict__ row_count, int32_t n_sb, int32_t rcap,
+                                                      int64_t n_users, int32_t* __restrict__ hot_list, int32_t hot_cap,
+                                                      int64_t max_rows, int64_t* __restrict__ status)
+{
+    __shared__ int wcnt[4];
+    __shared__ int base_s;
+    __shared__ long long tot[4];
+    if (threadIdx.x == 0) base_s = 0;
+    long long t = 0;
+    __syncthreads();
+    for (int s0 = 0; s0 < n_sb; s0 += 256) {
+        const int s = s0 + threadIdx.x;
+        const int c = s < n_sb ? row_count[s] : 0;
+        const bool hot = c > rcap;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(hot);
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (lane == 0) wcnt[wave] = __builtin_popcountll(m);
+        __syncthreads();
+        int idx = base_s + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+        for (int w = 0; w < wave; ++w) idx += wcnt[w];
+        if (hot) {
+            if (idx < hot_cap) hot_list[idx] = s;
+            row_count[s] = 0;
+        } else {
+            t += (c + GROUP_ROWS - 1) / GROUP_ROWS * GROUP_ROWS;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) base_s += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        __syncthreads();
+    }
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+    if ((threadIdx.x & 63) == 0) tot[threadIdx.x >> 6] = t;
+    __syncthreads();
+    const int n_hot = base_s;
+    for (int j = n_hot + threadIdx.x; j < hot_cap; j += 256) hot_list[j] = -1;
+    if (threadIdx.x == 0) {
+        const long long per_hot = (n_users + GROUP_ROWS - 1) / GROUP_ROWS * GROUP_ROWS;
+        const long long rows = tot[0] + tot[1] + tot[2] + tot[3] + (long long)(n_hot < hot_cap ? n_hot : hot_cap) * per_hot;
+        status[0] = rows;
+        status[1] = (n_hot > hot_cap || rows > max_rows) ? 1 : 0;
+    }
+}
+
 }  // namespace
 
 extern "C" int32_t trec_topk_rows_user_blocks(int64_t n_users) { return (int32_t)ceil_div64(n_users, CUSERS); }
@@ -394,6 +443,40 @@ extern "C" int trec_topk_rows_collect(const float* table, int32_t n_sb, int64_t 
                        dim3(256), 0, st, table, n_sb, n_users, stride, thr, user_err, sb_stats, kdim, rcap, row_count, row_user);
     hipLaunchKernelGGL(rows_status_kernel, dim3(1), dim3(256), 0, st, row_count, n_sb, rcap, status);
     return trec_check_launch("trec_topk_rows_collect");
+}
+
+// After trec_topk_rows_collect: superblocks whose count exceeds rcap go to hot_list [hot_cap] (ascending, -1 padded) and
+// their row_count becomes 0 (the fixed-capacity grouped launch skips them; trec_score_gemm_blockmax_hot refines them for every
+// user).  status = {resident rows of both launches, 1 when more than hot_cap superblocks are hot or the rows exceed max_rows
+// (the caller falls back to the dense bf16 stage 1)}.
+extern "C" int trec_topk_rows_hot(int32_t* row_count, int32_t n_sb, int32_t rcap, int64_t n_users, int32_t* hot_list,
+                                  int32_t hot_cap, int64_t max_rows, int64_t* status, void* stream)
+{
+    TREC_REQUIRE(row_count && hot_list && status, "trec_topk_rows_hot: null pointer");
+    TREC_REQUIRE(n_sb >= 1 && rcap >= 1 && hot_cap >= 1 && n_users >= 1, "trec_topk_rows_hot: bad sizes");
+    hipLaunchKernelGGL(rows_hot_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, row_count, n_sb, rcap, n_users, hot_list,
+                       hot_cap, max_rows, status);
+    return trec_check_launch("trec_topk_rows_hot");
+}
+
+// bf16 maxima of the listed superblocks for EVERY user, written over the table's entries: the dense bf16 filter kernel
+// (v_mfma_f32_16x16x32_bf16) with chunk c = superblock hot_list[c]; workgroups of -1 entries exit at once.
+extern "C" int trec_score_gemm_blockmax_hot(const void* users_bf16, const void* items_bf16, int32_t kpad, int64_t n_users,
+                                            int64_t n_items, const float* user_bias, const float* item_bias, int32_t sb_rows,
+                                            const int32_t* hot_list, int32_t hot_cap, float* blockmax, int64_t bm_stride,
+                                            void* stream)
+{
+    TREC_REQUIRE(users_bf16 && items_bf16 && hot_list && blockmax, "trec_score_gemm_blockmax_hot: null pointer");
+    TREC_REQUIRE(kpad == 64 || kpad == 128, "trec_score_gemm_blockmax_hot: kpad must be 64 or 128");
+    TREC_REQUIRE(sb_rows >= 64 && sb_rows % 64 == 0 && hot_cap >= 1 && bm_stride >= n_users, "trec_score_gemm_blockmax_hot: bad sizes");
+    if (n_users == 0 || n_items == 0) return TREC_OK;
+    ScoreParams p = {};
+    p.R = users_bf16; p.T = items_bf16; p.n_r = n_users; p.n_t = n_items;
+    p.chunk_len = sb_rows; p.n_chunks = hot_cap;
+    p.r_bias = user_bias; p.t_bias = item_bias;
+    p.blockmax = blockmax; p.bm_stride = bm_stride; p.sb_tiles = sb_rows / 64;
+    p.rblock_chunk = hot_list;
+    return launch_blockmax_filter16(p, kpad, (hipStream_t)stream);
 }
 
 // bf16 superblock maxima of the kept (superblock, user) pairs, written over the table's entries:

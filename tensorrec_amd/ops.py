@@ -913,6 +913,15 @@ def score_topk_two_stage(users_op, items_op, dtype, kpad, k, user_bias=None, ite
 # 48 -- a user beyond the limit goes to the exact fp32 fallback, whose launch chain costs ~1.2 ms however few users)
 FILTER_KSEL = 48
 LAST_FILTER_STATS = {}    # diagnostics of the most recent score_topk_filtered call (bench.py reports them)
+FILTER_DEBUG = None       # diagnostics only: set to a dict to collect per-stage counters (each costs a host sync)
+
+
+def _debug_counts(name, count):
+    c = count.float()
+    qs = torch.quantile(c[torch.randint(0, c.numel(), (min(c.numel(), 1_000_000),), device=c.device)],
+                        torch.tensor([0.5, 0.9, 0.99, 0.999, 1.0], device=c.device))
+    FILTER_DEBUG[name + "_mean"] = float(c.mean().item())
+    FILTER_DEBUG[name + "_q50_90_99_999_max"] = [float(v) for v in qs]
 
 
 class FilterOperand(object):
@@ -972,6 +981,7 @@ def spmm_filter_operand(features, w, bias=None, want_gstats=False):
 I8_USER_CLIP_SIGMAS = 4.0        # user rows clip at 4 rms (a clipped user only widens ITS bound; measured at 1M x 1M: refined
                                  # pairs 139M at 5.0, 125M at 4.5, 114M at 4.0, 119M at 3.5); item rows never clip
 CASCADE_MAX_REFINED = 0.20       # refine at most this fraction of the (superblock, user) pairs; beyond it bf16 does it all
+CASCADE_MAX_HOT = 160           # superblocks that may be refined for every user (each costs 1 / n_sb of a dense bf16 pass)
 CASCADE_MIN_ITEMS = 262144       # below ~512 superblocks the k-th largest maximum is not selective enough for int8 to pay
 
 
@@ -1072,10 +1082,23 @@ def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, 
         with _timed("topk_rows_compact"):
             N.call("trec_topk_rows_collect", N.ptr(table), n_sb, n_u, stride, N.ptr(tau), N.ptr(user_err),
                    N.ptr(iop.sb_stats), kpad, rcap, N.ptr(row_count), N.ptr(row_user), N.ptr(status))
+        if FILTER_DEBUG is not None:
+            FILTER_DEBUG.update({"int8_pairs_wanted": int(row_count.sum().item()), "int8_pairs_total": int(n_sb) * int(n_u),
+                                 "rcap": rcap, "row_count_max": int(row_count.max().item()),
+                                 "hot_superblocks": int((row_count > rcap).sum().item())})
+        # "hot" superblocks -- kept by more users than rcap: the few rows that hold a skewed catalogue's most popular items --
+        # are refined for EVERY user by a dense launch over that list; the fixed-capacity launch skips them
+        hot_cap = max(8, min(CASCADE_MAX_HOT, n_sb))
+        hot_list = torch.empty((hot_cap,), dtype=torch.int32, device=dev)
+        max_rows = int(CASCADE_MAX_REFINED * n_sb * ((n_u + 511) // 512 * 512))
+        N.call("trec_topk_rows_hot", N.ptr(row_count), n_sb, rcap, n_u, N.ptr(hot_list), hot_cap, max_rows, N.ptr(status))
         with _timed("score_gemm_blockmax_grouped"):
             N.call("trec_score_gemm_blockmax_grouped", N.ptr(uop.bf16), N.ptr(iop.bf16), kpad, n_sb * rcap, n_i,
                    N.ptr(user_bias), N.ptr(item_bias), sb_rows, N.ptr(row_count), N.ptr(row_user), N.ptr(table), stride,
                    rcap // 512)
+        with _timed("score_gemm_blockmax_hot"):
+            N.call("trec_score_gemm_blockmax_hot", N.ptr(uop.bf16), N.ptr(iop.bf16), kpad, n_u, n_i, N.ptr(user_bias),
+                   N.ptr(item_bias), sb_rows, N.ptr(hot_list), hot_cap, N.ptr(table), stride)
         return table, stride, status
     n_ublk = N.query("trec_topk_rows_user_blocks", n_u)
     block_off = torch.empty((n_sb * n_ublk,), dtype=torch.int32, device=dev)
@@ -1161,12 +1184,21 @@ def score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index_
     n_flagged = torch.zeros((1,), dtype=torch.int32, device=dev)
     N.call("trec_topk_filter_floor", N.ptr(tau), N.ptr(uop.stats), N.ptr(user_bias), N.ptr(gstats), kpad, n_u,
            N.ptr(floor), N.ptr(flag), N.ptr(n_flagged))
+    if FILTER_DEBUG is not None:
+        FILTER_DEBUG["flagged_after_floor"] = int(n_flagged.item())
     n_pairs = n_u * ksel
     keys = torch.empty((n_pairs,), dtype=torch.int32, device=dev)
     count = torch.empty((n_u,), dtype=torch.int32, device=dev)
     with _timed("topk_collect_blocks"):
         N.call("trec_topk_collect_blocks", N.ptr(blockmax), n_sb, n_u, bm_stride, N.ptr(floor), ksel, N.ptr(keys),
                N.ptr(count), N.ptr(flag), N.ptr(n_flagged))
+    if FILTER_DEBUG is not None:
+        FILTER_DEBUG["flagged_after_collect"] = int(n_flagged.item())
+        _debug_counts("kept_superblocks", count)
+        true_cnt = torch.zeros((n_u,), dtype=torch.int32, device=dev)       # without the ksel cap
+        for s0 in range(0, n_sb, 64):
+            true_cnt += (blockmax[s0:s0 + 64, :n_u] >= floor[None, :]).sum(0, dtype=torch.int32)
+        _debug_counts("kept_superblocks_uncapped", true_cnt)
     del blockmax
     # ---- stage 3a: group the kept (user, slot) pairs by superblock, pad groups to whole workgroups, gather bf16 rows
     indptr_t, users_t, perm_t = group_pairs_by_item(None, keys, ksel, n_sb + 1)

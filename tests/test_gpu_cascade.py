@@ -420,3 +420,47 @@ def test_grouped_bf16_blockmax_equals_the_full_kernel_on_the_listed_pairs(ops):
     N.call("trec_score_gemm_blockmax_grouped", N.ptr(uop.bf16), N.ptr(iop.bf16), d, n_sb * rcap, n_i, N.ptr(ub),
            N.ptr(ib), sb, N.ptr(dcounts), N.ptr(dru), N.ptr(table2), n_u, rcap // 512)
     assert np.array_equal(table2.cpu().numpy(), got)
+
+
+def test_cascade_hot_superblocks_of_a_popular_catalogue(ops):
+    """A Zipf-popular catalogue (what a fitted model looks like): a few items with large norms and biases are wanted by
+    nearly every user, so their superblocks are kept by more users than the compaction's fixed capacity although only a few
+    percent of ALL pairs are kept.  Those "hot" superblocks are refined for every user by a dense launch over the list
+    (trec_topk_rows_hot / trec_score_gemm_blockmax_hot): the cascade itself runs (no fall-back) and stays exact."""
+    rng = np.random.default_rng(21)
+    n_u, n_i, d, k = 2100, 300_000, 128, 10
+    u = rng.standard_normal((n_u, d)).astype(np.float32) / np.sqrt(d)
+    v = rng.standard_normal((n_i, d)).astype(np.float32) / np.sqrt(d)
+    pop = rng.permutation(n_i)[:40]                       # 40 popular items, spread over ~40 of the 586 superblocks
+    v[pop] *= 3.0
+    ub = (0.05 * rng.standard_normal(n_u)).astype(np.float32)
+    ib = (0.05 * rng.standard_normal(n_i)).astype(np.float32)
+    ib[pop] += 2.0
+    ops.FILTER_DEBUG = {}
+    try:
+        vals, idx, stats, _, _ = run_cascade(ops, u, v, k, ub, ib)
+        dbg = dict(ops.FILTER_DEBUG)
+    finally:
+        ops.FILTER_DEBUG = None
+    rv, ri = O.topk_rows(O.score_dense_exact(u, v, ub, ib), k)
+    assert np.array_equal(idx, ri) and np.array_equal(vals, rv)
+    assert stats["prefilter"] == "int8", stats            # the cascade ran: hot rows did not overflow it
+    assert dbg["hot_superblocks"] >= 10, dbg              # ... and there were hot rows
+    assert dbg["int8_pairs_wanted"] < 0.2 * dbg["int8_pairs_total"]
+
+
+def test_rows_hot_lists_rows_over_capacity(ops):
+    """trec_topk_rows_hot: rows with count > rcap, ascending, -1 padded; their counts zeroed; status = {rows, overflow}."""
+    from tensorrec_amd import _native as N
+    counts = np.array([5, 700, 512, 513, 0, 9000, 100, 513], dtype=np.int32)
+    rcap, n_users = 512, 1000
+    for hot_cap, max_rows, over in ((8, 1 << 40, 0), (3, 1 << 40, 1), (8, 5000, 1)):
+        rc = dev(counts.copy())
+        hot = torch.full((hot_cap,), -7, dtype=torch.int32, device="cuda")
+        status = torch.zeros((2,), dtype=torch.int64, device="cuda")
+        N.call("trec_topk_rows_hot", N.ptr(rc), len(counts), rcap, n_users, N.ptr(hot), hot_cap, max_rows, N.ptr(status))
+        want = [1, 3, 5, 7]
+        assert hot.cpu().tolist() == (want + [-1] * hot_cap)[:hot_cap]
+        assert rc.cpu().tolist() == [5, 0, 512, 0, 0, 0, 100, 0]
+        rows = 512 + 512 + 0 + 512 + min(len(want), hot_cap) * 1024
+        assert status.cpu().tolist() == [rows, over]
