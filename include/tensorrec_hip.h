@@ -222,12 +222,22 @@ int trec_score_prep_filter(const float* repr, int64_t n, int32_t d, int32_t kpad
  *   trec_score_prep_i8: repr [n, d] fp32 -> out_q int8 [n, kpad], row_stats [n][2] = {||x||, ||x - scale q||}.
  *     side 0 (users): scales[0] = min(clip_sigmas * rms, max |x|) / 127 (clip_sigmas <= 0: nothing clips); workspace 16 B.
  *     side 1 (items): sb_stats [n_sb][4], zero-initialised = {b_s = max |y| / 127 over superblock s (sb_rows rows), max
- *       ||y|| + ||dy||, max ||dy||, max |bias - scales[0] b_s bias_q|}; with a bias also side 2 (users first).
+ *       ||y|| + ||dy||, max ||dy||, max |bias - a b_s bias_q| / a (the bias quantisation error per unit of user scale a)};
+ *       with a bias also side 2 (users first).
  *     side 2: bias_q = rint(bias / (scales[0] b_s)), sb_stats[s][3] and gstats[2] = max |bias| (both zeroed by the caller)
  *       for the current user scale; the item rows are quantised once per catalogue.  kpad <= 128.
- *   trec_score_user_err_i8: r_err [n_users][3] = {||x||, ||x - a q||, ck (|b_u| + gstats[2])}, the users' part of e(u, s).
- *   trec_score_gemm_blockmax_i8: blockmax[s * bm_stride + u] = scales[0] * b_s * max over the items of superblock s of
- *     (q_u . q_i + bias_q[i]) + user_bias[u]; exact integer arithmetic on v_mfma_i32_32x32x32_i8.  kpad 64 / 128.
+ *   User scale CLASSES (the default): one scale for all users follows the largest of them and leaves small / heavy-tailed /
+ *     sparse rows a handful of levels.  trec_score_row_scale_i8: nat [n] = the scale each row wants (the best of max |x| / 127
+ *     and a half / a quarter of it by the error norm each leaves), gmax [1] (zeroed) = their maximum.  The host rounds them UP to
+ *     a geometric ladder of classes, sorts the users by class and gives every int8 workgroup
+ *     (trec_score_blockmax_i8_rows_per_workgroup rows) the scale of its first row.  trec_score_prep_i8_users: row r quantised
+ *     with wg_scale[r / wg_rows].  trec_score_bias_i8_classes: bias_q [n_classes][n_items] for the classes in use (the MFMA's
+ *     C operand is in units of ITS users' scale product), sb_stats[s][3] = the maximum over them.
+ *   trec_score_user_err_i8: r_err [n_users][4] = {||x||, ||x - a q||, ck (|b_u| + gstats[2]), a_u}, the users' part of e(u, s)
+ *     (a_u = wg_scale[u / wg_rows], or scales[0] without classes).
+ *   trec_score_gemm_blockmax_i8: blockmax[s * bm_stride + u] = a_u * b_s * max over the items of superblock s of
+ *     (q_u . q_i + bias_q[class][i]) + user_bias[u]; exact integer arithmetic on v_mfma_i32_16x16x64_i8.  kpad 64 / 128.
+ *     wg_scale / wg_class [workgroups of the launch] (nullable: scales[0], one bias table): the users' scale and class.
  *     With user_err / chunk_top / top_k (10 or 16): chunk_top [n_chunks_eff * top_k][bm_stride] = per chunk of superblocks
  *     and user the top_k largest lower bounds (sorted, -inf padded); trec_topk_select_blocks over it gives tau.
  *   trec_topk_rows_count / trec_topk_rows_fill: the pairs with table[s][u] + e(u, s) >= thr[u] (two floats below),
@@ -248,12 +258,20 @@ int trec_score_prep_filter(const float* repr, int64_t n, int32_t d, int32_t kpad
 int trec_score_prep_i8(const float* repr, int64_t n, int32_t d, int32_t kpad, int32_t side, float clip_sigmas,
                        int32_t sb_rows, const float* bias, float* scales, double* workspace, void* out_q,
                        float* row_stats, int32_t* bias_q, float* sb_stats, float* gstats, void* stream);
+int trec_score_row_scale_i8(const float* repr, int64_t n, int32_t d, float* nat, float* gmax, void* stream);
+int trec_score_prep_i8_users(const float* repr, int64_t n, int32_t d, int32_t kpad, const float* wg_scale, int32_t wg_rows,
+                             void* out_q, float* row_stats, void* stream);
+int trec_score_bias_i8_classes(const float* bias, int64_t n, int32_t sb_rows, const float* ladder, const int32_t* class_used,
+                               int32_t n_classes, float* sb_stats, int32_t* bias_q, float* gstats, void* stream);
+int32_t trec_score_blockmax_i8_rows_per_workgroup(int32_t top_k);
 int trec_score_user_err_i8(const float* user_stats, const float* user_bias, const float* gstats, int32_t kdim,
-                           int64_t n_users, float* r_err, void* stream);
+                           int64_t n_users, const float* scales, const float* wg_scale, int32_t wg_rows, float* r_err,
+                           void* stream);
 int trec_score_gemm_blockmax_i8(const void* users_q, const void* items_q, int32_t kpad, int64_t n_users, int64_t n_items,
                                 const float* user_bias, const int32_t* item_bias_q, const float* scales,
                                 const float* sb_stats, int32_t sb_rows, int32_t n_chunks, float* blockmax,
-                                int64_t bm_stride, const float* user_err, float* chunk_top, int32_t top_k, void* stream);
+                                int64_t bm_stride, const float* user_err, float* chunk_top, int32_t top_k,
+                                const float* wg_scale, const int32_t* wg_class, void* stream);
 int32_t trec_topk_rows_user_blocks(int64_t n_users);
 int trec_topk_rows_count(const float* table, int32_t n_sb, int64_t n_users, int64_t stride, const float* thr,
                          const float* user_err, const float* sb_stats, int32_t kdim, int32_t* block_off,
@@ -273,12 +291,12 @@ int trec_score_gemm_blockmax_grouped(const void* users_bf16, const void* items_b
 /* Skewed catalogues (fitted models, Zipf popularity: a few superblocks are wanted by most users although only 2-3% of all
  * pairs are kept).  trec_topk_rows_hot, after trec_topk_rows_collect: superblocks with row_count > rcap are listed in hot_list
  * [hot_cap] (ascending, -1 padded) and their row_count is zeroed -- the fixed-capacity grouped launch skips them;
- * status = {resident rows of both launches, 1 when more than hot_cap superblocks are hot or the rows exceed max_rows: the
+ * status = {resident rows of both launches, 1 when more than hot_cap superblocks are hot or more than max_pairs pairs would be refined: the
  * caller falls back to the dense bf16 stage 1}.  trec_score_gemm_blockmax_hot: the dense bf16 filter kernel over the listed superblocks only, EVERY user,
  * maxima written over the table's entries (same arithmetic as tf.matmul of tensorrec/prediction_graphs.py:49-50 in bf16,
  * used as a bounded filter like the grouped form). */
 int trec_topk_rows_hot(int32_t* row_count, int32_t n_sb, int32_t rcap, int64_t n_users, int32_t* hot_list, int32_t hot_cap,
-                       int64_t max_rows, int64_t* status, void* stream);
+                       int64_t max_pairs, int64_t* status, void* stream);
 int trec_score_gemm_blockmax_hot(const void* users_bf16, const void* items_bf16, int32_t kpad, int64_t n_users,
                                  int64_t n_items, const float* user_bias, const float* item_bias, int32_t sb_rows,
                                  const int32_t* hot_list, int32_t hot_cap, float* blockmax, int64_t bm_stride, void* stream);

@@ -38,15 +38,14 @@ for kind in KINDS:
         ib = (2.0 * pop).contiguous()
         ub = torch.randn(U, device="cuda", generator=g)
     out = {"kind": kind, "users": U, "items": I, "d": D}
-    uop = ops.score_prep_filter(u)
     ref = None
     for name, pre in (("cascade", "int8"), ("bf16_filter", None)):
         ops.FILTER_DEBUG = None
         times = []
         for rep in range(2):
             iop = ops.score_prep_filter(v, bias=ib, want_gstats=True)      # fresh: no memory of a too-loose catalogue
-            uop.i8 = None
             torch.cuda.synchronize(); t = time.perf_counter()
+            uop = ops.score_prep_filter(u, sort_users=pre == "int8")       # (the user-side prep, incl. the class sort, is timed)
             fv, fi = ops.score_topk_filtered(uop, iop, K, ub, ib, prefilter=pre)
             torch.cuda.synchronize(); times.append(1e3 * (time.perf_counter() - t))
         st = dict(ops.LAST_FILTER_STATS)
@@ -58,7 +57,8 @@ for kind in KINDS:
         if CHECK:
             if ref is None:
                 n_chk = min(U, 4096)
-                ref = ops.score_topk(uop.f32[:n_chk].contiguous(), iop.f32, ops.DTYPE_F32, uop.kpad, K,
+                uref = ops.score_prep_filter(u[:n_chk].contiguous())
+                ref = ops.score_topk(uref.f32, iop.f32, ops.DTYPE_F32, uref.kpad, K,
                                      ub[:n_chk].contiguous() if ub is not None else None, ib, ops.MODE_DOT, method="two_stage")
             out[name]["equals_fp32_mfma_path_on_%d_users" % ref[0].shape[0]] = bool(
                 torch.equal(fi[:ref[0].shape[0]], ref[1]) and torch.equal(fv[:ref[0].shape[0]], ref[0]))

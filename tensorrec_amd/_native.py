@@ -58,9 +58,13 @@ SIGNATURES = {
     "trec_topk_select_blocks_ex": [_vp, _i32, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp],
     "trec_score_prep_filter": [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "trec_score_prep_i8": [_vp, _i64, _i32, _i32, _i32, _f, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
-    "trec_score_user_err_i8": [_vp, _vp, _vp, _i32, _i64, _vp, _vp],
+    "trec_score_row_scale_i8": [_vp, _i64, _i32, _vp, _vp, _vp],
+    "trec_score_prep_i8_users": [_vp, _i64, _i32, _i32, _vp, _i32, _vp, _vp, _vp],
+    "trec_score_bias_i8_classes": [_vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp],
+    "trec_score_blockmax_i8_rows_per_workgroup": [_i32],
+    "trec_score_user_err_i8": [_vp, _vp, _vp, _i32, _i64, _vp, _vp, _i32, _vp, _vp],
     "trec_score_gemm_blockmax_i8": [_vp, _vp, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp, _i32,
-                                    _vp],
+                                    _vp, _vp, _vp],
     "trec_topk_rows_user_blocks": [_i64],
     "trec_topk_rows_count": [_vp, _i32, _i64, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
     "trec_topk_rows_fill": [_vp, _i32, _i64, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp],

@@ -87,7 +87,8 @@ __global__ __launch_bounds__(256, WPS) void blockmax_i8_kernel(ScoreParams p)
         slot_off[i] = row * RB + ((pc ^ sw) * 16);
     }
     const char* t_chunk = (const char*)p.T + t_begin * (int64_t)RB;
-    const int* t_bias_q = (const int*)p.t_bias;                   // integer item biases (units of the scale product)
+    // integer item biases (units of the scale product): one table per user scale class
+    const int* t_bias_q = p.t_bias ? (const int*)p.t_bias + (p.wg_class ? (int64_t)p.wg_class[rblock] * p.bias_stride : 0) : nullptr;
     auto stage_issue = [&](int tile, int buf) {
         const int64_t row0 = t_begin + (int64_t)tile * BNQ;
         const bool clamp = row0 + BNQ > p.n_t;                   // wave-uniform: only the very last tile
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(256, WPS) void blockmax_i8_kernel(ScoreParams p)
         for (int cb = 0; cb < NCB; ++cb) {
             int64_t row = r_base + cb * 32 + l31;
             if (row >= p.n_r) row = p.n_r - 1;
-            e_nx[cb] = p.r_err[row * 3]; e_ex[cb] = p.r_err[row * 3 + 1]; e_cu[cb] = p.r_err[row * 3 + 2];
+            e_nx[cb] = p.r_err[row * 4]; e_ex[cb] = p.r_err[row * 4 + 1]; e_cu[cb] = p.r_err[row * 4 + 2];
 #pragma unroll
             for (int j = 0; j < TK; ++j) top[cb][j] = -INFINITY;
         }
@@ -198,7 +199,8 @@ __global__ __launch_bounds__(256, WPS) void blockmax_i8_kernel(ScoreParams p)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    const float a_user = p.scales[0];            // integer score units -> float: a_user * (item scale of the superblock)
+    // integer score units -> float: a_user * (item scale of the superblock); a_user = the scale of this workgroup's users
+    const float a_user = p.wg_scale ? p.wg_scale[rblock] : p.scales[0];
     // the NEXT superblock's statistics are fetched while the first tile of the current one is computed: issued at a
     // superblock end they would sit, fresh, in front of the s_waitcnt vmcnt(0) that closes every tile
     const int64_t sb0 = t_begin / ((int64_t)p.sb_tiles * BNQ);
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(256, WPS) void blockmax_i8_kernel(ScoreParams p)
             // end of a superblock: combine the two half-wave maxima of each user, convert, add the user bias, store, reset
             const int64_t sb = sb0 + t / p.sb_tiles;
             const float scale = a_user * ss_cur[0];
-            const float yh = TK ? ss_cur[1] : 0.f, dy = TK ? ss_cur[2] : 0.f, db = TK ? ss_cur[3] : 0.f;
+            const float yh = TK ? ss_cur[1] : 0.f, dy = TK ? ss_cur[2] : 0.f, db = TK ? a_user * ss_cur[3] : 0.f;
             ss_cur = ss_next;
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) {
@@ -314,7 +316,7 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void blockmax_i8x16_kernel(ScorePa
         const int64_t row = own_u[o] < p.n_r ? own_u[o] : p.n_r - 1;
         own_bias[o] = (BIAS && p.r_bias) ? p.r_bias[row] : 0.f;
         if (TK) {
-            e_nx[o] = p.r_err[row * 3]; e_ex[o] = p.r_err[row * 3 + 1]; e_cu[o] = p.r_err[row * 3 + 2];
+            e_nx[o] = p.r_err[row * 4]; e_ex[o] = p.r_err[row * 4 + 1]; e_cu[o] = p.r_err[row * 4 + 2];
 #pragma unroll
             for (int j = 0; j < TK; ++j) top[o][j] = -INFINITY;
         }
@@ -328,7 +330,7 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void blockmax_i8x16_kernel(ScorePa
         slot_off[i] = row * RB + ((pc ^ swz(row)) * 16);
     }
     const char* t_chunk = (const char*)p.T + t_begin * (int64_t)RB;
-    const int* t_bias_q = (const int*)p.t_bias;
+    const int* t_bias_q = p.t_bias ? (const int*)p.t_bias + (p.wg_class ? (int64_t)p.wg_class[rblock] * p.bias_stride : 0) : nullptr;
     auto stage_issue = [&](int tile, int buf) {
         const int64_t row0 = t_begin + (int64_t)tile * BT;
         const bool clamp = row0 + BT > p.n_t;                   // wave-uniform: only the very last tile
@@ -407,7 +409,7 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void blockmax_i8x16_kernel(ScorePa
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    const float a_user = p.scales[0];
+    const float a_user = p.wg_scale ? p.wg_scale[rblock] : p.scales[0];      // the scale of this workgroup's users
     const int64_t sb0 = t_begin / ((int64_t)p.sb_tiles * BT);
     f32x4 ss_cur = *(const f32x4*)(p.sb_stats + sb0 * 4), ss_next = ss_cur;
     for (int t = 0; t < n_tiles; ++t) {
@@ -422,7 +424,7 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void blockmax_i8x16_kernel(ScorePa
             // end of a superblock: combine the four row-groups' maxima of every user; row-group g then finishes its OW blocks
             const int64_t sb = sb0 + t / p.sb_tiles;
             const float scale = a_user * ss_cur[0];
-            const float yh = TK ? ss_cur[1] : 0.f, dy = TK ? ss_cur[2] : 0.f, db = TK ? ss_cur[3] : 0.f;
+            const float yh = TK ? ss_cur[1] : 0.f, dy = TK ? ss_cur[2] : 0.f, db = TK ? a_user * ss_cur[3] : 0.f;
             ss_cur = ss_next;
             int m[NUB];
 #pragma unroll
@@ -500,17 +502,19 @@ int launch_i8(ScoreParams p, int sb_rows, hipStream_t st)
 // {||x||, ||x - scale q||} (the actual quantisation error of this row, clipping included).  Users: ONE scale (*scale_ptr).
 // Items: one scale per superblock of sb_rows rows, sb_stats[s][0] (= the superblock's max |y| / 127: no item clips), and the
 // running maxima sb_stats[s][1] = max ||y|| + ||dy|| (>= ||scale q||), sb_stats[s][2] = max ||dy|| over the superblock's rows.
+// wg_rows > 0 (users with scale classes): row r is quantised with scale_ptr[r / wg_rows] -- the users are sorted by class
+// and the wg_rows rows of one int8 workgroup share a scale.
 template <int G>
 __global__ __launch_bounds__(256) void prep_i8_kernel(const float* __restrict__ x, int64_t n, int d, int kt,
                                                      const float* __restrict__ scale_ptr, int sb_rows,
                                                      float* __restrict__ sb_stats, signed char* __restrict__ out_q,
-                                                     float2* __restrict__ row_stats)
+                                                     float2* __restrict__ row_stats, int wg_rows)
 {
     const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
     const bool ok = row < n;
     const int sub = threadIdx.x % G;
     const int64_t sb = sb_rows ? (ok ? row : n - 1) / sb_rows : 0;
-    const float scale = sb_rows ? sb_stats[sb * 4] : *scale_ptr;
+    const float scale = sb_rows ? sb_stats[sb * 4] : (wg_rows > 0 ? scale_ptr[(ok ? row : n - 1) / wg_rows] : *scale_ptr);
     const float inv = 1.0f / scale;
     const float* xr = x + (ok ? row : 0) * (int64_t)d;
     float sw = 0.f, se = 0.f;
@@ -600,22 +604,29 @@ __global__ __launch_bounds__(1024) void sb_scale_kernel(const float* __restrict_
     }
 }
 
-// item biases in integer units of the superblock's scale product a_user * b_s: bias_q = rint(bias / product),
-// gstats[2] = max |bias| (all items), sb_stats[s][3] = max |bias - product * bias_q| (superblock s).  One workgroup per superblock.
-__global__ __launch_bounds__(256) void bias_i8_kernel(const float* __restrict__ bias, int64_t n, const float* __restrict__ scales,
-                                                     int sb_rows, float* __restrict__ sb_stats, int* __restrict__ bias_q,
+// item biases in integer units of the scale product a_c * b_s, one table per user scale class c (blockIdx.y; classes nobody
+// uses are skipped): bias_q[c][i] = rint(bias / product), gstats[2] = max |bias| (all items),
+// sb_stats[s][3] = max over the classes in use of max |bias - product * bias_q| / a_c  (superblock s; zeroed by the caller) --
+// the bias part of e(u, s) is a_u times it.  One workgroup per (superblock, class).
+__global__ __launch_bounds__(256) void bias_i8_kernel(const float* __restrict__ bias, int64_t n, const float* __restrict__ ladder,
+                                                     const int32_t* __restrict__ class_used, int sb_rows,
+                                                     float* __restrict__ sb_stats, int* __restrict__ bias_q,
                                                      float* __restrict__ gstats)
 {
     const int64_t s = blockIdx.x;
+    const int c = blockIdx.y;
+    if (class_used && class_used[c] == 0) return;
     const int64_t r0 = s * sb_rows, r1 = (r0 + sb_rows < n) ? r0 + sb_rows : n;
-    const float sp = scales[0] * sb_stats[s * 4];                       // the same product the score kernel forms
+    const float a_c = ladder[c];
+    const float sp = a_c * sb_stats[s * 4];                             // the same product the score kernel forms
+    int* bq_c = bias_q + (int64_t)c * n;
     float g2 = 0.f, g3 = 0.f;
     for (int64_t i = r0 + threadIdx.x; i < r1; i += 256) {
         const float b = bias[i];
         float bq = rintf(b / sp);
         bq = fminf(fmaxf(bq, -4194304.f), 4194304.f);                   // |bq| <= 2^22: accumulators stay below 2^24
         if (!(bq == bq)) bq = 0.f;
-        bias_q[i] = (int)bq;
+        bq_c[i] = (int)bq;
         float a2 = fabsf(b), a3 = fabsf(b - bq * sp);
         if (a2 != a2) a2 = INFINITY;
         if (a3 != a3) a3 = INFINITY;
@@ -627,22 +638,85 @@ __global__ __launch_bounds__(256) void bias_i8_kernel(const float* __restrict__ 
     __syncthreads();
     if (threadIdx.x == 0) {
         g2 = fmaxf(fmaxf(w2[0], w2[1]), fmaxf(w2[2], w2[3]));
-        sb_stats[s * 4 + 3] = fmaxf(fmaxf(w3[0], w3[1]), fmaxf(w3[2], w3[3]));
+        g3 = fmaxf(fmaxf(w3[0], w3[1]), fmaxf(w3[2], w3[3]));
+        float rel = (g3 / a_c) * 1.0000005f;                            // rounded up: a_u * rel must dominate the class's error
+        if (!(rel == rel)) rel = INFINITY;
+        if (__float_as_uint(rel) > *(volatile unsigned int*)(sb_stats + s * 4 + 3))
+            atomicMax((unsigned int*)(sb_stats + s * 4 + 3), __float_as_uint(rel));
         if (__float_as_uint(g2) > *(volatile unsigned int*)(gstats + 2)) atomicMax((unsigned int*)(gstats + 2), __float_as_uint(g2));
     }
 }
 
-// r_err[u] = {||x_u||, ||x_u - a q_u||, ck (|b_u| + max |b_i|)}: the user's part of i8_pair_err
+// The scale a user row WANTS: the best of max |x| / 127 (nothing clips), half and a quarter of it (the largest elements clip)
+// by the quantisation error norm each would leave -- rows with a few huge elements are better off clipping them, rows
+// without outliers are not.  nat[row], and gmax[0] = the largest of them (zero-initialised by the caller).
+template <int G>
+__global__ __launch_bounds__(256) void row_natscale_kernel(const float* __restrict__ x, int64_t n, int d,
+                                                          float* __restrict__ nat, float* __restrict__ gmax)
+{
+    const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const bool ok = row < n;
+    const int sub = threadIdx.x % G;
+    const float* xr = x + (ok ? row : 0) * (int64_t)d;
+    f32x4 v[2];
+    float am = 0.f;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int c = (it * G + sub) * 4;
+        v[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (ok && c < d) {
+            if ((d & 3) == 0) v[it] = *(const f32x4*)(xr + c);
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (c + e < d) v[it][e] = xr[c + e];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float a = fabsf(v[it][e]); am = (a > am || a != a) ? a : am; }     // NaN sticks
+    }
+    if (am != am) am = INFINITY;
+    for (int off = G / 2; off > 0; off >>= 1) am = fmaxf(am, __shfl_xor(am, off, 64));
+    float best = am / 127.0f;
+    if (am > 0.f && am < INFINITY) {
+        float err[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int cnd = 0; cnd < 3; ++cnd) {
+            const float sc = (am / 127.0f) * (cnd == 0 ? 1.0f : (cnd == 1 ? 0.5f : 0.25f));
+            const float inv = 1.0f / sc;
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float q = rintf(v[it][e] * inv);
+                    q = fminf(fmaxf(q, -127.f), 127.f);
+                    const float r = v[it][e] - q * sc;
+                    err[cnd] = fmaf(r, r, err[cnd]);
+                }
+            for (int off = G / 2; off > 0; off >>= 1) err[cnd] += __shfl_xor(err[cnd], off, 64);
+        }
+        if (err[1] < err[0] && err[1] <= err[2]) best *= 0.5f;
+        else if (err[2] < err[0] && err[2] < err[1]) best *= 0.25f;
+    }
+    if (!(best > 0.f)) best = 0.f;                                       // an all-zero row wants nothing (smallest class)
+    if (sub == 0 && ok) nat[row] = best;
+    float gm = (sub == 0 && ok) ? best : 0.f;
+    for (int off = 32; off > 0; off >>= 1) gm = fmaxf(gm, __shfl_xor(gm, off, 64));
+    if ((threadIdx.x & 63) == 0 && __float_as_uint(gm) > *(volatile unsigned int*)gmax) atomicMax((unsigned int*)gmax, __float_as_uint(gm));
+}
+
+// r_err[u] = {||x_u||, ||x_u - a q_u||, ck (|b_u| + max |b_i|), a_u}: the user's part of i8_pair_err (a_u: the scale its row was
+// quantised with -- wg_scale[u / wg_rows] with scale classes, scales[0] otherwise)
 __global__ __launch_bounds__(256) void user_err_i8_kernel(const float2* __restrict__ ustats, const float* __restrict__ user_bias,
                                                          const float* __restrict__ gstats, int kdim, int64_t n_users,
-                                                         float* __restrict__ r_err)
+                                                         const float* __restrict__ scales, const float* __restrict__ wg_scale,
+                                                         int wg_rows, float* __restrict__ r_err)
 {
     const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (u >= n_users) return;
     const float2 st = ustats[u];
     const float bu = user_bias ? fabsf(user_bias[u]) : 0.f;
     const float ck = (float)(kdim + 4) * 2.98023224e-07f;
-    r_err[u * 3] = st.x; r_err[u * 3 + 1] = st.y; r_err[u * 3 + 2] = ck * (bu + gstats[2]);
+    *(f32x4*)(r_err + u * 4) = (f32x4){st.x, st.y, ck * (bu + gstats[2]), wg_scale ? wg_scale[u / wg_rows] : scales[0]};
 }
 
 // sum of squares (double) and maximum magnitude (float bits) of a [n, d] matrix into ws[0] / the low word of ws[1]
@@ -723,7 +797,7 @@ extern "C" int trec_score_prep_i8(const float* repr, int64_t n, int32_t d, int32
         }
         const int g = kpad >= 128 ? 32 : kpad / 4;
         const unsigned blocks = (unsigned)ceil_div64(n * g, 256);
-#define TREC_PQ(GV) hipLaunchKernelGGL(prep_i8_kernel<GV>, dim3(blocks), dim3(256), 0, st, repr, n, d, kpad, scales, side == 1 ? sb_rows : 0, sb_stats, (signed char*)out_q, (float2*)row_stats)
+#define TREC_PQ(GV) hipLaunchKernelGGL(prep_i8_kernel<GV>, dim3(blocks), dim3(256), 0, st, repr, n, d, kpad, scales, side == 1 ? sb_rows : 0, sb_stats, (signed char*)out_q, (float2*)row_stats, 0)
         if (g == 32) TREC_PQ(32);
         else if (g == 16) TREC_PQ(16);
         else TREC_PQ(8);
@@ -731,20 +805,89 @@ extern "C" int trec_score_prep_i8(const float* repr, int64_t n, int32_t d, int32
         if (side == 1)
             hipLaunchKernelGGL(sb_reduce_kernel, dim3((unsigned)ceil_div64(n, sb_rows)), dim3(256), 0, st, (const float2*)row_stats, n, sb_rows, sb_stats);
     }
-    if (side >= 1 && bias)
-        hipLaunchKernelGGL(bias_i8_kernel, dim3((unsigned)ceil_div64(n, sb_rows)), dim3(256), 0, st, bias, n, scales, sb_rows, sb_stats, bias_q, gstats);
+    if (side >= 1 && bias)          // one class: ladder = scales[0]
+        hipLaunchKernelGGL(bias_i8_kernel, dim3((unsigned)ceil_div64(n, sb_rows), 1), dim3(256), 0, st, bias, n, scales, (const int32_t*)nullptr, sb_rows, sb_stats, bias_q, gstats);
     return trec_check_launch("trec_score_prep_i8");
 }
 
-// r_err [n_users][3] = the users' part of the int8 bound ({||x||, ||x - a q||, ck (|b_u| + gstats[2])}); gstats[2] = max |item
-// bias| over ALL items (item shards all-reduce it with MAX first)
+// ---- user scale CLASSES ------------------------------------------------------------------------------------------------
+// One int8 scale for all users follows the largest of them: users with small rows (and every user of a heavy-tailed or sparse
+// population) are then quantised with a handful of levels and their bounds e(u, s) are useless.  Instead every user row gets
+// the scale it wants (trec_score_row_scale_i8), rounded UP to a geometric ladder of classes; the users are sorted by class
+// (host side: ops.score_prep_filter(sort_users=True)) so that the rows of one int8 workgroup share a class, and the integer item
+// biases exist once per class in use (the kernel's C operand must be in units of ITS users' scale product).
+
+// nat [n] = the scale each row wants, gmax [1] (zero-initialised by the caller) = their maximum
+extern "C" int trec_score_row_scale_i8(const float* repr, int64_t n, int32_t d, float* nat, float* gmax, void* stream)
+{
+    TREC_REQUIRE(repr && nat && gmax, "trec_score_row_scale_i8: null pointer");
+    TREC_REQUIRE(d >= 1 && d <= 256 && ((uintptr_t)repr % 16) == 0, "trec_score_row_scale_i8: need d <= 256 and 16-byte aligned rows");
+    if (n == 0) return TREC_OK;
+    const int kp = (d + 3) / 4 * 4;
+    const int g = kp > 64 ? 32 : (kp > 32 ? 16 : 8);
+    const unsigned blocks = (unsigned)ceil_div64(n * g, 256);
+    hipStream_t st = (hipStream_t)stream;
+    if (g == 32) hipLaunchKernelGGL(row_natscale_kernel<32>, dim3(blocks), dim3(256), 0, st, repr, n, d, nat, gmax);
+    else if (g == 16) hipLaunchKernelGGL(row_natscale_kernel<16>, dim3(blocks), dim3(256), 0, st, repr, n, d, nat, gmax);
+    else hipLaunchKernelGGL(row_natscale_kernel<8>, dim3(blocks), dim3(256), 0, st, repr, n, d, nat, gmax);
+    return trec_check_launch("trec_score_row_scale_i8");
+}
+
+// users (sorted by class): row r is quantised with wg_scale[r / wg_rows]; out_q [n, kpad], row_stats [n][2] = {||x||, ||x - a q||}
+extern "C" int trec_score_prep_i8_users(const float* repr, int64_t n, int32_t d, int32_t kpad, const float* wg_scale,
+                                        int32_t wg_rows, void* out_q, float* row_stats, void* stream)
+{
+    TREC_REQUIRE(repr && wg_scale && out_q && row_stats && wg_rows >= 1, "trec_score_prep_i8_users: bad arguments");
+    TREC_REQUIRE(d >= 1 && kpad >= d && kpad % 4 == 0 && kpad <= 128, "trec_score_prep_i8_users: need d <= kpad <= 128, kpad % 4 == 0");
+    TREC_REQUIRE(((uintptr_t)repr % 16) == 0, "trec_score_prep_i8_users: repr must be 16-byte aligned");
+    if (n == 0) return TREC_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int g = kpad >= 128 ? 32 : kpad / 4;
+    const unsigned blocks = (unsigned)ceil_div64(n * g, 256);
+#define TREC_PQU(GV) hipLaunchKernelGGL(prep_i8_kernel<GV>, dim3(blocks), dim3(256), 0, st, repr, n, d, kpad, wg_scale, 0, (float*)nullptr, (signed char*)out_q, (float2*)row_stats, wg_rows)
+    if (g == 32) TREC_PQU(32);
+    else if (g == 16) TREC_PQU(16);
+    else TREC_PQU(8);
+#undef TREC_PQU
+    return trec_check_launch("trec_score_prep_i8_users");
+}
+
+// integer item biases per class: bias_q [n_classes][n] (only the classes with class_used[c] != 0 are written),
+// sb_stats[s][3] (zeroed by the caller) = max over those classes of the bias quantisation error per unit of user scale,
+// gstats[2] (zeroed by the caller) = max |bias|; ladder [n_classes] = the classes' user scales; sb_stats[s][0] = item scales
+extern "C" int trec_score_bias_i8_classes(const float* bias, int64_t n, int32_t sb_rows, const float* ladder,
+                                          const int32_t* class_used, int32_t n_classes, float* sb_stats, int32_t* bias_q,
+                                          float* gstats, void* stream)
+{
+    TREC_REQUIRE(bias && ladder && sb_stats && bias_q && gstats, "trec_score_bias_i8_classes: null pointer");
+    TREC_REQUIRE(sb_rows >= 1 && n_classes >= 1 && n_classes <= 65535, "trec_score_bias_i8_classes: bad sizes");
+    if (n == 0) return TREC_OK;
+    hipLaunchKernelGGL(bias_i8_kernel, dim3((unsigned)ceil_div64(n, sb_rows), (unsigned)n_classes), dim3(256), 0, (hipStream_t)stream,
+                       bias, n, ladder, class_used, sb_rows, sb_stats, bias_q, gstats);
+    return trec_check_launch("trec_score_bias_i8_classes");
+}
+
+// rows of users one int8 workgroup covers under the current tuning (the granularity of a scale class boundary)
+extern "C" int32_t trec_score_blockmax_i8_rows_per_workgroup(int32_t top_k)
+{
+    if (trec_get_tuning("blockmax_i8_mfma", 1) == 0) return 4 * 4 * 32;
+    const int waves = trec_get_tuning("blockmax_i8_waves", 4) == 8 ? 8 : 4;
+    const int users = trec_get_tuning("blockmax_i8_users", top_k > 10 ? 128 : 192) == 192 ? 192 : 128;
+    return waves * users;
+}
+
+// r_err [n_users][4] = the users' part of the int8 bound ({||x||, ||x - a q||, ck (|b_u| + gstats[2]), a_u}); gstats[2] = max |item
+// bias| over ALL items (item shards all-reduce it with MAX first); a_u = wg_scale[u / wg_rows] (scale classes) or scales[0]
 extern "C" int trec_score_user_err_i8(const float* user_stats, const float* user_bias, const float* gstats, int32_t kdim,
-                                      int64_t n_users, float* r_err, void* stream)
+                                      int64_t n_users, const float* scales, const float* wg_scale, int32_t wg_rows,
+                                      float* r_err, void* stream)
 {
     TREC_REQUIRE(user_stats && gstats && r_err && kdim >= 1, "trec_score_user_err_i8: bad arguments");
+    TREC_REQUIRE((wg_scale && wg_rows >= 1) || scales, "trec_score_user_err_i8: need wg_scale + wg_rows or scales");
+    TREC_REQUIRE(((uintptr_t)r_err % 16) == 0, "trec_score_user_err_i8: r_err must be 16-byte aligned");
     if (n_users == 0) return TREC_OK;
     hipLaunchKernelGGL(user_err_i8_kernel, dim3((unsigned)ceil_div64(n_users, 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const float2*)user_stats, user_bias, gstats, kdim, n_users, r_err);
+                       (const float2*)user_stats, user_bias, gstats, kdim, n_users, scales, wg_scale, wg_rows, r_err);
     return trec_check_launch("trec_score_user_err_i8");
 }
 
@@ -757,9 +900,10 @@ extern "C" int trec_score_gemm_blockmax_i8(const void* users_q, const void* item
                                            int64_t n_items, const float* user_bias, const int32_t* item_bias_q,
                                            const float* scales, const float* sb_stats, int32_t sb_rows, int32_t n_chunks,
                                            float* blockmax, int64_t bm_stride, const float* user_err, float* chunk_top,
-                                           int32_t top_k, void* stream)
+                                           int32_t top_k, const float* wg_scale, const int32_t* wg_class, void* stream)
 {
-    TREC_REQUIRE(users_q && items_q && scales && sb_stats && blockmax && bm_stride >= n_users, "trec_score_gemm_blockmax_i8: bad arguments");
+    TREC_REQUIRE(users_q && items_q && (scales || wg_scale) && sb_stats && blockmax && bm_stride >= n_users, "trec_score_gemm_blockmax_i8: bad arguments");
+    TREC_REQUIRE(!wg_class || wg_scale, "trec_score_gemm_blockmax_i8: wg_class comes with wg_scale");
     TREC_REQUIRE(kpad == 64 || kpad == 128, "trec_score_gemm_blockmax_i8: kpad must be 64 or 128");
     TREC_REQUIRE(sb_rows >= BNQ && sb_rows % BNQ == 0, "trec_score_gemm_blockmax_i8: sb_rows must be a multiple of 128");
     TREC_REQUIRE(n_users >= 1 && n_items >= 1 && n_chunks >= 1, "trec_score_gemm_blockmax_i8: empty operand");
@@ -773,6 +917,7 @@ extern "C" int trec_score_gemm_blockmax_i8(const void* users_q, const void* item
     p.r_bias = user_bias; p.t_bias = (const float*)item_bias_q;
     p.blockmax = blockmax; p.bm_stride = bm_stride;
     p.scales = scales; p.sb_stats = sb_stats; p.r_err = user_err; p.chunk_top = chunk_top; p.top_k = top_k;
+    p.wg_scale = wg_scale; p.wg_class = item_bias_q ? wg_class : nullptr; p.bias_stride = n_items;
     hipStream_t st = (hipStream_t)stream;
     const bool bias = user_bias || item_bias_q;
     // "blockmax_i8_mfma": 1 (default) = v_mfma_i32_16x16x64_i8, 0 = v_mfma_i32_32x32x32_i8 (A/B runs)

@@ -32,9 +32,13 @@ struct ScoreParams {
     const float* row_floor;        // nullable [n_r]: a known lower bound of the row's final k-th best score (lists start there)
     const int32_t* row_index;      // grouped TOPK: nullable [n_r], resident row r is R[row_index[r]] (bias / sqnorm / floor too)
     int independent_lists;         // grouped TOPK: a list's threshold never rises from the partner half-wave's list (variant bit 4)
-    const float* scales;           // int8 BLOCKMAX (score_blockmax_i8.hip): device float[3] = {user scale, unused, unused}
-    const float* sb_stats;         // int8 BLOCKMAX: [n_sb][4] = {item scale b_s, max ||y|| + ||dy||, max ||dy||, max |bias - a b_s bq|}
-    const float* r_err;            // int8 BLOCKMAX: nullable [n_r][3] = {||x||, ||x - a q||, ck (|b_u| + max |b_i|)} -> per-chunk top lists
+    const float* scales;           // int8 BLOCKMAX (score_blockmax_i8.hip): device float[3] = {user scale (one class), unused, unused}
+    const float* sb_stats;         // int8 BLOCKMAX: [n_sb][4] = {item scale b_s, max ||y|| + ||dy||, max ||dy||, max |bias - a b_s bq| / a}
+    const float* r_err;            // int8 BLOCKMAX: nullable [n_r][4] = {||x||, ||x - a q||, ck (|b_u| + max |b_i|), a} -> per-chunk top lists
+    // int8 BLOCKMAX with user scale CLASSES (users sorted by class; a workgroup's users share one scale):
+    const float* wg_scale;         // nullable [n_rblocks]: the user scale of workgroup rblock (else scales[0])
+    const int32_t* wg_class;       // nullable [n_rblocks]: its class -> item biases t_bias + wg_class * bias_stride
+    int64_t bias_stride;
     float* chunk_top;              // int8 BLOCKMAX: [n_chunks * top_k][bm_stride]: the top_k largest LOWER BOUNDS of a chunk per user
     int top_k;
 };

@@ -36,9 +36,9 @@ constexpr int GROUP_ROWS = 512;   // resident rows per workgroup of the grouped 
 
 // table rows s0 .. s0 + CROWS - 1, users u .. u + 3 of this thread: bit (4 r + e) of the result = the superblock's UPPER
 // bound table[s0 + r][u + e] + e8 reaches thr[u + e] (the k-th largest LOWER bound, two floats down).  e8 here is
-// nx A_s + ex B_s + C_s + cu with the inflation of i8_pair_err folded into the per-row / per-user constants (rounded up):
+// nx A_s + ex B_s + a_u C_s + cu (C_s: the bias quantisation error per unit of user scale, sb_stats[s][3]) with the inflation of i8_pair_err folded into the per-row / per-user constants (rounded up):
 // it need not equal the int8 kernel's evaluation bit for bit, both only have to dominate the true error.
-struct UserConsts { float f[4], nx[4], ex[4]; };
+struct UserConsts { float f[4], nx[4], ex[4], au[4]; };
 
 __device__ __forceinline__ UserConsts load_user_consts(const float* __restrict__ thr, const float* __restrict__ user_err,
                                                        int64_t n_users, int64_t u)
@@ -48,9 +48,12 @@ __device__ __forceinline__ UserConsts load_user_consts(const float* __restrict__
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const bool in = u + e < n_users;
-        c.nx[e] = in ? user_err[(u + e) * 3] : 0.f;
-        c.ex[e] = in ? user_err[(u + e) * 3 + 1] : 0.f;
-        const float cu = in ? user_err[(u + e) * 3 + 2] * infl + 2e-30f : 0.f;
+        f32x4 ue = {0.f, 0.f, 0.f, 0.f};
+        if (in) ue = *(const f32x4*)(user_err + (u + e) * 4);              // {||x||, ||x - a q||, cu, a}
+        c.nx[e] = ue[0];
+        c.ex[e] = ue[1];
+        c.au[e] = ue[3];
+        const float cu = in ? ue[2] * infl + 2e-30f : 0.f;
         c.f[e] = in ? float_pred(float_pred(thr[u + e])) - cu : INFINITY;        // v + nx A + ex B + C >= thr - cu
         if (in) c.f[e] = float_pred(c.f[e]);                                      // the subtraction may have rounded up
     }
@@ -82,7 +85,7 @@ __device__ __forceinline__ unsigned int tile_bits(const float* __restrict__ tabl
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            if (s < n_sb && u + e < n_users && !(__fmaf_rn(c.nx[e], A, __fmaf_rn(c.ex[e], B, v[e] + C)) < c.f[e]))
+            if (s < n_sb && u + e < n_users && !(__fmaf_rn(c.nx[e], A, __fmaf_rn(c.ex[e], B, __fmaf_rn(c.au[e], C, v[e]))) < c.f[e]))
                 bits |= 1u << (4 * r + e);
     }
     return bits;
@@ -334,17 +337,17 @@ __global__ __launch_bounds__(256) void rows_status_kernel(const int32_t* __restr
 // users although only 2-3% of ALL pairs are kept: fitted models, Zipf catalogues).  They are listed -- ascending, -1 padded --
 // for a dense pass over every user (trec_score_gemm_blockmax_hot) and their counts are zeroed so that the fixed-capacity
 // grouped launch skips them; the call only fails (status[1]) when there are more than hot_cap of them or when both launches
-// together would work on more than max_rows resident rows (the int8 bound is too loose to pay).
+// together would refine more than max_pairs (superblock, user) pairs (the int8 bound is too loose to pay).
 // status[0] = resident rows both launches work on.  Single workgroup.
 __global__ __launch_bounds__(256) void rows_hot_kernel(int32_t* __restrict__ row_count, int32_t n_sb, int32_t rcap,
                                                       int64_t n_users, int32_t* __restrict__ hot_list, int32_t hot_cap,
-                                                      int64_t max_rows, int64_t* __restrict__ status)
+                                                      int64_t max_pairs, int64_t* __restrict__ status)
 {
     __shared__ int wcnt[4];
     __shared__ int base_s;
-    __shared__ long long tot[4];
+    __shared__ long long tot[4], totp[4];
     if (threadIdx.x == 0) base_s = 0;
-    long long t = 0;
+    long long t = 0, tp = 0;                                    // padded resident rows / kept pairs of the rows that are not hot
     __syncthreads();
     for (int s0 = 0; s0 < n_sb; s0 += 256) {
         const int s = s0 + threadIdx.x;
@@ -361,21 +364,23 @@ __global__ __launch_bounds__(256) void rows_hot_kernel(int32_t* __restrict__ row
             row_count[s] = 0;
         } else {
             t += (c + GROUP_ROWS - 1) / GROUP_ROWS * GROUP_ROWS;
+            tp += c;
         }
         __syncthreads();
         if (threadIdx.x == 0) base_s += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
         __syncthreads();
     }
-    for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
-    if ((threadIdx.x & 63) == 0) tot[threadIdx.x >> 6] = t;
+    for (int off = 32; off > 0; off >>= 1) { t += __shfl_xor(t, off, 64); tp += __shfl_xor(tp, off, 64); }
+    if ((threadIdx.x & 63) == 0) { tot[threadIdx.x >> 6] = t; totp[threadIdx.x >> 6] = tp; }
     __syncthreads();
     const int n_hot = base_s;
     for (int j = n_hot + threadIdx.x; j < hot_cap; j += 256) hot_list[j] = -1;
     if (threadIdx.x == 0) {
         const long long per_hot = (n_users + GROUP_ROWS - 1) / GROUP_ROWS * GROUP_ROWS;
-        const long long rows = tot[0] + tot[1] + tot[2] + tot[3] + (long long)(n_hot < hot_cap ? n_hot : hot_cap) * per_hot;
-        status[0] = rows;
-        status[1] = (n_hot > hot_cap || rows > max_rows) ? 1 : 0;
+        const long long nh = n_hot < hot_cap ? n_hot : hot_cap;
+        status[0] = tot[0] + tot[1] + tot[2] + tot[3] + nh * per_hot;
+        const long long pairs = totp[0] + totp[1] + totp[2] + totp[3] + (long long)n_hot * n_users;
+        status[1] = (n_hot > hot_cap || pairs > max_pairs) ? 1 : 0;
     }
 }
 
@@ -447,15 +452,15 @@ extern "C" int trec_topk_rows_collect(const float* table, int32_t n_sb, int64_t 
 
 // After trec_topk_rows_collect: superblocks whose count exceeds rcap go to hot_list [hot_cap] (ascending, -1 padded) and
 // their row_count becomes 0 (the fixed-capacity grouped launch skips them; trec_score_gemm_blockmax_hot refines them for every
-// user).  status = {resident rows of both launches, 1 when more than hot_cap superblocks are hot or the rows exceed max_rows
-// (the caller falls back to the dense bf16 stage 1)}.
+// user).  status = {resident rows of both launches, 1 when more than hot_cap superblocks are hot or more than max_pairs pairs
+// would be refined (the caller falls back to the dense bf16 stage 1)}.
 extern "C" int trec_topk_rows_hot(int32_t* row_count, int32_t n_sb, int32_t rcap, int64_t n_users, int32_t* hot_list,
-                                  int32_t hot_cap, int64_t max_rows, int64_t* status, void* stream)
+                                  int32_t hot_cap, int64_t max_pairs, int64_t* status, void* stream)
 {
     TREC_REQUIRE(row_count && hot_list && status, "trec_topk_rows_hot: null pointer");
     TREC_REQUIRE(n_sb >= 1 && rcap >= 1 && hot_cap >= 1 && n_users >= 1, "trec_topk_rows_hot: bad sizes");
     hipLaunchKernelGGL(rows_hot_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, row_count, n_sb, rcap, n_users, hot_list,
-                       hot_cap, max_rows, status);
+                       hot_cap, max_pairs, status);
     return trec_check_launch("trec_topk_rows_hot");
 }
 

@@ -932,18 +932,50 @@ class FilterOperand(object):
     and on the item side ``bias_q`` int32 [n], ``sb_stats`` [n_sb, 4] = per superblock of ``sb_rows`` items {scale, max
     ||y|| + ||dy||, max ||dy||, max bias quantisation error}, ``gstats8`` [4] ([2] = max |bias|), ``scales`` [3] ([0] = user scale)."""
     __slots__ = ("bf16", "f32", "n", "d", "kpad", "stats", "gstats", "i8", "stats8", "bias_q", "gstats8", "scales",
-                 "sb_stats", "sb_rows", "cascade_too_loose")
+                 "sb_stats", "sb_rows", "cascade_too_loose", "perm", "nat", "gmax", "cls", "wg_scale", "wg_class", "wg_rows")
 
     def __init__(self):
         self.i8 = self.stats8 = self.bias_q = self.gstats8 = self.scales = self.sb_stats = self.sb_rows = None
         self.cascade_too_loose = False      # set on the item side when the int8 bound did not pay for this catalogue
+        # users sorted by int8 scale class (score_prep_filter(sort_users=True)): row r of every array here is row perm[r] of
+        # the caller's representation; nat / cls = the scale each row wants and its class, gmax = the largest (device scalars)
+        self.perm = self.nat = self.gmax = self.cls = self.wg_scale = self.wg_class = self.wg_rows = None
 
 
-def score_prep_filter(repr_, normalize=False, bias=None, want_gstats=False):
+I8_CLASSES_PER_OCTAVE = 4         # user scale classes: a geometric ladder below the largest wanted scale, 2^(1/4) apart
+I8_N_CLASSES = 64                 # ... over 16 octaves; smaller rows share the last class
+
+
+def i8_user_classes_enabled():
+    return N.load().trec_get_tuning(b"i8_user_classes", 1) != 0
+
+
+def score_prep_filter(repr_, normalize=False, bias=None, want_gstats=False, sort_users=False):
+    """``sort_users`` (the USER side of score_topk_filtered with the int8 pre-filter): the rows are first sorted by the int8
+    scale class each wants (trec_score_row_scale_i8; largest scales first, stable) so that the rows of one int8 workgroup
+    share a scale -- every array of the result is in that order and ``perm`` maps its rows back (score_topk_filtered
+    permutes the user biases and un-permutes its results)."""
     x = _f32c(repr_.detach())
     n, d = x.shape
     kpad = score_kpad(d)
+    perm = nat = gmax = cls = None
+    if sort_users and kpad <= 128 and n > 0 and i8_user_classes_enabled():
+        nat = torch.empty((n,), dtype=torch.float32, device=x.device)
+        gmax = torch.zeros((1,), dtype=torch.float32, device=x.device)
+        with _timed("score_prep_i8"):
+            N.call("trec_score_row_scale_i8", N.ptr(x), n, d, N.ptr(nat), N.ptr(gmax))
+            if normalize:                    # the operand is the normalised row: its scale is the raw one over the row norm
+                nat = nat / torch.linalg.vector_norm(x, dim=1).clamp_(min=1e-6)
+                gmax = nat.max().reshape(1)
+            g = torch.where(gmax > 0, gmax, torch.ones_like(gmax))
+            cls = torch.floor(I8_CLASSES_PER_OCTAVE * torch.log2(g / nat)).clamp_(0, I8_N_CLASSES - 1)
+            cls = torch.nan_to_num(cls, nan=0.0).to(torch.int32)          # (a non-finite row poisons gmax: everything is flagged later)
+            cls, perm = torch.sort(cls, stable=True)
+            x = x.index_select(0, perm)
+            nat = nat.index_select(0, perm)
+            gmax = g
     op = FilterOperand()
+    op.perm, op.nat, op.gmax, op.cls = perm, nat, gmax, cls
     op.n, op.d, op.kpad = n, d, kpad
     own_f32 = normalize or kpad != d
     op.f32 = torch.empty((n, kpad), dtype=torch.float32, device=x.device) if own_f32 else x
@@ -992,18 +1024,19 @@ def cascade_prefilter_for(n_components, n_items_total):
     return "int8" if score_kpad(n_components) in (64, 128) and n_items_total >= CASCADE_MIN_ITEMS else None
 
 
-def score_prep_i8_pair(uop, iop, item_bias=None, sb_rows=None):
-    """int8 operands of both sides for the cascade's pre-filter (trec_score_prep_i8), from the fp32 operands of
-    FilterOperand (already normalised / padded).  Users: one scale, min(4 rms, max |x|) / 127.  Items: one scale per
-    superblock of ``sb_rows`` rows (max |y| / 127 over the superblock: no item clips), with the superblock's error maxima
-    in ``iop.sb_stats`` [n_sb, 4].  The item rows are quantised once per ``iop``; a new batch of users (its own scale) only
-    re-derives the item biases in units of the new scale products."""
+def score_prep_i8_pair(uop, iop, item_bias=None, sb_rows=None, top_k=10):
+    """int8 operands of both sides for the cascade's pre-filter, from the fp32 operands of FilterOperand (already
+    normalised / padded).  Items: one scale per superblock of ``sb_rows`` rows (max |y| / 127 over the superblock: no item
+    clips), with the superblock's error maxima in ``iop.sb_stats`` [n_sb, 4]; quantised once per ``iop``.
+    Users sorted by scale class (``uop.perm``, score_prep_filter(sort_users=True)): every int8 workgroup of ``wg_rows`` users
+    gets the scale of its first (largest) row on the ladder gmax * 2^(-c / 4), and the integer item biases exist once per class
+    in use (``iop.bias_q`` [n_classes, n_items]).  Users in the caller's order: ONE scale, min(4 rms, max |x|) / 127
+    (``iop.scales[0]``).  A new batch of users only re-derives the item biases."""
     if uop.kpad > 128:
         raise ValueError("int8 pre-filter covers kpad <= 128")
     sb_rows = int(sb_rows or SUPERBLOCK_ROWS)
     dev = uop.f32.device
-    ws = torch.empty((2,), dtype=torch.float64, device=dev)
-    clip = N.load().trec_get_tuning(b"i8_user_clip_x10", int(I8_USER_CLIP_SIGMAS * 10)) / 10.0
+    classes = uop.cls is not None
     with _timed("score_prep_i8"):
         fresh_items = iop.i8 is None or iop.sb_rows != sb_rows
         n_sb = (iop.n + sb_rows - 1) // sb_rows
@@ -1014,21 +1047,38 @@ def score_prep_i8_pair(uop, iop, item_bias=None, sb_rows=None):
             iop.sb_rows = sb_rows
             iop.i8 = torch.empty((iop.n, iop.kpad), dtype=torch.int8, device=dev)
             iop.stats8 = torch.empty((iop.n, 2), dtype=torch.float32, device=dev)
+            N.call("trec_score_prep_i8", N.ptr(iop.f32), iop.n, iop.f32.shape[1], iop.kpad, 1, 0.0, sb_rows, None,
+                   N.ptr(iop.scales), None, N.ptr(iop.i8), N.ptr(iop.stats8), None, N.ptr(iop.sb_stats), N.ptr(iop.gstats8))
         else:
             iop.gstats8[2:].zero_()
             iop.sb_stats[:, 3].zero_()
-        iop.bias_q = torch.empty((iop.n,), dtype=torch.int32, device=dev) if item_bias is not None else None
         uop.i8 = torch.empty((uop.n, uop.kpad), dtype=torch.int8, device=dev)
         uop.stats8 = torch.empty((uop.n, 2), dtype=torch.float32, device=dev)
-        N.call("trec_score_prep_i8", N.ptr(uop.f32), uop.n, uop.f32.shape[1], uop.kpad, 0, float(clip), 0, None,
-               N.ptr(iop.scales), N.ptr(ws), N.ptr(uop.i8), N.ptr(uop.stats8), None, None, None)
-        if fresh_items:
-            N.call("trec_score_prep_i8", N.ptr(iop.f32), iop.n, iop.f32.shape[1], iop.kpad, 1, 0.0, sb_rows,
-                   N.ptr(item_bias), N.ptr(iop.scales), None, N.ptr(iop.i8), N.ptr(iop.stats8), N.ptr(iop.bias_q),
-                   N.ptr(iop.sb_stats), N.ptr(iop.gstats8))
-        elif item_bias is not None:
-            N.call("trec_score_prep_i8", None, iop.n, iop.f32.shape[1], iop.kpad, 2, 0.0, sb_rows, N.ptr(item_bias),
-                   N.ptr(iop.scales), None, None, None, N.ptr(iop.bias_q), N.ptr(iop.sb_stats), N.ptr(iop.gstats8))
+        if classes:
+            wg_rows = int(N.query("trec_score_blockmax_i8_rows_per_workgroup", int(top_k)))
+            ladder = uop.gmax * torch.exp2(torch.arange(I8_N_CLASSES, device=dev, dtype=torch.float32) / (-float(I8_CLASSES_PER_OCTAVE)))
+            uop.wg_rows = wg_rows
+            uop.wg_class = uop.cls[::wg_rows].contiguous()                 # rows are sorted by class: the first is the largest scale
+            uop.wg_scale = ladder[uop.wg_class.long()].contiguous()
+            N.call("trec_score_prep_i8_users", N.ptr(uop.f32), uop.n, uop.f32.shape[1], uop.kpad, N.ptr(uop.wg_scale), wg_rows,
+                   N.ptr(uop.i8), N.ptr(uop.stats8))
+            iop.bias_q = None
+            if item_bias is not None:
+                used = torch.zeros((I8_N_CLASSES,), dtype=torch.int32, device=dev)
+                used[uop.wg_class.long()] = 1
+                iop.bias_q = torch.empty((I8_N_CLASSES, iop.n), dtype=torch.int32, device=dev)   # only the classes in use are touched
+                N.call("trec_score_bias_i8_classes", N.ptr(item_bias), iop.n, sb_rows, N.ptr(ladder), N.ptr(used), I8_N_CLASSES,
+                       N.ptr(iop.sb_stats), N.ptr(iop.bias_q), N.ptr(iop.gstats8))
+        else:
+            uop.wg_rows = uop.wg_class = uop.wg_scale = None
+            ws = torch.empty((2,), dtype=torch.float64, device=dev)
+            clip = N.load().trec_get_tuning(b"i8_user_clip_x10", int(I8_USER_CLIP_SIGMAS * 10)) / 10.0
+            N.call("trec_score_prep_i8", N.ptr(uop.f32), uop.n, uop.f32.shape[1], uop.kpad, 0, float(clip), 0, None,
+                   N.ptr(iop.scales), N.ptr(ws), N.ptr(uop.i8), N.ptr(uop.stats8), None, None, None)
+            iop.bias_q = torch.empty((iop.n,), dtype=torch.int32, device=dev) if item_bias is not None else None
+            if item_bias is not None:
+                N.call("trec_score_prep_i8", None, iop.n, iop.f32.shape[1], iop.kpad, 2, 0.0, sb_rows, N.ptr(item_bias),
+                       N.ptr(iop.scales), None, None, None, N.ptr(iop.bias_q), N.ptr(iop.sb_stats), N.ptr(iop.gstats8))
     return uop, iop
 
 
@@ -1047,23 +1097,24 @@ def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, 
     reads it when the pipeline has drained -- runs the dense bf16 stage 1 instead."""
     dev = uop.bf16.device
     n_u, n_i, kpad = uop.n, iop.n, uop.kpad
+    kk = int(k)
+    top_k = 10 if kk <= 10 else 16
     if uop.i8 is None or iop.i8 is None or iop.sb_rows != sb_rows:
-        score_prep_i8_pair(uop, iop, item_bias, sb_rows)
+        score_prep_i8_pair(uop, iop, item_bias, sb_rows, top_k)
     gstats8 = iop.gstats8
     if stats_exchange is not None:                  # max |item bias| over ALL shards enters every user's bound
         gstats8 = stats_exchange(gstats8).contiguous()
-    user_err = torch.empty((n_u, 3), dtype=torch.float32, device=dev)
-    N.call("trec_score_user_err_i8", N.ptr(uop.stats8), N.ptr(user_bias), N.ptr(gstats8), kpad, n_u, N.ptr(user_err))
+    user_err = torch.empty((n_u, 4), dtype=torch.float32, device=dev)
+    N.call("trec_score_user_err_i8", N.ptr(uop.stats8), N.ptr(user_bias), N.ptr(gstats8), kpad, n_u, N.ptr(iop.scales),
+           N.ptr(uop.wg_scale), int(uop.wg_rows or 0), N.ptr(user_err))
     stride = (n_u + 3) // 4 * 4
-    kk = int(k)
-    top_k = 10 if kk <= 10 else 16
     _, n_ch = blockmax_i8_chunks(n_i, n_chunks, sb_rows)
     table = torch.empty((n_sb, stride), dtype=torch.float32, device=dev)
     chunk_top = torch.empty((n_ch * top_k, stride), dtype=torch.float32, device=dev)
     with _timed("score_gemm_blockmax_i8"):
         N.call("trec_score_gemm_blockmax_i8", N.ptr(uop.i8), N.ptr(iop.i8), kpad, n_u, n_i, N.ptr(user_bias),
                N.ptr(iop.bias_q), N.ptr(iop.scales), N.ptr(iop.sb_stats), sb_rows, n_chunks, N.ptr(table), stride,
-               N.ptr(user_err), N.ptr(chunk_top), top_k)
+               N.ptr(user_err), N.ptr(chunk_top), top_k, N.ptr(uop.wg_scale), N.ptr(uop.wg_class))
     # tau = the k-th largest LOWER bound: from the chunks' lists (k rows per chunk), not from the 7.8 GB table
     sel = torch.empty((n_u, kk), dtype=torch.int32, device=dev)
     sel_max = torch.empty((kk, n_u), dtype=torch.float32, device=dev) if floor_exchange is not None else None
@@ -1090,8 +1141,8 @@ def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, 
         # are refined for EVERY user by a dense launch over that list; the fixed-capacity launch skips them
         hot_cap = max(8, min(CASCADE_MAX_HOT, n_sb))
         hot_list = torch.empty((hot_cap,), dtype=torch.int32, device=dev)
-        max_rows = int(CASCADE_MAX_REFINED * n_sb * ((n_u + 511) // 512 * 512))
-        N.call("trec_topk_rows_hot", N.ptr(row_count), n_sb, rcap, n_u, N.ptr(hot_list), hot_cap, max_rows, N.ptr(status))
+        max_pairs = int(CASCADE_MAX_REFINED * n_sb * n_u)
+        N.call("trec_topk_rows_hot", N.ptr(row_count), n_sb, rcap, n_u, N.ptr(hot_list), hot_cap, max_pairs, N.ptr(status))
         with _timed("score_gemm_blockmax_grouped"):
             N.call("trec_score_gemm_blockmax_grouped", N.ptr(uop.bf16), N.ptr(iop.bf16), kpad, n_sb * rcap, n_i,
                    N.ptr(user_bias), N.ptr(item_bias), sb_rows, N.ptr(row_count), N.ptr(row_user), N.ptr(table), stride,
@@ -1122,6 +1173,24 @@ def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, 
 
 def score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index_base=0, sb_rows=None, variant=1,
                         n_chunks=None, floor_exchange=None, stats_exchange=None, ksel=None, prefilter=None):
+    """See _score_topk_filtered.  A user operand sorted by int8 scale class (``uop.perm``) is handled here: the user biases
+    follow the operand's row order on the way in, the results return to the caller's order on the way out.  Item shards:
+    the per-user exchanges then carry users in the operand's order -- the same on every rank, because the user side is
+    replicated and the sort is deterministic."""
+    if uop.perm is None:
+        return _score_topk_filtered(uop, iop, k, user_bias, item_bias, item_index_base, sb_rows, variant, n_chunks,
+                                    floor_exchange, stats_exchange, ksel, prefilter)
+    ub = user_bias.index_select(0, uop.perm) if user_bias is not None else None
+    sv, si = _score_topk_filtered(uop, iop, k, ub, item_bias, item_index_base, sb_rows, variant, n_chunks,
+                                  floor_exchange, stats_exchange, ksel, prefilter)
+    ov, oi = torch.empty_like(sv), torch.empty_like(si)
+    ov.index_copy_(0, uop.perm, sv)
+    oi.index_copy_(0, uop.perm, si)
+    return ov, oi
+
+
+def _score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index_base=0, sb_rows=None, variant=1,
+                         n_chunks=None, floor_exchange=None, stats_exchange=None, ksel=None, prefilter=None):
     """EXACT fp32 top-k (values and ids bit-identical to ``score_topk(..., DTYPE_F32)`` and to the oracle) with the
     score matrix contracted ONCE on bf16 MFMA: the bf16 stage-1 maxima and the bf16 re-scoring act as a filter with a
     proven error bound (csrc/topk_filter.hip), the survivors (~15 items per user at 1M x 1M) are re-scored by the
@@ -1237,8 +1306,8 @@ def score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index_
             overflow = float(stats_exchange(torch.tensor([float(overflow)], device=dev)).item())
         if overflow:
             # the int8 bound was too loose for this data: nothing was refined and the lists above mean nothing
-            r = score_topk_filtered(uop, iop, k, user_bias, item_bias, item_index_base, sb_rows, variant, n_chunks,
-                                    floor_exchange, stats_exchange, ksel, None)
+            r = _score_topk_filtered(uop, iop, k, user_bias, item_bias, item_index_base, sb_rows, variant, n_chunks,
+                                     floor_exchange, stats_exchange, ksel, None)
             LAST_FILTER_STATS["prefilter"] = "int8 (too loose: bf16 stage 1 instead)"
             LAST_FILTER_STATS["refined_rows"] = int(rows)
             # the next user batches against this catalogue skip the attempt (item shards keep trying: every rank must take

@@ -27,11 +27,13 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-def run_cascade(ops, u, v, k, ub=None, ib=None, normalize=False, **kw):
+def run_cascade(ops, u, v, k, ub=None, ib=None, normalize=False, sort_users=True, **kw):
+    """sort_users=True is the product path (predict_top_k): users sorted by int8 scale class, one scale per int8 workgroup;
+    False: ONE scale for all users (round 2's form, kept as the A/B reference)."""
     du, dv = dev(u), dev(v)
     dub = dev(ub) if ub is not None else None
     dib = dev(ib) if ib is not None else None
-    uop = ops.score_prep_filter(du, normalize=normalize)
+    uop = ops.score_prep_filter(du, normalize=normalize, sort_users=sort_users)
     iop = ops.score_prep_filter(dv, normalize=normalize, bias=dib, want_gstats=True)
     vals, idx = ops.score_topk_filtered(uop, iop, k, dub, dib, prefilter="int8", **kw)
     return vals.cpu().numpy(), idx.cpu().numpy(), dict(ops.LAST_FILTER_STATS), uop, iop
@@ -88,7 +90,7 @@ def test_cascade_user_batches_share_the_item_operand(ops):
     iop = ops.score_prep_filter(dev(v), bias=dib, want_gstats=True)
     used = []
     for s in range(0, n_u, 300):
-        uop = ops.score_prep_filter(dev(u[s:s + 300]))
+        uop = ops.score_prep_filter(dev(u[s:s + 300]), sort_users=(s != 300))   # both forms of the user side against one item operand
         vals, idx = ops.score_topk_filtered(uop, iop, k, dev(ub[s:s + 300]), dib, prefilter="int8")
         used.append(ops.LAST_FILTER_STATS["prefilter"])
         rv, ri = O.topk_rows(O.score_dense_exact(u[s:s + 300], v, ub[s:s + 300], ib), k)
@@ -197,14 +199,16 @@ def test_int8_table_is_exact_integer_arithmetic_and_bound_holds(ops):
     assert np.array_equal(bq, np.rint(ib / sp_row).astype(np.int64))
     # the table: exact integer arithmetic, converted once per (user, superblock); the chunks' lists: the 10 largest lower bounds
     dub = dev(ub)
-    uerr = torch.empty((n_u, 3), dtype=torch.float32, device="cuda")
-    N.call("trec_score_user_err_i8", N.ptr(uop.stats8), N.ptr(dub), N.ptr(iop.gstats8), d, n_u, N.ptr(uerr))
+    uerr = torch.empty((n_u, 4), dtype=torch.float32, device="cuda")
+    N.call("trec_score_user_err_i8", N.ptr(uop.stats8), N.ptr(dub), N.ptr(iop.gstats8), d, n_u, N.ptr(iop.scales), None, 0,
+           N.ptr(uerr))
+    assert np.all(uerr.cpu().numpy()[:, 3] == a)                             # one class: every user carries the one scale
     n_chunks = 3
     chunk_len, n_ch = ops.blockmax_i8_chunks(n_i, n_chunks, sb)
     table = torch.empty((n_sb, n_u), dtype=torch.float32, device="cuda")
     ctop = torch.empty((n_ch * 10, n_u), dtype=torch.float32, device="cuda")
     N.call("trec_score_gemm_blockmax_i8", N.ptr(uop.i8), N.ptr(iop.i8), d, n_u, n_i, N.ptr(dub), N.ptr(iop.bias_q),
-           N.ptr(iop.scales), N.ptr(iop.sb_stats), sb, n_chunks, N.ptr(table), n_u, N.ptr(uerr), N.ptr(ctop), 10)
+           N.ptr(iop.scales), N.ptr(iop.sb_stats), sb, n_chunks, N.ptr(table), n_u, N.ptr(uerr), N.ptr(ctop), 10, None, None)
     s_int = uq @ iq.T + bq[None, :]
     pad = n_sb * sb - n_i
     m_int = np.concatenate([s_int, np.full((n_u, pad), np.iinfo(np.int64).min)], 1).reshape(n_u, n_sb, sb).max(2)
@@ -213,8 +217,9 @@ def test_int8_table_is_exact_integer_arithmetic_and_bound_holds(ops):
     got = table.cpu().numpy()
     assert np.array_equal(got, want)
     ue = uerr.cpu().numpy()
+    # sb_stats[s][3] is the bias quantisation error PER UNIT of user scale: the bound takes a_u times it
     e = _pair_err(ue[:, 0][None, :], ue[:, 1][None, :], ue[:, 2][None, :], sbs[:, 1][:, None], sbs[:, 2][:, None],
-                  sbs[:, 3][:, None], d)                                      # [n_sb, n_u]
+                  ue[:, 3][None, :] * sbs[:, 3][:, None], d)                  # [n_sb, n_u]
     lb = got - e
     spc = chunk_len // sb
     ct = ctop.cpu().numpy().reshape(n_ch, 10, n_u)
@@ -258,11 +263,11 @@ def test_int8_bound_is_tight_but_holds_on_aligned_quantisation_errors(ops):
     uq, iq = uop.i8.cpu().numpy().astype(np.int64), iop.i8.cpu().numpy().astype(np.int64)
     s8 = (uq @ iq.T).astype(np.float64) * float(a0) * float(b0)
     s32 = O.score_dense_exact(x, y).astype(np.float64)
-    uerr = torch.empty((n_u, 3), dtype=torch.float32, device="cuda")
-    N.call("trec_score_user_err_i8", N.ptr(uop.stats8), None, N.ptr(iop.gstats8), d, n_u, N.ptr(uerr))
+    uerr = torch.empty((n_u, 4), dtype=torch.float32, device="cuda")
+    N.call("trec_score_user_err_i8", N.ptr(uop.stats8), None, N.ptr(iop.gstats8), d, n_u, N.ptr(iop.scales), None, 0, N.ptr(uerr))
     ue, sbs = uerr.cpu().numpy(), iop.sb_stats.cpu().numpy()
     e = _pair_err(ue[:, 0][None, :], ue[:, 1][None, :], ue[:, 2][None, :], sbs[:, 1][:, None], sbs[:, 2][:, None],
-                  sbs[:, 3][:, None], d)                                      # [n_sb, n_u]
+                  ue[:, 3][None, :] * sbs[:, 3][:, None], d)                  # [n_sb, n_u]
     diff = np.abs(s8 - s32).reshape(n_u, n_i // sb, sb).max(2).T
     assert np.all(diff <= e)
     at_partner = np.abs(s8 - s32)[np.arange(n_u), partner] / e[partner // sb, np.arange(n_u)]
@@ -277,7 +282,7 @@ def test_rows_compaction_lists_exactly_the_pairs_whose_upper_bound_reaches_the_t
         thr = rng.uniform(0.5, 2.5, n_u).astype(np.float32)
         thr[5] = -np.inf                                                       # a user that keeps every superblock
         thr[6] = np.inf
-        uerr = rng.uniform(0.0, 0.3, (n_u, 3)).astype(np.float32)
+        uerr = rng.uniform(0.0, 0.3, (n_u, 4)).astype(np.float32)              # {||x||, ||x - a q||, cu, a}
         sbs = rng.uniform(0.0, 1.0, (n_sb, 4)).astype(np.float32)
         sbs[3, 2] = np.inf                                                     # a superblock with an unusable bound: always kept
         dt, dth, due, dsb = dev(table), dev(thr), dev(uerr), dev(sbs)
@@ -303,7 +308,8 @@ def test_rows_compaction_lists_exactly_the_pairs_whose_upper_bound_reaches_the_t
             fma = lambda a, b, c: (a.astype(f64) * b.astype(f64) + c.astype(f64)).astype(f32)
             tv = table[:, :n_u]
             lhs = fma(np.broadcast_to(uerr[:, 0][None, :], tv.shape), np.broadcast_to(A, tv.shape),
-                      fma(np.broadcast_to(uerr[:, 1][None, :], tv.shape), np.broadcast_to(B, tv.shape), tv + C))
+                      fma(np.broadcast_to(uerr[:, 1][None, :], tv.shape), np.broadcast_to(B, tv.shape),
+                          fma(np.broadcast_to(uerr[:, 3][None, :], tv.shape), np.broadcast_to(C, tv.shape), tv)))
             keep = ~(lhs < f[None, :])
         want_rows = int(((keep.sum(1) + 511) // 512 * 512).sum())
         for cap_rows in (want_rows + 1024, want_rows, want_rows - 512):          # roomy, exact fit, one workgroup short
@@ -340,7 +346,7 @@ def test_rows_collect_one_pass_keeps_the_same_pairs(ops):
         table = rng.standard_normal((n_sb, stride)).astype(np.float32)
         thr = rng.uniform(0.5, 2.5, n_u).astype(np.float32)
         thr[5] = -np.inf
-        uerr = rng.uniform(0.0, 0.3, (n_u, 3)).astype(np.float32)
+        uerr = rng.uniform(0.0, 0.3, (n_u, 4)).astype(np.float32)
         sbs = rng.uniform(0.0, 1.0, (n_sb, 4)).astype(np.float32)
         with np.errstate(invalid="ignore", over="ignore"):
             f32, f64 = np.float32, np.float64
@@ -358,7 +364,8 @@ def test_rows_collect_one_pass_keeps_the_same_pairs(ops):
             fma = lambda a, b, c: (a.astype(f64) * b.astype(f64) + c.astype(f64)).astype(f32)
             tv = table[:, :n_u]
             lhs = fma(np.broadcast_to(uerr[:, 0][None, :], tv.shape), np.broadcast_to(A, tv.shape),
-                      fma(np.broadcast_to(uerr[:, 1][None, :], tv.shape), np.broadcast_to(B, tv.shape), tv + C))
+                      fma(np.broadcast_to(uerr[:, 1][None, :], tv.shape), np.broadcast_to(B, tv.shape),
+                          fma(np.broadcast_to(uerr[:, 3][None, :], tv.shape), np.broadcast_to(C, tv.shape), tv)))
             keep = ~(lhs < f[None, :])
         row_count = torch.zeros((n_sb,), dtype=torch.int32, device="cuda")
         row_user = torch.full((n_sb * rcap,), -7, dtype=torch.int32, device="cuda")
@@ -454,11 +461,11 @@ def test_rows_hot_lists_rows_over_capacity(ops):
     from tensorrec_amd import _native as N
     counts = np.array([5, 700, 512, 513, 0, 9000, 100, 513], dtype=np.int32)
     rcap, n_users = 512, 1000
-    for hot_cap, max_rows, over in ((8, 1 << 40, 0), (3, 1 << 40, 1), (8, 5000, 1)):
+    for hot_cap, max_pairs, over in ((8, 1 << 40, 0), (3, 1 << 40, 1), (8, 4616, 1), (8, 4617, 0)):
         rc = dev(counts.copy())
         hot = torch.full((hot_cap,), -7, dtype=torch.int32, device="cuda")
         status = torch.zeros((2,), dtype=torch.int64, device="cuda")
-        N.call("trec_topk_rows_hot", N.ptr(rc), len(counts), rcap, n_users, N.ptr(hot), hot_cap, max_rows, N.ptr(status))
+        N.call("trec_topk_rows_hot", N.ptr(rc), len(counts), rcap, n_users, N.ptr(hot), hot_cap, max_pairs, N.ptr(status))
         want = [1, 3, 5, 7]
         assert hot.cpu().tolist() == (want + [-1] * hot_cap)[:hot_cap]
         assert rc.cpu().tolist() == [5, 0, 512, 0, 0, 0, 100, 0]
