@@ -207,8 +207,9 @@ int trec_topk_select_blocks_ex(const float* blockmax, int32_t n_sb, int64_t n_us
  *     independent of each other).
  *   trec_topk_filter_finish: part_idx is the [n_users * ksel * 2, capacity] item-id lists of the grouped pass;
  *     users_f32 / items_f32 the fp32 operands (row strides ld_*, contraction length kdim); writes the exact top-k and
- *     flags users whose lists were full or who had more than 64 survivors.  Flagged users must be re-done on the exact
- *     path by the caller (ops.score_topk_filtered does). */
+ *     flags users whose lists were full or who had more than 64 survivors.  Flagged users must be re-done by the caller
+ *     (ops.score_topk_filtered: a wide second pass -- larger ksel, 16-entry lists, trec_topk_filter_finish_wide -- then the
+ *     exact fp32 MFMA path for what is left).  trec_topk_collect_blocks empties the slots of a user it flags (count 0). */
 int trec_score_prep_filter(const float* repr, int64_t n, int32_t d, int32_t kpad, int32_t normalize, const float* bias,
                            float* out_f32, void* out_bf16, float* row_stats, float* gstats, void* stream);
 /* ---- K2q / K2c: the int8 -> bf16 -> fp32 cascade of the exact top-k (csrc/score_blockmax_i8.hip, csrc/topk_cascade.hip;
@@ -309,6 +310,13 @@ int trec_topk_filter_finish(const int32_t* part_idx, int32_t capacity, int32_t k
                             int32_t kdim, const float* user_bias, const float* item_bias, int32_t item_index_base,
                             int64_t n_users, int32_t k, float* out_vals, int32_t* out_idx, int32_t* flag,
                             int32_t* n_flagged, void* stream);
+/* The same finish without capacity limits (any ksel, any number of survivors, k <= 16): the WIDE second pass over the users
+ * the first pass flagged (trec_topk_collect_blocks with a larger ksel, 16-entry stage-3 lists); flags only a full list. */
+int trec_topk_filter_finish_wide(const int32_t* part_idx, int32_t capacity, int32_t ksel, const int32_t* count,
+                                 const float* users_f32, const float* items_f32, int64_t ld_users, int64_t ld_items,
+                                 int32_t kdim, const float* user_bias, const float* item_bias, int32_t item_index_base,
+                                 int64_t n_users, int32_t k, float* out_vals, int32_t* out_idx, int32_t* flag,
+                                 int32_t* n_flagged, void* stream);
 
 /* k best of n_cand candidates per user, ordered (value desc, index asc) = tf.nn.top_k tie rule; also the merge
  * step after the all-gather of per-shard lists */

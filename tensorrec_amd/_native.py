@@ -76,6 +76,8 @@ SIGNATURES = {
     "trec_topk_collect_blocks": [_vp, _i32, _i64, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
     "trec_topk_filter_finish": [_vp, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _i32, _i64, _i32, _vp, _vp,
                                 _vp, _vp, _vp],
+    "trec_topk_filter_finish_wide": [_vp, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _i32, _i64, _i32, _vp, _vp,
+                                     _vp, _vp, _vp],
     "trec_topk_group_keys": [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp],
     "trec_topk_pad_counts": [_vp, _i32, _i32, _vp, _vp],
     "trec_exclusive_scan_i32": [_vp, _i64, _vp, _vp, _vp],

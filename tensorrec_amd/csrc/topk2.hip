@@ -190,9 +190,12 @@ __global__ __launch_bounds__(256) void collect_blocks_tiled_kernel(const float* 
         buf ^= 1;
     }
     if (ok) {
-        for (int32_t j = c; j < ksel; ++j) keys[u * ksel + j] = -1;
-        count[u] = c < ksel ? c : ksel;
-        if (c > ksel && flag[u] == 0) { flag[u] = 1; atomicAdd(n_flagged, 1); }
+        // a user with more qualifying superblocks than slots is flagged and re-done by the caller (a wider pass, then the exact
+        // path): nothing of its partial selection is used, so its slots are emptied and the later stages skip it
+        const bool over = c > ksel;
+        for (int32_t j = over ? 0 : c; j < ksel; ++j) keys[u * ksel + j] = -1;
+        count[u] = over ? 0 : c;
+        if (over && flag[u] == 0) { flag[u] = 1; atomicAdd(n_flagged, 1); }
     }
 }
 
@@ -383,7 +386,7 @@ extern "C" int trec_topk_collect_blocks(const float* blockmax, int32_t n_sb, int
                                         int32_t* n_flagged, void* stream)
 {
     TREC_REQUIRE(blockmax && floor_ && keys && count && flag && n_flagged, "trec_topk_collect_blocks: null pointer");
-    TREC_REQUIRE(ksel >= 1 && ksel <= 64 && n_sb >= 1 && stride >= n_users, "trec_topk_collect_blocks: need 1 <= ksel <= 64");
+    TREC_REQUIRE(ksel >= 1 && ksel <= 4096 && n_sb >= 1 && stride >= n_users, "trec_topk_collect_blocks: need 1 <= ksel <= 4096");
     if (n_users == 0) return TREC_OK;
     hipLaunchKernelGGL(collect_blocks_tiled_kernel, dim3((unsigned)ceil_div64(n_users, 256)), dim3(256), 0,
                        (hipStream_t)stream, blockmax, n_sb, n_users, stride, floor_, ksel, keys, count, flag, n_flagged);

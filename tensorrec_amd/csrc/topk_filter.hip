@@ -310,6 +310,131 @@ __global__ __launch_bounds__(256) void filter_finish_kernel(
     }
 }
 
+// The same finish without capacity limits, for the WIDE second pass over the users the first pass flagged (hundreds of kept
+// superblocks, hundreds of survivors: rows near a few dominant items early in training, near-duplicate catalogues).  One wave
+// per user streams through the id lists of its count[u] kept slots 64 entries at a time; survivors queue up in LDS and are
+// re-scored WIDE_NEW at a time (the exact k-ordered fmaf chain, 8 rows staged per round like filter_finish_kernel); after every
+// batch the running top-k (lanes 0..k-1) and the batch's keys (lanes 16..63) go through k rounds of a DPP wave maximum.
+// Only a FULL stage-3 list (it may have dropped an item above the floor) still flags the user.
+#define WIDE_NEW 48
+__global__ __launch_bounds__(256) void filter_finish_wide_kernel(
+    const int32_t* __restrict__ pi, int cap, int ksel, const int32_t* __restrict__ count, const float* __restrict__ U,
+    const float* __restrict__ V, int64_t ld_u, int64_t ld_v, int kdim, const float* __restrict__ user_bias,
+    const float* __restrict__ item_bias, int32_t item_index_base, int64_t n_users, int k, float* __restrict__ ov,
+    int32_t* __restrict__ oi, int32_t* __restrict__ flag, int32_t* __restrict__ n_flagged)
+{
+    extern __shared__ __attribute__((aligned(16))) char fsmem[];
+    const int wave = threadIdx.x >> 6;
+    const int64_t u = (int64_t)blockIdx.x * 4 + wave;
+    if (u >= n_users) return;
+    const int lane = lane_id();
+    const int kd4 = (kdim + 3) & ~3;
+    const int rstride = kd4 + 4;
+    int32_t* cand = (int32_t*)fsmem + wave * 128;                       // queue: at most 47 left over + 64 new ids
+    float* urow = (float*)(fsmem + 4 * 128 * 4) + (size_t)wave * kd4;
+    float* rows = (float*)(fsmem + 4 * 128 * 4) + (size_t)4 * kd4 + (size_t)wave * FILTER_RB * rstride;
+    const int chunks = kd4 >> 2;
+    const bool vec = ((ld_v & 3) == 0) && ((ld_u & 3) == 0);
+    int c_u = count[u];
+    if (c_u > ksel) c_u = ksel;
+    const int64_t base = u * (int64_t)ksel * 2 * cap;
+    const int n_ent = c_u * 2 * cap;                                    // the kept slots are the first count[u] ones
+    for (int ch = lane; ch < chunks; ch += 64) {
+        const float* src = U + u * ld_u + ch * 4;
+        f32x4 w;
+        if (vec) w = *(const f32x4*)src;
+        else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[e] = (ch * 4 + e < kdim) ? src[e] : 0.f;
+        }
+        *(f32x4*)(urow + ch * 4) = w;
+    }
+    const float bu = user_bias ? user_bias[u] : 0.f;
+    const unsigned long long EMPTY = merge_key(-INFINITY, 0x7fffffff);
+    unsigned long long best = EMPTY;                                    // lane t < k: the t-th best key so far
+    bool lossy = false;
+    int queued = 0;
+    __builtin_amdgcn_wave_barrier();
+    for (int e0 = 0; e0 < n_ent || queued > 0; e0 += 64) {
+        if (e0 < n_ent) {
+            const int j = e0 + lane;
+            const int32_t id = (j < n_ent) ? pi[base + j] : -1;
+            if (id >= 0 && (j % cap) == cap - 1) lossy = true;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(id >= 0);
+            if (id >= 0) cand[queued + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = id;
+            queued += __builtin_popcountll(m);
+            __builtin_amdgcn_wave_barrier();
+        }
+        const bool last = e0 + 64 >= n_ent;
+        while (queued >= WIDE_NEW || (last && queued > 0)) {
+            const int nb = queued < WIDE_NEW ? queued : WIDE_NEW;
+            unsigned long long mine = (lane < 16) ? best : EMPTY;      // lanes 16 .. 16 + nb - 1 take the batch's keys
+            for (int r0 = 0; r0 < nb; r0 += FILTER_RB) {
+                const int nr = (nb - r0 < FILTER_RB) ? nb - r0 : FILTER_RB;
+                for (int idx = lane; idx < nr * chunks; idx += 64) {
+                    const int r = idx / chunks, ch = idx - r * chunks;
+                    const float* src = V + (int64_t)(cand[r0 + r] - item_index_base) * ld_v + ch * 4;
+                    f32x4 w;
+                    if (vec) w = *(const f32x4*)src;
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) w[e] = (ch * 4 + e < kdim) ? src[e] : 0.f;
+                    }
+                    *(f32x4*)(rows + r * rstride + ch * 4) = w;
+                }
+                const int32_t item = (lane < nr) ? cand[r0 + lane] : item_index_base;
+                const float ibv = (item_bias && lane < nr) ? item_bias[item - item_index_base] : 0.f;
+                __builtin_amdgcn_wave_barrier();
+                unsigned long long key = EMPTY;
+                if (lane < nr) {
+                    const float* b = rows + lane * rstride;
+                    float acc = 0.0f;
+                    int kk = 0;
+                    for (; kk + 4 <= kdim; kk += 4) {
+                        const f32x4 a4 = *(const f32x4*)(urow + kk);
+                        const f32x4 b4 = *(const f32x4*)(b + kk);
+                        acc = __fmaf_rn(a4[0], b4[0], acc); acc = __fmaf_rn(a4[1], b4[1], acc);
+                        acc = __fmaf_rn(a4[2], b4[2], acc); acc = __fmaf_rn(a4[3], b4[3], acc);
+                    }
+                    for (; kk < kdim; ++kk) acc = __fmaf_rn(urow[kk], b[kk], acc);
+                    if (user_bias) acc = acc + bu;
+                    if (item_bias) acc = acc + ibv;
+                    key = merge_key(acc, item);
+                }
+                __builtin_amdgcn_wave_barrier();
+                {   // lane 16 + r0 + r takes over lane r's key
+                    const int srcl = (lane - 16 - r0) & 63;
+                    const unsigned int lo = (unsigned int)__shfl((int)(unsigned int)key, srcl, 64);
+                    const unsigned int hi = (unsigned int)__shfl((int)(unsigned int)(key >> 32), srcl, 64);
+                    if (lane >= 16 + r0 && lane < 16 + r0 + nr) mine = ((unsigned long long)hi << 32) | lo;
+                }
+            }
+            // the k best of (running top-k, this batch): keys are unique (an item sits in exactly one list)
+            unsigned long long nxt = EMPTY;
+            for (int t = 0; t < k; ++t) {
+                const unsigned long long b = wave_max_u64(mine);
+                if (mine == b && b != EMPTY) mine = EMPTY;
+                if (lane == t) nxt = b;
+            }
+            best = nxt;
+            // drop the batch from the queue
+            const int rest = queued - nb;
+            const int32_t tmp = (lane < rest) ? cand[nb + lane] : 0;
+            __builtin_amdgcn_wave_barrier();
+            if (lane < rest) cand[lane] = tmp;
+            __builtin_amdgcn_wave_barrier();
+            queued = rest;
+        }
+    }
+    if (__builtin_amdgcn_ballot_w64(lossy) != 0ull && lane == 0 && flag[u] == 0) { flag[u] = 1; atomicAdd(n_flagged, 1); }
+    if (lane < k) {
+        const unsigned int hi = (unsigned int)(best >> 32);
+        const unsigned int bits = (hi & 0x80000000u) ? (hi & 0x7fffffffu) : ~hi;
+        ov[u * k + lane] = (best == EMPTY) ? -INFINITY : __uint_as_float(bits);
+        oi[u * k + lane] = (best == EMPTY) ? -1 : (int32_t)(~(unsigned int)best);
+    }
+}
+
 extern "C" int trec_score_prep_filter(const float* repr, int64_t n, int32_t d, int32_t kpad, int32_t normalize,
                                       const float* bias, float* out_f32, void* out_bf16, float* row_stats, float* gstats,
                                       void* stream)
@@ -372,4 +497,27 @@ extern "C" int trec_topk_filter_finish(const int32_t* part_idx, int32_t capacity
     else { TREC_FF(32); }
 #undef TREC_FF
     return trec_check_launch("trec_topk_filter_finish");
+}
+
+// trec_topk_filter_finish without its capacity limits (any ksel, any number of survivors; k <= 16): the wide second pass over
+// the users the first pass flagged.  Same arguments; flags only users with a full stage-3 list.
+extern "C" int trec_topk_filter_finish_wide(const int32_t* part_idx, int32_t capacity, int32_t ksel, const int32_t* count,
+                                            const float* users_f32, const float* items_f32, int64_t ld_users, int64_t ld_items,
+                                            int32_t kdim, const float* user_bias, const float* item_bias,
+                                            int32_t item_index_base, int64_t n_users, int32_t k, float* out_vals,
+                                            int32_t* out_idx, int32_t* flag, int32_t* n_flagged, void* stream)
+{
+    TREC_REQUIRE(part_idx && count && users_f32 && items_f32 && out_vals && out_idx && flag && n_flagged,
+                 "trec_topk_filter_finish_wide: null pointer");
+    TREC_REQUIRE(ksel >= 1 && k >= 1 && k <= 16 && capacity >= 1, "trec_topk_filter_finish_wide: need k <= 16");
+    TREC_REQUIRE(kdim >= 1 && kdim <= 1024 && ld_users >= kdim && ld_items >= ((kdim + 3) & ~3),
+                 "trec_topk_filter_finish_wide: need kdim <= 1024 and item rows padded to a multiple of 4");
+    if (n_users == 0) return TREC_OK;
+    const int kd4 = (kdim + 3) & ~3;
+    const size_t lds = 4 * 128 * 4 + (size_t)4 * kd4 * 4 + (size_t)4 * FILTER_RB * (kd4 + 4) * 4;
+    (void)hipFuncSetAttribute((const void*)filter_finish_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(filter_finish_wide_kernel, dim3((unsigned)ceil_div64(n_users, 4)), dim3(256), lds, (hipStream_t)stream,
+                       part_idx, capacity, ksel, count, users_f32, items_f32, ld_users, ld_items, kdim, user_bias, item_bias,
+                       item_index_base, n_users, k, out_vals, out_idx, flag, n_flagged);
+    return trec_check_launch("trec_topk_filter_finish_wide");
 }

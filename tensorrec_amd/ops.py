@@ -912,6 +912,7 @@ def score_topk_two_stage(users_op, items_op, dtype, kpad, k, user_bias=None, ite
 # superblocks a user may keep (1M x 1M, d = 128, k = 10: 15.5 on average; 19 users of 1M need more than 32, none more than
 # 48 -- a user beyond the limit goes to the exact fp32 fallback, whose launch chain costs ~1.2 ms however few users)
 FILTER_KSEL = 48
+FILTER_KSEL_WIDE = 320     # ... in the wide second pass over the flagged users (its finish kernel has no survivor limit)
 LAST_FILTER_STATS = {}    # diagnostics of the most recent score_topk_filtered call (bench.py reports them)
 FILTER_DEBUG = None       # diagnostics only: set to a dict to collect per-stage counters (each costs a host sync)
 
@@ -1171,6 +1172,86 @@ def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, 
     return table, stride, status
 
 
+def _filter_tail(uop, iop, blockmax, bm_stride, n_u, n_sb, k, user_bias, item_bias, item_index_base, sb_rows, variant, ksel,
+                 cap, floor, flag, n_flagged, rows_wg, wide=False):
+    """Stages 2b-4 of the filtered top-k on a table of superblock maxima: every superblock reaching the user's floor
+    (at most ``ksel``), grouped bf16 re-scoring with ``cap``-entry lists, exact fp32 finish.  ``wide``: the second pass over
+    the users the first one flagged -- the finish kernel without capacity limits."""
+    dev = uop.bf16.device
+    n_i, kpad = iop.n, uop.kpad
+    n_pairs = n_u * ksel
+    keys = torch.empty((n_pairs,), dtype=torch.int32, device=dev)
+    count = torch.empty((n_u,), dtype=torch.int32, device=dev)
+    with _timed("topk_collect_blocks"):
+        N.call("trec_topk_collect_blocks", N.ptr(blockmax), n_sb, n_u, bm_stride, N.ptr(floor), ksel, N.ptr(keys),
+               N.ptr(count), N.ptr(flag), N.ptr(n_flagged))
+    if FILTER_DEBUG is not None and not wide:
+        FILTER_DEBUG["flagged_after_collect"] = int(n_flagged.item())
+        _debug_counts("kept_superblocks", count)
+        true_cnt = torch.zeros((n_u,), dtype=torch.int32, device=dev)       # without the ksel cap
+        for s0 in range(0, n_sb, 64):
+            true_cnt += (blockmax[s0:s0 + 64, :n_u] >= floor[None, :]).sum(0, dtype=torch.int32)
+        _debug_counts("kept_superblocks_uncapped", true_cnt)
+    # ---- stage 3a: group the kept (user, slot) pairs by superblock, pad groups to whole workgroups, gather bf16 rows
+    indptr_t, users_t, perm_t = group_pairs_by_item(None, keys, ksel, n_sb + 1)
+    cnt_pad = torch.empty((n_sb + 1,), dtype=torch.int32, device=dev)
+    N.call("trec_topk_pad_counts", N.ptr(indptr_t), n_sb, rows_wg, N.ptr(cnt_pad))
+    pstart = torch.empty((n_sb + 2,), dtype=torch.int64, device=dev)
+    ws64 = torch.empty(((n_sb + 1 + 1023) // 1024 + 1,), dtype=torch.int64, device=dev)
+    N.call("trec_exclusive_scan_i32", N.ptr(cnt_pad), n_sb + 1, N.ptr(ws64), N.ptr(pstart))
+    max_rows = (n_pairs + min(n_sb, n_pairs) * (rows_wg - 1) + rows_wg - 1) // rows_wg * rows_wg
+    row_user = torch.empty((max_rows,), dtype=torch.int32, device=dev)
+    row_pair = torch.empty((max_rows,), dtype=torch.int32, device=dev)
+    rblock_chunk = torch.empty((max_rows // rows_wg,), dtype=torch.int32, device=dev)
+    with _timed("topk_fill_groups"):
+        N.call("trec_topk_fill_groups_index", N.ptr(pstart), N.ptr(indptr_t), N.ptr(users_t), N.ptr(perm_t), n_sb, rows_wg,
+               max_rows, N.ptr(row_user), N.ptr(row_pair), N.ptr(rblock_chunk))
+    # ---- stage 3b: bf16 re-scoring of the kept superblocks, every item >= floor listed (independent lists: bit 4);
+    # the user rows / biases / floors are fetched through row_user, only item ids are written
+    pi = torch.empty((n_pairs * 2, cap), dtype=torch.int32, device=dev)        # only the kept pairs' lists are touched
+    with _timed("score_gemm_topk_grouped"):
+        N.call("trec_score_gemm_topk_grouped", N.ptr(uop.bf16), N.ptr(iop.bf16), DTYPE_BF16, kpad, max_rows, n_i,
+               item_index_base, N.ptr(user_bias), N.ptr(item_bias), MODE_DOT, None, None, sb_rows, N.ptr(rblock_chunk),
+               N.ptr(row_pair), N.ptr(floor), cap, None, N.ptr(pi), (variant & 1) | 16, N.ptr(row_user))
+    # ---- stage 4: exact fp32 scores of the survivors, exact top-k
+    ov = torch.empty((n_u, int(k)), dtype=torch.float32, device=dev)
+    oi = torch.empty((n_u, int(k)), dtype=torch.int32, device=dev)
+    with _timed("topk_filter_finish"):
+        N.call("trec_topk_filter_finish_wide" if wide else "trec_topk_filter_finish", N.ptr(pi), cap, ksel, N.ptr(count),
+               N.ptr(uop.f32), N.ptr(iop.f32), kpad, kpad, uop.d, N.ptr(user_bias), N.ptr(item_bias), item_index_base, n_u,
+               int(k), N.ptr(ov), N.ptr(oi), N.ptr(flag), N.ptr(n_flagged))
+    return ov, oi, count
+
+
+WIDE_PASS_USERS = 131072   # flagged users per launch chain of the wide pass (bounds its list workspace: 5.4 GB at 320 slots)
+
+
+def _wide_second_pass(uop, iop, blockmax, bad, n_sb, k, user_bias, item_bias, item_index_base, sb_rows, variant, floor, rows_wg):
+    """The users the first pass could not certify (more than FILTER_KSEL kept superblocks, more than 64 survivors, a full
+    8-entry list) again, on THEIR columns of the table that already exists: FILTER_KSEL_WIDE slots, 16-entry lists, a finish
+    without survivor limit.  Returns (values, ids, flag) for the rows ``bad``; what is still flagged goes to the exact path."""
+    dev = uop.bf16.device
+    ksel_w = max(int(k), min(FILTER_KSEL_WIDE, n_sb))
+    out_v, out_i, out_f = [], [], []
+    with _timed("topk_filter_wide_pass"):
+        for s0 in range(0, int(bad.numel()), WIDE_PASS_USERS):
+            b = bad[s0:s0 + WIDE_PASS_USERS]
+            n_b = int(b.numel())
+            sub = FilterOperand()
+            sub.n, sub.d, sub.kpad = n_b, uop.d, uop.kpad
+            sub.bf16 = uop.bf16.index_select(0, b)
+            sub.f32 = uop.f32.index_select(0, b)
+            table_b = blockmax.index_select(1, b)
+            ub = user_bias.index_select(0, b) if user_bias is not None else None
+            flag_b = torch.zeros((n_b,), dtype=torch.int32, device=dev)
+            n_flagged_b = torch.zeros((1,), dtype=torch.int32, device=dev)
+            wv, wi, _ = _filter_tail(sub, iop, table_b, n_b, n_b, n_sb, k, ub, item_bias, item_index_base, sb_rows, variant,
+                                     ksel_w, 16, floor.index_select(0, b), flag_b, n_flagged_b, rows_wg, wide=True)
+            out_v.append(wv); out_i.append(wi); out_f.append(flag_b)
+            del table_b, sub
+    return torch.cat(out_v), torch.cat(out_i), torch.cat(out_f)
+
+
 def score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index_base=0, sb_rows=None, variant=1,
                         n_chunks=None, floor_exchange=None, stats_exchange=None, ksel=None, prefilter=None):
     """See _score_topk_filtered.  A user operand sorted by int8 scale class (``uop.perm``) is handled here: the user biases
@@ -1255,50 +1336,9 @@ def _score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index
            N.ptr(floor), N.ptr(flag), N.ptr(n_flagged))
     if FILTER_DEBUG is not None:
         FILTER_DEBUG["flagged_after_floor"] = int(n_flagged.item())
-    n_pairs = n_u * ksel
-    keys = torch.empty((n_pairs,), dtype=torch.int32, device=dev)
-    count = torch.empty((n_u,), dtype=torch.int32, device=dev)
-    with _timed("topk_collect_blocks"):
-        N.call("trec_topk_collect_blocks", N.ptr(blockmax), n_sb, n_u, bm_stride, N.ptr(floor), ksel, N.ptr(keys),
-               N.ptr(count), N.ptr(flag), N.ptr(n_flagged))
-    if FILTER_DEBUG is not None:
-        FILTER_DEBUG["flagged_after_collect"] = int(n_flagged.item())
-        _debug_counts("kept_superblocks", count)
-        true_cnt = torch.zeros((n_u,), dtype=torch.int32, device=dev)       # without the ksel cap
-        for s0 in range(0, n_sb, 64):
-            true_cnt += (blockmax[s0:s0 + 64, :n_u] >= floor[None, :]).sum(0, dtype=torch.int32)
-        _debug_counts("kept_superblocks_uncapped", true_cnt)
-    del blockmax
-    # ---- stage 3a: group the kept (user, slot) pairs by superblock, pad groups to whole workgroups, gather bf16 rows
-    indptr_t, users_t, perm_t = group_pairs_by_item(None, keys, ksel, n_sb + 1)
-    cnt_pad = torch.empty((n_sb + 1,), dtype=torch.int32, device=dev)
-    N.call("trec_topk_pad_counts", N.ptr(indptr_t), n_sb, rows_wg, N.ptr(cnt_pad))
-    pstart = torch.empty((n_sb + 2,), dtype=torch.int64, device=dev)
-    ws64 = torch.empty(((n_sb + 1 + 1023) // 1024 + 1,), dtype=torch.int64, device=dev)
-    N.call("trec_exclusive_scan_i32", N.ptr(cnt_pad), n_sb + 1, N.ptr(ws64), N.ptr(pstart))
-    max_rows = (n_pairs + min(n_sb, n_pairs) * (rows_wg - 1) + rows_wg - 1) // rows_wg * rows_wg
-    row_user = torch.empty((max_rows,), dtype=torch.int32, device=dev)
-    row_pair = torch.empty((max_rows,), dtype=torch.int32, device=dev)
-    rblock_chunk = torch.empty((max_rows // rows_wg,), dtype=torch.int32, device=dev)
-    with _timed("topk_fill_groups"):
-        N.call("trec_topk_fill_groups_index", N.ptr(pstart), N.ptr(indptr_t), N.ptr(users_t), N.ptr(perm_t), n_sb, rows_wg,
-               max_rows, N.ptr(row_user), N.ptr(row_pair), N.ptr(rblock_chunk))
-    # ---- stage 3b: bf16 re-scoring of the kept superblocks, every item >= floor listed (independent lists: bit 4);
-    # the user rows / biases / floors are fetched through row_user, only item ids are written
-    pi = torch.empty((n_pairs * 2, cap), dtype=torch.int32, device=dev)        # only the kept pairs' lists are touched
-    with _timed("score_gemm_topk_grouped"):
-        N.call("trec_score_gemm_topk_grouped", N.ptr(uop.bf16), N.ptr(iop.bf16), DTYPE_BF16, kpad, max_rows, n_i,
-               item_index_base, N.ptr(user_bias), N.ptr(item_bias), MODE_DOT, None, None, sb_rows, N.ptr(rblock_chunk),
-               N.ptr(row_pair), N.ptr(floor), cap, None, N.ptr(pi), (variant & 1) | 16, N.ptr(row_user))
-    # ---- stage 4: exact fp32 scores of the survivors, exact top-k
-    ov = torch.empty((n_u, int(k)), dtype=torch.float32, device=dev)
-    oi = torch.empty((n_u, int(k)), dtype=torch.int32, device=dev)
-    with _timed("topk_filter_finish"):
-        N.call("trec_topk_filter_finish", N.ptr(pi), cap, ksel, N.ptr(count), N.ptr(uop.f32), N.ptr(iop.f32), kpad, kpad,
-               uop.d, N.ptr(user_bias), N.ptr(item_bias), item_index_base, n_u, int(k), N.ptr(ov), N.ptr(oi), N.ptr(flag),
-               N.ptr(n_flagged))
-    del pi
-    # ---- users the filter could not certify: the exact fp32 MFMA path (one host read of a counter)
+    ov, oi, count = _filter_tail(uop, iop, blockmax, bm_stride, n_u, n_sb, k, user_bias, item_bias, item_index_base, sb_rows,
+                                 variant, ksel, cap, floor, flag, n_flagged, rows_wg, wide=False)
+    # ---- users the filter could not certify (one host read of a counter): a wide second pass, then the exact fp32 MFMA path
     n_bad = int(n_flagged.item())
     if cascade_status is not None:
         rows, overflow = cascade_status.tolist()
@@ -1306,6 +1346,7 @@ def _score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index
             overflow = float(stats_exchange(torch.tensor([float(overflow)], device=dev)).item())
         if overflow:
             # the int8 bound was too loose for this data: nothing was refined and the lists above mean nothing
+            del blockmax
             r = _score_topk_filtered(uop, iop, k, user_bias, item_bias, item_index_base, sb_rows, variant, n_chunks,
                                      floor_exchange, stats_exchange, ksel, None)
             LAST_FILTER_STATS["prefilter"] = "int8 (too loose: bf16 stage 1 instead)"
@@ -1320,6 +1361,15 @@ def _score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index
                               "kept_superblocks_per_user": float(count.sum().item()) / max(1, n_u)})
     if n_bad:
         bad = torch.nonzero(flag, as_tuple=False).reshape(-1)
+        if N.load().trec_get_tuning(b"topk_filter_wide_pass", 1) != 0 and n_sb > ksel:
+            wv, wi, wflag = _wide_second_pass(uop, iop, blockmax, bad, n_sb, k, user_bias, item_bias, item_index_base,
+                                              sb_rows, variant, floor, rows_wg)
+            ov[bad] = wv
+            oi[bad] = wi
+            bad = bad[wflag != 0]
+            LAST_FILTER_STATS["flagged_after_wide_pass"] = int(bad.numel())
+    del blockmax
+    if n_bad and bad.numel():
         ub = user_bias[bad].contiguous() if user_bias is not None else None
         with _timed("topk_filter_fallback"):
             fv, fi = score_topk(uop.f32[bad].contiguous(), iop.f32, DTYPE_F32, kpad, int(k), ub, item_bias, MODE_DOT,

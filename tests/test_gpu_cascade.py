@@ -151,8 +151,9 @@ def test_cascade_non_finite_rows_fall_back(ops):
     v = rng.standard_normal((n_i, d)).astype(np.float32)
     u[7, 3] = np.inf
     v[123, 5] = np.nan
-    vals, idx, stats, uop, iop = run_cascade(ops, u, v, k)
-    ev, ei = ops.score_topk(uop.f32, iop.f32, ops.DTYPE_F32, uop.kpad, k, method="two_stage")
+    vals, idx, stats, _, iop = run_cascade(ops, u, v, k)
+    uref = ops.score_prep_filter(dev(u))                                     # (the cascade's own user operand is sorted by class)
+    ev, ei = ops.score_topk(uref.f32, iop.f32, ops.DTYPE_F32, uref.kpad, k, method="two_stage")
     assert np.array_equal(idx, ei.cpu().numpy())
     assert np.array_equal(vals, ev.cpu().numpy(), equal_nan=True)
 

@@ -272,3 +272,29 @@ def test_k1_filter_epilogue_equals_gather_plus_prep(ops):
     va, ia = ops.score_topk_filtered(a_u, a_i, k, None, ib)
     vb, ib_ = ops.score_topk_filtered(b_u, b_i, k, None, ib)
     assert torch.equal(va, vb) and torch.equal(ia, ib_)
+
+
+def test_wide_second_pass_certifies_users_beyond_the_first_pass_capacities(ops):
+    """A few items with 12x the typical norm inflate the filter's bound (it uses the catalogue-wide maxima): most users keep
+    more than FILTER_KSEL = 48 superblocks and have more than 64 survivors -- what fitted models look like early in training.
+    The wide second pass (320 slots, 16-entry lists, a finish without survivor limit) certifies them on the table that already
+    exists; nobody reaches the fp32 MFMA fall-back, and the result is the oracle's."""
+    rng = np.random.default_rng(31)
+    n_u, n_i, d, k = 1500, 90_000, 128, 10
+    u = rng.standard_normal((n_u, d)).astype(np.float32)
+    v = rng.standard_normal((n_i, d)).astype(np.float32)
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    v[rng.permutation(n_i)[:25]] *= 12.0
+    v *= rng.uniform(0.97, 1.0, (n_i, 1)).astype(np.float32)
+    ub = (0.05 * rng.standard_normal(n_u)).astype(np.float32)
+    ib = (0.05 * rng.standard_normal(n_i)).astype(np.float32)
+    du, dv, dub, dib = dev(u), dev(v), dev(ub), dev(ib)
+    uop = ops.score_prep_filter(du)
+    iop = ops.score_prep_filter(dv, bias=dib, want_gstats=True)
+    vals, idx = ops.score_topk_filtered(uop, iop, k, dub, dib)
+    stats = dict(ops.LAST_FILTER_STATS)
+    rv, ri = O.topk_rows(O.score_dense_exact(u, v, ub, ib), k)
+    assert np.array_equal(idx.cpu().numpy(), ri) and np.array_equal(vals.cpu().numpy(), rv)
+    assert stats["flagged_users"] > n_u // 4, stats                  # the first pass gave up on many users ...
+    assert stats["flagged_after_wide_pass"] == 0, stats              # ... the wide pass certified all of them
