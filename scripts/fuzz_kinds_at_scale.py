@@ -12,6 +12,9 @@ KINDS = os.environ.get("KINDS", "gauss,normalised,heavy_tail,sparse,integers,clu
 CHECK = int(os.environ.get("CHECK", 1))
 OUT = os.environ.get("OUT", "gpurun_out/fuzz_kinds_at_scale.json")
 g = torch.Generator(device="cuda"); g.manual_seed(SEED)
+from tensorrec_amd import _native
+for kv in filter(None, os.environ.get("TUNE", "").split(",")):      # e.g. TUNE=cascade_rcap_pct=50,cascade_max_refined_pct=45
+    _native.set_tuning(kv.split("=")[0], int(kv.split("=")[1]))
 
 
 def make(kind, n, d):

@@ -913,6 +913,7 @@ def score_topk_two_stage(users_op, items_op, dtype, kpad, k, user_bias=None, ite
 # 48 -- a user beyond the limit goes to the exact fp32 fallback, whose launch chain costs ~1.2 ms however few users)
 FILTER_KSEL = 48
 FILTER_KSEL_WIDE = 320     # ... in the wide second pass over the flagged users (its finish kernel has no survivor limit)
+WIDE_TIER2_MAX_FRACTION = 0.05   # the all-superblocks tier runs only when at most this fraction of the users is still flagged
 LAST_FILTER_STATS = {}    # diagnostics of the most recent score_topk_filtered call (bench.py reports them)
 FILTER_DEBUG = None       # diagnostics only: set to a dict to collect per-stage counters (each costs a host sync)
 
@@ -1013,8 +1014,13 @@ def spmm_filter_operand(features, w, bias=None, want_gstats=False):
 
 I8_USER_CLIP_SIGMAS = 4.0        # user rows clip at 4 rms (a clipped user only widens ITS bound; measured at 1M x 1M: refined
                                  # pairs 139M at 5.0, 125M at 4.5, 114M at 4.0, 119M at 3.5); item rows never clip
-CASCADE_MAX_REFINED = 0.20       # refine at most this fraction of the (superblock, user) pairs; beyond it bf16 does it all
-CASCADE_MAX_HOT = 160           # superblocks that may be refined for every user (each costs 1 / n_sb of a dense bf16 pass)
+# refine at most this fraction of the (superblock, user) pairs; beyond it bf16 does it all.  Break-even: the int8 pass costs
+# ~0.53 of a dense bf16 pass and a refined pair ~1.5x a dense one (gathered rows), so the cascade wins below ~0.31 and still
+# beats "int8 pass wasted + dense bf16" up to ~0.67 (measured, 32,768 x 1M: 23.6% refined 9.3 ms vs 8.1 bf16-only vs 15.0 wasted)
+CASCADE_MAX_REFINED = 0.45
+CASCADE_ROW_CAPACITY = 0.50      # fixed capacity of a superblock's user list (fraction of the users); fuller rows are "hot":
+                                 # the dense kernel re-scores them for everybody at 1.5x the grouped kernel's rate
+CASCADE_MAX_HOT = 1 << 20        # superblocks that may be hot (no limit of its own: CASCADE_MAX_REFINED bounds the work)
 CASCADE_MIN_ITEMS = 262144       # below ~512 superblocks the k-th largest maximum is not selective enough for int8 to pay
 
 
@@ -1128,7 +1134,8 @@ def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, 
     status = torch.empty((2,), dtype=torch.int64, device=dev)
     if N.load().trec_get_tuning(b"cascade_rows_onepass", 1) != 0 and N.load().trec_get_tuning(b"blockmax_bf16_mfma16", 1) != 0:
         # one pass over the table: a fixed capacity per superblock, slots handed out by atomics (csrc/topk_cascade.hip)
-        rcap = (int(CASCADE_MAX_REFINED * n_u) + 511) // 512 * 512 + 512
+        rcap_frac = N.load().trec_get_tuning(b"cascade_rcap_pct", int(100 * CASCADE_ROW_CAPACITY)) / 100.0
+        rcap = (int(rcap_frac * n_u) + 511) // 512 * 512 + 512
         row_count = torch.zeros((n_sb,), dtype=torch.int32, device=dev)
         row_user = torch.empty((n_sb * rcap,), dtype=torch.int32, device=dev)      # only the kept pairs' part is touched
         with _timed("topk_rows_compact"):
@@ -1140,9 +1147,9 @@ def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, 
                                  "hot_superblocks": int((row_count > rcap).sum().item())})
         # "hot" superblocks -- kept by more users than rcap: the few rows that hold a skewed catalogue's most popular items --
         # are refined for EVERY user by a dense launch over that list; the fixed-capacity launch skips them
-        hot_cap = max(8, min(CASCADE_MAX_HOT, n_sb))
+        hot_cap = max(8, min(N.load().trec_get_tuning(b"cascade_max_hot", CASCADE_MAX_HOT), n_sb))
         hot_list = torch.empty((hot_cap,), dtype=torch.int32, device=dev)
-        max_pairs = int(CASCADE_MAX_REFINED * n_sb * n_u)
+        max_pairs = int(N.load().trec_get_tuning(b"cascade_max_refined_pct", int(100 * CASCADE_MAX_REFINED)) / 100.0 * n_sb * n_u)
         N.call("trec_topk_rows_hot", N.ptr(row_count), n_sb, rcap, n_u, N.ptr(hot_list), hot_cap, max_pairs, N.ptr(status))
         with _timed("score_gemm_blockmax_grouped"):
             N.call("trec_score_gemm_blockmax_grouped", N.ptr(uop.bf16), N.ptr(iop.bf16), kpad, n_sb * rcap, n_i,
@@ -1223,19 +1230,20 @@ def _filter_tail(uop, iop, blockmax, bm_stride, n_u, n_sb, k, user_bias, item_bi
     return ov, oi, count
 
 
-WIDE_PASS_USERS = 131072   # flagged users per launch chain of the wide pass (bounds its list workspace: 5.4 GB at 320 slots)
+WIDE_PASS_BYTES = 4 << 30     # list workspace of one launch chain of the wide pass (bounds the flagged users per chain)
 
 
-def _wide_second_pass(uop, iop, blockmax, bad, n_sb, k, user_bias, item_bias, item_index_base, sb_rows, variant, floor, rows_wg):
+def _wide_second_pass(uop, iop, blockmax, bad, n_sb, k, user_bias, item_bias, item_index_base, sb_rows, variant, floor, rows_wg,
+                      ksel_w):
     """The users the first pass could not certify (more than FILTER_KSEL kept superblocks, more than 64 survivors, a full
-    8-entry list) again, on THEIR columns of the table that already exists: FILTER_KSEL_WIDE slots, 16-entry lists, a finish
-    without survivor limit.  Returns (values, ids, flag) for the rows ``bad``; what is still flagged goes to the exact path."""
+    8-entry list) again, on THEIR columns of the table that already exists: ``ksel_w`` slots, 16-entry lists, a finish without
+    survivor limit.  Returns (values, ids, flag) for the rows ``bad``; what is still flagged goes to the next tier."""
     dev = uop.bf16.device
-    ksel_w = max(int(k), min(FILTER_KSEL_WIDE, n_sb))
+    per_chain = max(1024, WIDE_PASS_BYTES // (ksel_w * 2 * 16 * 4))
     out_v, out_i, out_f = [], [], []
     with _timed("topk_filter_wide_pass"):
-        for s0 in range(0, int(bad.numel()), WIDE_PASS_USERS):
-            b = bad[s0:s0 + WIDE_PASS_USERS]
+        for s0 in range(0, int(bad.numel()), per_chain):
+            b = bad[s0:s0 + per_chain]
             n_b = int(b.numel())
             sub = FilterOperand()
             sub.n, sub.d, sub.kpad = n_b, uop.d, uop.kpad
@@ -1362,12 +1370,18 @@ def _score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index
     if n_bad:
         bad = torch.nonzero(flag, as_tuple=False).reshape(-1)
         if N.load().trec_get_tuning(b"topk_filter_wide_pass", 1) != 0 and n_sb > ksel:
-            wv, wi, wflag = _wide_second_pass(uop, iop, blockmax, bad, n_sb, k, user_bias, item_bias, item_index_base,
-                                              sb_rows, variant, floor, rows_wg)
-            ov[bad] = wv
-            oi[bad] = wi
-            bad = bad[wflag != 0]
-            LAST_FILTER_STATS["flagged_after_wide_pass"] = int(bad.numel())
+            # tier 1: FILTER_KSEL_WIDE slots; tier 2, for the few users still over (and only if they are few: it re-scores ALL
+            # their superblocks that reach the floor): every superblock may be kept
+            for tier, ksel_w in enumerate((min(FILTER_KSEL_WIDE, n_sb), n_sb)):
+                if bad.numel() == 0 or (tier == 1 and (ksel_w <= FILTER_KSEL_WIDE or bad.numel() > WIDE_TIER2_MAX_FRACTION * n_u)):
+                    break
+                wv, wi, wflag = _wide_second_pass(uop, iop, blockmax, bad, n_sb, k, user_bias, item_bias, item_index_base,
+                                                  sb_rows, variant, floor, rows_wg, max(int(k), ksel_w))
+                ov[bad] = wv
+                oi[bad] = wi
+                bad = bad[wflag != 0]
+                LAST_FILTER_STATS["flagged_after_wide_pass" + ("" if tier == 0 else "_2")] = int(bad.numel())
+            LAST_FILTER_STATS["users_on_fp32_fallback"] = int(bad.numel())
     del blockmax
     if n_bad and bad.numel():
         ub = user_bias[bad].contiguous() if user_bias is not None else None

@@ -444,12 +444,15 @@ def test_cascade_hot_superblocks_of_a_popular_catalogue(ops):
     ub = (0.05 * rng.standard_normal(n_u)).astype(np.float32)
     ib = (0.05 * rng.standard_normal(n_i)).astype(np.float32)
     ib[pop] += 2.0
+    from tensorrec_amd import _native as N
     ops.FILTER_DEBUG = {}
+    N.set_tuning("cascade_rcap_pct", 10)                  # (2,100 users: a list capacity of 10% instead of 50% of them)
     try:
         vals, idx, stats, _, _ = run_cascade(ops, u, v, k, ub, ib)
         dbg = dict(ops.FILTER_DEBUG)
     finally:
         ops.FILTER_DEBUG = None
+        N.set_tuning("cascade_rcap_pct", int(100 * ops.CASCADE_ROW_CAPACITY))
     rv, ri = O.topk_rows(O.score_dense_exact(u, v, ub, ib), k)
     assert np.array_equal(idx, ri) and np.array_equal(vals, rv)
     assert stats["prefilter"] == "int8", stats            # the cascade ran: hot rows did not overflow it
