@@ -1097,11 +1097,12 @@ def blockmax_i8_chunks(n_items, n_chunks, sb_rows):
 
 def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, floor_exchange, stats_exchange):
     """Stages 0-1 of the int8 -> bf16 -> fp32 cascade (csrc/topk_cascade.hip): the [n_sb, n_users] table of superblock
-    maxima whose entries are bf16 maxima wherever a top-k item can be and int8 maxima elsewhere, its row stride, and the
-    device int64[2] ``status`` = {resident rows of the grouped launch, overflow}.  No host round trip: the grouped launch is
-    sized for CASCADE_MAX_REFINED of the pairs (workgroups beyond the kept pairs exit at once); when the int8 bound is too
-    loose for the data and more pairs reach the threshold, ``status[1]`` is set, nothing is refined, and the caller -- who
-    reads it when the pipeline has drained -- runs the dense bf16 stage 1 instead."""
+    maxima whose entries are bf16 maxima wherever a top-k item can be and int8 maxima elsewhere (None after an overflow), its
+    row stride, and (resident rows of the bf16 launches, overflow).  Every superblock has a list of CASCADE_ROW_CAPACITY of the
+    users (workgroups beyond the kept pairs exit at once); rows kept by more are "hot" and re-scored for everybody by a dense
+    launch.  When the int8 bound is too loose for the data -- more than CASCADE_MAX_REFINED of all pairs wanted -- nothing is
+    refined and the caller runs the dense bf16 stage 1 instead: the ONE host read of the call (two int64) happens right
+    after the compaction, before any bf16 launch."""
     dev = uop.bf16.device
     n_u, n_i, kpad = uop.n, iop.n, uop.kpad
     kk = int(k)
@@ -1151,6 +1152,14 @@ def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, 
         hot_list = torch.empty((hot_cap,), dtype=torch.int32, device=dev)
         max_pairs = int(N.load().trec_get_tuning(b"cascade_max_refined_pct", int(100 * CASCADE_MAX_REFINED)) / 100.0 * n_sb * n_u)
         N.call("trec_topk_rows_hot", N.ptr(row_count), n_sb, rcap, n_u, N.ptr(hot_list), hot_cap, max_pairs, N.ptr(status))
+        # the overflow flag is read HERE, before the bf16 launches: when the int8 bound is too loose, refining
+        # close to half of all pairs and then running the filter's tail on the result would only be thrown away.  One host
+        # read per call (the following launches are queued within the launch latency); item shards agree on it (MAX).
+        rows, overflow = status.tolist()
+        if stats_exchange is not None:
+            overflow = float(stats_exchange(torch.tensor([float(overflow)], device=dev)).item())
+        if overflow:
+            return None, stride, (int(rows), True)
         with _timed("score_gemm_blockmax_grouped"):
             N.call("trec_score_gemm_blockmax_grouped", N.ptr(uop.bf16), N.ptr(iop.bf16), kpad, n_sb * rcap, n_i,
                    N.ptr(user_bias), N.ptr(item_bias), sb_rows, N.ptr(row_count), N.ptr(row_user), N.ptr(table), stride,
@@ -1158,7 +1167,7 @@ def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, 
         with _timed("score_gemm_blockmax_hot"):
             N.call("trec_score_gemm_blockmax_hot", N.ptr(uop.bf16), N.ptr(iop.bf16), kpad, n_u, n_i, N.ptr(user_bias),
                    N.ptr(item_bias), sb_rows, N.ptr(hot_list), hot_cap, N.ptr(table), stride)
-        return table, stride, status
+        return table, stride, (int(rows), False)
     n_ublk = N.query("trec_topk_rows_user_blocks", n_u)
     block_off = torch.empty((n_sb * n_ublk,), dtype=torch.int32, device=dev)
     row_total = torch.empty((n_sb,), dtype=torch.int32, device=dev)
@@ -1176,7 +1185,10 @@ def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, 
     with _timed("score_gemm_blockmax_grouped"):
         N.call("trec_score_gemm_blockmax_grouped", N.ptr(uop.bf16), N.ptr(iop.bf16), kpad, cap_rows, n_i,
                N.ptr(user_bias), N.ptr(item_bias), sb_rows, N.ptr(rblock_chunk), N.ptr(row_user), N.ptr(table), stride, 0)
-    return table, stride, status
+    rows, overflow = status.tolist()                    # (the two-pass form: its fill pass and grouped launch idle after an overflow)
+    if stats_exchange is not None:
+        overflow = float(stats_exchange(torch.tensor([float(overflow)], device=dev)).item())
+    return (None if overflow else table), stride, (int(rows), bool(overflow))
 
 
 def _filter_tail(uop, iop, blockmax, bm_stride, n_u, n_sb, k, user_bias, item_bias, item_index_base, sb_rows, variant, ksel,
@@ -1313,6 +1325,18 @@ def _score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index
         # ---- stages 0 + 1: int8 maxima everywhere, bf16 maxima where a top-k item can be
         blockmax, bm_stride, cascade_status = _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks,
                                                               floor_exchange, stats_exchange)
+        rows, overflow = cascade_status
+        if overflow:
+            # the int8 bound was too loose for this data: nothing was refined.  bf16 does stage 1; the next user batches
+            # against this catalogue skip the attempt (item shards keep trying: every rank must take the same path and the
+            # flag is local)
+            r = _score_topk_filtered(uop, iop, k, user_bias, item_bias, item_index_base, sb_rows, variant, n_chunks,
+                                     floor_exchange, stats_exchange, ksel, None)
+            LAST_FILTER_STATS["prefilter"] = "int8 (too loose: bf16 stage 1 instead)"
+            LAST_FILTER_STATS["refined_rows"] = int(rows)
+            iop.cascade_too_loose = True
+            return r
+        cascade_rows = int(rows)
     elif prefilter not in (None, "int8"):
         raise ValueError("unknown prefilter %r" % (prefilter,))
     if blockmax is None:
@@ -1349,22 +1373,8 @@ def _score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index
     # ---- users the filter could not certify (one host read of a counter): a wide second pass, then the exact fp32 MFMA path
     n_bad = int(n_flagged.item())
     if cascade_status is not None:
-        rows, overflow = cascade_status.tolist()
-        if stats_exchange is not None:                  # item shards: every rank takes the same path (collectives inside)
-            overflow = float(stats_exchange(torch.tensor([float(overflow)], device=dev)).item())
-        if overflow:
-            # the int8 bound was too loose for this data: nothing was refined and the lists above mean nothing
-            del blockmax
-            r = _score_topk_filtered(uop, iop, k, user_bias, item_bias, item_index_base, sb_rows, variant, n_chunks,
-                                     floor_exchange, stats_exchange, ksel, None)
-            LAST_FILTER_STATS["prefilter"] = "int8 (too loose: bf16 stage 1 instead)"
-            LAST_FILTER_STATS["refined_rows"] = int(rows)
-            # the next user batches against this catalogue skip the attempt (item shards keep trying: every rank must take
-            # the same path and the flag is local)
-            iop.cascade_too_loose = True
-            return r
         LAST_FILTER_STATS["prefilter"] = "int8"
-        LAST_FILTER_STATS["refined_rows"] = int(rows)
+        LAST_FILTER_STATS["refined_rows"] = cascade_rows
     LAST_FILTER_STATS.update({"users": n_u, "flagged_users": n_bad, "ksel": ksel,
                               "kept_superblocks_per_user": float(count.sum().item()) / max(1, n_u)})
     if n_bad:
