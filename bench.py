@@ -59,6 +59,10 @@ def parse():
     ap.add_argument("--parity-users", type=int, default=4096, help="users checked against the oracle in exact mode")
     ap.add_argument("--no-fp32-mode", action="store_true", help="skip the all-fp32-MFMA record")
     ap.add_argument("--no-k1-multi", action="store_true", help="skip the multi-nnz K1 roofline")
+    ap.add_argument("--configs", default="all", choices=["all", "headline"],
+                    help="all (default): also the records of BASELINE.json configs[1], [3] (one rank's shard) and [4], the "
+                         "trained-weights record, parity_fit and the multi-nnz parity; headline: the 1M x 1M line only")
+    ap.add_argument("--trained-epochs", type=int, default=20, help="epochs of the fit behind the trained-weights record")
     ap.add_argument("--fused-k1", action="store_true",
                     help="K1 emits the filter's operands in its epilogue (trec_spmm_csr_filter) instead of a separate prep "
                          "pass: 0.1 ms per side less in total, but the gather kernel itself then runs at 0.49 of the HBM "
@@ -103,22 +107,22 @@ def cpu_baseline(n_items, d, k, n_users_sample, seed=0):
                       "d=%d, top-%d, %.1f s" % (n_users_sample, n_items, d, k, dt)}
 
 
-def cpu_baseline_fit(n_users_total, n_items, d, per_user=20, n_sampled=100, shard_sizes=(4096, 49152), seed=0):
+def cpu_baseline_fit(n_users_total, n_items, d, per_user=20, n_sampled=100, shard=49152, small_shard=4096,
+                     small_shard_seconds=None, seed=0):
     """CPU leg of the fit half of the metric: ONE optimiser step of the oracle's model (oracle/model.py -- the restated
-    _build_tf_graph + TF-form Adam, torch-CPU autograd, float32, all host cores) on user shards of the same 1M-item,
-    d = 128, WMRB workload.  A step costs a + b * users (a: the item-side dense work -- 1M x 128 weights, their Adam
-    update; b: per-user pairs), so two shard sizes are timed and the full epoch (one step over ALL users, as on the GPU)
-    is a + b * n_users_total.  (The shards are 12x apart: with 2,048 / 8,192 users the slope was the difference of two
-    ~22 s measurements 0.2-0.9 s apart and the extrapolation moved between 46 s and 130 s from run to run.)"""
+    _build_tf_graph + TF-form Adam, torch-CPU autograd, float32, all host cores) on a user shard of the same 1M-item, d = 128,
+    WMRB workload.  Reported: the MEASURED rate of a 49,152-user shard, timed twice (both times given -- round 2's driver run
+    moved 2-3x between runs), and, separately and labelled as such, the extrapolation to one step over all users: a step costs
+    a + b * users (a: the item-side dense work -- 1M x 128 weights, their Adam update), a and b from the 4,096-user step
+    that parity_fit times anyway and the faster of the two large-shard times."""
     import scipy.sparse as sp
     import torch
-    from oracle import oracle as O
     from oracle.model import OracleTensorRec
     cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
     itf = sp.identity(n_items, dtype=np.float32, format="csr")
-    times = []
-    for n_u in (64,) + tuple(shard_sizes):                # the first, tiny step pays the one-time costs and is dropped
+
+    def one(n_u):
         rng = np.random.default_rng(seed)
         cols = rng.integers(0, n_items, size=(n_u, per_user), dtype=np.int64)
         inter = sp.csr_matrix((np.ones(n_u * per_user, np.float32), cols.reshape(-1),
@@ -130,17 +134,26 @@ def cpu_baseline_fit(n_users_total, n_items, d, per_user=20, n_sampled=100, shar
         samples = rng.integers(0, n_items, size=(n_u, n_sampled), dtype=np.int64)   # (cost only: distinctness is irrelevant)
         t0 = time.perf_counter()
         model.step(inter, uf, itf, 0.1, 1e-5, samples)
-        times.append(time.perf_counter() - t0)
-        del model
-    (u1, u2), (t1, t2) = shard_sizes, times[1:]
-    b = max(0.0, (t2 - t1) / float(u2 - u1))
-    a = max(0.0, t1 - b * u1)
+        return time.perf_counter() - t0
+    if small_shard_seconds is None:
+        one(64)                                           # the first, tiny step pays the one-time costs and is dropped
+        small_shard_seconds = one(small_shard)
+    big = [one(shard), one(shard)]
+    t2 = min(big)
+    b = max(0.0, (t2 - small_shard_seconds) / float(shard - small_shard))
+    a = max(0.0, small_shard_seconds - b * small_shard)
     epoch = a + b * n_users_total
     return {"value": 1.0 / epoch, "unit": "epochs/s", "cores": cores, "kind": "port",
-            "sample": "oracle/model.py (torch-CPU autograd + NumPy TF-form Adam, fp32): one optimiser step on %d and %d users "
-                      "x %d items, d=%d, WMRB, %d interactions + %d samples per user: %.2f s and %.2f s -> step = %.2f s + "
-                      "%.3g s/user, extrapolated to one step over %d users = %.1f s"
-                      % (u1, u2, n_items, d, per_user, n_sampled, t1, t2, a, b, n_users_total, epoch)}
+            "measured_shard": {"users": shard, "seconds": big, "users_per_second": shard / t2,
+                               "epoch_if_users_ran_in_shards_of_this_size_s": t2 * n_users_total / float(shard)},
+            "extrapolation": {"small_shard_users": small_shard, "small_shard_seconds": small_shard_seconds, "fixed_s": a,
+                              "per_user_s": b, "one_step_over_all_users_s": epoch,
+                              "label": "EXTRAPOLATED (two measured points, a + b * users); `value` = 1 / this"},
+            "sample": "oracle/model.py (torch-CPU autograd + NumPy TF-form Adam, fp32): one optimiser step on %d users (%.1f s) and "
+                      "twice on %d users (%.1f / %.1f s) x %d items, d=%d, WMRB, %d interactions + %d samples per user -> step = "
+                      "%.2f s + %.3g s/user, extrapolated to one step over %d users = %.1f s"
+                      % (small_shard, small_shard_seconds, shard, big[0], big[1], n_items, d, per_user, n_sampled, a, b,
+                         n_users_total, epoch)}
 
 
 def fit_epochs_per_sec(n_users, n_items, d, per_user=20, n_sampled=100, epochs=3, rank=0, world=1):
@@ -284,8 +297,10 @@ def main():
     w_i = torch.randn((I, d), device=device, generator=w_i_full_seeded)[i_begin:i_end].contiguous()
     w_u = ops.l2_normalize_rows(w_u)
     w_i = ops.l2_normalize_rows(w_i)
-    beta_u = torch.zeros((U, 1), device=device)
-    beta_i = torch.zeros((n_local, 1), device=device)
+    # per-feature biases: small and NON-zero (a freshly initialised model has zeros, any fitted one does not: the integer
+    # item-bias path of the int8 stage and the (s + b_u) + b_i order are on the timed path and in the parity check)
+    beta_u = 0.05 * torch.randn((U, 1), device=device, generator=gen)
+    beta_i = (0.05 * torch.randn((I, 1), device=device, generator=w_i_full_seeded))[i_begin:i_end].contiguous()
     f_u = SparseFeatures(sp.identity(U, dtype=np.float32, format="csr"), device)
     f_i = SparseFeatures(sp.identity(n_local, dtype=np.float32, format="csr"), device)   # this rank's item rows
     kpad = ops.score_kpad(d)
@@ -309,53 +324,57 @@ def main():
 
     prefilter = "int8" if exact and args.prefilter == "int8" and kpad in (64, 128) else None
 
-    def step():
-        with torch.no_grad():
-            if exact and method == "two_stage" and d in (32, 64, 128, 256) and args.fused_k1:
-                # K1 emits the filter's operands itself (fp32 representation + bf16 image + error norms): no prep pass
+    def make_step(w_u, w_i, beta_u, beta_i):
+        def step():
+            with torch.no_grad():
+                if exact and method == "two_stage" and d in (32, 64, 128, 256) and args.fused_k1:
+                    # K1 emits the filter's operands itself (fp32 representation + bf16 image + error norms): no prep pass
+                    ub = None if args.unbiased else ops.sparse_matvec(f_u, beta_u)
+                    ib = None if args.unbiased else ops.sparse_matvec(f_i, beta_i)
+                    u_f = ops.spmm_filter_operand(f_u, w_u)
+                    i_f = ops.spmm_filter_operand(f_i, w_i, bias=ib, want_gstats=True)
+                    vals, idx = ops.score_topk_filtered(
+                        u_f, i_f, k, ub, ib, item_index_base=i_begin, variant=args.variant,
+                        n_chunks=args.chunks if args.chunks > 0 else None,
+                        floor_exchange=floor_fn if world > 1 else None,
+                        stats_exchange=sharding.all_reduce_max if world > 1 else None, prefilter=prefilter)
+                    if world > 1:
+                        vals, idx = topk_fn(vals, idx, k)
+                    return vals, idx, u_f.f32, i_f.f32
+                user_repr = ops.spmm_raw(f_u.indptr, f_u.indices, f_u.values, None, U, f_u.nnz, w_u,          # K1
+                                         one_per_row=f_u.one_per_row)
+                item_repr = ops.spmm_raw(f_i.indptr, f_i.indices, f_i.values, None, n_local, f_i.nnz, w_i,    # K1
+                                         one_per_row=f_i.one_per_row)
                 ub = None if args.unbiased else ops.sparse_matvec(f_u, beta_u)
                 ib = None if args.unbiased else ops.sparse_matvec(f_i, beta_i)
-                u_f = ops.spmm_filter_operand(f_u, w_u)
-                i_f = ops.spmm_filter_operand(f_i, w_i, bias=ib, want_gstats=True)
-                vals, idx = ops.score_topk_filtered(
-                    u_f, i_f, k, ub, ib, item_index_base=i_begin, variant=args.variant,
-                    n_chunks=args.chunks if args.chunks > 0 else None,
-                    floor_exchange=floor_fn if world > 1 else None,
-                    stats_exchange=sharding.all_reduce_max if world > 1 else None, prefilter=prefilter)
+                if exact and method == "two_stage":
+                    # fp32-exact top-k: bf16 MFMA stage 1 as an error-bounded filter, survivors re-scored in fp32
+                    u_f = ops.score_prep_filter(user_repr, sort_users=prefilter == "int8")     # users sorted by int8 scale class
+                    i_f = ops.score_prep_filter(item_repr, bias=ib, want_gstats=True)
+                    vals, idx = ops.score_topk_filtered(
+                        u_f, i_f, k, ub, ib, item_index_base=i_begin, variant=args.variant,
+                        n_chunks=args.chunks if args.chunks > 0 else None,
+                        floor_exchange=floor_fn if world > 1 else None,
+                        stats_exchange=sharding.all_reduce_max if world > 1 else None, prefilter=prefilter)
+                    if world > 1:
+                        vals, idx = topk_fn(vals, idx, k)              # every rank finalises ITS users (all-to-all + merge)
+                    return vals, idx, user_repr, item_repr
+                u_op, _, _ = ops.score_prep(user_repr, dtype)
+                i_op, _, _ = ops.score_prep(item_repr, dtype)
+                if method == "direct":
+                    vals, idx = ops.score_topk_direct(u_op, i_op, dtype, kpad, k, ub, ib, item_index_base=i_begin,
+                                                      n_chunks=n_chunks, variant=args.variant, workspace=ws)  # K2 + merge
+                else:
+                    # item shards share ONE top-k floor per user (all-gather of k superblock maxima) before re-scoring
+                    vals, idx = ops.score_topk_two_stage(u_op, i_op, dtype, kpad, k, ub, ib, item_index_base=i_begin,
+                                                         variant=args.variant, n_chunks=args.chunks if args.chunks > 0 else None,
+                                                         floor_exchange=floor_fn if world > 1 else None)
                 if world > 1:
                     vals, idx = topk_fn(vals, idx, k)
-                return vals, idx, u_f.f32, i_f.f32
-            user_repr = ops.spmm_raw(f_u.indptr, f_u.indices, f_u.values, None, U, f_u.nnz, w_u,          # K1
-                                     one_per_row=f_u.one_per_row)
-            item_repr = ops.spmm_raw(f_i.indptr, f_i.indices, f_i.values, None, n_local, f_i.nnz, w_i,    # K1
-                                     one_per_row=f_i.one_per_row)
-            ub = None if args.unbiased else ops.sparse_matvec(f_u, beta_u)
-            ib = None if args.unbiased else ops.sparse_matvec(f_i, beta_i)
-            if exact and method == "two_stage":
-                # fp32-exact top-k: bf16 MFMA stage 1 as an error-bounded filter, survivors re-scored in fp32
-                u_f = ops.score_prep_filter(user_repr, sort_users=prefilter == "int8")     # users sorted by int8 scale class
-                i_f = ops.score_prep_filter(item_repr, bias=ib, want_gstats=True)
-                vals, idx = ops.score_topk_filtered(
-                    u_f, i_f, k, ub, ib, item_index_base=i_begin, variant=args.variant,
-                    n_chunks=args.chunks if args.chunks > 0 else None,
-                    floor_exchange=floor_fn if world > 1 else None,
-                    stats_exchange=sharding.all_reduce_max if world > 1 else None, prefilter=prefilter)
-                if world > 1:
-                    vals, idx = topk_fn(vals, idx, k)              # every rank finalises ITS users (all-to-all + merge)
                 return vals, idx, user_repr, item_repr
-            u_op, _, _ = ops.score_prep(user_repr, dtype)
-            i_op, _, _ = ops.score_prep(item_repr, dtype)
-            if method == "direct":
-                vals, idx = ops.score_topk_direct(u_op, i_op, dtype, kpad, k, ub, ib, item_index_base=i_begin,
-                                                  n_chunks=n_chunks, variant=args.variant, workspace=ws)  # K2 + merge
-            else:
-                # item shards share ONE top-k floor per user (all-gather of k superblock maxima) before re-scoring
-                vals, idx = ops.score_topk_two_stage(u_op, i_op, dtype, kpad, k, ub, ib, item_index_base=i_begin,
-                                                     variant=args.variant, n_chunks=args.chunks if args.chunks > 0 else None,
-                                                     floor_exchange=floor_fn if world > 1 else None)
-            if world > 1:
-                vals, idx = topk_fn(vals, idx, k)
-            return vals, idx, user_repr, item_repr
+        return step
+
+    step = make_step(w_u, w_i, beta_u, beta_i)
 
     def sync():
         if world > 1:
@@ -385,6 +404,10 @@ def main():
         pad[: item_repr_local.shape[0]] = item_repr_local
         full = sharding.all_gather_cat(pad, dim=0)[:I].contiguous()
         out = (vals, idx, user_repr, full)
+        padb = torch.zeros((per,), dtype=torch.float32, device=device)
+        if not args.unbiased:
+            padb[: n_local] = ops.sparse_matvec(f_i, beta_i).reshape(-1)
+        item_bias_full = sharding.all_gather_cat(padb, dim=0)[:I].contiguous()
     fit = None
     if not args.no_fit:
         try:                      # every rank takes part (data-parallel over users for world > 1)
@@ -472,7 +495,10 @@ def main():
             alg = f_m.nnz * (4 + 4) + (n_rows + 1) * 8 + float(f_m.nnz) * d * 4 + float(n_rows) * d * 4
             gbs = alg / (ms * 1e-3) / 1e9
             roofline_k1_multi = {"kernel": "spmm_csr_vec4_kernel, %d rows x %d non-zeros over %d feature columns, d=%d" % (n_rows, nnz_row, F, d),
-                                 "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                 "bound": "hbm+mall", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                 "bound_note": "about half of the 512 MB weight table is served by the 256 MB Infinity Cache (MALL): the "
+                                               "fabric-side counters include those hits, so this is NOT an HBM-only fraction (the HBM-only "
+                                               "copy ceiling of the guide is ~6.3 TB/s)",
                                  "traffic": None, "avg_launch_ms": ms, "algorithmic_bytes_per_launch": alg}
             import glob as _g, re as _re
             files = sorted(_g.glob(os.path.join(ROOT, "profiles", "*k1_multi_pmc*.txt")))
@@ -520,32 +546,33 @@ def main():
     parity = None
     try:
         from oracle import oracle as O
+        import bench_records as BR
         vals, idx, user_repr, item_repr = out
         n_sample = args.parity_users if exact else 32
         n_have = int(vals.shape[0])               # rank 0 holds all users (N = 1) or its own slice [0, n_have) (N > 1)
         sample = np.unique(np.linspace(0, n_have - 1, min(n_sample, n_have)).astype(np.int64))
         sample_dev = torch.from_numpy(sample).to(device)
-        it = item_repr.cpu().numpy()
         got_i = idx[sample_dev].cpu().numpy()
         got_v = vals[sample_dev].cpu().numpy()
-        us_all = user_repr[sample_dev].cpu().numpy()
-        ids_equal = vals_equal = True
-        overlap, max_rel = [], 0.0
-        t_par = time.perf_counter()
-        for s0 in range(0, len(sample), 512):                       # 512 x 1M fp32 scores = 2 GB per tile on the host
-            us = us_all[s0:s0 + 512]
-            ref = O.score_dense_exact(us, it)                        # fp32 k-ordered fmaf chain (tr_oracle.c), zero biases
-            rv, ri = O.topk_rows(ref, k)
-            gi, gv = got_i[s0:s0 + 512], got_v[s0:s0 + 512]
-            ids_equal = ids_equal and bool(np.array_equal(gi, ri))
-            vals_equal = vals_equal and bool(np.array_equal(gv, rv))
-            overlap += [len(set(a) & set(b)) / float(k) for a, b in zip(gi, ri)]
-            max_rel = max(max_rel, float(np.max(np.abs(gv - np.take_along_axis(ref, gi.astype(np.int64), 1)))
-                                         / np.abs(ref).max()))
-        parity = {"sample_users": int(len(sample)), "mode": args.precision,
-                  "topk_overlap_vs_fp32_oracle": float(np.mean(overlap)),
-                  "topk_ids_bit_exact_vs_oracle": ids_equal, "topk_values_bit_exact_vs_oracle": vals_equal,
-                  "max_rel_score_err": max_rel, "oracle_seconds": time.perf_counter() - t_par}
+        if world == 1 and not args.unbiased:
+            # the oracle starts from the WEIGHTS: its own SpMM (tr_oracle.c) over the feature rows of the sampled users and of
+            # every item, its own bias projection (non-zero biases), its fp32 score chain, its top-k
+            fs = BR._identity_rows(sample, U)
+            fi = sp.identity(I, dtype=np.float32, format="csr")
+            us_all = O.spmm_exact(fs, w_u.cpu().numpy())
+            it = O.spmm_exact(fi, w_i.cpu().numpy())
+            ub_h = O.spmm_exact(fs, beta_u.cpu().numpy()).reshape(-1)
+            ib_h = O.spmm_exact(fi, beta_i.cpu().numpy()).reshape(-1)
+            source = "oracle SpMM + bias projection from the weights (non-zero biases)"
+        else:
+            # item shards: rank 0 does not hold the other ranks' weights; the gathered representations feed the oracle
+            us_all, it = user_repr[sample_dev].cpu().numpy(), item_repr.cpu().numpy()
+            ub_h = None if args.unbiased else ops.sparse_matvec(f_u, beta_u)[sample_dev].cpu().numpy()
+            ib_h = None if args.unbiased else item_bias_full.cpu().numpy()
+            source = "gathered device representations and biases"
+        parity = BR.oracle_topk_parity(O, us_all, it, ub_h, ib_h, got_v, got_i, k)
+        parity["mode"] = args.precision
+        parity["oracle_inputs"] = source
         if exact:
             parity["filter"] = dict(ops.LAST_FILTER_STATS)
     except Exception as exc:      # the measurement stands on its own; report why the check could not run
@@ -559,12 +586,14 @@ def main():
             n32 = min(U, 65536)
             u32, _, _ = ops.score_prep(user_repr[:n32].contiguous(), ops.DTYPE_F32)
             i32, _, _ = ops.score_prep(item_repr, ops.DTYPE_F32)
-            ops.score_topk_two_stage(u32, i32, ops.DTYPE_F32, kpad, k)                    # warm-up
+            ub32 = None if args.unbiased else ops.sparse_matvec(f_u, beta_u)[:n32].contiguous()
+            ib32 = None if args.unbiased else ops.sparse_matvec(f_i, beta_i)
+            ops.score_topk_two_stage(u32, i32, ops.DTYPE_F32, kpad, k, ub32, ib32)        # warm-up
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             reps = 3
             for _ in range(reps):
-                ev, ei = ops.score_topk_two_stage(u32, i32, ops.DTYPE_F32, kpad, k)
+                ev, ei = ops.score_topk_two_stage(u32, i32, ops.DTYPE_F32, kpad, k, ub32, ib32)
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / reps
             fp32_mode = {"workload": "%d users x %d items, whole two-stage top-%d on fp32 MFMA" % (n32, n_local, k),
@@ -608,13 +637,66 @@ def main():
         except Exception as exc:
             ops.KERNEL_EVENTS = None
             bf16_mode = {"error": repr(exc)}
+    # north_star's own target kernel -- the DENSE bf16 MFMA score kernel -- as a roofline object of its own: time from the HIP
+    # events of the record above, HBM-side traffic from the committed rocprofv3 PMC passes of `bench.py --prefilter none`
+    roofline_bf16_dense = None
+    if bf16_mode is not None and "error" not in bf16_mode:
+        tf_ = bf16_mode["stage1_tflops"]
+        roofline_bf16_dense = {"kernel": "blockmax_bf16x16_kernel<128, true, false> (v_mfma_f32_16x16x32_bf16: dense bf16 superblock "
+                                         "maxima of every (user, item) pair -- stage 1 of the bf16 filter, north_star's score kernel)",
+                               "bound": "mfma", "achieved": tf_, "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": tf_ / BF16_DENSE_PEAK_TFLOPS, "traffic": None,
+                               "avg_launch_ms": bf16_mode["stage1_avg_launch_ms"], "algorithmic_flops_per_launch": k2_flops}
+        try:
+            import glob, re
+            files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bf16dense_pmc_summary.txt")))
+            if files and (U, I, d) == (1_000_000, 1_000_000, 128):
+                txt = open(files[-1]).read()
+                f_ = re.findall(r"blockmax_bf16x16_kernel<128, true, false>[^\n]*?FETCH_SIZE=([0-9.e+]+)", txt)
+                w_ = re.findall(r"blockmax_bf16x16_kernel<128, true, false>[^\n]*?WRITE_SIZE=([0-9.e+]+)", txt)
+                h_ = re.findall(r"blockmax_bf16x16_kernel<128, true, false>[^\n]*?TCC_HIT=([0-9.e+]+)", txt)
+                m_ = re.findall(r"blockmax_bf16x16_kernel<128, true, false>[^\n]*?TCC_MISS=([0-9.e+]+)", txt)
+                if f_ and w_:
+                    roofline_bf16_dense["traffic"] = (2.0 * float(f_[0]) + float(w_[0])) * 1024.0
+                    roofline_bf16_dense["traffic_note"] = ("(2*FETCH_SIZE + WRITE_SIZE) KB per launch from %s; algorithmic minimum "
+                                                           "%.3g bytes (bf16 operands once + the [n_sb, U] table)"
+                                                           % (os.path.basename(files[-1]), (U + n_local) * kpad * 2.0 + U * 4.0 * (n_local // 512)))
+                if h_ and m_:
+                    roofline_bf16_dense["l2_hit_rate"] = float(h_[0]) / (float(h_[0]) + float(m_[0]))
+        except Exception:
+            pass
+
+    # ---- further driver-visible records (rank 0, one GPU): fitted weights, fit parity, multi-nnz parity, the other configs
+    trained = parity_fit = parity_multi = configs = None
+    oracle_small_shard_s = None
+    if world == 1 and args.configs == "all" and exact:
+        import bench_records as BR
+        try:
+            trained = BR.trained_weights_record(make_step, device, U, I, d, k, steps=max(2, min(args.steps, 3)),
+                                                epochs=args.trained_epochs)
+        except Exception as exc:
+            trained = {"error": repr(exc)}
+        torch.cuda.empty_cache()
+        try:
+            vals, idx, user_repr, item_repr = out
+            parity_multi = BR.parity_multi_nnz_record(device, item_repr, None if args.unbiased else ops.sparse_matvec(f_i, beta_i),
+                                                      d, k)
+        except Exception as exc:
+            parity_multi = {"error": repr(exc)}
+        if not args.no_cpu_baseline:
+            try:
+                parity_fit, oracle_small_shard_s = BR.parity_fit_record(I, d)
+            except Exception as exc:
+                parity_fit = {"error": repr(exc)}
+        torch.cuda.empty_cache()
+        configs = BR.config_records(device)
 
     cpu = cpu_fit = None
     if not args.no_cpu_baseline and world == 1:
         cpu = cpu_baseline(I, d, k, args.cpu_users)
         if fit is not None and "error" not in fit:
             try:
-                cpu_fit = cpu_baseline_fit(U, I, d)
+                cpu_fit = cpu_baseline_fit(U, I, d, small_shard_seconds=oracle_small_shard_s)
             except Exception as exc:
                 cpu_fit = {"error": repr(exc)}
 
@@ -641,7 +723,8 @@ def main():
                    "topk_method": method,
                    "score_kernel_variant": "global_load_lds" if args.variant & 1 else "register-staged"},
         "roofline": roofline, "roofline_bf16_stage": roofline_bf16_stage, "roofline_k1": roofline_k1, "roofline_k1_multi_nnz": roofline_k1_multi, "cpu_baseline": cpu, "parity": parity,
-        "fp32_mfma_mode": fp32_mode, "bf16_filter_mode": bf16_mode, "fit": fit,
+        "fp32_mfma_mode": fp32_mode, "bf16_filter_mode": bf16_mode, "roofline_bf16_dense": roofline_bf16_dense,
+        "trained_weights_mode": trained, "parity_fit": parity_fit, "parity_multi_nnz": parity_multi, "configs": configs, "fit": fit,
         "roofline_fit": (fit or {}).get("roofline_fit"), "cpu_baseline_fit": cpu_fit,
     }
     print(json.dumps(line))

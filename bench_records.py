@@ -1,0 +1,467 @@
+"""Extra records of the bench line (bench.py imports this; nothing here is timed into ``value``).
+
+  trained_weights_record   the same exact top-10 step on FITTED weights: a WMRB model fitted for N epochs on planted-cluster,
+                           Zipf-popular interactions at the bench shape -- ms/step, which stage 1 ran, refined fraction, flagged
+                           users, bit-equality with the oracle on sampled users (VERDICT r2 #1a)
+  parity_fit_record        one optimiser step of a 4,096-user x 1M-item WMRB shard against oracle/model.py: loss vector, raw
+                           gradients, post-step weights -- the oracle step is the one cpu_baseline_fit times anyway (#2)
+  parity_multi_nnz_record  top-10 of users whose representation comes from 20-non-zero feature rows, the oracle doing its OWN
+                           SpMM and bias projection (#2)
+  config_records           BASELINE.json configs[1], [3] (one rank's shard) and [4]: ms, dominant kernel's roofline, sampled
+                           oracle parity (#5)
+
+The oracle (oracle/) is used as the checker / CPU baseline only."""
+import os
+import time
+
+import numpy as np
+import scipy.sparse as sp
+
+HBM_PEAK_GBS = 8000.0
+BF16_DENSE_PEAK_TFLOPS = 2500.0
+FP32_MFMA_PEAK_TFLOPS = 157.3
+
+
+def oracle_topk_parity(O, user_rows, item_rows, user_bias, item_bias, got_vals, got_idx, k, tile=512):
+    """Top-k of ``user_rows`` x ``item_rows`` (+ biases) by the oracle's fp32 k-ordered chain (tr_oracle.c) against the GPU's
+    lists.  Returns a dict with bit-equality of ids and values."""
+    ids_equal = vals_equal = True
+    overlap = []
+    t0 = time.perf_counter()
+    for s0 in range(0, user_rows.shape[0], tile):
+        ub = None if user_bias is None else user_bias[s0:s0 + tile]
+        ref = O.score_dense_exact(user_rows[s0:s0 + tile], item_rows, ub, item_bias)
+        rv, ri = O.topk_rows(ref, k)
+        gi, gv = got_idx[s0:s0 + tile], got_vals[s0:s0 + tile]
+        ids_equal = ids_equal and bool(np.array_equal(gi, ri))
+        vals_equal = vals_equal and bool(np.array_equal(gv, rv))
+        overlap += [len(set(a) & set(b)) / float(k) for a, b in zip(gi, ri)]
+    return {"sample_users": int(user_rows.shape[0]), "topk_ids_bit_exact_vs_oracle": ids_equal,
+            "topk_values_bit_exact_vs_oracle": vals_equal, "topk_overlap_vs_fp32_oracle": float(np.mean(overlap)),
+            "oracle_seconds": time.perf_counter() - t0}
+
+
+def _identity_rows(rows, n_cols):
+    rows = np.asarray(rows, dtype=np.int64)
+    return sp.csr_matrix((np.ones(len(rows), np.float32), rows.astype(np.int32), np.arange(len(rows) + 1, dtype=np.int64)),
+                         shape=(len(rows), n_cols))
+
+
+def trained_weights_record(make_step, device, U, I, d, k, steps=3, epochs=20, lr=0.1, n_sampled=100, n_clusters=256,
+                           per_user=20, parity_users=1024):
+    """Fit, then time the bench's own step on the fitted weights."""
+    import torch
+    import tensorrec_amd as T
+    from tensorrec_amd import ops
+    from tensorrec_amd.synth import planted_cluster_interactions
+    from oracle import oracle as O
+    t0 = time.perf_counter()
+    inter, held, ucl, icl = planted_cluster_interactions(U, I, n_clusters, per_user, seed=0, holdout=0.05, device=device)
+    uf = sp.identity(U, dtype=np.float32, format="csr")
+    itf = sp.identity(I, dtype=np.float32, format="csr")
+    model = T.TensorRec(n_components=d, loss_graph=T.loss_graphs.WMRBLossGraph(), seed=0)
+    model.fit_partial(inter, uf, itf, epochs=1, learning_rate=lr, n_sampled_items=n_sampled)       # build + first step
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    model.fit_partial(inter, uf, itf, epochs=epochs - 1, learning_rate=lr, n_sampled_items=n_sampled)
+    torch.cuda.synchronize()
+    fit_s = time.perf_counter() - t1
+    w = model.get_weights()
+    del model
+    w_u_h, w_i_h = w["linear_weights_user_0"], w["linear_weights_item"]
+    b_u_h, b_i_h = w["user_feature_biases"].reshape(-1, 1), w["item_feature_biases"].reshape(-1, 1)
+    w_u, w_i = torch.from_numpy(w_u_h).to(device), torch.from_numpy(w_i_h).to(device)
+    beta_u, beta_i = torch.from_numpy(b_u_h).to(device), torch.from_numpy(b_i_h).to(device)
+    step = make_step(w_u, w_i, beta_u, beta_i)
+    step()
+    torch.cuda.synchronize()
+    ops.KERNEL_EVENTS = []
+    t2 = time.perf_counter()
+    for _ in range(steps):
+        vals, idx, _, _ = step()
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t2) / steps
+    ev, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
+    dur = {}
+    for name, a, b in ev:
+        dur.setdefault(name, []).append(a.elapsed_time(b))
+    stats = dict(ops.LAST_FILTER_STATS)
+    n_sb = (I + ops.SUPERBLOCK_ROWS - 1) // ops.SUPERBLOCK_ROWS
+    rec = {"workload": "%d users x %d items, d=%d, Linear + DotProduct + WMRB (biased), fitted for %d epochs (lr %.3g, %d sampled "
+                       "items) on planted-cluster Zipf interactions (%d clusters, %d draws per user, %d interactions); then the "
+                       "bench's own exact top-%d step on THOSE weights" % (U, I, d, epochs, lr, n_sampled, n_clusters, per_user,
+                                                                          inter.nnz, k),
+           "fit_seconds": fit_s, "ms_per_step": ms, "predictions_per_s": float(U) * float(I) / (ms * 1e-3), "steps": steps,
+           "stage1": stats.get("prefilter", "bf16 (no int8 stage)"), "flagged_users_first_pass": stats.get("flagged_users"),
+           "flagged_after_wide_pass": stats.get("flagged_after_wide_pass", 0 if stats.get("flagged_users") == 0 else None),
+           "users_on_fp32_fallback": stats.get("users_on_fp32_fallback", 0),
+           "refined_fraction_of_pairs": (stats.get("refined_rows", 0) / float(U * n_sb)) if "refined_rows" in stats else None,
+           "kept_superblocks_per_user": stats.get("kept_superblocks_per_user"),
+           "kernels_avg_ms": {n: float(np.mean(v)) for n, v in dur.items()},
+           "weights": {"user_row_norm_q01_50_99_max": [float(v) for v in np.quantile(np.linalg.norm(w_u_h[::97], axis=1), [0.01, 0.5, 0.99, 1.0])],
+                       "item_row_norm_q01_50_99_max": [float(v) for v in np.quantile(np.linalg.norm(w_i_h[::97], axis=1), [0.01, 0.5, 0.99, 1.0])],
+                       "item_bias_q01_50_99_max": [float(v) for v in np.quantile(b_i_h[::97], [0.01, 0.5, 0.99, 1.0])]}}
+    # fitted at all?  held-out recall@k of the lists just computed, on 20,000 users with held-out positives
+    hu = np.unique(held.nonzero()[0])[:20000]
+    top = idx[torch.from_numpy(hu).to(device)].cpu().numpy()
+    hits = tot = 0
+    for row, u in zip(top, hu):
+        pos = held.indices[held.indptr[u]:held.indptr[u + 1]]
+        hits += len(set(row.tolist()) & set(pos.tolist()))
+        tot += len(pos)
+    rec["heldout_recall_at_%d" % k] = hits / max(1, tot)
+    rec["chance_recall"] = k / float(I)
+    # parity: the oracle from the WEIGHTS (its own SpMM / bias projection), sampled users x all items
+    sample = np.unique(np.linspace(0, U - 1, min(parity_users, U)).astype(np.int64))
+    fs = _identity_rows(sample, U)
+    ur = O.spmm_exact(fs, w_u_h)
+    ir = O.spmm_exact(itf, w_i_h)
+    ub = O.spmm_exact(fs, b_u_h).reshape(-1)
+    ib = O.spmm_exact(itf, b_i_h).reshape(-1)
+    sd = torch.from_numpy(sample).to(device)
+    rec["parity"] = oracle_topk_parity(O, ur, ir, ub, ib, vals[sd].cpu().numpy(), idx[sd].cpu().numpy(), k)
+    rec["total_seconds"] = time.perf_counter() - t0
+    return rec
+
+
+def parity_fit_record(n_items, d, n_users=4096, per_user=20, n_sampled=100, lr=0.1, alpha=1e-5, seed=0):
+    """ONE optimiser step of a WMRB shard (n_users x n_items, identity features, non-zero biases) on the GPU through the public
+    API (ReplaySampler with the oracle's samples) against oracle/model.py: serial predictions, loss vector (1e-4), raw
+    gradients (1e-4 of the largest), post-step weights (Adam-aware bar, oracle/parity.py).  Returns (record, oracle step
+    seconds) -- the oracle step doubles as the small shard of cpu_baseline_fit."""
+    import torch
+    import tensorrec_amd as T
+    from oracle.model import OracleTensorRec
+    from oracle.parity import check_weights_after_adam
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    rng = np.random.default_rng(seed)
+    cols = rng.integers(0, n_items, size=(n_users, per_user), dtype=np.int64)
+    inter = sp.csr_matrix((np.ones(n_users * per_user, np.float32), cols.reshape(-1),
+                           np.arange(0, (n_users + 1) * per_user, per_user, dtype=np.int64)), shape=(n_users, n_items))
+    inter.sum_duplicates()
+    inter.data[:] = 1.0
+    inter.sort_indices()
+    uf = sp.identity(n_users, dtype=np.float32, format="csr")
+    itf = sp.identity(n_items, dtype=np.float32, format="csr")
+    samples = np.empty((n_users, n_sampled), np.int64)                   # distinct per user (the reference samples without replacement)
+    for u in range(n_users):
+        c = np.unique(rng.integers(0, n_items, size=n_sampled + 16))
+        samples[u] = rng.permutation(c)[:n_sampled]
+    oracle = OracleTensorRec(d, "linear", "linear", "dot", "wmrb", True)
+    oracle.init_weights(n_users, n_items, rng)
+    oracle.weights["user_feature_biases"] = (0.1 * rng.standard_normal((n_users, 1))).astype(np.float32)
+    oracle.weights["item_feature_biases"] = (0.1 * rng.standard_normal((n_items, 1))).astype(np.float32)
+    rename = lambda w: {(k_ + "_0" if k_.endswith("_user") else k_): v for k_, v in w.items()}     # noqa: E731
+    w0 = {k_: v.copy() for k_, v in oracle.weights.items()}
+    model = T.TensorRec(n_components=d, loss_graph=T.loss_graphs.WMRBLossGraph(), sampler=T.ReplaySampler([samples]), seed=1)
+    model.build(n_users, n_items)
+    model.set_weights(rename(w0))
+    model._capture = {}
+    model.fit_partial(inter, uf, itf, epochs=1, learning_rate=lr, alpha=alpha, n_sampled_items=n_sampled)
+    cap = model._capture
+    model._capture = None
+    got_w = model.get_weights()
+    del model
+    t0 = time.perf_counter()
+    basic, _, pred_serial = oracle.step(inter, uf, itf, lr, alpha, samples)
+    oracle_s = time.perf_counter() - t0
+    # raw gradients of the oracle: its step differentiates sum(loss vector + alpha * reg) -- the scalar regulariser is broadcast
+    # over the P+ entries of the WMRB loss vector (tensorrec.py:487-488) -- whose gradient is raw + P+ * alpha * w
+    n_loss = float(np.asarray(basic).size)
+    raw = {k_: (None if g is None else g - np.float32(n_loss * alpha) * w0[k_]) for k_, g in oracle.last_grads.items()}
+    gmax = max(float(np.abs(g).max()) for g in raw.values() if g is not None)
+    rec = {"workload": "%d users x %d items, identity features, d=%d, Linear + DotProduct + WMRB, biased (non-zero biases), %d "
+                       "interactions, %d replayed samples per user, lr %.3g, alpha %.1e: one optimiser step, GPU (public API) vs "
+                       "oracle/model.py" % (n_users, n_items, d, inter.nnz, n_sampled, lr, alpha),
+           "oracle_step_seconds": oracle_s}
+    ps_err = float(np.abs(cap["pred_serial"] - pred_serial).max() / max(1e-30, np.abs(pred_serial).max()))
+    loss_err = float(np.abs(cap["loss"] - basic).max())
+    rec["pred_serial_max_rel_err"] = ps_err
+    rec["loss_vector_max_abs_err"] = loss_err
+    rec["loss_vector_ok_1e-4"] = bool(np.allclose(cap["loss"], basic, rtol=1e-4, atol=1e-5))
+    gerr = {}
+    for k_, ref in rename(raw).items():
+        if ref is None:
+            continue
+        gerr[k_] = float(np.abs(cap["grads"][k_] - ref).max() / gmax)
+    rec["raw_gradient_max_err_over_gmax"] = gerr
+    rec["raw_gradients_ok_1e-4"] = bool(all(v <= 1e-4 for v in gerr.values()))
+    try:
+        rep = check_weights_after_adam(got_w, rename(oracle.weights), cap["grads"], rename(raw), lr, 1,
+                                       exempt=("user_feature_biases",), label="bench parity_fit")
+        rec["weights_after_step"] = {k_: {"max_abs_dw": v[0], "share_beyond_1e-4_lr": v[1]} for k_, v in rep.items()}
+        rec["weights_ok_adam_aware_bar"] = True
+    except AssertionError as exc:
+        rec["weights_ok_adam_aware_bar"] = False
+        rec["weights_error"] = str(exc)
+    rec["green"] = bool(ps_err <= 1e-4 and rec["loss_vector_ok_1e-4"] and rec["raw_gradients_ok_1e-4"] and
+                        rec["weights_ok_adam_aware_bar"])
+    return rec, oracle_s
+
+
+def parity_multi_nnz_record(device, item_repr, item_bias_dev, d, k, n_users=1024, nnz_row=20, n_features=1_000_000, seed=9):
+    """Users described by ``nnz_row`` sparse features each: GPU = K1 (general CSR gather) + bias SpMV + exact top-k cascade;
+    oracle = its OWN SpMM (tr_oracle.c, CSR-order fmaf), bias projection, fp32 score chain and top-k."""
+    import torch
+    from tensorrec_amd import ops
+    from tensorrec_amd.sparse import SparseFeatures
+    from oracle import oracle as O
+    rng = np.random.default_rng(seed)
+    cols = rng.integers(0, n_features, size=(n_users, nnz_row), dtype=np.int32)
+    cols.sort(axis=1)
+    m = sp.csr_matrix((rng.random(n_users * nnz_row, dtype=np.float32), cols.reshape(-1),
+                       np.arange(0, (n_users + 1) * nnz_row, nnz_row, dtype=np.int64)), shape=(n_users, n_features))
+    m.sum_duplicates()
+    w_h = (rng.standard_normal((n_features, d)) / np.sqrt(d * nnz_row / 3.0)).astype(np.float32)
+    b_h = (0.05 * rng.standard_normal((n_features, 1))).astype(np.float32)
+    f = SparseFeatures(m, device)
+    w, b = torch.from_numpy(w_h).to(device), torch.from_numpy(b_h).to(device)
+    with torch.no_grad():
+        ur = ops.spmm_raw(f.indptr, f.indices, f.values, None, n_users, f.nnz, w)
+        ub = ops.sparse_matvec(f, b)
+        u_f = ops.score_prep_filter(ur, sort_users=True)
+        i_f = ops.score_prep_filter(item_repr, bias=item_bias_dev, want_gstats=True)
+        vals, idx = ops.score_topk_filtered(u_f, i_f, k, ub, item_bias_dev, prefilter=ops.cascade_prefilter_for(d, item_repr.shape[0]))
+    rec = oracle_topk_parity(O, O.spmm_exact(m, w_h), item_repr.cpu().numpy(), O.spmm_exact(m, b_h).reshape(-1),
+                             None if item_bias_dev is None else item_bias_dev.cpu().numpy(), vals.cpu().numpy(),
+                             idx.cpu().numpy(), k)
+    rec["workload"] = ("%d users with %d non-zero features each over %d feature columns (d=%d) against the timed run's %d items: "
+                       "the oracle computes representations and biases from the WEIGHTS itself"
+                       % (n_users, nnz_row, n_features, d, item_repr.shape[0]))
+    rec["stage1"] = ops.LAST_FILTER_STATS.get("prefilter", "bf16")
+    return rec
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE.json configs[1], [3], [4]
+def _zipf_interactions(n_users, n_items, per_user, rng, exponent=0.9):
+    pop = 1.0 / np.arange(1, n_items + 1) ** exponent
+    pop /= pop.sum()
+    cols = rng.choice(n_items, size=(n_users, per_user), p=pop).astype(np.int32)
+    cols.sort(axis=1)
+    keep = np.ones_like(cols, dtype=bool)
+    keep[:, 1:] = cols[:, 1:] != cols[:, :-1]
+    indptr = np.zeros(n_users + 1, np.int64)
+    np.cumsum(keep.sum(1), out=indptr[1:])
+    return sp.csr_matrix((np.ones(int(keep.sum()), np.float32), cols[keep], indptr), shape=(n_users, n_items))
+
+
+def _side_features(n, n_side, per_row, rng):
+    """identity block | ``per_row`` random indicator columns out of ``n_side``"""
+    cols = np.sort(rng.integers(0, n_side, size=(n, per_row), dtype=np.int64) + n, axis=1)
+    allc = np.concatenate([np.arange(n, dtype=np.int64)[:, None], cols], axis=1)
+    keep = np.ones_like(allc, dtype=bool)
+    keep[:, 2:] = allc[:, 2:] != allc[:, 1:-1]
+    indptr = np.zeros(n + 1, np.int64)
+    np.cumsum(keep.sum(1), out=indptr[1:])
+    return sp.csr_matrix((np.ones(int(keep.sum()), np.float32), allc[keep].astype(np.int32), indptr), shape=(n, n + n_side))
+
+
+def _rename(w):
+    return {(k + "_0" if k.endswith("_user") else k): v for k, v in w.items()}
+
+
+def _events_summary(events):
+    dur = {}
+    for name, a, b in events:
+        dur.setdefault(name, []).append(a.elapsed_time(b))
+    return {n: {"avg_ms": float(np.mean(v)), "launches": len(v), "total_ms": float(np.sum(v))} for n, v in dur.items()}
+
+
+def _one_step_parity(make_model, oracle, inter, uf, itf, table, lr, alpha, S, grad_tol):
+    """One replayed-sample step on the GPU against oracle.loss_and_grads: serial predictions, loss vector, raw gradients."""
+    model = make_model([table])
+    model.build(uf.shape[1], itf.shape[1])
+    model.set_weights(_rename(oracle.weights))
+    model._capture = {}
+    model.fit_partial(inter, uf, itf, epochs=1, learning_rate=lr, alpha=alpha, n_sampled_items=S)
+    cap = model._capture
+    basic, _, grads, pred_serial = oracle.loss_and_grads(inter, uf, itf, 0.0, table)
+    gmax = max(float(np.abs(g).max()) for g in grads.values() if g is not None)
+    gerr = {k: float(np.abs(cap["grads"][k] - ref).max() / gmax) for k, ref in _rename(grads).items() if ref is not None}
+    dl = np.abs(cap["loss"] - basic)
+    rec = {"pred_serial_max_rel_err": float(np.abs(cap["pred_serial"] - pred_serial).max() / max(1e-30, np.abs(pred_serial).max())),
+           "loss_share_within_1e-4": float((dl <= 1e-5 + 1e-4 * np.abs(basic)).mean()),
+           "loss_max_abs_err_over_max_loss": float(dl.max() / max(1e-30, np.abs(basic).max())),
+           "raw_gradient_max_err_over_gmax": gerr, "gradient_bar": grad_tol}
+    rec["green"] = bool(rec["pred_serial_max_rel_err"] <= 1e-4 and rec["loss_share_within_1e-4"] >= 0.999 and
+                        rec["loss_max_abs_err_over_max_loss"] <= 1e-3 and all(v <= grad_tol for v in gerr.values()))
+    return rec
+
+
+def config1_record(device):
+    """configs[1]: MovieLens-100K-shaped 943 x 1,682 (identity users, identity (+) 19 genre columns), d = 64, WMRB, S = 168:
+    fit epochs/sec through the public API (HIP-graph replay of the step) + one replayed step against the oracle."""
+    import torch
+    import tensorrec_amd as T
+    from tensorrec_amd import ops
+    from oracle import oracle as O
+    from oracle.model import OracleTensorRec
+    rng = np.random.default_rng(0)
+    n_users, n_items, d, S, lr, alpha = 943, 1682, 64, 168, 0.05, 1e-5
+    inter = _zipf_interactions(n_users, n_items, 160, rng, exponent=1.0)
+    uf = sp.identity(n_users, dtype=np.float32, format="csr")
+    itf = _side_features(n_items, 19, 3, rng)
+    model = T.TensorRec(n_components=d, loss_graph=T.loss_graphs.WMRBLossGraph(), seed=0)
+    model.fit_partial(inter, uf, itf, epochs=5, learning_rate=lr, n_sampled_items=S)          # build, capture, warm up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    model.fit_partial(inter, uf, itf, epochs=20, learning_rate=lr, n_sampled_items=S)
+    torch.cuda.synchronize()
+    t20 = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    model.fit_partial(inter, uf, itf, epochs=220, learning_rate=lr, n_sampled_items=S)
+    torch.cuda.synchronize()
+    per_epoch = (time.perf_counter() - t0 - t20) / 200.0
+    del model
+    # algorithmic bytes of a step: every pair's item row once + user rows in / out + the dense Adam update
+    pairs = n_users * S + inter.nnz
+    n_w = (n_users + itf.shape[1]) * (d + 1)
+    alg = pairs * d * 4.0 + 2.0 * n_users * d * 4 + 28.0 * n_w
+    srng = np.random.RandomState(3)
+    table = O.sample_items(n_items, n_users, S, False, srng)[:, 1].reshape(n_users, S)
+    oracle = OracleTensorRec(d, "linear", "linear", "dot", "wmrb", True)
+    oracle.init_weights(uf.shape[1], itf.shape[1], np.random.default_rng(42))
+    brng = np.random.default_rng(7)
+    oracle.weights["user_feature_biases"] = (0.1 * brng.standard_normal((uf.shape[1], 1))).astype(np.float32)
+    oracle.weights["item_feature_biases"] = (0.1 * brng.standard_normal((itf.shape[1], 1))).astype(np.float32)
+    mk = lambda tables: T.TensorRec(n_components=d, loss_graph=T.loss_graphs.WMRBLossGraph(), sampler=T.ReplaySampler(tables), seed=1)  # noqa: E731
+    parity = _one_step_parity(mk, oracle, inter, uf, itf, table, lr, alpha, S, 1e-4)
+    return {"workload": "BASELINE.json configs[1]: %d x %d (MovieLens-100K-shaped, %d interactions, Zipf items; item features "
+                        "identity (+) 19 indicator columns), Linear d=%d + DotProduct + WMRB, S=%d" % (n_users, n_items, inter.nnz, d, S),
+            "ms_per_epoch": 1e3 * per_epoch, "fit_epochs_per_sec": 1.0 / per_epoch,
+            "note": "latency-bound: the whole step is one HIP-graph replay (~25 kernels of a few microseconds each)",
+            "roofline": {"bound": "latency (graph replay); priced against HBM for reference", "achieved": alg / per_epoch / 1e9,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / per_epoch / 1e9 / HBM_PEAK_GBS,
+                         "algorithmic_bytes_per_step": alg},
+            "parity_one_step_vs_oracle": parity}
+
+
+def config3_shard_record(device, n_users=65536, n_items=1_250_000, d=128, k=10, reps=3, parity_users=256):
+    """configs[3], one rank's share: 65,536 users against a 1.25M-item shard (an eighth of 10M), CosineSimilarity, exact
+    top-10 (both sides row-normalised by the prep pass, then the int8 -> bf16 -> fp32 cascade)."""
+    import torch
+    from tensorrec_amd import ops
+    from oracle import oracle as O
+    g = torch.Generator(device=device)
+    g.manual_seed(0)
+    items = torch.randn((n_items, d), device=device, generator=g)
+    users = torch.randn((n_users, d), device=device, generator=g)
+    pre = ops.cascade_prefilter_for(d, n_items)
+
+    def step():
+        with torch.no_grad():
+            u_f = ops.score_prep_filter(users, normalize=True, sort_users=pre == "int8")
+            i_f = ops.score_prep_filter(items, normalize=True, want_gstats=True)
+            v, i = ops.score_topk_filtered(u_f, i_f, k, prefilter=pre)
+            return v, i, i_f
+    step()
+    torch.cuda.synchronize()
+    ops.KERNEL_EVENTS = []
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        vals, idx, i_f = step()
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / reps
+    ev, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
+    ks = _events_summary(ev)
+    stats = dict(ops.LAST_FILTER_STATS)
+    dom = "score_gemm_blockmax_i8" if "score_gemm_blockmax_i8" in ks else "score_gemm_blockmax"
+    ops_per_launch = 2.0 * n_users * n_items * d
+    peak = 2.0 * BF16_DENSE_PEAK_TFLOPS if dom.endswith("i8") else BF16_DENSE_PEAK_TFLOPS
+    ach = ops_per_launch / (ks[dom]["avg_ms"] * 1e-3) / 1e12
+    # parity on the path's own operands (row-normalised fp32 rows): ids and values bit-exact; and against NumPy's cosine
+    sample = np.unique(np.linspace(0, n_users - 1, parity_users).astype(np.int64))
+    u_ref = ops.score_prep_filter(users[torch.from_numpy(sample).to(device)].contiguous(), normalize=True)
+    par = oracle_topk_parity(O, u_ref.f32.cpu().numpy(), i_f.f32.cpu().numpy(), None, None,
+                             vals[torch.from_numpy(sample).to(device)].cpu().numpy(),
+                             idx[torch.from_numpy(sample).to(device)].cpu().numpy(), k, tile=256)
+    return {"workload": "BASELINE.json configs[3], one of 8 ranks: %d users x %d items (of 10M), d=%d, CosineSimilarity, exact "
+                        "top-%d; operands prepared inside the step" % (n_users, n_items, d, k),
+            "ms_per_step": ms, "predictions_per_s": float(n_users) * n_items / (ms * 1e-3), "stage1": stats.get("prefilter", "bf16"),
+            "flagged_users": stats.get("flagged_users"),
+            "roofline": {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                         "avg_launch_ms": ks[dom]["avg_ms"]},
+            "kernels_avg_ms": {n: v["avg_ms"] for n, v in ks.items()}, "parity": par}
+
+
+def config4_record(device, n_users=138_493, n_items=26_744, per_user=160, d=256, epochs=3, parity_users=256):
+    """configs[4]: MovieLens-20M-shaped fit on one GPU -- identity (+) indicator side features, ReLURepresentation d = 256
+    (hidden 1024) + EuclideanSimilarity + WMRB with S = 10% of the items (examples/check_movielens_losses.py:26), one optimiser
+    step per epoch; and one replayed step of a user tile against the oracle."""
+    import torch
+    import tensorrec_amd as T
+    from tensorrec_amd import ops
+    from tensorrec_amd.representation_graphs import ReLURepresentationGraph
+    from tensorrec_amd.prediction_graphs import EuclideanSimilarityPredictionGraph
+    from oracle import oracle as O
+    from oracle.model import OracleTensorRec
+    rng = np.random.default_rng(1)
+    S = n_items // 10
+    inter = _zipf_interactions(n_users, n_items, per_user, rng, exponent=0.8)
+    uf = sp.identity(n_users, dtype=np.float32, format="csr")
+    itf = _side_features(n_items, 1148, 8, rng)
+
+    def mk(tables=None):
+        return T.TensorRec(n_components=d, user_repr_graph=ReLURepresentationGraph(), item_repr_graph=ReLURepresentationGraph(),
+                           prediction_graph=EuclideanSimilarityPredictionGraph(), loss_graph=T.loss_graphs.WMRBLossGraph(),
+                           seed=0, **({"sampler": T.ReplaySampler(tables)} if tables is not None else {}))
+    model = mk()
+    model.fit_partial(inter, uf, itf, epochs=1, learning_rate=0.01, n_sampled_items=S)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    model.fit_partial(inter, uf, itf, epochs=1, learning_rate=0.01, n_sampled_items=S)
+    torch.cuda.synchronize()
+    one = time.perf_counter() - t0
+    ops.KERNEL_EVENTS = []
+    t0 = time.perf_counter()
+    model.fit_partial(inter, uf, itf, epochs=1 + epochs, learning_rate=0.01, n_sampled_items=S)
+    torch.cuda.synchronize()
+    per_epoch = (time.perf_counter() - t0 - one) / epochs
+    ev, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
+    ks = _events_summary(ev)
+    del model
+    torch.cuda.empty_cache()
+    top = sorted(ks.items(), key=lambda kv: -kv[1]["total_ms"])[:6]
+    pairs = float(n_users) * S + inter.nnz
+    # every (user, item) pair of the step gathers its 256-wide ITEM row forward and again backward (the user's own row stays
+    # with the subgroup that owns the user); + 12 bytes of ids / coefficients per pair and pass (K3 / K6)
+    alg = pairs * (d * 4 + 12) * 2.0
+    dom_name, dom = top[0]
+    rec = {"workload": "BASELINE.json configs[4] on one GPU: %d x %d (MovieLens-20M-shaped, %d interactions, Zipf items; item "
+                       "features identity (+) 1,148 indicator columns), ReLU d=%d (hidden %d) + Euclidean + WMRB, S=%d (%.3g sampled "
+                       "pairs per epoch)" % (n_users, n_items, inter.nnz, d, 4 * d, S, float(n_users) * S),
+           "sec_per_epoch": per_epoch, "fit_epochs_per_sec": 1.0 / per_epoch,
+           "top_kernels_ms_per_epoch": {n: v["total_ms"] / (epochs + 1.0) for n, v in top},
+           "roofline": {"kernel": "the pair kernels of one epoch together (score forward, WMRB, structured backward gathers)",
+                        "bound": "l2/mall gathers: the 27 MB item representation table lives in the 256 MB Infinity Cache, so the row "
+                                 "gathers never reach HBM; priced against the HBM peak for reference only",
+                        "achieved": alg / per_epoch / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / per_epoch / 1e9 / HBM_PEAK_GBS,
+                        "algorithmic_bytes_per_epoch": alg,
+                        "note": "whole-epoch rate: every pair's 1 KB item row forward and backward over the epoch time; the kernels "
+                                "named under top_kernels_ms_per_epoch are only those with HIP events around them"}}
+    # parity: one replayed step of a user tile (same weight shapes) against oracle/model.py
+    tile = np.arange(0, n_users, n_users // parity_users)[:parity_users]
+    inter_t, uf_t = inter[tile], uf[tile]
+    table = np.stack([rng.permutation(n_items)[:S] for _ in range(len(tile))]).astype(np.int64)
+    oracle = OracleTensorRec(d, "relu", "relu", "euclidean", "wmrb", True)
+    oracle.init_weights(uf.shape[1], itf.shape[1], np.random.default_rng(42))
+    rec["parity_one_step_vs_oracle"] = _one_step_parity(lambda tables: mk(tables), oracle, inter_t, uf_t, itf, table, 0.01, 1e-5, S, 2e-4)
+    rec["parity_one_step_vs_oracle"]["tile"] = "%d users (every %d-th), all items, the full weight shapes" % (len(tile), n_users // parity_users)
+    return rec
+
+
+def config_records(device, which=("cfg1", "cfg3_shard", "cfg4")):
+    import torch
+    out = {}
+    for name, fn in (("cfg1", config1_record), ("cfg3_shard", config3_shard_record), ("cfg4", config4_record)):
+        if name not in which:
+            continue
+        t0 = time.perf_counter()
+        try:
+            out[name] = fn(device)
+        except Exception as exc:                       # a record, not the measurement: report why it could not run
+            out[name] = {"error": repr(exc)}
+        out[name]["record_seconds"] = time.perf_counter() - t0
+        torch.cuda.empty_cache()
+    return out

@@ -252,6 +252,7 @@ class OracleTensorRec(object):
     def step(self, interactions, user_features, item_features, learning_rate, alpha, sample_items=None):
         basic, reg, grads, pred_serial = self.loss_and_grads(interactions, user_features, item_features, alpha,
                                                              sample_items)
+        self.last_grads = grads                  # d(loss + alpha * reg) / dw of this step (bench.py's parity_fit reads them)
         self.t += 1
         lr_t = O.adam_lr_t(learning_rate, self.t)
         for k, g in grads.items():
