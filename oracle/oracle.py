@@ -4,7 +4,7 @@ oracle/oracle.py -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
 CPU restatement (NumPy / SciPy / torch-CPU float32) of the arithmetic on TensorRec's
 scoring + training hot path.  Only ``tests/``, ``__graft_entry__.smoke()`` and
 ``bench.py``'s ``cpu_baseline`` leg may import this package; nothing under
-``tensorrec_amd/`` does (tests/test_no_oracle_in_product.py enforces it).
+``tensorrec_amd/`` does (tests/test_host_logic.py::test_no_oracle_in_product enforces it).
 
 Why a restatement: the reference (jfkirk/tensorrec v0.26.2, /root/reference) is pure
 Python over TensorFlow 1.x (``tensorflow>=1.7.0``, setup.py:21).  TensorFlow is not

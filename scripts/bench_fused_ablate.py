@@ -1,6 +1,8 @@
 """Where the one-pass WMRB step's time goes: trec_wmrb_fused_step alone on the bench's fit workload (1M users x 1M items,
 d = 128, 20 interactions + 100 samples per user) with parts switched off (tuning knob wmrb_ablate; results are wrong
-in ablated runs, only the time is read)."""
+in ablated runs, only the time is read).
+Needs a library built with the ablation branches: make -C tensorrec_amd/csrc FLAGS_wmrb_fused=-DTREC_WMRB_ABLATE (the shipped
+build has none of them and ignores the knob)."""
 import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, scipy.sparse as sp, torch

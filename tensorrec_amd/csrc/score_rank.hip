@@ -179,6 +179,14 @@ __global__ __launch_bounds__(256, (KT >= 256 ? 1 : 2)) void score_rankcount_kern
                 int c = 0;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) c += (s[r] > thr) ? 1 : 0;
+                if (tv == -INFINITY && ti >= blk1) {
+                    // a target scoring -inf ties with every -inf item, and float_pred(-inf) = -inf cannot express ">=": in a
+                    // block wholly below the target's index EVERY valid row beats or ties-and-precedes it (rows
+                    // past the end, set to -inf above, do not count).  NaN scores stay outside the guarantee.
+                    c = 0;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) c += (rc_cd_row(r, half) < rows_left) ? 1 : 0;
+                }
                 if (__builtin_amdgcn_ballot_w64(inside) != 0ull) {              // the block holding the target itself
                     if (inside) {
                         c = 0;

@@ -42,6 +42,15 @@ __device__ __forceinline__ float dpp_add(float x, const int ctrl_tag)
 
 constexpr int SR = 4;                 // sample registers per lane in the loss phase: S <= 256
 
+// The ablation switches of scripts/bench_fused_ablate.py (histogram atomics / loss phases / dU off: WRONG results, only the
+// time is read) exist only in a build with -DTREC_WMRB_ABLATE; the shipped kernel has none of the branches and no tuning
+// lookup per launch (a knob left set would train wrong gradients silently).
+#ifdef TREC_WMRB_ABLATE
+#define TREC_ABLATED(bit) (ablate & (bit))
+#else
+#define TREC_ABLATED(bit) false
+#endif
+
 // ITERS: float4 chunks per lane of a 32-lane subgroup (d <= 128 * ITERS); RMAX: item rows a subgroup holds
 template <int ITERS, int RMAX>
 __global__ __launch_bounds__(256, (ITERS == 1 && RMAX == 16) ? 4 : 1) void wmrb_user_fused_kernel(
@@ -139,7 +148,7 @@ __global__ __launch_bounds__(256, (ITERS == 1 && RMAX == 16) ? 4 : 1) void wmrb_
     for (int h = 0; h < H; ++h) {
         const int j = sg + 8 * (own + 16 * h);
         rk[h] = 0;
-        if (sample_hist && own >= 0 && j < S && !(ablate & 1))
+        if (sample_hist && own >= 0 && j < S && !TREC_ABLATED(1))
             rk[h] = __hip_atomic_fetch_add(sample_hist + samples[u * S + j], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // predictions: no per-row branch (a wave holds two subgroups with different rows), so the RMAX reduction chains
@@ -181,7 +190,7 @@ __global__ __launch_bounds__(256, (ITERS == 1 && RMAX == 16) ? 4 : 1) void wmrb_
     //      first threads = interactions, each walking the S sample predictions (LDS broadcast reads) for its hinge sum
     //      and active count; then threads = samples, each walking the interactions for its coefficient ----
     // (c1) hinge sum and active count of interaction q, 8 threads per interaction, each over every 8th float4 of samples
-    for (int q0 = 0; q0 < ((ablate & 2) ? 0 : n_pos); q0 += 32) {
+    for (int q0 = 0; q0 < (TREC_ABLATED(2) ? 0 : n_pos); q0 += 32) {
         const int q = q0 + (tid >> 3), k = tid & 7;
         float acc = 0.f;
         int cnt = 0;
@@ -227,7 +236,7 @@ __global__ __launch_bounds__(256, (ITERS == 1 && RMAX == 16) ? 4 : 1) void wmrb_
     for (int s = tid; s < S; s += 256) {
         const float ys = l_y[s];
         float g = 0.f;
-        for (int q = 0; q < ((ablate & 2) ? 0 : n_pos); ++q) g += (l_base[q] + ys >= 0.f) ? l_c[q] : 0.f;     // l_c = 0 for non-positives
+        for (int q = 0; q < (TREC_ABLATED(2) ? 0 : n_pos); ++q) g += (l_base[q] + ys >= 0.f) ? l_c[q] : 0.f;     // l_c = 0 for non-positives
         l_coef[s] = g;
         coef_samples[u * S + s] = g;
     }
@@ -241,7 +250,7 @@ __global__ __launch_bounds__(256, (ITERS == 1 && RMAX == 16) ? 4 : 1) void wmrb_
 #pragma unroll
         for (int r = 0; r < RMAX; ++r) {
             const int j = sg + 8 * r;
-            if (j < R && !(ablate & 4)) {
+            if (j < R && !TREC_ABLATED(4)) {
                 const float cf = l_coef[j];
 #pragma unroll
                 for (int it = 0; it < ITERS; ++it) {
@@ -269,7 +278,7 @@ __global__ __launch_bounds__(256, (ITERS == 1 && RMAX == 16) ? 4 : 1) void wmrb_
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
         if (lane == 0) dub[u] = acc;
     }
-    if (sample_hist && sample_rank && own >= 0 && !(ablate & 1)) {
+    if (sample_hist && sample_rank && own >= 0 && !TREC_ABLATED(1)) {
 #pragma unroll
         for (int h = 0; h < H; ++h) {
             const int j = sg + 8 * (own + 16 * h);
@@ -315,11 +324,15 @@ extern "C" int trec_wmrb_fused_step(const float* U, const float* V, const float*
     const float ratio = (float)n_items / (float)n_sampled;
     const int32_t max_rows = n_sampled + max_interactions_per_user;
     hipStream_t st = (hipStream_t)stream;
+#ifdef TREC_WMRB_ABLATE
+    const int ablate = trec_get_tuning("wmrb_ablate", 0);
+#else
+    const int ablate = 0;
+#endif
 #define TREC_FUSED(IT, RM)                                                                                             \
     hipLaunchKernelGGL((wmrb_user_fused_kernel<IT, RM>), dim3((unsigned)n_users), dim3(256), lds, st, U, V, user_bias,  \
                        item_bias, indptr, x_item, pos_slot, pos_weight, samples, n_users, n_sampled, d, ratio, max_rows, \
-                       loss, pred_serial, dU, d_user_bias, coef_samples, coef_pairs, sample_hist, sample_rank,    \
-                       trec_get_tuning("wmrb_ablate", 0))
+                       loss, pred_serial, dU, d_user_bias, coef_samples, coef_pairs, sample_hist, sample_rank, ablate)
     if (d <= 128 && max_rows <= 128) TREC_FUSED(1, 16);
     else if (d <= 128) TREC_FUSED(1, 32);
     else TREC_FUSED(2, 16);

@@ -384,7 +384,31 @@ class _PairScore(torch.autograd.Function):
         return du, dv, dub, dib, None, None, None, None, None
 
 
-DETERMINISTIC_GROUPING = False      # set by TensorRec(deterministic=True) for the duration of a fit call
+import threading as _threading
+
+
+class _Local(_threading.local):
+    deterministic_grouping = False
+
+
+_LOCAL = _Local()       # per THREAD: two models fitting in different threads must not switch each other's grouping mode
+
+
+class deterministic_grouping(object):
+    """``with ops.deterministic_grouping(flag):`` -- group_pairs_by_item uses the stable (bit-reproducible) grouping inside the
+    block, in this thread only; the previous mode returns on exit (TensorRec(deterministic=True) wraps its fit calls in it)."""
+
+    def __init__(self, flag=True):
+        self.flag = bool(flag)
+
+    def __enter__(self):
+        self.prev = _LOCAL.deterministic_grouping
+        _LOCAL.deterministic_grouping = self.flag
+        return self
+
+    def __exit__(self, *exc):
+        _LOCAL.deterministic_grouping = self.prev
+        return False
 
 
 def group_pairs_by_item(xu32, xi32, pairs_per_user, n_items, workspace_with_counts=None, ranks=None, values=None):
@@ -397,7 +421,7 @@ def group_pairs_by_item(xu32, xi32, pairs_per_user, n_items, workspace_with_coun
     8-byte scattered store per pair, consumed by trec_spmm_csr_packed."""
     dev = xi32.device
     n_pairs = xi32.numel()
-    if DETERMINISTIC_GROUPING and n_pairs:
+    if _LOCAL.deterministic_grouping and n_pairs:
         # bit-reproducible fits (TensorRec(deterministic=True)): a STABLE sort by item keeps the pairs of a bucket in pair
         # order, so the fp32 sums over a bucket are added in the same order every run (the counting sort below orders a
         # bucket by atomic arrival).  Negative keys sort to the front and fall before indptr[0].

@@ -27,6 +27,17 @@ import torch
 import torch.distributed as dist
 
 
+# Collectives are skipped in a one-rank world -- unless FORCE_COLLECTIVES is set: the one-GPU RCCL smoke test
+# (tests/test_gpu_rccl_world1.py) runs every exchange of the scoring / training path through the real "nccl" backend at
+# world size 1, which is as much of RCCL as a one-GPU box can execute.
+FORCE_COLLECTIVES = False
+
+
+def active(group=None):
+    """True when the multi-rank code paths (and their collectives) run for ``group``."""
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or FORCE_COLLECTIVES)
+
+
 def shard_bounds(n_items, world_size, rank, align=64):
     """Contiguous, aligned, nearly equal item ranges: [begin, end) of ``rank``.  ``align`` keeps shard starts on the
     score kernel's tile so float4 bias loads stay aligned; the last shard takes the remainder."""
@@ -42,7 +53,7 @@ def shard_bounds(n_items, world_size, rank, align=64):
 def all_gather_cat(t, group=None, dim=1):
     """All-gather equal-shaped tensors and concatenate along ``dim`` (rank order): ONE collective into one buffer."""
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not FORCE_COLLECTIVES:
         return t
     t = t.contiguous()
     out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
@@ -71,14 +82,14 @@ def sharded_top_k(local_vals, local_idx, k, group=None):
 
 def reduce_rank_counts(local_counts, group=None):
     """Partial 'items that beat the target' counts (int32) -> global ranks - 1 on every rank (all-reduce SUM)."""
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if active(group):
         dist.all_reduce(local_counts, op=dist.ReduceOp.SUM, group=group)
     return local_counts
 
 
 def all_reduce_sum_(tensors, group=None):
     """In-place SUM all-reduce of a list of tensors (weight gradients of the user-sharded fit)."""
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if active(group):
         for t in tensors:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return tensors
@@ -101,7 +112,7 @@ def shared_topk_floor(sel_max, group=None):
     world * k gathered maxima bounds every user's global k-th best score from below (k disjoint superblocks each hold an
     item scoring at least that).  ONE all-gather; the result is identical on every rank."""
     k = sel_max.shape[0]
-    gathered = all_gather_cat(sel_max, group, dim=0) if dist.is_initialized() else sel_max     # [world * k, n_users]
+    gathered = all_gather_cat(sel_max, group, dim=0) if active(group) else sel_max             # [world * k, n_users]
     return kth_largest_block_max(gathered, k)
 
 
@@ -151,7 +162,7 @@ def shared_topk_floor_a2a(sel_max, group=None, kth_fn=None):
     [n_users] floor is completed by an all-gather of the slices (4 bytes per user)."""
     kth_fn = kth_fn or kth_largest_block_max
     k, n_users = sel_max.shape
-    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+    if not active(group):
         return kth_fn(sel_max, k)
     world = dist.get_world_size(group)
     table, (b, e) = exchange_floor_table_a2a(sel_max, group)
@@ -184,7 +195,7 @@ def sharded_top_k_a2a(local_vals, local_idx, k, group=None, replicate=False, mer
     (user_slice(n_users, world, rank)): one all-to-all of list slices + a local merge (``merge_fn``, default the HIP merge
     kernel).  ``replicate``: finish with an all-gather of the merged lists so that every rank holds all users (what
     sharded_top_k returns)."""
-    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+    if not active(group):
         return local_vals, local_idx
     merge_fn = merge_fn or merge_topk
     n_users = local_vals.shape[0]
@@ -201,12 +212,36 @@ def sharded_top_k_a2a(local_vals, local_idx, k, group=None, replicate=False, mer
     return ov[:n_users], oi[:n_users]
 
 
+_A2A_CHECKED = {}          # process group -> the all-to-all known-answer check passed (agreed over the ranks)
+
+
 def a2a_available(t, group=None):
     """All-to-all of device tensors needs RCCL ("nccl"); gloo carries CUDA tensors only for the gather / reduce
-    collectives (the one-GPU functional tests).  CPU tensors: gloo has all_to_all_single."""
-    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+    collectives (the one-GPU functional tests).  CPU tensors: gloo has all_to_all_single.
+    The first call per process group runs a known-answer all-to-all (a COLLECTIVE: every rank reaches this point, as every
+    rank reaches the exchange it guards) and the ranks agree on the outcome; a wrong answer -- or TREC_SHARD_EXCHANGE=allgather
+    in the environment -- keeps the all-gather forms for the life of the process (the public API used to trust the
+    backend name alone)."""
+    import os
+    if not active(group):
         return False
-    return (not t.is_cuda) or dist.get_backend(group) == "nccl"
+    if t.is_cuda and dist.get_backend(group) != "nccl":
+        return False
+    if os.environ.get("TREC_SHARD_EXCHANGE", "").lower() == "allgather":
+        return False
+    key = id(group) if group is not None else 0
+    if key not in _A2A_CHECKED:
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        x = torch.arange(world * 3, dtype=torch.float32, device=t.device) + 100.0 * rank
+        want = torch.stack([torch.arange(rank * 3, rank * 3 + 3, dtype=torch.float32) + 100.0 * s_ for s_ in range(world)])
+        try:
+            good = torch.equal(_all_to_all_user_slices(x, 0, group).cpu(), want)
+        except RuntimeError:                                      # (a backend without all_to_all raises on every rank alike)
+            good = False
+        ok = torch.tensor([1.0 if good else 0.0], device=t.device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)    # every rank must take the same exchange form
+        _A2A_CHECKED[key] = bool(ok.item() == 1.0)
+    return _A2A_CHECKED[key]
 
 
 def collective_selfcheck(device, group=None):
@@ -219,17 +254,9 @@ def collective_selfcheck(device, group=None):
     g = all_gather_cat(x.reshape(1, -1), group, dim=0)
     want = torch.stack([torch.arange(world * 3, dtype=torch.float32) + 100.0 * r for r in range(world)]).to(device)
     assert torch.equal(g, want), "all-gather self-check failed"
-    if a2a_available(x, group):
-        want = torch.stack([torch.arange(rank * 3, rank * 3 + 3, dtype=torch.float32) + 100.0 * s for s in range(world)])
-        try:
-            got = _all_to_all_user_slices(x, 0, group)            # [world, 3]: entry s = rank s's values for my slice
-            good = torch.equal(got.cpu(), want)
-        except RuntimeError:                                      # (a backend without all_to_all raises on every rank alike)
-            good = False
-        ok = torch.tensor([1.0 if good else 0.0], device=device)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)    # every rank must take the same exchange form
-        if ok.item() != 1.0:
-            return "all-to-all self-check failed: falling back to the all-gather exchange"
+    a2a_expected = x.is_cuda and dist.get_backend(group) == "nccl" or not x.is_cuda
+    if a2a_expected and not a2a_available(x, group):
+        return "all-to-all self-check failed: falling back to the all-gather exchange"
     s = torch.tensor([rank + 1.0, 10.0], device=device)
     dist.all_reduce(s, op=dist.ReduceOp.SUM, group=group)
     assert s.tolist() == [world * (world + 1) / 2.0, 10.0 * world], "all-reduce(SUM) self-check failed"
@@ -241,7 +268,7 @@ def collective_selfcheck(device, group=None):
 def all_reduce_max(t, group=None):
     """MAX all-reduce of a small float tensor (the item-side maxima behind the bf16 filter's error bound: the bound must
     cover the items of EVERY shard, ops.score_topk_filtered)."""
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if active(group):
         t = t.clone()
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return t
@@ -249,7 +276,7 @@ def all_reduce_max(t, group=None):
 
 def all_reduce_scalar(value, device, group=None):
     t = torch.tensor([int(value)], dtype=torch.int64, device=device)
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if active(group):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return int(t.item())
 
@@ -257,6 +284,6 @@ def all_reduce_scalar(value, device, group=None):
 def max_over_ranks(seconds, device, group=None):
     """Timing helper for bench.py: the slowest rank defines the step time."""
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if active(group):
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return float(t.item())

@@ -260,7 +260,8 @@ class TensorRec(object):
         if not self.data_parallel:
             return False
         import torch.distributed as dist
-        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.process_group) > 1
+        from . import sharding
+        return sharding.active(self.process_group)
 
     def _device(self):
         N.require_gpu()
@@ -533,11 +534,10 @@ class TensorRec(object):
         # eager execution and replayed; see _GraphedStep
         graphed = {}
         self._graph_pool_owner = []          # graphs captured by this call (they share the first one's memory pool)
-        ops.DETERMINISTIC_GROUPING = bool(getattr(self, "deterministic", False))
-        try:
+        # (thread-local, previous mode restored on exit: two models fitting in different threads do not switch each other's
+        # grouping, and a predict_top_k elsewhere keeps the counting sort -- ADVICE r2)
+        with ops.deterministic_grouping(bool(getattr(self, "deterministic", False))):
             self._run_epochs(epochs, dev_batches, graphed, learning_rate, alpha, batched_alpha, n_sampled_items, verbose)
-        finally:
-            ops.DETERMINISTIC_GROUPING = False
 
     def _run_epochs(self, epochs, dev_batches, graphed, learning_rate, alpha, batched_alpha, n_sampled_items, verbose):
         for epoch in range(epochs):
@@ -904,8 +904,7 @@ class TensorRec(object):
             raise NotImplementedError("predict_top_k is not available for attention models: the softmax-weighted sum "
                                       "over tastes does not decompose into per-taste top-k lists; use predict_rank")
         import torch.distributed as dist
-        sharded = bool(item_sharded) and dist.is_available() and dist.is_initialized() and \
-            dist.get_world_size(self.process_group) > 1
+        sharded = bool(item_sharded) and sharding.active(self.process_group)
         method, floor_exchange = "auto", None
         if sharded:
             # every rank must take the same code path (the floor exchange is a collective): decide on the smallest shard

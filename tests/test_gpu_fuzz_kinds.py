@@ -1,0 +1,76 @@
+"""The data kinds of scripts/fuzz_cascade.py as tests ("run it in -m gpu with >= 2 seeds"): for every kind the
+exact top-k through the int8 -> bf16 -> fp32 cascade equals the all-fp32 MFMA path (values and ids), the int8 stage itself
+runs on the kinds it is meant to handle, and almost nobody is left to the fp32 MFMA fall-back.
+
+What each kind stresses:
+  gauss / normalised            the isotropic baseline of the bench
+  heavy_tail / sparse           element magnitudes spread over decades / 90% zeros: one int8 scale for all users is useless
+                                (round 2: "too loose" on 26 of 34 cases); user scale classes handle them
+  scaled_rows                   row norms spread over e^+-6: scale classes on the user side, hot superblocks on the item side
+  integers                      exact ties everywhere: ids follow tf.nn.top_k's lower-index-first order
+  popular_bias                  a Zipf catalogue: a few items with large norms and biases wanted by everybody (hot superblocks)
+  clustered256_10 / _03         256 clusters with within-cluster spread 1.0 / 0.3 of the centre scale: the int8 bound loosens,
+                                the wide second pass takes the users with many near-equal superblocks
+  clustered                     8 tight clusters (spread 0.05): thousands of items per user within the bf16 bound of the k-th
+                                best -- no filter can separate them; documented as the adversarial case: everybody goes to the
+                                fp32 MFMA path, the result stays exact"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+KINDS = ["gauss", "normalised", "heavy_tail", "sparse", "integers", "scaled_rows", "popular_bias", "clustered256_10",
+         "clustered256_03", "clustered"]
+INT8_MUST_RUN = {"gauss", "normalised", "heavy_tail", "sparse", "integers", "scaled_rows", "popular_bias", "clustered256_10"}
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from tensorrec_amd import ops as _ops, _native
+    _native.require_gpu()
+    _native.load()
+    return _ops
+
+
+def make(ops, kind, n, d, g):
+    x = torch.randn((n, d), device="cuda", generator=g)
+    if kind == "normalised": x = ops.l2_normalize_rows(x)
+    elif kind == "heavy_tail": x = x * torch.exp(1.5 * torch.randn((n, d), device="cuda", generator=g))
+    elif kind == "sparse": x = x * (torch.rand((n, d), device="cuda", generator=g) < 0.1)
+    elif kind == "integers": x = torch.round(x * 2)
+    elif kind == "clustered": x = torch.randn((8, d), device="cuda", generator=g)[torch.randint(0, 8, (n,), device="cuda", generator=g)] + 0.05 * x
+    elif kind.startswith("clustered256_"):
+        x = torch.randn((256, d), device="cuda", generator=g)[torch.randint(0, 256, (n,), device="cuda", generator=g)] + float(kind.split("_")[1]) / 10.0 * x
+    elif kind == "scaled_rows": x = x * torch.exp(2.0 * torch.randn((n, 1), device="cuda", generator=g))
+    return x.contiguous()
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+@pytest.mark.parametrize("kind", KINDS)
+def test_cascade_exact_on_every_data_kind(ops, kind, seed):
+    g = torch.Generator(device="cuda")
+    g.manual_seed(1000 * seed + KINDS.index(kind))
+    n_u, n_i, d, k = 1536, 300_000, (128 if seed == 1 else 64), 10
+    u, v = make(ops, kind, n_u, d, g), make(ops, kind, n_i, d, g)
+    ub = ib = None
+    if kind == "popular_bias":
+        pop = torch.log1p(1e4 / torch.arange(1, n_i + 1, device="cuda").float())[torch.randperm(n_i, device="cuda", generator=g)]
+        v = (v * (0.3 + pop / pop.max()).unsqueeze(1)).contiguous()
+        ib = (2.0 * pop).contiguous()
+        ub = torch.randn(n_u, device="cuda", generator=g)
+    elif seed == 2:
+        scale = float(v.abs().mean() * u.abs().mean() * d ** 0.5)
+        ub = torch.randn(n_u, device="cuda", generator=g) * scale * 0.3
+        ib = torch.randn(n_i, device="cuda", generator=g) * scale * 0.3
+    uref = ops.score_prep_filter(u)
+    iop = ops.score_prep_filter(v, bias=ib, want_gstats=True)
+    ev, ei = ops.score_topk(uref.f32, iop.f32, ops.DTYPE_F32, uref.kpad, k, ub, ib, ops.MODE_DOT, method="two_stage")
+    uop = ops.score_prep_filter(u, sort_users=True)
+    fv, fi = ops.score_topk_filtered(uop, iop, k, ub, ib, prefilter="int8")
+    stats = dict(ops.LAST_FILTER_STATS)
+    assert torch.equal(fi, ei) and torch.equal(fv, ev), (kind, stats)
+    if kind in INT8_MUST_RUN:
+        assert stats.get("prefilter") == "int8", (kind, stats)
+    if kind != "clustered":
+        assert stats.get("users_on_fp32_fallback", 0) <= max(1, n_u // 100), (kind, stats)     # <= 1% of the users

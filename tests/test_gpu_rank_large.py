@@ -115,6 +115,30 @@ def test_rankcount_fused_bit_exact_vs_oracle(ops, d, biased, integer):
     assert np.array_equal((c0 + c1).cpu().numpy(), counts)
 
 
+def test_rankcount_targets_scoring_minus_infinity(ops):
+    """Items masked out with a -inf bias score -inf for every user; a TARGET among them ties with all the others and the
+    lower-index ones precede it (tf.nn.top_k's order) -- also in item blocks wholly below the target's index, where the kernel
+    counts s >= t as s > float_pred(t) and float_pred(-inf) = -inf."""
+    rng = np.random.default_rng(17)
+    n_users, n_items, d = 64, 20_000, 64
+    u = rng.standard_normal((n_users, d)).astype(np.float32)
+    v = rng.standard_normal((n_items, d)).astype(np.float32)
+    ub = rng.standard_normal(n_users).astype(np.float32)
+    ib = rng.standard_normal(n_items).astype(np.float32)
+    masked = np.sort(rng.permutation(n_items)[:400])
+    ib[masked] = -np.inf
+    per_user = 6
+    xi = np.stack([np.concatenate([rng.permutation(masked)[:3], rng.permutation(n_items)[:3]]) for _ in range(n_users)])
+    xi = np.sort(xi, axis=1).reshape(-1).astype(np.int32)
+    xu = np.repeat(np.arange(n_users), per_user)
+    indptr = np.arange(0, (n_users + 1) * per_user, per_user, dtype=np.int64)
+    u_op, _, kpad = ops.score_prep(dev(u), ops.DTYPE_F32)
+    v_op, _, _ = ops.score_prep(dev(v), ops.DTYPE_F32)
+    counts = ops.rank_counts_fused(u_op, v_op, kpad, d, indptr, dev(xi), dev(ub), dev(ib)).cpu().numpy()
+    ref = O.rank_predictions_exact(O.score_dense_exact(u, v, ub, ib))
+    assert np.array_equal(counts + 1, ref[xu, xi])
+
+
 def test_rankcount_matches_slab_path_for_cosine_and_euclidean(ops):
     """cosine / Euclidean scores have no bit-exact oracle (normalisation / sqrt rounding); the fused counts must equal the
     ranks of the score matrix the STORE kernel writes from the same operands (what predict_rank ranks)."""
