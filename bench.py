@@ -349,7 +349,7 @@ def main():
                 ib = None if args.unbiased else ops.sparse_matvec(f_i, beta_i)
                 if exact and method == "two_stage":
                     # fp32-exact top-k: bf16 MFMA stage 1 as an error-bounded filter, survivors re-scored in fp32
-                    u_f = ops.score_prep_filter(user_repr, sort_users=prefilter == "int8")     # users sorted by int8 scale class
+                    u_f = ops.score_prep_filter(user_repr, sort_users=prefilter == "int8", k=k)     # users sorted by int8 scale class
                     i_f = ops.score_prep_filter(item_repr, bias=ib, want_gstats=True)
                     vals, idx = ops.score_topk_filtered(
                         u_f, i_f, k, ub, ib, item_index_base=i_begin, variant=args.variant,

@@ -35,7 +35,7 @@ for c in range(n_cases):
     ev, ei = ops.score_topk(uop.f32, iop.f32, ops.DTYPE_F32, uop.kpad, k, ub, ib, ops.MODE_DOT, method="two_stage")
     out = {"case": c, "kind": kind, "d": d, "k": k, "users": n_u, "items": n_i, "biased": biased}
     for name, pre in (("bf16_filter", None), ("cascade", "int8")):
-        uo = ops.score_prep_filter(u, sort_users=True) if pre == "int8" else uop
+        uo = ops.score_prep_filter(u, sort_users=True, k=k) if pre == "int8" else uop
         fv, fi = ops.score_topk_filtered(uo, iop, k, ub, ib, prefilter=pre)
         ok = bool(torch.equal(fi, ei) and torch.equal(fv, ev))
         out[name] = ok

@@ -958,14 +958,16 @@ class FilterOperand(object):
     and on the item side ``bias_q`` int32 [n], ``sb_stats`` [n_sb, 4] = per superblock of ``sb_rows`` items {scale, max
     ||y|| + ||dy||, max ||dy||, max bias quantisation error}, ``gstats8`` [4] ([2] = max |bias|), ``scales`` [3] ([0] = user scale)."""
     __slots__ = ("bf16", "f32", "n", "d", "kpad", "stats", "gstats", "i8", "stats8", "bias_q", "gstats8", "scales",
-                 "sb_stats", "sb_rows", "cascade_too_loose", "perm", "nat", "gmax", "cls", "wg_scale", "wg_class", "wg_rows")
+                 "sb_stats", "sb_rows", "cascade_too_loose", "perm", "nat", "gmax", "cls", "wg_scale", "wg_class", "wg_rows", "pos",
+                 "order", "pad")
 
     def __init__(self):
         self.i8 = self.stats8 = self.bias_q = self.gstats8 = self.scales = self.sb_stats = self.sb_rows = None
         self.cascade_too_loose = False      # set on the item side when the int8 bound did not pay for this catalogue
         # users sorted by int8 scale class (score_prep_filter(sort_users=True)): row r of every array here is row perm[r] of
         # the caller's representation; nat / cls = the scale each row wants and its class, gmax = the largest (device scalars)
-        self.perm = self.nat = self.gmax = self.cls = self.wg_scale = self.wg_class = self.wg_rows = None
+        self.perm = self.nat = self.gmax = self.cls = self.wg_scale = self.wg_class = self.wg_rows = self.pos = self.order = None
+        self.pad = None                     # bool [n]: padding rows (their thresholds are +inf: they keep nothing)
 
 
 I8_CLASSES_PER_OCTAVE = 4         # user scale classes: a geometric ladder below the largest wanted scale, 2^(1/4) apart
@@ -976,15 +978,23 @@ def i8_user_classes_enabled():
     return N.load().trec_get_tuning(b"i8_user_classes", 1) != 0
 
 
-def score_prep_filter(repr_, normalize=False, bias=None, want_gstats=False, sort_users=False):
+I8_CLASS_BAND = 2                 # classes per band: the users of one int8 workgroup come from ONE band (scales within 2^(1/2))
+
+
+def score_prep_filter(repr_, normalize=False, bias=None, want_gstats=False, sort_users=False, k=10):
     """``sort_users`` (the USER side of score_topk_filtered with the int8 pre-filter): the rows are first sorted by the int8
-    scale class each wants (trec_score_row_scale_i8; largest scales first, stable) so that the rows of one int8 workgroup
-    share a scale -- every array of the result is in that order and ``perm`` maps its rows back (score_topk_filtered
-    permutes the user biases and un-permutes its results)."""
+    scale class each wants (trec_score_row_scale_i8; largest scales first, stable) and laid out so that the ``wg_rows`` rows
+    of one int8 workgroup come from one BAND of I8_CLASS_BAND adjacent classes -- every band's rows are padded to whole
+    workgroups with rows that keep nothing (``pad``: their thresholds are +inf; at most 32 bands x (wg_rows - 1) of them, 0.2% of
+    1M Gaussian users).  Every array of the result is in that layout: ``perm`` [n] maps its rows to the
+    caller's rows, ``pos`` [n_real] gives the row of the i-th sorted user, ``order`` [n_real] the caller's row of that user
+    (score_topk_filtered permutes the user biases and un-permutes its results).  ``k``: the top-k this operand is for (the
+    int8 kernel's workgroup covers 768 users for k <= 10, 512 above).  One host read (the padded row count)."""
     x = _f32c(repr_.detach())
     n, d = x.shape
     kpad = score_kpad(d)
-    perm = nat = gmax = cls = None
+    perm = nat = gmax = cls = pos = order = pad = None
+    wg_rows = None
     if sort_users and kpad <= 128 and n > 0 and i8_user_classes_enabled():
         nat = torch.empty((n,), dtype=torch.float32, device=x.device)
         gmax = torch.zeros((1,), dtype=torch.float32, device=x.device)
@@ -996,12 +1006,29 @@ def score_prep_filter(repr_, normalize=False, bias=None, want_gstats=False, sort
             g = torch.where(gmax > 0, gmax, torch.ones_like(gmax))
             cls = torch.floor(I8_CLASSES_PER_OCTAVE * torch.log2(g / nat)).clamp_(0, I8_N_CLASSES - 1)
             cls = torch.nan_to_num(cls, nan=0.0).to(torch.int32)          # (a non-finite row poisons gmax: everything is flagged later)
-            cls, perm = torch.sort(cls, stable=True)
+            cls_s, order = torch.sort(cls, stable=True)
+            wg_rows = int(N.query("trec_score_blockmax_i8_rows_per_workgroup", 10 if int(k) <= 10 else 16))
+            n_bands = (I8_N_CLASSES + I8_CLASS_BAND - 1) // I8_CLASS_BAND
+            band = torch.div(cls_s, I8_CLASS_BAND, rounding_mode="floor").long()
+            counts = torch.bincount(band, minlength=n_bands)
+            padded = (counts + wg_rows - 1) // wg_rows * wg_rows
+            start = torch.cumsum(counts, 0) - counts
+            pstart = torch.cumsum(padded, 0) - padded
+            pos = pstart[band] + (torch.arange(n, device=x.device) - start[band])
+            n_pad = int(padded.sum().item())                             # the one host read of the user-side preparation
+            slot = torch.full((n_pad,), -1, dtype=torch.int64, device=x.device)
+            slot[pos] = torch.arange(n, device=x.device)
+            pad = slot < 0                                               # padding rows keep nothing: their thresholds are set to
+            slot = slot.clamp_(min=0)                                    # +inf after every selection (their content -- a copy of
+            perm = order[slot]                                           # the first sorted user -- never matters)
             x = x.index_select(0, perm)
             nat = nat.index_select(0, perm)
+            cls = torch.where(pad, torch.full_like(cls_s[:1], I8_N_CLASSES - 1).expand(n_pad), cls_s[slot]).contiguous()
             gmax = g
+            n = n_pad
+            pad = pad if n_pad > int(order.numel()) else None
     op = FilterOperand()
-    op.perm, op.nat, op.gmax, op.cls = perm, nat, gmax, cls
+    op.perm, op.nat, op.gmax, op.cls, op.pos, op.order, op.wg_rows, op.pad = perm, nat, gmax, cls, pos, order, wg_rows, pad
     op.n, op.d, op.kpad = n, d, kpad
     own_f32 = normalize or kpad != d
     op.f32 = torch.empty((n, kpad), dtype=torch.float32, device=x.device) if own_f32 else x
@@ -1087,8 +1114,10 @@ def score_prep_i8_pair(uop, iop, item_bias=None, sb_rows=None, top_k=10):
         uop.stats8 = torch.empty((uop.n, 2), dtype=torch.float32, device=dev)
         if classes:
             wg_rows = int(N.query("trec_score_blockmax_i8_rows_per_workgroup", int(top_k)))
+            if wg_rows != uop.wg_rows:
+                raise ValueError("the user operand was laid out for int8 workgroups of %s rows, this call needs %d "
+                                 "(score_prep_filter(sort_users=True, k=...) must be given the same k)" % (uop.wg_rows, wg_rows))
             ladder = uop.gmax * torch.exp2(torch.arange(I8_N_CLASSES, device=dev, dtype=torch.float32) / (-float(I8_CLASSES_PER_OCTAVE)))
-            uop.wg_rows = wg_rows
             uop.wg_class = uop.cls[::wg_rows].contiguous()                 # rows are sorted by class: the first is the largest scale
             uop.wg_scale = ladder[uop.wg_class.long()].contiguous()
             N.call("trec_score_prep_i8_users", N.ptr(uop.f32), uop.n, uop.f32.shape[1], uop.kpad, N.ptr(uop.wg_scale), wg_rows,
@@ -1101,7 +1130,7 @@ def score_prep_i8_pair(uop, iop, item_bias=None, sb_rows=None, top_k=10):
                 N.call("trec_score_bias_i8_classes", N.ptr(item_bias), iop.n, sb_rows, N.ptr(ladder), N.ptr(used), I8_N_CLASSES,
                        N.ptr(iop.sb_stats), N.ptr(iop.bias_q), N.ptr(iop.gstats8))
         else:
-            uop.wg_rows = uop.wg_class = uop.wg_scale = None
+            uop.wg_class = uop.wg_scale = None
             ws = torch.empty((2,), dtype=torch.float64, device=dev)
             clip = N.load().trec_get_tuning(b"i8_user_clip_x10", int(I8_USER_CLIP_SIGMAS * 10)) / 10.0
             N.call("trec_score_prep_i8", N.ptr(uop.f32), uop.n, uop.f32.shape[1], uop.kpad, 0, float(clip), 0, None,
@@ -1138,7 +1167,7 @@ def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, 
         gstats8 = stats_exchange(gstats8).contiguous()
     user_err = torch.empty((n_u, 4), dtype=torch.float32, device=dev)
     N.call("trec_score_user_err_i8", N.ptr(uop.stats8), N.ptr(user_bias), N.ptr(gstats8), kpad, n_u, N.ptr(iop.scales),
-           N.ptr(uop.wg_scale), int(uop.wg_rows or 0), N.ptr(user_err))
+           N.ptr(uop.wg_scale), int(uop.wg_rows or 0) if uop.wg_scale is not None else 0, N.ptr(user_err))
     stride = (n_u + 3) // 4 * 4
     _, n_ch = blockmax_i8_chunks(n_i, n_chunks, sb_rows)
     table = torch.empty((n_sb, stride), dtype=torch.float32, device=dev)
@@ -1156,6 +1185,8 @@ def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, 
                N.ptr(tau))
     if floor_exchange is not None:
         tau = floor_exchange(sel_max).contiguous()
+    if uop.pad is not None:
+        tau.masked_fill_(uop.pad, float("inf"))         # padding rows refine nothing
     status = torch.empty((2,), dtype=torch.int64, device=dev)
     if N.load().trec_get_tuning(b"cascade_rows_onepass", 1) != 0 and N.load().trec_get_tuning(b"blockmax_bf16_mfma16", 1) != 0:
         # one pass over the table: a fixed capacity per superblock, slots handed out by atomics (csrc/topk_cascade.hip)
@@ -1308,9 +1339,13 @@ def score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index_
     ub = user_bias.index_select(0, uop.perm) if user_bias is not None else None
     sv, si = _score_topk_filtered(uop, iop, k, ub, item_bias, item_index_base, sb_rows, variant, n_chunks,
                                   floor_exchange, stats_exchange, ksel, prefilter)
-    ov, oi = torch.empty_like(sv), torch.empty_like(si)
-    ov.index_copy_(0, uop.perm, sv)
-    oi.index_copy_(0, uop.perm, si)
+    n_real = int(uop.order.numel())
+    ov = torch.empty((n_real, sv.shape[1]), dtype=sv.dtype, device=sv.device)
+    oi = torch.empty((n_real, si.shape[1]), dtype=si.dtype, device=si.device)
+    ov.index_copy_(0, uop.order, sv.index_select(0, uop.pos))            # (the padding rows are dropped)
+    oi.index_copy_(0, uop.order, si.index_select(0, uop.pos))
+    LAST_FILTER_STATS["users"] = n_real
+    LAST_FILTER_STATS["padding_rows"] = int(uop.n) - n_real
     return ov, oi
 
 
@@ -1390,6 +1425,8 @@ def _score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index
     n_flagged = torch.zeros((1,), dtype=torch.int32, device=dev)
     N.call("trec_topk_filter_floor", N.ptr(tau), N.ptr(uop.stats), N.ptr(user_bias), N.ptr(gstats), kpad, n_u,
            N.ptr(floor), N.ptr(flag), N.ptr(n_flagged))
+    if uop.pad is not None:
+        floor.masked_fill_(uop.pad, float("inf"))       # padding rows keep nothing: no lists, no survivors, never flagged
     if FILTER_DEBUG is not None:
         FILTER_DEBUG["flagged_after_floor"] = int(n_flagged.item())
     ov, oi, count = _filter_tail(uop, iop, blockmax, bm_stride, n_u, n_sb, k, user_bias, item_bias, item_index_base, sb_rows,

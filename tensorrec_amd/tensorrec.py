@@ -963,7 +963,7 @@ class TensorRec(object):
                 for user_repr in user_reprs:
                     if filtered:
                         u_f = ops.score_prep_filter(user_repr[s:e], normalize=graph.engine_normalize,
-                                                    sort_users=prefilter == "int8")
+                                                    sort_users=prefilter == "int8", k=k)
                         per_taste.append(ops.score_topk_filtered(u_f, i_f, k, ub, ib, item_index_base=int(item_offset),
                                                                  floor_exchange=floor_exchange,
                                                                  stats_exchange=stats_exchange, prefilter=prefilter))

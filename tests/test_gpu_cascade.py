@@ -33,7 +33,7 @@ def run_cascade(ops, u, v, k, ub=None, ib=None, normalize=False, sort_users=True
     du, dv = dev(u), dev(v)
     dub = dev(ub) if ub is not None else None
     dib = dev(ib) if ib is not None else None
-    uop = ops.score_prep_filter(du, normalize=normalize, sort_users=sort_users)
+    uop = ops.score_prep_filter(du, normalize=normalize, sort_users=sort_users, k=k)
     iop = ops.score_prep_filter(dv, normalize=normalize, bias=dib, want_gstats=True)
     vals, idx = ops.score_topk_filtered(uop, iop, k, dub, dib, prefilter="int8", **kw)
     return vals.cpu().numpy(), idx.cpu().numpy(), dict(ops.LAST_FILTER_STATS), uop, iop
@@ -456,7 +456,7 @@ def test_cascade_hot_superblocks_of_a_popular_catalogue(ops):
     rv, ri = O.topk_rows(O.score_dense_exact(u, v, ub, ib), k)
     assert np.array_equal(idx, ri) and np.array_equal(vals, rv)
     assert stats["prefilter"] == "int8", stats            # the cascade ran: hot rows did not overflow it
-    assert dbg["hot_superblocks"] >= 10, dbg              # ... and there were hot rows
+    assert dbg["hot_superblocks"] >= 3, dbg               # ... and there were hot rows (wanted by > 1,024 of the 2,100 users)
     assert dbg["int8_pairs_wanted"] < 0.2 * dbg["int8_pairs_total"]
 
 
