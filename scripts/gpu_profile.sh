@@ -4,16 +4,16 @@ set +e
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; REPO=$PWD; OUT=$REPO/gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp
 TAG=${1:-r01}
 timeout 900 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err; echo "bench rc=$?"; cat $OUT/${TAG}_bench.json
-( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o $TAG -- python $REPO/bench.py --no-cpu-baseline --no-fit > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/${TAG}_prof.err ); echo "rocprof rc=$?"
+( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o $TAG -- python $REPO/bench.py --configs headline --no-cpu-baseline --no-fit > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/${TAG}_prof.err ); echo "rocprof rc=$?"
 f=$(find $OUT/${TAG}_prof -name "*kernel_stats.csv" | head -1); cp $f $OUT/${TAG}_kernel_stats.csv 2>/dev/null; head -12 $OUT/${TAG}_kernel_stats.csv | cut -c1-200
 for s in "FETCH_SIZE" "WRITE_SIZE TCC_HIT TCC_MISS" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES"; do
   n=$(echo $s | cut -d' ' -f1)
-  ( cd /tmp && timeout 900 rocprofv3 --pmc $s --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_$n -o pmc -- python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-fit > /dev/null 2> $OUT/${TAG}_pmc_$n.err ); echo "pmc $n rc=$?"
+  ( cd /tmp && timeout 900 rocprofv3 --pmc $s --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_$n -o pmc -- python $REPO/bench.py --configs headline --steps 1 --warmup 0 --no-cpu-baseline --no-fit --no-fp32-mode --no-k1-multi --parity-users 64 > /dev/null 2> $OUT/${TAG}_pmc_$n.err ); echo "pmc $n rc=$?"
 done
 python - <<PY
 import csv, glob, collections
 out=open("$OUT/${TAG}_pmc_summary.txt","w")
-out.write("# rocprofv3 --pmc <set> --kernel-trace -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-fit ; per-dispatch averages\n")
+out.write("# rocprofv3 --pmc <set> --kernel-trace -- python bench.py --configs headline --steps 1 --warmup 0 --no-cpu-baseline --no-fit --no-fp32-mode --no-k1-multi --parity-users 64 ; per-dispatch averages\n")
 out.write("# FETCH_SIZE / WRITE_SIZE are in KB as reported; on gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md)\n")
 for f in sorted(glob.glob("$OUT/${TAG}_pmc_*/**/*counter_collection.csv", recursive=True)):
     agg=collections.defaultdict(lambda: collections.defaultdict(float)); seen=set()
@@ -21,7 +21,7 @@ for f in sorted(glob.glob("$OUT/${TAG}_pmc_*/**/*counter_collection.csv", recurs
         k=r["Kernel_Name"][:70]; agg[k][r["Counter_Name"]]+=float(r["Counter_Value"]); seen.add((k,r["Dispatch_Id"]))
     cnt=collections.Counter(k for k,_ in seen)
     for k in agg:
-        if any(x in k for x in ("score_gemm","blockmax_pipe","spmm_csr","topk","select_blocks","fill_groups","score_prep","seg_")):
+        if any(x in k for x in ("score_gemm","blockmax","spmm","topk","select_blocks","collect_blocks","rows_","fill_groups","prep_","filter_","seg_","natscale","bias_i8")):
             out.write("%s | dispatches=%d | "%(k,cnt[k])+" ".join("%s=%.5g"%(c,v/cnt[k]) for c,v in sorted(agg[k].items()))+"\n")
 out.close(); print(open("$OUT/${TAG}_pmc_summary.txt").read())
 PY

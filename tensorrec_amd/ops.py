@@ -1148,7 +1148,7 @@ def blockmax_i8_chunks(n_items, n_chunks, sb_rows):
     return chunk_len, -(-n_items // chunk_len)
 
 
-def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, floor_exchange, stats_exchange):
+def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, floor_exchange, stats_exchange, gstats_all=None):
     """Stages 0-1 of the int8 -> bf16 -> fp32 cascade (csrc/topk_cascade.hip): the [n_sb, n_users] table of superblock
     maxima whose entries are bf16 maxima wherever a top-k item can be and int8 maxima elsewhere (None after an overflow), its
     row stride, and (resident rows of the bf16 launches, overflow).  Every superblock has a list of CASCADE_ROW_CAPACITY of the
@@ -1163,8 +1163,9 @@ def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, 
     if uop.i8 is None or iop.i8 is None or iop.sb_rows != sb_rows:
         score_prep_i8_pair(uop, iop, item_bias, sb_rows, top_k)
     gstats8 = iop.gstats8
-    if stats_exchange is not None:                  # max |item bias| over ALL shards enters every user's bound
-        gstats8 = stats_exchange(gstats8).contiguous()
+    if stats_exchange is not None:                  # max |item bias| over ALL shards enters every user's bound: the same number
+        gstats8 = gstats8.clone()                   # the bf16 filter's statistics carry (gstats[2]), already MAX-reduced
+        gstats8[2] = gstats_all[2] if gstats_all is not None else stats_exchange(gstats8)[2]
     user_err = torch.empty((n_u, 4), dtype=torch.float32, device=dev)
     N.call("trec_score_user_err_i8", N.ptr(uop.stats8), N.ptr(user_bias), N.ptr(gstats8), kpad, n_u, N.ptr(iop.scales),
            N.ptr(uop.wg_scale), int(uop.wg_rows or 0) if uop.wg_scale is not None else 0, N.ptr(user_err))
@@ -1379,11 +1380,15 @@ def _score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index
         n_chunks = max(1, min(n_sb, -(-32 * 768 // rblocks)))
     LAST_FILTER_STATS.clear()
     blockmax, bm_stride, cascade_status = None, n_u, None
+    # item shards: the item-side maxima behind both bounds (norms, rounding-error norms, |bias|) are MAX-reduced ONCE per call
+    gstats = iop.gstats
+    if stats_exchange is not None:
+        gstats = stats_exchange(gstats).contiguous()
     if prefilter == "int8" and kpad in (64, 128) and sb_rows % 128 == 0 and not (iop.cascade_too_loose and
                                                                                  floor_exchange is None):
         # ---- stages 0 + 1: int8 maxima everywhere, bf16 maxima where a top-k item can be
         blockmax, bm_stride, cascade_status = _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks,
-                                                              floor_exchange, stats_exchange)
+                                                              floor_exchange, stats_exchange, gstats)
         rows, overflow = cascade_status
         if overflow:
             # the int8 bound was too loose for this data: nothing was refined.  bf16 does stage 1; the next user batches
@@ -1414,11 +1419,8 @@ def _score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index
     with _timed("topk_select_blocks"):
         N.call("trec_topk_select_blocks", N.ptr(blockmax), n_sb, n_u, bm_stride, kk, N.ptr(sel), N.ptr(sel_max),
                N.ptr(tau))
-    gstats = iop.gstats
     if floor_exchange is not None:                  # item shards: the k-th largest maximum over ALL shards
         tau = floor_exchange(sel_max).contiguous()
-    if stats_exchange is not None:
-        gstats = stats_exchange(gstats).contiguous()
     # ---- floor = tau - 2 eps (proven bound, csrc/topk_filter.hip); pass 2: every superblock reaching the floor
     floor = torch.empty((n_u,), dtype=torch.float32, device=dev)
     flag = torch.empty((n_u,), dtype=torch.int32, device=dev)
