@@ -328,10 +328,13 @@ __global__ __launch_bounds__(256, WPS) void blockmax_pipe_kernel(ScoreParams p)
 // this form serves the FILTERS only (K2f / K2c: their bound charges every addition of the chain, in any order); the plain
 // bf16 two-stage top-k, whose stage 3 must reproduce stage 1's maxima bit for bit, keeps the 32x32x16 kernel.
 // GRP: the grouped launch of the cascade (one superblock per workgroup, rows through row_index), as in blockmax_pipe_kernel.
-template <int KT, bool BIAS, bool GRP>
-__global__ __launch_bounds__(256, 2) void blockmax_bf16x16_kernel(ScoreParams p)
+// NUB: 16-user blocks per wave (8: 128 users, 512 per workgroup, 2 workgroups per CU; 4: 64 users, 256 per workgroup, 3 per CU --
+// the grouped form's alternative: its workgroups start with a dependent gather of their user rows, and more of them in flight
+// hide more of that latency, at twice the item-tile reads per flop)
+template <int KT, bool BIAS, bool GRP, int NUB = 8>
+__global__ __launch_bounds__(256, NUB == 8 ? 2 : 3) void blockmax_bf16x16_kernel(ScoreParams p)
 {
-    constexpr int NUB = 8;                   // 16-user blocks per wave
+    constexpr int RW = 4 * NUB * 16;         // resident rows per workgroup
     constexpr int OW = NUB / 4;
     constexpr int RB = KT * 2;               // bytes per operand row
     constexpr int CH = RB / 16;              // 16-byte chunks per row (16 at K = 128, 8 at K = 64)
@@ -349,7 +352,15 @@ __global__ __launch_bounds__(256, 2) void blockmax_bf16x16_kernel(ScoreParams p)
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, lu = lane & 15;
-    const int rblock = GRP ? (int)blockIdx.x : (int)(blockIdx.x % p.n_rblocks);
+    int rblock = GRP ? (int)blockIdx.x : (int)(blockIdx.x % p.n_rblocks);
+    if (GRP && p.capacity > 0 && p.grp_band_major) {
+        // fixed-capacity layout walked band-major: consecutive workgroups take list chunk j of superblocks 0, 1, 2, ... -- the
+        // users of chunk j of every superblock's (roughly ascending) list lie in one band of ~512 / (kept fraction) users, so
+        // the 128 KB of gathered user rows of the workgroups running together come from L2 instead of 256-byte random reads
+        // of the 256 MB table, and the operand that misses is the item superblock: a sequential, double-buffered stream
+        const int n_sb_g = p.n_rblocks / p.capacity;
+        rblock = (int)(blockIdx.x % n_sb_g) * p.capacity + (int)(blockIdx.x / n_sb_g);
+    }
     // grouped launch, two layouts: a list (rblock_chunk[w] = the superblock of workgroup w, -1 = idle, padding rows -1 in
     // row_index) or fixed capacity (p.capacity workgroups per superblock, rblock_chunk = the superblocks' row counts)
     // dense launch over a LIST of superblocks (the cascade's "hot" superblocks -- kept by more users than the fixed capacity
@@ -357,11 +368,11 @@ __global__ __launch_bounds__(256, 2) void blockmax_bf16x16_kernel(ScoreParams p)
     const bool fixed = GRP && p.capacity > 0;
     const int chunk = !GRP ? (p.rblock_chunk ? p.rblock_chunk[blockIdx.x / p.n_rblocks] : (int)(blockIdx.x / p.n_rblocks))
                            : (fixed ? rblock / p.capacity : p.rblock_chunk[rblock]);
-    int rows_here = 512;                                         // fixed layout: valid rows of this workgroup
+    int rows_here = RW;                                          // fixed layout: valid rows of this workgroup
     if (fixed) {
         int cnt = p.rblock_chunk[chunk];
-        if (cnt > p.capacity * 512) cnt = p.capacity * 512;
-        rows_here = cnt - (rblock % p.capacity) * 512;
+        if (cnt > p.capacity * RW) cnt = p.capacity * RW;
+        rows_here = cnt - (rblock % p.capacity) * RW;
     }
     if (chunk < 0 || (GRP && rows_here <= 0)) return;            // idle workgroup of a grouped / listed launch
     const int64_t r_base = ((int64_t)rblock * 4 + wave) * (NUB * 16);
@@ -512,17 +523,19 @@ __global__ __launch_bounds__(256, 2) void blockmax_bf16x16_kernel(ScoreParams p)
     }
 }
 
-template <int KT, bool BIAS, bool GRP>
+template <int KT, bool BIAS, bool GRP, int NUB = 8>
 int launch_bf16x16(ScoreParams p, hipStream_t st)
 {
     constexpr int LDS = 2 * BN * KT * 2 + 2 * BN * 4;
-    auto kern = blockmax_bf16x16_kernel<KT, BIAS, GRP>;
+    constexpr int RW = 4 * NUB * 16;
+    auto kern = blockmax_bf16x16_kernel<KT, BIAS, GRP, NUB>;
     static bool attr_set = false;
     if (!attr_set && LDS > 32 * 1024) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
-    p.n_rblocks = GRP ? (int)(p.n_r / 512) : (int)ceil_div64(p.n_r, 512);
+    if (GRP && p.capacity > 0) p.capacity = p.capacity * 512 / RW;           // the caller counts a superblock's list in 512-row units
+    p.n_rblocks = GRP ? (int)(p.n_r / RW) : (int)ceil_div64(p.n_r, RW);
     const unsigned blocks = GRP ? (unsigned)p.n_rblocks : (unsigned)p.n_rblocks * (unsigned)p.n_chunks;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), LDS, st, p);
     return trec_check_launch(GRP ? "trec_score_gemm_blockmax_grouped (16x16x32)" : "trec_score_gemm_blockmax (16x16x32)");
@@ -753,6 +766,8 @@ int launch_blockmax_pipelined_grouped(const ScoreParams& p, int kt, hipStream_t 
 {
     const bool bias = p.r_bias || p.t_bias;
     if (trec_get_tuning("blockmax_bf16_mfma16", 1) != 0) {       // the 16x16x32 form (filters only: see blockmax_bf16x16_kernel)
+        if (kt == 128 && p.capacity > 0 && trec_get_tuning("cascade_grouped_nub", 8) == 4)
+            return bias ? launch_bf16x16<128, true, true, 4>(p, st) : launch_bf16x16<128, false, true, 4>(p, st);
         if (kt == 128) return bias ? launch_bf16x16<128, true, true>(p, st) : launch_bf16x16<128, false, true>(p, st);
         if (kt == 64) return bias ? launch_bf16x16<64, true, true>(p, st) : launch_bf16x16<64, false, true>(p, st);
     }

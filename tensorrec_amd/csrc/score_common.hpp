@@ -39,6 +39,8 @@ struct ScoreParams {
     const float* wg_scale;         // nullable [n_rblocks]: the user scale of workgroup rblock (else scales[0])
     const int32_t* wg_class;       // nullable [n_rblocks]: its class -> item biases t_bias + wg_class * bias_stride
     int64_t bias_stride;
+    int grp_band_major;            // grouped bf16 BLOCKMAX, fixed-capacity layout: workgroup order (list chunk j, superblock s) instead of
+                                   // (s, j): the workgroups running together share a band of users (their rows come from L2)
     float* chunk_top;              // int8 BLOCKMAX: [n_chunks * top_k][bm_stride]: the top_k largest LOWER BOUNDS of a chunk per user
     int top_k;
 };

@@ -507,5 +507,6 @@ extern "C" int trec_score_gemm_blockmax_grouped(const void* users_bf16, const vo
     p.r_bias = user_bias; p.t_bias = item_bias;
     p.blockmax = blockmax; p.bm_stride = bm_stride; p.sb_tiles = sb_rows / 64;
     p.rblock_chunk = rblock_chunk; p.row_index = row_user; p.capacity = wgs_per_row;
+    p.grp_band_major = trec_get_tuning("cascade_band_major", 0);      // measured slower (8.25 vs 6.83 ms at 1M x 1M): see DESIGN 5d
     return launch_blockmax_pipelined_grouped(p, kpad, (hipStream_t)stream);
 }

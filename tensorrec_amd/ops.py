@@ -1117,7 +1117,8 @@ def score_prep_i8_pair(uop, iop, item_bias=None, sb_rows=None, top_k=10):
             if wg_rows != uop.wg_rows:
                 raise ValueError("the user operand was laid out for int8 workgroups of %s rows, this call needs %d "
                                  "(score_prep_filter(sort_users=True, k=...) must be given the same k)" % (uop.wg_rows, wg_rows))
-            ladder = uop.gmax * torch.exp2(torch.arange(I8_N_CLASSES, device=dev, dtype=torch.float32) / (-float(I8_CLASSES_PER_OCTAVE)))
+            # (torch.pow, not torch.exp2: exp2 is a jiterator kernel that is compiled at first use in every process)
+            ladder = uop.gmax * torch.pow(2.0, torch.arange(I8_N_CLASSES, device=dev, dtype=torch.float32) / (-float(I8_CLASSES_PER_OCTAVE)))
             uop.wg_class = uop.cls[::wg_rows].contiguous()                 # rows are sorted by class: the first is the largest scale
             uop.wg_scale = ladder[uop.wg_class.long()].contiguous()
             N.call("trec_score_prep_i8_users", N.ptr(uop.f32), uop.n, uop.f32.shape[1], uop.kpad, N.ptr(uop.wg_scale), wg_rows,
