@@ -2,7 +2,7 @@
 set +e
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; OUT=gpurun_out; mkdir -p $OUT
 true
-for T in "cascade_grouped_nub=8" "cascade_grouped_nub=4" "cascade_grouped_nub=8" "cascade_grouped_nub=4"; do
+for T in "blockmax_i8_rdlate=0" "blockmax_i8_rdlate=1" "blockmax_i8_rdlate=2" "blockmax_i8_rdlate=3" "blockmax_i8_rdlate=1" "blockmax_i8_rdlate=2" "blockmax_i8_rdlate=3"; do
 ( timeout 600 python bench.py --configs headline --no-fit --no-cpu-baseline --no-k1-multi --no-fp32-mode --parity-users 64 --steps 6 --warmup 2 --tune $T > $OUT/bench_l.json 2> $OUT/bench_l.err ); tail -1 $OUT/bench_l.err | grep -v amdgpu.ids
 python - <<PY
 import json

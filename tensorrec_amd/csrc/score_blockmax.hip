@@ -331,7 +331,10 @@ __global__ __launch_bounds__(256, WPS) void blockmax_pipe_kernel(ScoreParams p)
 // NUB: 16-user blocks per wave (8: 128 users, 512 per workgroup, 2 workgroups per CU; 4: 64 users, 256 per workgroup, 3 per CU --
 // the grouped form's alternative: its workgroups start with a dependent gather of their user rows, and more of them in flight
 // hide more of that latency, at twice the item-tile reads per flop)
-template <int KT, bool BIAS, bool GRP, int NUB = 8>
+// RDL: the step's LDS operand prefetch is issued AFTER its MFMAs (true) instead of before (false, the default): the change
+// that gave the int8 kernel 3% (score_blockmax_i8.hip) measured slightly SLOWER here (dense 151.5 vs 150.5 ms, grouped 6.79 vs
+// 6.74: 8 user blocks and 4 k-steps per block leave the drain less exposed); kept as tuning blockmax_bf16_rdlate = 1.
+template <int KT, bool BIAS, bool GRP, int NUB = 8, bool RDL = false>
 __global__ __launch_bounds__(256, NUB == 8 ? 2 : 3) void blockmax_bf16x16_kernel(ScoreParams p)
 {
     constexpr int RW = 4 * NUB * 16;         // resident rows per workgroup
@@ -467,18 +470,22 @@ __global__ __launch_bounds__(256, NUB == 8 ? 2 : 3) void blockmax_bf16x16_kernel
 #pragma unroll
         for (int s = 0; s < NSTEP; ++s) {
             const int blk = s / KS, ks = s % KS;
-            if (s + 2 < NSTEP)
+            if (!RDL && s + 2 < NSTEP)
                 tf[(s + 2) % 3] = *(const bf16x8*)(tb + ((s + 2) / KS) * 16 * RB + koff[(s + 2) % KS]);
             if (ks == 0) {
 #pragma unroll
                 for (int ub = 0; ub < NUB; ++ub)
                     acc[ub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tf[s % 3], rfb[ub][0], c0, 0, 0, 0);
+                if (RDL) __builtin_amdgcn_sched_barrier(0);
                 if (BIAS && blk + 1 < NBLK) c0 = *(const f32x4*)(sd + 16 * (blk + 1));      // lands under this block's MFMAs
             } else {
 #pragma unroll
                 for (int ub = 0; ub < NUB; ++ub)
                     acc[ub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tf[s % 3], rfb[ub][ks], acc[ub], 0, 0, 0);
+                if (RDL) __builtin_amdgcn_sched_barrier(0);
             }
+            if (RDL && s + 2 < NSTEP)
+                tf[(s + 2) % 3] = *(const bf16x8*)(tb + ((s + 2) / KS) * 16 * RB + koff[(s + 2) % KS]);
             if (ks == KS - 1) {
 #pragma unroll
                 for (int ub = 0; ub < NUB; ++ub) {
@@ -523,12 +530,12 @@ __global__ __launch_bounds__(256, NUB == 8 ? 2 : 3) void blockmax_bf16x16_kernel
     }
 }
 
-template <int KT, bool BIAS, bool GRP, int NUB = 8>
+template <int KT, bool BIAS, bool GRP, int NUB = 8, bool RDL = false>
 int launch_bf16x16(ScoreParams p, hipStream_t st)
 {
     constexpr int LDS = 2 * BN * KT * 2 + 2 * BN * 4;
     constexpr int RW = 4 * NUB * 16;
-    auto kern = blockmax_bf16x16_kernel<KT, BIAS, GRP, NUB>;
+    auto kern = blockmax_bf16x16_kernel<KT, BIAS, GRP, NUB, RDL>;
     static bool attr_set = false;
     if (!attr_set && LDS > 32 * 1024) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -768,6 +775,7 @@ int launch_blockmax_pipelined_grouped(const ScoreParams& p, int kt, hipStream_t 
     if (trec_get_tuning("blockmax_bf16_mfma16", 1) != 0) {       // the 16x16x32 form (filters only: see blockmax_bf16x16_kernel)
         if (kt == 128 && p.capacity > 0 && trec_get_tuning("cascade_grouped_nub", 8) == 4)
             return bias ? launch_bf16x16<128, true, true, 4>(p, st) : launch_bf16x16<128, false, true, 4>(p, st);
+        if (kt == 128 && bias && trec_get_tuning("blockmax_bf16_rdlate", 0) != 0) return launch_bf16x16<128, true, true, 8, true>(p, st);
         if (kt == 128) return bias ? launch_bf16x16<128, true, true>(p, st) : launch_bf16x16<128, false, true>(p, st);
         if (kt == 64) return bias ? launch_bf16x16<64, true, true>(p, st) : launch_bf16x16<64, false, true>(p, st);
     }
@@ -786,6 +794,7 @@ int launch_blockmax_filter16(const ScoreParams& p, int kt, hipStream_t st)
 {
     if (p.euclid || (trec_get_tuning("blockmax_bf16_mfma16", 1) == 0 && !p.rblock_chunk)) return TREC_ERR_UNSUPPORTED;
     const bool bias = p.r_bias || p.t_bias;
+    if (kt == 128 && bias && trec_get_tuning("blockmax_bf16_rdlate", 0) != 0) return launch_bf16x16<128, true, false, 8, true>(p, st);
     if (kt == 128) return bias ? launch_bf16x16<128, true, false>(p, st) : launch_bf16x16<128, false, false>(p, st);
     if (kt == 64) return bias ? launch_bf16x16<64, true, false>(p, st) : launch_bf16x16<64, false, false>(p, st);
     return TREC_ERR_UNSUPPORTED;

@@ -264,7 +264,14 @@ __global__ __launch_bounds__(256, WPS) void blockmax_i8_kernel(ScoreParams p)
 // NUB: 16-user blocks per wave (8: 128 users, 12: 192 users); NW: waves per workgroup sharing one item tile stream (4: two
 // workgroups per CU, 8: one)
 // BT: item rows per tile (one barrier per tile)
-template <int KT, bool BIAS, int TK, int NUB, int NW, int BT>
+// RDL: where a step's LDS operand prefetch (for step s + 2) sits.  0: before the step's MFMAs (the first form).  The
+// compiler closes every block start with s_waitcnt lgkmcnt(0) -- a full drain, although the operands the MFMAs need were
+// read two steps earlier -- so the prefetch issued right in front of it is waited for at its full LDS latency, once per 24
+// MFMAs.  1 (default): the prefetch is issued AFTER the step's MFMAs, so the next drain finds it a whole group of max3 old:
+// 78.1 -> 75.7 ms at 1M x 1M on one box (0.656 -> 0.677 of 5 Pop/s).  2: in the middle of the MFMAs (77.2).  3: after them,
+// with the block's max3 interleaved between the MFMAs by sched_group_barrier (75.5: the same -- two waves per SIMD already
+// cover each other's max3 phase).
+template <int KT, bool BIAS, int TK, int NUB, int NW, int BT, int RDL = 1>
 __global__ __launch_bounds__(NW * 64, 8 / NW) void blockmax_i8x16_kernel(ScoreParams p)
 {
     constexpr int NT = NW * 64;              // threads per workgroup
@@ -382,23 +389,49 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void blockmax_i8x16_kernel(ScorePa
 #pragma unroll
         for (int s = 0; s < NSTEP; ++s) {
             const int blk = s / KS, ks = s % KS;
-            if (s + 2 < NSTEP)
-                tf[(s + 2) % 3] = *(const v4i32*)(tb + ((s + 2) / KS) * 16 * RB + koff[(s + 2) % KS]);
+            auto prefetch = [&]() {
+                if (s + 2 < NSTEP) tf[(s + 2) % 3] = *(const v4i32*)(tb + ((s + 2) / KS) * 16 * RB + koff[(s + 2) % KS]);
+            };
+            if (RDL == 0) prefetch();
             if (ks == 0) {
 #pragma unroll
-                for (int ub = 0; ub < NUB; ++ub)
+                for (int ub = 0; ub < NUB; ++ub) {
                     acc[ub] = __builtin_amdgcn_mfma_i32_16x16x64_i8(tf[s % 3], rfq[ub][0], c0, 0, 0, 0);
+                    if (RDL == 2 && ub == NUB / 2 - 1) { __builtin_amdgcn_sched_barrier(0); prefetch(); __builtin_amdgcn_sched_barrier(0); }
+                }
+                if (RDL == 1) __builtin_amdgcn_sched_barrier(0);
                 if (BIAS && blk + 1 < NBLK) c0 = *(const v4i32*)(sd + 16 * (blk + 1));     // lands under this block's MFMAs
             } else {
 #pragma unroll
-                for (int ub = 0; ub < NUB; ++ub)
+                for (int ub = 0; ub < NUB; ++ub) {
                     acc[ub] = __builtin_amdgcn_mfma_i32_16x16x64_i8(tf[s % 3], rfq[ub][ks], acc[ub], 0, 0, 0);
+                    if (RDL == 2 && ub == NUB / 2 - 1) { __builtin_amdgcn_sched_barrier(0); prefetch(); __builtin_amdgcn_sched_barrier(0); }
+                }
+                if (RDL == 1) __builtin_amdgcn_sched_barrier(0);
             }
+            if (RDL == 1 || RDL == 3) prefetch();
             if (ks == KS - 1) {
 #pragma unroll
                 for (int ub = 0; ub < NUB; ++ub) {
                     bm[ub] = max(max(bm[ub], acc[ub][0]), acc[ub][1]);
                     bm[ub] = max(max(bm[ub], acc[ub][2]), acc[ub][3]);
+                }
+            }
+            if (RDL == 3) {
+                // pin the order inside the step: 3 MFMAs ahead, then (2 max3, 1 MFMA) pairs, the prefetch read in the middle
+                if (ks == KS - 1) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+#pragma unroll
+                    for (int i = 0; i < NUB - 3; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        if (i == (NUB - 3) / 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                } else {
+                    __builtin_amdgcn_sched_group_barrier(0x008, NUB / 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, NUB - NUB / 2, 0);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -464,11 +497,11 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void blockmax_i8x16_kernel(ScorePa
     }
 }
 
-template <int KT, bool BIAS, int TK, int NUB, int NW, int BT>
+template <int KT, bool BIAS, int TK, int NUB, int NW, int BT, int RDL = 1>
 int launch_i8x16(ScoreParams p, int sb_rows, hipStream_t st)
 {
     constexpr int LDS = 2 * BT * KT + 2 * BT * 4;
-    auto kern = blockmax_i8x16_kernel<KT, BIAS, TK, NUB, NW, BT>;
+    auto kern = blockmax_i8x16_kernel<KT, BIAS, TK, NUB, NW, BT, RDL>;
     static bool attr_set = false;
     if (!attr_set && LDS > 32 * 1024) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -931,6 +964,16 @@ extern "C" int trec_score_gemm_blockmax_i8(const void* users_q, const void* item
         // users per wave: 192 (12 blocks of 16: a third fewer LDS reads and tile streams per flop; 78.8 vs 81.9 ms at 1M x 1M
         // with the 10-slot lists, profiles/r02_power_trace_i8.txt) unless the 16-slot lists need the registers
         const int users = trec_get_tuning("blockmax_i8_users", top_k > 10 ? 128 : 192);
+        // the late-prefetch form exists for the default shape only (K = 128, 10-slot lists, 192 users per wave, 4 waves, 128-row tiles)
+        // where a step's operand prefetch sits (see the kernel header): 1 (default, every shape) = after the step's MFMAs;
+        // 0 / 2 / 3 = the first form / mid-step / pinned interleave, for the default shape only (A/B: 78.1 / 77.2 / 75.5 ms against
+        // 75.7 for form 1 on one box, 1M x 1M)
+        const int rdl = trec_get_tuning("blockmax_i8_rdlate", 1);
+        if (kpad == 128 && top_k == 10 && users == 192 && waves == 4 && tile == 128 && rdl != 1) {
+            if (rdl == 2) return bias ? launch_i8x16<128, true, 10, 12, 4, 128, 2>(p, sb_rows, st) : launch_i8x16<128, false, 10, 12, 4, 128, 2>(p, sb_rows, st);
+            if (rdl == 3) return bias ? launch_i8x16<128, true, 10, 12, 4, 128, 3>(p, sb_rows, st) : launch_i8x16<128, false, 10, 12, 4, 128, 3>(p, sb_rows, st);
+            return bias ? launch_i8x16<128, true, 10, 12, 4, 128, 0>(p, sb_rows, st) : launch_i8x16<128, false, 10, 12, 4, 128, 0>(p, sb_rows, st);
+        }
         if (kpad == 128) return top_k == 0 ? TREC_I8X(128, 0) : (top_k == 10 ? TREC_I8X(128, 10) : TREC_I8X(128, 16));
         return top_k == 0 ? TREC_I8X(64, 0) : (top_k == 10 ? TREC_I8X(64, 10) : TREC_I8X(64, 16));
 #undef TREC_I8X
