@@ -23,7 +23,8 @@ inter, held, ucl, icl = planted_cluster_interactions(U, I, NC, PER, seed=0, hold
 print("interactions %d (held out %d), most popular item %d, %.1f s" % (inter.nnz, held.nnz, int(np.bincount(inter.indices, minlength=I).max()), time.time() - t0), flush=True)
 uf = sp.identity(U, dtype=np.float32, format="csr"); itf = sp.identity(I, dtype=np.float32, format="csr")
 model = T.TensorRec(n_components=D, loss_graph=T.loss_graphs.WMRBLossGraph(), seed=0)
-ops.FILTER_DEBUG = {}
+DEBUG = int(os.environ.get("DEBUG", 1))          # 0: no per-stage counters (they cost host syncs and extra passes): clean times
+ops.FILTER_DEBUG = {} if DEBUG else None
 res = {"shape": [U, I, D], "clusters": NC, "per_user": PER, "lr": LR, "n_sampled": S, "stages": []}
 
 
@@ -36,11 +37,12 @@ def q(x):
 
 
 def topk_run(label, **kw):
-    ops.FILTER_DEBUG.clear()
+    if ops.FILTER_DEBUG is not None:
+        ops.FILTER_DEBUG.clear()
     torch.cuda.synchronize(); t = time.perf_counter()
     v, i = model.predict_top_k(uf, itf, k=10, user_batch_size=U, return_device=True, **kw)
     torch.cuda.synchronize(); dt = time.perf_counter() - t
-    return {"mode": label, "ms": 1e3 * dt, "stats": dict(ops.LAST_FILTER_STATS), "debug": dict(ops.FILTER_DEBUG)}, v, i
+    return {"mode": label, "ms": 1e3 * dt, "stats": dict(ops.LAST_FILTER_STATS), "debug": dict(ops.FILTER_DEBUG or {})}, v, i
 
 
 total_epochs = 0
