@@ -199,6 +199,119 @@ __global__ __launch_bounds__(256) void collect_blocks_tiled_kernel(const float* 
     }
 }
 
+// ---- select + collect in ONE pass over the table (the cascade's bf16 filter, round 3) ------------------------------------
+// trec_topk_select_blocks (tau = the k-th largest entry of a user's column) and trec_topk_collect_blocks (every entry >= floor =
+// tau - 2 eps) each read the 7.8 GB table.  The second pass only exists because the floor is not known during the first.  But a
+// PROVISIONAL floor is: with the int8 stage in front, floor >= tau8 - 3 eps (k superblocks certify items with fp32 score >=
+// tau8; they are refined, so their entries are >= tau8 - eps: tau >= tau8 - eps).  One pass keeps the k largest entries (sorted
+// registers, as select does) AND appends every entry >= floor0 to the user's candidate list (superblock, value; at most
+// cand_cap, in superblock order, stored slot-major [cand_cap][n_users]); a second kernel that touches ~45 candidates per user instead of 1,954 table entries prunes
+// them with the final floor.  cand_n[u] counts ALL entries >= floor0: above cand_cap the list is incomplete and the prune
+// kernel flags the user.
+template <int KSEL>
+__global__ __launch_bounds__(256) void scan_blocks_tiled_kernel(const float* __restrict__ blockmax, int32_t n_sb,
+                                                               int64_t n_users, int64_t stride, int32_t k,
+                                                               const float* __restrict__ floor0, int32_t cand_cap,
+                                                               float* __restrict__ sel_max, float* __restrict__ tau,
+                                                               int32_t* __restrict__ cand_s, float* __restrict__ cand_v,
+                                                               int32_t* __restrict__ cand_n)
+{
+    __shared__ __attribute__((aligned(16))) float tile[2][SEL_TS][256];
+    const int t = threadIdx.x;
+    const int64_t u0 = (int64_t)blockIdx.x * 256;
+    const int64_t u = u0 + t;
+    const bool ok = u < n_users;
+    const int lrow = t >> 6, lcol = (t & 63) * 4;
+    const bool vec = (stride % 4 == 0) && (((uintptr_t)blockmax % 16) == 0) && (u0 + lcol + 3 < stride);
+    float tv[KSEL];
+    int32_t ti[KSEL];
+#pragma unroll
+    for (int j = 0; j < KSEL; ++j) { tv[j] = -INFINITY; ti[j] = -1; }
+    const float f0 = ok ? floor0[u] : INFINITY;
+    int32_t c = 0;
+    // candidate j of user u lives at [j][u] (slot-major): the prune kernel's lanes then read consecutive addresses
+    int32_t* cs = cand_s + u;
+    float* cv = cand_v + u;
+    auto fetch = [&](int32_t s0, f32x4 (&r)[2]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int32_t srow = s0 + lrow + 4 * i;
+            r[i] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            if (srow < n_sb && vec) r[i] = __builtin_nontemporal_load((const f32x4*)(blockmax + (int64_t)srow * stride + u0 + lcol));
+            else if (srow < n_sb) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (u0 + lcol + e < stride) r[i][e] = blockmax[(int64_t)srow * stride + u0 + lcol + e];
+            }
+        }
+    };
+    f32x4 cur[2], nxt[2];
+    fetch(0, cur);
+    int buf = 0;
+    for (int32_t s0 = 0; s0 < n_sb; s0 += SEL_TS) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *(f32x4*)(&tile[buf][lrow + 4 * i][lcol]) = cur[i];
+        if (s0 + SEL_TS < n_sb) fetch(s0 + SEL_TS, nxt);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < SEL_TS; ++r) {
+            const int32_t s = s0 + r;
+            const float v = (ok && s < n_sb) ? tile[buf][r][t] : -INFINITY;
+            const bool hit = s < n_sb && ((v > tv[KSEL - 1]) || (ti[KSEL - 1] < 0 && ok));
+            if (__builtin_amdgcn_ballot_w64(hit) != 0ull) sel_insert<KSEL>(tv, ti, hit ? v : -INFINITY, hit ? s : -1);
+            if (ok && s < n_sb && !(v < f0)) {                   // (NaN entries stay candidates, as in collect)
+                if (c < cand_cap) { cs[(int64_t)c * n_users] = s; cv[(int64_t)c * n_users] = v; }
+                ++c;
+            }
+        }
+        cur[0] = nxt[0]; cur[1] = nxt[1];
+        buf ^= 1;
+    }
+    if (ok) {
+        cand_n[u] = c;
+        if (sel_max) {
+#pragma unroll
+            for (int j = 0; j < KSEL; ++j)
+                if (j < k) sel_max[(int64_t)j * n_users + u] = tv[j];
+        }
+        float tk = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < KSEL; ++j)
+            if (j == k - 1 && ti[j] >= 0) tk = tv[j];
+        tau[u] = tk;
+    }
+}
+
+// keys / count of trec_topk_collect_blocks from the candidate lists: entries with value >= floor, in superblock order.
+// Flags (and empties) a user with more than ksel of them or with an incomplete candidate list.  One thread per user.
+__global__ __launch_bounds__(256) void prune_candidates_kernel(const int32_t* __restrict__ cand_s, const float* __restrict__ cand_v,
+                                                              const int32_t* __restrict__ cand_n, int32_t cand_cap,
+                                                              const float* __restrict__ floor_, int32_t ksel, int64_t n_users,
+                                                              int32_t* __restrict__ keys, int32_t* __restrict__ count,
+                                                              int32_t* __restrict__ flag, int32_t* __restrict__ n_flagged)
+{
+    const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (u >= n_users) return;
+    const int32_t n_all = cand_n[u];
+    const int32_t n = n_all < cand_cap ? n_all : cand_cap;
+    const float fl = floor_[u];
+    const int32_t* cs = cand_s + u;                                     // [j][u]: coalesced over the lanes
+    const float* cv = cand_v + u;
+    int32_t* ku = keys + u * (int64_t)ksel;
+    int32_t c = 0;
+    for (int32_t j = 0; j < n; ++j) {
+        if (!(cv[(int64_t)j * n_users] < fl)) {
+            if (c < ksel) ku[c] = cs[(int64_t)j * n_users];
+            ++c;
+        }
+    }
+    // an incomplete list may have lost entries >= floor -- unless the floor turned out +inf (padding rows keep nothing)
+    const bool over = c > ksel || (n_all > cand_cap && fl < INFINITY);
+    for (int32_t j = over ? 0 : c; j < ksel; ++j) ku[j] = -1;
+    count[u] = over ? 0 : c;
+    if (over && flag[u] == 0) { flag[u] = 1; atomicAdd(n_flagged, 1); }
+}
+
 // keys for the counting sort: superblock id, or -1 (skipped by the sort) for empty slots and for superblocks whose
 // maximum lies below the user's floor.  The floor is any lower bound of the user's final k-th best score -- with item
 // shards, the MAX over ranks of the per-shard tau (every shard's k-th best is a floor of the global k-th best): a
@@ -429,4 +542,41 @@ extern "C" int trec_topk_fill_groups(const int64_t* pstart, const int64_t* indpt
                        pstart, indptr_t, users_t, perm_t, n_sb, rows_wg, max_rows, (const char*)users_op, row_bytes,
                        user_bias, user_sq, user_tau, (char*)G, g_bias, g_sq, g_tau, row_pair, rblock_chunk);
     return trec_check_launch("trec_topk_fill_groups");
+}
+
+// The k-th largest entry of every user's column (tau, and sel_max [k][n_users] for item shards) AND the candidates for the
+// collect step in ONE pass over the table: cand_s / cand_v [cand_cap][n_users] = the entries >= floor0[u] in superblock order,
+// cand_n [n_users] = how many there were (possibly more than cand_cap).  floor0 must not exceed the final floor (see the
+// kernel's header).  k <= 16.
+extern "C" int trec_topk_scan_blocks(const float* blockmax, int32_t n_sb, int64_t n_users, int64_t stride, int32_t k,
+                                     const float* floor0, int32_t cand_cap, float* sel_max, float* tau, int32_t* cand_s,
+                                     float* cand_v, int32_t* cand_n, void* stream)
+{
+    TREC_REQUIRE(blockmax && floor0 && tau && cand_s && cand_v && cand_n, "trec_topk_scan_blocks: null pointer");
+    TREC_REQUIRE(k >= 1 && k <= 16 && n_sb >= 1 && cand_cap >= 1 && stride >= n_users, "trec_topk_scan_blocks: need 1 <= k <= 16");
+    if (n_users == 0) return TREC_OK;
+    const unsigned blocks = (unsigned)ceil_div64(n_users, 256);
+    hipStream_t st = (hipStream_t)stream;
+#define TREC_SCAN(KS) hipLaunchKernelGGL((scan_blocks_tiled_kernel<KS>), dim3(blocks), dim3(256), 0, st, blockmax, n_sb, n_users, \
+                                         stride, k, floor0, cand_cap, sel_max, tau, cand_s, cand_v, cand_n)
+    if (k <= 4) TREC_SCAN(4);
+    else if (k <= 8) TREC_SCAN(8);
+    else if (k <= 10) TREC_SCAN(10);
+    else if (k <= 12) TREC_SCAN(12);
+    else TREC_SCAN(16);
+#undef TREC_SCAN
+    return trec_check_launch("trec_topk_scan_blocks");
+}
+
+// the collect step from the candidate lists: keys [n_users][ksel] / count as trec_topk_collect_blocks writes them
+extern "C" int trec_topk_prune_candidates(const int32_t* cand_s, const float* cand_v, const int32_t* cand_n, int32_t cand_cap,
+                                          const float* floor_, int32_t ksel, int64_t n_users, int32_t* keys, int32_t* count,
+                                          int32_t* flag, int32_t* n_flagged, void* stream)
+{
+    TREC_REQUIRE(cand_s && cand_v && cand_n && floor_ && keys && count && flag && n_flagged, "trec_topk_prune_candidates: null pointer");
+    TREC_REQUIRE(ksel >= 1 && cand_cap >= 1, "trec_topk_prune_candidates: bad sizes");
+    if (n_users == 0) return TREC_OK;
+    hipLaunchKernelGGL(prune_candidates_kernel, dim3((unsigned)ceil_div64(n_users, 256)), dim3(256), 0, (hipStream_t)stream,
+                       cand_s, cand_v, cand_n, cand_cap, floor_, ksel, n_users, keys, count, flag, n_flagged);
+    return trec_check_launch("trec_topk_prune_candidates");
 }

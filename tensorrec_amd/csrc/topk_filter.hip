@@ -140,11 +140,12 @@ __global__ __launch_bounds__(256) void prep_filter_kernel(const float* __restric
     }
 }
 
-// floor_u = tau_u - 2 eps_u (rounded DOWN twice); flag_u = 1 when the bound is unusable (then floor_u = -inf).
+// floor_u = tau_u - mult eps_u (rounded DOWN twice; mult = 2 for the filter's floor); flag_u = 1 when the bound is unusable
+// (then floor_u = -inf).  flag / n_flagged may be NULL (a provisional floor: trec_topk_filter_floor_ex).
 __global__ __launch_bounds__(256) void filter_floor_kernel(const float* __restrict__ tau, const float2* __restrict__ ustats,
                                                           const float* __restrict__ user_bias,
                                                           const float* __restrict__ gstats, int kdim, int64_t n_users,
-                                                          float* __restrict__ floor_, int32_t* __restrict__ flag,
+                                                          float mult, float* __restrict__ floor_, int32_t* __restrict__ flag,
                                                           int32_t* __restrict__ n_flagged)
 {
     const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -156,15 +157,17 @@ __global__ __launch_bounds__(256) void filter_floor_kernel(const float* __restri
     float eps = st.y * (ni * 1.00390625f) + st.x * ai + ck * (st.x * ni * 1.0078125f + bu + bi);
     eps = eps * 1.001953125f + 1e-30f;
     const float t = tau[u];
-    float f = t - 2.0f * eps;
+    float f = t - mult * eps;
     bool bad = !(eps < INFINITY);                                               // inf or NaN
     if (t == -INFINITY) f = -INFINITY;                                          // fewer than k superblocks: keep all
     else if (!(f == f)) bad = true;
     else f = float_pred(float_pred(f));
     if (bad) f = -INFINITY;
     floor_[u] = f;
-    flag[u] = bad ? 1 : 0;
-    if (bad) atomicAdd(n_flagged, 1);
+    if (flag) {
+        flag[u] = bad ? 1 : 0;
+        if (bad) atomicAdd(n_flagged, 1);
+    }
 }
 
 // One wave per user.  Only the first count[u] slots of a user have stage-3 lists.  Survivors are re-scored FILTER_RB at a time: their fp32
@@ -454,15 +457,29 @@ extern "C" int trec_score_prep_filter(const float* repr, int64_t n, int32_t d, i
     return trec_check_launch("trec_score_prep_filter");
 }
 
+extern "C" int trec_topk_filter_floor_ex(const float* tau, const float* user_stats, const float* user_bias,
+                                         const float* item_gstats, int32_t kdim, int64_t n_users, float mult, float* floor_,
+                                         int32_t* flag, int32_t* n_flagged, void* stream);
+
 extern "C" int trec_topk_filter_floor(const float* tau, const float* user_stats, const float* user_bias,
                                       const float* item_gstats, int32_t kdim, int64_t n_users, float* floor_, int32_t* flag,
                                       int32_t* n_flagged, void* stream)
 {
     TREC_REQUIRE(tau && user_stats && item_gstats && floor_ && flag && n_flagged, "trec_topk_filter_floor: null pointer");
+    return trec_topk_filter_floor_ex(tau, user_stats, user_bias, item_gstats, kdim, n_users, 2.0f, floor_, flag, n_flagged, stream);
+}
+
+// floor = tau - mult * eps (rounded down twice) with the same eps; flag / n_flagged may be NULL.  mult = 4 on tau8 gives the
+// provisional floor of trec_topk_scan_blocks (the final floor tau16 - 2 eps is >= tau8 - 3 eps).
+extern "C" int trec_topk_filter_floor_ex(const float* tau, const float* user_stats, const float* user_bias,
+                                         const float* item_gstats, int32_t kdim, int64_t n_users, float mult, float* floor_,
+                                         int32_t* flag, int32_t* n_flagged, void* stream)
+{
+    TREC_REQUIRE(tau && user_stats && item_gstats && floor_ && (!flag == !n_flagged) && mult >= 0.f, "trec_topk_filter_floor_ex: bad arguments");
     TREC_REQUIRE(kdim >= 1, "trec_topk_filter_floor: bad sizes");
     if (n_users == 0) return TREC_OK;
     hipLaunchKernelGGL(filter_floor_kernel, dim3((unsigned)ceil_div64(n_users, 256)), dim3(256), 0, (hipStream_t)stream,
-                       tau, (const float2*)user_stats, user_bias, item_gstats, kdim, n_users, floor_, flag, n_flagged);
+                       tau, (const float2*)user_stats, user_bias, item_gstats, kdim, n_users, mult, floor_, flag, n_flagged);
     return trec_check_launch("trec_topk_filter_floor");
 }
 

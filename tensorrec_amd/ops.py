@@ -936,6 +936,7 @@ def score_topk_two_stage(users_op, items_op, dtype, kpad, k, user_bias=None, ite
 # superblocks a user may keep (1M x 1M, d = 128, k = 10: 15.5 on average; 19 users of 1M need more than 32, none more than
 # 48 -- a user beyond the limit goes to the exact fp32 fallback, whose launch chain costs ~1.2 ms however few users)
 FILTER_KSEL = 48
+FILTER_CANDIDATES = 128    # candidates per user of the one-pass scan (entries above the provisional floor: ~45 at 1M x 1M)
 FILTER_KSEL_WIDE = 320     # ... in the wide second pass over the flagged users (its finish kernel has no survivor limit)
 WIDE_TIER2_MAX_FRACTION = 0.05   # the all-superblocks tier runs only when at most this fraction of the users is still flagged
 LAST_FILTER_STATS = {}    # diagnostics of the most recent score_topk_filtered call (bench.py reports them)
@@ -1216,7 +1217,7 @@ def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, 
         if stats_exchange is not None:
             overflow = float(stats_exchange(torch.tensor([float(overflow)], device=dev)).item())
         if overflow:
-            return None, stride, (int(rows), True)
+            return None, stride, (int(rows), True), tau
         with _timed("score_gemm_blockmax_grouped"):
             N.call("trec_score_gemm_blockmax_grouped", N.ptr(uop.bf16), N.ptr(iop.bf16), kpad, n_sb * rcap, n_i,
                    N.ptr(user_bias), N.ptr(item_bias), sb_rows, N.ptr(row_count), N.ptr(row_user), N.ptr(table), stride,
@@ -1224,7 +1225,7 @@ def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, 
         with _timed("score_gemm_blockmax_hot"):
             N.call("trec_score_gemm_blockmax_hot", N.ptr(uop.bf16), N.ptr(iop.bf16), kpad, n_u, n_i, N.ptr(user_bias),
                    N.ptr(item_bias), sb_rows, N.ptr(hot_list), hot_cap, N.ptr(table), stride)
-        return table, stride, (int(rows), False)
+        return table, stride, (int(rows), False), tau
     n_ublk = N.query("trec_topk_rows_user_blocks", n_u)
     block_off = torch.empty((n_sb * n_ublk,), dtype=torch.int32, device=dev)
     row_total = torch.empty((n_sb,), dtype=torch.int32, device=dev)
@@ -1245,22 +1246,25 @@ def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, 
     rows, overflow = status.tolist()                    # (the two-pass form: its fill pass and grouped launch idle after an overflow)
     if stats_exchange is not None:
         overflow = float(stats_exchange(torch.tensor([float(overflow)], device=dev)).item())
-    return (None if overflow else table), stride, (int(rows), bool(overflow))
+    return (None if overflow else table), stride, (int(rows), bool(overflow)), tau
 
 
 def _filter_tail(uop, iop, blockmax, bm_stride, n_u, n_sb, k, user_bias, item_bias, item_index_base, sb_rows, variant, ksel,
-                 cap, floor, flag, n_flagged, rows_wg, wide=False):
+                 cap, floor, flag, n_flagged, rows_wg, wide=False, keys_count=None):
     """Stages 2b-4 of the filtered top-k on a table of superblock maxima: every superblock reaching the user's floor
     (at most ``ksel``), grouped bf16 re-scoring with ``cap``-entry lists, exact fp32 finish.  ``wide``: the second pass over
     the users the first one flagged -- the finish kernel without capacity limits."""
     dev = uop.bf16.device
     n_i, kpad = iop.n, uop.kpad
     n_pairs = n_u * ksel
-    keys = torch.empty((n_pairs,), dtype=torch.int32, device=dev)
-    count = torch.empty((n_u,), dtype=torch.int32, device=dev)
-    with _timed("topk_collect_blocks"):
-        N.call("trec_topk_collect_blocks", N.ptr(blockmax), n_sb, n_u, bm_stride, N.ptr(floor), ksel, N.ptr(keys),
-               N.ptr(count), N.ptr(flag), N.ptr(n_flagged))
+    if keys_count is not None:                          # the one-pass scan already produced them (trec_topk_prune_candidates)
+        keys, count = keys_count
+    else:
+        keys = torch.empty((n_pairs,), dtype=torch.int32, device=dev)
+        count = torch.empty((n_u,), dtype=torch.int32, device=dev)
+        with _timed("topk_collect_blocks"):
+            N.call("trec_topk_collect_blocks", N.ptr(blockmax), n_sb, n_u, bm_stride, N.ptr(floor), ksel, N.ptr(keys),
+                   N.ptr(count), N.ptr(flag), N.ptr(n_flagged))
     if FILTER_DEBUG is not None and not wide:
         FILTER_DEBUG["flagged_after_collect"] = int(n_flagged.item())
         _debug_counts("kept_superblocks", count)
@@ -1380,7 +1384,7 @@ def _score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index
         rblocks = (n_u + rows_wg - 1) // rows_wg
         n_chunks = max(1, min(n_sb, -(-32 * 768 // rblocks)))
     LAST_FILTER_STATS.clear()
-    blockmax, bm_stride, cascade_status = None, n_u, None
+    blockmax, bm_stride, cascade_status, tau8 = None, n_u, None, None
     # item shards: the item-side maxima behind both bounds (norms, rounding-error norms, |bias|) are MAX-reduced ONCE per call
     gstats = iop.gstats
     if stats_exchange is not None:
@@ -1388,8 +1392,8 @@ def _score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index
     if prefilter == "int8" and kpad in (64, 128) and sb_rows % 128 == 0 and not (iop.cascade_too_loose and
                                                                                  floor_exchange is None):
         # ---- stages 0 + 1: int8 maxima everywhere, bf16 maxima where a top-k item can be
-        blockmax, bm_stride, cascade_status = _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks,
-                                                              floor_exchange, stats_exchange, gstats)
+        blockmax, bm_stride, cascade_status, tau8 = _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks,
+                                                                    floor_exchange, stats_exchange, gstats)
         rows, overflow = cascade_status
         if overflow:
             # the int8 bound was too loose for this data: nothing was refined.  bf16 does stage 1; the next user batches
@@ -1412,28 +1416,52 @@ def _score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index
             N.call("trec_score_gemm_blockmax", N.ptr(uop.bf16), N.ptr(iop.bf16), DTYPE_BF16, kpad, n_u, n_i,
                    N.ptr(user_bias), N.ptr(item_bias), MODE_DOT, None, None, sb_rows, n_chunks, N.ptr(blockmax), n_u,
                    variant | 32)          # bit 5: filter use -> the 16x16x32 MFMA form (any summation order obeys the bound)
-    # ---- stage 2, pass 1: tau = k-th largest superblock maximum (a floor of the k-th best bf16 score)
+    # ---- stage 2: tau = k-th largest superblock maximum (a floor of the k-th best bf16 score), floor = tau - 2 eps (proven
+    # bound, csrc/topk_filter.hip), then every superblock reaching the floor.  Two passes over the table -- or, behind the int8
+    # stage, ONE: tau8 gives a provisional floor (tau >= tau8 - eps, so the final floor is >= tau8 - 3 eps), the scan keeps the
+    # k largest entries AND lists the entries above it, and the final floor only prunes those ~45 candidates per user
     kk = int(k)
-    sel = torch.empty((n_u, kk), dtype=torch.int32, device=dev)
-    sel_max = torch.empty((kk, n_u), dtype=torch.float32, device=dev) if floor_exchange is not None else None
     tau = torch.empty((n_u,), dtype=torch.float32, device=dev)
-    with _timed("topk_select_blocks"):
-        N.call("trec_topk_select_blocks", N.ptr(blockmax), n_sb, n_u, bm_stride, kk, N.ptr(sel), N.ptr(sel_max),
-               N.ptr(tau))
-    if floor_exchange is not None:                  # item shards: the k-th largest maximum over ALL shards
-        tau = floor_exchange(sel_max).contiguous()
-    # ---- floor = tau - 2 eps (proven bound, csrc/topk_filter.hip); pass 2: every superblock reaching the floor
+    sel_max = torch.empty((kk, n_u), dtype=torch.float32, device=dev) if floor_exchange is not None else None
     floor = torch.empty((n_u,), dtype=torch.float32, device=dev)
     flag = torch.empty((n_u,), dtype=torch.int32, device=dev)
     n_flagged = torch.zeros((1,), dtype=torch.int32, device=dev)
+    keys_count = None
+    one_pass = tau8 is not None and cascade_status is not None and N.load().trec_get_tuning(b"filter_scan_one_pass", 1) != 0
+    if one_pass:
+        cand_cap = FILTER_CANDIDATES
+        floor0 = torch.empty((n_u,), dtype=torch.float32, device=dev)
+        N.call("trec_topk_filter_floor_ex", N.ptr(tau8), N.ptr(uop.stats), N.ptr(user_bias), N.ptr(gstats), kpad, n_u, 4.0,
+               N.ptr(floor0), None, None)
+        cand_s = torch.empty((cand_cap, n_u), dtype=torch.int32, device=dev)       # slot-major; only the first ~45 rows are touched
+        cand_v = torch.empty((cand_cap, n_u), dtype=torch.float32, device=dev)
+        cand_n = torch.empty((n_u,), dtype=torch.int32, device=dev)
+        with _timed("topk_select_blocks"):
+            N.call("trec_topk_scan_blocks", N.ptr(blockmax), n_sb, n_u, bm_stride, kk, N.ptr(floor0), cand_cap, N.ptr(sel_max),
+                   N.ptr(tau), N.ptr(cand_s), N.ptr(cand_v), N.ptr(cand_n))
+    else:
+        sel = torch.empty((n_u, kk), dtype=torch.int32, device=dev)
+        with _timed("topk_select_blocks"):
+            N.call("trec_topk_select_blocks", N.ptr(blockmax), n_sb, n_u, bm_stride, kk, N.ptr(sel), N.ptr(sel_max),
+                   N.ptr(tau))
+    if floor_exchange is not None:                  # item shards: the k-th largest maximum over ALL shards
+        tau = floor_exchange(sel_max).contiguous()
     N.call("trec_topk_filter_floor", N.ptr(tau), N.ptr(uop.stats), N.ptr(user_bias), N.ptr(gstats), kpad, n_u,
            N.ptr(floor), N.ptr(flag), N.ptr(n_flagged))
     if uop.pad is not None:
         floor.masked_fill_(uop.pad, float("inf"))       # padding rows keep nothing: no lists, no survivors, never flagged
     if FILTER_DEBUG is not None:
         FILTER_DEBUG["flagged_after_floor"] = int(n_flagged.item())
+    if one_pass:
+        keys = torch.empty((n_u * ksel,), dtype=torch.int32, device=dev)
+        count = torch.empty((n_u,), dtype=torch.int32, device=dev)
+        with _timed("topk_collect_blocks"):
+            N.call("trec_topk_prune_candidates", N.ptr(cand_s), N.ptr(cand_v), N.ptr(cand_n), cand_cap, N.ptr(floor), ksel, n_u,
+                   N.ptr(keys), N.ptr(count), N.ptr(flag), N.ptr(n_flagged))
+        keys_count = (keys, count)
+        del cand_s, cand_v
     ov, oi, count = _filter_tail(uop, iop, blockmax, bm_stride, n_u, n_sb, k, user_bias, item_bias, item_index_base, sb_rows,
-                                 variant, ksel, cap, floor, flag, n_flagged, rows_wg, wide=False)
+                                 variant, ksel, cap, floor, flag, n_flagged, rows_wg, wide=False, keys_count=keys_count)
     # ---- users the filter could not certify (one host read of a counter): a wide second pass, then the exact fp32 MFMA path
     n_bad = int(n_flagged.item())
     if cascade_status is not None:
