@@ -310,7 +310,8 @@ int trec_topk_collect_blocks(const float* blockmax, int32_t n_sb, int64_t n_user
  * every column (tau; sel_max [k][n_users] for item shards) AND lists the entries >= that floor (cand_s / cand_v
  * [cand_cap][n_users] -- slot-major -- in superblock order, cand_n = their number, possibly above cand_cap); trec_topk_prune_candidates applies
  * the final floor to the ~45 candidates of a user instead of its 1,954 table entries and writes keys / count exactly as
- * trec_topk_collect_blocks does (an incomplete candidate list flags the user). */
+ * trec_topk_collect_blocks does; users with an incomplete candidate list are marked in redo [n_users] and
+ * trec_topk_collect_blocks_masked collects exactly those from the table (workgroups without a marked user exit at once). */
 int trec_topk_filter_floor_ex(const float* tau, const float* user_stats, const float* user_bias, const float* item_gstats,
                               int32_t kdim, int64_t n_users, float mult, float* floor, int32_t* flag, int32_t* n_flagged,
                               void* stream);
@@ -319,7 +320,10 @@ int trec_topk_scan_blocks(const float* blockmax, int32_t n_sb, int64_t n_users, 
                           void* stream);
 int trec_topk_prune_candidates(const int32_t* cand_s, const float* cand_v, const int32_t* cand_n, int32_t cand_cap,
                                const float* floor, int32_t ksel, int64_t n_users, int32_t* keys, int32_t* count, int32_t* flag,
-                               int32_t* n_flagged, void* stream);
+                               int32_t* n_flagged, int32_t* redo, void* stream);
+int trec_topk_collect_blocks_masked(const float* blockmax, int32_t n_sb, int64_t n_users, int64_t stride, const float* floor,
+                                    int32_t ksel, int32_t* keys, int32_t* count, int32_t* flag, int32_t* n_flagged,
+                                    const int32_t* redo, void* stream);
 int trec_topk_filter_finish(const int32_t* part_idx, int32_t capacity, int32_t ksel, const int32_t* count,
                             const float* users_f32, const float* items_f32, int64_t ld_users, int64_t ld_items,
                             int32_t kdim, const float* user_bias, const float* item_bias, int32_t item_index_base,

@@ -76,7 +76,8 @@ SIGNATURES = {
     "trec_topk_collect_blocks": [_vp, _i32, _i64, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
     "trec_topk_filter_floor_ex": [_vp, _vp, _vp, _vp, _i32, _i64, _f, _vp, _vp, _vp, _vp],
     "trec_topk_scan_blocks": [_vp, _i32, _i64, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
-    "trec_topk_prune_candidates": [_vp, _vp, _vp, _i32, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp],
+    "trec_topk_prune_candidates": [_vp, _vp, _vp, _i32, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp],
+    "trec_topk_collect_blocks_masked": [_vp, _i32, _i64, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "trec_topk_filter_finish": [_vp, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _i32, _i64, _i32, _vp, _vp,
                                 _vp, _vp, _vp],
     "trec_topk_filter_finish_wide": [_vp, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _i32, _i64, _i32, _vp, _vp,

@@ -145,13 +145,17 @@ __global__ __launch_bounds__(256) void collect_blocks_tiled_kernel(const float* 
                                                                   int64_t n_users, int64_t stride,
                                                                   const float* __restrict__ floor_, int32_t ksel,
                                                                   int32_t* __restrict__ keys, int32_t* __restrict__ count,
-                                                                  int32_t* __restrict__ flag, int32_t* __restrict__ n_flagged)
+                                                                  int32_t* __restrict__ flag, int32_t* __restrict__ n_flagged,
+                                                                  const int32_t* __restrict__ redo)
 {
     __shared__ __attribute__((aligned(16))) float tile[2][SEL_TS][256];
     const int t = threadIdx.x;
     const int64_t u0 = (int64_t)blockIdx.x * 256;
     const int64_t u = u0 + t;
-    const bool ok = u < n_users;
+    // redo (nullable): only the users marked there are collected (the ones whose candidate list of the one-pass scan was
+    // incomplete); a workgroup none of whose 256 users is marked leaves before touching the table
+    const bool ok = u < n_users && (!redo || redo[u] != 0);
+    if (redo && !__syncthreads_or(ok ? 1 : 0)) return;
     const int lrow = t >> 6, lcol = (t & 63) * 4;
     const bool vec = (stride % 4 == 0) && (((uintptr_t)blockmax % 16) == 0) && (u0 + lcol + 3 < stride);
     const float fl = ok ? floor_[u] : INFINITY;
@@ -288,7 +292,8 @@ __global__ __launch_bounds__(256) void prune_candidates_kernel(const int32_t* __
                                                               const int32_t* __restrict__ cand_n, int32_t cand_cap,
                                                               const float* __restrict__ floor_, int32_t ksel, int64_t n_users,
                                                               int32_t* __restrict__ keys, int32_t* __restrict__ count,
-                                                              int32_t* __restrict__ flag, int32_t* __restrict__ n_flagged)
+                                                              int32_t* __restrict__ flag, int32_t* __restrict__ n_flagged,
+                                                              int32_t* __restrict__ redo)
 {
     const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (u >= n_users) return;
@@ -305,10 +310,14 @@ __global__ __launch_bounds__(256) void prune_candidates_kernel(const int32_t* __
             ++c;
         }
     }
-    // an incomplete list may have lost entries >= floor -- unless the floor turned out +inf (padding rows keep nothing)
-    const bool over = c > ksel || (n_all > cand_cap && fl < INFINITY);
-    for (int32_t j = over ? 0 : c; j < ksel; ++j) ku[j] = -1;
-    count[u] = over ? 0 : c;
+    // an incomplete list may have lost entries >= floor (unless the floor turned out +inf: padding rows keep nothing): such a
+    // user is marked for the masked collect pass that follows (a loose int8 bound leaves hundreds of entries above the
+    // provisional floor); the keys written here are then overwritten
+    const bool incomplete = n_all > cand_cap && fl < INFINITY;
+    redo[u] = incomplete ? 1 : 0;
+    const bool over = c > ksel && !incomplete;
+    for (int32_t j = (over || incomplete) ? 0 : c; j < ksel; ++j) ku[j] = -1;
+    count[u] = (over || incomplete) ? 0 : c;
     if (over && flag[u] == 0) { flag[u] = 1; atomicAdd(n_flagged, 1); }
 }
 
@@ -494,15 +503,28 @@ extern "C" int trec_topk_select_blocks(const float* blockmax, int32_t n_sb, int6
     return trec_topk_select_blocks_ex(blockmax, n_sb, n_users, stride, k, k, sel, sel_max, tau, stream);
 }
 
+extern "C" int trec_topk_collect_blocks_masked(const float* blockmax, int32_t n_sb, int64_t n_users, int64_t stride,
+                                               const float* floor_, int32_t ksel, int32_t* keys, int32_t* count, int32_t* flag,
+                                               int32_t* n_flagged, const int32_t* redo, void* stream);
+
 extern "C" int trec_topk_collect_blocks(const float* blockmax, int32_t n_sb, int64_t n_users, int64_t stride,
                                         const float* floor_, int32_t ksel, int32_t* keys, int32_t* count, int32_t* flag,
                                         int32_t* n_flagged, void* stream)
+{
+    return trec_topk_collect_blocks_masked(blockmax, n_sb, n_users, stride, floor_, ksel, keys, count, flag, n_flagged, nullptr, stream);
+}
+
+// trec_topk_collect_blocks for the users with redo[u] != 0 only (redo == NULL: everybody): the others' keys / count are left
+// alone, and a workgroup of 256 users without a marked one exits before reading the table.
+extern "C" int trec_topk_collect_blocks_masked(const float* blockmax, int32_t n_sb, int64_t n_users, int64_t stride,
+                                               const float* floor_, int32_t ksel, int32_t* keys, int32_t* count, int32_t* flag,
+                                               int32_t* n_flagged, const int32_t* redo, void* stream)
 {
     TREC_REQUIRE(blockmax && floor_ && keys && count && flag && n_flagged, "trec_topk_collect_blocks: null pointer");
     TREC_REQUIRE(ksel >= 1 && ksel <= 4096 && n_sb >= 1 && stride >= n_users, "trec_topk_collect_blocks: need 1 <= ksel <= 4096");
     if (n_users == 0) return TREC_OK;
     hipLaunchKernelGGL(collect_blocks_tiled_kernel, dim3((unsigned)ceil_div64(n_users, 256)), dim3(256), 0,
-                       (hipStream_t)stream, blockmax, n_sb, n_users, stride, floor_, ksel, keys, count, flag, n_flagged);
+                       (hipStream_t)stream, blockmax, n_sb, n_users, stride, floor_, ksel, keys, count, flag, n_flagged, redo);
     return trec_check_launch("trec_topk_collect_blocks");
 }
 
@@ -568,15 +590,16 @@ extern "C" int trec_topk_scan_blocks(const float* blockmax, int32_t n_sb, int64_
     return trec_check_launch("trec_topk_scan_blocks");
 }
 
-// the collect step from the candidate lists: keys [n_users][ksel] / count as trec_topk_collect_blocks writes them
+// the collect step from the candidate lists: keys [n_users][ksel] / count as trec_topk_collect_blocks writes them; redo
+// [n_users] = 1 for the users whose candidate list was incomplete (trec_topk_collect_blocks_masked re-does exactly those)
 extern "C" int trec_topk_prune_candidates(const int32_t* cand_s, const float* cand_v, const int32_t* cand_n, int32_t cand_cap,
                                           const float* floor_, int32_t ksel, int64_t n_users, int32_t* keys, int32_t* count,
-                                          int32_t* flag, int32_t* n_flagged, void* stream)
+                                          int32_t* flag, int32_t* n_flagged, int32_t* redo, void* stream)
 {
-    TREC_REQUIRE(cand_s && cand_v && cand_n && floor_ && keys && count && flag && n_flagged, "trec_topk_prune_candidates: null pointer");
+    TREC_REQUIRE(cand_s && cand_v && cand_n && floor_ && keys && count && flag && n_flagged && redo, "trec_topk_prune_candidates: null pointer");
     TREC_REQUIRE(ksel >= 1 && cand_cap >= 1, "trec_topk_prune_candidates: bad sizes");
     if (n_users == 0) return TREC_OK;
     hipLaunchKernelGGL(prune_candidates_kernel, dim3((unsigned)ceil_div64(n_users, 256)), dim3(256), 0, (hipStream_t)stream,
-                       cand_s, cand_v, cand_n, cand_cap, floor_, ksel, n_users, keys, count, flag, n_flagged);
+                       cand_s, cand_v, cand_n, cand_cap, floor_, ksel, n_users, keys, count, flag, n_flagged, redo);
     return trec_check_launch("trec_topk_prune_candidates");
 }

@@ -936,6 +936,7 @@ def score_topk_two_stage(users_op, items_op, dtype, kpad, k, user_bias=None, ite
 # superblocks a user may keep (1M x 1M, d = 128, k = 10: 15.5 on average; 19 users of 1M need more than 32, none more than
 # 48 -- a user beyond the limit goes to the exact fp32 fallback, whose launch chain costs ~1.2 ms however few users)
 FILTER_KSEL = 48
+FILTER_ONE_PASS_MIN_ENTRIES = 1 << 28   # table entries from which select + collect run as one scan (1 GB of maxima)
 FILTER_CANDIDATES = 128    # candidates per user of the one-pass scan (entries above the provisional floor: ~45 at 1M x 1M)
 FILTER_KSEL_WIDE = 320     # ... in the wide second pass over the flagged users (its finish kernel has no survivor limit)
 WIDE_TIER2_MAX_FRACTION = 0.05   # the all-superblocks tier runs only when at most this fraction of the users is still flagged
@@ -1427,7 +1428,12 @@ def _score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index
     flag = torch.empty((n_u,), dtype=torch.int32, device=dev)
     n_flagged = torch.zeros((1,), dtype=torch.int32, device=dev)
     keys_count = None
-    one_pass = tau8 is not None and cascade_status is not None and N.load().trec_get_tuning(b"filter_scan_one_pass", 1) != 0
+    # (it pays on big tables: 4.0 -> 3.55 ms of table passes at 1M users x 1,954 superblocks; on a 32,768-user batch the two
+    # passes cost 0.15 ms and the extra launches more than they save)
+    # tuning filter_scan_one_pass: 0 = never, 1 = by table size (default), 2 = always (tests)
+    mode1p = N.load().trec_get_tuning(b"filter_scan_one_pass", 1)
+    one_pass = tau8 is not None and cascade_status is not None and mode1p != 0 and \
+        (mode1p == 2 or n_u * n_sb >= FILTER_ONE_PASS_MIN_ENTRIES)
     if one_pass:
         cand_cap = FILTER_CANDIDATES
         floor0 = torch.empty((n_u,), dtype=torch.float32, device=dev)
@@ -1455,9 +1461,14 @@ def _score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index
     if one_pass:
         keys = torch.empty((n_u * ksel,), dtype=torch.int32, device=dev)
         count = torch.empty((n_u,), dtype=torch.int32, device=dev)
+        redo = torch.empty((n_u,), dtype=torch.int32, device=dev)
         with _timed("topk_collect_blocks"):
             N.call("trec_topk_prune_candidates", N.ptr(cand_s), N.ptr(cand_v), N.ptr(cand_n), cand_cap, N.ptr(floor), ksel, n_u,
-                   N.ptr(keys), N.ptr(count), N.ptr(flag), N.ptr(n_flagged))
+                   N.ptr(keys), N.ptr(count), N.ptr(flag), N.ptr(n_flagged), N.ptr(redo))
+            # users with more entries above the provisional floor than the candidate list holds (a loose int8 bound): their
+            # column is collected from the table after all; workgroups of 256 users without such a user exit at once
+            N.call("trec_topk_collect_blocks_masked", N.ptr(blockmax), n_sb, n_u, bm_stride, N.ptr(floor), ksel, N.ptr(keys),
+                   N.ptr(count), N.ptr(flag), N.ptr(n_flagged), N.ptr(redo))
         keys_count = (keys, count)
         del cand_s, cand_v
     ov, oi, count = _filter_tail(uop, iop, blockmax, bm_stride, n_u, n_sb, k, user_bias, item_bias, item_index_base, sb_rows,

@@ -475,3 +475,30 @@ def test_rows_hot_lists_rows_over_capacity(ops):
         assert rc.cpu().tolist() == [5, 0, 512, 0, 0, 0, 100, 0]
         rows = 512 + 512 + 0 + 512 + min(len(want), hot_cap) * 1024
         assert status.cpu().tolist() == [rows, over]
+
+
+@pytest.mark.parametrize("cand_cap", [128, 6])
+def test_one_pass_scan_equals_select_plus_collect(ops, cand_cap):
+    """Behind the int8 stage, select + collect run as ONE pass over big tables (trec_topk_scan_blocks with a provisional floor
+    from tau8 + trec_topk_prune_candidates); forced here on a small one.  cand_cap = 6: nearly every user has more entries
+    above the provisional floor than its candidate list holds -- those are re-collected by the masked pass
+    (trec_topk_collect_blocks_masked).  Same result as the two-pass form and as the oracle."""
+    from tensorrec_amd import _native as N
+    rng = np.random.default_rng(41)
+    n_u, n_i, d, k = 1300, 300_000, 128, 10
+    u = rng.standard_normal((n_u, d)).astype(np.float32)
+    v = rng.standard_normal((n_i, d)).astype(np.float32)
+    ub = (0.3 * rng.standard_normal(n_u)).astype(np.float32)
+    ib = (0.3 * rng.standard_normal(n_i)).astype(np.float32)
+    rv, ri = O.topk_rows(O.score_dense_exact(u, v, ub, ib), k)
+    old_cap = ops.FILTER_CANDIDATES
+    try:
+        ops.FILTER_CANDIDATES = cand_cap
+        N.set_tuning("filter_scan_one_pass", 2)
+        vals, idx, stats, _, _ = run_cascade(ops, u, v, k, ub, ib)
+    finally:
+        ops.FILTER_CANDIDATES = old_cap
+        N.set_tuning("filter_scan_one_pass", 1)
+    assert stats["prefilter"] == "int8"
+    assert np.array_equal(idx, ri) and np.array_equal(vals, rv)
+    assert stats["flagged_users"] <= 13

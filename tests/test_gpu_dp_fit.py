@@ -130,6 +130,9 @@ def _topk_worker(rank, world, port, n_items, n_tastes, ret, d=32):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        if os.environ.get("TREC_TEST_ONE_PASS"):                # the one-pass select + collect, forced on these small tables
+            from tensorrec_amd import _native
+            _native.set_tuning("filter_scan_one_pass", 2)
         model, uf, itf = _topk_case(n_items, n_tastes, d)
         b, e = sharding.shard_bounds(n_items, world, rank)
         ret[rank] = model.predict_top_k(uf, itf[b:e], k=10, item_sharded=True, item_offset=b)
@@ -147,6 +150,20 @@ def test_item_sharded_predict_top_k_equals_single_process(n_items, n_tastes, d):
     mgr = mp.get_context("spawn").Manager()
     ret = mgr.dict()
     mp.spawn(_topk_worker, args=(2, _free_port(), n_items, n_tastes, ret, d), nprocs=2, join=True)
+    for r in (0, 1):
+        v, i = ret[r]
+        assert np.array_equal(i, ref_i) and np.array_equal(v, ref_v), "rank %d" % r
+
+
+def test_item_sharded_cascade_with_the_one_pass_scan(monkeypatch):
+    """300,000 items over two ranks with select + collect as ONE scan (forced: these tables are small): the scan's k largest
+    entries are what the ranks exchange for the shared floor, the provisional floor comes from the shared tau8."""
+    monkeypatch.setenv("TREC_TEST_ONE_PASS", "1")
+    model, uf, itf = _topk_case(300000, 1, 64)
+    ref_v, ref_i = model.predict_top_k(uf, itf, k=10)
+    mgr = mp.get_context("spawn").Manager()
+    ret = mgr.dict()
+    mp.spawn(_topk_worker, args=(2, _free_port(), 300000, 1, ret, 64), nprocs=2, join=True)
     for r in (0, 1):
         v, i = ret[r]
         assert np.array_equal(i, ref_i) and np.array_equal(v, ref_v), "rank %d" % r
