@@ -596,7 +596,18 @@ def main():
                 ev, ei = ops.score_topk_two_stage(u32, i32, ops.DTYPE_F32, kpad, k, ub32, ib32)
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / reps
+            # ... and the equality check over ALL users (the fp32 MFMA path is bit-exact against the oracle: tests), untimed
+            all_equal = bool(torch.equal(ei, idx[:n32]) and torch.equal(ev, vals[:n32]))
+            ub_all = None if args.unbiased else ops.sparse_matvec(f_u, beta_u)
+            for s0 in range(n32, U, n32):
+                if not all_equal:
+                    break
+                uu, _, _ = ops.score_prep(user_repr[s0:s0 + n32].contiguous(), ops.DTYPE_F32)
+                cv_, ci_ = ops.score_topk_two_stage(uu, i32, ops.DTYPE_F32, kpad, k,
+                                                    None if ub_all is None else ub_all[s0:s0 + n32].contiguous(), ib32)
+                all_equal = bool(torch.equal(ci_, idx[s0:s0 + n32]) and torch.equal(cv_, vals[s0:s0 + n32]))
             fp32_mode = {"workload": "%d users x %d items, whole two-stage top-%d on fp32 MFMA" % (n32, n_local, k),
+                         "equals_timed_exact_mode_output_all_%d_users" % U: all_equal,
                          "ms": 1e3 * dt, "predictions_per_s": n32 * float(n_local) / dt,
                          "tflops": 2.0 * n32 * n_local * kpad / dt / 1e12,
                          "frac_of_fp32_mfma_peak": 2.0 * n32 * n_local * kpad / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS,
