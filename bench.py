@@ -663,10 +663,10 @@ def main():
             files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bf16dense_pmc_summary.txt")))
             if files and (U, I, d) == (1_000_000, 1_000_000, 128):
                 txt = open(files[-1]).read()
-                f_ = re.findall(r"blockmax_bf16x16_kernel<128, true, false>[^\n]*?FETCH_SIZE=([0-9.e+]+)", txt)
-                w_ = re.findall(r"blockmax_bf16x16_kernel<128, true, false>[^\n]*?WRITE_SIZE=([0-9.e+]+)", txt)
-                h_ = re.findall(r"blockmax_bf16x16_kernel<128, true, false>[^\n]*?TCC_HIT=([0-9.e+]+)", txt)
-                m_ = re.findall(r"blockmax_bf16x16_kernel<128, true, false>[^\n]*?TCC_MISS=([0-9.e+]+)", txt)
+                f_ = re.findall(r"blockmax_bf16x16_kernel<128, true, false[^\n]*?FETCH_SIZE=([0-9.e+]+)", txt)
+                w_ = re.findall(r"blockmax_bf16x16_kernel<128, true, false[^\n]*?WRITE_SIZE=([0-9.e+]+)", txt)
+                h_ = re.findall(r"blockmax_bf16x16_kernel<128, true, false[^\n]*?TCC_HIT=([0-9.e+]+)", txt)
+                m_ = re.findall(r"blockmax_bf16x16_kernel<128, true, false[^\n]*?TCC_MISS=([0-9.e+]+)", txt)
                 if f_ and w_:
                     roofline_bf16_dense["traffic"] = (2.0 * float(f_[0]) + float(w_[0])) * 1024.0
                     roofline_bf16_dense["traffic_note"] = ("(2*FETCH_SIZE + WRITE_SIZE) KB per launch from %s; algorithmic minimum "

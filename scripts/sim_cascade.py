@@ -78,7 +78,7 @@ def simulate(X, Y, bu=None, bi=None, k=10, lay="none", residual=False, uscale="g
     Y, bi = Y[perm].contiguous(), bi[perm].contiguous()
     n_sb = ni // SB
     K = d
-    cK = (K + 4) * (2.0 ** -24 + 2.0 ** -22)
+    cK = (K + 6) * (2.0 ** -24 + 2.0 ** -22)
     S = X @ Y.t() + bu[:, None] + bi[None, :]                              # "truth" (fp32)
     tk = torch.topk(S, k, dim=1).values[:, -1]
     Ysb = Y.view(n_sb, SB, d)
@@ -110,7 +110,7 @@ def simulate(X, Y, bu=None, bi=None, k=10, lay="none", residual=False, uscale="g
     dY_s = dR.norm(dim=1).view(n_sb, SB).max(1).values
     I8 = (qu @ qi.t())                                                     # exact integers in fp32 (|acc| < 2^24)
     unit = a[:, None] * bs.repeat_interleave(SB)[None, :]
-    bq = (bi[None, :] / unit).round().clamp(-2 ** 22, 2 ** 22)
+    bq = (bi[None, :] / unit).round().clamp(-2 ** 30, 2 ** 30)
     S8 = unit * (I8 + bq)
     dB = (bi[None, :] - unit * bq).abs().view(nu, n_sb, SB).max(2).values    # [nu, n_sb]
     M8 = S8.view(nu, n_sb, SB).max(2).values + O + bu[:, None]

@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256, WPS) void blockmax_i8_kernel(ScoreParams p)
             for (int cb = 0; cb < NCB; ++cb) {
                 const int o = __shfl_xor(bm[cb], 32, 64);
                 const int m = bm[cb] > o ? bm[cb] : o;
-                float v = (float)m * scale;                   // |m| < 2^24: the conversion is exact
+                float v = (float)m * scale;                   // (exact below 2^24; beyond it one rounding, charged in i8_pair_err)
                 if (BIAS) v = v + r_bias[cb];
                 const int64_t u = r_base + cb * 32 + l31;
                 if (half == 0 && u < p.n_r) p.blockmax[sb * p.bm_stride + u] = v;
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void blockmax_i8x16_kernel(ScorePa
 #pragma unroll
             for (int o = 0; o < OW; ++o) {
                 const int mo = g == 0 ? m[o] : (g == 1 ? m[OW + o] : (g == 2 ? m[2 * OW + o] : m[3 * OW + o]));
-                float v = (float)mo * scale;                  // |m| < 2^24: the conversion is exact
+                float v = (float)mo * scale;                  // (exact below 2^24; beyond it one rounding, charged in i8_pair_err)
                 if (BIAS) v = v + own_bias[o];
                 if (own_u[o] < p.n_r) p.blockmax[sb * p.bm_stride + own_u[o]] = v;
                 if (TK) {
@@ -657,7 +657,11 @@ __global__ __launch_bounds__(256) void bias_i8_kernel(const float* __restrict__ 
     for (int64_t i = r0 + threadIdx.x; i < r1; i += 256) {
         const float b = bias[i];
         float bq = rintf(b / sp);
-        bq = fminf(fmaxf(bq, -4194304.f), 4194304.f);                   // |bq| <= 2^22: accumulators stay below 2^24
+        // |bq| <= 2^30: the int32 accumulator (|q.q| <= 2^21) cannot overflow.  (Round 2 clamped at 2^22 to keep the int -> float
+        // conversion of the maximum exact; with a scale per user class the product a_c b_s of a small user and a superblock
+        // of small items is ~1e-8 and a bias of 1 is 1e8 units: clamped, the bias error made every bound useless -- fitted
+        // models fell back to bf16.  The conversion now rounds (2^-24 relative): one more unit of c_K in i8_pair_err.)
+        bq = fminf(fmaxf(bq, -1073741824.f), 1073741824.f);
         if (!(bq == bq)) bq = 0.f;
         bq_c[i] = (int)bq;
         float a2 = fabsf(b), a3 = fabsf(b - bq * sp);
@@ -748,7 +752,7 @@ __global__ __launch_bounds__(256) void user_err_i8_kernel(const float2* __restri
     if (u >= n_users) return;
     const float2 st = ustats[u];
     const float bu = user_bias ? fabsf(user_bias[u]) : 0.f;
-    const float ck = (float)(kdim + 4) * 2.98023224e-07f;
+    const float ck = (float)(kdim + 6) * 2.98023224e-07f;
     *(f32x4*)(r_err + u * 4) = (f32x4){st.x, st.y, ck * (bu + gstats[2]), wg_scale ? wg_scale[u / wg_rows] : scales[0]};
 }
 

@@ -50,7 +50,9 @@ struct ScoreParams {
 // kernel (lower bounds M - e) and by the compaction (upper bounds M + e)
 __device__ __forceinline__ float i8_pair_err(float nx, float ex, float cu, float yh, float dy, float db, int kdim)
 {
-    const float ck = (float)(kdim + 4) * 2.98023224e-07f;                       // (K + 4) (2^-24 + 2^-22)
+    // (K + 6) (2^-24 + 2^-22): the reference's own fp32 chain (K + 2), the two roundings of a b_s m + b_u, the int32 -> float
+    // conversion of the maximum (exact below 2^24; the integer item bias may reach 2^30) and the bias error's own evaluation
+    const float ck = (float)(kdim + 6) * 2.98023224e-07f;
     const float e = nx * (dy + ck * yh) + ex * yh + db + cu;
     return e * 1.001953125f + 1e-30f;
 }

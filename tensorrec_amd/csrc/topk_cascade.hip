@@ -65,7 +65,7 @@ __device__ __forceinline__ unsigned int tile_bits(const float* __restrict__ tabl
                                                   int32_t s0, int64_t u)
 {
     const float infl = 1.0029296875f;
-    const float ck = (float)(kdim + 4) * 2.98023224e-07f;
+    const float ck = (float)(kdim + 6) * 2.98023224e-07f;
     const bool vec = (stride % 4 == 0) && (((uintptr_t)table % 16) == 0) && (u + 3 < stride);
     unsigned int bits = 0;
 #pragma unroll

@@ -161,7 +161,7 @@ def test_cascade_non_finite_rows_fall_back(ops):
 def _pair_err(nx, ex, cu, yh, dy, db, kdim):
     """i8_pair_err (csrc/score_common.hpp) in float32, operation for operation."""
     f = np.float32
-    ck = f(kdim + 4) * f(2.98023224e-07)
+    ck = f(kdim + 6) * f(2.98023224e-07)
     e = nx * (dy + ck * yh) + ex * yh + db + cu
     return e * f(1.001953125) + f(1e-30)
 
@@ -295,7 +295,7 @@ def test_rows_compaction_lists_exactly_the_pairs_whose_upper_bound_reaches_the_t
         with np.errstate(invalid="ignore", over="ignore"):
             # tile_bits (csrc/topk_cascade.hip), operation for operation in float32 (fma through float64: exact product)
             f32, f64 = np.float32, np.float64
-            infl, ck = f32(1.0029296875), f32(128 + 4) * f32(2.98023224e-07)
+            infl, ck = f32(1.0029296875), f32(128 + 6) * f32(2.98023224e-07)
             A = ((sbs[:, 2] + ck * sbs[:, 1]) * infl)[:, None]
             B = (sbs[:, 1] * infl)[:, None]
             C = (sbs[:, 3] * infl)[:, None]
@@ -351,7 +351,7 @@ def test_rows_collect_one_pass_keeps_the_same_pairs(ops):
         sbs = rng.uniform(0.0, 1.0, (n_sb, 4)).astype(np.float32)
         with np.errstate(invalid="ignore", over="ignore"):
             f32, f64 = np.float32, np.float64
-            infl, ck = f32(1.0029296875), f32(128 + 4) * f32(2.98023224e-07)
+            infl, ck = f32(1.0029296875), f32(128 + 6) * f32(2.98023224e-07)
             A = ((sbs[:, 2] + ck * sbs[:, 1]) * infl)[:, None]
             B = (sbs[:, 1] * infl)[:, None]
             C = (sbs[:, 3] * infl)[:, None]

@@ -9,6 +9,9 @@ What each kind stresses:
   scaled_rows                   row norms spread over e^+-6: scale classes on the user side, hot superblocks on the item side
   integers                      exact ties everywhere: ids follow tf.nn.top_k's lower-index-first order
   popular_bias                  a Zipf catalogue: a few items with large norms and biases wanted by everybody (hot superblocks)
+  fitted_like                   what 50 WMRB epochs leave behind: user norms over two decades, item rows of norm ~0.05 with a few
+                                at 300x that, item biases up to +4 -- the scale product of a small user's class and a superblock of
+                                small items is ~1e-8, so a bias of 1 is 1e8 integer units (clamped at 2^22 it made the bounds useless)
   clustered256_10 / _03         256 clusters with within-cluster spread 1.0 / 0.3 of the centre scale: the int8 bound loosens,
                                 the wide second pass takes the users with many near-equal superblocks
   clustered                     8 tight clusters (spread 0.05): thousands of items per user within the bf16 bound of the k-th
@@ -20,9 +23,10 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-KINDS = ["gauss", "normalised", "heavy_tail", "sparse", "integers", "scaled_rows", "popular_bias", "clustered256_10",
-         "clustered256_03", "clustered"]
-INT8_MUST_RUN = {"gauss", "normalised", "heavy_tail", "sparse", "integers", "scaled_rows", "popular_bias", "clustered256_10"}
+KINDS = ["gauss", "normalised", "heavy_tail", "sparse", "integers", "scaled_rows", "popular_bias", "fitted_like",
+         "clustered256_10", "clustered256_03", "clustered"]
+INT8_MUST_RUN = {"gauss", "normalised", "heavy_tail", "sparse", "integers", "scaled_rows", "popular_bias", "fitted_like",
+                 "clustered256_10"}
 
 
 @pytest.fixture(scope="module")
@@ -43,6 +47,7 @@ def make(ops, kind, n, d, g):
     elif kind.startswith("clustered256_"):
         x = torch.randn((256, d), device="cuda", generator=g)[torch.randint(0, 256, (n,), device="cuda", generator=g)] + float(kind.split("_")[1]) / 10.0 * x
     elif kind == "scaled_rows": x = x * torch.exp(2.0 * torch.randn((n, 1), device="cuda", generator=g))
+    elif kind == "fitted_like": x = x * 0.004
     return x.contiguous()
 
 
@@ -59,6 +64,13 @@ def test_cascade_exact_on_every_data_kind(ops, kind, seed):
         v = (v * (0.3 + pop / pop.max()).unsqueeze(1)).contiguous()
         ib = (2.0 * pop).contiguous()
         ub = torch.randn(n_u, device="cuda", generator=g)
+    elif kind == "fitted_like":
+        u = (u * 5.0 * torch.exp(1.2 * torch.randn((n_u, 1), device="cuda", generator=g))).contiguous()      # norms 0.05 .. 5
+        heavy = torch.randperm(n_i, device="cuda", generator=g)[: n_i // 1000]
+        v[heavy] *= 300.0
+        ib = 0.05 * torch.randn(n_i, device="cuda", generator=g)
+        ib[heavy] += 1.0 + 3.0 * torch.rand(heavy.numel(), device="cuda", generator=g)
+        ub = 0.005 * torch.randn(n_u, device="cuda", generator=g)
     elif seed == 2:
         scale = float(v.abs().mean() * u.abs().mean() * d ** 0.5)
         ub = torch.randn(n_u, device="cuda", generator=g) * scale * 0.3
