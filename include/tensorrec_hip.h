@@ -292,8 +292,8 @@ int trec_score_gemm_blockmax_grouped(const void* users_bf16, const void* items_b
 /* Skewed catalogues (fitted models, Zipf popularity: a few superblocks are wanted by most users although only 2-3% of all
  * pairs are kept).  trec_topk_rows_hot, after trec_topk_rows_collect: superblocks with row_count > rcap are listed in hot_list
  * [hot_cap] (ascending, -1 padded) and their row_count is zeroed -- the fixed-capacity grouped launch skips them;
- * status = {resident rows of both launches, 1 when more than hot_cap superblocks are hot or more than max_pairs pairs would be refined: the
- * caller falls back to the dense bf16 stage 1}.  trec_score_gemm_blockmax_hot: the dense bf16 filter kernel over the listed superblocks only, EVERY user,
+ * status [3] = {resident rows of both launches, 1 when more than hot_cap superblocks are hot or more than max_pairs pairs would be refined: the
+ * caller falls back to the dense bf16 stage 1, the number of hot superblocks (the grid of the hot launch: hot_cap = that)}.  trec_score_gemm_blockmax_hot: the dense bf16 filter kernel over the listed superblocks only, EVERY user,
  * maxima written over the table's entries (same arithmetic as tf.matmul of tensorrec/prediction_graphs.py:49-50 in bf16,
  * used as a bounded filter like the grouped form). */
 int trec_topk_rows_hot(int32_t* row_count, int32_t n_sb, int32_t rcap, int64_t n_users, int32_t* hot_list, int32_t hot_cap,
@@ -301,6 +301,32 @@ int trec_topk_rows_hot(int32_t* row_count, int32_t n_sb, int32_t rcap, int64_t n
 int trec_score_gemm_blockmax_hot(const void* users_bf16, const void* items_bf16, int32_t kpad, int64_t n_users,
                                  int64_t n_items, const float* user_bias, const float* item_bias, int32_t sb_rows,
                                  const int32_t* hot_list, int32_t hot_cap, float* blockmax, int64_t bm_stride, void* stream);
+/* The refining launches that also LIST candidates (csrc/topk_cascade.hip, kernel form LIST of csrc/score_blockmax.hip; same
+ * place in the reference: the fp32 tf.matmul + tf.nn.top_k of prediction_graphs.py:49-50 / recommendation_graphs.py:80, used
+ * as a bounded filter).  Same work as trec_score_gemm_blockmax_grouped (fixed-capacity layout: wgs_per_row > 0, rblock_chunk =
+ * row_count) / trec_score_gemm_blockmax_hot, and besides the maxima every ITEM of a refined pair whose bf16 score (+ user bias)
+ * reaches cand_floor[user] -- tauLB - eps, trec_topk_filter_floor_ex(tau8, ..., mult = 1): +inf lists nothing -- is appended
+ * to cand [n_users][cand_cap] of {int32 item id + item_index_base, float score bits}; cand_n [n_users] (zeroed by the caller)
+ * counts the appends, beyond cand_cap they are dropped.  trec_topk_candidates_finish: tau = the k-th largest listed score,
+ * survivors = listed items >= tau - 2 eps (user_stats / item_gstats as for trec_topk_filter_floor), exact fp32 re-scoring
+ * and top-k as trec_topk_filter_finish; users with cand_n > cand_cap (64, 128, 192 or 256) or more than 64 survivors are
+ * flagged, users whose cand_floor is +inf are skipped (their outputs are -inf / -1).  This replaces, behind the int8 stage,
+ * the table scan, the grouping by superblock and the grouped list kernel of the bf16 filter. */
+int trec_score_gemm_refine_candidates(const void* users_bf16, const void* items_bf16, int32_t kpad, int64_t n_rows_g,
+                                      int64_t n_items, const float* user_bias, const float* item_bias, int32_t sb_rows,
+                                      const int32_t* row_count, const int32_t* row_user, float* blockmax, int64_t bm_stride,
+                                      int32_t wgs_per_row, const float* cand_floor, int32_t* cand_n, void* cand,
+                                      int32_t cand_cap, int32_t item_index_base, void* stream);
+int trec_score_gemm_refine_candidates_hot(const void* users_bf16, const void* items_bf16, int32_t kpad, int64_t n_users,
+                                          int64_t n_items, const float* user_bias, const float* item_bias, int32_t sb_rows,
+                                          const int32_t* hot_list, int32_t hot_cap, float* blockmax, int64_t bm_stride,
+                                          const float* cand_floor, int32_t* cand_n, void* cand, int32_t cand_cap,
+                                          int32_t item_index_base, void* stream);
+int trec_topk_candidates_finish(const int32_t* cand_n, const void* cand, int32_t cand_cap, const float* cand_floor,
+                                const float* user_stats, const float* item_gstats, const float* users_f32,
+                                const float* items_f32, int64_t ld_users, int64_t ld_items, int32_t kdim,
+                                const float* user_bias, const float* item_bias, int32_t item_index_base, int64_t n_users,
+                                int32_t k, float* out_vals, int32_t* out_idx, int32_t* flag, int32_t* n_flagged, void* stream);
 int trec_topk_filter_floor(const float* tau, const float* user_stats, const float* user_bias, const float* item_gstats,
                            int32_t kdim, int64_t n_users, float* floor, int32_t* flag, int32_t* n_flagged, void* stream);
 int trec_topk_collect_blocks(const float* blockmax, int32_t n_sb, int64_t n_users, int64_t stride, const float* floor,

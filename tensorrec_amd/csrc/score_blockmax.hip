@@ -334,7 +334,17 @@ __global__ __launch_bounds__(256, WPS) void blockmax_pipe_kernel(ScoreParams p)
 // RDL: the step's LDS operand prefetch is issued AFTER its MFMAs (true) instead of before (false, the default): the change
 // that gave the int8 kernel 3% (score_blockmax_i8.hip) measured slightly SLOWER here (dense 151.5 vs 150.5 ms, grouped 6.79 vs
 // 6.74: 8 user blocks and 4 k-steps per block leave the drain less exposed); kept as tuning blockmax_bf16_rdlate = 1.
-template <int KT, bool BIAS, bool GRP, int NUB = 8, bool RDL = false>
+// LIST (the cascade's refining launches, csrc/topk_candidates.hip): besides the maxima, every ITEM whose bf16 score reaches the
+// user's provisional floor p.cand_floor[u] is appended to the user's candidate list (p.cand[u][slot], slot from an atomic on
+// p.cand_n[u]).  In the MFMA loop that costs one v_max3 + v_max + v_cmp per 4-item accumulator; a lane whose four scores hold a
+// hit copies them (ds_write_b128) with a 4-byte code to a queue in LDS that only its wave uses (slots from ballot + mbcnt: no
+// atomics, no waiting); the queue is emptied -- scores + user bias compared exactly, atomics, 8-byte stores -- at the end of
+// the superblock, and inside it only if it runs more than LQ_FLUSH entries full: then the 256 entries half a block step can add
+// always fit (popular items of fitted catalogues hit for every user of the wave at once), so no hit is ever dropped.
+constexpr int LQ_CAP = 448;               // queue entries per wave (20 bytes each: 35,840 bytes per workgroup)
+constexpr int LQ_FLUSH = 192;             // a queue fuller than this is emptied before the next half block step (192 + 4 * 64 <= 448)
+
+template <int KT, bool BIAS, bool GRP, int NUB = 8, bool RDL = false, bool LIST = false>
 __global__ __launch_bounds__(256, NUB == 8 ? 2 : 3) void blockmax_bf16x16_kernel(ScoreParams p)
 {
     constexpr int RW = 4 * NUB * 16;         // resident rows per workgroup
@@ -355,6 +365,14 @@ __global__ __launch_bounds__(256, NUB == 8 ? 2 : 3) void blockmax_bf16x16_kernel
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, lu = lane & 15;
+    // LIST: per wave a queue of (four scores, code) and the floor / bias / id of its NUB * 16 users, behind the tiles
+    constexpr int LQ_OFF = 2 * TILE_BYTES + 2 * BN * 4;
+    f32x4* qv = (f32x4*)(smem + LQ_OFF) + wave * LQ_CAP;
+    int32_t* qc = (int32_t*)(smem + LQ_OFF + 4 * LQ_CAP * 16) + wave * LQ_CAP;
+    float* q_fl = (float*)(smem + LQ_OFF + 4 * LQ_CAP * 20) + wave * (NUB * 16);
+    float* q_bu = q_fl + 4 * NUB * 16;
+    int32_t* q_id = (int32_t*)(q_bu + 4 * NUB * 16);
+    int qn = 0;                                                  // wave-uniform: entries in the queue
     int rblock = GRP ? (int)blockIdx.x : (int)(blockIdx.x % p.n_rblocks);
     if (GRP && p.capacity > 0 && p.grp_band_major) {
         // fixed-capacity layout walked band-major: consecutive workgroups take list chunk j of superblocks 0, 1, 2, ... -- the
@@ -388,18 +406,38 @@ __global__ __launch_bounds__(256, NUB == 8 ? 2 : 3) void blockmax_bf16x16_kernel
 
     // ---- resident user fragments: lane holds k = 32 ks + 8 g + 0..7 of user lu of each block ----
     bf16x8 rfb[NUB][KS];
+    float thr_a[NUB];                                            // LIST: an accumulator below this cannot reach the user's floor
 #pragma unroll
     for (int ub = 0; ub < NUB; ++ub) {
         int64_t row = r_base + ub * 16 + lu;
+        bool real = row < p.n_r;
         if (row >= p.n_r) row = p.n_r - 1;                       // clamped rows are never written
         if (GRP) {                                               // padding rows compute on user 0
             const bool pad = fixed && wave * (NUB * 16) + ub * 16 + lu >= rows_here;
             const int32_t s = pad ? -1 : p.row_index[row];
+            real = s >= 0;
             row = s < 0 ? 0 : s;
         }
         const char* src = (const char*)p.R + row * (int64_t)RB;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) rfb[ub][ks] = *(const bf16x8*)(src + (ks * 4 + g) * 16);
+        thr_a[ub] = INFINITY;
+        if (LIST) {
+            const float fl = real ? p.cand_floor[row] : INFINITY;
+            const float bu = (BIAS && p.r_bias && real) ? p.r_bias[row] : 0.f;
+            // acc + bu >= fl (evaluated exactly when the queue is emptied) implies acc >= thr_a: fl - bu less three roundings
+            const float t = fl - bu;
+            float ta = t - (fabsf(fl) + fabsf(bu) + fabsf(t)) * 2.4e-7f;
+            if (bu == 0.f) ta = fl;
+            if (!(fl < INFINITY)) ta = INFINITY;                 // padding rows, users without a usable bound: nothing is listed
+            else if (!(ta == ta)) ta = -INFINITY;                // (fl = -inf: everything is)
+            thr_a[ub] = ta;
+            if (g == 0) {
+                q_fl[ub * 16 + lu] = fl;
+                q_bu[ub * 16 + lu] = bu;
+                q_id[ub * 16 + lu] = real ? (int32_t)row : -1;
+            }
+        }
     }
     // the users this lane stores at superblock ends
     int64_t own_u[OW];
@@ -457,6 +495,43 @@ __global__ __launch_bounds__(256, NUB == 8 ? 2 : 3) void blockmax_bf16x16_kernel
 #pragma unroll
     for (int ub = 0; ub < NUB; ++ub) bm[ub] = -INFINITY;
 
+    // LIST: empty this wave's queue.  Entry = the four scores of items item0 .. item0 + 3 of one user (code = user slot << 16 |
+    // 4-item group of the superblock); a score that reaches the floor with the user bias added takes the next slot of the
+    // user's list.  One lane, one entry: its (up to four) hits take their slots with independent atomics, then the 8-byte stores.
+    int tile_now = 0;                                            // first 16-item block of the tile the step loop is in, counted inside its superblock
+    int64_t sb_first = t_begin;                                  // first item of the superblock whose entries the queue holds
+    auto queue_entry = [&](int i, int n) __attribute__((always_inline)) {
+        const bool in = i < n;
+        const int32_t code = in ? qc[i] : 0;
+        const f32x4 a = in ? qv[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int ul = code >> 16;
+        const int32_t uid = in ? q_id[ul] : -1;
+        const float fl = q_fl[ul], bu = q_bu[ul];
+        const int64_t item0 = sb_first + (int64_t)(code & 0xffff) * 4;
+        float v[4];
+        int32_t slot[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] = BIAS ? a[e] + bu : a[e];
+            slot[e] = 0x7fffffff;
+            if (uid >= 0 && v[e] >= fl && item0 + e < p.n_t) slot[e] = atomicAdd(p.cand_n + uid, 1);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (slot[e] < p.cand_cap && p.cand_diag != 2)
+                p.cand[(int64_t)uid * p.cand_cap + slot[e]] = make_int2((int32_t)(item0 + e) + p.t_index_base, __float_as_int(v[e]));
+    };
+    auto queue_flush = [&](auto unrc) __attribute__((always_inline)) {
+        constexpr int UNR = decltype(unrc)::value;              // entries per lane and round (their atomics are in flight together)
+        const int n = p.cand_diag == 1 ? 0 : qn;
+#pragma unroll 1
+        for (int i0 = 0; i0 < n; i0 += 64 * UNR) {
+#pragma unroll
+            for (int j = 0; j < UNR; ++j) queue_entry(i0 + j * 64 + lane, n);
+        }
+        qn = 0;
+    };
+
     auto tile_body = [&](auto bufc) __attribute__((always_inline)) {
         constexpr int buf = decltype(bufc)::value;
         const char* tb = smem + buf * TILE_BYTES;
@@ -486,11 +561,33 @@ __global__ __launch_bounds__(256, NUB == 8 ? 2 : 3) void blockmax_bf16x16_kernel
             }
             if (RDL && s + 2 < NSTEP)
                 tf[(s + 2) % 3] = *(const bf16x8*)(tb + ((s + 2) / KS) * 16 * RB + koff[(s + 2) % KS]);
-            if (ks == KS - 1) {
+            if (ks == KS - 1 && !LIST) {
 #pragma unroll
                 for (int ub = 0; ub < NUB; ++ub) {
                     bm[ub] = fmaxf(fmaxf(bm[ub], acc[ub][0]), acc[ub][1]);
                     bm[ub] = fmaxf(fmaxf(bm[ub], acc[ub][2]), acc[ub][3]);
+                }
+            }
+            if (ks == KS - 1 && LIST) {
+                const int32_t grp = ((tile_now + blk) << 2) + g;                             // 4-item group of the superblock
+#pragma unroll
+                for (int ub = 0; ub < NUB; ++ub) {
+                    // (a wave of 128 users meets ~4 hits per 16-item block on Gaussian rows: the branch per accumulator set is taken
+                    // for four of ten; ONE test per block step for all eight sets measured slower, 13.2 against 10.2 ms)
+                    if ((ub % (NUB / 2)) == 0 && __builtin_expect(qn > LQ_FLUSH, 0)) queue_flush(std::integral_constant<int, 1>{});
+                    const float m4 = fmaxf(fmaxf(fmaxf(acc[ub][0], acc[ub][1]), acc[ub][2]), acc[ub][3]);
+                    bm[ub] = fmaxf(bm[ub], m4);
+                    const bool hit = m4 >= thr_a[ub];
+                    const unsigned long long hm = __builtin_amdgcn_ballot_w64(hit);
+                    if (hm != 0ull) {                            // wave-uniform
+                        const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(hm >> 32),
+                                                                            __builtin_amdgcn_mbcnt_lo((unsigned int)hm, 0u));
+                        if (hit) {
+                            qv[pos] = acc[ub];
+                            qc[pos] = ((ub * 16 + lu) << 16) | grp;
+                        }
+                        qn += __builtin_popcountll(hm);
+                    }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -504,10 +601,12 @@ __global__ __launch_bounds__(256, NUB == 8 ? 2 : 3) void blockmax_bf16x16_kernel
     for (int t = 0; t < n_tiles; ++t) {
         const int buf = t & 1;
         if (t + 1 < n_tiles) stage_issue(t + 1, buf ^ 1);
+        if (LIST) tile_now = (t % p.sb_tiles) * NBLK;
         if (buf == 0) tile_body(std::integral_constant<int, 0>{});
         else tile_body(std::integral_constant<int, 1>{});
 
         if (((t + 1) % p.sb_tiles) == 0 || t + 1 == n_tiles) {
+            if (LIST) { queue_flush(std::integral_constant<int, 3>{}); sb_first = t_begin + (int64_t)(t + 1) * BN; }
             // end of a superblock: the four row-groups' maxima of every user meet; row-group g stores blocks OW g .. OW g + OW - 1
             const int64_t sb = GRP ? (int64_t)chunk : t_begin / ((int64_t)p.sb_tiles * BN) + t / p.sb_tiles;
             float m[NUB];
@@ -530,12 +629,12 @@ __global__ __launch_bounds__(256, NUB == 8 ? 2 : 3) void blockmax_bf16x16_kernel
     }
 }
 
-template <int KT, bool BIAS, bool GRP, int NUB = 8, bool RDL = false>
+template <int KT, bool BIAS, bool GRP, int NUB = 8, bool RDL = false, bool LIST = false>
 int launch_bf16x16(ScoreParams p, hipStream_t st)
 {
-    constexpr int LDS = 2 * BN * KT * 2 + 2 * BN * 4;
+    constexpr int LDS = 2 * BN * KT * 2 + 2 * BN * 4 + (LIST ? 4 * LQ_CAP * 20 + 3 * 4 * NUB * 16 * 4 : 0);
     constexpr int RW = 4 * NUB * 16;
-    auto kern = blockmax_bf16x16_kernel<KT, BIAS, GRP, NUB, RDL>;
+    auto kern = blockmax_bf16x16_kernel<KT, BIAS, GRP, NUB, RDL, LIST>;
     static bool attr_set = false;
     if (!attr_set && LDS > 32 * 1024) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -775,6 +874,10 @@ int launch_blockmax_pipelined_grouped(const ScoreParams& p, int kt, hipStream_t 
     if (trec_get_tuning("blockmax_bf16_mfma16", 1) != 0) {       // the 16x16x32 form (filters only: see blockmax_bf16x16_kernel)
         if (kt == 128 && p.capacity > 0 && trec_get_tuning("cascade_grouped_nub", 8) == 4)
             return bias ? launch_bf16x16<128, true, true, 4>(p, st) : launch_bf16x16<128, false, true, 4>(p, st);
+        if (p.cand) {                                             // the refining launch that also lists candidates (LIST)
+            if (kt == 128) return bias ? launch_bf16x16<128, true, true, 8, false, true>(p, st) : launch_bf16x16<128, false, true, 8, false, true>(p, st);
+            if (kt == 64) return bias ? launch_bf16x16<64, true, true, 8, false, true>(p, st) : launch_bf16x16<64, false, true, 8, false, true>(p, st);
+        }
         if (kt == 128 && bias && trec_get_tuning("blockmax_bf16_rdlate", 0) != 0) return launch_bf16x16<128, true, true, 8, true>(p, st);
         if (kt == 128) return bias ? launch_bf16x16<128, true, true>(p, st) : launch_bf16x16<128, false, true>(p, st);
         if (kt == 64) return bias ? launch_bf16x16<64, true, true>(p, st) : launch_bf16x16<64, false, true>(p, st);
@@ -794,6 +897,10 @@ int launch_blockmax_filter16(const ScoreParams& p, int kt, hipStream_t st)
 {
     if (p.euclid || (trec_get_tuning("blockmax_bf16_mfma16", 1) == 0 && !p.rblock_chunk)) return TREC_ERR_UNSUPPORTED;
     const bool bias = p.r_bias || p.t_bias;
+    if (p.cand) {
+        if (kt == 128) return bias ? launch_bf16x16<128, true, false, 8, false, true>(p, st) : launch_bf16x16<128, false, false, 8, false, true>(p, st);
+        if (kt == 64) return bias ? launch_bf16x16<64, true, false, 8, false, true>(p, st) : launch_bf16x16<64, false, false, 8, false, true>(p, st);
+    }
     if (kt == 128 && bias && trec_get_tuning("blockmax_bf16_rdlate", 0) != 0) return launch_bf16x16<128, true, false, 8, true>(p, st);
     if (kt == 128) return bias ? launch_bf16x16<128, true, false>(p, st) : launch_bf16x16<128, false, false>(p, st);
     if (kt == 64) return bias ? launch_bf16x16<64, true, false>(p, st) : launch_bf16x16<64, false, false>(p, st);

@@ -41,6 +41,13 @@ struct ScoreParams {
     int64_t bias_stride;
     int grp_band_major;            // grouped bf16 BLOCKMAX, fixed-capacity layout: workgroup order (list chunk j, superblock s) instead of
                                    // (s, j): the workgroups running together share a band of users (their rows come from L2)
+    // bf16 BLOCKMAX that also lists candidates (the cascade's refining launches, topk_candidates.hip): every item whose bf16
+    // score reaches cand_floor[user] is appended to cand[user][0 .. cand_cap) = {item id + t_index_base, score bits}
+    const float* cand_floor;       // nullable [n users]
+    int32_t* cand_n;               // [n users] entries appended so far (may exceed cand_cap: the list is then incomplete)
+    int2* cand;                    // [n users][cand_cap]
+    int32_t cand_cap;
+    int cand_diag;                 // diagnostics (tuning cascade_cand_diag): 1 = the queues are emptied without looking, 2 = atomics but no stores
     float* chunk_top;              // int8 BLOCKMAX: [n_chunks * top_k][bm_stride]: the top_k largest LOWER BOUNDS of a chunk per user
     int top_k;
 };

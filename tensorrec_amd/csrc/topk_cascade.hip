@@ -381,6 +381,7 @@ __global__ __launch_bounds__(256) void rows_hot_kernel(int32_t* __restrict__ row
         status[0] = tot[0] + tot[1] + tot[2] + tot[3] + nh * per_hot;
         const long long pairs = totp[0] + totp[1] + totp[2] + totp[3] + (long long)n_hot * n_users;
         status[1] = (n_hot > hot_cap || pairs > max_pairs) ? 1 : 0;
+        status[2] = n_hot;
     }
 }
 
@@ -509,4 +510,66 @@ extern "C" int trec_score_gemm_blockmax_grouped(const void* users_bf16, const vo
     p.rblock_chunk = rblock_chunk; p.row_index = row_user; p.capacity = wgs_per_row;
     p.grp_band_major = trec_get_tuning("cascade_band_major", 0);      // measured slower (8.25 vs 6.83 ms at 1M x 1M): see DESIGN 5d
     return launch_blockmax_pipelined_grouped(p, kpad, (hipStream_t)stream);
+}
+
+// ---- the refining launches that also LIST -------------------------------------------------------------------
+// Same launches as trec_score_gemm_blockmax_grouped (fixed-capacity layout) / trec_score_gemm_blockmax_hot, with the kernel's
+// LIST form: besides writing the bf16 maxima over the table's entries, every item of a refined (superblock, user) pair whose
+// bf16 score (+ user bias) reaches cand_floor[user] is appended to cand[user][slot] = {item id + item_index_base, score bits},
+// slot = atomicAdd(cand_n[user], 1) (entries beyond cand_cap are dropped, the count keeps growing: trec_topk_candidates_finish
+// flags such a user).  cand_n must be zero before the first of the two launches.
+//
+// Why the lists are enough (tauLB = the k-th largest int8 lower bound, eps = the bf16 filter's bound of topk_filter.hip,
+// cand_floor = tauLB - eps rounded down, sh = the bf16-path score, s = the fp32 score): a top-k item has s >= t_k >= tauLB, so
+// its superblock is refined (header above) and sh >= s - eps >= cand_floor: it is listed.  The list S therefore holds k items;
+// tau = the k-th largest sh in S; the k items at or above it have s >= tau - eps, hence t_k >= tau - eps, and a top-k item has
+// sh >= t_k - eps >= tau - 2 eps: it survives the finish kernel's floor and is re-scored exactly.  Item shards: tauLB is the
+// exchanged one, tau stays local (k local candidates certify k items of the whole catalogue just as well).
+extern "C" int trec_score_gemm_refine_candidates(const void* users_bf16, const void* items_bf16, int32_t kpad, int64_t n_rows_g,
+                                                 int64_t n_items, const float* user_bias, const float* item_bias,
+                                                 int32_t sb_rows, const int32_t* row_count, const int32_t* row_user,
+                                                 float* blockmax, int64_t bm_stride, int32_t wgs_per_row,
+                                                 const float* cand_floor, int32_t* cand_n, void* cand, int32_t cand_cap,
+                                                 int32_t item_index_base, void* stream)
+{
+    TREC_REQUIRE(users_bf16 && items_bf16 && row_count && row_user && blockmax && cand_floor && cand_n && cand,
+                 "trec_score_gemm_refine_candidates: null pointer");
+    TREC_REQUIRE(wgs_per_row > 0 && cand_cap >= 1, "trec_score_gemm_refine_candidates: needs the fixed-capacity layout (wgs_per_row > 0)");
+    TREC_REQUIRE(kpad == 64 || kpad == 128, "trec_score_gemm_refine_candidates: kpad must be 64 or 128");
+    TREC_REQUIRE(n_rows_g % GROUP_ROWS == 0 && n_rows_g < ((int64_t)1 << 40), "trec_score_gemm_refine_candidates: n_rows_g % 512 != 0");
+    TREC_REQUIRE(sb_rows >= 64 && sb_rows % 64 == 0 && sb_rows <= 65536, "trec_score_gemm_refine_candidates: sb_rows must be a multiple of 64, <= 65536");
+    TREC_REQUIRE(trec_get_tuning("blockmax_bf16_mfma16", 1) != 0, "trec_score_gemm_refine_candidates: needs the 16x16x32 kernel (tuning blockmax_bf16_mfma16)");
+    if (n_rows_g == 0) return TREC_OK;
+    TREC_REQUIRE(n_rows_g / GROUP_ROWS < ((int64_t)1 << 31), "trec_score_gemm_refine_candidates: too many workgroups");
+    ScoreParams p = {};
+    p.R = users_bf16; p.T = items_bf16; p.n_r = n_rows_g; p.n_t = n_items;
+    p.chunk_len = sb_rows; p.n_chunks = 1;
+    p.r_bias = user_bias; p.t_bias = item_bias;
+    p.blockmax = blockmax; p.bm_stride = bm_stride; p.sb_tiles = sb_rows / 64;
+    p.rblock_chunk = row_count; p.row_index = row_user; p.capacity = wgs_per_row;
+    p.cand_floor = cand_floor; p.cand_n = cand_n; p.cand = (int2*)cand; p.cand_cap = cand_cap; p.t_index_base = item_index_base;
+    p.cand_diag = trec_get_tuning("cascade_cand_diag", 0);
+    return launch_blockmax_pipelined_grouped(p, kpad, (hipStream_t)stream);
+}
+
+extern "C" int trec_score_gemm_refine_candidates_hot(const void* users_bf16, const void* items_bf16, int32_t kpad, int64_t n_users,
+                                                     int64_t n_items, const float* user_bias, const float* item_bias,
+                                                     int32_t sb_rows, const int32_t* hot_list, int32_t hot_cap, float* blockmax,
+                                                     int64_t bm_stride, const float* cand_floor, int32_t* cand_n, void* cand,
+                                                     int32_t cand_cap, int32_t item_index_base, void* stream)
+{
+    TREC_REQUIRE(users_bf16 && items_bf16 && hot_list && blockmax && cand_floor && cand_n && cand,
+                 "trec_score_gemm_refine_candidates_hot: null pointer");
+    TREC_REQUIRE(kpad == 64 || kpad == 128, "trec_score_gemm_refine_candidates_hot: kpad must be 64 or 128");
+    TREC_REQUIRE(sb_rows >= 64 && sb_rows % 64 == 0 && sb_rows <= 65536 && hot_cap >= 1 && bm_stride >= n_users && cand_cap >= 1,
+                 "trec_score_gemm_refine_candidates_hot: bad sizes");
+    if (n_users == 0 || n_items == 0) return TREC_OK;
+    ScoreParams p = {};
+    p.R = users_bf16; p.T = items_bf16; p.n_r = n_users; p.n_t = n_items;
+    p.chunk_len = sb_rows; p.n_chunks = hot_cap;
+    p.r_bias = user_bias; p.t_bias = item_bias;
+    p.blockmax = blockmax; p.bm_stride = bm_stride; p.sb_tiles = sb_rows / 64;
+    p.rblock_chunk = hot_list;
+    p.cand_floor = cand_floor; p.cand_n = cand_n; p.cand = (int2*)cand; p.cand_cap = cand_cap; p.t_index_base = item_index_base;
+    return launch_blockmax_filter16(p, kpad, (hipStream_t)stream);
 }

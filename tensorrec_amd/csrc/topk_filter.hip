@@ -140,6 +140,16 @@ __global__ __launch_bounds__(256) void prep_filter_kernel(const float* __restric
     }
 }
 
+// eps_u >= |bf16-path score - fp32 score| for every item (the bound of the header): st = {||x||, ||x - bf16(x)||} of the user,
+// gstats = the item side's maxima {||y||, ||y - bf16(y)||, |bias|}
+__device__ __forceinline__ float filter_eps(float2 st, float bu_abs, const float* __restrict__ gstats, int kdim)
+{
+    const float ni = gstats[0], ai = gstats[1], bi = gstats[2];
+    const float ck = (float)(kdim + 2) * 2.98023224e-07f;                       // (K + 2) (2^-24 + 2^-22)
+    const float eps = st.y * (ni * 1.00390625f) + st.x * ai + ck * (st.x * ni * 1.0078125f + bu_abs + bi);
+    return eps * 1.001953125f + 1e-30f;
+}
+
 // floor_u = tau_u - mult eps_u (rounded DOWN twice; mult = 2 for the filter's floor); flag_u = 1 when the bound is unusable
 // (then floor_u = -inf).  flag / n_flagged may be NULL (a provisional floor: trec_topk_filter_floor_ex).
 __global__ __launch_bounds__(256) void filter_floor_kernel(const float* __restrict__ tau, const float2* __restrict__ ustats,
@@ -150,12 +160,7 @@ __global__ __launch_bounds__(256) void filter_floor_kernel(const float* __restri
 {
     const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (u >= n_users) return;
-    const float ni = gstats[0], ai = gstats[1], bi = gstats[2];
-    const float2 st = ustats[u];
-    const float bu = user_bias ? fabsf(user_bias[u]) : 0.f;
-    const float ck = (float)(kdim + 2) * 2.98023224e-07f;                       // (K + 2) (2^-24 + 2^-22)
-    float eps = st.y * (ni * 1.00390625f) + st.x * ai + ck * (st.x * ni * 1.0078125f + bu + bi);
-    eps = eps * 1.001953125f + 1e-30f;
+    const float eps = filter_eps(ustats[u], user_bias ? fabsf(user_bias[u]) : 0.f, gstats, kdim);
     const float t = tau[u];
     float f = t - mult * eps;
     bool bad = !(eps < INFINITY);                                               // inf or NaN
@@ -170,11 +175,86 @@ __global__ __launch_bounds__(256) void filter_floor_kernel(const float* __restri
     }
 }
 
+#define FILTER_RB 8          // survivors re-scored per round (their fp32 rows staged in LDS)
+// The second half of the finish kernels: ``total`` (<= FILTER_CMAX) survivors' item ids sit in cand[] (LDS of this wave), the
+// user's row in registers uw.  Exact fp32 scores by the reference's k-ordered fmaf chain, then (s + b_u) + b_i, then the k
+// best by (value desc, index asc) to ov / oi.
+__device__ __forceinline__ void finish_rescore_topk(int total, const int32_t* cand, float* urow, float* rows, const f32x4 (&uw)[4],
+                                                    int lane, int kdim, int chunks, int rstride, bool vec,
+                                                    const float* __restrict__ V, int64_t ld_v, int32_t item_index_base,
+                                                    const float* __restrict__ item_bias, bool has_user_bias, float bu, int k,
+                                                    float* __restrict__ ov, int32_t* __restrict__ oi, int64_t u)
+{
+    __builtin_amdgcn_wave_barrier();              // cand[] / rows[] are private to this wave; a wave's DS operations execute in order
+    // ---- exact fp32 scores of the survivors: the reference's k-ordered fmaf chain, then (s + b_u) + b_i
+    const unsigned long long EMPTY = merge_key(-INFINITY, 0x7fffffff);
+    unsigned long long key = EMPTY;                // lane r ends up holding survivor (round * FILTER_RB + r)'s key ...
+    unsigned long long mine = EMPTY;               // ... moved to lane (round * FILTER_RB + r) here
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int ch = q * 64 + lane;
+        if (ch < chunks) *(f32x4*)(urow + ch * 4) = uw[q];        // broadcast from LDS by every chain step
+    }
+    const float* a = urow;
+    for (int r0 = 0; r0 < total; r0 += FILTER_RB) {
+        const int nr = (total - r0 < FILTER_RB) ? total - r0 : FILTER_RB;
+        for (int idx = lane; idx < nr * chunks; idx += 64) {
+            const int r = idx / chunks, ch = idx - r * chunks;
+            const float* src = V + (int64_t)(cand[r0 + r] - item_index_base) * ld_v + ch * 4;
+            f32x4 w;
+            if (vec) w = *(const f32x4*)src;
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[e] = (ch * 4 + e < kdim) ? src[e] : 0.f;
+            }
+            *(f32x4*)(rows + r * rstride + ch * 4) = w;
+        }
+        const int32_t item = (lane < nr) ? cand[r0 + lane] : item_index_base;
+        const float ibv = (item_bias && lane < nr) ? item_bias[item - item_index_base] : 0.f;   // rides with the row loads
+        __builtin_amdgcn_wave_barrier();
+        if (lane < nr) {
+            const float* b = rows + lane * rstride;
+            float acc = 0.0f;
+            int kk = 0;
+            {
+                for (; kk + 4 <= kdim; kk += 4) {
+                    const f32x4 a4 = *(const f32x4*)(a + kk);
+                    const f32x4 b4 = *(const f32x4*)(b + kk);
+                    acc = __fmaf_rn(a4[0], b4[0], acc); acc = __fmaf_rn(a4[1], b4[1], acc);
+                    acc = __fmaf_rn(a4[2], b4[2], acc); acc = __fmaf_rn(a4[3], b4[3], acc);
+                }
+            }
+            for (; kk < kdim; ++kk) acc = __fmaf_rn(a[kk], b[kk], acc);
+            if (has_user_bias) acc = acc + bu;
+            if (item_bias) acc = acc + ibv;
+            key = merge_key(acc, item);
+        } else key = EMPTY;
+        __builtin_amdgcn_wave_barrier();
+        // lane r0 + r takes over lane r's key (r0 is a multiple of 16: a fixed rotation per round)
+        {
+            const int srcl = (lane - r0) & 63;
+            const unsigned int lo = (unsigned int)__shfl((int)(unsigned int)key, srcl, 64);
+            const unsigned int hi = (unsigned int)__shfl((int)(unsigned int)(key >> 32), srcl, 64);
+            if (lane >= r0 && lane < r0 + nr) mine = ((unsigned long long)hi << 32) | lo;
+        }
+    }
+    // ---- the k best by (value desc, index asc)
+    for (int t = 0; t < k; ++t) {
+        const unsigned long long best = wave_max_u64(mine);
+        if (mine == best && best != EMPTY) mine = EMPTY;
+        if (lane == 0) {
+            const unsigned int hi = (unsigned int)(best >> 32);
+            const unsigned int bits = (hi & 0x80000000u) ? (hi & 0x7fffffffu) : ~hi;
+            ov[u * k + t] = (best == EMPTY) ? -INFINITY : __uint_as_float(bits);
+            oi[u * k + t] = (best == EMPTY) ? -1 : (int32_t)(~(unsigned int)best);
+        }
+    }
+}
+
 // One wave per user.  Only the first count[u] slots of a user have stage-3 lists.  Survivors are re-scored FILTER_RB at a time: their fp32
 // rows are fetched with coalesced 16-byte loads (a row = KT/4 consecutive lanes) into LDS, then lane r walks row r with
 // the reference's k-ordered fmaf chain (a row per lane straight from global memory is a 16-byte access per 512-byte
 // row per load: 4.6 ms at 1M users, ~15 survivors each; staged: see DESIGN.md).
-#define FILTER_RB 8
 #define FILTER_SPEC 24       // slots whose id lists are fetched before the user's slot count is known
 template <int CPL>
 __global__ __launch_bounds__(256) void filter_finish_kernel(
@@ -247,70 +327,8 @@ __global__ __launch_bounds__(256) void filter_finish_kernel(
     const bool over = __builtin_amdgcn_ballot_w64(lossy) != 0ull || total > FILTER_CMAX;
     if (over && lane == 0 && flag[u] == 0) { flag[u] = 1; atomicAdd(n_flagged, 1); }
     if (total > FILTER_CMAX) total = FILTER_CMAX;
-    __builtin_amdgcn_wave_barrier();              // cand[] / rows[] are private to this wave; a wave's DS operations execute in order
-    // ---- exact fp32 scores of the survivors: the reference's k-ordered fmaf chain, then (s + b_u) + b_i
-    const unsigned long long EMPTY = merge_key(-INFINITY, 0x7fffffff);
-    unsigned long long key = EMPTY;                // lane r ends up holding survivor (round * FILTER_RB + r)'s key ...
-    unsigned long long mine = EMPTY;               // ... moved to lane (round * FILTER_RB + r) here
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int ch = q * 64 + lane;
-        if (ch < chunks) *(f32x4*)(urow + ch * 4) = uw[q];        // broadcast from LDS by every chain step
-    }
-    const float* a = urow;
-    for (int r0 = 0; r0 < total; r0 += FILTER_RB) {
-        const int nr = (total - r0 < FILTER_RB) ? total - r0 : FILTER_RB;
-        for (int idx = lane; idx < nr * chunks; idx += 64) {
-            const int r = idx / chunks, ch = idx - r * chunks;
-            const float* src = V + (int64_t)(cand[r0 + r] - item_index_base) * ld_v + ch * 4;
-            f32x4 w;
-            if (vec) w = *(const f32x4*)src;
-            else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) w[e] = (ch * 4 + e < kdim) ? src[e] : 0.f;
-            }
-            *(f32x4*)(rows + r * rstride + ch * 4) = w;
-        }
-        const int32_t item = (lane < nr) ? cand[r0 + lane] : item_index_base;
-        const float ibv = (item_bias && lane < nr) ? item_bias[item - item_index_base] : 0.f;   // rides with the row loads
-        __builtin_amdgcn_wave_barrier();
-        if (lane < nr) {
-            const float* b = rows + lane * rstride;
-            float acc = 0.0f;
-            int kk = 0;
-            {
-                for (; kk + 4 <= kdim; kk += 4) {
-                    const f32x4 a4 = *(const f32x4*)(a + kk);
-                    const f32x4 b4 = *(const f32x4*)(b + kk);
-                    acc = __fmaf_rn(a4[0], b4[0], acc); acc = __fmaf_rn(a4[1], b4[1], acc);
-                    acc = __fmaf_rn(a4[2], b4[2], acc); acc = __fmaf_rn(a4[3], b4[3], acc);
-                }
-            }
-            for (; kk < kdim; ++kk) acc = __fmaf_rn(a[kk], b[kk], acc);
-            if (user_bias) acc = acc + bu;
-            if (item_bias) acc = acc + ibv;
-            key = merge_key(acc, item);
-        } else key = EMPTY;
-        __builtin_amdgcn_wave_barrier();
-        // lane r0 + r takes over lane r's key (r0 is a multiple of 16: a fixed rotation per round)
-        {
-            const int srcl = (lane - r0) & 63;
-            const unsigned int lo = (unsigned int)__shfl((int)(unsigned int)key, srcl, 64);
-            const unsigned int hi = (unsigned int)__shfl((int)(unsigned int)(key >> 32), srcl, 64);
-            if (lane >= r0 && lane < r0 + nr) mine = ((unsigned long long)hi << 32) | lo;
-        }
-    }
-    // ---- the k best by (value desc, index asc)
-    for (int t = 0; t < k; ++t) {
-        const unsigned long long best = wave_max_u64(mine);
-        if (mine == best && best != EMPTY) mine = EMPTY;
-        if (lane == 0) {
-            const unsigned int hi = (unsigned int)(best >> 32);
-            const unsigned int bits = (hi & 0x80000000u) ? (hi & 0x7fffffffu) : ~hi;
-            ov[u * k + t] = (best == EMPTY) ? -INFINITY : __uint_as_float(bits);
-            oi[u * k + t] = (best == EMPTY) ? -1 : (int32_t)(~(unsigned int)best);
-        }
-    }
+    finish_rescore_topk(total, cand, urow, rows, uw, lane, kdim, chunks, rstride, vec, V, ld_v, item_index_base, item_bias,
+                        user_bias != nullptr, bu, k, ov, oi, u);
 }
 
 // The same finish without capacity limits, for the WIDE second pass over the users the first pass flagged (hundreds of kept
@@ -438,6 +456,110 @@ __global__ __launch_bounds__(256) void filter_finish_wide_kernel(
     }
 }
 
+
+// ---- the finish behind the cascade's candidate lists (csrc/topk_candidates.hip) ---------------------------------------------
+// One wave per user.  cand[u][0 .. n) = {item id, bf16-path score sh} of EVERY item of the user's refined superblocks with
+// sh >= cand_floor[u] (blockmax_bf16x16_kernel<.., LIST>).  tau = the k-th largest sh among them, floor = tau - 2 eps (the
+// filter's floor, from item scores instead of superblock maxima), survivors = candidates with sh >= floor, re-scored exactly.
+// A user with more than ``cap`` candidates (its list is incomplete) or more than FILTER_CMAX survivors is flagged; a user whose
+// provisional floor is +inf (padding rows; users the floor kernel flagged for an unusable bound) is skipped.
+template <int CPL>
+__global__ __launch_bounds__(256) void candidates_finish_kernel(
+    const int32_t* __restrict__ cand_n, const int2* __restrict__ cand_list, int cap, const float* __restrict__ cand_floor,
+    const float2* __restrict__ ustats, const float* __restrict__ gstats, const float* __restrict__ U,
+    const float* __restrict__ V, int64_t ld_u, int64_t ld_v, int kdim, const float* __restrict__ user_bias,
+    const float* __restrict__ item_bias, int32_t item_index_base, int64_t n_users, int k, float* __restrict__ ov,
+    int32_t* __restrict__ oi, int32_t* __restrict__ flag, int32_t* __restrict__ n_flagged)
+{
+    extern __shared__ __attribute__((aligned(16))) char fsmem[];
+    const int wave = threadIdx.x >> 6;
+    const int64_t u = (int64_t)blockIdx.x * 4 + wave;
+    if (u >= n_users) return;
+    const int lane = lane_id();
+    const int kd4 = (kdim + 3) & ~3;
+    const int rstride = kd4 + 4;
+    int32_t* cand = (int32_t*)fsmem + wave * FILTER_CMAX;
+    float* urow = (float*)(fsmem + 4 * FILTER_CMAX * 4) + (size_t)wave * kd4;
+    float* rows = (float*)(fsmem + 4 * FILTER_CMAX * 4) + (size_t)4 * kd4 + (size_t)wave * FILTER_RB * rstride;
+    // everything that depends on nothing leaves at once: the count, the floor, the list (masked by the count afterwards), the row
+    const int n = cand_n[u];
+    const float f0 = cand_floor[u];
+    const int chunks = kd4 >> 2;
+    const bool vec = ((ld_v & 3) == 0) && ((ld_u & 3) == 0);
+    int2 ent[CPL];                                          // the first 64 entries before the count is known (a user has ~32), the rest after
+    ent[0] = cand_list[u * (int64_t)cap + lane];
+    f32x4 uw[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int ch = q * 64 + lane;
+        uw[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (ch < chunks) {
+            const float* src = U + u * ld_u + ch * 4;
+            if (vec) uw[q] = *(const f32x4*)src;
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) uw[q][e] = (ch * 4 + e < kdim) ? src[e] : 0.f;
+            }
+        }
+    }
+    const float bu = user_bias ? user_bias[u] : 0.f;
+    const float2 st = ustats[u];
+    const unsigned long long EMPTY = merge_key(-INFINITY, 0x7fffffff);
+    const bool skip = !(f0 < INFINITY);
+    const bool over = n > cap;
+#pragma unroll
+    for (int c = 1; c < CPL; ++c) {
+        ent[c] = make_int2(0, 0);
+        if (n > c * 64 && !over) ent[c] = cand_list[u * (int64_t)cap + c * 64 + lane];
+    }
+    if (skip || over) {                                     // (wave-uniform)
+        if (over && !skip && lane == 0 && flag[u] == 0) { flag[u] = 1; atomicAdd(n_flagged, 1); }
+        if (lane < k) { ov[u * k + lane] = -INFINITY; oi[u * k + lane] = -1; }
+        return;
+    }
+    // ---- tau = the k-th largest candidate score (keys: value desc, id asc -- an item is listed once, keys are unique)
+    unsigned long long key[CPL], w[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+        key[c] = (c * 64 + lane < n) ? merge_key(__int_as_float(ent[c].y), ent[c].x) : EMPTY;
+        w[c] = key[c];
+    }
+    unsigned long long kth = EMPTY;
+    for (int t = 0; t < k; ++t) {
+        unsigned long long m = w[0];
+#pragma unroll
+        for (int c = 1; c < CPL; ++c) m = w[c] > m ? w[c] : m;
+        kth = wave_max_u64(m);
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) if (w[c] == kth && kth != EMPTY) w[c] = EMPTY;
+    }
+    float tau = -INFINITY;                                  // fewer than k candidates: every one survives
+    if (kth != EMPTY) {
+        const unsigned int hi = (unsigned int)(kth >> 32);
+        tau = __uint_as_float((hi & 0x80000000u) ? (hi & 0x7fffffffu) : ~hi);
+    }
+    const float eps = filter_eps(st, fabsf(bu), gstats, kdim);
+    float fl = tau - 2.0f * eps;
+    if (tau == -INFINITY) fl = -INFINITY;
+    else fl = float_pred(float_pred(fl));                   // (eps is finite here: cand_floor was)
+    // ---- survivors
+    int total = 0;
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+        const bool keep = (c * 64 + lane < n) && __int_as_float(ent[c].y) >= fl;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+        const int pos = total + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+        if (keep && pos < FILTER_CMAX) cand[pos] = ent[c].x;
+        total += __builtin_popcountll(m);
+    }
+    if (total > FILTER_CMAX) {
+        if (lane == 0 && flag[u] == 0) { flag[u] = 1; atomicAdd(n_flagged, 1); }
+        total = FILTER_CMAX;
+    }
+    finish_rescore_topk(total, cand, urow, rows, uw, lane, kdim, chunks, rstride, vec, V, ld_v, item_index_base, item_bias,
+                        user_bias != nullptr, bu, k, ov, oi, u);
+}
+
 extern "C" int trec_score_prep_filter(const float* repr, int64_t n, int32_t d, int32_t kpad, int32_t normalize,
                                       const float* bias, float* out_f32, void* out_bf16, float* row_stats, float* gstats,
                                       void* stream)
@@ -537,4 +659,39 @@ extern "C" int trec_topk_filter_finish_wide(const int32_t* part_idx, int32_t cap
                        part_idx, capacity, ksel, count, users_f32, items_f32, ld_users, ld_items, kdim, user_bias, item_bias,
                        item_index_base, n_users, k, out_vals, out_idx, flag, n_flagged);
     return trec_check_launch("trec_topk_filter_finish_wide");
+}
+
+// The finish behind the candidate lists of trec_score_gemm_refine_candidates(_hot): cand_n [n_users], cand [n_users][cand_cap]
+// {item id, score bits}, cand_floor [n_users] the provisional floor the lists were made with (+inf: the user is skipped),
+// user_stats [n_users][2] / item_gstats [3] as for trec_topk_filter_floor.  Writes the exact top-k; flags users with more than
+// cand_cap candidates or more than 64 survivors (the caller re-does them: ops.score_topk_filtered).
+extern "C" int trec_topk_candidates_finish(const int32_t* cand_n, const void* cand, int32_t cand_cap, const float* cand_floor,
+                                           const float* user_stats, const float* item_gstats, const float* users_f32,
+                                           const float* items_f32, int64_t ld_users, int64_t ld_items, int32_t kdim,
+                                           const float* user_bias, const float* item_bias, int32_t item_index_base,
+                                           int64_t n_users, int32_t k, float* out_vals, int32_t* out_idx, int32_t* flag,
+                                           int32_t* n_flagged, void* stream)
+{
+    TREC_REQUIRE(cand_n && cand && cand_floor && user_stats && item_gstats && users_f32 && items_f32 && out_vals && out_idx &&
+                 flag && n_flagged, "trec_topk_candidates_finish: null pointer");
+    TREC_REQUIRE(cand_cap >= 64 && cand_cap % 64 == 0 && cand_cap <= 256, "trec_topk_candidates_finish: cand_cap must be 64, 128, 192 or 256");
+    TREC_REQUIRE(k >= 1 && k <= 16, "trec_topk_candidates_finish: need k <= 16");
+    TREC_REQUIRE(kdim >= 1 && kdim <= 1024 && ld_users >= kdim && ld_items >= ((kdim + 3) & ~3),
+                 "trec_topk_candidates_finish: need kdim <= 1024 and item rows padded to a multiple of 4");
+    if (n_users == 0) return TREC_OK;
+    const unsigned blocks = (unsigned)ceil_div64(n_users, 4);
+    hipStream_t st = (hipStream_t)stream;
+    const int kd4 = (kdim + 3) & ~3;
+    const size_t lds = 4 * FILTER_CMAX * 4 + (size_t)4 * kd4 * 4 + (size_t)4 * FILTER_RB * (kd4 + 4) * 4;
+#define TREC_CF(CPLV)                                                                                                  \
+    (void)hipFuncSetAttribute((const void*)candidates_finish_kernel<CPLV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((candidates_finish_kernel<CPLV>), dim3(blocks), dim3(256), lds, st, cand_n, (const int2*)cand, cand_cap, \
+                       cand_floor, (const float2*)user_stats, item_gstats, users_f32, items_f32, ld_users, ld_items, kdim,   \
+                       user_bias, item_bias, item_index_base, n_users, k, out_vals, out_idx, flag, n_flagged)
+    if (cand_cap == 64) { TREC_CF(1); }
+    else if (cand_cap == 128) { TREC_CF(2); }
+    else if (cand_cap == 192) { TREC_CF(3); }
+    else { TREC_CF(4); }
+#undef TREC_CF
+    return trec_check_launch("trec_topk_candidates_finish");
 }

@@ -1074,6 +1074,8 @@ CASCADE_MAX_REFINED = 0.45
 CASCADE_ROW_CAPACITY = 0.50      # fixed capacity of a superblock's user list (fraction of the users); fuller rows are "hot":
                                  # the dense kernel re-scores them for everybody at 1.5x the grouped kernel's rate
 CASCADE_MAX_HOT = 1 << 20        # superblocks that may be hot (no limit of its own: CASCADE_MAX_REFINED bounds the work)
+CASCADE_CANDIDATES = 128         # candidate items per user the refining launches may list (trec_score_gemm_refine_candidates:
+                                 # every item of a refined pair within eps of the k-th largest int8 lower bound; ~32 at 1M x 1M)
 CASCADE_MIN_ITEMS = 262144       # below ~512 superblocks the k-th largest maximum is not selective enough for int8 to pay
 
 
@@ -1151,7 +1153,22 @@ def blockmax_i8_chunks(n_items, n_chunks, sb_rows):
     return chunk_len, -(-n_items // chunk_len)
 
 
-def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, floor_exchange, stats_exchange, gstats_all=None):
+class _Candidates(object):
+    """What the refining launches listed (trec_score_gemm_refine_candidates): per user ``n`` appended entries of ``items``
+    [n_users, cap, 2] = {item id, score bits}, made with the provisional floor ``floor0`` (+inf: nothing listed); ``flag`` /
+    ``n_flagged``: users without a usable bound so far."""
+    __slots__ = ("n", "items", "cap", "floor0", "flag", "n_flagged")
+
+
+def cascade_lists_candidates():
+    """Tuning ``cascade_candidates`` (default 1): the bf16 refining launches of the cascade also list, per user, the items
+    that can still reach the top-k, and trec_topk_candidates_finish ends the call -- no table scan, no grouping by superblock,
+    no grouped list kernel.  0: the bf16 filter's tail runs on the mixed table (the round-2 form)."""
+    return N.load().trec_get_tuning(b"cascade_candidates", 1) != 0
+
+
+def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, floor_exchange, stats_exchange, gstats_all=None,
+                    item_index_base=0):
     """Stages 0-1 of the int8 -> bf16 -> fp32 cascade (csrc/topk_cascade.hip): the [n_sb, n_users] table of superblock
     maxima whose entries are bf16 maxima wherever a top-k item can be and int8 maxima elsewhere (None after an overflow), its
     row stride, and (resident rows of the bf16 launches, overflow).  Every superblock has a list of CASCADE_ROW_CAPACITY of the
@@ -1191,7 +1208,7 @@ def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, 
         tau = floor_exchange(sel_max).contiguous()
     if uop.pad is not None:
         tau.masked_fill_(uop.pad, float("inf"))         # padding rows refine nothing
-    status = torch.empty((2,), dtype=torch.int64, device=dev)
+    status = torch.zeros((3,), dtype=torch.int64, device=dev)
     if N.load().trec_get_tuning(b"cascade_rows_onepass", 1) != 0 and N.load().trec_get_tuning(b"blockmax_bf16_mfma16", 1) != 0:
         # one pass over the table: a fixed capacity per superblock, slots handed out by atomics (csrc/topk_cascade.hip)
         rcap_frac = N.load().trec_get_tuning(b"cascade_rcap_pct", int(100 * CASCADE_ROW_CAPACITY)) / 100.0
@@ -1214,19 +1231,48 @@ def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, 
         # the overflow flag is read HERE, before the bf16 launches: when the int8 bound is too loose, refining
         # close to half of all pairs and then running the filter's tail on the result would only be thrown away.  One host
         # read per call (the following launches are queued within the launch latency); item shards agree on it (MAX).
-        rows, overflow = status.tolist()
+        rows, overflow, n_hot = status.tolist()
         if stats_exchange is not None:
             overflow = float(stats_exchange(torch.tensor([float(overflow)], device=dev)).item())
         if overflow:
-            return None, stride, (int(rows), True), tau
+            return None, stride, (int(rows), True), tau, None
+        n_hot = min(int(n_hot), hot_cap)                # the hot launch's grid: nothing is launched when no superblock is hot
+        cands = None
+        if cascade_lists_candidates() and gstats_all is not None and sb_rows <= 65536:
+            # the refining launches also list every item that can still reach the top-k: provisional floor = the
+            # k-th largest int8 lower bound less ONE eps of the bf16 filter; users without a usable bound are flagged and skipped
+            cands = _Candidates()
+            cands.cap = int(N.load().trec_get_tuning(b"cascade_candidates_cap", CASCADE_CANDIDATES))
+            cands.floor0 = torch.empty((n_u,), dtype=torch.float32, device=dev)
+            cands.flag = torch.empty((n_u,), dtype=torch.int32, device=dev)
+            cands.n_flagged = torch.zeros((1,), dtype=torch.int32, device=dev)
+            N.call("trec_topk_filter_floor_ex", N.ptr(tau), N.ptr(uop.stats), N.ptr(user_bias), N.ptr(gstats_all), kpad, n_u, 1.0,
+                   N.ptr(cands.floor0), N.ptr(cands.flag), N.ptr(cands.n_flagged))
+            cands.floor0.masked_fill_(cands.flag != 0, float("inf"))
+            if uop.pad is not None:
+                cands.floor0.masked_fill_(uop.pad, float("inf"))
+            cands.n = torch.zeros((n_u,), dtype=torch.int32, device=dev)
+            cands.items = torch.empty((n_u, cands.cap, 2), dtype=torch.int32, device=dev)     # only the listed part is touched
         with _timed("score_gemm_blockmax_grouped"):
-            N.call("trec_score_gemm_blockmax_grouped", N.ptr(uop.bf16), N.ptr(iop.bf16), kpad, n_sb * rcap, n_i,
-                   N.ptr(user_bias), N.ptr(item_bias), sb_rows, N.ptr(row_count), N.ptr(row_user), N.ptr(table), stride,
-                   rcap // 512)
+            if cands is not None:
+                N.call("trec_score_gemm_refine_candidates", N.ptr(uop.bf16), N.ptr(iop.bf16), kpad, n_sb * rcap, n_i,
+                       N.ptr(user_bias), N.ptr(item_bias), sb_rows, N.ptr(row_count), N.ptr(row_user), N.ptr(table), stride,
+                       rcap // 512, N.ptr(cands.floor0), N.ptr(cands.n), N.ptr(cands.items), cands.cap, int(item_index_base))
+            else:
+                N.call("trec_score_gemm_blockmax_grouped", N.ptr(uop.bf16), N.ptr(iop.bf16), kpad, n_sb * rcap, n_i,
+                       N.ptr(user_bias), N.ptr(item_bias), sb_rows, N.ptr(row_count), N.ptr(row_user), N.ptr(table), stride,
+                       rcap // 512)
         with _timed("score_gemm_blockmax_hot"):
-            N.call("trec_score_gemm_blockmax_hot", N.ptr(uop.bf16), N.ptr(iop.bf16), kpad, n_u, n_i, N.ptr(user_bias),
-                   N.ptr(item_bias), sb_rows, N.ptr(hot_list), hot_cap, N.ptr(table), stride)
-        return table, stride, (int(rows), False), tau
+            if n_hot == 0:
+                pass
+            elif cands is not None:
+                N.call("trec_score_gemm_refine_candidates_hot", N.ptr(uop.bf16), N.ptr(iop.bf16), kpad, n_u, n_i,
+                       N.ptr(user_bias), N.ptr(item_bias), sb_rows, N.ptr(hot_list), n_hot, N.ptr(table), stride,
+                       N.ptr(cands.floor0), N.ptr(cands.n), N.ptr(cands.items), cands.cap, int(item_index_base))
+            else:
+                N.call("trec_score_gemm_blockmax_hot", N.ptr(uop.bf16), N.ptr(iop.bf16), kpad, n_u, n_i, N.ptr(user_bias),
+                       N.ptr(item_bias), sb_rows, N.ptr(hot_list), n_hot, N.ptr(table), stride)
+        return table, stride, (int(rows), False), tau, cands
     n_ublk = N.query("trec_topk_rows_user_blocks", n_u)
     block_off = torch.empty((n_sb * n_ublk,), dtype=torch.int32, device=dev)
     row_total = torch.empty((n_sb,), dtype=torch.int32, device=dev)
@@ -1244,10 +1290,10 @@ def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, 
     with _timed("score_gemm_blockmax_grouped"):
         N.call("trec_score_gemm_blockmax_grouped", N.ptr(uop.bf16), N.ptr(iop.bf16), kpad, cap_rows, n_i,
                N.ptr(user_bias), N.ptr(item_bias), sb_rows, N.ptr(rblock_chunk), N.ptr(row_user), N.ptr(table), stride, 0)
-    rows, overflow = status.tolist()                    # (the two-pass form: its fill pass and grouped launch idle after an overflow)
+    rows, overflow = status.tolist()[:2]                # (the two-pass form: its fill pass and grouped launch idle after an overflow)
     if stats_exchange is not None:
         overflow = float(stats_exchange(torch.tensor([float(overflow)], device=dev)).item())
-    return (None if overflow else table), stride, (int(rows), bool(overflow)), tau
+    return (None if overflow else table), stride, (int(rows), bool(overflow)), tau, None
 
 
 def _filter_tail(uop, iop, blockmax, bm_stride, n_u, n_sb, k, user_bias, item_bias, item_index_base, sb_rows, variant, ksel,
@@ -1308,10 +1354,13 @@ WIDE_PASS_BYTES = 4 << 30     # list workspace of one launch chain of the wide p
 
 
 def _wide_second_pass(uop, iop, blockmax, bad, n_sb, k, user_bias, item_bias, item_index_base, sb_rows, variant, floor, rows_wg,
-                      ksel_w):
+                      ksel_w, gstats=None):
     """The users the first pass could not certify (more than FILTER_KSEL kept superblocks, more than 64 survivors, a full
     8-entry list) again, on THEIR columns of the table that already exists: ``ksel_w`` slots, 16-entry lists, a finish without
-    survivor limit.  Returns (values, ids, flag) for the rows ``bad``; what is still flagged goes to the next tier."""
+    survivor limit.  Returns (values, ids, flag) for the rows ``bad``; what is still flagged goes to the next tier.
+    ``floor`` None (the first pass went through candidate lists and never derived the table's floor): it is derived here, from
+    the columns of these users -- on an item shard from the LOCAL table, which is sound (k local entries certify k items) if
+    less selective than the exchanged one."""
     dev = uop.bf16.device
     per_chain = max(1024, WIDE_PASS_BYTES // (ksel_w * 2 * 16 * 4))
     out_v, out_i, out_f = [], [], []
@@ -1327,8 +1376,18 @@ def _wide_second_pass(uop, iop, blockmax, bad, n_sb, k, user_bias, item_bias, it
             ub = user_bias.index_select(0, b) if user_bias is not None else None
             flag_b = torch.zeros((n_b,), dtype=torch.int32, device=dev)
             n_flagged_b = torch.zeros((1,), dtype=torch.int32, device=dev)
+            if floor is None:
+                sub.stats = uop.stats.index_select(0, b)
+                sel_b = torch.empty((n_b, int(k)), dtype=torch.int32, device=dev)
+                tau_b = torch.empty((n_b,), dtype=torch.float32, device=dev)
+                floor_b = torch.empty((n_b,), dtype=torch.float32, device=dev)
+                N.call("trec_topk_select_blocks", N.ptr(table_b), n_sb, n_b, n_b, int(k), N.ptr(sel_b), None, N.ptr(tau_b))
+                N.call("trec_topk_filter_floor", N.ptr(tau_b), N.ptr(sub.stats), N.ptr(ub), N.ptr(gstats), uop.kpad, n_b,
+                       N.ptr(floor_b), N.ptr(flag_b), N.ptr(n_flagged_b))
+            else:
+                floor_b = floor.index_select(0, b)
             wv, wi, _ = _filter_tail(sub, iop, table_b, n_b, n_b, n_sb, k, ub, item_bias, item_index_base, sb_rows, variant,
-                                     ksel_w, 16, floor.index_select(0, b), flag_b, n_flagged_b, rows_wg, wide=True)
+                                     ksel_w, 16, floor_b, flag_b, n_flagged_b, rows_wg, wide=True)
             out_v.append(wv); out_i.append(wi); out_f.append(flag_b)
             del table_b, sub
     return torch.cat(out_v), torch.cat(out_i), torch.cat(out_f)
@@ -1385,7 +1444,7 @@ def _score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index
         rblocks = (n_u + rows_wg - 1) // rows_wg
         n_chunks = max(1, min(n_sb, -(-32 * 768 // rblocks)))
     LAST_FILTER_STATS.clear()
-    blockmax, bm_stride, cascade_status, tau8 = None, n_u, None, None
+    blockmax, bm_stride, cascade_status, tau8, cands = None, n_u, None, None, None
     # item shards: the item-side maxima behind both bounds (norms, rounding-error norms, |bias|) are MAX-reduced ONCE per call
     gstats = iop.gstats
     if stats_exchange is not None:
@@ -1393,8 +1452,9 @@ def _score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index
     if prefilter == "int8" and kpad in (64, 128) and sb_rows % 128 == 0 and not (iop.cascade_too_loose and
                                                                                  floor_exchange is None):
         # ---- stages 0 + 1: int8 maxima everywhere, bf16 maxima where a top-k item can be
-        blockmax, bm_stride, cascade_status, tau8 = _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks,
-                                                                    floor_exchange, stats_exchange, gstats)
+        blockmax, bm_stride, cascade_status, tau8, cands = _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb,
+                                                                           n_chunks, floor_exchange, stats_exchange, gstats,
+                                                                           item_index_base)
         rows, overflow = cascade_status
         if overflow:
             # the int8 bound was too loose for this data: nothing was refined.  bf16 does stage 1; the next user batches
@@ -1422,6 +1482,25 @@ def _score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index
     # stage, ONE: tau8 gives a provisional floor (tau >= tau8 - eps, so the final floor is >= tau8 - 3 eps), the scan keeps the
     # k largest entries AND lists the entries above it, and the final floor only prunes those ~45 candidates per user
     kk = int(k)
+    if cands is not None:
+        # ---- the refining launches listed every item that can still reach the top-k: finish from the lists (stages 2-3 gone)
+        ov = torch.empty((n_u, kk), dtype=torch.float32, device=dev)
+        oi = torch.empty((n_u, kk), dtype=torch.int32, device=dev)
+        flag, n_flagged = cands.flag, cands.n_flagged
+        with _timed("topk_filter_finish"):
+            N.call("trec_topk_candidates_finish", N.ptr(cands.n), N.ptr(cands.items), cands.cap, N.ptr(cands.floor0),
+                   N.ptr(uop.stats), N.ptr(gstats), N.ptr(uop.f32), N.ptr(iop.f32), kpad, kpad, uop.d, N.ptr(user_bias),
+                   N.ptr(item_bias), item_index_base, n_u, kk, N.ptr(ov), N.ptr(oi), N.ptr(flag), N.ptr(n_flagged))
+        if FILTER_DEBUG is not None:
+            _debug_counts("candidates", cands.n)
+        n_bad = int(n_flagged.item())
+        LAST_FILTER_STATS.update({"prefilter": "int8", "refined_rows": cascade_rows, "users": n_u, "flagged_users": n_bad,
+                                  "tail": "candidate lists", "candidates_cap": cands.cap,
+                                  "candidates_per_user": float(cands.n.clamp(max=cands.cap).sum().item()) / max(1, n_u)})
+        floor = None
+        cands = None
+        return _redo_flagged(uop, iop, blockmax, flag, n_bad, n_sb, k, user_bias, item_bias, item_index_base, sb_rows, variant,
+                             floor, rows_wg, ksel, gstats, ov, oi)
     tau = torch.empty((n_u,), dtype=torch.float32, device=dev)
     sel_max = torch.empty((kk, n_u), dtype=torch.float32, device=dev) if floor_exchange is not None else None
     floor = torch.empty((n_u,), dtype=torch.float32, device=dev)
@@ -1480,6 +1559,15 @@ def _score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index
         LAST_FILTER_STATS["refined_rows"] = cascade_rows
     LAST_FILTER_STATS.update({"users": n_u, "flagged_users": n_bad, "ksel": ksel,
                               "kept_superblocks_per_user": float(count.sum().item()) / max(1, n_u)})
+    return _redo_flagged(uop, iop, blockmax, flag, n_bad, n_sb, k, user_bias, item_bias, item_index_base, sb_rows, variant, floor,
+                         rows_wg, ksel, gstats, ov, oi)
+
+
+def _redo_flagged(uop, iop, blockmax, flag, n_bad, n_sb, k, user_bias, item_bias, item_index_base, sb_rows, variant, floor, rows_wg,
+                  ksel, gstats, ov, oi):
+    """The users the first pass flagged (``n_bad`` of them, ``flag`` != 0): the wide second pass on their table columns, then
+    the exact fp32 MFMA path for what is left.  Returns (ov, oi) with their rows replaced."""
+    n_u, n_i, kpad = uop.n, iop.n, uop.kpad
     if n_bad:
         bad = torch.nonzero(flag, as_tuple=False).reshape(-1)
         if N.load().trec_get_tuning(b"topk_filter_wide_pass", 1) != 0 and n_sb > ksel:
@@ -1489,7 +1577,7 @@ def _score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index
                 if bad.numel() == 0 or (tier == 1 and (ksel_w <= FILTER_KSEL_WIDE or bad.numel() > WIDE_TIER2_MAX_FRACTION * n_u)):
                     break
                 wv, wi, wflag = _wide_second_pass(uop, iop, blockmax, bad, n_sb, k, user_bias, item_bias, item_index_base,
-                                                  sb_rows, variant, floor, rows_wg, max(int(k), ksel_w))
+                                                  sb_rows, variant, floor, rows_wg, max(int(k), ksel_w), gstats)
                 ov[bad] = wv
                 oi[bad] = wi
                 bad = bad[wflag != 0]

@@ -1,0 +1,143 @@
+"""The cascade's candidate lists: the bf16 refining launches (trec_score_gemm_refine_candidates / _hot, kernel form
+LIST of csrc/score_blockmax.hip) also list, per user, every item of a refined (superblock, user) pair whose bf16 score reaches
+the provisional floor tauLB - eps, and trec_topk_candidates_finish derives the filter's floor from the listed ITEM scores and
+re-scores the survivors exactly -- no table scan, no grouping by superblock, no grouped list kernel.
+
+Bar: values AND item ids bit-identical to the oracle's fp32 restatement of tf.matmul + tf.nn.top_k
+(tensorrec/prediction_graphs.py:49-50, tensorrec/recommendation_graphs.py:80), identical to the table-driven tail (tuning
+cascade_candidates = 0), and the lists themselves: nothing below the floor, nothing twice, nothing missing that could matter."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from tensorrec_amd import ops as _ops, _native
+    _native.require_gpu()
+    _native.load()
+    return _ops
+
+
+@pytest.fixture
+def tuning():
+    from tensorrec_amd import _native
+    defaults = {"cascade_candidates": 1, "cascade_candidates_cap": 128}
+
+    def set_(name, value):
+        assert name in defaults
+        _native.set_tuning(name, value)
+    yield set_
+    for name, value in defaults.items():
+        _native.set_tuning(name, value)
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def run(ops, u, v, k, ub=None, ib=None, base=0, **kw):
+    dub = dev(ub) if ub is not None else None
+    dib = dev(ib) if ib is not None else None
+    uop = ops.score_prep_filter(dev(u), sort_users=True, k=k)
+    iop = ops.score_prep_filter(dev(v), bias=dib, want_gstats=True)
+    vals, idx = ops.score_topk_filtered(uop, iop, k, dub, dib, item_index_base=base, prefilter="int8", **kw)
+    return vals.cpu().numpy(), idx.cpu().numpy(), dict(ops.LAST_FILTER_STATS)
+
+
+@pytest.mark.parametrize("d,biased,n_u,n_i,k", [(128, True, 1300, 300_000, 10), (64, True, 700, 280_011, 16), (128, False, 515, 262_144, 1),
+                                                (100, True, 300, 270_000, 5)])
+def test_candidate_tail_is_exact_and_equals_the_table_tail(ops, tuning, d, biased, n_u, n_i, k):
+    rng = np.random.default_rng(d + n_u)
+    u = rng.standard_normal((n_u, d)).astype(np.float32)
+    v = rng.standard_normal((n_i, d)).astype(np.float32)
+    ub = (0.3 * rng.standard_normal(n_u)).astype(np.float32) if biased else None
+    ib = (0.3 * rng.standard_normal(n_i)).astype(np.float32) if biased else None
+    vals, idx, stats = run(ops, u, v, k, ub, ib, base=1000)
+    assert stats["prefilter"] == "int8" and stats.get("tail") == "candidate lists"
+    rv, ri = O.topk_rows(O.score_dense_exact(u, v, ub, ib), k)
+    assert np.array_equal(idx, ri + 1000) and np.array_equal(vals, rv)
+    assert stats["flagged_users"] <= max(1, n_u // 50)
+    assert 0.3 * k <= stats["candidates_per_user"] <= 100       # (per row of the padded operand: up to 767 padding rows)
+    tuning("cascade_candidates", 0)
+    vals0, idx0, stats0 = run(ops, u, v, k, ub, ib, base=1000)
+    assert stats0["prefilter"] == "int8" and "tail" not in stats0
+    assert np.array_equal(idx0, idx) and np.array_equal(vals0, vals)
+
+
+def test_candidate_lists_hold_what_they_must_and_nothing_twice(ops):
+    """The lists behind one call, read back: every entry is an item of the catalogue listed once, with a bf16-path score at or
+    above the user's provisional floor and within eps of the fp32 score; every item whose fp32 score exceeds the floor by eps
+    is listed (it lies in a refined pair: its score is above the k-th largest lower bound)."""
+    rng = np.random.default_rng(5)
+    n_u, n_i, d, k = 800, 300_000, 128, 10
+    u = rng.standard_normal((n_u, d)).astype(np.float32)
+    v = rng.standard_normal((n_i, d)).astype(np.float32)
+    ub = (0.2 * rng.standard_normal(n_u)).astype(np.float32)
+    ib = (0.2 * rng.standard_normal(n_i)).astype(np.float32)
+    dub, dib = dev(ub), dev(ib)
+    uop = ops.score_prep_filter(dev(u), sort_users=True, k=k)
+    iop = ops.score_prep_filter(dev(v), bias=dib, want_gstats=True)
+    ubp = dub.index_select(0, uop.perm)
+    n_sb = (n_i + 511) // 512
+    table, stride, (rows, overflow), tau8, cands = ops._cascade_stage1(uop, iop, k, ubp, dib, 512, n_sb, 8, None, None, iop.gstats, 0)
+    assert not overflow and cands is not None
+    n = cands.n.cpu().numpy()
+    items = cands.items.cpu().numpy()
+    floor0 = cands.floor0.cpu().numpy()
+    pad = uop.pad.cpu().numpy() if uop.pad is not None else np.zeros(uop.n, bool)
+    assert (n[pad] == 0).all() and (n[~pad] >= k).all() and (n <= cands.cap).all()
+    perm = uop.perm.cpu().numpy()
+    exact = O.score_dense_exact(u, v, ub, ib)
+    st = uop.stats.cpu().numpy()
+    g = iop.gstats.cpu().numpy()
+    for r in np.flatnonzero(~pad)[::7]:
+        ids = items[r, :n[r], 0]
+        sh = items[r, :n[r], 1].copy().view(np.float32)
+        assert len(np.unique(ids)) == len(ids) and ids.min() >= 0 and ids.max() < n_i
+        assert (sh >= floor0[r]).all()
+        s = exact[perm[r]]
+        eps = st[r, 1] * g[0] * 1.01 + st[r, 0] * g[1] + (d + 2) * 3e-7 * (st[r, 0] * g[0] * 1.01 + abs(ub[perm[r]]) + g[2])
+        assert np.abs(sh - s[ids]).max() <= eps * 1.01
+        must = np.flatnonzero(s >= floor0[r] + eps * 1.01)
+        assert np.isin(must, ids).all()
+        assert np.isin(np.argsort(-s, kind="stable")[:k], ids).all()
+
+
+def test_users_with_more_candidates_than_the_lists_hold_are_redone(ops, tuning):
+    """300 copies of the best item: every copy is a candidate of every user who likes it -- more than the 64 entries the lists
+    are given here.  Such users are flagged and re-done (wide pass on the table, then fp32); the result stays exact and ties
+    come out in index order."""
+    rng = np.random.default_rng(9)
+    n_u, n_i, d, k = 520, 280_000, 64, 10
+    u = rng.standard_normal((n_u, d)).astype(np.float32)
+    v = rng.standard_normal((n_i, d)).astype(np.float32)
+    u[:100, 0] += 4.0                                           # 100 users share a taste ...
+    star = np.zeros(d, np.float32); star[0] = 20.0              # ... for this item: score ~ 80 against a k-th best of ~ 4.4 * 8
+    where = rng.choice(n_i, 300, replace=False)
+    v[where] = star
+    tuning("cascade_candidates_cap", 64)
+    vals, idx, stats = run(ops, u, v, k)
+    rv, ri = O.topk_rows(O.score_dense_exact(u, v, None, None), k)
+    assert np.array_equal(idx, ri) and np.array_equal(vals, rv)
+    assert stats["prefilter"] == "int8" and stats["flagged_users"] >= 10
+
+
+def test_popular_items_fill_the_wave_queues(ops):
+    """Items every user wants (a large bias) sit next to each other: all 128 users of a wave hit in the same 16-item blocks, far
+    more than the queue's flush threshold -- the mid-superblock flush must keep every hit (hot superblocks: the dense launch)."""
+    rng = np.random.default_rng(21)
+    n_u, n_i, d, k = 1100, 300_000, 128, 16
+    u = rng.standard_normal((n_u, d)).astype(np.float32) * 0.1
+    v = rng.standard_normal((n_i, d)).astype(np.float32) * 0.1
+    ib = (0.01 * rng.standard_normal(n_i)).astype(np.float32)
+    ib[70_000:70_024] += 5.0                     # 24 adjacent popular items: 16 of them are every user's top-16
+    ib[150_003] += 5.0
+    vals, idx, stats = run(ops, u, v, k, None, ib)
+    rv, ri = O.topk_rows(O.score_dense_exact(u, v, None, ib), k)
+    assert np.array_equal(idx, ri) and np.array_equal(vals, rv)
+    assert stats["prefilter"] == "int8" and stats["flagged_users"] == 0

@@ -461,20 +461,20 @@ def test_cascade_hot_superblocks_of_a_popular_catalogue(ops):
 
 
 def test_rows_hot_lists_rows_over_capacity(ops):
-    """trec_topk_rows_hot: rows with count > rcap, ascending, -1 padded; their counts zeroed; status = {rows, overflow}."""
+    """trec_topk_rows_hot: rows with count > rcap, ascending, -1 padded; their counts zeroed; status = {rows, overflow, hot rows}."""
     from tensorrec_amd import _native as N
     counts = np.array([5, 700, 512, 513, 0, 9000, 100, 513], dtype=np.int32)
     rcap, n_users = 512, 1000
     for hot_cap, max_pairs, over in ((8, 1 << 40, 0), (3, 1 << 40, 1), (8, 4616, 1), (8, 4617, 0)):
         rc = dev(counts.copy())
         hot = torch.full((hot_cap,), -7, dtype=torch.int32, device="cuda")
-        status = torch.zeros((2,), dtype=torch.int64, device="cuda")
+        status = torch.zeros((3,), dtype=torch.int64, device="cuda")
         N.call("trec_topk_rows_hot", N.ptr(rc), len(counts), rcap, n_users, N.ptr(hot), hot_cap, max_pairs, N.ptr(status))
         want = [1, 3, 5, 7]
         assert hot.cpu().tolist() == (want + [-1] * hot_cap)[:hot_cap]
         assert rc.cpu().tolist() == [5, 0, 512, 0, 0, 0, 100, 0]
         rows = 512 + 512 + 0 + 512 + min(len(want), hot_cap) * 1024
-        assert status.cpu().tolist() == [rows, over]
+        assert status.cpu().tolist() == [rows, over, len(want)]
 
 
 @pytest.mark.parametrize("cand_cap", [128, 6])
@@ -495,10 +495,12 @@ def test_one_pass_scan_equals_select_plus_collect(ops, cand_cap):
     try:
         ops.FILTER_CANDIDATES = cand_cap
         N.set_tuning("filter_scan_one_pass", 2)
+        N.set_tuning("cascade_candidates", 0)             # (the table-driven tail: the default goes through candidate lists)
         vals, idx, stats, _, _ = run_cascade(ops, u, v, k, ub, ib)
     finally:
         ops.FILTER_CANDIDATES = old_cap
         N.set_tuning("filter_scan_one_pass", 1)
-    assert stats["prefilter"] == "int8"
+        N.set_tuning("cascade_candidates", 1)
+    assert stats["prefilter"] == "int8" and "tail" not in stats
     assert np.array_equal(idx, ri) and np.array_equal(vals, rv)
     assert stats["flagged_users"] <= 13

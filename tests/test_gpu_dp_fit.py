@@ -133,6 +133,7 @@ def _topk_worker(rank, world, port, n_items, n_tastes, ret, d=32):
         if os.environ.get("TREC_TEST_ONE_PASS"):                # the one-pass select + collect, forced on these small tables
             from tensorrec_amd import _native
             _native.set_tuning("filter_scan_one_pass", 2)
+            _native.set_tuning("cascade_candidates", 0)         # (the table-driven tail; the default is the candidate lists)
         model, uf, itf = _topk_case(n_items, n_tastes, d)
         b, e = sharding.shard_bounds(n_items, world, rank)
         ret[rank] = model.predict_top_k(uf, itf[b:e], k=10, item_sharded=True, item_offset=b)
