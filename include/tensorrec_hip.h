@@ -311,7 +311,13 @@ int trec_score_gemm_blockmax_hot(const void* users_bf16, const void* items_bf16,
  * survivors = listed items >= tau - 2 eps (user_stats / item_gstats as for trec_topk_filter_floor), exact fp32 re-scoring
  * and top-k as trec_topk_filter_finish; users with cand_n > cand_cap (64, 128, 192 or 256) or more than 64 survivors are
  * flagged, users whose cand_floor is +inf are skipped (their outputs are -inf / -1).  This replaces, behind the int8 stage,
- * the table scan, the grouping by superblock and the grouped list kernel of the bf16 filter. */
+ * the table scan, the grouping by superblock and the grouped list kernel of the bf16 filter.  trec_topk_dense_users, before
+ * the refining launches: a user for whom `limit` or more of 32 sampled superblocks reach the threshold of
+ * trec_topk_rows_collect (the int8 bound says nothing about its row) gets cand_floor = +inf and is flagged at once -- listing
+ * most of the catalogue for it would only end in the same flag. */
+int trec_topk_dense_users(const float* table, int32_t n_sb, int64_t n_users, int64_t stride, const float* thr,
+                          const float* user_err, const float* sb_stats, int32_t kdim, int32_t limit, float* cand_floor,
+                          int32_t* flag, int32_t* n_flagged, void* stream);
 int trec_score_gemm_refine_candidates(const void* users_bf16, const void* items_bf16, int32_t kpad, int64_t n_rows_g,
                                       int64_t n_items, const float* user_bias, const float* item_bias, int32_t sb_rows,
                                       const int32_t* row_count, const int32_t* row_user, float* blockmax, int64_t bm_stride,

@@ -423,7 +423,8 @@ __global__ __launch_bounds__(256, NUB == 8 ? 2 : 3) void blockmax_bf16x16_kernel
         for (int ks = 0; ks < KS; ++ks) rfb[ub][ks] = *(const bf16x8*)(src + (ks * 4 + g) * 16);
         thr_a[ub] = INFINITY;
         if (LIST) {
-            const float fl = real ? p.cand_floor[row] : INFINITY;
+            float fl = real ? p.cand_floor[row] : INFINITY;
+            if (real && p.cand_n[row] > p.cand_cap) fl = INFINITY;        // the list is already incomplete: the user will be re-done
             const float bu = (BIAS && p.r_bias && real) ? p.r_bias[row] : 0.f;
             // acc + bu >= fl (evaluated exactly when the queue is emptied) implies acc >= thr_a: fl - bu less three roundings
             const float t = fl - bu;

@@ -310,6 +310,37 @@ __global__ __launch_bounds__(256) void rows_collect_kernel(const float* __restri
     }
 }
 
+// Users the int8 bound says nothing about (a row far smaller than its scale class, a row of outliers): nearly every superblock
+// reaches their threshold, so every superblock would be refined for them and -- with the candidate lists -- most items listed,
+// only for the finish kernel to flag them anyway.  32 sampled table rows (4 groups of CROWS, evenly spaced) decide: ``limit`` or
+// more kept -> cand_floor = +inf (the refining launches list nothing for the user) and the user is flagged now.  A heuristic
+// for speed only: flagged users are re-done exactly by the caller.
+__global__ __launch_bounds__(256) void dense_users_kernel(const float* __restrict__ table, int32_t n_sb, int64_t n_users,
+                                                         int64_t stride, const float* __restrict__ thr,
+                                                         const float* __restrict__ user_err,
+                                                         const float* __restrict__ sb_stats, int kdim, int32_t limit,
+                                                         float* __restrict__ cand_floor, int32_t* __restrict__ flag,
+                                                         int32_t* __restrict__ n_flagged)
+{
+    const int64_t u = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (u >= n_users) return;
+    const UserConsts c = load_user_consts(thr, user_err, n_users, u);
+    int cnt[4] = {0, 0, 0, 0};
+    const int32_t groups = n_sb / CROWS;
+    for (int j = 0; j < 4; ++j) {
+        const int32_t s0 = (int32_t)(((int64_t)groups * j) / 4) * CROWS;
+        const unsigned int bits = tile_bits(table, n_sb, n_users, stride, c, sb_stats, kdim, s0, u);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cnt[e] += __builtin_popcount(bits & (0x11111111u << e));
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (u + e < n_users && cnt[e] >= limit && cand_floor[u + e] < INFINITY) {
+            cand_floor[u + e] = INFINITY;
+            if (flag[u + e] == 0) { flag[u + e] = 1; atomicAdd(n_flagged, 1); }
+        }
+}
+
 // status[0] = resident rows the grouped launch works on (every row's count, capped, rounded up to whole workgroups),
 // status[1] = 1 when some superblock kept more users than rcap
 __global__ __launch_bounds__(256) void rows_status_kernel(const int32_t* __restrict__ row_count, int32_t n_sb, int32_t rcap,
@@ -572,4 +603,19 @@ extern "C" int trec_score_gemm_refine_candidates_hot(const void* users_bf16, con
     p.rblock_chunk = hot_list;
     p.cand_floor = cand_floor; p.cand_n = cand_n; p.cand = (int2*)cand; p.cand_cap = cand_cap; p.t_index_base = item_index_base;
     return launch_blockmax_filter16(p, kpad, (hipStream_t)stream);
+}
+
+// Before the refining launches that list candidates: users for whom ``limit`` or more of 32 sampled superblocks reach their
+// threshold (the criterion of trec_topk_rows_collect on the int8 table) get cand_floor = +inf -- nothing is listed for them --
+// and are flagged (flag / n_flagged as trec_topk_filter_floor_ex left them).  n_sb >= 32.
+extern "C" int trec_topk_dense_users(const float* table, int32_t n_sb, int64_t n_users, int64_t stride, const float* thr,
+                                     const float* user_err, const float* sb_stats, int32_t kdim, int32_t limit,
+                                     float* cand_floor, int32_t* flag, int32_t* n_flagged, void* stream)
+{
+    TREC_REQUIRE(table && thr && user_err && sb_stats && cand_floor && flag && n_flagged, "trec_topk_dense_users: null pointer");
+    TREC_REQUIRE(n_sb >= 32 && stride >= n_users && limit >= 1 && limit <= 32, "trec_topk_dense_users: need n_sb >= 32, 1 <= limit <= 32");
+    if (n_users == 0) return TREC_OK;
+    hipLaunchKernelGGL(dense_users_kernel, dim3((unsigned)ceil_div64(n_users, 1024)), dim3(256), 0, (hipStream_t)stream, table, n_sb,
+                       n_users, stride, thr, user_err, sb_stats, kdim, limit, cand_floor, flag, n_flagged);
+    return trec_check_launch("trec_topk_dense_users");
 }

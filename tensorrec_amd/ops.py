@@ -1074,8 +1074,10 @@ CASCADE_MAX_REFINED = 0.45
 CASCADE_ROW_CAPACITY = 0.50      # fixed capacity of a superblock's user list (fraction of the users); fuller rows are "hot":
                                  # the dense kernel re-scores them for everybody at 1.5x the grouped kernel's rate
 CASCADE_MAX_HOT = 1 << 20        # superblocks that may be hot (no limit of its own: CASCADE_MAX_REFINED bounds the work)
-CASCADE_CANDIDATES = 128         # candidate items per user the refining launches may list (trec_score_gemm_refine_candidates:
-                                 # every item of a refined pair within eps of the k-th largest int8 lower bound; ~32 at 1M x 1M)
+CASCADE_CANDIDATES = 256         # candidate items per user the refining launches may list (trec_score_gemm_refine_candidates:
+                                 # every item of a refined pair within eps of the k-th largest int8 lower bound; ~30 at 1M x 1M,
+                                 # 138 (median) on clustered rows; the finish reads the first 64 unasked, the rest by the count)
+CASCADE_DENSE_USER_LIMIT = 16    # of 32 sampled superblocks kept (Gaussian rows keep 2.6 % of them, clustered ones 23 %): the int8 bound says nothing about this user -- flagged at once
 CASCADE_MIN_ITEMS = 262144       # below ~512 superblocks the k-th largest maximum is not selective enough for int8 to pay
 
 
@@ -1153,6 +1155,34 @@ def blockmax_i8_chunks(n_items, n_chunks, sb_rows):
     return chunk_len, -(-n_items // chunk_len)
 
 
+import contextlib as _contextlib
+
+
+@_contextlib.contextmanager
+def _tail_of(tail_stream, *tensors):
+    """Launches inside run on ``tail_stream`` (None: the current one) once everything queued on the current stream so far is
+    done; ``tensors`` -- allocated on the current stream, used inside -- are recorded on it so that the allocator does not hand
+    their memory out again before the tail stream is through with them."""
+    if tail_stream is None:
+        yield
+        return
+    tail_stream.wait_stream(torch.cuda.current_stream())
+    for t in tensors:
+        if t is not None:
+            t.record_stream(tail_stream)
+    with torch.cuda.stream(tail_stream):
+        yield
+
+
+class _Pending(object):
+    """A filtered top-k whose tail is still running on another stream: ``complete()`` -- once the caller's stream has waited
+    for that stream -- reads the flagged-user counter, re-does those users and returns (values, ids, stats)."""
+    __slots__ = ("complete",)
+
+    def __init__(self, complete):
+        self.complete = complete
+
+
 class _Candidates(object):
     """What the refining launches listed (trec_score_gemm_refine_candidates): per user ``n`` appended entries of ``items``
     [n_users, cap, 2] = {item id, score bits}, made with the provisional floor ``floor0`` (+inf: nothing listed); ``flag`` /
@@ -1168,7 +1198,7 @@ def cascade_lists_candidates():
 
 
 def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, floor_exchange, stats_exchange, gstats_all=None,
-                    item_index_base=0):
+                    item_index_base=0, tail_stream=None):
     """Stages 0-1 of the int8 -> bf16 -> fp32 cascade (csrc/topk_cascade.hip): the [n_sb, n_users] table of superblock
     maxima whose entries are bf16 maxima wherever a top-k item can be and int8 maxima elsewhere (None after an overflow), its
     row stride, and (resident rows of the bf16 launches, overflow).  Every superblock has a list of CASCADE_ROW_CAPACITY of the
@@ -1251,9 +1281,15 @@ def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, 
             cands.floor0.masked_fill_(cands.flag != 0, float("inf"))
             if uop.pad is not None:
                 cands.floor0.masked_fill_(uop.pad, float("inf"))
+            if n_sb >= 32:                              # users the int8 bound says nothing about are flagged now, not listed for
+                N.call("trec_topk_dense_users", N.ptr(table), n_sb, n_u, stride, N.ptr(tau), N.ptr(user_err), N.ptr(iop.sb_stats),
+                       kpad, CASCADE_DENSE_USER_LIMIT, N.ptr(cands.floor0), N.ptr(cands.flag), N.ptr(cands.n_flagged))
             cands.n = torch.zeros((n_u,), dtype=torch.int32, device=dev)
             cands.items = torch.empty((n_u, cands.cap, 2), dtype=torch.int32, device=dev)     # only the listed part is touched
-        with _timed("score_gemm_blockmax_grouped"):
+        # (user batches in a pipeline: from here on the launches go to the tail stream, next to the following batch's int8 stage)
+        tail = _tail_of(tail_stream if cands is not None else None, table, row_count, row_user, hot_list,
+                        *((cands.floor0, cands.n, cands.items) if cands is not None else ()))
+        with tail, _timed("score_gemm_blockmax_grouped"):
             if cands is not None:
                 N.call("trec_score_gemm_refine_candidates", N.ptr(uop.bf16), N.ptr(iop.bf16), kpad, n_sb * rcap, n_i,
                        N.ptr(user_bias), N.ptr(item_bias), sb_rows, N.ptr(row_count), N.ptr(row_user), N.ptr(table), stride,
@@ -1262,7 +1298,7 @@ def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, 
                 N.call("trec_score_gemm_blockmax_grouped", N.ptr(uop.bf16), N.ptr(iop.bf16), kpad, n_sb * rcap, n_i,
                        N.ptr(user_bias), N.ptr(item_bias), sb_rows, N.ptr(row_count), N.ptr(row_user), N.ptr(table), stride,
                        rcap // 512)
-        with _timed("score_gemm_blockmax_hot"):
+        with _tail_of(tail_stream if cands is not None else None), _timed("score_gemm_blockmax_hot"):
             if n_hot == 0:
                 pass
             elif cands is not None:
@@ -1403,8 +1439,13 @@ def score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index_
         return _score_topk_filtered(uop, iop, k, user_bias, item_bias, item_index_base, sb_rows, variant, n_chunks,
                                     floor_exchange, stats_exchange, ksel, prefilter)
     ub = user_bias.index_select(0, uop.perm) if user_bias is not None else None
-    sv, si = _score_topk_filtered(uop, iop, k, ub, item_bias, item_index_base, sb_rows, variant, n_chunks,
-                                  floor_exchange, stats_exchange, ksel, prefilter)
+    n_batches = cascade_user_batches(uop, iop, prefilter, floor_exchange, stats_exchange)
+    if n_batches > 1:
+        sv, si = _score_topk_filtered_pipelined(uop, iop, k, ub, item_bias, item_index_base, sb_rows, variant, n_chunks, ksel,
+                                                n_batches)
+    else:
+        sv, si = _score_topk_filtered(uop, iop, k, ub, item_bias, item_index_base, sb_rows, variant, n_chunks,
+                                      floor_exchange, stats_exchange, ksel, prefilter)
     n_real = int(uop.order.numel())
     ov = torch.empty((n_real, sv.shape[1]), dtype=sv.dtype, device=sv.device)
     oi = torch.empty((n_real, si.shape[1]), dtype=si.dtype, device=si.device)
@@ -1415,8 +1456,89 @@ def score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index_
     return ov, oi
 
 
+CASCADE_PIPELINE_MIN_ROWS = 131072     # user rows per batch below which the two-stream pipeline is not worth its launches
+_TAIL_STREAMS = {}
+
+
+def cascade_user_batches(uop, iop, prefilter, floor_exchange, stats_exchange):
+    """User batches of the two-stream pipeline (tuning ``cascade_user_batches``; default 1 = off): the int8 stage of batch
+    b + 1 runs next to the bf16 refinement and the finish of batch b -- the first is bound by the matrix pipe at the power limit,
+    the others by gathers and latencies.  Single process, class-sorted users, a catalogue the cascade is used on.
+    MEASURED at 1M x 1M: 4 batches 98.6-98.8 ms against 95.7-96.5 for one -- the tail kernels do run next to the
+    int8 launch (their event time stretches to its ~20 ms) but the chip is at its power limit either way: the int8 launches
+    lose what the hidden tail gains, and four smaller launches of everything cost more than one.  Kept as a knob."""
+    want = N.load().trec_get_tuning(b"cascade_user_batches", 1)
+    if want <= 1 or prefilter != "int8" or floor_exchange is not None or stats_exchange is not None or uop.wg_rows is None:
+        return 1
+    if uop.kpad not in (64, 128) or iop.cascade_too_loose or not cascade_lists_candidates():
+        return 1
+    return max(1, min(int(want), int(uop.n) // CASCADE_PIPELINE_MIN_ROWS))
+
+
+def _rows_of(uop, r0, r1):
+    """Rows r0 .. r1 (multiples of the int8 workgroup height) of a class-sorted user operand, as views."""
+    sub = FilterOperand()
+    sub.n, sub.d, sub.kpad = r1 - r0, uop.d, uop.kpad
+    sub.bf16, sub.f32, sub.stats = uop.bf16[r0:r1], uop.f32[r0:r1], uop.stats[r0:r1]
+    sub.i8, sub.stats8 = uop.i8[r0:r1], uop.stats8[r0:r1]
+    sub.pad = uop.pad[r0:r1] if uop.pad is not None else None
+    sub.wg_rows = uop.wg_rows
+    sub.wg_scale = uop.wg_scale[r0 // uop.wg_rows:r1 // uop.wg_rows]
+    sub.wg_class = uop.wg_class[r0 // uop.wg_rows:r1 // uop.wg_rows]
+    sub.cls, sub.gmax = uop.cls[r0:r1], uop.gmax
+    return sub
+
+
+def _score_topk_filtered_pipelined(uop, iop, k, user_bias, item_bias, item_index_base, sb_rows, variant, n_chunks, ksel, n_batches):
+    """_score_topk_filtered(prefilter="int8") over ``n_batches`` row ranges of the class-sorted operand, two streams: everything
+    up to the host's read of the compaction status runs on the caller's stream, the bf16 refinement and the finish of a batch on
+    a second one -- next to the following batch's int8 stage.  The flagged users of all batches are re-done at the end."""
+    sb_rows = int(sb_rows or SUPERBLOCK_ROWS)
+    top_k = 10 if int(k) <= 10 else 16
+    if uop.i8 is None or iop.i8 is None or iop.sb_rows != sb_rows:
+        score_prep_i8_pair(uop, iop, item_bias, sb_rows, top_k)          # ONCE for all batches (the classes in use, the item biases)
+    dev = uop.bf16.device
+    main = torch.cuda.current_stream()
+    tail = _TAIL_STREAMS.get(dev)
+    if tail is None:
+        # high priority: a tail kernel's workgroups take the slots the int8 kernel's retiring workgroups free (at equal priority
+        # the int8 launch -- queued first, 16,000+ workgroups -- keeps every slot and the tail only runs once it has drained)
+        prio = -1 if N.load().trec_get_tuning(b"cascade_tail_priority", 1) != 0 else 0
+        tail = _TAIL_STREAMS[dev] = torch.cuda.Stream(device=dev, priority=prio)
+    wgs = int(uop.n) // int(uop.wg_rows)
+    bounds = [int(uop.wg_rows) * (wgs * b // n_batches) for b in range(n_batches + 1)]
+    parts = []
+    for b in range(n_batches):
+        r0, r1 = bounds[b], bounds[b + 1]
+        sub = _rows_of(uop, r0, r1)
+        ub = user_bias[r0:r1] if user_bias is not None else None
+        parts.append(_score_topk_filtered(sub, iop, k, ub, item_bias, item_index_base, sb_rows, variant, n_chunks, None, None,
+                                          ksel, "int8", tail_stream=tail))
+        if not isinstance(parts[-1], _Pending):
+            parts[-1] = (parts[-1], dict(LAST_FILTER_STATS))
+    main.wait_stream(tail)
+    out_v, out_i, stats = [], [], []
+    for part in parts:
+        if isinstance(part, _Pending):
+            v, i = part.complete()
+            part = ((v, i), dict(LAST_FILTER_STATS))
+        out_v.append(part[0][0]); out_i.append(part[0][1]); stats.append(part[1])
+    LAST_FILTER_STATS.clear()
+    LAST_FILTER_STATS.update(stats[0])
+    for key in ("refined_rows", "users", "flagged_users", "flagged_after_wide_pass", "flagged_after_wide_pass_2",
+                "users_on_fp32_fallback"):
+        if any(key in st for st in stats):
+            LAST_FILTER_STATS[key] = sum(st.get(key, 0) for st in stats)
+    if all("candidates_per_user" in st for st in stats):
+        LAST_FILTER_STATS["candidates_per_user"] = sum(st["candidates_per_user"] * st["users"] for st in stats) / max(1, uop.n)
+    if any(st.get("prefilter") != "int8" for st in stats):
+        LAST_FILTER_STATS["prefilter"] = "; ".join(sorted(set(str(st.get("prefilter")) for st in stats)))
+    LAST_FILTER_STATS["user_batches"] = n_batches
+    return torch.cat(out_v), torch.cat(out_i)
+
+
 def _score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index_base=0, sb_rows=None, variant=1,
-                         n_chunks=None, floor_exchange=None, stats_exchange=None, ksel=None, prefilter=None):
+                         n_chunks=None, floor_exchange=None, stats_exchange=None, ksel=None, prefilter=None, tail_stream=None):
     """EXACT fp32 top-k (values and ids bit-identical to ``score_topk(..., DTYPE_F32)`` and to the oracle) with the
     score matrix contracted ONCE on bf16 MFMA: the bf16 stage-1 maxima and the bf16 re-scoring act as a filter with a
     proven error bound (csrc/topk_filter.hip), the survivors (~15 items per user at 1M x 1M) are re-scored by the
@@ -1454,7 +1576,7 @@ def _score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index
         # ---- stages 0 + 1: int8 maxima everywhere, bf16 maxima where a top-k item can be
         blockmax, bm_stride, cascade_status, tau8, cands = _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb,
                                                                            n_chunks, floor_exchange, stats_exchange, gstats,
-                                                                           item_index_base)
+                                                                           item_index_base, tail_stream)
         rows, overflow = cascade_status
         if overflow:
             # the int8 bound was too loose for this data: nothing was refined.  bf16 does stage 1; the next user batches
@@ -1487,20 +1609,25 @@ def _score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index
         ov = torch.empty((n_u, kk), dtype=torch.float32, device=dev)
         oi = torch.empty((n_u, kk), dtype=torch.int32, device=dev)
         flag, n_flagged = cands.flag, cands.n_flagged
-        with _timed("topk_filter_finish"):
+        with _tail_of(tail_stream, ov, oi, flag, n_flagged, gstats), _timed("topk_filter_finish"):
             N.call("trec_topk_candidates_finish", N.ptr(cands.n), N.ptr(cands.items), cands.cap, N.ptr(cands.floor0),
                    N.ptr(uop.stats), N.ptr(gstats), N.ptr(uop.f32), N.ptr(iop.f32), kpad, kpad, uop.d, N.ptr(user_bias),
                    N.ptr(item_bias), item_index_base, n_u, kk, N.ptr(ov), N.ptr(oi), N.ptr(flag), N.ptr(n_flagged))
-        if FILTER_DEBUG is not None:
-            _debug_counts("candidates", cands.n)
-        n_bad = int(n_flagged.item())
-        LAST_FILTER_STATS.update({"prefilter": "int8", "refined_rows": cascade_rows, "users": n_u, "flagged_users": n_bad,
-                                  "tail": "candidate lists", "candidates_cap": cands.cap,
-                                  "candidates_per_user": float(cands.n.clamp(max=cands.cap).sum().item()) / max(1, n_u)})
-        floor = None
-        cands = None
-        return _redo_flagged(uop, iop, blockmax, flag, n_bad, n_sb, k, user_bias, item_bias, item_index_base, sb_rows, variant,
-                             floor, rows_wg, ksel, gstats, ov, oi)
+
+        def complete(cands=cands, blockmax=blockmax):
+            if FILTER_DEBUG is not None:
+                _debug_counts("candidates", cands.n)
+            n_bad = int(n_flagged.item())
+            LAST_FILTER_STATS.clear()
+            LAST_FILTER_STATS.update({"prefilter": "int8", "refined_rows": cascade_rows, "users": n_u, "flagged_users": n_bad,
+                                      "tail": "candidate lists", "candidates_cap": cands.cap,
+                                      "candidates_per_user": float(cands.n.clamp(max=cands.cap).sum().item()) / max(1, n_u)})
+            return _redo_flagged(uop, iop, blockmax, flag, n_bad, n_sb, k, user_bias, item_bias, item_index_base, sb_rows,
+                                 variant, None, rows_wg, ksel, gstats, ov, oi)
+        cands = blockmax = None
+        if tail_stream is not None:
+            return _Pending(complete)
+        return complete()
     tau = torch.empty((n_u,), dtype=torch.float32, device=dev)
     sel_max = torch.empty((kk, n_u), dtype=torch.float32, device=dev) if floor_exchange is not None else None
     floor = torch.empty((n_u,), dtype=torch.float32, device=dev)

@@ -26,7 +26,7 @@ def ops():
 @pytest.fixture
 def tuning():
     from tensorrec_amd import _native
-    defaults = {"cascade_candidates": 1, "cascade_candidates_cap": 128}
+    defaults = {"cascade_candidates": 1, "cascade_candidates_cap": 256, "cascade_user_batches": 1}
 
     def set_(name, value):
         assert name in defaults
@@ -141,3 +141,56 @@ def test_popular_items_fill_the_wave_queues(ops):
     rv, ri = O.topk_rows(O.score_dense_exact(u, v, None, ib), k)
     assert np.array_equal(idx, ri) and np.array_equal(vals, rv)
     assert stats["prefilter"] == "int8" and stats["flagged_users"] == 0
+
+
+def test_user_batches_on_two_streams_equal_one_batch(ops, tuning):
+    """The two-stream pipeline (ops.cascade_user_batches: the int8 stage of batch b + 1 next to the refinement and finish of
+    batch b), forced on a small problem: 3 batches of a class-sorted operand whose rows have very different scales, some users
+    beyond the candidate lists' capacity (re-done at the end, from their batch's table).  Same result as one batch, as the oracle."""
+    rng = np.random.default_rng(33)
+    n_u, n_i, d, k = 2900, 300_000, 128, 10
+    u = (rng.standard_normal((n_u, d)) * np.exp(rng.standard_normal((n_u, 1)))).astype(np.float32)
+    v = rng.standard_normal((n_i, d)).astype(np.float32)
+    u[:120, 0] += 6.0 * np.abs(u[:120]).max(1)
+    star = np.zeros(d, np.float32); star[0] = 25.0
+    v[rng.choice(n_i, 200, replace=False)] = star
+    ub = rng.standard_normal(n_u).astype(np.float32)
+    ib = (0.3 * rng.standard_normal(n_i)).astype(np.float32)
+    rv, ri = O.topk_rows(O.score_dense_exact(u, v, ub, ib), k)
+    tuning("cascade_candidates_cap", 64)
+    old = ops.CASCADE_PIPELINE_MIN_ROWS
+    try:
+        ops.CASCADE_PIPELINE_MIN_ROWS = 768
+        tuning("cascade_user_batches", 3)
+        vals, idx, stats = run(ops, u, v, k, ub, ib)
+        tuning("cascade_user_batches", 1)
+        vals1, idx1, stats1 = run(ops, u, v, k, ub, ib)
+    finally:
+        ops.CASCADE_PIPELINE_MIN_ROWS = old
+    assert stats.get("user_batches") == 3 and "user_batches" not in stats1
+    assert np.array_equal(idx, ri) and np.array_equal(vals, rv)
+    assert np.array_equal(idx1, ri) and np.array_equal(vals1, rv)
+    assert stats["flagged_users"] == stats1["flagged_users"] >= 50
+    assert stats["refined_rows"] >= stats1["refined_rows"] * 0.9
+
+
+def test_users_the_int8_bound_says_nothing_about_are_flagged_before_the_lists(ops):
+    """Rows 2^-20 of the others share the last scale class with rows a thousand times larger: their int8 images are zero, every
+    superblock reaches their threshold.  trec_topk_dense_users flags them before the refining launches (nothing is listed for
+    them: no candidate count beyond the capacity), the wide pass / fp32 path re-does them; everything stays exact."""
+    rng = np.random.default_rng(77)
+    n_u, n_i, d, k = 1500, 300_000, 128, 10
+    u = rng.standard_normal((n_u, d)).astype(np.float32)
+    u[::50] *= 2.0 ** -20
+    u[1::50] *= 2.0 ** -17
+    v = rng.standard_normal((n_i, d)).astype(np.float32)
+    ops.FILTER_DEBUG = {}
+    try:
+        vals, idx, stats = run(ops, u, v, k)
+        dbg = dict(ops.FILTER_DEBUG)
+    finally:
+        ops.FILTER_DEBUG = None
+    rv, ri = O.topk_rows(O.score_dense_exact(u, v, None, None), k)
+    assert np.array_equal(idx, ri) and np.array_equal(vals, rv)
+    assert stats["prefilter"] == "int8" and 30 <= stats["flagged_users"] <= 90
+    assert dbg["candidates_q50_90_99_999_max"][-1] <= 256
