@@ -96,7 +96,7 @@ def trained_weights_record(make_step, device, U, I, d, k, steps=3, epochs=20, lr
            "flagged_after_wide_pass": stats.get("flagged_after_wide_pass", 0 if stats.get("flagged_users") == 0 else None),
            "users_on_fp32_fallback": stats.get("users_on_fp32_fallback", 0),
            "refined_fraction_of_pairs": (stats.get("refined_rows", 0) / float(U * n_sb)) if "refined_rows" in stats else None,
-           "kept_superblocks_per_user": stats.get("kept_superblocks_per_user"),
+           "candidates_per_user": stats.get("candidates_per_user"), "tail": stats.get("tail", "bf16 filter on the mixed table"),
            "kernels_avg_ms": {n: float(np.mean(v)) for n, v in dur.items()},
            "weights": {"user_row_norm_q01_50_99_max": [float(v) for v in np.quantile(np.linalg.norm(w_u_h[::97], axis=1), [0.01, 0.5, 0.99, 1.0])],
                        "item_row_norm_q01_50_99_max": [float(v) for v in np.quantile(np.linalg.norm(w_i_h[::97], axis=1), [0.01, 0.5, 0.99, 1.0])],

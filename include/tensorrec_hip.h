@@ -322,7 +322,14 @@ int trec_score_gemm_refine_candidates(const void* users_bf16, const void* items_
                                       int64_t n_items, const float* user_bias, const float* item_bias, int32_t sb_rows,
                                       const int32_t* row_count, const int32_t* row_user, float* blockmax, int64_t bm_stride,
                                       int32_t wgs_per_row, const float* cand_floor, int32_t* cand_n, void* cand,
-                                      int32_t cand_cap, int32_t item_index_base, void* stream);
+                                      int32_t cand_cap, int32_t item_index_base, const int32_t* wg_map, int32_t n_wgs,
+                                      void* stream);
+/* Only the workgroup slots of the [n_sb][wgs_per_row] grid that hold rows (after trec_topk_rows_hot): wg_start [n_sb + 1] =
+ * exclusive prefix of min(ceil(row_count / 512), wgs_per_row), wg_map[wg_start[s] + j] = s * wgs_per_row + j (map_cap entries
+ * at most).  trec_score_gemm_refine_candidates(wg_map, n_wgs) then launches n_wgs workgroups instead of n_sb * wgs_per_row
+ * (1.9M at 1M users, 98k of them with rows); wg_map NULL = the full grid. */
+int trec_topk_rows_wg_map(const int32_t* row_count, int32_t n_sb, int32_t wgs_per_row, int32_t* wg_start, int32_t* wg_map,
+                          int64_t map_cap, void* stream);
 int trec_score_gemm_refine_candidates_hot(const void* users_bf16, const void* items_bf16, int32_t kpad, int64_t n_users,
                                           int64_t n_items, const float* user_bias, const float* item_bias, int32_t sb_rows,
                                           const int32_t* hot_list, int32_t hot_cap, float* blockmax, int64_t bm_stride,

@@ -39,10 +39,13 @@ def q(x):
 def topk_run(label, **kw):
     if ops.FILTER_DEBUG is not None:
         ops.FILTER_DEBUG.clear()
-    torch.cuda.synchronize(); t = time.perf_counter()
-    v, i = model.predict_top_k(uf, itf, k=10, user_batch_size=U, return_device=True, **kw)
-    torch.cuda.synchronize(); dt = time.perf_counter() - t
-    return {"mode": label, "ms": 1e3 * dt, "stats": dict(ops.LAST_FILTER_STATS), "debug": dict(ops.FILTER_DEBUG or {})}, v, i
+    dts = []
+    for rep in range(1 if ops.FILTER_DEBUG is not None else 2):      # the first call after a fit also pays for ~12 GB of hipMalloc
+        torch.cuda.synchronize(); t = time.perf_counter()
+        v, i = model.predict_top_k(uf, itf, k=10, user_batch_size=U, return_device=True, **kw)
+        torch.cuda.synchronize(); dts.append(time.perf_counter() - t)
+    dt = min(dts)
+    return {"mode": label, "ms": 1e3 * dt, "ms_first_call": 1e3 * dts[0], "stats": dict(ops.LAST_FILTER_STATS), "debug": dict(ops.FILTER_DEBUG or {})}, v, i
 
 
 total_epochs = 0

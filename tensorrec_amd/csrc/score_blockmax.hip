@@ -373,8 +373,8 @@ __global__ __launch_bounds__(256, NUB == 8 ? 2 : 3) void blockmax_bf16x16_kernel
     float* q_bu = q_fl + 4 * NUB * 16;
     int32_t* q_id = (int32_t*)(q_bu + 4 * NUB * 16);
     int qn = 0;                                                  // wave-uniform: entries in the queue
-    int rblock = GRP ? (int)blockIdx.x : (int)(blockIdx.x % p.n_rblocks);
-    if (GRP && p.capacity > 0 && p.grp_band_major) {
+    int rblock = GRP ? (p.wg_map ? p.wg_map[blockIdx.x] : (int)blockIdx.x) : (int)(blockIdx.x % p.n_rblocks);
+    if (GRP && p.capacity > 0 && p.grp_band_major && !p.wg_map) {
         // fixed-capacity layout walked band-major: consecutive workgroups take list chunk j of superblocks 0, 1, 2, ... -- the
         // users of chunk j of every superblock's (roughly ascending) list lie in one band of ~512 / (kept fraction) users, so
         // the 128 KB of gathered user rows of the workgroups running together come from L2 instead of 256-byte random reads
@@ -643,7 +643,8 @@ int launch_bf16x16(ScoreParams p, hipStream_t st)
     }
     if (GRP && p.capacity > 0) p.capacity = p.capacity * 512 / RW;           // the caller counts a superblock's list in 512-row units
     p.n_rblocks = GRP ? (int)(p.n_r / RW) : (int)ceil_div64(p.n_r, RW);
-    const unsigned blocks = GRP ? (unsigned)p.n_rblocks : (unsigned)p.n_rblocks * (unsigned)p.n_chunks;
+    const unsigned blocks = GRP ? (p.wg_map ? (unsigned)p.n_wgs : (unsigned)p.n_rblocks) : (unsigned)p.n_rblocks * (unsigned)p.n_chunks;
+    if (blocks == 0) return TREC_OK;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), LDS, st, p);
     return trec_check_launch(GRP ? "trec_score_gemm_blockmax_grouped (16x16x32)" : "trec_score_gemm_blockmax (16x16x32)");
 }

@@ -561,10 +561,12 @@ extern "C" int trec_score_gemm_refine_candidates(const void* users_bf16, const v
                                                  int32_t sb_rows, const int32_t* row_count, const int32_t* row_user,
                                                  float* blockmax, int64_t bm_stride, int32_t wgs_per_row,
                                                  const float* cand_floor, int32_t* cand_n, void* cand, int32_t cand_cap,
-                                                 int32_t item_index_base, void* stream)
+                                                 int32_t item_index_base, const int32_t* wg_map, int32_t n_wgs, void* stream)
 {
     TREC_REQUIRE(users_bf16 && items_bf16 && row_count && row_user && blockmax && cand_floor && cand_n && cand,
                  "trec_score_gemm_refine_candidates: null pointer");
+    TREC_REQUIRE(n_wgs >= 0 && (wg_map || n_wgs == 0), "trec_score_gemm_refine_candidates: n_wgs without wg_map");
+    if (wg_map && n_wgs == 0) return TREC_OK;
     TREC_REQUIRE(wgs_per_row > 0 && cand_cap >= 1, "trec_score_gemm_refine_candidates: needs the fixed-capacity layout (wgs_per_row > 0)");
     TREC_REQUIRE(kpad == 64 || kpad == 128, "trec_score_gemm_refine_candidates: kpad must be 64 or 128");
     TREC_REQUIRE(n_rows_g % GROUP_ROWS == 0 && n_rows_g < ((int64_t)1 << 40), "trec_score_gemm_refine_candidates: n_rows_g % 512 != 0");
@@ -580,6 +582,7 @@ extern "C" int trec_score_gemm_refine_candidates(const void* users_bf16, const v
     p.rblock_chunk = row_count; p.row_index = row_user; p.capacity = wgs_per_row;
     p.cand_floor = cand_floor; p.cand_n = cand_n; p.cand = (int2*)cand; p.cand_cap = cand_cap; p.t_index_base = item_index_base;
     p.cand_diag = trec_get_tuning("cascade_cand_diag", 0);
+    p.wg_map = wg_map; p.n_wgs = n_wgs;
     return launch_blockmax_pipelined_grouped(p, kpad, (hipStream_t)stream);
 }
 
@@ -618,4 +621,62 @@ extern "C" int trec_topk_dense_users(const float* table, int32_t n_sb, int64_t n
     hipLaunchKernelGGL(dense_users_kernel, dim3((unsigned)ceil_div64(n_users, 1024)), dim3(256), 0, (hipStream_t)stream, table, n_sb,
                        n_users, stride, thr, user_err, sb_stats, kdim, limit, cand_floor, flag, n_flagged);
     return trec_check_launch("trec_topk_dense_users");
+}
+
+// ---- only the workgroups that hold rows -----------------------------------------------------------------------------------
+// The fixed-capacity layout gives every superblock wgs_per_row workgroup slots (50 % of the users: 981 at 1M) of which ~50
+// hold rows; launched as a full [n_sb][wgs_per_row] grid, 1.8M of 1.9M workgroups start -- with their 79 KB of LDS and 256
+// VGPRs allotted -- only to exit.  trec_topk_rows_wg_map lists the occupied slots: wg_start [n_sb + 1] = exclusive prefix of
+// min(ceil(row_count / 512), wgs_per_row), wg_map[wg_start[s] + j] = s * wgs_per_row + j.  The host knows the total from the
+// status of trec_topk_rows_hot ((rows - hot rows * padded users) / 512) and launches exactly that many.
+namespace {
+__global__ __launch_bounds__(256) void wg_start_kernel(const int32_t* __restrict__ row_count, int32_t n_sb, int32_t wgs_per_row,
+                                                      int32_t* __restrict__ wg_start)
+{
+    __shared__ int wsum[4];
+    __shared__ int base_s;
+    if (threadIdx.x == 0) base_s = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int s0 = 0; s0 < n_sb; s0 += 256) {
+        const int s = s0 + threadIdx.x;
+        int c = s < n_sb ? (row_count[s] + GROUP_ROWS - 1) / GROUP_ROWS : 0;
+        if (c > wgs_per_row) c = wgs_per_row;
+        int inc = c;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += t;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int excl = base_s + inc - c;
+        for (int w = 0; w < wave; ++w) excl += wsum[w];
+        if (s < n_sb) wg_start[s] = excl;
+        __syncthreads();
+        if (threadIdx.x == 0) base_s += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) wg_start[n_sb] = base_s;
+}
+
+__global__ __launch_bounds__(256) void wg_map_kernel(const int32_t* __restrict__ wg_start, int32_t wgs_per_row, int64_t map_cap,
+                                                    int32_t* __restrict__ wg_map)
+{
+    const int s = blockIdx.x;
+    const int b = wg_start[s], e = wg_start[s + 1];
+    for (int j = threadIdx.x; j < e - b; j += 256)
+        if ((int64_t)b + j < map_cap) wg_map[b + j] = s * wgs_per_row + j;
+}
+}  // namespace
+
+extern "C" int trec_topk_rows_wg_map(const int32_t* row_count, int32_t n_sb, int32_t wgs_per_row, int32_t* wg_start,
+                                     int32_t* wg_map, int64_t map_cap, void* stream)
+{
+    TREC_REQUIRE(row_count && wg_start && wg_map, "trec_topk_rows_wg_map: null pointer");
+    TREC_REQUIRE(n_sb >= 1 && wgs_per_row >= 1 && map_cap >= 0 && (int64_t)n_sb * wgs_per_row < ((int64_t)1 << 31),
+                 "trec_topk_rows_wg_map: bad sizes");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(wg_start_kernel, dim3(1), dim3(256), 0, st, row_count, n_sb, wgs_per_row, wg_start);
+    hipLaunchKernelGGL(wg_map_kernel, dim3((unsigned)n_sb), dim3(256), 0, st, wg_start, wgs_per_row, map_cap, wg_map);
+    return trec_check_launch("trec_topk_rows_wg_map");
 }

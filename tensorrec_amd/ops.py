@@ -1258,16 +1258,13 @@ def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, 
         hot_list = torch.empty((hot_cap,), dtype=torch.int32, device=dev)
         max_pairs = int(N.load().trec_get_tuning(b"cascade_max_refined_pct", int(100 * CASCADE_MAX_REFINED)) / 100.0 * n_sb * n_u)
         N.call("trec_topk_rows_hot", N.ptr(row_count), n_sb, rcap, n_u, N.ptr(hot_list), hot_cap, max_pairs, N.ptr(status))
-        # the overflow flag is read HERE, before the bf16 launches (ADVICE r2): when the int8 bound is too loose, refining
-        # close to half of all pairs and then running the filter's tail on the result would only be thrown away.  One host
-        # read per call (the following launches are queued within the launch latency); item shards agree on it (MAX).
-        rows, overflow, n_hot = status.tolist()
-        if stats_exchange is not None:
-            overflow = float(stats_exchange(torch.tensor([float(overflow)], device=dev)).item())
-        if overflow:
-            return None, stride, (int(rows), True), tau, None
-        n_hot = min(int(n_hot), hot_cap)                # the hot launch's grid: nothing is launched when no superblock is hot
+        # Everything that does not need the host's decision is queued BEFORE the host reads the status -- behind the int8 launch,
+        # while it still runs: the provisional floors, the users the int8 bound says nothing about, the zeroed counters, the map of
+        # the occupied workgroup slots.  After the read only the refining launches and the finish remain: on a host that is slow
+        # to launch (a box in its first minute: ~0.4 ms per launch measured, against ~10 us later) the step used to wait for ten
+        # launches there.
         cands = None
+        wg_map, wg_cap = None, 0
         if cascade_lists_candidates() and gstats_all is not None and sb_rows <= 65536:
             # the refining launches also list every item that can still reach the top-k: provisional floor = the
             # k-th largest int8 lower bound less ONE eps of the bf16 filter; users without a usable bound are flagged and skipped
@@ -1283,17 +1280,37 @@ def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, 
                 cands.floor0.masked_fill_(uop.pad, float("inf"))
             if n_sb >= 32:                              # users the int8 bound says nothing about are flagged now, not listed for
                 N.call("trec_topk_dense_users", N.ptr(table), n_sb, n_u, stride, N.ptr(tau), N.ptr(user_err), N.ptr(iop.sb_stats),
-                       kpad, CASCADE_DENSE_USER_LIMIT, N.ptr(cands.floor0), N.ptr(cands.flag), N.ptr(cands.n_flagged))
+                       kpad, CASCADE_DENSE_USER_LIMIT if n_i >= CASCADE_MIN_ITEMS else 30, N.ptr(cands.floor0), N.ptr(cands.flag),
+                       N.ptr(cands.n_flagged))             # (small catalogues: the k-th largest of few maxima keeps half the rows of anybody)
             cands.n = torch.zeros((n_u,), dtype=torch.int32, device=dev)
             cands.items = torch.empty((n_u, cands.cap, 2), dtype=torch.int32, device=dev)     # only the listed part is touched
+            if N.load().trec_get_tuning(b"cascade_wg_map", 1) != 0:
+                # only the workgroup slots that hold rows are launched (98k of the 1.9M of the [n_sb][rcap / 512] grid at 1M x 1M)
+                wg_cap = min(n_sb * (rcap // 512), max_pairs // 512 + n_sb + 1)
+                wg_start = torch.empty((n_sb + 1,), dtype=torch.int32, device=dev)
+                wg_map = torch.empty((wg_cap,), dtype=torch.int32, device=dev)
+                N.call("trec_topk_rows_wg_map", N.ptr(row_count), n_sb, rcap // 512, N.ptr(wg_start), N.ptr(wg_map), wg_cap)
+        # the overflow flag is read HERE, before the bf16 launches (ADVICE r2): when the int8 bound is too loose, refining
+        # close to half of all pairs and then running the filter's tail on the result would only be thrown away.  One host
+        # read per call; item shards agree on it (MAX).
+        rows, overflow, n_hot = status.tolist()
+        if stats_exchange is not None:
+            overflow = float(stats_exchange(torch.tensor([float(overflow)], device=dev)).item())
+        if overflow:
+            return None, stride, (int(rows), True), tau, None
+        n_hot = min(int(n_hot), hot_cap)                # the hot launch's grid: nothing is launched when no superblock is hot
+        n_wgs = 0
+        if wg_map is not None:
+            n_wgs = min(wg_cap, (int(rows) - n_hot * ((n_u + 511) // 512 * 512)) // 512)
         # (user batches in a pipeline: from here on the launches go to the tail stream, next to the following batch's int8 stage)
-        tail = _tail_of(tail_stream if cands is not None else None, table, row_count, row_user, hot_list,
+        tail = _tail_of(tail_stream if cands is not None else None, table, row_count, row_user, hot_list, wg_map,
                         *((cands.floor0, cands.n, cands.items) if cands is not None else ()))
         with tail, _timed("score_gemm_blockmax_grouped"):
             if cands is not None:
                 N.call("trec_score_gemm_refine_candidates", N.ptr(uop.bf16), N.ptr(iop.bf16), kpad, n_sb * rcap, n_i,
                        N.ptr(user_bias), N.ptr(item_bias), sb_rows, N.ptr(row_count), N.ptr(row_user), N.ptr(table), stride,
-                       rcap // 512, N.ptr(cands.floor0), N.ptr(cands.n), N.ptr(cands.items), cands.cap, int(item_index_base))
+                       rcap // 512, N.ptr(cands.floor0), N.ptr(cands.n), N.ptr(cands.items), cands.cap, int(item_index_base),
+                       N.ptr(wg_map), n_wgs)
             else:
                 N.call("trec_score_gemm_blockmax_grouped", N.ptr(uop.bf16), N.ptr(iop.bf16), kpad, n_sb * rcap, n_i,
                        N.ptr(user_bias), N.ptr(item_bias), sb_rows, N.ptr(row_count), N.ptr(row_user), N.ptr(table), stride,
@@ -1617,11 +1634,12 @@ def _score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index
         def complete(cands=cands, blockmax=blockmax):
             if FILTER_DEBUG is not None:
                 _debug_counts("candidates", cands.n)
-            n_bad = int(n_flagged.item())
+            # ONE host read: the flagged-user counter and the number of listed candidates (queued behind the finish kernel)
+            n_bad, n_listed = torch.stack((n_flagged[0].to(torch.int64), cands.n.clamp(max=cands.cap).sum())).tolist()
             LAST_FILTER_STATS.clear()
             LAST_FILTER_STATS.update({"prefilter": "int8", "refined_rows": cascade_rows, "users": n_u, "flagged_users": n_bad,
                                       "tail": "candidate lists", "candidates_cap": cands.cap,
-                                      "candidates_per_user": float(cands.n.clamp(max=cands.cap).sum().item()) / max(1, n_u)})
+                                      "candidates_per_user": float(n_listed) / max(1, n_u)})
             return _redo_flagged(uop, iop, blockmax, flag, n_bad, n_sb, k, user_bias, item_bias, item_index_base, sb_rows,
                                  variant, None, rows_wg, ksel, gstats, ov, oi)
         cands = blockmax = None
