@@ -5,7 +5,7 @@
 set +e
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; OUT=gpurun_out; mkdir -p $OUT
 if [ "$TESTS" = "1" ]; then timeout 1500 python -m pytest tests/test_gpu_cascade.py tests/test_gpu_filter.py tests/test_gpu_fuzz_kinds.py tests/test_gpu_dp_fit.py tests/test_gpu_candidates.py -q 2>&1 | tail -4; fi
-ARGS="--configs headline --no-fit --no-cpu-baseline --no-k1-multi --no-fp32-mode --parity-users 64 --steps 5 --warmup 2"
+ARGS="--prewarm-seconds 0 --configs headline --no-fit --no-cpu-baseline --no-k1-multi --no-fp32-mode --parity-users 64 --steps 5 --warmup 2"
 if [ "$WARM" != "0" ]; then timeout 600 python bench.py $ARGS > /dev/null 2>&1; fi
 for T in "$@"; do
 ( timeout 600 python bench.py $ARGS --tune $T > $OUT/bench_ab.json 2> $OUT/bench_ab.err ); tail -1 $OUT/bench_ab.err | grep -v amdgpu.ids

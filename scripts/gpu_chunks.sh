@@ -3,7 +3,7 @@
 set +e
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; OUT=gpurun_out; mkdir -p $OUT
 for C in "$@"; do
-( timeout 600 python bench.py --configs headline --no-fit --no-cpu-baseline --no-k1-multi --no-fp32-mode --parity-users 64 --steps 5 --warmup 2 --chunks $C > $OUT/bench_ab.json 2> $OUT/bench_ab.err ); tail -1 $OUT/bench_ab.err | grep -v amdgpu.ids
+( timeout 600 python bench.py --prewarm-seconds 0 --configs headline --no-fit --no-cpu-baseline --no-k1-multi --no-fp32-mode --parity-users 64 --steps 5 --warmup 2 --chunks $C > $OUT/bench_ab.json 2> $OUT/bench_ab.err ); tail -1 $OUT/bench_ab.err | grep -v amdgpu.ids
 python - <<PY
 import json
 d=json.loads(open('gpurun_out/bench_ab.json').read().strip().splitlines()[-1])

@@ -4,11 +4,11 @@ set +e
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; REPO=$PWD; OUT=$REPO/gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp
 TAG=${1:-r01}
 timeout 900 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err; echo "bench rc=$?"; cat $OUT/${TAG}_bench.json
-( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o $TAG -- python $REPO/bench.py --configs headline --no-cpu-baseline --no-fit > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/${TAG}_prof.err ); echo "rocprof rc=$?"
+( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o $TAG -- python $REPO/bench.py --configs headline --no-cpu-baseline --no-fit --prewarm-seconds 0 > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/${TAG}_prof.err ); echo "rocprof rc=$?"
 f=$(find $OUT/${TAG}_prof -name "*kernel_stats.csv" | head -1); cp $f $OUT/${TAG}_kernel_stats.csv 2>/dev/null; head -12 $OUT/${TAG}_kernel_stats.csv | cut -c1-200
 for s in "FETCH_SIZE" "WRITE_SIZE TCC_HIT TCC_MISS" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES"; do
   n=$(echo $s | cut -d' ' -f1)
-  ( cd /tmp && timeout 900 rocprofv3 --pmc $s --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_$n -o pmc -- python $REPO/bench.py --configs headline --steps 1 --warmup 0 --no-cpu-baseline --no-fit --no-fp32-mode --no-k1-multi --parity-users 64 > /dev/null 2> $OUT/${TAG}_pmc_$n.err ); echo "pmc $n rc=$?"
+  ( cd /tmp && timeout 900 rocprofv3 --pmc $s --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_$n -o pmc -- python $REPO/bench.py --configs headline --steps 1 --warmup 0 --prewarm-seconds 0 --no-cpu-baseline --no-fit --no-fp32-mode --no-k1-multi --parity-users 64 > /dev/null 2> $OUT/${TAG}_pmc_$n.err ); echo "pmc $n rc=$?"
 done
 python - <<PY
 import csv, glob, collections

@@ -14,10 +14,10 @@ bash scripts/gpu_r3_m.sh 2>&1 | tail -4
 cp $OUT/rank_sim.json $OUT/r03_rank_sim_n8.json; cp $OUT/bench_2rank_gloo.json $OUT/r03_bench_2rank_gloo_one_gpu.json
 bash scripts/gpu_profile.sh r03 > $OUT/profile.log 2>&1; grep -E "rc=" $OUT/profile.log
 if [ "$BF16DENSE" = "1" ]; then
-BARGS="bench.py --configs headline --prefilter none --no-fit --no-cpu-baseline --no-fp32-mode --no-k1-multi --steps 3 --warmup 1 --parity-users 64"
+BARGS="bench.py --configs headline --prefilter none --no-fit --no-cpu-baseline --no-fp32-mode --no-k1-multi --steps 3 --warmup 1 --prewarm-seconds 0 --parity-users 64"
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/r03_bf16dense_prof -o r03 -- python $REPO/$BARGS > $OUT/r03_bf16dense_bench_under_rocprof.json 2> $OUT/r03_bf16dense_prof.err ); echo "bf16 dense rocprof rc=$?"
 f=$(find $OUT/r03_bf16dense_prof -name "*kernel_stats.csv" | head -1); cp $f $OUT/r03_bf16dense_kernel_stats.csv 2>/dev/null
-bash scripts/gpu_pmc_cmd.sh "bench.py --configs headline --prefilter none --no-fit --no-cpu-baseline --no-fp32-mode --no-k1-multi --steps 1 --warmup 0 --parity-users 64" r03_bf16dense_pmc_summary "blockmax_bf16x16|blockmax_pipe" s1 s3 s4 | tail -4 | cut -c1-300
+bash scripts/gpu_pmc_cmd.sh "bench.py --configs headline --prefilter none --no-fit --no-cpu-baseline --no-fp32-mode --no-k1-multi --steps 1 --warmup 0 --prewarm-seconds 0 --parity-users 64" r03_bf16dense_pmc_summary "blockmax_bf16x16|blockmax_pipe" s1 s3 s4 | tail -4 | cut -c1-300
 fi
 # the tail behind the int8 stage: candidate lists (default) against the table-driven tail, and the two-stream user batches
 WARM=0 bash scripts/gpu_ab.sh cascade_candidates=1 cascade_candidates=0 cascade_candidates=1 cascade_candidates=0 cascade_user_batches=4 2>&1 | tee $OUT/r03_ab_tail.txt | cut -c1-60

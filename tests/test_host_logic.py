@@ -247,3 +247,25 @@ def test_cascade_host_helpers():
         assert ops.cascade_prefilter_for(128, 1_000_000) is None
     finally:
         _native.set_tuning("topk_int8_prefilter", 1)
+
+
+def test_cascade_user_batches_is_off_by_default_and_only_for_the_single_process_int8_path():
+    """ops.cascade_user_batches (the two-stream pipeline of DESIGN 5e: measured slower, a knob): 1 unless asked for, and never
+    for item shards, operands in the caller's order, or catalogues the cascade gave up on."""
+    from tensorrec_amd import ops, _native
+    u, i = ops.FilterOperand(), ops.FilterOperand()
+    u.n, u.kpad, u.wg_rows = 1_002_240, 128, 768
+    assert ops.cascade_user_batches(u, i, "int8", None, None) == 1
+    _native.set_tuning("cascade_user_batches", 4)
+    try:
+        assert ops.cascade_user_batches(u, i, "int8", None, None) == 4
+        assert ops.cascade_user_batches(u, i, None, None, None) == 1
+        assert ops.cascade_user_batches(u, i, "int8", lambda x: x, None) == 1          # item shards: every rank in lockstep
+        u.n = 300_000
+        assert ops.cascade_user_batches(u, i, "int8", None, None) == 2                  # at least 131,072 rows per batch
+        u.wg_rows = None
+        assert ops.cascade_user_batches(u, i, "int8", None, None) == 1                  # users in the caller's order
+        u.wg_rows, i.cascade_too_loose = 768, True
+        assert ops.cascade_user_batches(u, i, "int8", None, None) == 1
+    finally:
+        _native.set_tuning("cascade_user_batches", 1)
