@@ -1201,11 +1201,13 @@ def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, 
                     item_index_base=0, tail_stream=None):
     """Stages 0-1 of the int8 -> bf16 -> fp32 cascade (csrc/topk_cascade.hip): the [n_sb, n_users] table of superblock
     maxima whose entries are bf16 maxima wherever a top-k item can be and int8 maxima elsewhere (None after an overflow), its
-    row stride, and (resident rows of the bf16 launches, overflow).  Every superblock has a list of CASCADE_ROW_CAPACITY of the
-    users (workgroups beyond the kept pairs exit at once); rows kept by more are "hot" and re-scored for everybody by a dense
-    launch.  When the int8 bound is too loose for the data -- more than CASCADE_MAX_REFINED of all pairs wanted -- nothing is
-    refined and the caller runs the dense bf16 stage 1 instead: the ONE host read of the call (two int64) happens right
-    after the compaction, before any bf16 launch."""
+    row stride, (resident rows of the bf16 launches, overflow), the k-th largest int8 lower bounds, and -- the default, DESIGN
+    5e -- the candidate lists the refining launches made (else None).  Every superblock has a list of CASCADE_ROW_CAPACITY of
+    the users (only the workgroup slots that hold rows are launched); rows kept by more are "hot" and re-scored for everybody
+    by a dense launch.  When the int8 bound is too loose for the data -- more than CASCADE_MAX_REFINED of all pairs wanted --
+    nothing is refined and the caller runs the dense bf16 stage 1 instead: the ONE host read of the call (three int64: rows,
+    overflow, hot rows) happens right after the compaction, before any bf16 launch.  ``tail_stream``: the refining launches
+    go there (ops._score_topk_filtered_pipelined)."""
     dev = uop.bf16.device
     n_u, n_i, kpad = uop.n, iop.n, uop.kpad
     kk = int(k)
