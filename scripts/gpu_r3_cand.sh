@@ -1,5 +1,6 @@
 #!/bin/bash
-# candidate-list tail: diagnostics of the refining launch (tuning cascade_cand_diag) and a kernel trace of one configuration
+# candidate-list tail: diagnostics of the refining launch (tuning cascade_cand_diag; needs a library built with
+# FLAGS_score_blockmax="-fno-honor-nans -DTREC_CAND_DIAG") and a kernel trace of one configuration
 set +e
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; OUT=gpurun_out; mkdir -p $OUT
 timeout 600 python -m pytest tests/test_gpu_candidates.py tests/test_gpu_cascade.py -x -q 2>&1 | tail -4

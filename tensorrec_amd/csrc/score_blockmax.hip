@@ -519,12 +519,19 @@ __global__ __launch_bounds__(256, NUB == 8 ? 2 : 3) void blockmax_bf16x16_kernel
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            if (slot[e] < p.cand_cap && p.cand_diag != 2)
+#ifdef TREC_CAND_DIAG
+            if (p.cand_diag == 2) continue;
+#endif
+            if (slot[e] < p.cand_cap)
                 p.cand[(int64_t)uid * p.cand_cap + slot[e]] = make_int2((int32_t)(item0 + e) + p.t_index_base, __float_as_int(v[e]));
     };
     auto queue_flush = [&](auto unrc) __attribute__((always_inline)) {
         constexpr int UNR = decltype(unrc)::value;              // entries per lane and round (their atomics are in flight together)
+#ifdef TREC_CAND_DIAG                                          // diagnostics build only (the cost of the parts: DESIGN 5e)
         const int n = p.cand_diag == 1 ? 0 : qn;
+#else
+        const int n = qn;
+#endif
 #pragma unroll 1
         for (int i0 = 0; i0 < n; i0 += 64 * UNR) {
 #pragma unroll
