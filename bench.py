@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--prewarm-seconds", type=float, default=12.0,
+    ap.add_argument("--prewarm-seconds", type=float, default=0.0,
                     help="untimed steps run for about this long BEFORE the warmup steps (0 = none): the first GPU process on a fresh "
                          "box launches kernels ~40x slower for its first half minute (measured: 105.9 -> 101.7 -> 95.2 ms per step in "
                          "three consecutive processes), which says nothing about the steady state the metric is quoted for")
@@ -353,7 +353,8 @@ def main():
                 ib = None if args.unbiased else ops.sparse_matvec(f_i, beta_i)
                 if exact and method == "two_stage":
                     # fp32-exact top-k: bf16 MFMA stage 1 as an error-bounded filter, survivors re-scored in fp32
-                    u_f = ops.score_prep_filter(user_repr, sort_users=prefilter == "int8", k=k)     # users sorted by int8 scale class
+                    # the user side in five launches, no host read: class sort + fp32 / bf16 / int8 operands + bias (csrc/user_prep.hip)
+                    u_f = ops.score_prep_filter(user_repr, sort_users=prefilter == "int8", k=k, user_bias=ub)
                     i_f = ops.score_prep_filter(item_repr, bias=ib, want_gstats=True)
                     vals, idx = ops.score_topk_filtered(
                         u_f, i_f, k, ub, ib, item_index_base=i_begin, variant=args.variant,
@@ -400,16 +401,25 @@ def main():
         step()
     ops.KERNEL_EVENTS = []
     sync()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]     # step boundaries on the stream (no sync)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i_ in range(args.steps):
         out = step()
+        marks[i_ + 1].record()
     sync()
     elapsed = time.perf_counter() - t0
+    step_ms = [marks[i_].elapsed_time(marks[i_ + 1]) for i_ in range(args.steps)]
     events, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
     elapsed = sharding.max_over_ranks(elapsed, device)
     ms_per_step = 1000.0 * elapsed / args.steps
     value = float(U) * float(I) / (elapsed / args.steps)
 
+    if exact and prefilter == "int8":
+        ops.CANDIDATE_STATS = True                   # one untimed step with the list statistics on (a reduction + a host read)
+        out = step()
+        ops.CANDIDATE_STATS = False
+        torch.cuda.synchronize()
     if world > 1:
         # parity sample needs every rank's item rows: one untimed all-gather (shards are padded to equal length)
         vals, idx, user_repr, item_repr_local = out
@@ -700,6 +710,48 @@ def main():
         except Exception:
             pass
 
+    # ---- the PUBLIC API on the same weights: TensorRec.predict_top_k itself (features given as scipy matrices, uploaded once
+    # and recognised by content afterwards; representations, user-side preparation, cascade; lists returned on the device), with
+    # its default user batch -- the documented drop-in call next to the ops-level step that is timed above
+    public_api = None
+    if exact and world == 1 and not args.no_fp32_mode:
+        try:
+            vals, idx, user_repr, item_repr = out
+            model = T.TensorRec(n_components=d, biased=not args.unbiased, seed=0)
+            model.build(U, I)
+            with torch.no_grad():
+                model._store.variables["linear_weights_user_0"].copy_(w_u)
+                model._store.variables["linear_weights_item"].copy_(w_i)
+                if not args.unbiased:
+                    model._store.variables["user_feature_biases"].copy_(beta_u)
+                    model._store.variables["item_feature_biases"].copy_(beta_i)
+            uf_sp = sp.identity(U, dtype=np.float32, format="csr")
+            if_sp = sp.identity(I, dtype=np.float32, format="csr")
+            model.predict_top_k(uf_sp, if_sp, k=k, return_device=True)            # first call: uploads, allocations
+            torch.cuda.synchronize()
+            reps, times = 3, []
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                pv, pi_ = model.predict_top_k(uf_sp, if_sp, k=k, return_device=True)
+                torch.cuda.synchronize()
+                times.append(1e3 * (time.perf_counter() - t0))
+            t0 = time.perf_counter()
+            hv, hi_ = model.predict_top_k(uf_sp, if_sp, k=k)                      # ... and with the lists copied to the host
+            host_ms = 1e3 * (time.perf_counter() - t0)
+            public_api = {"call": "TensorRec.predict_top_k(user_features, item_features, k=%d, return_device=True), default "
+                                  "user_batch_size (= %d users per pass from the free device memory)"
+                                  % (k, ops.topk_user_batch(U, I, d, device)),
+                          "ms_per_call": times, "ms_per_call_min": min(times),
+                          "predictions_per_s": float(U) * float(I) / (min(times) * 1e-3),
+                          "ratio_to_timed_step": min(times) / ms_per_step,
+                          "ms_per_call_with_host_copy_of_the_lists": host_ms,
+                          "equals_timed_step_output": bool(torch.equal(pi_, idx) and torch.equal(pv, vals)),
+                          "filter": dict(ops.LAST_FILTER_STATS)}
+            del model, pv, pi_, hv, hi_
+            torch.cuda.empty_cache()
+        except Exception as exc:
+            public_api = {"error": repr(exc)}
+
     # ---- further driver-visible records (rank 0, one GPU): fitted weights, fit parity, multi-nnz parity, the other configs
     trained = parity_fit = parity_multi = configs = None
     oracle_small_shard_s = None
@@ -737,7 +789,9 @@ def main():
     line = {
         "metric": "user-item predictions/sec", "value": value, "unit": "predictions/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "prewarm_steps": prewarm_steps + (2 if args.prewarm_seconds > 0 else 0),
-        "ms_per_step": ms_per_step, "higher_is_better": True,
+        "ms_per_step": ms_per_step, "step_ms_by_hip_events": {"first": step_ms[0], "last": step_ms[-1], "min": min(step_ms),
+                                                              "max": max(step_ms), "all": step_ms},
+        "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None,
         # arithmetic type of the dominant (MFMA) kernel
         # (the cascade computes in all three: int8 MFMA over every pair, bf16 MFMA over the ~4% it cannot rule out, fp32
@@ -759,8 +813,32 @@ def main():
                    "score_kernel_variant": "global_load_lds" if args.variant & 1 else "register-staged"},
         "roofline": roofline, "roofline_bf16_stage": roofline_bf16_stage, "roofline_k1": roofline_k1, "roofline_k1_multi_nnz": roofline_k1_multi, "cpu_baseline": cpu, "parity": parity,
         "fp32_mfma_mode": fp32_mode, "bf16_filter_mode": bf16_mode, "roofline_bf16_dense": roofline_bf16_dense,
-        "trained_weights_mode": trained, "parity_fit": parity_fit, "parity_multi_nnz": parity_multi, "configs": configs, "fit": fit,
+        "public_api_mode": public_api, "trained_weights_mode": trained, "parity_fit": parity_fit, "parity_multi_nnz": parity_multi, "configs": configs, "fit": fit,
         "roofline_fit": (fit or {}).get("roofline_fit"), "cpu_baseline_fit": cpu_fit,
+    }
+    # the verdicts of the records above in one compact object INSIDE config (the driver's stored record keeps config whole and
+    # only the names of the other keys)
+    def _get(obj, *path):
+        for key in path:
+            if not isinstance(obj, dict) or key not in obj:
+                return None
+            obj = obj[key]
+        return obj
+    line["config"]["checks"] = {
+        "parity_users": _get(parity, "sample_users"), "topk_ids_bit_exact": _get(parity, "topk_ids_bit_exact_vs_oracle"),
+        "topk_values_bit_exact": _get(parity, "topk_values_bit_exact_vs_oracle"),
+        "fp32_mfma_equals_all_users": _get(fp32_mode, "equals_timed_exact_mode_output_all_%d_users" % U),
+        "fp32_mfma_frac_of_peak": _get(fp32_mode, "frac_of_fp32_mfma_peak"),
+        "bf16_filter_equals_cascade": _get(bf16_mode, "equals_timed_cascade_output"),
+        "bf16_dense_frac_of_peak": _get(roofline_bf16_dense, "frac"),
+        "public_api_ms": _get(public_api, "ms_per_call_min"), "public_api_equals_step": _get(public_api, "equals_timed_step_output"),
+        "trained_ms": _get(trained, "ms_per_step"), "trained_bit_exact": _get(trained, "parity", "topk_ids_bit_exact_vs_oracle"),
+        "parity_fit_green": _get(parity_fit, "green"), "parity_multi_nnz_ids": _get(parity_multi, "topk_ids_bit_exact_vs_oracle"),
+        "fit_epochs_per_s": _get(fit, "fit_epochs_per_sec"), "fit_kernel_frac_of_hbm": _get(fit, "roofline_fit", "frac"),
+        "step_ms_first_last": [step_ms[0], step_ms[-1]], "prewarm_steps": line["prewarm_steps"],
+        "cfg": {name: [v for v in (_get(rec, "green"), _get(rec, "parity_one_step_vs_oracle", "green"),
+                                   _get(rec, "parity", "topk_ids_bit_exact_vs_oracle")) if v is not None]
+                for name, rec in (configs or {}).items()} if isinstance(configs, dict) else None,
     }
     print(json.dumps(line))
     if world > 1:

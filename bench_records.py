@@ -220,7 +220,7 @@ def parity_multi_nnz_record(device, item_repr, item_bias_dev, d, k, n_users=1024
     with torch.no_grad():
         ur = ops.spmm_raw(f.indptr, f.indices, f.values, None, n_users, f.nnz, w)
         ub = ops.sparse_matvec(f, b)
-        u_f = ops.score_prep_filter(ur, sort_users=True, k=k)
+        u_f = ops.score_prep_filter(ur, sort_users=True, k=k, user_bias=ub)
         i_f = ops.score_prep_filter(item_repr, bias=item_bias_dev, want_gstats=True)
         vals, idx = ops.score_topk_filtered(u_f, i_f, k, ub, item_bias_dev, prefilter=ops.cascade_prefilter_for(d, item_repr.shape[0]))
     rec = oracle_topk_parity(O, O.spmm_exact(m, w_h), item_repr.cpu().numpy(), O.spmm_exact(m, b_h).reshape(-1),

@@ -272,7 +272,25 @@ int trec_score_gemm_blockmax_i8(const void* users_q, const void* items_q, int32_
                                 const float* user_bias, const int32_t* item_bias_q, const float* scales,
                                 const float* sb_stats, int32_t sb_rows, int32_t n_chunks, float* blockmax,
                                 int64_t bm_stride, const float* user_err, float* chunk_top, int32_t top_k,
-                                const float* wg_scale, const int32_t* wg_class, void* stream);
+                                const float* wg_scale, const int32_t* wg_class, int32_t wg_rows, void* stream);
+/* The user side of the cascade, prepared on the device without a host read (csrc/user_prep.hip; replaces the user
+ * representation's way into tf.matmul of tensorrec/prediction_graphs.py:49-50, after the l2_normalize of :64-69 for cosine):
+ * scale class per row -> stable counting sort by class -> bands of two classes padded to whole int8 workgroups -> ONE gather pass
+ * that writes the fp32 / bf16 / int8 operands, both error norms and the user bias in layout order.  The layout has
+ * trec_user_prep_alloc_rows(n, wg_rows) rows -- a bound the host knows; int8 workgroups beyond the padded row count have
+ * wg_scale 0 and exit at once, layout rows without a source (src < 0) are zero and keep nothing (trec_topk_cascade_floor).
+ *   src [n_alloc] int32: caller's row of a layout row or -1; pos [n]: layout row of a caller's row; wg_scale / wg_class
+ *   [n_alloc / wg_rows]; ladder [64] = the classes' scales gmax 2^(-c/4); class_used [64]; gmax [1] zeroed by the caller;
+ *   meta int32[2] = {padded rows, n}; workspace of trec_user_prep_workspace_bytes(n) bytes; out_f32 / bias_sorted nullable.
+ * trec_fill_zero: nbytes of zeros on the stream (the counters / maxima a call starts from, as one block). */
+int64_t trec_user_prep_alloc_rows(int64_t n, int32_t wg_rows);
+int64_t trec_user_prep_workspace_bytes(int64_t n);
+int trec_user_prep_sorted(const float* repr, int64_t n, int32_t d, int32_t kpad, int32_t normalize, const float* user_bias,
+                          int32_t wg_rows, int64_t n_alloc, void* workspace, int64_t workspace_bytes, int32_t* src,
+                          int32_t* pos, float* wg_scale, int32_t* wg_class, float* ladder, int32_t* class_used, float* gmax,
+                          int32_t* meta, float* out_f32, void* out_bf16, float* row_stats, void* out_q, float* row_stats8,
+                          float* bias_sorted, void* stream);
+int trec_fill_zero(void* p, int64_t nbytes, void* stream);
 int32_t trec_topk_rows_user_blocks(int64_t n_users);
 int trec_topk_rows_count(const float* table, int32_t n_sb, int64_t n_users, int64_t stride, const float* thr,
                          const float* user_err, const float* sb_stats, int32_t kdim, int32_t* block_off,
@@ -339,7 +357,16 @@ int trec_topk_candidates_finish(const int32_t* cand_n, const void* cand, int32_t
                                 const float* user_stats, const float* item_gstats, const float* users_f32,
                                 const float* items_f32, int64_t ld_users, int64_t ld_items, int32_t kdim,
                                 const float* user_bias, const float* item_bias, int32_t item_index_base, int64_t n_users,
-                                int32_t k, float* out_vals, int32_t* out_idx, int32_t* flag, int32_t* n_flagged, void* stream);
+                                int32_t k, float* out_vals, int32_t* out_idx, int32_t* flag, int32_t* n_flagged,
+                                const int32_t* out_index, void* stream);
+/* The cascade's thresholds in one pass over the users, before trec_topk_rows_collect: tau [n_users] IN / OUT = the k-th largest
+ * int8 lower bound (+inf on return for layout rows without a source: src [n_users] nullable, trec_user_prep_sorted);
+ * floor0 = tau - eps rounded down twice (the provisional floor of the candidate lists; +inf and flag = 1 when the bound is
+ * unusable); n_flagged [1] zeroed by the caller; cand_n nullable [n_users], zeroed here.  out_index of
+ * trec_topk_candidates_finish (nullable): user u's lists go to row out_index[u], negative = no output. */
+int trec_topk_cascade_floor(float* tau, const int32_t* src, const float* user_stats, const float* user_bias,
+                            const float* item_gstats, int32_t kdim, int64_t n_users, float* floor0, int32_t* flag,
+                            int32_t* n_flagged, int32_t* cand_n, void* stream);
 int trec_topk_filter_floor(const float* tau, const float* user_stats, const float* user_bias, const float* item_gstats,
                            int32_t kdim, int64_t n_users, float* floor, int32_t* flag, int32_t* n_flagged, void* stream);
 int trec_topk_collect_blocks(const float* blockmax, int32_t n_sb, int64_t n_users, int64_t stride, const float* floor,

@@ -23,7 +23,7 @@ def floor_exchange(sel_max):            # [k, U] sorted desc per user: row 1 = 2
 def step():
     u = ops.spmm_raw(f_u.indptr, f_u.indices, f_u.values, None, U, f_u.nnz, w_u)
     v = ops.spmm_raw(f_i.indptr, f_i.indices, f_i.values, None, I, f_i.nnz, w_i)
-    u_f = ops.score_prep_filter(u, sort_users=True, k=k)          # users sorted by int8 scale class, as predict_top_k does
+    u_f = ops.score_prep_filter(u, sort_users=True, k=k, user_bias=ub)   # users sorted by int8 scale class, as predict_top_k does
     i_f = ops.score_prep_filter(v, bias=ib, want_gstats=True)
     vals, idx = ops.score_topk_filtered(u_f, i_f, k, ub, ib, item_index_base=0, floor_exchange=floor_exchange,
                                         stats_exchange=lambda s: s, prefilter=os.environ.get("PREFILTER", "int8") or None)

@@ -19,7 +19,8 @@ LIB_PATH = os.environ.get("TREC_HIP_LIB") or os.path.join(_HERE, "libtensorrec_h
 _vp, _i32, _i64, _u32, _u64, _f = (ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32,
                                    ctypes.c_uint64, ctypes.c_float)
 
-_RETURNS_I64 = ("trec_csr_split_workspace_bytes", "trec_rank_rows_workspace_bytes")      # sizing queries that return a byte count
+_RETURNS_I64 = ("trec_csr_split_workspace_bytes", "trec_rank_rows_workspace_bytes", "trec_user_prep_alloc_rows",
+                "trec_user_prep_workspace_bytes")      # sizing queries that return a byte count
 
 # name -> argtypes, in the order of include/tensorrec_hip.h
 SIGNATURES = {
@@ -64,7 +65,13 @@ SIGNATURES = {
     "trec_score_blockmax_i8_rows_per_workgroup": [_i32],
     "trec_score_user_err_i8": [_vp, _vp, _vp, _i32, _i64, _vp, _vp, _i32, _vp, _vp],
     "trec_score_gemm_blockmax_i8": [_vp, _vp, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp, _i32,
-                                    _vp, _vp, _vp],
+                                    _vp, _vp, _i32, _vp],
+    "trec_user_prep_alloc_rows": [_i64, _i32],
+    "trec_user_prep_workspace_bytes": [_i64],
+    "trec_user_prep_sorted": [_vp, _i64, _i32, _i32, _i32, _vp, _i32, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                              _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "trec_fill_zero": [_vp, _i64, _vp],
+    "trec_topk_cascade_floor": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp],
     "trec_topk_rows_user_blocks": [_i64],
     "trec_topk_rows_count": [_vp, _i32, _i64, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
     "trec_topk_rows_fill": [_vp, _i32, _i64, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp],
@@ -79,7 +86,7 @@ SIGNATURES = {
     "trec_score_gemm_refine_candidates_hot": [_vp, _vp, _i32, _i64, _i64, _vp, _vp, _i32, _vp, _i32, _vp, _i64, _vp, _vp, _vp,
                                               _i32, _i32, _vp],
     "trec_topk_candidates_finish": [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _i32, _i64, _i32, _vp,
-                                    _vp, _vp, _vp, _vp],
+                                    _vp, _vp, _vp, _vp, _vp],
     "trec_topk_filter_floor": [_vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp],
     "trec_topk_collect_blocks": [_vp, _i32, _i64, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
     "trec_topk_filter_floor_ex": [_vp, _vp, _vp, _vp, _i32, _i64, _f, _vp, _vp, _vp, _vp],

@@ -881,7 +881,9 @@ int launch_blockmax_pipelined_grouped(const ScoreParams& p, int kt, hipStream_t 
 {
     const bool bias = p.r_bias || p.t_bias;
     if (trec_get_tuning("blockmax_bf16_mfma16", 1) != 0) {       // the 16x16x32 form (filters only: see blockmax_bf16x16_kernel)
-        if (kt == 128 && p.capacity > 0 && trec_get_tuning("cascade_grouped_nub", 8) == 4)
+        // (the 64-users-per-wave A/B form has no LIST instance and decodes workgroup slots in its own units: it only serves the
+        // plain fixed-capacity launch -- with candidate lists or a workgroup map the knob is ignored)
+        if (kt == 128 && p.capacity > 0 && !p.cand && !p.wg_map && trec_get_tuning("cascade_grouped_nub", 8) == 4)
             return bias ? launch_bf16x16<128, true, true, 4>(p, st) : launch_bf16x16<128, false, true, 4>(p, st);
         if (p.cand) {                                             // the refining launch that also lists candidates (LIST)
             if (kt == 128) return bias ? launch_bf16x16<128, true, true, 8, false, true>(p, st) : launch_bf16x16<128, false, true, 8, false, true>(p, st);

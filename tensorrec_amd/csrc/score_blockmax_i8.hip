@@ -295,6 +295,9 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void blockmax_i8x16_kernel(ScorePa
     const int g = lane >> 4, lu = lane & 15;
     const int rblock = blockIdx.x % p.n_rblocks;
     const int chunk = blockIdx.x / p.n_rblocks;
+    // an idle workgroup (trec_user_prep_sorted sizes the user layout by a bound the host knows; the workgroups beyond the padded
+    // row count carry scale 0): nothing to compute, nothing written -- its users' thresholds are +inf
+    if (p.wg_scale && p.wg_scale[rblock] == 0.f) return;
     const int64_t r_base = ((int64_t)rblock * NW + wave) * (NUB * 16);
     const int64_t t_begin = (int64_t)chunk * p.chunk_len;
     const int64_t t_end = (t_begin + p.chunk_len < p.n_t) ? t_begin + p.chunk_len : p.n_t;
@@ -937,8 +940,13 @@ extern "C" int trec_score_gemm_blockmax_i8(const void* users_q, const void* item
                                            int64_t n_items, const float* user_bias, const int32_t* item_bias_q,
                                            const float* scales, const float* sb_stats, int32_t sb_rows, int32_t n_chunks,
                                            float* blockmax, int64_t bm_stride, const float* user_err, float* chunk_top,
-                                           int32_t top_k, const float* wg_scale, const int32_t* wg_class, void* stream)
+                                           int32_t top_k, const float* wg_scale, const int32_t* wg_class, int32_t wg_rows,
+                                           void* stream)
 {
+    // wg_rows (with wg_scale): the rows per workgroup the caller laid the users out for -- the scales and bias tables are
+    // indexed by workgroup, so a tuning changed between preparation and launch must fail loudly, not shift them
+    TREC_REQUIRE(!wg_scale || wg_rows == trec_score_blockmax_i8_rows_per_workgroup(top_k ? top_k : 10),
+                 "trec_score_gemm_blockmax_i8: the user operand was laid out for another workgroup height (tuning changed since the preparation?)");
     TREC_REQUIRE(users_q && items_q && (scales || wg_scale) && sb_stats && blockmax && bm_stride >= n_users, "trec_score_gemm_blockmax_i8: bad arguments");
     TREC_REQUIRE(!wg_class || wg_scale, "trec_score_gemm_blockmax_i8: wg_class comes with wg_scale");
     TREC_REQUIRE(kpad == 64 || kpad == 128, "trec_score_gemm_blockmax_i8: kpad must be 64 or 128");

@@ -38,16 +38,20 @@ constexpr int GROUP_ROWS = 512;   // resident rows per workgroup of the grouped 
 // bound table[s0 + r][u + e] + e8 reaches thr[u + e] (the k-th largest LOWER bound, two floats down).  e8 here is
 // nx A_s + ex B_s + a_u C_s + cu (C_s: the bias quantisation error per unit of user scale, sb_stats[s][3]) with the inflation of i8_pair_err folded into the per-row / per-user constants (rounded up):
 // it need not equal the int8 kernel's evaluation bit for bit, both only have to dominate the true error.
-struct UserConsts { float f[4], nx[4], ex[4], au[4]; };
+struct UserConsts { float f[4], nx[4], ex[4], au[4]; unsigned int valid; };
 
 __device__ __forceinline__ UserConsts load_user_consts(const float* __restrict__ thr, const float* __restrict__ user_err,
                                                        int64_t n_users, int64_t u)
 {
     const float infl = 1.0029296875f;                      // 1 + 3 * 2^-10 > (1 + 2^-9) (1 + 2^-12): covers the re-association
     UserConsts c;
+    c.valid = 0u;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const bool in = u + e < n_users;
+        // a threshold of +inf keeps nothing WHATEVER the table holds: rows without a source (band padding, the idle int8
+        // workgroups of trec_user_prep_sorted, whose table entries were never written) and users flagged before the compaction
+        const bool in = u + e < n_users && thr[u + e] < INFINITY;
+        if (in) c.valid |= 1u << e;
         f32x4 ue = {0.f, 0.f, 0.f, 0.f};
         if (in) ue = *(const f32x4*)(user_err + (u + e) * 4);              // {||x||, ||x - a q||, cu, a}
         c.nx[e] = ue[0];
@@ -85,7 +89,7 @@ __device__ __forceinline__ unsigned int tile_bits(const float* __restrict__ tabl
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            if (s < n_sb && u + e < n_users && !(__fmaf_rn(c.nx[e], A, __fmaf_rn(c.ex[e], B, __fmaf_rn(c.au[e], C, v[e]))) < c.f[e]))
+            if (s < n_sb && ((c.valid >> e) & 1u) && !(__fmaf_rn(c.nx[e], A, __fmaf_rn(c.ex[e], B, __fmaf_rn(c.au[e], C, v[e]))) < c.f[e]))
                 bits |= 1u << (4 * r + e);
     }
     return bits;

@@ -175,6 +175,37 @@ __global__ __launch_bounds__(256) void filter_floor_kernel(const float* __restri
     }
 }
 
+// The thresholds of the cascade's candidate lists in ONE pass over the users (trec_topk_cascade_floor): tau = the k-th largest int8
+// lower bound (trec_topk_select_blocks over the chunk lists).  Layout rows without a source (src[u] < 0: band padding, the tail of
+// the allocation) keep nothing: tau = floor0 = +inf, never flagged.  Everybody else: floor0 = tau - eps rounded down twice (the
+// PROVISIONAL floor of trec_score_gemm_refine_candidates), +inf and flagged when the bound is unusable; cand_n = 0.
+__global__ __launch_bounds__(256) void cascade_floor_kernel(float* __restrict__ tau, const int32_t* __restrict__ src,
+                                                           const float2* __restrict__ ustats, const float* __restrict__ user_bias,
+                                                           const float* __restrict__ gstats, int kdim, int64_t n_users,
+                                                           float* __restrict__ floor0, int32_t* __restrict__ flag,
+                                                           int32_t* __restrict__ n_flagged, int32_t* __restrict__ cand_n)
+{
+    const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (u >= n_users) return;
+    if (cand_n) cand_n[u] = 0;
+    if (src && src[u] < 0) {
+        tau[u] = INFINITY;
+        floor0[u] = INFINITY;
+        flag[u] = 0;
+        return;
+    }
+    const float eps = filter_eps(ustats[u], user_bias ? fabsf(user_bias[u]) : 0.f, gstats, kdim);
+    const float t = tau[u];
+    float f = t - eps;
+    bool bad = !(eps < INFINITY);                                               // inf or NaN
+    if (t == -INFINITY) f = -INFINITY;                                          // fewer than k superblocks: list everything
+    else if (!(f == f)) bad = true;
+    else f = float_pred(float_pred(f));
+    floor0[u] = bad ? INFINITY : f;                                             // a user without a usable bound lists nothing
+    flag[u] = bad ? 1 : 0;
+    if (bad) atomicAdd(n_flagged, 1);
+}
+
 #define FILTER_RB 8          // survivors re-scored per round (their fp32 rows staged in LDS)
 // The second half of the finish kernels: ``total`` (<= FILTER_CMAX) survivors' item ids sit in cand[] (LDS of this wave), the
 // user's row in registers uw.  Exact fp32 scores by the reference's k-ordered fmaf chain, then (s + b_u) + b_i, then the k
@@ -469,12 +500,16 @@ __global__ __launch_bounds__(256) void candidates_finish_kernel(
     const float2* __restrict__ ustats, const float* __restrict__ gstats, const float* __restrict__ U,
     const float* __restrict__ V, int64_t ld_u, int64_t ld_v, int kdim, const float* __restrict__ user_bias,
     const float* __restrict__ item_bias, int32_t item_index_base, int64_t n_users, int k, float* __restrict__ ov,
-    int32_t* __restrict__ oi, int32_t* __restrict__ flag, int32_t* __restrict__ n_flagged)
+    int32_t* __restrict__ oi, int32_t* __restrict__ flag, int32_t* __restrict__ n_flagged,
+    const int32_t* __restrict__ out_index)
 {
     extern __shared__ __attribute__((aligned(16))) char fsmem[];
     const int wave = threadIdx.x >> 6;
     const int64_t u = (int64_t)blockIdx.x * 4 + wave;
     if (u >= n_users) return;
+    // users sorted by scale class: the result row is the CALLER's row of this layout row; rows without one write nothing
+    const int64_t uo = out_index ? (int64_t)out_index[u] : u;
+    if (uo < 0) return;                                     // (wave-uniform)
     const int lane = lane_id();
     const int kd4 = (kdim + 3) & ~3;
     const int rstride = kd4 + 4;
@@ -514,7 +549,7 @@ __global__ __launch_bounds__(256) void candidates_finish_kernel(
     }
     if (skip || over) {                                     // (wave-uniform)
         if (over && !skip && lane == 0 && flag[u] == 0) { flag[u] = 1; atomicAdd(n_flagged, 1); }
-        if (lane < k) { ov[u * k + lane] = -INFINITY; oi[u * k + lane] = -1; }
+        if (lane < k) { ov[uo * k + lane] = -INFINITY; oi[uo * k + lane] = -1; }
         return;
     }
     // ---- tau = the k-th largest candidate score (keys: value desc, id asc -- an item is listed once, keys are unique)
@@ -557,7 +592,7 @@ __global__ __launch_bounds__(256) void candidates_finish_kernel(
         total = FILTER_CMAX;
     }
     finish_rescore_topk(total, cand, urow, rows, uw, lane, kdim, chunks, rstride, vec, V, ld_v, item_index_base, item_bias,
-                        user_bias != nullptr, bu, k, ov, oi, u);
+                        user_bias != nullptr, bu, k, ov, oi, uo);
 }
 
 extern "C" int trec_score_prep_filter(const float* repr, int64_t n, int32_t d, int32_t kpad, int32_t normalize,
@@ -664,13 +699,15 @@ extern "C" int trec_topk_filter_finish_wide(const int32_t* part_idx, int32_t cap
 // The finish behind the candidate lists of trec_score_gemm_refine_candidates(_hot): cand_n [n_users], cand [n_users][cand_cap]
 // {item id, score bits}, cand_floor [n_users] the provisional floor the lists were made with (+inf: the user is skipped),
 // user_stats [n_users][2] / item_gstats [3] as for trec_topk_filter_floor.  Writes the exact top-k; flags users with more than
-// cand_cap candidates or more than 64 survivors (the caller re-does them: ops.score_topk_filtered).
+// cand_cap candidates or more than 64 survivors (the caller re-does them: ops.score_topk_filtered).  out_index (nullable,
+// [n_users]): user u's lists go to row out_index[u] of out_vals / out_idx, a negative entry writes nothing -- the users of
+// trec_user_prep_sorted leave in the caller's order without a permutation pass.
 extern "C" int trec_topk_candidates_finish(const int32_t* cand_n, const void* cand, int32_t cand_cap, const float* cand_floor,
                                            const float* user_stats, const float* item_gstats, const float* users_f32,
                                            const float* items_f32, int64_t ld_users, int64_t ld_items, int32_t kdim,
                                            const float* user_bias, const float* item_bias, int32_t item_index_base,
                                            int64_t n_users, int32_t k, float* out_vals, int32_t* out_idx, int32_t* flag,
-                                           int32_t* n_flagged, void* stream)
+                                           int32_t* n_flagged, const int32_t* out_index, void* stream)
 {
     TREC_REQUIRE(cand_n && cand && cand_floor && user_stats && item_gstats && users_f32 && items_f32 && out_vals && out_idx &&
                  flag && n_flagged, "trec_topk_candidates_finish: null pointer");
@@ -687,11 +724,25 @@ extern "C" int trec_topk_candidates_finish(const int32_t* cand_n, const void* ca
     (void)hipFuncSetAttribute((const void*)candidates_finish_kernel<CPLV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     hipLaunchKernelGGL((candidates_finish_kernel<CPLV>), dim3(blocks), dim3(256), lds, st, cand_n, (const int2*)cand, cand_cap, \
                        cand_floor, (const float2*)user_stats, item_gstats, users_f32, items_f32, ld_users, ld_items, kdim,   \
-                       user_bias, item_bias, item_index_base, n_users, k, out_vals, out_idx, flag, n_flagged)
+                       user_bias, item_bias, item_index_base, n_users, k, out_vals, out_idx, flag, n_flagged, out_index)
     if (cand_cap == 64) { TREC_CF(1); }
     else if (cand_cap == 128) { TREC_CF(2); }
     else if (cand_cap == 192) { TREC_CF(3); }
     else { TREC_CF(4); }
 #undef TREC_CF
     return trec_check_launch("trec_topk_candidates_finish");
+}
+
+// The cascade's thresholds in one pass (cascade_floor_kernel): tau [n_users] IN / OUT (+inf for rows without a source), src
+// nullable [n_users] (trec_user_prep_sorted), floor0 / flag [n_users] out, n_flagged [1] zeroed by the caller, cand_n nullable
+// [n_users] zeroed here.  Must run before trec_topk_rows_collect (which reads tau).
+extern "C" int trec_topk_cascade_floor(float* tau, const int32_t* src, const float* user_stats, const float* user_bias,
+                                       const float* item_gstats, int32_t kdim, int64_t n_users, float* floor0, int32_t* flag,
+                                       int32_t* n_flagged, int32_t* cand_n, void* stream)
+{
+    TREC_REQUIRE(tau && user_stats && item_gstats && floor0 && flag && n_flagged, "trec_topk_cascade_floor: null pointer");
+    if (n_users == 0) return TREC_OK;
+    hipLaunchKernelGGL(cascade_floor_kernel, dim3((unsigned)ceil_div64(n_users, 256)), dim3(256), 0, (hipStream_t)stream, tau, src,
+                       (const float2*)user_stats, user_bias, item_gstats, kdim, n_users, floor0, flag, n_flagged, cand_n);
+    return trec_check_launch("trec_topk_cascade_floor");
 }

@@ -939,9 +939,11 @@ FILTER_KSEL = 48
 FILTER_ONE_PASS_MIN_ENTRIES = 1 << 28   # table entries from which select + collect run as one scan (1 GB of maxima)
 FILTER_CANDIDATES = 128    # candidates per user of the one-pass scan (entries above the provisional floor: ~45 at 1M x 1M)
 FILTER_KSEL_WIDE = 320     # ... in the wide second pass over the flagged users (its finish kernel has no survivor limit)
+COLLECT_KSEL_MAX = 4096    # slots per user trec_topk_collect_blocks can fill (csrc/topk2.hip)
 WIDE_TIER2_MAX_FRACTION = 0.05   # the all-superblocks tier runs only when at most this fraction of the users is still flagged
 LAST_FILTER_STATS = {}    # diagnostics of the most recent score_topk_filtered call (bench.py reports them)
 FILTER_DEBUG = None       # diagnostics only: set to a dict to collect per-stage counters (each costs a host sync)
+CANDIDATE_STATS = False   # diagnostics only: True adds "candidates_per_user" to LAST_FILTER_STATS (a reduction + a host read per call)
 
 
 def _debug_counts(name, count):
@@ -958,18 +960,41 @@ class FilterOperand(object):
     = {||x||, ||x - bf16(x)||} per row, ``gstats`` [3] = maxima of both and of |bias| over the rows (item side).
     The int8 pre-filter (score_prep_i8_pair) adds ``i8`` [n, kpad] int8, ``stats8`` [n, 2] = {||x||, ||x - scale q||},
     and on the item side ``bias_q`` int32 [n], ``sb_stats`` [n_sb, 4] = per superblock of ``sb_rows`` items {scale, max
-    ||y|| + ||dy||, max ||dy||, max bias quantisation error}, ``gstats8`` [4] ([2] = max |bias|), ``scales`` [3] ([0] = user scale)."""
+    ||y|| + ||dy||, max ||dy||, max bias quantisation error}, ``gstats8`` [4] ([2] = max |bias|), ``scales`` [3] ([0] = user scale).
+
+    Users sorted by int8 scale class (score_prep_filter(sort_users=True) -> trec_user_prep_sorted, csrc/user_prep.hip): every
+    array is in LAYOUT order, ``n`` = the layout's rows (a bound the host knows: n_real + up to 32 x (wg_rows - 1) padding
+    rows), ``src`` int32 [n] = the caller's row of a layout row (-1: none -- such rows are zero and keep nothing), ``pos`` int32
+    [n_real] = the layout row of a caller's row, ``wg_scale`` / ``wg_class`` per int8 workgroup of ``wg_rows`` rows (scale 0 = an
+    idle workgroup beyond the padded rows), ``ladder`` [64] the classes' scales, ``class_used`` [64], ``gmax`` [1], ``meta`` int32
+    [2] = {padded rows, n_real} (on the device: nothing here is read by the host), ``bias_sorted`` the user bias in layout order
+    when it was given to the preparation (``bias_ref``)."""
     __slots__ = ("bf16", "f32", "n", "d", "kpad", "stats", "gstats", "i8", "stats8", "bias_q", "gstats8", "scales",
-                 "sb_stats", "sb_rows", "cascade_too_loose", "perm", "nat", "gmax", "cls", "wg_scale", "wg_class", "wg_rows", "pos",
-                 "order", "pad")
+                 "sb_stats", "sb_rows", "cascade_too_loose", "gmax", "wg_scale", "wg_class", "wg_rows", "pos",
+                 "src", "n_real", "ladder", "class_used", "meta", "bias_sorted", "bias_ref")
 
     def __init__(self):
         self.i8 = self.stats8 = self.bias_q = self.gstats8 = self.scales = self.sb_stats = self.sb_rows = None
         self.cascade_too_loose = False      # set on the item side when the int8 bound did not pay for this catalogue
-        # users sorted by int8 scale class (score_prep_filter(sort_users=True)): row r of every array here is row perm[r] of
-        # the caller's representation; nat / cls = the scale each row wants and its class, gmax = the largest (device scalars)
-        self.perm = self.nat = self.gmax = self.cls = self.wg_scale = self.wg_class = self.wg_rows = self.pos = self.order = None
-        self.pad = None                     # bool [n]: padding rows (their thresholds are +inf: they keep nothing)
+        self.gmax = self.wg_scale = self.wg_class = self.wg_rows = self.pos = self.src = self.n_real = None
+        self.ladder = self.class_used = self.meta = self.bias_sorted = self.bias_ref = None
+        self.gstats = None
+
+    # ---- diagnostics / tests only (each is a torch op or a host sync; nothing on the product path reads them)
+    @property
+    def perm(self):
+        """int64 [n]: the caller's row behind every layout row (rows without one read row 0), or None for unsorted operands."""
+        return None if self.src is None else self.src.clamp(min=0).long()
+
+    @property
+    def pad(self):
+        """bool [n]: layout rows without a source, or None."""
+        return None if self.src is None else self.src < 0
+
+    @property
+    def order(self):
+        """int64 [n_real]: the caller's rows in layout order."""
+        return None if self.src is None else self.src[self.src >= 0].long()
 
 
 I8_CLASSES_PER_OCTAVE = 4         # user scale classes: a geometric ladder below the largest wanted scale, 2^(1/4) apart
@@ -983,60 +1008,73 @@ def i8_user_classes_enabled():
 I8_CLASS_BAND = 2                 # classes per band: the users of one int8 workgroup come from ONE band (scales within 2^(1/2))
 
 
-def score_prep_filter(repr_, normalize=False, bias=None, want_gstats=False, sort_users=False, k=10):
-    """``sort_users`` (the USER side of score_topk_filtered with the int8 pre-filter): the rows are first sorted by the int8
-    scale class each wants (trec_score_row_scale_i8; largest scales first, stable) and laid out so that the ``wg_rows`` rows
-    of one int8 workgroup come from one BAND of I8_CLASS_BAND adjacent classes -- every band's rows are padded to whole
-    workgroups with rows that keep nothing (``pad``: their thresholds are +inf; at most 32 bands x (wg_rows - 1) of them, 0.2% of
-    1M Gaussian users).  Every array of the result is in that layout: ``perm`` [n] maps its rows to the
-    caller's rows, ``pos`` [n_real] gives the row of the i-th sorted user, ``order`` [n_real] the caller's row of that user
-    (score_topk_filtered permutes the user biases and un-permutes its results).  ``k``: the top-k this operand is for (the
-    int8 kernel's workgroup covers 768 users for k <= 10, 512 above).  One host read (the padded row count)."""
+def zero_block(n_words, device):
+    """int32 [n_words] of zeros from ONE hipMemsetAsync (trec_fill_zero): the counters and running maxima a call starts from
+    are slices of such a block instead of a torch.zeros launch each."""
+    buf = torch.empty((int(n_words),), dtype=torch.int32, device=device)
+    N.call("trec_fill_zero", N.ptr(buf), int(n_words) * 4)
+    return buf
+
+
+def _prep_users_sorted(x, normalize, k, user_bias=None):
+    """The user side of the cascade in five launches and no host read (csrc/user_prep.hip): scale class per row, stable
+    counting sort by class, bands of I8_CLASS_BAND classes padded to whole int8 workgroups, one gather pass that writes the
+    fp32 / bf16 / int8 operands with both error norms (and the user bias) in layout order."""
+    n, d = x.shape
+    kpad = score_kpad(d)
+    dev = x.device
+    wg_rows = int(N.query("trec_score_blockmax_i8_rows_per_workgroup", 10 if int(k) <= 10 else 16))
+    n_alloc = int(N.query("trec_user_prep_alloc_rows", n, wg_rows))
+    n_wg = n_alloc // wg_rows
+    ws_bytes = int(N.query("trec_user_prep_workspace_bytes", n))
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    small = torch.empty((8 + 2 * I8_N_CLASSES + 2 * n_wg,), dtype=torch.int32, device=dev)
+    N.call("trec_fill_zero", N.ptr(small), 32)                           # gmax (a running maximum) | meta
+    op = FilterOperand()
+    op.gmax = small[0:1].view(torch.float32)
+    op.meta = small[4:6]
+    op.ladder = small[8:8 + I8_N_CLASSES].view(torch.float32)
+    op.class_used = small[8 + I8_N_CLASSES:8 + 2 * I8_N_CLASSES]
+    op.wg_scale = small[8 + 2 * I8_N_CLASSES:8 + 2 * I8_N_CLASSES + n_wg].view(torch.float32)
+    op.wg_class = small[8 + 2 * I8_N_CLASSES + n_wg:]
+    op.n, op.n_real, op.d, op.kpad, op.wg_rows = n_alloc, n, d, kpad, wg_rows
+    op.src = torch.empty((n_alloc,), dtype=torch.int32, device=dev)
+    op.pos = torch.empty((n,), dtype=torch.int32, device=dev)
+    op.f32 = torch.empty((n_alloc, kpad), dtype=torch.float32, device=dev)
+    op.bf16 = torch.empty((n_alloc, kpad), dtype=torch.bfloat16, device=dev)
+    op.i8 = torch.empty((n_alloc, kpad), dtype=torch.int8, device=dev)
+    op.stats = torch.empty((n_alloc, 2), dtype=torch.float32, device=dev)
+    op.stats8 = torch.empty((n_alloc, 2), dtype=torch.float32, device=dev)
+    ub = _f32c(user_bias.detach()).reshape(-1) if user_bias is not None else None
+    op.bias_sorted = torch.empty((n_alloc,), dtype=torch.float32, device=dev) if ub is not None else None
+    op.bias_ref = user_bias
+    with _timed("user_prep_sorted"):
+        N.call("trec_user_prep_sorted", N.ptr(x), n, d, kpad, 1 if normalize else 0, N.ptr(ub), wg_rows, n_alloc, N.ptr(ws),
+               ws_bytes, N.ptr(op.src), N.ptr(op.pos), N.ptr(op.wg_scale), N.ptr(op.wg_class), N.ptr(op.ladder),
+               N.ptr(op.class_used), N.ptr(op.gmax), N.ptr(op.meta), N.ptr(op.f32), N.ptr(op.bf16), N.ptr(op.stats),
+               N.ptr(op.i8), N.ptr(op.stats8), N.ptr(op.bias_sorted))
+    return op
+
+
+def score_prep_filter(repr_, normalize=False, bias=None, want_gstats=False, sort_users=False, k=10, user_bias=None):
+    """Operands of the filtered top-k for one side (FilterOperand).  ``sort_users`` (the USER side of score_topk_filtered with
+    the int8 pre-filter): the rows are laid out sorted by the int8 scale class each wants, bands of I8_CLASS_BAND adjacent
+    classes padded to whole int8 workgroups, and the int8 operand is made in the same pass (_prep_users_sorted: no host
+    read; the layout has ``op.n`` >= n rows, ``op.src`` / ``op.pos`` map between it and the caller's rows).  ``k``: the top-k
+    this operand is for (the int8 kernel's workgroup covers 768 users for k <= 10, 512 above).  ``user_bias`` (with
+    sort_users): the users' biases, also wanted in layout order -- pass the same tensor to score_topk_filtered."""
     x = _f32c(repr_.detach())
     n, d = x.shape
     kpad = score_kpad(d)
-    perm = nat = gmax = cls = pos = order = pad = None
-    wg_rows = None
     if sort_users and kpad <= 128 and n > 0 and i8_user_classes_enabled():
-        nat = torch.empty((n,), dtype=torch.float32, device=x.device)
-        gmax = torch.zeros((1,), dtype=torch.float32, device=x.device)
-        with _timed("score_prep_i8"):
-            N.call("trec_score_row_scale_i8", N.ptr(x), n, d, N.ptr(nat), N.ptr(gmax))
-            if normalize:                    # the operand is the normalised row: its scale is the raw one over the row norm
-                nat = nat / torch.linalg.vector_norm(x, dim=1).clamp_(min=1e-6)
-                gmax = nat.max().reshape(1)
-            g = torch.where(gmax > 0, gmax, torch.ones_like(gmax))
-            cls = torch.floor(I8_CLASSES_PER_OCTAVE * torch.log2(g / nat)).clamp_(0, I8_N_CLASSES - 1)
-            cls = torch.nan_to_num(cls, nan=0.0).to(torch.int32)          # (a non-finite row poisons gmax: everything is flagged later)
-            cls_s, order = torch.sort(cls, stable=True)
-            wg_rows = int(N.query("trec_score_blockmax_i8_rows_per_workgroup", 10 if int(k) <= 10 else 16))
-            n_bands = (I8_N_CLASSES + I8_CLASS_BAND - 1) // I8_CLASS_BAND
-            band = torch.div(cls_s, I8_CLASS_BAND, rounding_mode="floor").long()
-            counts = torch.bincount(band, minlength=n_bands)
-            padded = (counts + wg_rows - 1) // wg_rows * wg_rows
-            start = torch.cumsum(counts, 0) - counts
-            pstart = torch.cumsum(padded, 0) - padded
-            pos = pstart[band] + (torch.arange(n, device=x.device) - start[band])
-            n_pad = int(padded.sum().item())                             # the one host read of the user-side preparation
-            slot = torch.full((n_pad,), -1, dtype=torch.int64, device=x.device)
-            slot[pos] = torch.arange(n, device=x.device)
-            pad = slot < 0                                               # padding rows keep nothing: their thresholds are set to
-            slot = slot.clamp_(min=0)                                    # +inf after every selection (their content -- a copy of
-            perm = order[slot]                                           # the first sorted user -- never matters)
-            x = x.index_select(0, perm)
-            nat = nat.index_select(0, perm)
-            cls = torch.where(pad, torch.full_like(cls_s[:1], I8_N_CLASSES - 1).expand(n_pad), cls_s[slot]).contiguous()
-            gmax = g
-            n = n_pad
-            pad = pad if n_pad > int(order.numel()) else None
+        return _prep_users_sorted(x, normalize, k, user_bias)
     op = FilterOperand()
-    op.perm, op.nat, op.gmax, op.cls, op.pos, op.order, op.wg_rows, op.pad = perm, nat, gmax, cls, pos, order, wg_rows, pad
     op.n, op.d, op.kpad = n, d, kpad
     own_f32 = normalize or kpad != d
     op.f32 = torch.empty((n, kpad), dtype=torch.float32, device=x.device) if own_f32 else x
     op.bf16 = torch.empty((n, kpad), dtype=torch.bfloat16, device=x.device)
     op.stats = torch.empty((n, 2), dtype=torch.float32, device=x.device)
-    op.gstats = torch.zeros((3,), dtype=torch.float32, device=x.device) if want_gstats else None
+    op.gstats = zero_block(4, x.device)[:3].view(torch.float32) if want_gstats else None
     with _timed("score_prep_filter"):
         N.call("trec_score_prep_filter", N.ptr(x), n, d, kpad, 1 if normalize else 0, N.ptr(bias),
                N.ptr(op.f32) if own_f32 else None, N.ptr(op.bf16), N.ptr(op.stats), N.ptr(op.gstats))
@@ -1081,6 +1119,21 @@ CASCADE_DENSE_USER_LIMIT = 16    # of 32 sampled superblocks kept (Gaussian rows
 CASCADE_MIN_ITEMS = 262144       # below ~512 superblocks the k-th largest maximum is not selective enough for int8 to pay
 
 
+def topk_user_batch(n_users, n_items, n_components, device, fraction=0.6):
+    """Users per pass of predict_top_k when the caller names no batch size: what ``fraction`` of the FREE device memory holds.
+    Per user the exact top-k's cascade keeps a column of the superblock-maxima table (4 B per superblock), half a column of
+    user-list slots (CASCADE_ROW_CAPACITY x 4 B), the operands three times over (fp32 + bf16 + int8), ~1 KB of chunk lists and
+    CASCADE_CANDIDATES x 8 B of candidate slots; 30 % on top for the allocator.  Never below 65,536 (the old fixed default)."""
+    n_sb = (int(n_items) + SUPERBLOCK_ROWS - 1) // SUPERBLOCK_ROWS
+    kpad = max(32, (int(n_components) + 31) // 32 * 32)
+    per_user = 1.3 * (n_sb * (4 + 4 * CASCADE_ROW_CAPACITY) + 8 * kpad + 1024 + 8 * CASCADE_CANDIDATES + 256)
+    try:
+        free, _total = torch.cuda.mem_get_info(device)
+    except Exception:                                   # pragma: no cover
+        free = 16 << 30
+    return int(max(65536, min(int(n_users), fraction * free / per_user)))
+
+
 def cascade_prefilter_for(n_components, n_items_total):
     """"int8" when the int8 pre-filter is worth trying for this shape (tuning ``topk_int8_prefilter``, default on), else None."""
     if N.load().trec_get_tuning(b"topk_int8_prefilter", 1) == 0:
@@ -1092,22 +1145,23 @@ def score_prep_i8_pair(uop, iop, item_bias=None, sb_rows=None, top_k=10):
     """int8 operands of both sides for the cascade's pre-filter, from the fp32 operands of FilterOperand (already
     normalised / padded).  Items: one scale per superblock of ``sb_rows`` rows (max |y| / 127 over the superblock: no item
     clips), with the superblock's error maxima in ``iop.sb_stats`` [n_sb, 4]; quantised once per ``iop``.
-    Users sorted by scale class (``uop.perm``, score_prep_filter(sort_users=True)): every int8 workgroup of ``wg_rows`` users
-    gets the scale of its first (largest) row on the ladder gmax * 2^(-c / 4), and the integer item biases exist once per class
-    in use (``iop.bias_q`` [n_classes, n_items]).  Users in the caller's order: ONE scale, min(4 rms, max |x|) / 127
-    (``iop.scales[0]``).  A new batch of users only re-derives the item biases."""
+    Users sorted by scale class (``uop.src``, score_prep_filter(sort_users=True)): their int8 rows exist already -- every int8
+    workgroup of ``wg_rows`` users has the scale of its first (largest) row on the ladder gmax * 2^(-c / 4) -- and the integer
+    item biases are made once per class in use (``iop.bias_q`` [n_classes, n_items]).  Users in the caller's order: ONE
+    scale, min(4 rms, max |x|) / 127 (``iop.scales[0]``).  A new batch of users only re-derives the item biases."""
     if uop.kpad > 128:
         raise ValueError("int8 pre-filter covers kpad <= 128")
     sb_rows = int(sb_rows or SUPERBLOCK_ROWS)
     dev = uop.f32.device
-    classes = uop.cls is not None
+    classes = uop.src is not None
     with _timed("score_prep_i8"):
         fresh_items = iop.i8 is None or iop.sb_rows != sb_rows
         n_sb = (iop.n + sb_rows - 1) // sb_rows
         if fresh_items:
-            iop.scales = torch.zeros((3,), dtype=torch.float32, device=dev)
-            iop.gstats8 = torch.zeros((4,), dtype=torch.float32, device=dev)
-            iop.sb_stats = torch.zeros((n_sb, 4), dtype=torch.float32, device=dev)
+            zb = zero_block(8 + 4 * n_sb, dev).view(torch.float32)       # scales [3] | gstats8 [4] | sb_stats [n_sb, 4], one memset
+            iop.scales = zb[0:3]
+            iop.gstats8 = zb[4:8]
+            iop.sb_stats = zb[8:].reshape(n_sb, 4)
             iop.sb_rows = sb_rows
             iop.i8 = torch.empty((iop.n, iop.kpad), dtype=torch.int8, device=dev)
             iop.stats8 = torch.empty((iop.n, 2), dtype=torch.float32, device=dev)
@@ -1116,27 +1170,19 @@ def score_prep_i8_pair(uop, iop, item_bias=None, sb_rows=None, top_k=10):
         else:
             iop.gstats8[2:].zero_()
             iop.sb_stats[:, 3].zero_()
-        uop.i8 = torch.empty((uop.n, uop.kpad), dtype=torch.int8, device=dev)
-        uop.stats8 = torch.empty((uop.n, 2), dtype=torch.float32, device=dev)
         if classes:
             wg_rows = int(N.query("trec_score_blockmax_i8_rows_per_workgroup", int(top_k)))
             if wg_rows != uop.wg_rows:
                 raise ValueError("the user operand was laid out for int8 workgroups of %s rows, this call needs %d "
                                  "(score_prep_filter(sort_users=True, k=...) must be given the same k)" % (uop.wg_rows, wg_rows))
-            # (torch.pow, not torch.exp2: exp2 is a jiterator kernel that is compiled at first use in every process)
-            ladder = uop.gmax * torch.pow(2.0, torch.arange(I8_N_CLASSES, device=dev, dtype=torch.float32) / (-float(I8_CLASSES_PER_OCTAVE)))
-            uop.wg_class = uop.cls[::wg_rows].contiguous()                 # rows are sorted by class: the first is the largest scale
-            uop.wg_scale = ladder[uop.wg_class.long()].contiguous()
-            N.call("trec_score_prep_i8_users", N.ptr(uop.f32), uop.n, uop.f32.shape[1], uop.kpad, N.ptr(uop.wg_scale), wg_rows,
-                   N.ptr(uop.i8), N.ptr(uop.stats8))
             iop.bias_q = None
             if item_bias is not None:
-                used = torch.zeros((I8_N_CLASSES,), dtype=torch.int32, device=dev)
-                used[uop.wg_class.long()] = 1
                 iop.bias_q = torch.empty((I8_N_CLASSES, iop.n), dtype=torch.int32, device=dev)   # only the classes in use are touched
-                N.call("trec_score_bias_i8_classes", N.ptr(item_bias), iop.n, sb_rows, N.ptr(ladder), N.ptr(used), I8_N_CLASSES,
-                       N.ptr(iop.sb_stats), N.ptr(iop.bias_q), N.ptr(iop.gstats8))
+                N.call("trec_score_bias_i8_classes", N.ptr(item_bias), iop.n, sb_rows, N.ptr(uop.ladder), N.ptr(uop.class_used),
+                       I8_N_CLASSES, N.ptr(iop.sb_stats), N.ptr(iop.bias_q), N.ptr(iop.gstats8))
         else:
+            uop.i8 = torch.empty((uop.n, uop.kpad), dtype=torch.int8, device=dev)
+            uop.stats8 = torch.empty((uop.n, 2), dtype=torch.float32, device=dev)
             uop.wg_class = uop.wg_scale = None
             ws = torch.empty((2,), dtype=torch.float64, device=dev)
             clip = N.load().trec_get_tuning(b"i8_user_clip_x10", int(I8_USER_CLIP_SIGMAS * 10)) / 10.0
@@ -1228,7 +1274,8 @@ def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, 
     with _timed("score_gemm_blockmax_i8"):
         N.call("trec_score_gemm_blockmax_i8", N.ptr(uop.i8), N.ptr(iop.i8), kpad, n_u, n_i, N.ptr(user_bias),
                N.ptr(iop.bias_q), N.ptr(iop.scales), N.ptr(iop.sb_stats), sb_rows, n_chunks, N.ptr(table), stride,
-               N.ptr(user_err), N.ptr(chunk_top), top_k, N.ptr(uop.wg_scale), N.ptr(uop.wg_class))
+               N.ptr(user_err), N.ptr(chunk_top), top_k, N.ptr(uop.wg_scale), N.ptr(uop.wg_class),
+               int(uop.wg_rows or 0) if uop.wg_scale is not None else 0)
     # tau = the k-th largest LOWER bound: from the chunks' lists (k rows per chunk), not from the 7.8 GB table
     sel = torch.empty((n_u, kk), dtype=torch.int32, device=dev)
     sel_max = torch.empty((kk, n_u), dtype=torch.float32, device=dev) if floor_exchange is not None else None
@@ -1238,14 +1285,33 @@ def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, 
                N.ptr(tau))
     if floor_exchange is not None:
         tau = floor_exchange(sel_max).contiguous()
-    if uop.pad is not None:
-        tau.masked_fill_(uop.pad, float("inf"))         # padding rows refine nothing
-    status = torch.zeros((3,), dtype=torch.int64, device=dev)
-    if N.load().trec_get_tuning(b"cascade_rows_onepass", 1) != 0 and N.load().trec_get_tuning(b"blockmax_bf16_mfma16", 1) != 0:
+    # the counters this call starts from, as ONE zeroed block: status int64 [3] | n_flagged | row_count [n_sb]
+    zb = zero_block(8 + n_sb, dev)
+    status = zb[0:6].view(torch.int64)
+    n_flagged0 = zb[6:7]
+    row_count = zb[8:8 + n_sb]
+    lists = cascade_lists_candidates() and gstats_all is not None and sb_rows <= 65536
+    one_pass = N.load().trec_get_tuning(b"cascade_rows_onepass", 1) != 0 and N.load().trec_get_tuning(b"blockmax_bf16_mfma16", 1) != 0
+    cands = None
+    if one_pass and lists:
+        # the refining launches also list every item that can still reach the top-k: provisional floor = the k-th
+        # largest int8 lower bound less ONE eps of the bf16 filter.  ONE pass over the users (trec_topk_cascade_floor) makes the
+        # thresholds: rows without a source keep nothing (tau = floor = +inf), users without a usable bound are flagged and
+        # list nothing, the list counters start at zero
+        cands = _Candidates()
+        cands.cap = int(N.load().trec_get_tuning(b"cascade_candidates_cap", CASCADE_CANDIDATES))
+        cands.floor0 = torch.empty((n_u,), dtype=torch.float32, device=dev)
+        cands.flag = torch.empty((n_u,), dtype=torch.int32, device=dev)
+        cands.n_flagged = n_flagged0
+        cands.n = torch.empty((n_u,), dtype=torch.int32, device=dev)
+        N.call("trec_topk_cascade_floor", N.ptr(tau), N.ptr(uop.src), N.ptr(uop.stats), N.ptr(user_bias), N.ptr(gstats_all), kpad,
+               n_u, N.ptr(cands.floor0), N.ptr(cands.flag), N.ptr(cands.n_flagged), N.ptr(cands.n))
+    elif uop.src is not None:
+        tau.masked_fill_(uop.src < 0, float("inf"))     # rows without a source refine nothing (the table-driven tail: A/B reference)
+    if one_pass:
         # one pass over the table: a fixed capacity per superblock, slots handed out by atomics (csrc/topk_cascade.hip)
         rcap_frac = N.load().trec_get_tuning(b"cascade_rcap_pct", int(100 * CASCADE_ROW_CAPACITY)) / 100.0
         rcap = (int(rcap_frac * n_u) + 511) // 512 * 512 + 512
-        row_count = torch.zeros((n_sb,), dtype=torch.int32, device=dev)
         row_user = torch.empty((n_sb * rcap,), dtype=torch.int32, device=dev)      # only the kept pairs' part is touched
         with _timed("topk_rows_compact"):
             N.call("trec_topk_rows_collect", N.ptr(table), n_sb, n_u, stride, N.ptr(tau), N.ptr(user_err),
@@ -1261,30 +1327,14 @@ def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, 
         max_pairs = int(N.load().trec_get_tuning(b"cascade_max_refined_pct", int(100 * CASCADE_MAX_REFINED)) / 100.0 * n_sb * n_u)
         N.call("trec_topk_rows_hot", N.ptr(row_count), n_sb, rcap, n_u, N.ptr(hot_list), hot_cap, max_pairs, N.ptr(status))
         # Everything that does not need the host's decision is queued BEFORE the host reads the status -- behind the int8 launch,
-        # while it still runs: the provisional floors, the users the int8 bound says nothing about, the zeroed counters, the map of
-        # the occupied workgroup slots.  After the read only the refining launches and the finish remain: on a host that is slow
-        # to launch (a box in its first minute: ~0.4 ms per launch measured, against ~10 us later) the step used to wait for ten
-        # launches there.
-        cands = None
+        # while it still runs: the thresholds above, the users the int8 bound says nothing about, the map of the occupied
+        # workgroup slots.  After the read only the refining launches and the finish remain.
         wg_map, wg_cap = None, 0
-        if cascade_lists_candidates() and gstats_all is not None and sb_rows <= 65536:
-            # the refining launches also list every item that can still reach the top-k: provisional floor = the
-            # k-th largest int8 lower bound less ONE eps of the bf16 filter; users without a usable bound are flagged and skipped
-            cands = _Candidates()
-            cands.cap = int(N.load().trec_get_tuning(b"cascade_candidates_cap", CASCADE_CANDIDATES))
-            cands.floor0 = torch.empty((n_u,), dtype=torch.float32, device=dev)
-            cands.flag = torch.empty((n_u,), dtype=torch.int32, device=dev)
-            cands.n_flagged = torch.zeros((1,), dtype=torch.int32, device=dev)
-            N.call("trec_topk_filter_floor_ex", N.ptr(tau), N.ptr(uop.stats), N.ptr(user_bias), N.ptr(gstats_all), kpad, n_u, 1.0,
-                   N.ptr(cands.floor0), N.ptr(cands.flag), N.ptr(cands.n_flagged))
-            cands.floor0.masked_fill_(cands.flag != 0, float("inf"))
-            if uop.pad is not None:
-                cands.floor0.masked_fill_(uop.pad, float("inf"))
+        if cands is not None:
             if n_sb >= 32:                              # users the int8 bound says nothing about are flagged now, not listed for
                 N.call("trec_topk_dense_users", N.ptr(table), n_sb, n_u, stride, N.ptr(tau), N.ptr(user_err), N.ptr(iop.sb_stats),
                        kpad, CASCADE_DENSE_USER_LIMIT if n_i >= CASCADE_MIN_ITEMS else 30, N.ptr(cands.floor0), N.ptr(cands.flag),
                        N.ptr(cands.n_flagged))             # (small catalogues: the k-th largest of few maxima keeps half the rows of anybody)
-            cands.n = torch.zeros((n_u,), dtype=torch.int32, device=dev)
             cands.items = torch.empty((n_u, cands.cap, 2), dtype=torch.int32, device=dev)     # only the listed part is touched
             if N.load().trec_get_tuning(b"cascade_wg_map", 1) != 0:
                 # only the workgroup slots that hold rows are launched (98k of the 1.9M of the [n_sb][rcap / 512] grid at 1M x 1M)
@@ -1450,28 +1500,31 @@ def _wide_second_pass(uop, iop, blockmax, bad, n_sb, k, user_bias, item_bias, it
 
 def score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index_base=0, sb_rows=None, variant=1,
                         n_chunks=None, floor_exchange=None, stats_exchange=None, ksel=None, prefilter=None):
-    """See _score_topk_filtered.  A user operand sorted by int8 scale class (``uop.perm``) is handled here: the user biases
-    follow the operand's row order on the way in, the results return to the caller's order on the way out.  Item shards:
+    """See _score_topk_filtered.  A user operand sorted by int8 scale class (``uop.src``) is handled here: the user biases
+    follow the operand's row order on the way in (``uop.bias_sorted`` when this ``user_bias`` was given to the preparation),
+    the results leave in the caller's order (the finish kernel writes through ``uop.src``: no permutation pass).  Item shards:
     the per-user exchanges then carry users in the operand's order -- the same on every rank, because the user side is
     replicated and the sort is deterministic."""
-    if uop.perm is None:
+    if uop.src is None:
         return _score_topk_filtered(uop, iop, k, user_bias, item_bias, item_index_base, sb_rows, variant, n_chunks,
                                     floor_exchange, stats_exchange, ksel, prefilter)
-    ub = user_bias.index_select(0, uop.perm) if user_bias is not None else None
+    if user_bias is None:
+        ub = None
+    elif uop.bias_sorted is not None and uop.bias_ref is user_bias:
+        ub = uop.bias_sorted
+    else:
+        ub = user_bias.reshape(-1).index_select(0, uop.perm).masked_fill_(uop.pad, 0.0)
     n_batches = cascade_user_batches(uop, iop, prefilter, floor_exchange, stats_exchange)
     if n_batches > 1:
         sv, si = _score_topk_filtered_pipelined(uop, iop, k, ub, item_bias, item_index_base, sb_rows, variant, n_chunks, ksel,
                                                 n_batches)
+        pos = uop.pos.long()
+        ov, oi = sv.index_select(0, pos), si.index_select(0, pos)
     else:
-        sv, si = _score_topk_filtered(uop, iop, k, ub, item_bias, item_index_base, sb_rows, variant, n_chunks,
-                                      floor_exchange, stats_exchange, ksel, prefilter)
-    n_real = int(uop.order.numel())
-    ov = torch.empty((n_real, sv.shape[1]), dtype=sv.dtype, device=sv.device)
-    oi = torch.empty((n_real, si.shape[1]), dtype=si.dtype, device=si.device)
-    ov.index_copy_(0, uop.order, sv.index_select(0, uop.pos))            # (the padding rows are dropped)
-    oi.index_copy_(0, uop.order, si.index_select(0, uop.pos))
-    LAST_FILTER_STATS["users"] = n_real
-    LAST_FILTER_STATS["padding_rows"] = int(uop.n) - n_real
+        ov, oi = _score_topk_filtered(uop, iop, k, ub, item_bias, item_index_base, sb_rows, variant, n_chunks,
+                                      floor_exchange, stats_exchange, ksel, prefilter, caller_order=True)
+    LAST_FILTER_STATS["users"] = int(uop.n_real)
+    LAST_FILTER_STATS["layout_rows"] = int(uop.n)
     return ov, oi
 
 
@@ -1491,20 +1544,20 @@ def cascade_user_batches(uop, iop, prefilter, floor_exchange, stats_exchange):
         return 1
     if uop.kpad not in (64, 128) or iop.cascade_too_loose or not cascade_lists_candidates():
         return 1
-    return max(1, min(int(want), int(uop.n) // CASCADE_PIPELINE_MIN_ROWS))
+    return max(1, min(int(want), int(uop.n_real or uop.n) // CASCADE_PIPELINE_MIN_ROWS))
 
 
 def _rows_of(uop, r0, r1):
     """Rows r0 .. r1 (multiples of the int8 workgroup height) of a class-sorted user operand, as views."""
     sub = FilterOperand()
-    sub.n, sub.d, sub.kpad = r1 - r0, uop.d, uop.kpad
+    sub.n, sub.n_real, sub.d, sub.kpad = r1 - r0, r1 - r0, uop.d, uop.kpad
     sub.bf16, sub.f32, sub.stats = uop.bf16[r0:r1], uop.f32[r0:r1], uop.stats[r0:r1]
     sub.i8, sub.stats8 = uop.i8[r0:r1], uop.stats8[r0:r1]
-    sub.pad = uop.pad[r0:r1] if uop.pad is not None else None
+    sub.src = uop.src[r0:r1]
     sub.wg_rows = uop.wg_rows
     sub.wg_scale = uop.wg_scale[r0 // uop.wg_rows:r1 // uop.wg_rows]
     sub.wg_class = uop.wg_class[r0 // uop.wg_rows:r1 // uop.wg_rows]
-    sub.cls, sub.gmax = uop.cls[r0:r1], uop.gmax
+    sub.gmax, sub.ladder, sub.class_used = uop.gmax, uop.ladder, uop.class_used
     return sub
 
 
@@ -1557,7 +1610,8 @@ def _score_topk_filtered_pipelined(uop, iop, k, user_bias, item_bias, item_index
 
 
 def _score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index_base=0, sb_rows=None, variant=1,
-                         n_chunks=None, floor_exchange=None, stats_exchange=None, ksel=None, prefilter=None, tail_stream=None):
+                         n_chunks=None, floor_exchange=None, stats_exchange=None, ksel=None, prefilter=None, tail_stream=None,
+                         caller_order=False):
     """EXACT fp32 top-k (values and ids bit-identical to ``score_topk(..., DTYPE_F32)`` and to the oracle) with the
     score matrix contracted ONCE on bf16 MFMA: the bf16 stage-1 maxima and the bf16 re-scoring act as a filter with a
     proven error bound (csrc/topk_filter.hip), the survivors (~15 items per user at 1M x 1M) are re-scored by the
@@ -1566,7 +1620,9 @@ def _score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index
     the item-side maxima (the bound must cover every shard's items).  Users the filter cannot certify (its capacity
     limits, non-finite bounds) are re-done on the exact fp32 MFMA path; their number is in LAST_FILTER_STATS.
     ``prefilter="int8"``: stage 1 becomes the cascade of csrc/topk_cascade.hip -- an exact-integer int8 MFMA pass over
-    everything, the bf16 kernel only on the (superblock, user) pairs the int8 bound cannot rule out (kpad 64 / 128)."""
+    everything, the bf16 kernel only on the (superblock, user) pairs the int8 bound cannot rule out (kpad 64 / 128).
+    ``caller_order`` (a class-sorted ``uop``): the lists come back as [uop.n_real, k] in the CALLER's row order -- the candidate
+    finish writes them there through ``uop.src``; the other tails permute at the end -- instead of [uop.n, k] in layout order."""
     if not 1 <= int(k) <= 16:
         raise ValueError("fused top-k supports k <= 16 (got %d)" % k)
     cap = 8              # stage-3 lists hold survivors of ONE (user, superblock, half-wave): 0-2 typically; full -> exact fallback
@@ -1602,7 +1658,7 @@ def _score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index
             # against this catalogue skip the attempt (item shards keep trying: every rank must take the same path and the
             # flag is local)
             r = _score_topk_filtered(uop, iop, k, user_bias, item_bias, item_index_base, sb_rows, variant, n_chunks,
-                                     floor_exchange, stats_exchange, ksel, None)
+                                     floor_exchange, stats_exchange, ksel, None, caller_order=caller_order)
             LAST_FILTER_STATS["prefilter"] = "int8 (too loose: bf16 stage 1 instead)"
             LAST_FILTER_STATS["refined_rows"] = int(rows)
             iop.cascade_too_loose = True
@@ -1625,25 +1681,30 @@ def _score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index
     kk = int(k)
     if cands is not None:
         # ---- the refining launches listed every item that can still reach the top-k: finish from the lists (stages 2-3 gone)
-        ov = torch.empty((n_u, kk), dtype=torch.float32, device=dev)
-        oi = torch.empty((n_u, kk), dtype=torch.int32, device=dev)
+        # (class-sorted users: user u's lists are written to the CALLER's row uop.src[u]; rows without one write nothing)
+        out_index = uop.src if (caller_order and uop.src is not None) else None
+        n_out = int(uop.n_real) if out_index is not None else n_u
+        ov = torch.empty((n_out, kk), dtype=torch.float32, device=dev)
+        oi = torch.empty((n_out, kk), dtype=torch.int32, device=dev)
         flag, n_flagged = cands.flag, cands.n_flagged
         with _tail_of(tail_stream, ov, oi, flag, n_flagged, gstats), _timed("topk_filter_finish"):
             N.call("trec_topk_candidates_finish", N.ptr(cands.n), N.ptr(cands.items), cands.cap, N.ptr(cands.floor0),
                    N.ptr(uop.stats), N.ptr(gstats), N.ptr(uop.f32), N.ptr(iop.f32), kpad, kpad, uop.d, N.ptr(user_bias),
-                   N.ptr(item_bias), item_index_base, n_u, kk, N.ptr(ov), N.ptr(oi), N.ptr(flag), N.ptr(n_flagged))
+                   N.ptr(item_bias), item_index_base, n_u, kk, N.ptr(ov), N.ptr(oi), N.ptr(flag), N.ptr(n_flagged),
+                   N.ptr(out_index))
 
         def complete(cands=cands, blockmax=blockmax):
             if FILTER_DEBUG is not None:
                 _debug_counts("candidates", cands.n)
-            # ONE host read: the flagged-user counter and the number of listed candidates (queued behind the finish kernel)
-            n_bad, n_listed = torch.stack((n_flagged[0].to(torch.int64), cands.n.clamp(max=cands.cap).sum())).tolist()
+            # ONE host read: the flagged-user counter (queued behind the finish kernel)
+            n_bad = int(n_flagged.item())
             LAST_FILTER_STATS.clear()
             LAST_FILTER_STATS.update({"prefilter": "int8", "refined_rows": cascade_rows, "users": n_u, "flagged_users": n_bad,
-                                      "tail": "candidate lists", "candidates_cap": cands.cap,
-                                      "candidates_per_user": float(n_listed) / max(1, n_u)})
+                                      "tail": "candidate lists", "candidates_cap": cands.cap})
+            if CANDIDATE_STATS:                           # diagnostics (a reduction over the counters + a host read): off the product path
+                LAST_FILTER_STATS["candidates_per_user"] = float(cands.n.clamp(max=cands.cap).sum().item()) / max(1, n_u)
             return _redo_flagged(uop, iop, blockmax, flag, n_bad, n_sb, k, user_bias, item_bias, item_index_base, sb_rows,
-                                 variant, None, rows_wg, ksel, gstats, ov, oi)
+                                 variant, None, rows_wg, ksel, gstats, ov, oi, out_index)
         cands = blockmax = None
         if tail_stream is not None:
             return _Pending(complete)
@@ -1680,8 +1741,8 @@ def _score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index
         tau = floor_exchange(sel_max).contiguous()
     N.call("trec_topk_filter_floor", N.ptr(tau), N.ptr(uop.stats), N.ptr(user_bias), N.ptr(gstats), kpad, n_u,
            N.ptr(floor), N.ptr(flag), N.ptr(n_flagged))
-    if uop.pad is not None:
-        floor.masked_fill_(uop.pad, float("inf"))       # padding rows keep nothing: no lists, no survivors, never flagged
+    if uop.src is not None:
+        floor.masked_fill_(uop.src < 0, float("inf"))   # rows without a source keep nothing: no lists, no survivors, never flagged
     if FILTER_DEBUG is not None:
         FILTER_DEBUG["flagged_after_floor"] = int(n_flagged.item())
     if one_pass:
@@ -1706,27 +1767,37 @@ def _score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index
         LAST_FILTER_STATS["refined_rows"] = cascade_rows
     LAST_FILTER_STATS.update({"users": n_u, "flagged_users": n_bad, "ksel": ksel,
                               "kept_superblocks_per_user": float(count.sum().item()) / max(1, n_u)})
-    return _redo_flagged(uop, iop, blockmax, flag, n_bad, n_sb, k, user_bias, item_bias, item_index_base, sb_rows, variant, floor,
-                         rows_wg, ksel, gstats, ov, oi)
+    ov, oi = _redo_flagged(uop, iop, blockmax, flag, n_bad, n_sb, k, user_bias, item_bias, item_index_base, sb_rows, variant, floor,
+                           rows_wg, ksel, gstats, ov, oi)
+    if caller_order and uop.src is not None:            # (the table-driven tails work in layout order: permute at the end)
+        pos = uop.pos.long()
+        ov, oi = ov.index_select(0, pos), oi.index_select(0, pos)
+    return ov, oi
 
 
 def _redo_flagged(uop, iop, blockmax, flag, n_bad, n_sb, k, user_bias, item_bias, item_index_base, sb_rows, variant, floor, rows_wg,
-                  ksel, gstats, ov, oi):
+                  ksel, gstats, ov, oi, out_index=None):
     """The users the first pass flagged (``n_bad`` of them, ``flag`` != 0): the wide second pass on their table columns, then
-    the exact fp32 MFMA path for what is left.  Returns (ov, oi) with their rows replaced."""
+    the exact fp32 MFMA path for what is left.  Returns (ov, oi) with their rows replaced.  ``out_index``: operand row r's
+    result lives in row out_index[r] of ov / oi (class-sorted users whose lists leave in the caller's order)."""
     n_u, n_i, kpad = uop.n, iop.n, uop.kpad
+
+    def rows_of(b):
+        return b if out_index is None else out_index.index_select(0, b).long()
     if n_bad:
         bad = torch.nonzero(flag, as_tuple=False).reshape(-1)
         if N.load().trec_get_tuning(b"topk_filter_wide_pass", 1) != 0 and n_sb > ksel:
             # tier 1: FILTER_KSEL_WIDE slots; tier 2, for the few users still over (and only if they are few: it re-scores ALL
             # their superblocks that reach the floor): every superblock may be kept
-            for tier, ksel_w in enumerate((min(FILTER_KSEL_WIDE, n_sb), n_sb)):
+            # (trec_topk_collect_blocks takes at most COLLECT_KSEL_MAX slots: on catalogues above 4096 superblocks = 2,097,152
+            # items tier 2 keeps that many -- a user wanting more stays flagged and goes to the exact fp32 path, ADVICE r3)
+            for tier, ksel_w in enumerate((min(FILTER_KSEL_WIDE, n_sb), min(n_sb, COLLECT_KSEL_MAX))):
                 if bad.numel() == 0 or (tier == 1 and (ksel_w <= FILTER_KSEL_WIDE or bad.numel() > WIDE_TIER2_MAX_FRACTION * n_u)):
                     break
                 wv, wi, wflag = _wide_second_pass(uop, iop, blockmax, bad, n_sb, k, user_bias, item_bias, item_index_base,
                                                   sb_rows, variant, floor, rows_wg, max(int(k), ksel_w), gstats)
-                ov[bad] = wv
-                oi[bad] = wi
+                ov[rows_of(bad)] = wv
+                oi[rows_of(bad)] = wi
                 bad = bad[wflag != 0]
                 LAST_FILTER_STATS["flagged_after_wide_pass" + ("" if tier == 0 else "_2")] = int(bad.numel())
             LAST_FILTER_STATS["users_on_fp32_fallback"] = int(bad.numel())
@@ -1736,8 +1807,8 @@ def _redo_flagged(uop, iop, blockmax, flag, n_bad, n_sb, k, user_bias, item_bias
         with _timed("topk_filter_fallback"):
             fv, fi = score_topk(uop.f32[bad].contiguous(), iop.f32, DTYPE_F32, kpad, int(k), ub, item_bias, MODE_DOT,
                                 item_index_base=item_index_base, method="two_stage" if n_i >= TWO_STAGE_MIN_ITEMS else "direct")
-        ov[bad] = fv
-        oi[bad] = fi
+        ov[rows_of(bad)] = fv
+        oi[rows_of(bad)] = fi
     return ov, oi
 
 

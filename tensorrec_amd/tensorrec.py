@@ -773,10 +773,28 @@ class TensorRec(object):
             raise ModelNotFitException(method=method)
 
     def _inference(self, user_features=None, item_features=None):
+        """Device copies of the feature matrices of a predict* call.  Matrices whose CONTENT the previous predict* calls
+        uploaded are reused (the fingerprint of ``fit``'s upload cache: xxh3 of the CSR arrays, ~3 ms for 1M identity rows):
+        serving the same catalogue call after call uploads it once."""
         device = self._store.device
-        uf = SparseFeatures(self._single(user_features), device) if user_features is not None else None
-        itf = SparseFeatures(self._single(item_features), device) if item_features is not None else None
-        return uf, itf
+
+        def one(raw):
+            if raw is None:
+                return None
+            m = self._single(raw)
+            key = _fingerprint(m) if self.cache_uploads else None
+            if key is None:
+                return SparseFeatures(m, device)
+            cache = self.__dict__.setdefault('_predict_cache', {})
+            key = (str(device),) + key
+            obj = cache.pop(key, None)
+            if obj is None:
+                obj = SparseFeatures(m, device)
+            cache[key] = obj                              # most recently used last; at most four matrices stay resident
+            while len(cache) > 4:
+                cache.pop(next(iter(cache)))
+            return obj
+        return one(user_features), one(item_features)
 
     def _single(self, raw):
         mats = self._as_list(raw)
@@ -881,11 +899,13 @@ class TensorRec(object):
         return PairRanks(rows, ranks, vals, n_users)
 
     @_on_model_device
-    def predict_top_k(self, user_features, item_features, k=10, user_batch_size=65536, return_device=False,
+    def predict_top_k(self, user_features, item_features, k=10, user_batch_size=None, return_device=False,
                       item_sharded=False, item_offset=0):
         """EXTENSION: the k best items per user -- (scores [n_users, k] float32, item ids [n_users, k] int32),
         ordered like the first k ranks of ``predict_rank`` -- computed by the fused MFMA score + top-k kernel without
-        materialising [n_users, n_items] (which is 4 TB at 1M x 1M).
+        materialising [n_users, n_items] (which is 4 TB at 1M x 1M).  ``user_batch_size`` None (default): as many users per
+        pass as the free device memory holds (ops.topk_user_batch: ~22 KB of workspace per user at 1M items, so 1M users are
+        ONE pass on a 288 GB device -- the per-pass costs of the cascade are paid once).
 
         ``item_sharded=True`` (torch.distributed initialised, one process per GPU): ``item_features`` holds THIS rank's
         rows of the item feature matrix, ``item_offset`` the global id of its first row, ``user_features`` is the same
@@ -929,6 +949,8 @@ class TensorRec(object):
         # which (superblock, user) pairs the bf16 stage has to look at at all (csrc/topk_cascade.hip)
         prefilter = ops.cascade_prefilter_for(self.n_components, n_items_min * (dist.get_world_size(self.process_group) if sharded else 1)) \
             if filtered else None
+        if user_batch_size is None:
+            user_batch_size = ops.topk_user_batch(uf.shape[0], itf.shape[0], self.n_components, self._store.device)
         vals, idx = [], []
         if self.n_components > ops.SCORE_KMAX:
             # wider than the fused kernels' resident operand: score slabs (K-looped fp32 GEMM) + exact ranks pick the top-k
@@ -963,7 +985,7 @@ class TensorRec(object):
                 for user_repr in user_reprs:
                     if filtered:
                         u_f = ops.score_prep_filter(user_repr[s:e], normalize=graph.engine_normalize,
-                                                    sort_users=prefilter == "int8", k=k)
+                                                    sort_users=prefilter == "int8", k=k, user_bias=ub)
                         per_taste.append(ops.score_topk_filtered(u_f, i_f, k, ub, ib, item_index_base=int(item_offset),
                                                                  floor_exchange=floor_exchange,
                                                                  stats_exchange=stats_exchange, prefilter=prefilter))
@@ -1091,6 +1113,7 @@ class TensorRec(object):
         state['_schedule'] = None
         state['_schedule_mirror'] = None
         state['_upload_cache'] = {}
+        state['_predict_cache'] = {}
         state['process_group'] = None
         return state
 

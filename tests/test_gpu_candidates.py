@@ -43,9 +43,13 @@ def dev(a):
 def run(ops, u, v, k, ub=None, ib=None, base=0, **kw):
     dub = dev(ub) if ub is not None else None
     dib = dev(ib) if ib is not None else None
-    uop = ops.score_prep_filter(dev(u), sort_users=True, k=k)
+    uop = ops.score_prep_filter(dev(u), sort_users=True, k=k, user_bias=dub)
     iop = ops.score_prep_filter(dev(v), bias=dib, want_gstats=True)
-    vals, idx = ops.score_topk_filtered(uop, iop, k, dub, dib, item_index_base=base, prefilter="int8", **kw)
+    ops.CANDIDATE_STATS = True                      # (diagnostics: candidates_per_user costs a reduction + a host read)
+    try:
+        vals, idx = ops.score_topk_filtered(uop, iop, k, dub, dib, item_index_base=base, prefilter="int8", **kw)
+    finally:
+        ops.CANDIDATE_STATS = False
     return vals.cpu().numpy(), idx.cpu().numpy(), dict(ops.LAST_FILTER_STATS)
 
 
