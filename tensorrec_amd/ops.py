@@ -202,16 +202,32 @@ def colsum(x):
     return out
 
 
+def _note_row_support(w, feats):
+    """A trainable table multiplied with a sparse feature matrix receives gradient only in the rows that matrix has columns
+    for.  The table remembers WHICH matrices it met this fit call (``w._trec_feats``); the data-parallel fit turns them into
+    the rows this rank can touch and skips the gradient exchange of tables whose row supports are rank-disjoint
+    (TensorRec._dp_make_plan, sharding.plan_gradient_exchange).  Any other use of a table leaves it unmarked: its gradient is
+    exchanged in full."""
+    if isinstance(w, torch.Tensor) and w.requires_grad and w.is_leaf:
+        met = getattr(w, "_trec_feats", None)
+        if met is None:
+            met = w._trec_feats = set()
+        met.add(id(feats))
+
+
 def sparse_dense_matmul(feats: SparseFeatures, w):
     """tf.sparse_tensor_dense_matmul(features, w)"""
+    _note_row_support(w, feats)
     return _SpMM.apply(w, feats)
 
 
 def sparse_dense_matmul_l2norm(feats, w):
+    _note_row_support(w, feats)
     return _SpMMNorm.apply(w, feats)
 
 
 def sparse_dense_matmul_bias_relu(feats, w, bias):
+    _note_row_support(w, feats)
     return _SpMMBiasRelu.apply(w, bias, feats)
 
 
@@ -233,6 +249,7 @@ class _SpMV(torch.autograd.Function):
 
 
 def sparse_matvec(feats, beta):
+    _note_row_support(beta, feats)
     return _SpMV.apply(beta, feats)
 
 
@@ -971,7 +988,7 @@ class FilterOperand(object):
     when it was given to the preparation (``bias_ref``)."""
     __slots__ = ("bf16", "f32", "n", "d", "kpad", "stats", "gstats", "i8", "stats8", "bias_q", "gstats8", "scales",
                  "sb_stats", "sb_rows", "cascade_too_loose", "gmax", "wg_scale", "wg_class", "wg_rows", "pos",
-                 "src", "n_real", "ladder", "class_used", "meta", "bias_sorted", "bias_ref")
+                 "src", "n_real", "ladder", "class_used", "meta", "bias_sorted", "bias_ref", "bias_owner", "__weakref__")
 
     def __init__(self):
         self.i8 = self.stats8 = self.bias_q = self.gstats8 = self.scales = self.sb_stats = self.sb_rows = None
@@ -979,6 +996,7 @@ class FilterOperand(object):
         self.gmax = self.wg_scale = self.wg_class = self.wg_rows = self.pos = self.src = self.n_real = None
         self.ladder = self.class_used = self.meta = self.bias_sorted = self.bias_ref = None
         self.gstats = None
+        self.bias_owner = None              # item side: weak reference to the USER operand its integer biases were derived for
 
     # ---- diagnostics / tests only (each is a torch op or a host sync; nothing on the product path reads them)
     @property
@@ -1192,6 +1210,8 @@ def score_prep_i8_pair(uop, iop, item_bias=None, sb_rows=None, top_k=10):
             if item_bias is not None:
                 N.call("trec_score_prep_i8", None, iop.n, iop.f32.shape[1], iop.kpad, 2, 0.0, sb_rows, N.ptr(item_bias),
                        N.ptr(iop.scales), None, None, None, N.ptr(iop.bias_q), N.ptr(iop.sb_stats), N.ptr(iop.gstats8))
+    import weakref
+    iop.bias_owner = weakref.ref(uop)       # the integer item biases (and sb_stats[:, 3]) belong to THIS batch's user scales
     return uop, iop
 
 
@@ -1258,7 +1278,10 @@ def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, 
     n_u, n_i, kpad = uop.n, iop.n, uop.kpad
     kk = int(k)
     top_k = 10 if kk <= 10 else 16
-    if uop.i8 is None or iop.i8 is None or iop.sb_rows != sb_rows:
+    # (the item rows are quantised once per catalogue; the integer item biases are in units of the USERS' scale products, so
+    # every user batch derives them again -- a class-sorted user operand brings its own int8 rows, which says nothing about
+    # whose scales the item side's tables were made for)
+    if uop.i8 is None or iop.i8 is None or iop.sb_rows != sb_rows or iop.bias_owner is None or iop.bias_owner() is not uop:
         score_prep_i8_pair(uop, iop, item_bias, sb_rows, top_k)
     gstats8 = iop.gstats8
     if stats_exchange is not None:                  # max |item bias| over ALL shards enters every user's bound: the same number
@@ -1567,7 +1590,7 @@ def _score_topk_filtered_pipelined(uop, iop, k, user_bias, item_bias, item_index
     a second one -- next to the following batch's int8 stage.  The flagged users of all batches are re-done at the end."""
     sb_rows = int(sb_rows or SUPERBLOCK_ROWS)
     top_k = 10 if int(k) <= 10 else 16
-    if uop.i8 is None or iop.i8 is None or iop.sb_rows != sb_rows:
+    if uop.i8 is None or iop.i8 is None or iop.sb_rows != sb_rows or iop.bias_owner is None or iop.bias_owner() is not uop:
         score_prep_i8_pair(uop, iop, item_bias, sb_rows, top_k)          # ONCE for all batches (the classes in use, the item biases)
     dev = uop.bf16.device
     main = torch.cuda.current_stream()
@@ -1583,6 +1606,7 @@ def _score_topk_filtered_pipelined(uop, iop, k, user_bias, item_bias, item_index
     for b in range(n_batches):
         r0, r1 = bounds[b], bounds[b + 1]
         sub = _rows_of(uop, r0, r1)
+        iop.bias_owner = __import__("weakref").ref(sub)         # (the tables made for the whole operand serve its row ranges)
         ub = user_bias[r0:r1] if user_bias is not None else None
         parts.append(_score_topk_filtered(sub, iop, k, ub, item_bias, item_index_base, sb_rows, variant, n_chunks, None, None,
                                           ksel, "int8", tail_stream=tail))

@@ -153,6 +153,9 @@ def _on_model_device(method):
 class TensorRec(object):
     cache_uploads = True          # defaults for objects unpickled from before these attributes existed
     _upload_cache = {}
+    dp_sync_every_call = True
+    _dp_plan = _dp_prev_plan = _dp_batches = None
+    _dp_stale_rows = _dp_stale_slots = False
 
 
     def __init__(self,
@@ -172,7 +175,8 @@ class TensorRec(object):
                  data_parallel=False,
                  process_group=None,
                  hip_graphs=True,
-                 deterministic=False):
+                 deterministic=False,
+                 dp_sync_every_call=True):
         """
         A TensorRec recommendation model (arguments as tensorrec/tensorrec.py:28-61).
         :param precision: 'fp32' (default; exact float32 results: fp32 MFMA, or -- top-k on large catalogues -- the bf16
@@ -191,6 +195,13 @@ class TensorRec(object):
         equals the single-process step on the union of the shards (the reference's ``user_batch_size=None`` case).
         Needs ``seed`` (identical initial weights on every rank) and a loss that is a per-interaction vector (the
         WMRB family); see sharding.py.
+        :param dp_sync_every_call: data-parallel fit only.  Tables whose gradient rows are rank-disjoint (identity / one-hot
+        user features under user sharding) are stepped by their owner alone, with NO exchange per step; the other ranks'
+        copies of those rows are refreshed by one broadcast round at the END of every ``fit_partial`` call -- every rank is
+        inside the call then, so a later predict / get_weights on one rank alone sees current weights.  False: the refresh is
+        left to an explicit ``dp_sync()`` (a collective: every rank must call it) -- for loops of one-epoch ``fit_partial``
+        calls.  The Adam slots of rows a rank does not own are only brought together when a fit call changes the row ownership,
+        or by ``dp_sync(optimizer_state=True)`` (needed before ``save_model``).
         :param hip_graphs: capture the forward + backward of a small, launch-bound training step in a HIP graph after its
         first eager execution and replay it for the remaining epochs of a ``fit`` call (the sampler and the optimiser
         stay outside the graph: their step counters change every step).  Large steps run eagerly either way.
@@ -235,6 +246,10 @@ class TensorRec(object):
         self.process_group = process_group
         self.hip_graphs = bool(hip_graphs)
         self.deterministic = bool(deterministic)
+        self.dp_sync_every_call = bool(dp_sync_every_call)
+        self._dp_plan = None              # sharding.GradPlan of the latest fit call (data-parallel fit)
+        self._dp_stale_rows = False       # rows of rank-disjoint tables in this replica wait for their owners' values
+        self._dp_stale_slots = False      # ... and Adam slots of rows this rank does not own (needed by save_model / a new plan)
         self.cache_uploads = True          # reuse device copies of matrices whose content did not change between fit calls
         self._upload_cache = {}
         if self.data_parallel and seed is None:
@@ -536,8 +551,21 @@ class TensorRec(object):
         self._graph_pool_owner = []          # graphs captured by this call (they share the first one's memory pool)
         # (thread-local, previous mode restored on exit: two models fitting in different threads do not switch each other's
         # grouping, and a predict_top_k elsewhere keeps the counting sort -- ADVICE r2)
+        dp = self._dp_active()
+        if dp:
+            # the exchange plan of this call is made at its first step, from the feature matrices the variables meet there
+            self._dp_batches = dev_batches
+            for var in self._store.variables.values():
+                var._trec_feats = None
+            if getattr(self, "_dp_stale_rows", False):
+                self.dp_sync()                          # (a previous call left rows to their owners: start from equal weights)
+            self._dp_prev_plan, self._dp_plan = getattr(self, "_dp_plan", None), None
         with ops.deterministic_grouping(bool(getattr(self, "deterministic", False))):
             self._run_epochs(epochs, dev_batches, graphed, learning_rate, alpha, batched_alpha, n_sampled_items, verbose)
+        if dp:
+            self._dp_batches = None
+            if getattr(self, "dp_sync_every_call", True):
+                self.dp_sync()
 
     def _run_epochs(self, epochs, dev_batches, graphed, learning_rate, alpha, batched_alpha, n_sampled_items, verbose):
         for epoch in range(epochs):
@@ -726,18 +754,7 @@ class TensorRec(object):
         loss_graph = self.loss_graph_factory
 
         if self._dp_active():
-            # data-parallel over users: the objective is a sum over interactions, so the gradient of the union batch is
-            # the sum of the shard gradients -- ONE all-reduce per weight tensor (RCCL over xGMI), plus the loss length
-            from . import sharding
-            if basic_loss.dim() == 0:
-                raise NotImplementedError("data-parallel fit needs a loss that is a per-interaction vector (WMRB "
-                                          "family); %s returns a scalar" % type(loss_graph).__name__)
-            n_loss = sharding.all_reduce_scalar(n_loss, self._store.device, self.process_group)
-            for name in self._store.order:
-                var = self._store.variables[name]
-                if var.grad is None:
-                    var.grad = torch.zeros_like(var)
-            sharding.all_reduce_sum_([self._store.variables[n].grad for n in self._store.order], self.process_group)
+            return self._dp_apply_gradients(basic_loss, pred_serial, weights, n_loss, learning_rate, alpha, want_stats)
 
         reg_ids = set(id(w) for w in weights)
         if self._capture is not None:
@@ -766,6 +783,161 @@ class TensorRec(object):
                 wr = float(sum(0.5 * float((w.detach() ** 2).sum()) for w in weights))
             return basic_loss.detach(), pred_serial.detach(), wr
         return None, None, None
+
+    # ------------------------------------------------------------------------------------------ data-parallel step
+    def _dp_make_plan(self):
+        """The gradient-exchange plan of this fit call (sharding.plan_gradient_exchange; a COLLECTIVE, at the call's first
+        step): a variable that met only this call's user (or item) feature matrices -- sparse_dense_matmul / sparse_matvec
+        mark it -- can receive gradient only in the rows those matrices have columns for, over ALL of the call's batches."""
+        from . import sharding
+        store = self._store
+        batches = getattr(self, "_dp_batches", None) or []
+        supports = {}
+        if batches:
+            uf0, itf0 = id(batches[0][1]), id(batches[0][2])
+            for name in store.order:
+                met = getattr(store.variables[name], "_trec_feats", None)
+                if not met or not met <= {uf0, itf0}:
+                    continue
+                ranges = [b[1].col_range for b in batches] if uf0 in met else []
+                ranges += [b[2].col_range for b in batches] if itf0 in met else []
+                ranges = [r for r in ranges if r[1] > r[0]]
+                supports[name] = (min(r[0] for r in ranges), max(r[1] for r in ranges)) if ranges else (0, 0)
+        shapes = {name: tuple(store.variables[name].shape) for name in store.order}
+        plan = sharding.plan_gradient_exchange(store.order, shapes, supports, store.device, self.process_group)
+        # the marks are structural, the check is not: a gradient outside the claimed rows (a table ALSO used some other way)
+        # would be lost silently -- one look at the first step's gradients, once per call; the ranks agree on the outcome and
+        # such a table is exchanged in full
+        names = [n for n in store.order if plan.mode[n] == "disjoint"]
+        if names:
+            bad = torch.zeros((len(names),), dtype=torch.float32, device=store.device)
+            for j, name in enumerate(names):
+                g, (lo, hi) = store.variables[name].grad, supports[name]
+                if g is not None:
+                    bad[j] = float(bool(g[:lo].any().item()) or bool(g[hi:].any().item()))
+            bad = sharding.all_reduce_max(bad, self.process_group).cpu().numpy()
+            if bad.any():
+                for j, name in enumerate(names):
+                    if bad[j]:
+                        supports.pop(name)
+                plan = sharding.plan_gradient_exchange(store.order, shapes, supports, store.device, self.process_group)
+        # Adam slots left with their owners under ANOTHER ownership: bring them together (under the old plan) first
+        prev = getattr(self, "_dp_prev_plan", None)
+        if prev is not None and prev.key != plan.key and getattr(self, "_dp_stale_slots", False):
+            self._dp_plan = prev
+            self.dp_sync(optimizer_state=True)
+        self._dp_prev_plan = None
+        return plan
+
+    def _dp_apply_gradients(self, basic_loss, pred_serial, weights, n_loss, learning_rate, alpha, want_stats):
+        """One optimiser step of the user-sharded fit (sharding.py, "gradient exchange"): the objective is a sum over
+        interactions, so the union batch's gradient is the sum of the shard gradients.  Rank-disjoint tables: no exchange, the
+        owner steps its rows.  Large shared tables: reduce-scatter -> Adam on the owned rows -> all-gather, the exchange in
+        flight (RCCL's stream) while the other tables are stepped.  Small tensors: all-reduce + the same Adam everywhere."""
+        import torch.distributed as dist
+        from . import sharding
+        loss_graph = self.loss_graph_factory
+        if basic_loss.dim() == 0:
+            raise NotImplementedError("data-parallel fit needs a loss that is a per-interaction vector (WMRB "
+                                      "family); %s returns a scalar" % type(loss_graph).__name__)
+        store, group = self._store, self.process_group
+        for name in store.order:
+            var = store.variables[name]
+            if var.grad is None:
+                var.grad = torch.zeros_like(var)
+        if self._dp_plan is None:
+            self._dp_plan = self._dp_make_plan()
+        plan = self._dp_plan
+        rank = dist.get_rank(group)
+        n_loss = sharding.all_reduce_scalar(n_loss, store.device, group)
+        if self._capture is not None:                       # (tests: the LOCAL gradients, before any exchange)
+            self._capture['loss'] = basic_loss.detach().cpu().numpy().copy()
+            self._capture['pred_serial'] = pred_serial.detach().cpu().numpy().copy()
+            self._capture['grads'] = {n: v.grad.detach().cpu().numpy().copy() for n, v in store.variables.items()}
+        self._opt_step += 1
+        lr_t = _adam_lr_t(learning_rate, self._opt_step)
+        l2 = float(np.float32(np.float32(n_loss) * np.float32(alpha)))
+        reg_ids = set(id(w) for w in weights)
+        # ---- the exchanges leave first
+        pending = {}
+        for name in store.order:
+            var = store.variables[name]
+            if plan.mode[name] == "sharded":
+                pending[name] = sharding.reduce_scatter_rows(var.grad, plan.bounds[name], rank, group, async_op=True)
+            elif plan.mode[name] == "replicated" and sharding.active(group):
+                pending[name] = (var.grad, dist.all_reduce(var.grad, op=dist.ReduceOp.SUM, group=group, async_op=True))
+
+        def step(name, lo=None, hi=None, grad=None):
+            var = store.variables[name]
+            if name not in self._adam:
+                self._adam[name] = (torch.zeros_like(var), torch.zeros_like(var))
+            m, v = self._adam[name]
+            w = var.detach()
+            if lo is not None:
+                w, m, v = w[lo:hi], m[lo:hi], v[lo:hi]
+            if w.numel():
+                ops.adam_tf_step(w, m, v, grad, lr_t, l2 if id(var) in reg_ids else 0.0, ADAM_BETA1, ADAM_BETA2, ADAM_EPSILON)
+
+        # ---- tables that need nobody: the owner steps its rows
+        with torch.no_grad():
+            for name in store.order:
+                if plan.mode[name] == "disjoint":
+                    lo, hi = plan.own[name]
+                    step(name, lo, hi, store.variables[name].grad[lo:hi])
+                    self._dp_stale_rows = self._dp_stale_slots = True
+            gathers = []
+            for name in store.order:
+                if name not in pending:
+                    if plan.mode[name] == "replicated":
+                        step(name, grad=store.variables[name].grad)
+                    continue
+                grad, work = pending[name]
+                if work is not None:
+                    work.wait()
+                if plan.mode[name] == "replicated":
+                    step(name, grad=grad)
+                else:
+                    lo, hi = plan.own[name]
+                    step(name, lo, hi, grad)
+                    gathers.append(sharding.all_gather_rows(store.variables[name].detach(), plan.bounds[name], rank, group,
+                                                            async_op=True))
+                    self._dp_stale_slots = True               # (the Adam slots of the rows this rank does not own)
+            for work in gathers:
+                if work is not None:
+                    work.wait()
+        for var in store.variables.values():
+            var.grad = None
+        if want_stats:
+            self.dp_sync()
+            with torch.no_grad():
+                wr = float(sum(0.5 * float((w.detach() ** 2).sum()) for w in weights))
+            return basic_loss.detach(), pred_serial.detach(), wr
+        return None, None, None
+
+    @_on_model_device
+    def dp_sync(self, optimizer_state=False):
+        """Data-parallel fit: bring this replica's copy of the rows other ranks own up to date -- the weights of rank-disjoint
+        tables (one broadcast per owner); with ``optimizer_state`` also every Adam slot a rank stepped alone (rank-disjoint and
+        sharded tables).  A COLLECTIVE over the model's process group: every rank must call it.  ``fit_partial`` calls it at its
+        end unless ``dp_sync_every_call=False``; ``save_model`` needs ``dp_sync(optimizer_state=True)`` first."""
+        from . import sharding
+        plan = getattr(self, "_dp_plan", None)
+        if plan is None or not sharding.active(self.process_group):
+            self._dp_stale_rows = self._dp_stale_slots = False
+            return
+        store = self._store
+        for name in store.order:
+            mode = plan.mode.get(name)
+            tensors = []
+            if mode == "disjoint" and self._dp_stale_rows:
+                tensors.append(store.variables[name].detach())
+            if mode in ("disjoint", "sharded") and optimizer_state and self._dp_stale_slots and name in self._adam:
+                tensors += list(self._adam[name])
+            if tensors:
+                sharding.sync_owned_rows(tensors, plan.bounds[name], self.process_group)
+        self._dp_stale_rows = False
+        if optimizer_state:
+            self._dp_stale_slots = False
 
     # ------------------------------------------------------------------------------------------ predict
     def _check_fit(self, method):
@@ -1114,6 +1286,9 @@ class TensorRec(object):
         state['_schedule_mirror'] = None
         state['_upload_cache'] = {}
         state['_predict_cache'] = {}
+        state['_dp_plan'] = None
+        state['_dp_prev_plan'] = None
+        state['_dp_batches'] = None
         state['process_group'] = None
         return state
 
@@ -1123,6 +1298,9 @@ class TensorRec(object):
         object: hyper-parameters and graph objects) and ``tensorrec_session.npz`` (every variable, its Adam slots and
         the step counters -- what the TF checkpoint holds in the reference)."""
         self._check_fit('save_model')
+        if getattr(self, "_dp_stale_rows", False) or getattr(self, "_dp_stale_slots", False):
+            raise RuntimeError("data-parallel fit left rows / Adam slots with the ranks that own them: call "
+                               "model.dp_sync(optimizer_state=True) on EVERY rank before save_model")
         if not os.path.exists(directory_path):
             os.makedirs(directory_path)
         arrays = {}

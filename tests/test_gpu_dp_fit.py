@@ -13,13 +13,15 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 
-def _data():
+def _data(identity_users=False):
     rng = np.random.RandomState(0)
     n_u, n_i = 70, 120
     inter = sp.random(n_u, n_i, density=0.08, random_state=rng, format="csr", dtype=np.float32)
     inter.data[:] = 1.0
     uf = sp.hstack([sp.identity(n_u, format="csr", dtype=np.float32),
                     sp.random(n_u, 9, density=0.3, random_state=rng, format="csr", dtype=np.float32)], format="csr")
+    if identity_users:               # one-hot user features: under user sharding the user tables' gradient rows are rank-disjoint
+        uf = sp.identity(n_u, format="csr", dtype=np.float32)
     itf = sp.identity(n_i, format="csr", dtype=np.float32)
     return inter, uf, itf
 
@@ -42,17 +44,25 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, bounds, ret, kind="linear"):
+def _worker(rank, world, port, bounds, ret, kind="linear", identity_users=False, min_numel=None, calls=1):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        inter, uf, itf = _data()
+        from tensorrec_amd import sharding
+        if min_numel is not None:
+            sharding.SHARD_MIN_NUMEL = min_numel
+        inter, uf, itf = _data(identity_users)
         b, e = bounds[rank], bounds[rank + 1]
         model = _model(True, kind)
-        model.fit(inter[b:e], uf[b:e], itf, epochs=3, learning_rate=0.05, n_sampled_items=20, user_offset=b)
-        ret[rank] = model.get_weights()
+        for _ in range(calls):
+            model.fit_partial(inter[b:e], uf[b:e], itf, epochs=3 // calls, learning_rate=0.05, n_sampled_items=20, user_offset=b)
+        out = model.get_weights()
+        out["__plan__"] = dict(model._dp_plan.mode)
+        model.dp_sync(optimizer_state=True)
+        out["__adam_m_item__"] = model._adam["linear_weights_item"][0].cpu().numpy() if "linear_weights_item" in model._adam else None
+        ret[rank] = out
     finally:
         dist.destroy_process_group()
 
@@ -79,6 +89,37 @@ def test_two_rank_fit_equals_single_process_fit():
         assert np.allclose(ret[0][k], v, rtol=2e-3, atol=5e-3), "%s: %g" % (k, np.abs(ret[0][k] - v).max())
     moved = np.abs(ref["linear_weights_item"] - _initial("linear_weights_item")).max()
     assert moved > 0.05          # the comparison above is not trivially true: weights did move
+
+
+@pytest.mark.parametrize("calls", [1, 3])
+def test_two_rank_fit_rank_disjoint_and_sharded_tables(calls):
+    """Identity user features: the user table and the user biases receive gradient only in a rank's own rows -- no exchange, the
+    owner steps them (sharding "disjoint"); the item table is reduce-scattered, stepped by row range and all-gathered
+    ("sharded": the threshold is lowered for this toy size); the item biases stay all-reduced.  The replicas are identical
+    after the end-of-call sync and equal the single-process fit on the union batch; also as three one-epoch calls."""
+    inter, uf, itf = _data(identity_users=True)
+    single = _model(False)
+    single.fit(inter, uf, itf, epochs=3, learning_rate=0.05, n_sampled_items=20)
+    ref = single.get_weights()
+    ref_m = single._adam["linear_weights_item"][0].cpu().numpy()
+    mgr = mp.get_context("spawn").Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), [0, 41, 70], ret, "linear", True, 1000, calls), nprocs=2, join=True)
+    assert sorted(ret.keys()) == [0, 1]
+    plan = ret[0]["__plan__"]
+    assert plan["linear_weights_user_0"] == "disjoint" and plan["user_feature_biases"] == "disjoint"
+    assert plan["linear_weights_item"] == "sharded" and plan["item_feature_biases"] == "replicated"
+    for k, v in ref.items():
+        assert np.array_equal(ret[0][k], ret[1][k]), "ranks diverged on %s" % k
+        if k == "user_feature_biases":
+            assert np.abs(ret[0][k]).max() <= 3 * 0.05 + 1e-6
+            continue
+        assert np.allclose(ret[0][k], v, rtol=2e-3, atol=5e-3), "%s: %g" % (k, np.abs(ret[0][k] - v).max())
+    # the user table is stepped from ONE rank's gradient: the same sums as the single process makes -> tight agreement
+    assert np.allclose(ret[0]["linear_weights_user_0"], ref["linear_weights_user_0"], rtol=1e-5, atol=1e-6)
+    # the Adam slots come together on request
+    assert np.array_equal(ret[0]["__adam_m_item__"], ret[1]["__adam_m_item__"])
+    assert np.allclose(ret[0]["__adam_m_item__"], ref_m, rtol=1e-3, atol=1e-5)
 
 
 def test_two_rank_fit_relu_euclidean_wmrb():

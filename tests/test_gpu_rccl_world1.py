@@ -75,6 +75,22 @@ def _worker(rank, port, ret):
         w_dp, w_plain = fit(True), fit(False)
         # (same sums in the same order except that the DP step keeps loss and L2 gradients apart until after the all-reduce)
         out["dp_fit_equals_plain"] = bool(all(np.allclose(w_dp[k], w_plain[k], rtol=1e-4, atol=1e-6) for k in w_plain))
+        # ... and with every exchange form of the gradient plan on RCCL: a ReLU tower's dense layers are untagged -> with the
+        # threshold lowered they are reduce-scattered (reduce_scatter_tensor), stepped by row range and all-gathered IN PLACE
+        # (all_gather_into_tensor); the tables multiplied with features are "disjoint" (no exchange; broadcast at the end)
+        sharding.SHARD_MIN_NUMEL = 64
+
+        def fit_relu(dp):
+            m = T.TensorRec(n_components=16, user_repr_graph=T.representation_graphs.ReLURepresentationGraph(),
+                            loss_graph=T.loss_graphs.WMRBLossGraph(), seed=3, data_parallel=dp, deterministic=True)
+            m.fit(inter, uf, itf2, epochs=2, learning_rate=0.05, n_sampled_items=20)
+            modes = dict(m._dp_plan.mode) if dp else None
+            if dp:
+                m.dp_sync(optimizer_state=True)
+            return m.get_weights(), modes
+        (w_dp, modes), (w_plain, _) = fit_relu(True), fit_relu(False)
+        out["dp_plan_modes"] = sorted(set(modes.values()))
+        out["dp_relu_fit_equals_plain"] = bool(all(np.allclose(w_dp[k], w_plain[k], rtol=1e-4, atol=1e-6) for k in w_plain))
         ret.update(out)
     finally:
         dist.destroy_process_group()
@@ -91,3 +107,5 @@ def test_every_collective_runs_through_rccl_at_world_size_one():
     assert ret["sharded_predict_equals_plain"], ret
     assert str(ret["sharded_stage1"]).startswith("int8"), ret
     assert ret["dp_fit_equals_plain"], ret
+    assert "sharded" in ret["dp_plan_modes"] and "disjoint" in ret["dp_plan_modes"], ret
+    assert ret["dp_relu_fit_equals_plain"], ret

@@ -170,3 +170,91 @@ def test_gradient_all_reduce_helpers_over_gloo():
     ret = mgr.dict()
     mp.spawn(_dp_worker, args=(2, port, ret), nprocs=2, join=True)
     assert dict(ret) == {0: "ok", 1: "ok"}
+
+
+# ---- the gradient exchange of the data-parallel fit (sharding.plan_gradient_exchange and its collectives) --------------------
+def _exchange_worker(rank, world, port, ret):
+    """Three tables over 3 optimiser steps: A -- rank-disjoint row supports in rank order (identity user features under user
+    sharding) -> no exchange, the owner steps its rows; B -- every rank touches every row (the item table) -> reduce-scatter /
+    owned-rows Adam / all-gather; C -- small -> all-reduce + the same Adam everywhere.  Against ONE process stepping the summed
+    gradients (the oracle's TF-form Adam on both sides): bit-identical at world 2 (a + b commutes), to rounding at world 3."""
+    from oracle import oracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        old_min = sharding.SHARD_MIN_NUMEL
+        sharding.SHARD_MIN_NUMEL = 1000
+        rows_a, rows_b, d = 101, 67, 16                                  # 67 rows do not divide by 2 or 3: the padded forms
+        cuts = [0] + [int(rows_a * (r + 1) / world) - (3 if r + 1 < world else 0) for r in range(world)]   # gaps of untouched rows
+        sup_a = (cuts[rank] + (2 if rank else 0), cuts[rank + 1])
+        names = ["A", "B", "C"]
+        shapes = {"A": (rows_a, d), "B": (rows_b, d), "C": (7, 1)}
+        plan = sharding.plan_gradient_exchange(names, shapes, {"A": sup_a}, "cpu")
+        assert plan.mode == {"A": "disjoint", "B": "sharded", "C": "replicated"}
+        assert plan.bounds["A"][0] == 0 and plan.bounds["A"][-1] == rows_a and plan.own["A"][0] <= sup_a[0] and sup_a[1] <= plan.own["A"][1]
+        assert plan.bounds["B"][-1] == rows_b and len(plan.bounds["B"]) == world + 1
+        wire = plan.wire_bytes_per_step(shapes)
+        assert wire["A"] == 0 and wire["B"] == 2.0 * (world - 1) / world * rows_b * d * 4
+        # overlapping or out-of-order supports are NOT disjoint
+        p2 = sharding.plan_gradient_exchange(["A"], shapes, {"A": (0, rows_a)}, "cpu")
+        assert p2.mode["A"] == "sharded"
+        p3 = sharding.plan_gradient_exchange(["A"], shapes, {"A": (cuts[world - 1 - rank], cuts[world - rank])}, "cpu")
+        assert p3.mode["A"] == ("sharded" if world > 1 else "disjoint")
+        rng = np.random.default_rng(5)                                   # same stream on every rank: all ranks' gradients known
+        w = {n: rng.standard_normal(shapes[n]).astype(np.float32) for n in names}
+        ref = {n: (w[n].copy(), np.zeros(shapes[n], np.float32), np.zeros(shapes[n], np.float32)) for n in names}
+        mine = {n: (torch.from_numpy(w[n].copy()), torch.zeros(shapes[n]), torch.zeros(shapes[n])) for n in names}
+        for step in range(3):
+            grads = []
+            for r in range(world):
+                g = {n: rng.standard_normal(shapes[n]).astype(np.float32) for n in names}
+                lo, hi = cuts[r] + (2 if r else 0), cuts[r + 1]
+                g["A"][:lo] = 0
+                g["A"][hi:] = 0
+                grads.append(g)
+            lr_t = 0.05 * (step + 1)
+            for n in names:                                              # the single process: sum in rank order, dense Adam
+                total = grads[0][n].copy()
+                for r in range(1, world):
+                    total = total + grads[r][n]
+                O.adam_tf_step(ref[n][0], ref[n][1], ref[n][2], total, lr_t)
+            g_mine = {n: torch.from_numpy(grads[rank][n].copy()) for n in names}
+            own_b, work = sharding.reduce_scatter_rows(g_mine["B"], plan.bounds["B"], rank, async_op=True)
+            work_c = dist.all_reduce(g_mine["C"], async_op=True)
+            lo, hi = plan.own["A"]
+            wa, ma, va = (t.numpy()[lo:hi] for t in mine["A"])
+            O.adam_tf_step(wa, ma, va, g_mine["A"].numpy()[lo:hi], lr_t)
+            work_c.wait()
+            O.adam_tf_step(*(t.numpy() for t in mine["C"]), g_mine["C"].numpy(), lr_t)
+            if work is not None:
+                work.wait()
+            lo, hi = plan.own["B"]
+            wb, mb, vb = (t.numpy()[lo:hi] for t in mine["B"])
+            O.adam_tf_step(wb, mb, vb, own_b.numpy(), lr_t)
+            sharding.all_gather_rows(mine["B"][0], plan.bounds["B"], rank)
+        # before the sync: the owned rows are right, A's other rows are stale
+        lo, hi = plan.own["A"]
+        exact = world == 2
+        same = (lambda a, b: np.array_equal(a, b)) if exact else (lambda a, b: np.allclose(a, b, rtol=1e-5, atol=1e-6))
+        assert np.array_equal(mine["A"][0].numpy()[lo:hi], ref["A"][0][lo:hi])          # (disjoint rows: one contributor, always exact)
+        assert same(mine["B"][0].numpy(), ref["B"][0]) and same(mine["C"][0].numpy(), ref["C"][0])
+        sharding.sync_owned_rows(list(mine["A"]), plan.bounds["A"])
+        sharding.sync_owned_rows(list(mine["B"][1:]), plan.bounds["B"])
+        for n in names:
+            for j in range(3):
+                assert same(mine[n][j].numpy(), ref[n][j]), (n, j)
+        assert np.array_equal(mine["A"][0].numpy(), ref["A"][0])
+        sharding.SHARD_MIN_NUMEL = old_min
+        ret[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gradient_exchange_plan_and_step_equivalence_over_gloo(world):
+    port = _free_port()
+    mgr = mp.get_context("spawn").Manager()
+    ret = mgr.dict()
+    mp.spawn(_exchange_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert dict(ret) == {r: "ok" for r in range(world)}
