@@ -516,6 +516,15 @@ int trec_wmrb_fused_step(const float* U, const float* V, const float* user_bias,
                          float* d_user_bias, float* coef_samples, float* coef_pairs, int32_t* sample_hist,
                          int32_t* sample_rank, void* stream);
 /* RMSE, loss_graphs.py:58-59 */
+/* Dense and separation losses (csrc/loss_dense.hip) -- tensorrec/loss_graphs.py:62-72 (RMSEDense), :75-97 (Separation), :100-134
+ * (SeparationDense) as streaming reductions: kind 0 = Separation over the serial predictions (pred [n_pairs], values [n_pairs],
+ * rows = n_pairs, cols = 1, no indices), 1 = SeparationDense, 2 = RMSEDense (pred [rows, cols] contiguous; xu / xi / values = the
+ * interactions, one entry per cell).  st: double[16] statistics kept for the backward pass; loss: float[1].
+ * trec_dense_loss_bwd: d loss / d pred (same shape as pred) times the upstream gradient gl[0]. */
+int trec_dense_loss_fwd(int32_t kind, const float* pred, int64_t rows, int64_t cols, const int32_t* xu, const int32_t* xi,
+                        const float* values, int64_t n_pairs, double* st, float* loss, void* stream);
+int trec_dense_loss_bwd(int32_t kind, const float* pred, int64_t rows, int64_t cols, const int32_t* xu, const int32_t* xi,
+                        const float* values, int64_t n_pairs, const double* st, const float* gl, float* d_pred, void* stream);
 int trec_rmse_fwd(const float* y, const float* pred, int64_t n, float* partial_ws, int32_t n_partial, float* loss,
                   void* stream);
 int trec_rmse_bwd(const float* y, const float* pred, const float* loss, const float* grad_loss, int64_t n,

@@ -123,6 +123,8 @@ SIGNATURES = {
     "trec_wmrb_fused_lds_bytes": [_i32, _i32, _i32],
     "trec_wmrb_fused_step": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp,
                              _vp, _vp, _vp, _vp, _vp],
+    "trec_dense_loss_fwd": [_i32, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp],
+    "trec_dense_loss_bwd": [_i32, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp],
     "trec_rmse_fwd": [_vp, _vp, _i64, _vp, _i32, _vp, _vp],
     "trec_rmse_bwd": [_vp, _vp, _vp, _vp, _i64, _vp, _vp],
     "trec_sample_items": [_i64, _i64, _i32, _i32, _i32, _u64, _u32, _vp, _vp],

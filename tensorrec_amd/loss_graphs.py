@@ -8,8 +8,6 @@ scalar OR a vector; the trainer differentiates the SUM of ``loss + alpha * reg``
 """
 import abc
 
-import torch
-
 from . import ops
 
 
@@ -45,48 +43,32 @@ class RMSELossGraph(AbstractLossGraph):
 
 
 class RMSEDenseLossGraph(AbstractLossGraph):
-    """RMSE against the dense interaction matrix, non-interacted pairs counting as 0 (loss_graphs.py:62-72)."""
+    """RMSE against the dense interaction matrix, non-interacted pairs counting as 0 (loss_graphs.py:62-72): one streaming
+    reduction over the [n_users, n_items] predictions plus a gather over the interactions (csrc/loss_dense.hip) -- the dense
+    interaction matrix of ``tf.sparse_add`` is never built."""
     is_dense = True
 
     def connect_loss_graph(self, tf_interactions, tf_prediction, **kwargs):
-        error = -1.0 * tf_prediction
-        flat = error.reshape(-1)
-        lin = tf_interactions.x_user * tf_prediction.shape[1] + tf_interactions.x_item
-        flat = flat.index_add(0, lin, tf_interactions.values)          # tf.sparse_add(interactions, -prediction)
-        return torch.sqrt(torch.mean(flat * flat))
-
-
-def _separation(pos, neg):
-    """1 - Normal(neg_mean - pos_mean, sqrt(neg_var + pos_var)).cdf(0)  (loss_graphs.py:90-96); tf.nn.moments is
-    the population variance."""
-    pos_mean, neg_mean = pos.mean(), neg.mean()
-    pos_var = ((pos - pos_mean) ** 2).mean()
-    neg_var = ((neg - neg_mean) ** 2).mean()
-    loc = neg_mean - pos_mean
-    scale = torch.sqrt(neg_var + pos_var)
-    cdf0 = 0.5 * (1.0 + torch.erf((0.0 - loc) / (scale * 1.4142135623730951)))
-    return 1.0 - cdf0
+        return ops.rmse_dense_loss(tf_prediction, tf_interactions)
 
 
 class SeparationLossGraph(AbstractLossGraph):
-    """Overlap of the normal fits of positive and non-positive interaction predictions (loss_graphs.py:75-97)."""
+    """Overlap of the normal fits of positive and non-positive interaction predictions (loss_graphs.py:75-97):
+    1 - Normal(mu_neg - mu_pos, sqrt(var_neg + var_pos)).cdf(0) with tf.nn.moments' population variance -- two reduction passes
+    (means, centred second moments) and a closed-form backward pass, no boolean-mask copies."""
 
     def connect_loss_graph(self, tf_prediction_serial, tf_interactions_serial, **kwargs):
-        positive = tf_prediction_serial[tf_interactions_serial > 0.0]
-        negative = tf_prediction_serial[tf_interactions_serial <= 0.0]
-        return _separation(positive, negative)
+        return ops.separation_loss(tf_prediction_serial, tf_interactions_serial)
 
 
 class SeparationDenseLossGraph(AbstractLossGraph):
-    """Separation loss over the dense matrix, non-interacted pairs counting as negatives (loss_graphs.py:100-134)."""
+    """Separation loss over the dense matrix, non-interacted pairs counting as negatives (loss_graphs.py:100-134): the
+    negatives' moments are "all predictions minus the positive interactions'", so neither the dense interaction matrix nor the
+    masks exist."""
     is_dense = True
 
     def connect_loss_graph(self, tf_prediction, tf_interactions, **kwargs):
-        dense = torch.zeros(tf_prediction.shape, dtype=torch.float32, device=tf_prediction.device)
-        dense.index_put_((tf_interactions.x_user, tf_interactions.x_item), tf_interactions.values, accumulate=True)
-        inter_serial = dense.reshape(-1)
-        pred_serial = tf_prediction.reshape(-1)
-        return _separation(pred_serial[inter_serial > 0.0], pred_serial[inter_serial <= 0.0])
+        return ops.separation_dense_loss(tf_prediction, tf_interactions)
 
 
 class WMRBLossGraph(AbstractLossGraph):

@@ -748,6 +748,56 @@ def rmse_loss(pred_serial, interactions_serial):
     return _RMSE.apply(pred_serial, interactions_serial)
 
 
+# ------------------------------------------------------------------------------------------------ dense / separation losses
+DENSE_LOSS_SEPARATION, DENSE_LOSS_SEPARATION_DENSE, DENSE_LOSS_RMSE_DENSE = 0, 1, 2
+
+
+class _DenseLoss(torch.autograd.Function):
+    """RMSEDense / Separation / SeparationDense (loss_graphs.py:62-134) as streaming reductions (csrc/loss_dense.hip): the
+    predictions are read once per pass, the interactions enter as their sparse list, the statistics stay on the device in a
+    double[16] block that the backward kernels read."""
+
+    @staticmethod
+    def forward(ctx, pred, kind, xu32, xi32, values):
+        pred = _f32c(pred)
+        if kind == DENSE_LOSS_SEPARATION:
+            rows, cols = int(pred.numel()), 1
+        else:
+            rows, cols = int(pred.shape[0]), int(pred.shape[1])
+        n_pairs = int(values.numel())
+        st = torch.empty((16,), dtype=torch.float64, device=pred.device)
+        loss = torch.empty((1,), dtype=torch.float32, device=pred.device)
+        N.call("trec_dense_loss_fwd", kind, N.ptr(pred), rows, cols, N.ptr(xu32), N.ptr(xi32), N.ptr(values), n_pairs, N.ptr(st),
+               N.ptr(loss))
+        ctx.save_for_backward(pred, st)
+        ctx.meta = (kind, rows, cols, xu32, xi32, values, n_pairs)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gl):
+        pred, st = ctx.saved_tensors
+        kind, rows, cols, xu32, xi32, values, n_pairs = ctx.meta
+        d_pred = torch.empty_like(pred)
+        N.call("trec_dense_loss_bwd", kind, N.ptr(pred), rows, cols, N.ptr(xu32), N.ptr(xi32), N.ptr(values), n_pairs, N.ptr(st),
+               N.ptr(_f32c(gl).reshape(1)), N.ptr(d_pred))
+        return d_pred, None, None, None, None
+
+
+def separation_loss(pred_serial, interactions_serial):
+    """SeparationLossGraph (loss_graphs.py:75-97): 1 - Normal(mu_n - mu_p, sqrt(var_n + var_p)).cdf(0) over the interactions"""
+    return _DenseLoss.apply(pred_serial.reshape(-1), DENSE_LOSS_SEPARATION, None, None, _f32c(interactions_serial).reshape(-1))
+
+
+def separation_dense_loss(prediction, interactions):
+    """SeparationDenseLossGraph (loss_graphs.py:100-134): the same over every user-item pair, non-positives as negatives"""
+    return _DenseLoss.apply(prediction, DENSE_LOSS_SEPARATION_DENSE, interactions.x_user32, interactions.x_item32, interactions.values)
+
+
+def rmse_dense_loss(prediction, interactions):
+    """RMSEDenseLossGraph (loss_graphs.py:62-72): RMSE against the dense interaction matrix"""
+    return _DenseLoss.apply(prediction, DENSE_LOSS_RMSE_DENSE, interactions.x_user32, interactions.x_item32, interactions.values)
+
+
 # ------------------------------------------------------------------------------------------------ K2 / K4 / K7 / K8
 def score_kpad(d):
     k = N.query("trec_score_kpad", int(d))
@@ -1726,7 +1776,8 @@ def _score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index
             LAST_FILTER_STATS.update({"prefilter": "int8", "refined_rows": cascade_rows, "users": n_u, "flagged_users": n_bad,
                                       "tail": "candidate lists", "candidates_cap": cands.cap})
             if CANDIDATE_STATS:                           # diagnostics (a reduction over the counters + a host read): off the product path
-                LAST_FILTER_STATS["candidates_per_user"] = float(cands.n.clamp(max=cands.cap).sum().item()) / max(1, n_u)
+                LAST_FILTER_STATS["candidates_per_user"] = float(cands.n.clamp(max=cands.cap).sum().item()) / \
+                    max(1, int(uop.n_real or n_u))        # (per real user: the layout's rows without a source list nothing)
             return _redo_flagged(uop, iop, blockmax, flag, n_bad, n_sb, k, user_bias, item_bias, item_index_base, sb_rows,
                                  variant, None, rows_wg, ksel, gstats, ov, oi, out_index)
         cands = blockmax = None

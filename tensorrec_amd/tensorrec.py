@@ -32,7 +32,7 @@ from .errors import (
 )
 from .framework import VariableStore, variable_scope, resolve_device
 from .loss_graphs import (AbstractLossGraph, RMSELossGraph, RMSEDenseLossGraph, WMRBLossGraph,
-                          BalancedWMRBLossGraph)
+                          BalancedWMRBLossGraph, SeparationLossGraph, SeparationDenseLossGraph)
 from .prediction_graphs import AbstractPredictionGraph, DotProductPredictionGraph
 from .recommendation_graphs import (
     project_biases, bias_prediction_dense, bias_prediction_serial, rank_predictions,
@@ -613,9 +613,9 @@ class TensorRec(object):
     def _graph_eligible(self, inter, n_sampled_items, verbose):
         if not self.hip_graphs or self._dp_active() or self._capture is not None or getattr(self, 'deterministic', False):
             return False
-        # only steps made of the library's own launches are captured: the built-in capturable losses on built-in
-        # graphs.  Separation* losses index with boolean masks (a host sync inside the step) and user-defined torch
-        # graphs / losses may do anything -- capturing them would fail, warn and fall back on every fit call.
+        # only steps made of the library's own launches are captured: the built-in losses on built-in graphs.  User-defined
+        # torch graphs / losses may do anything (host syncs, allocations the capture cannot follow) -- capturing them would
+        # fail, warn and fall back on every fit call.
         if type(self.loss_graph_factory) not in _GRAPH_CAPTURABLE_LOSSES or not self._is_engine_graph():
             return False
         if len(self._graph_pool_owner) >= MAX_GRAPHED_BATCHES:
@@ -1352,7 +1352,10 @@ class TensorRec(object):
         return self
 
 
-_GRAPH_CAPTURABLE_LOSSES = (RMSELossGraph, RMSEDenseLossGraph, WMRBLossGraph, BalancedWMRBLossGraph)
+# (every built-in loss is made of this library's launches only: the separation losses lost their boolean-mask host syncs when
+# they became streaming reductions, csrc/loss_dense.hip)
+_GRAPH_CAPTURABLE_LOSSES = (RMSELossGraph, RMSEDenseLossGraph, WMRBLossGraph, BalancedWMRBLossGraph, SeparationLossGraph,
+                            SeparationDenseLossGraph)
 MAX_GRAPHED_BATCHES = 64        # graphs kept alive by one fit call; further batches run eagerly
 
 
