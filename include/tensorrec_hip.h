@@ -367,6 +367,16 @@ int trec_topk_candidates_finish(const int32_t* cand_n, const void* cand, int32_t
 int trec_topk_cascade_floor(float* tau, const int32_t* src, const float* user_stats, const float* user_bias,
                             const float* item_gstats, int32_t kdim, int64_t n_users, float* floor0, int32_t* flag,
                             int32_t* n_flagged, int32_t* cand_n, void* stream);
+/* The exact EUCLIDEAN top-k (tensorrec/prediction_graphs.py:84-100 + tf.nn.top_k of recommendation_graphs.py:73-82) through the
+ * dot-product cascade: per user, nearest = largest g = u.i - r_i / 2, a dot product with item "bias" -r_i / 2.  After the cascade
+ * gave the kc = 16 largest g per user and trec_pair_score_exact their reference-chain scores (biases included),
+ * trec_topk_euclid_certify orders them by (score desc, id asc), writes the first k, and flags the users for whom an item OUTSIDE the
+ * kc could still reach the first k places (score upper bound from the kc-th largest g and the largest item bias; csrc/euclid_topk.hip):
+ * those are re-done on the exact fp32 MFMA path.  item_gstats: trec_score_prep_filter's maxima with bias = -r / 2. */
+int trec_topk_euclid_certify(const int32_t* cand_idx, const float* cand_g, const float* exact, int32_t kc, int32_t k,
+                             const float* user_sq, const float* user_bias, const float* item_gstats, const float* bias_max,
+                             int32_t kdim, int64_t n_users, float* out_vals, int32_t* out_idx, int32_t* flag,
+                             int32_t* n_flagged, void* stream);
 int trec_topk_filter_floor(const float* tau, const float* user_stats, const float* user_bias, const float* item_gstats,
                            int32_t kdim, int64_t n_users, float* floor, int32_t* flag, int32_t* n_flagged, void* stream);
 int trec_topk_collect_blocks(const float* blockmax, int32_t n_sb, int64_t n_users, int64_t stride, const float* floor,

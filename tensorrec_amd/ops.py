@@ -1383,8 +1383,10 @@ def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, 
         tau.masked_fill_(uop.src < 0, float("inf"))     # rows without a source refine nothing (the table-driven tail: A/B reference)
     if one_pass:
         # one pass over the table: a fixed capacity per superblock, slots handed out by atomics (csrc/topk_cascade.hip)
+        # (capacities are fractions of the REAL users: a class-sorted layout of few users is mostly rows without a source)
+        n_cap = int(uop.n_real or n_u)
         rcap_frac = N.load().trec_get_tuning(b"cascade_rcap_pct", int(100 * CASCADE_ROW_CAPACITY)) / 100.0
-        rcap = (int(rcap_frac * n_u) + 511) // 512 * 512 + 512
+        rcap = (int(rcap_frac * n_cap) + 511) // 512 * 512 + 512
         row_user = torch.empty((n_sb * rcap,), dtype=torch.int32, device=dev)      # only the kept pairs' part is touched
         with _timed("topk_rows_compact"):
             N.call("trec_topk_rows_collect", N.ptr(table), n_sb, n_u, stride, N.ptr(tau), N.ptr(user_err),
@@ -1397,7 +1399,7 @@ def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, 
         # are refined for EVERY user by a dense launch over that list; the fixed-capacity launch skips them
         hot_cap = max(8, min(N.load().trec_get_tuning(b"cascade_max_hot", CASCADE_MAX_HOT), n_sb))
         hot_list = torch.empty((hot_cap,), dtype=torch.int32, device=dev)
-        max_pairs = int(N.load().trec_get_tuning(b"cascade_max_refined_pct", int(100 * CASCADE_MAX_REFINED)) / 100.0 * n_sb * n_u)
+        max_pairs = int(N.load().trec_get_tuning(b"cascade_max_refined_pct", int(100 * CASCADE_MAX_REFINED)) / 100.0 * n_sb * n_cap)
         N.call("trec_topk_rows_hot", N.ptr(row_count), n_sb, rcap, n_u, N.ptr(hot_list), hot_cap, max_pairs, N.ptr(status))
         # Everything that does not need the host's decision is queued BEFORE the host reads the status -- behind the int8 launch,
         # while it still runs: the thresholds above, the users the int8 bound says nothing about, the map of the occupied
@@ -1836,6 +1838,11 @@ def _score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index
     ov, oi, count = _filter_tail(uop, iop, blockmax, bm_stride, n_u, n_sb, k, user_bias, item_bias, item_index_base, sb_rows,
                                  variant, ksel, cap, floor, flag, n_flagged, rows_wg, wide=False, keys_count=keys_count)
     # ---- users the filter could not certify (one host read of a counter): a wide second pass, then the exact fp32 MFMA path
+    if uop.src is not None:
+        # (this table-driven tail is the A/B reference of a class-sorted operand: the columns of layout rows without a source --
+        # idle int8 workgroups never wrote them -- may hold anything, NaN included, and get flagged; they have no result)
+        flag.masked_fill_(uop.src < 0, 0)
+        n_flagged = flag.sum().reshape(1)
     n_bad = int(n_flagged.item())
     if cascade_status is not None:
         LAST_FILTER_STATS["prefilter"] = "int8"
@@ -1884,6 +1891,66 @@ def _redo_flagged(uop, iop, blockmax, flag, n_bad, n_sb, k, user_bias, item_bias
                                 item_index_base=item_index_base, method="two_stage" if n_i >= TWO_STAGE_MIN_ITEMS else "direct")
         ov[rows_of(bad)] = fv
         oi[rows_of(bad)] = fi
+    return ov, oi
+
+
+EUCLID_CANDIDATES = 16       # K' of the Euclidean route: the cascade's largest list
+
+
+def score_topk_euclid_filtered(user_repr, item_repr, k, user_bias=None, item_bias=None, item_index_base=0):
+    """EXACT top-k of the Euclidean scores -sqrt(max(r_u - 2 u.i + r_i, 1e-16)) (+ biases) -- prediction_graphs.py:84-100 +
+    recommendation_graphs.py:33-41, :73-82 -- through the DOT-product cascade (csrc/euclid_topk.hip): per user, nearest = largest
+    g = u.i - r_i / 2, so the cascade runs with the item "bias" -r_i / 2 and lists the K' = 16 nearest items; the reference's own
+    chain re-scores those pairs (trec_pair_score_exact: the oracle's bits, biases included); a per-user certificate -- no item
+    outside the 16 can reach the first k places, given the 16th largest g and the largest item bias -- decides whether the first
+    k of them ARE the answer; users without it (item biases outweighing the distance gap, near-ties) are re-done on the exact
+    fp32 MFMA path.  Values and ids are bit-identical to score_topk(..., DTYPE_F32, MODE_EUCLIDEAN) either way.
+    Returns (values [U, k], ids [U, k]); LAST_FILTER_STATS["euclid_uncertified_users"] counts the re-done users."""
+    kk = int(k)
+    if not 1 <= kk <= EUCLID_CANDIDATES - 4:
+        raise ValueError("the filtered Euclidean top-k supports k <= %d" % (EUCLID_CANDIDATES - 4))
+    u = _f32c(user_repr.detach())
+    v = _f32c(item_repr.detach())
+    n_u, d = u.shape
+    n_i = v.shape[0]
+    dev = u.device
+    u32, u_sq, kpad = score_prep(u, DTYPE_F32, want_sqnorm=True)
+    i32, i_sq, _ = score_prep(v, DTYPE_F32, want_sqnorm=True)
+    c = i_sq * -0.5                                                   # exact halving: the item "bias" of the g ordering
+    prefilter = cascade_prefilter_for(d, n_i)
+    u_f = score_prep_filter(u, sort_users=prefilter == "int8", k=EUCLID_CANDIDATES)
+    i_f = score_prep_filter(v, bias=c, want_gstats=True)
+    gv, gi = score_topk_filtered(u_f, i_f, EUCLID_CANDIDATES, None, c, item_index_base=0, prefilter=prefilter)
+    stats = dict(LAST_FILTER_STATS)
+    # ---- the reference's chain on the U x 16 candidate pairs
+    xu32 = torch.arange(n_u, dtype=torch.int32, device=dev).repeat_interleave(EUCLID_CANDIDATES)
+    xi32 = gi.reshape(-1).clamp(min=0).contiguous()
+    ub = _f32c(user_bias.detach()).reshape(-1) if user_bias is not None else None
+    ib = _f32c(item_bias.detach()).reshape(-1) if item_bias is not None else None
+    exact = pair_scores_exact(u32, i32, kpad, d, xu32, xi32, ub, ib, MODE_EUCLIDEAN, u_sq, i_sq)
+    bmax = ib.max().reshape(1) if ib is not None else None
+    ov = torch.empty((n_u, kk), dtype=torch.float32, device=dev)
+    oi = torch.empty((n_u, kk), dtype=torch.int32, device=dev)
+    flag = torch.empty((n_u,), dtype=torch.int32, device=dev)
+    n_flagged = zero_block(1, dev)
+    with _timed("topk_euclid_certify"):
+        N.call("trec_topk_euclid_certify", N.ptr(gi), N.ptr(gv), N.ptr(exact), EUCLID_CANDIDATES, kk, N.ptr(u_sq), N.ptr(ub),
+               N.ptr(i_f.gstats), N.ptr(bmax), int(d), n_u, N.ptr(ov), N.ptr(oi), N.ptr(flag), N.ptr(n_flagged))
+    n_bad = int(n_flagged.item())
+    if n_bad:
+        bad = torch.nonzero(flag, as_tuple=False).reshape(-1)
+        with _timed("topk_filter_fallback"):
+            fv, fi = score_topk(u32[bad].contiguous(), i32, DTYPE_F32, kpad, kk, ub[bad].contiguous() if ub is not None else None,
+                                ib, MODE_EUCLIDEAN, u_sq[bad].contiguous(), i_sq,
+                                method="two_stage" if n_i >= TWO_STAGE_MIN_ITEMS else "direct")
+        ov[bad] = fv
+        oi[bad] = fi
+    if item_index_base:
+        oi = torch.where(oi >= 0, oi + int(item_index_base), oi)
+    LAST_FILTER_STATS.clear()
+    LAST_FILTER_STATS.update(stats)
+    LAST_FILTER_STATS.update({"route": "euclidean via the dot-product cascade (g = u.i - r_i / 2, %d nearest, certificate)" % EUCLID_CANDIDATES,
+                              "users": n_u, "euclid_uncertified_users": n_bad})
     return ov, oi
 
 

@@ -1116,6 +1116,12 @@ class TensorRec(object):
         filtered = (dtype == ops.DTYPE_F32 and graph.engine_mode == ops.MODE_DOT and 1 <= k <= 16 and
                     n_items_min >= ops.TWO_STAGE_MIN_ITEMS and self.n_components <= 256 and
                     ops.N.load().trec_get_tuning(b"topk_bf16_filter", 1) != 0)
+        # Euclidean scores (one taste, fp32): the same cascade finds the 16 NEAREST items of every user -- nearest = largest
+        # u.i - r_i / 2 -- the reference's chain re-scores them and a per-user certificate decides (ops.score_topk_euclid_filtered)
+        euclid_filtered = (dtype == ops.DTYPE_F32 and graph.engine_mode == ops.MODE_EUCLIDEAN and not sharded and
+                           1 <= k <= ops.EUCLID_CANDIDATES - 4 and itf.shape[0] >= ops.TWO_STAGE_MIN_ITEMS and
+                           self.n_components <= 256 and self.n_tastes == 1 and
+                           ops.N.load().trec_get_tuning(b"topk_euclid_filter", 1) != 0)
         stats_exchange = (lambda g: sharding.all_reduce_max(g, self.process_group)) if sharded else None
         # ... and on a catalogue of >= 262,144 items an int8 MFMA pass (exact integer arithmetic, proven bound) first decides
         # which (superblock, user) pairs the bf16 stage has to look at at all (csrc/topk_cascade.hip)
@@ -1155,6 +1161,10 @@ class TensorRec(object):
                 ub = user_bias[s:e].contiguous() if self.biased else None
                 per_taste = []
                 for user_repr in user_reprs:
+                    if euclid_filtered:
+                        per_taste.append(ops.score_topk_euclid_filtered(user_repr[s:e], item_repr, k, ub, ib,
+                                                                        item_index_base=int(item_offset)))
+                        continue
                     if filtered:
                         u_f = ops.score_prep_filter(user_repr[s:e], normalize=graph.engine_normalize,
                                                     sort_users=prefilter == "int8", k=k, user_bias=ub)

@@ -209,7 +209,7 @@ def test_int8_table_is_exact_integer_arithmetic_and_bound_holds(ops):
     table = torch.empty((n_sb, n_u), dtype=torch.float32, device="cuda")
     ctop = torch.empty((n_ch * 10, n_u), dtype=torch.float32, device="cuda")
     N.call("trec_score_gemm_blockmax_i8", N.ptr(uop.i8), N.ptr(iop.i8), d, n_u, n_i, N.ptr(dub), N.ptr(iop.bias_q),
-           N.ptr(iop.scales), N.ptr(iop.sb_stats), sb, n_chunks, N.ptr(table), n_u, N.ptr(uerr), N.ptr(ctop), 10, None, None)
+           N.ptr(iop.scales), N.ptr(iop.sb_stats), sb, n_chunks, N.ptr(table), n_u, N.ptr(uerr), N.ptr(ctop), 10, None, None, 0)
     s_int = uq @ iq.T + bq[None, :]
     pad = n_sb * sb - n_i
     m_int = np.concatenate([s_int, np.full((n_u, pad), np.iinfo(np.int64).min)], 1).reshape(n_u, n_sb, sb).max(2)
@@ -312,6 +312,7 @@ def test_rows_compaction_lists_exactly_the_pairs_whose_upper_bound_reaches_the_t
                       fma(np.broadcast_to(uerr[:, 1][None, :], tv.shape), np.broadcast_to(B, tv.shape),
                           fma(np.broadcast_to(uerr[:, 3][None, :], tv.shape), np.broadcast_to(C, tv.shape), tv)))
             keep = ~(lhs < f[None, :])
+            keep[:, ~(thr < np.inf)] = False          # a threshold of +inf keeps NOTHING, whatever the table or the bound holds
         want_rows = int(((keep.sum(1) + 511) // 512 * 512).sum())
         for cap_rows in (want_rows + 1024, want_rows, want_rows - 512):          # roomy, exact fit, one workgroup short
             status = torch.full((2,), -5, dtype=torch.int64, device="cuda")

@@ -298,3 +298,79 @@ def test_wide_second_pass_certifies_users_beyond_the_first_pass_capacities(ops):
     assert np.array_equal(idx.cpu().numpy(), ri) and np.array_equal(vals.cpu().numpy(), rv)
     assert stats["flagged_users"] > n_u // 4, stats                  # the first pass gave up on many users ...
     assert stats["flagged_after_wide_pass"] == 0, stats              # ... the wide pass certified all of them
+
+
+# ---- Euclidean scores through the dot-product cascade (csrc/euclid_topk.hip) ----------------------------------------------
+@pytest.mark.parametrize("d,n_u,n_i,k,bias_scale", [(128, 900, 300_000, 10, 0.0), (128, 700, 280_000, 10, 0.02), (64, 400, 40_000, 5, 0.01),
+                                                    (100, 300, 30_000, 12, 0.0), (128, 500, 270_000, 10, 2.0)])
+def test_euclidean_topk_through_the_dot_cascade_is_the_oracles(ops, d, n_u, n_i, k, bias_scale):
+    """-sqrt(max(r_u - 2 u.i + r_i, 1e-16)) (+ biases): per user the nearest items are the largest u.i - r_i / 2, so the dot
+    cascade lists the 16 nearest, the reference chain re-scores them and a certificate decides per user; without it (the last
+    case: item biases that outweigh the distance gaps) the exact fp32 path answers.  Values and ids == the oracle's, always."""
+    rng = np.random.default_rng(d + n_u + k)
+    u = rng.standard_normal((n_u, d)).astype(np.float32)
+    v = (rng.standard_normal((n_i, d)) * rng.uniform(0.7, 1.3, (n_i, 1))).astype(np.float32)
+    ub = (bias_scale * rng.standard_normal(n_u)).astype(np.float32) if bias_scale else None
+    ib = (bias_scale * rng.standard_normal(n_i)).astype(np.float32) if bias_scale else None
+    du, dv = dev(u), dev(v)
+    dub = dev(ub) if ub is not None else None
+    dib = dev(ib) if ib is not None else None
+    vals, idx = ops.score_topk_euclid_filtered(du, dv, k, dub, dib)
+    stats = dict(ops.LAST_FILTER_STATS)
+    _, u_sq, _ = ops.score_prep(du, ops.DTYPE_F32, want_sqnorm=True)
+    _, v_sq, _ = ops.score_prep(dv, ops.DTYPE_F32, want_sqnorm=True)
+    ref = O.score_dense_euclid_exact(u, v, u_sq.cpu().numpy(), v_sq.cpu().numpy(), ub, ib)
+    rv, ri = O.topk_rows(ref, k)
+    assert np.array_equal(idx.cpu().numpy(), ri) and np.array_equal(vals.cpu().numpy(), rv)
+    if bias_scale <= 0.02:
+        assert stats["euclid_uncertified_users"] <= n_u // 20, stats          # the certificate holds for (nearly) everybody
+    else:
+        assert stats["euclid_uncertified_users"] > n_u // 2, stats            # ... and honestly fails when biases dominate
+    if n_i >= 262_144 and d in (64, 128):
+        assert str(stats.get("prefilter", "")).startswith("int8"), stats      # the int8 -> bf16 -> fp32 cascade itself ran
+
+
+def test_euclidean_predict_top_k_through_the_public_api(ops):
+    """TensorRec.predict_top_k for EuclideanSimilarityPredictionGraph takes the filtered route and equals predict_rank's order."""
+    import scipy.sparse as sp
+    import tensorrec_amd as T
+    rng = np.random.RandomState(4)
+    n_u, n_i, d = 200, 20_000, 32
+    uf = sp.random(n_u, 40, density=0.2, random_state=rng, format="csr", dtype=np.float32)
+    itf = sp.hstack([sp.identity(n_i, format="csr", dtype=np.float32),
+                     sp.random(n_i, 6, density=0.3, random_state=rng, format="csr", dtype=np.float32)], format="csr")
+    model = T.TensorRec(n_components=d, seed=2, prediction_graph=T.prediction_graphs.EuclideanSimilarityPredictionGraph())
+    model.build(uf.shape[1], itf.shape[1])
+    w = model.get_weights()
+    w["item_feature_biases"] = (0.01 * rng.standard_normal(w["item_feature_biases"].shape)).astype(np.float32)
+    w["user_feature_biases"] = (0.3 * rng.standard_normal(w["user_feature_biases"].shape)).astype(np.float32)
+    model.set_weights(w)
+    vals, idx = model.predict_top_k(uf, itf, k=10)
+    assert "euclidean" in str(ops.LAST_FILTER_STATS.get("route", ""))
+    scores = model.predict(uf, itf)
+    rv, ri = O.topk_rows(scores, 10)
+    assert np.array_equal(idx, ri) and np.array_equal(vals, rv)
+
+
+# ---- ADVICE r3: the all-superblocks tier of the wide pass on a catalogue above 4096 superblocks ---------------------------
+def test_wide_pass_tier_two_respects_the_collect_limit_above_two_million_items(ops):
+    """2.2M items = 4,297 superblocks: tier 2 used to ask trec_topk_collect_blocks for more slots than it has and the call
+    raised.  Users built to keep (nearly) every superblock are flagged through both tiers and must come back exact from the
+    fp32 path; the others take the filter."""
+    rng = np.random.default_rng(77)
+    n_u, n_i, d, k = 96, 2_200_000, 32, 10
+    u = rng.standard_normal((n_u, d)).astype(np.float32)
+    v = rng.standard_normal((n_i, d)).astype(np.float32)
+    u[:2] *= 1e-4                              # two users whose scores all lie within the bound of each other: every superblock is kept
+    du, dv = dev(u), dev(v)
+    uop = ops.score_prep_filter(du)
+    iop = ops.score_prep_filter(dv, want_gstats=True)
+    v2 = dv.clone()
+    v2[::400_000] *= 30.0                      # a few huge items inflate the item-side maxima: the bound is loose for everybody
+    iop2 = ops.score_prep_filter(v2, want_gstats=True)
+    vals, idx = ops.score_topk_filtered(uop, iop2, k)
+    stats = dict(ops.LAST_FILTER_STATS)
+    ref = O.score_dense_exact(u, v2.cpu().numpy())
+    rv, ri = O.topk_rows(ref, k)
+    assert np.array_equal(idx.cpu().numpy(), ri) and np.array_equal(vals.cpu().numpy(), rv)
+    assert stats["flagged_users"] >= 1, stats

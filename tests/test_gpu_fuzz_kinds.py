@@ -82,6 +82,16 @@ def test_cascade_exact_on_every_data_kind(ops, kind, seed):
     fv, fi = ops.score_topk_filtered(uop, iop, k, ub, ib, prefilter="int8")
     stats = dict(ops.LAST_FILTER_STATS)
     assert torch.equal(fi, ei) and torch.equal(fv, ev), (kind, stats)
+    # ... and against the ORACLE itself (oracle/tr_oracle.c: the k-ordered fmaf chain, (s + b_u) + b_i, top-k by value desc /
+    # index asc) on 256 users of every kind -- the comparison above pins the cascade to the fp32 MFMA path, which is
+    # oracle-tested on Gaussian rows only; here the heavy-tailed, outlier and 2^30-integer-bias kinds meet the oracle directly
+    from oracle import oracle as O
+    sample = np.unique(np.linspace(0, n_u - 1, 256).astype(np.int64))
+    sd = torch.from_numpy(sample).cuda()
+    ref = O.score_dense_exact(u[sd].cpu().numpy(), v.cpu().numpy(), None if ub is None else ub[sd].cpu().numpy(),
+                              None if ib is None else ib.cpu().numpy())
+    rv, ri = O.topk_rows(ref, k)
+    assert np.array_equal(fi[sd].cpu().numpy(), ri) and np.array_equal(fv[sd].cpu().numpy(), rv), (kind, "vs oracle")
     if kind in INT8_MUST_RUN:
         assert stats.get("prefilter") == "int8", (kind, stats)
     if kind != "clustered":
