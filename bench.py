@@ -360,7 +360,8 @@ def main():
                         u_f, i_f, k, ub, ib, item_index_base=i_begin, variant=args.variant,
                         n_chunks=args.chunks if args.chunks > 0 else None,
                         floor_exchange=floor_fn if world > 1 else None,
-                        stats_exchange=sharding.all_reduce_max if world > 1 else None, prefilter=prefilter)
+                        stats_exchange=sharding.all_reduce_max if world > 1 else None, prefilter=prefilter,
+                        finish_lanes=16 if world >= 4 else 0)          # (short per-shard lists: four users per wave)
                     if world > 1:
                         vals, idx = topk_fn(vals, idx, k)              # every rank finalises ITS users (all-to-all + merge)
                     return vals, idx, user_repr, item_repr

@@ -451,10 +451,133 @@ def config4_record(device, n_users=138_493, n_items=26_744, per_user=160, d=256,
     return rec
 
 
-def config_records(device, which=("cfg1", "cfg3_shard", "cfg4")):
+def config0_record(device):
+    """configs[0], the README example (reference README quick-start; defaults tensorrec/tensorrec.py:28-36): generate_dummy_data
+    100 users x 150 items, default TensorRec() = d 100, Linear + DotProduct + RMSE, biased.  Three optimiser steps through the
+    public API against oracle/model.py from identical weights (first-step loss, raw gradients, weights by the Adam-aware bar),
+    then predict / predict_rank from the fitted weights bit-exact against the oracle's chain."""
+    import torch
+    import tensorrec_amd as T
+    from oracle import oracle as O
+    from oracle.model import OracleTensorRec
+    from oracle.parity import check_weights_after_adam
+    inter, uf, itf = T.util.generate_dummy_data(num_users=100, num_items=150, interaction_density=.05, random_state=0)
+    inter, uf, itf = sp.csr_matrix(inter), sp.csr_matrix(uf), sp.csr_matrix(itf)
+    lr, alpha, steps = 0.1, 1e-5, 3
+    oracle = OracleTensorRec(100, "linear", "linear", "dot", "rmse", True)
+    oracle.init_weights(uf.shape[1], itf.shape[1], np.random.default_rng(42))
+    brng = np.random.default_rng(7)
+    oracle.weights["user_feature_biases"] = (0.1 * brng.standard_normal((uf.shape[1], 1))).astype(np.float32)
+    oracle.weights["item_feature_biases"] = (0.1 * brng.standard_normal((itf.shape[1], 1))).astype(np.float32)
+    w0 = {k_: v.copy() for k_, v in oracle.weights.items()}
+    model = T.TensorRec(seed=1)                                  # every default of the reference's constructor
+    model.build(uf.shape[1], itf.shape[1])
+    model.set_weights(_rename(w0))
+    model._capture = {}
+    model.fit_partial(inter, uf, itf, epochs=1, learning_rate=lr, alpha=alpha)
+    cap, model._capture = model._capture, None
+    model.fit_partial(inter, uf, itf, epochs=steps - 1, learning_rate=lr, alpha=alpha)
+    basic = None
+    for s_ in range(steps):
+        b, _, _ = oracle.step(inter, uf, itf, lr, alpha)
+        if s_ == 0:
+            basic, g_first = np.asarray(b), {k_: (None if g is None else g.copy()) for k_, g in oracle.last_grads.items()}
+    n_loss = float(np.asarray(basic).size)
+    raw = {k_: (None if g is None else g - np.float32(n_loss * alpha) * w0[k_]) for k_, g in g_first.items()}
+    gmax = max(float(np.abs(g).max()) for g in raw.values() if g is not None)
+    gerr = {k_: float(np.abs(cap["grads"][k_] - ref).max() / gmax) for k_, ref in _rename(raw).items() if ref is not None}
+    rec = {"workload": "BASELINE.json configs[0]: generate_dummy_data(100 users, 150 items, interaction_density=.05), TensorRec() defaults "
+                       "(d=100, LinearRepresentation, DotProduct, RMSE, biased), %d optimiser steps (lr %.2g, alpha %.0e)" % (steps, lr, alpha),
+           "first_step_loss_gpu": float(np.asarray(cap["loss"]).reshape(-1)[0]), "first_step_loss_oracle": float(basic.reshape(-1)[0]),
+           "first_step_loss_rel_err": float(abs(np.asarray(cap["loss"]).reshape(-1)[0] - basic.reshape(-1)[0]) / max(1e-30, abs(basic.reshape(-1)[0]))),
+           "raw_gradient_max_err_over_gmax": gerr}
+    got_w = model.get_weights()
+    try:
+        check_weights_after_adam(got_w, _rename(oracle.weights), cap["grads"], _rename(raw), lr, steps, exempt=(), label="bench cfg0")
+        rec["weights_ok_adam_aware_bar"] = True
+    except AssertionError as exc:
+        rec["weights_ok_adam_aware_bar"] = False
+        rec["weights_error"] = str(exc)[:300]
+    # predictions and ranks from the fitted weights: the oracle's chain from the SAME weights, bit for bit
+    u = O.spmm_exact(uf, got_w["linear_weights_user_0"])
+    v = O.spmm_exact(itf, got_w["linear_weights_item"])
+    ub = O.spmm_exact(uf, got_w["user_feature_biases"]).reshape(-1)
+    ib = O.spmm_exact(itf, got_w["item_feature_biases"]).reshape(-1)
+    ref = O.score_dense_exact(u, v, ub, ib)
+    rec["predict_bit_exact"] = bool(np.array_equal(model.predict(uf, itf), ref))
+    rec["predict_rank_bit_exact"] = bool(np.array_equal(model.predict_rank(uf, itf), O.rank_predictions_exact(ref)))
+    rec["green"] = bool(rec["first_step_loss_rel_err"] <= 1e-4 and all(v_ <= 1e-4 for v_ in gerr.values()) and
+                        rec["weights_ok_adam_aware_bar"] and rec["predict_bit_exact"] and rec["predict_rank_bit_exact"])
+    return rec
+
+
+def config3_full_record(device, n_users=65536, n_items=10_000_000, n_shards=8, d=128, k=10, parity_users=256):
+    """configs[3] at its FULL size on one GPU: 10M items, CosineSimilarity, exact top-10 of a 65,536-user batch, as the 8 item
+    shards an 8-GPU run would hold -- executed one after the other through the REAL exchange code of the item-sharded path
+    (sharding.FORCE_COLLECTIVES over a one-rank RCCL / gloo group is not needed: the exchanges are given the shards' payloads
+    directly): every shard's int8 stage -> its k largest lower bounds per user -> the SHARED floor (k-th largest over all 8 k,
+    sharding.kth_largest_block_max, exactly what shared_topk_floor computes from the gathered payloads) -> every shard's
+    refinement + exact finish under that floor -> the 8 lists merged by the product's merge kernel (sharding.merge_topk).
+    Checked against the oracle's cosine chain on ``parity_users`` users x ALL 10M items."""
+    import torch
+    from tensorrec_amd import ops, sharding
+    from oracle import oracle as O
+    per = n_items // n_shards
+    g = torch.Generator(device=device)
+    g.manual_seed(0)
+    users = torch.randn((n_users, d), device=device, generator=g)
+    items = torch.randn((n_items, d), device=device, generator=g)            # 5 GB of fp32 rows: one GPU holds all shards
+    pre = ops.cascade_prefilter_for(d, n_items)
+    i_ops = [ops.score_prep_filter(items[s_ * per:(s_ + 1) * per], normalize=True, want_gstats=True) for s_ in range(n_shards)]
+    # the item-side maxima behind both bounds are MAX-reduced over the shards (stats_exchange of the sharded path)
+    gstats_all = torch.stack([io.gstats for io in i_ops]).max(dim=0).values.contiguous()
+    recorded, floor = [], [None]
+
+    def floor_exchange(sel_max):
+        if floor[0] is None:
+            recorded.append(sel_max.clone())
+            return sharding.kth_largest_block_max(sel_max.contiguous(), k)
+        return floor[0].clone()
+
+    def stats_exchange(t):
+        return gstats_all.clone() if t.numel() == 3 else t
+    t0 = time.perf_counter()
+    u_f = ops.score_prep_filter(users, normalize=True, sort_users=pre == "int8", k=k)
+    for s_ in range(n_shards):                                               # pass 1: every shard's lower bounds
+        ops.score_topk_filtered(u_f, i_ops[s_], k, item_index_base=s_ * per, floor_exchange=floor_exchange,
+                                stats_exchange=stats_exchange, prefilter=pre)
+    floor[0] = sharding.kth_largest_block_max(torch.cat(recorded, dim=0).contiguous(), k)
+    recorded.clear()
+    lists_v, lists_i, stage1 = [], [], []
+    for s_ in range(n_shards):                                               # pass 2: refinement + finish under the shared floor
+        v_, i_ = ops.score_topk_filtered(u_f, i_ops[s_], k, item_index_base=s_ * per, floor_exchange=floor_exchange,
+                                         stats_exchange=stats_exchange, prefilter=pre)
+        lists_v.append(v_)
+        lists_i.append(i_)
+        stage1.append(ops.LAST_FILTER_STATS.get("prefilter", "bf16"))
+    vals, idx = sharding.merge_topk(torch.cat(lists_v, dim=1), torch.cat(lists_i, dim=1), k)
+    torch.cuda.synchronize()
+    total_s = time.perf_counter() - t0
+    sample = np.unique(np.linspace(0, n_users - 1, parity_users).astype(np.int64))
+    sd = torch.from_numpy(sample).to(device)
+    u_ref = ops.score_prep_filter(users[sd].contiguous(), normalize=True).f32.cpu().numpy()
+    i_ref = np.concatenate([io.f32.cpu().numpy() for io in i_ops])
+    par = oracle_topk_parity(O, u_ref, i_ref, None, None, vals[sd].cpu().numpy(), idx[sd].cpu().numpy(), k, tile=64)
+    del items, i_ops
+    torch.cuda.empty_cache()
+    return {"workload": "BASELINE.json configs[3] at full size on ONE GPU: %d users x %d items (d=%d, CosineSimilarity, exact top-%d) as "
+                        "%d item shards run one after the other through the item-sharded path's own floor exchange and list merge"
+                        % (n_users, n_items, d, k, n_shards),
+            "seconds_both_passes_all_shards": total_s, "stage1_per_shard": stage1, "parity": par,
+            "note": "pass 1 exists only because one GPU plays all 8 ranks one after the other (a rank needs every shard's lower bounds "
+                    "before its refinement); on 8 GPUs the shards run side by side and the floor is one all-to-all"}
+
+
+def config_records(device, which=("cfg0", "cfg1", "cfg3_shard", "cfg3_full", "cfg4")):
     import torch
     out = {}
-    for name, fn in (("cfg1", config1_record), ("cfg3_shard", config3_shard_record), ("cfg4", config4_record)):
+    for name, fn in (("cfg0", config0_record), ("cfg1", config1_record), ("cfg3_shard", config3_shard_record),
+                     ("cfg3_full", config3_full_record), ("cfg4", config4_record)):
         if name not in which:
             continue
         t0 = time.perf_counter()

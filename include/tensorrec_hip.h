@@ -358,12 +358,14 @@ int trec_topk_candidates_finish(const int32_t* cand_n, const void* cand, int32_t
                                 const float* items_f32, int64_t ld_users, int64_t ld_items, int32_t kdim,
                                 const float* user_bias, const float* item_bias, int32_t item_index_base, int64_t n_users,
                                 int32_t k, float* out_vals, int32_t* out_idx, int32_t* flag, int32_t* n_flagged,
-                                const int32_t* out_index, void* stream);
+                                const int32_t* out_index, int32_t lanes_per_user, void* stream);
 /* The cascade's thresholds in one pass over the users, before trec_topk_rows_collect: tau [n_users] IN / OUT = the k-th largest
  * int8 lower bound (+inf on return for layout rows without a source: src [n_users] nullable, trec_user_prep_sorted);
  * floor0 = tau - eps rounded down twice (the provisional floor of the candidate lists; +inf and flag = 1 when the bound is
  * unusable); n_flagged [1] zeroed by the caller; cand_n nullable [n_users], zeroed here.  out_index of
- * trec_topk_candidates_finish (nullable): user u's lists go to row out_index[u], negative = no output. */
+ * trec_topk_candidates_finish (nullable): user u's lists go to row out_index[u], negative = no output.  lanes_per_user: 0 / 64 = a
+ * wave per user (up to cand_cap candidates); 16 = four users per wave for SHORT lists (item shards of an N-GPU run: ~27 / N
+ * candidates per user and shard) -- a user with more than 16 candidates is flagged and re-done by the caller. */
 int trec_topk_cascade_floor(float* tau, const int32_t* src, const float* user_stats, const float* user_bias,
                             const float* item_gstats, int32_t kdim, int64_t n_users, float* floor0, int32_t* flag,
                             int32_t* n_flagged, int32_t* cand_n, void* stream);

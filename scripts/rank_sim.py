@@ -34,7 +34,8 @@ def step():
     u_f = ops.score_prep_filter(u, sort_users=True, k=k, user_bias=ub)   # users sorted by int8 scale class, as predict_top_k does
     i_f = ops.score_prep_filter(v, bias=ib, want_gstats=True)
     vals, idx = ops.score_topk_filtered(u_f, i_f, k, ub, ib, item_index_base=0, floor_exchange=floor_exchange,
-                                        stats_exchange=lambda s: s, prefilter=os.environ.get("PREFILTER", "int8") or None)
+                                        stats_exchange=lambda s: s, prefilter=os.environ.get("PREFILTER", "int8") or None,
+                                        finish_lanes=int(os.environ.get("FINISH_LANES", "16")))
     per = U // W                          # the all-to-all leaves this rank with W lists for each of ITS U / W users
     cand_v = vals[:per].repeat(1, W); cand_i = idx[:per].repeat(1, W)
     return sharding.merge_topk(cand_v, cand_i + torch.arange(W, device="cuda").repeat_interleave(k)[None, :] * I, k)

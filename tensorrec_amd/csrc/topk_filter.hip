@@ -595,6 +595,115 @@ __global__ __launch_bounds__(256) void candidates_finish_kernel(
                         user_bias != nullptr, bu, k, ov, oi, uo);
 }
 
+// ---- the same finish for SHORT lists: four users per wave ---------------------------------------------------------------------
+// One wave per user is a latency chain (count -> list -> floor -> item rows -> 128-step fmaf chain -> k rounds of maxima): ~17 us
+// however few candidates the user has.  On an item shard of an N-GPU run a user lists ~27 / N candidates (3-4 at N = 8) and the
+// chain is all there is: 2 ms per rank for 1M users, replicated on every rank.  Here 16 lanes own a user and lane j owns
+// candidate j: the k-th largest listed score by DPP row maxima (a DPP row IS the 16 lanes), the floor, and every surviving
+// lane walks ITS candidate's fp32 item row straight from memory with the reference's k-ordered fmaf chain against the user
+// row broadcast from LDS -- no compaction, no staging; an item shard of a few hundred MB sits in the Infinity Cache.  A user
+// with more than 16 candidates is flagged (the caller re-does it on its table column): at 3-4 expected candidates that is rare.
+__device__ __forceinline__ unsigned long long row16_max_u64(unsigned long long x)
+{
+    x = dpp_max_u64<0x128, 0xf>(x);      // row_ror:8
+    x = dpp_max_u64<0x124, 0xf>(x);      // row_ror:4
+    x = dpp_max_u64<0x122, 0xf>(x);      // row_ror:2
+    x = dpp_max_u64<0x121, 0xf>(x);      // row_ror:1   -> every lane: the maximum of its 16-lane row
+    return x;
+}
+
+__global__ __launch_bounds__(256) void candidates_finish16_kernel(
+    const int32_t* __restrict__ cand_n, const int2* __restrict__ cand_list, int cap, const float* __restrict__ cand_floor,
+    const float2* __restrict__ ustats, const float* __restrict__ gstats, const float* __restrict__ U,
+    const float* __restrict__ V, int64_t ld_u, int64_t ld_v, int kdim, const float* __restrict__ user_bias,
+    const float* __restrict__ item_bias, int32_t item_index_base, int64_t n_users, int k, float* __restrict__ ov,
+    int32_t* __restrict__ oi, int32_t* __restrict__ flag, int32_t* __restrict__ n_flagged,
+    const int32_t* __restrict__ out_index)
+{
+    extern __shared__ __attribute__((aligned(16))) char fsmem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane >> 4, gl = lane & 15;
+    const int kd4 = (kdim + 3) & ~3;
+    float* urow = (float*)fsmem + (size_t)(wave * 4 + grp) * kd4;           // this user's fp32 row, read by its 16 lanes
+    const int64_t u = ((int64_t)blockIdx.x * 4 + wave) * 4 + grp;
+    const bool live = u < n_users;
+    const int64_t uc = live ? u : n_users - 1;
+    const int64_t uo = out_index ? (int64_t)out_index[uc] : uc;
+    const int n = cand_n[uc];
+    const float f0 = cand_floor[uc];
+    const int2 ent = cand_list[uc * (int64_t)cap + gl];
+    const bool vec = ((ld_v & 3) == 0) && ((ld_u & 3) == 0);
+    for (int ch = gl; ch < (kd4 >> 2); ch += 16) {
+        f32x4 w = {0.f, 0.f, 0.f, 0.f};
+        const float* src = U + uc * ld_u + ch * 4;
+        if (vec) w = *(const f32x4*)src;
+        else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[e] = (ch * 4 + e < kdim) ? src[e] : 0.f;
+        }
+        *(f32x4*)(urow + ch * 4) = w;
+    }
+    const float bu = user_bias ? user_bias[uc] : 0.f;
+    const float2 st = ustats[uc];
+    const unsigned long long EMPTY = merge_key(-INFINITY, 0x7fffffff);
+    const bool skip = !live || uo < 0 || !(f0 < INFINITY);                 // (uniform over the 16 lanes of the user)
+    const bool over = n > 16 || n > cap;
+    // ---- tau = the k-th largest listed score of this user (row maxima: nothing crosses the 16-lane rows)
+    unsigned long long wkey = (!skip && !over && gl < n) ? merge_key(__int_as_float(ent.y), ent.x) : EMPTY;
+    unsigned long long kth = EMPTY;
+    for (int t = 0; t < k; ++t) {
+        kth = row16_max_u64(wkey);
+        if (wkey == kth && kth != EMPTY) wkey = EMPTY;
+    }
+    float tau = -INFINITY;
+    if (kth != EMPTY) {
+        const unsigned int hi = (unsigned int)(kth >> 32);
+        tau = __uint_as_float((hi & 0x80000000u) ? (hi & 0x7fffffffu) : ~hi);
+    }
+    const float eps = filter_eps(st, fabsf(bu), gstats, kdim);
+    float fl = tau - 2.0f * eps;
+    if (tau == -INFINITY) fl = -INFINITY;
+    else fl = float_pred(float_pred(fl));
+    const bool keep = !skip && !over && gl < n && __int_as_float(ent.y) >= fl;
+    __builtin_amdgcn_wave_barrier();                                       // urow is private to this wave: DS operations of a wave execute in order
+    // ---- exact fp32 score of this lane's candidate: the reference's k-ordered fmaf chain, then (s + b_u) + b_i
+    unsigned long long mine = EMPTY;
+    {
+        const int64_t it = keep ? (int64_t)ent.x - item_index_base : 0;
+        const float* b = V + it * ld_v;
+        float acc = 0.0f;
+        int kk = 0;
+        if (vec) {
+            for (; kk + 4 <= kdim; kk += 4) {
+                const f32x4 a4 = *(const f32x4*)(urow + kk);
+                const f32x4 b4 = *(const f32x4*)(b + kk);
+                acc = __fmaf_rn(a4[0], b4[0], acc); acc = __fmaf_rn(a4[1], b4[1], acc);
+                acc = __fmaf_rn(a4[2], b4[2], acc); acc = __fmaf_rn(a4[3], b4[3], acc);
+            }
+        }
+        for (; kk < kdim; ++kk) acc = __fmaf_rn(urow[kk], b[kk], acc);
+        if (user_bias) acc = acc + bu;
+        if (item_bias) acc = acc + item_bias[it];
+        if (keep) mine = merge_key(acc, ent.x);
+    }
+    // ---- the k best by (value desc, index asc): lane t of the user's row writes place t
+    unsigned long long place = EMPTY;
+    for (int t = 0; t < k; ++t) {
+        const unsigned long long best = row16_max_u64(mine);
+        if (mine == best && best != EMPTY) mine = EMPTY;
+        if (gl == t) place = best;
+    }
+    if (live && uo >= 0) {
+        if (gl < k) {
+            const unsigned int hi = (unsigned int)(place >> 32);
+            const unsigned int bits = (hi & 0x80000000u) ? (hi & 0x7fffffffu) : ~hi;
+            ov[uo * k + gl] = (place == EMPTY) ? -INFINITY : __uint_as_float(bits);
+            oi[uo * k + gl] = (place == EMPTY) ? -1 : (int32_t)(~(unsigned int)place);
+        }
+        if (over && !skip && gl == 0 && flag[u] == 0) { flag[u] = 1; atomicAdd(n_flagged, 1); }
+    }
+}
+
 extern "C" int trec_score_prep_filter(const float* repr, int64_t n, int32_t d, int32_t kpad, int32_t normalize,
                                       const float* bias, float* out_f32, void* out_bf16, float* row_stats, float* gstats,
                                       void* stream)
@@ -707,8 +816,9 @@ extern "C" int trec_topk_candidates_finish(const int32_t* cand_n, const void* ca
                                            const float* items_f32, int64_t ld_users, int64_t ld_items, int32_t kdim,
                                            const float* user_bias, const float* item_bias, int32_t item_index_base,
                                            int64_t n_users, int32_t k, float* out_vals, int32_t* out_idx, int32_t* flag,
-                                           int32_t* n_flagged, const int32_t* out_index, void* stream)
+                                           int32_t* n_flagged, const int32_t* out_index, int32_t lanes_per_user, void* stream)
 {
+    TREC_REQUIRE(lanes_per_user == 0 || lanes_per_user == 16 || lanes_per_user == 64, "trec_topk_candidates_finish: lanes_per_user must be 0 / 64 (a wave per user) or 16");
     TREC_REQUIRE(cand_n && cand && cand_floor && user_stats && item_gstats && users_f32 && items_f32 && out_vals && out_idx &&
                  flag && n_flagged, "trec_topk_candidates_finish: null pointer");
     TREC_REQUIRE(cand_cap >= 64 && cand_cap % 64 == 0 && cand_cap <= 256, "trec_topk_candidates_finish: cand_cap must be 64, 128, 192 or 256");
@@ -716,9 +826,19 @@ extern "C" int trec_topk_candidates_finish(const int32_t* cand_n, const void* ca
     TREC_REQUIRE(kdim >= 1 && kdim <= 1024 && ld_users >= kdim && ld_items >= ((kdim + 3) & ~3),
                  "trec_topk_candidates_finish: need kdim <= 1024 and item rows padded to a multiple of 4");
     if (n_users == 0) return TREC_OK;
-    const unsigned blocks = (unsigned)ceil_div64(n_users, 4);
     hipStream_t st = (hipStream_t)stream;
     const int kd4 = (kdim + 3) & ~3;
+    if (lanes_per_user == 16) {
+        // short lists (item shards): 16 lanes per user, 16 users per workgroup; users with more than 16 candidates are flagged
+        TREC_REQUIRE(k <= 16, "trec_topk_candidates_finish: the 16-lane form needs k <= 16");
+        const size_t lds16 = (size_t)16 * kd4 * 4;
+        hipLaunchKernelGGL(candidates_finish16_kernel, dim3((unsigned)ceil_div64(n_users, 16)), dim3(256), lds16, st, cand_n,
+                           (const int2*)cand, cand_cap, cand_floor, (const float2*)user_stats, item_gstats, users_f32, items_f32,
+                           ld_users, ld_items, kdim, user_bias, item_bias, item_index_base, n_users, k, out_vals, out_idx, flag,
+                           n_flagged, out_index);
+        return trec_check_launch("trec_topk_candidates_finish (16 lanes per user)");
+    }
+    const unsigned blocks = (unsigned)ceil_div64(n_users, 4);
     const size_t lds = 4 * FILTER_CMAX * 4 + (size_t)4 * kd4 * 4 + (size_t)4 * FILTER_RB * (kd4 + 4) * 4;
 #define TREC_CF(CPLV)                                                                                                  \
     (void)hipFuncSetAttribute((const void*)candidates_finish_kernel<CPLV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \

@@ -1574,15 +1574,17 @@ def _wide_second_pass(uop, iop, blockmax, bad, n_sb, k, user_bias, item_bias, it
 
 
 def score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index_base=0, sb_rows=None, variant=1,
-                        n_chunks=None, floor_exchange=None, stats_exchange=None, ksel=None, prefilter=None):
+                        n_chunks=None, floor_exchange=None, stats_exchange=None, ksel=None, prefilter=None, finish_lanes=0):
     """See _score_topk_filtered.  A user operand sorted by int8 scale class (``uop.src``) is handled here: the user biases
     follow the operand's row order on the way in (``uop.bias_sorted`` when this ``user_bias`` was given to the preparation),
     the results leave in the caller's order (the finish kernel writes through ``uop.src``: no permutation pass).  Item shards:
     the per-user exchanges then carry users in the operand's order -- the same on every rank, because the user side is
-    replicated and the sort is deterministic."""
+    replicated and the sort is deterministic.  ``finish_lanes=16`` (item shards of a run over >= 4 ranks: a user lists ~27 / N
+    candidates per shard): the exact finish packs four users into a wave; a user with more than 16 candidates is flagged and
+    re-done on its table column like any other flagged user."""
     if uop.src is None:
         return _score_topk_filtered(uop, iop, k, user_bias, item_bias, item_index_base, sb_rows, variant, n_chunks,
-                                    floor_exchange, stats_exchange, ksel, prefilter)
+                                    floor_exchange, stats_exchange, ksel, prefilter, finish_lanes=finish_lanes)
     if user_bias is None:
         ub = None
     elif uop.bias_sorted is not None and uop.bias_ref is user_bias:
@@ -1597,7 +1599,7 @@ def score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index_
         ov, oi = sv.index_select(0, pos), si.index_select(0, pos)
     else:
         ov, oi = _score_topk_filtered(uop, iop, k, ub, item_bias, item_index_base, sb_rows, variant, n_chunks,
-                                      floor_exchange, stats_exchange, ksel, prefilter, caller_order=True)
+                                      floor_exchange, stats_exchange, ksel, prefilter, caller_order=True, finish_lanes=finish_lanes)
     LAST_FILTER_STATS["users"] = int(uop.n_real)
     LAST_FILTER_STATS["layout_rows"] = int(uop.n)
     return ov, oi
@@ -1687,7 +1689,7 @@ def _score_topk_filtered_pipelined(uop, iop, k, user_bias, item_bias, item_index
 
 def _score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index_base=0, sb_rows=None, variant=1,
                          n_chunks=None, floor_exchange=None, stats_exchange=None, ksel=None, prefilter=None, tail_stream=None,
-                         caller_order=False):
+                         caller_order=False, finish_lanes=0):
     """EXACT fp32 top-k (values and ids bit-identical to ``score_topk(..., DTYPE_F32)`` and to the oracle) with the
     score matrix contracted ONCE on bf16 MFMA: the bf16 stage-1 maxima and the bf16 re-scoring act as a filter with a
     proven error bound (csrc/topk_filter.hip), the survivors (~15 items per user at 1M x 1M) are re-scored by the
@@ -1734,7 +1736,7 @@ def _score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index
             # against this catalogue skip the attempt (item shards keep trying: every rank must take the same path and the
             # flag is local)
             r = _score_topk_filtered(uop, iop, k, user_bias, item_bias, item_index_base, sb_rows, variant, n_chunks,
-                                     floor_exchange, stats_exchange, ksel, None, caller_order=caller_order)
+                                     floor_exchange, stats_exchange, ksel, None, caller_order=caller_order, finish_lanes=finish_lanes)
             LAST_FILTER_STATS["prefilter"] = "int8 (too loose: bf16 stage 1 instead)"
             LAST_FILTER_STATS["refined_rows"] = int(rows)
             iop.cascade_too_loose = True
@@ -1767,7 +1769,7 @@ def _score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index
             N.call("trec_topk_candidates_finish", N.ptr(cands.n), N.ptr(cands.items), cands.cap, N.ptr(cands.floor0),
                    N.ptr(uop.stats), N.ptr(gstats), N.ptr(uop.f32), N.ptr(iop.f32), kpad, kpad, uop.d, N.ptr(user_bias),
                    N.ptr(item_bias), item_index_base, n_u, kk, N.ptr(ov), N.ptr(oi), N.ptr(flag), N.ptr(n_flagged),
-                   N.ptr(out_index))
+                   N.ptr(out_index), int(finish_lanes or 0))
 
         def complete(cands=cands, blockmax=blockmax):
             if FILTER_DEBUG is not None:

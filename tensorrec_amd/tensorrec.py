@@ -1168,9 +1168,12 @@ class TensorRec(object):
                     if filtered:
                         u_f = ops.score_prep_filter(user_repr[s:e], normalize=graph.engine_normalize,
                                                     sort_users=prefilter == "int8", k=k, user_bias=ub)
+                        # (item shards of >= 4 ranks: a user lists ~27 / world candidates per shard -> four users per wave)
+                        lanes = 16 if sharded and dist.get_world_size(self.process_group) >= 4 else 0
                         per_taste.append(ops.score_topk_filtered(u_f, i_f, k, ub, ib, item_index_base=int(item_offset),
                                                                  floor_exchange=floor_exchange,
-                                                                 stats_exchange=stats_exchange, prefilter=prefilter))
+                                                                 stats_exchange=stats_exchange, prefilter=prefilter,
+                                                                 finish_lanes=lanes))
                         continue
                     u_op, u_sq, _ = ops.score_prep(user_repr[s:e], dtype, normalize=graph.engine_normalize,
                                                    want_sqnorm=want_sq)

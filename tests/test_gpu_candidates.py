@@ -174,7 +174,9 @@ def test_user_batches_on_two_streams_equal_one_batch(ops, tuning):
     assert stats.get("user_batches") == 3 and "user_batches" not in stats1
     assert np.array_equal(idx, ri) and np.array_equal(vals, rv)
     assert np.array_equal(idx1, ri) and np.array_equal(vals1, rv)
-    assert stats["flagged_users"] == stats1["flagged_users"] >= 50
+    # (which users overflow their lists depends on which superblocks are "hot" -- refined for everybody -- and the hot threshold is
+    # a fraction of the batch: the counts of the two forms need not agree; both re-do their flagged users exactly)
+    assert stats["flagged_users"] >= 50 and stats1["flagged_users"] >= 50
     assert stats["refined_rows"] >= stats1["refined_rows"] * 0.9
 
 
@@ -198,3 +200,54 @@ def test_users_the_int8_bound_says_nothing_about_are_flagged_before_the_lists(op
     assert np.array_equal(idx, ri) and np.array_equal(vals, rv)
     assert stats["prefilter"] == "int8" and 30 <= stats["flagged_users"] <= 90
     assert dbg["candidates_q50_90_99_999_max"][-1] <= 256
+
+
+@pytest.mark.parametrize("n_shards,short", [(8, True), (2, False)])
+def test_sixteen_lane_finish_on_item_shards(ops, n_shards, short):
+    """finish_lanes=16 (four users per wave) on the lists of item SHARDS that share the all-shard floor, as an N-GPU run makes
+    them: with 8 shards a user lists 3-4 candidates per shard and the packed finish answers; with 2 shards most users list
+    more than 16 -- they are flagged and re-done on their table column.  Either way the merged lists are the oracle's."""
+    from tensorrec_amd import sharding
+    rng = np.random.default_rng(3 + n_shards)
+    n_u, d, k = 700, 128, 10
+    per = 65_536 if short else 160_000
+    n_i = per * n_shards
+    u = rng.standard_normal((n_u, d)).astype(np.float32)
+    v = rng.standard_normal((n_i, d)).astype(np.float32)
+    ub = (0.2 * rng.standard_normal(n_u)).astype(np.float32)
+    ib = (0.2 * rng.standard_normal(n_i)).astype(np.float32)
+    du, dub = dev(u), dev(ub)
+    uop = ops.score_prep_filter(du, sort_users=True, k=k, user_bias=dub)
+    iops = [ops.score_prep_filter(dev(v[s * per:(s + 1) * per]), bias=dev(ib[s * per:(s + 1) * per]), want_gstats=True)
+            for s in range(n_shards)]
+    dibs = [dev(ib[s * per:(s + 1) * per]) for s in range(n_shards)]
+    gall = torch.stack([io.gstats for io in iops]).max(dim=0).values.contiguous()
+    recorded, floor = [], [None]
+
+    def floor_exchange(sel_max):
+        if floor[0] is None:
+            recorded.append(sel_max.clone())
+            return sharding.kth_largest_block_max(sel_max.contiguous(), k)
+        return floor[0].clone()
+
+    def stats_exchange(t):
+        return gall.clone() if t.numel() == 3 else t
+    for s in range(n_shards):
+        ops.score_topk_filtered(uop, iops[s], k, dub, dibs[s], item_index_base=s * per, floor_exchange=floor_exchange,
+                                stats_exchange=stats_exchange, prefilter="int8")
+    floor[0] = sharding.kth_largest_block_max(torch.cat(recorded, dim=0).contiguous(), k)
+    lv, li, flagged = [], [], 0
+    for s in range(n_shards):
+        v_, i_ = ops.score_topk_filtered(uop, iops[s], k, dub, dibs[s], item_index_base=s * per, floor_exchange=floor_exchange,
+                                         stats_exchange=stats_exchange, prefilter="int8", finish_lanes=16)
+        assert ops.LAST_FILTER_STATS.get("tail") == "candidate lists"
+        flagged += ops.LAST_FILTER_STATS["flagged_users"]
+        lv.append(v_)
+        li.append(i_)
+    vals, idx = sharding.merge_topk(torch.cat(lv, dim=1), torch.cat(li, dim=1), k)
+    rv, ri = O.topk_rows(O.score_dense_exact(u, v, ub, ib), k)
+    assert np.array_equal(idx.cpu().numpy(), ri) and np.array_equal(vals.cpu().numpy(), rv)
+    if short:
+        assert flagged <= n_u // 20                      # short lists: (nearly) everybody through the packed finish
+    else:
+        assert flagged > n_u                             # long lists: the flag path did the work (over the two shards together)
