@@ -1,11 +1,47 @@
 #!/bin/bash
-# Round-end evidence: default bench line, rocprofv3 kernel stats of the same command, PMC passes for HBM traffic.
+# Round-end evidence: default bench line, rocprofv3 kernel stats of the same command, PMC passes for HBM traffic, the per-rank
+# emulations of the 8-GPU predict and fit (scripts/rank_sim.py, scripts/fit_rank_sim.py), configs[4]'s fit under rocprofv3 + PMC.
+# STAGES (default all): bench prof pmc sims cfg4 tests
 set +e
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; REPO=$PWD; OUT=$REPO/gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp
 TAG=${1:-r01}
-timeout 900 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err; echo "bench rc=$?"; cat $OUT/${TAG}_bench.json
+STAGES="${STAGES:-bench prof pmc sims cfg4 tests}"
+has() { case " $STAGES " in *" $1 "*) return 0;; *) return 1;; esac; }
+if has sims; then
+timeout 300 python scripts/rank_sim.py > $OUT/${TAG}_rank_sim.log 2>&1; echo "rank_sim rc=$?"; cp $OUT/rank_sim.json $OUT/${TAG}_rank_sim_n8.json 2>/dev/null; tail -1 $OUT/${TAG}_rank_sim.log | cut -c1-900
+timeout 300 python scripts/fit_rank_sim.py > $OUT/${TAG}_fit_rank_sim.log 2>&1; echo "fit_rank_sim rc=$?"; cp $OUT/fit_rank_sim.json $OUT/${TAG}_fit_rank_sim_n8.json 2>/dev/null; tail -1 $OUT/${TAG}_fit_rank_sim.log | cut -c1-900
+mkdir -p profiles; cp $OUT/${TAG}_rank_sim_n8.json $OUT/${TAG}_fit_rank_sim_n8.json profiles/ 2>/dev/null      # (the bench line below reads them: scale_emulation)
+fi
+if has bench; then
+timeout 1200 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err; echo "bench rc=$?"; cat $OUT/${TAG}_bench.json | cut -c1-6000
+fi
+if has cfg4; then
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_cfg4_prof -o cfg4 -- python $REPO/scripts/profile_cfg4.py 3 > $OUT/${TAG}_cfg4.log 2> $OUT/${TAG}_cfg4.err ); echo "cfg4 rocprof rc=$?"; tail -1 $OUT/${TAG}_cfg4.log
+f=$(find $OUT/${TAG}_cfg4_prof -name "*kernel_stats.csv" | head -1); cp $f $OUT/${TAG}_cfg4_fit_kernel_stats.csv 2>/dev/null; head -8 $OUT/${TAG}_cfg4_fit_kernel_stats.csv | cut -c1-160
+( cd /tmp && timeout 600 rocprofv3 --pmc FETCH_SIZE WRITE_SIZE TCC_HIT TCC_MISS --kernel-trace --output-format csv -d $OUT/${TAG}_cfg4_pmc -o pmc -- python $REPO/scripts/profile_cfg4.py 1 > /dev/null 2> $OUT/${TAG}_cfg4_pmc.err ); echo "cfg4 pmc rc=$?"
+python - <<PY
+import csv, glob, collections
+out=open("$OUT/${TAG}_cfg4_pmc_summary.txt","w")
+out.write("# rocprofv3 --pmc FETCH_SIZE WRITE_SIZE TCC_HIT TCC_MISS --kernel-trace -- python scripts/profile_cfg4.py 1 ; per-dispatch averages (KB)\n")
+for f in sorted(glob.glob("$OUT/${TAG}_cfg4_pmc/**/*counter_collection.csv", recursive=True)):
+    agg=collections.defaultdict(lambda: collections.defaultdict(float)); seen=set()
+    for r in csv.DictReader(open(f)):
+        k=r["Kernel_Name"][:70]; agg[k][r["Counter_Name"]]+=float(r["Counter_Value"]); seen.add((k,r["Dispatch_Id"]))
+    cnt=collections.Counter(k for k,_ in seen)
+    for k in agg:
+        if any(x in k for x in ("split","pair_score","spmm","wmrb","gemm","seg_","adam")):
+            out.write("%s | dispatches=%d | "%(k,cnt[k])+" ".join("%s=%.5g"%(c,v/cnt[k]) for c,v in sorted(agg[k].items()))+"\n")
+out.close(); print(open("$OUT/${TAG}_cfg4_pmc_summary.txt").read()[:3000])
+PY
+fi
+if has tests; then
+timeout 1200 python -m pytest tests -q -m gpu > $OUT/${TAG}_pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -4 $OUT/${TAG}_pytest_gpu.log
+fi
+if has prof; then
 ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o $TAG -- python $REPO/bench.py --configs headline --no-cpu-baseline --no-fit --prewarm-seconds 0 > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/${TAG}_prof.err ); echo "rocprof rc=$?"
 f=$(find $OUT/${TAG}_prof -name "*kernel_stats.csv" | head -1); cp $f $OUT/${TAG}_kernel_stats.csv 2>/dev/null; head -12 $OUT/${TAG}_kernel_stats.csv | cut -c1-200
+fi
+if has pmc; then
 for s in "FETCH_SIZE" "WRITE_SIZE TCC_HIT TCC_MISS" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES"; do
   n=$(echo $s | cut -d' ' -f1)
   ( cd /tmp && timeout 900 rocprofv3 --pmc $s --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_$n -o pmc -- python $REPO/bench.py --configs headline --steps 1 --warmup 0 --prewarm-seconds 0 --no-cpu-baseline --no-fit --no-fp32-mode --no-k1-multi --parity-users 64 > /dev/null 2> $OUT/${TAG}_pmc_$n.err ); echo "pmc $n rc=$?"
@@ -25,3 +61,4 @@ for f in sorted(glob.glob("$OUT/${TAG}_pmc_*/**/*counter_collection.csv", recurs
             out.write("%s | dispatches=%d | "%(k,cnt[k])+" ".join("%s=%.5g"%(c,v/cnt[k]) for c,v in sorted(agg[k].items()))+"\n")
 out.close(); print(open("$OUT/${TAG}_pmc_summary.txt").read())
 PY
+fi
