@@ -817,6 +817,29 @@ def main():
         "public_api_mode": public_api, "trained_weights_mode": trained, "parity_fit": parity_fit, "parity_multi_nnz": parity_multi, "configs": configs, "fit": fit,
         "roofline_fit": (fit or {}).get("roofline_fit"), "cpu_baseline_fit": cpu_fit,
     }
+    # ---- what ONE rank of an 8-GPU run does per step, emulated on one GPU (scripts/rank_sim.py, scripts/fit_rank_sim.py: every
+    # kernel at its per-rank size, the shared floor / the exchange plan real, nothing on the wire) -- read from the committed
+    # profiles of the same code; the multi-GPU numbers themselves are the driver's to measure
+    scale_emulation = None
+    try:
+        import glob
+        rs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_rank_sim_n8.json")))
+        fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_fit_rank_sim_n8.json")))
+        scale_emulation = {"note": "one-GPU emulations of ONE rank of an 8-GPU run (committed profiles, not measured in this run)"}
+        if rs:
+            r_ = json.load(open(rs[-1]))
+            scale_emulation["predict"] = {"file": os.path.basename(rs[-1]), "per_rank_step_ms": r_.get("per_rank_step_ms_at_N8_emulated"),
+                                          "ideal_ms": ms_per_step / 8.0 if world == 1 else None,
+                                          "kernels_ms": r_.get("kernels_ms"),
+                                          "exchange_bytes_received_per_rank": r_.get("exchange_bytes_received_per_rank")}
+        if fs:
+            f_ = json.load(open(fs[-1]))
+            scale_emulation["fit"] = {"file": os.path.basename(fs[-1]), "per_rank_compute_ms_per_step": f_.get("per_rank_compute_ms_per_step"),
+                                      "plan": f_.get("plan"), "wire_bytes_per_rank_and_step": f_.get("wire_bytes_per_rank_and_step_total"),
+                                      "round3_wire_bytes_per_rank_and_step": f_.get("round3_wire_bytes_per_rank_and_step")}
+    except Exception as exc:
+        scale_emulation = {"error": repr(exc)}
+    line["scale_emulation"] = scale_emulation
     # the verdicts of the records above in one compact object INSIDE config (the driver's stored record keeps config whole and
     # only the names of the other keys)
     def _get(obj, *path):
@@ -837,6 +860,9 @@ def main():
         "parity_fit_green": _get(parity_fit, "green"), "parity_multi_nnz_ids": _get(parity_multi, "topk_ids_bit_exact_vs_oracle"),
         "fit_epochs_per_s": _get(fit, "fit_epochs_per_sec"), "fit_kernel_frac_of_hbm": _get(fit, "roofline_fit", "frac"),
         "step_ms_first_last": [step_ms[0], step_ms[-1]], "prewarm_steps": line["prewarm_steps"],
+        "emulated_rank_ms_predict_n8": _get(scale_emulation, "predict", "per_rank_step_ms"),
+        "emulated_rank_ms_fit_n8": _get(scale_emulation, "fit", "per_rank_compute_ms_per_step"),
+        "fit_wire_gb_per_rank_step_n8": (_get(scale_emulation, "fit", "wire_bytes_per_rank_and_step") or 0) / 1e9 or None,
         "cfg": {name: [v for v in (_get(rec, "green"), _get(rec, "parity_one_step_vs_oracle", "green"),
                                    _get(rec, "parity", "topk_ids_bit_exact_vs_oracle")) if v is not None]
                 for name, rec in (configs or {}).items()} if isinstance(configs, dict) else None,

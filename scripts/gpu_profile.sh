@@ -34,6 +34,12 @@ for f in sorted(glob.glob("$OUT/${TAG}_cfg4_pmc/**/*counter_collection.csv", rec
 out.close(); print(open("$OUT/${TAG}_cfg4_pmc_summary.txt").read()[:3000])
 PY
 fi
+if has ab; then          # item chunks of the int8 launch (workgroup rounds / tail): AB="13 26 52"
+for c in ${AB:-13 26}; do
+  timeout 300 python bench.py --configs headline --no-cpu-baseline --no-fit --no-fp32-mode --no-k1-multi --parity-users 64 --steps 8 --warmup 2 --chunks $c > $OUT/${TAG}_ab_chunks$c.json 2> /dev/null
+  python -c "import json;d=json.load(open('$OUT/${TAG}_ab_chunks$c.json'));print('chunks $c: ms/step %.2f  int8 %.2f ms  frac %.4f  parity %s' % (d['ms_per_step'], d['roofline']['avg_launch_ms'], d['roofline']['frac'], d['parity']['topk_ids_bit_exact_vs_oracle']))"
+done
+fi
 if has tests; then
 timeout 1200 python -m pytest tests -q -m gpu > $OUT/${TAG}_pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -4 $OUT/${TAG}_pytest_gpu.log
 fi

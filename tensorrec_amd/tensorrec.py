@@ -1129,6 +1129,10 @@ class TensorRec(object):
             if filtered else None
         if user_batch_size is None:
             user_batch_size = ops.topk_user_batch(uf.shape[0], itf.shape[0], self.n_components, self._store.device)
+            if sharded:                  # every rank walks the SAME user batches (each batch holds collectives): the smallest wins
+                ubs = torch.tensor([user_batch_size], dtype=torch.int64, device=self._store.device)
+                dist.all_reduce(ubs, op=dist.ReduceOp.MIN, group=self.process_group)
+                user_batch_size = int(ubs.item())
         vals, idx = [], []
         if self.n_components > ops.SCORE_KMAX:
             # wider than the fused kernels' resident operand: score slabs (K-looped fp32 GEMM) + exact ranks pick the top-k
