@@ -455,6 +455,14 @@ int trec_group_pairs_by_item(const int32_t* xu, const int32_t* xi, int64_t n_pai
                              int64_t n_items, int32_t* workspace_i32, int64_t* workspace_i64, int64_t* indptr_t,
                              int32_t* users_t, int32_t* perm_t, int32_t counts_given, const int32_t* ranks,
                              const float* values_in, float* values_out, void* stream);
+/* The same grouping for <= 32,768 buckets and >= 4M pairs (MovieLens-shaped catalogues: 3.7e8 sampled pairs over 26,744 items)
+ * without a single global atomic: per-run counters in the LDS of one workgroup, a column scan over the runs, placement through LDS
+ * cursors (csrc/segment.hip).  trec_group_pairs_lds_runs: the runs the form uses (0: it does not apply); run_counts: int32
+ * [runs][n_items] scratch; workspace_i32: n_items int32; workspace_i64: ceil(n_items / 1024) + 1 int64. */
+int32_t trec_group_pairs_lds_runs(int64_t n_pairs, int64_t n_items);
+int trec_group_pairs_by_item_lds(const int32_t* xu, const int32_t* xi, int64_t n_pairs, int32_t pairs_per_user, int64_t n_items,
+                                 int32_t* workspace_i32, int64_t* workspace_i64, int32_t* run_counts, int64_t* indptr_t,
+                                 int32_t* users_t, int32_t* perm_t, void* stream);
 
 /* ---- K4: ranks ----------------------------------------------------------------------------------------------
  * rank_predictions, recommendation_graphs.py:73-82 (double tf.nn.top_k) as an exact count; int32, 1 = best. */

@@ -18,12 +18,15 @@ fi
 if has cfg4; then
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_cfg4_prof -o cfg4 -- python $REPO/scripts/profile_cfg4.py 3 > $OUT/${TAG}_cfg4.log 2> $OUT/${TAG}_cfg4.err ); echo "cfg4 rocprof rc=$?"; tail -1 $OUT/${TAG}_cfg4.log
 f=$(find $OUT/${TAG}_cfg4_prof -name "*kernel_stats.csv" | head -1); cp $f $OUT/${TAG}_cfg4_fit_kernel_stats.csv 2>/dev/null; head -8 $OUT/${TAG}_cfg4_fit_kernel_stats.csv | cut -c1-160
-( cd /tmp && timeout 600 rocprofv3 --pmc FETCH_SIZE WRITE_SIZE TCC_HIT TCC_MISS --kernel-trace --output-format csv -d $OUT/${TAG}_cfg4_pmc -o pmc -- python $REPO/scripts/profile_cfg4.py 1 > /dev/null 2> $OUT/${TAG}_cfg4_pmc.err ); echo "cfg4 pmc rc=$?"
+for s in "FETCH_SIZE" "WRITE_SIZE TCC_HIT TCC_MISS"; do       # (all four in one pass exceed what the hardware collects at once)
+  n=$(echo $s | cut -d' ' -f1)
+  ( cd /tmp && timeout 600 rocprofv3 --pmc $s --kernel-trace --output-format csv -d $OUT/${TAG}_cfg4_pmc_$n -o pmc -- python $REPO/scripts/profile_cfg4.py 1 > /dev/null 2> $OUT/${TAG}_cfg4_pmc_$n.err ); echo "cfg4 pmc $n rc=$?"
+done
 python - <<PY
 import csv, glob, collections
 out=open("$OUT/${TAG}_cfg4_pmc_summary.txt","w")
 out.write("# rocprofv3 --pmc FETCH_SIZE WRITE_SIZE TCC_HIT TCC_MISS --kernel-trace -- python scripts/profile_cfg4.py 1 ; per-dispatch averages (KB)\n")
-for f in sorted(glob.glob("$OUT/${TAG}_cfg4_pmc/**/*counter_collection.csv", recursive=True)):
+for f in sorted(glob.glob("$OUT/${TAG}_cfg4_pmc_*/**/*counter_collection.csv", recursive=True)):
     agg=collections.defaultdict(lambda: collections.defaultdict(float)); seen=set()
     for r in csv.DictReader(open(f)):
         k=r["Kernel_Name"][:70]; agg[k][r["Counter_Name"]]+=float(r["Counter_Value"]); seen.add((k,r["Dispatch_Id"]))

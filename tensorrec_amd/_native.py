@@ -110,6 +110,8 @@ SIGNATURES = {
     "trec_pair_score_fwd": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
     "trec_pair_score_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
     "trec_group_pairs_by_item": [_vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp],
+    "trec_group_pairs_lds_runs": [_i64, _i64],
+    "trec_group_pairs_by_item_lds": [_vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "trec_rank_rows": [_vp, _i64, _i64, _i64, _vp, _i64, _vp],
     "trec_rank_rows_workspace_bytes": [_i64, _i64],
     "trec_rank_rows_chunked": [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp],

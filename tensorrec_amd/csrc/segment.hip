@@ -244,3 +244,111 @@ extern "C" int trec_exclusive_scan_i32(const int32_t* counts, int64_t n, int64_t
     hipLaunchKernelGGL(seg_add_offsets_kernel, dim3((unsigned)ceil_div64(n + 1, 256)), dim3(256), 0, st, out, n, block_sum, total);
     return trec_check_launch("trec_exclusive_scan_i32");
 }
+
+// ---- a few tens of thousands of buckets, hundreds of millions of pairs: counters in LDS, no global atomics ------------------
+// BASELINE.json configs[4] (MovieLens-20M-shaped): 3.7e8 sampled pairs per step over 26,744 items -- 13,800 pairs per bucket.
+// The plain path issues one global atomic per pair in the histogram AND in the fill, thousands deep on every counter: 16 + 30 ms
+// of a 200 ms epoch (profiles/r04_cfg4_fit_kernel_stats.csv).  The counters of <= 32,768 buckets fit the LDS of ONE workgroup
+// (128 KB), so: (1) every workgroup counts a contiguous RUN of pairs in LDS and writes its counters out, run_counts [n_runs]
+// [n_items]; (2) one thread per bucket scans its column over the runs (exclusive, in place) and leaves the bucket's total; the
+// usual scan of the totals gives indptr; (3) every workgroup loads ITS row of run bases into LDS and places its run --
+// slot = indptr[item] + (LDS cursor)++ -- so a run's pairs of one item land on consecutive slots.  No global atomic anywhere;
+// the order of pairs inside a (run, item) group follows LDS atomic arrival (runs themselves are in order).
+#define SEG_LDS_MAX 32768
+
+__global__ __launch_bounds__(1024) void seg_lds_count_kernel(const int32_t* __restrict__ xi, int64_t n_pairs, int32_t n_items,
+                                                            int64_t run_len, int32_t* __restrict__ run_counts)
+{
+    extern __shared__ int32_t l_cnt[];
+    for (int i = threadIdx.x; i < n_items; i += 1024) l_cnt[i] = 0;
+    __syncthreads();
+    const int64_t p0 = (int64_t)blockIdx.x * run_len;
+    const int64_t p1 = (p0 + run_len < n_pairs) ? p0 + run_len : n_pairs;
+    for (int64_t p = p0 + threadIdx.x; p < p1; p += 1024) {
+        const int32_t i = xi[p];
+        if (i >= 0) atomicAdd(l_cnt + i, 1);
+    }
+    __syncthreads();
+    int32_t* out = run_counts + (int64_t)blockIdx.x * n_items;
+    for (int i = threadIdx.x; i < n_items; i += 1024) out[i] = l_cnt[i];
+}
+
+__global__ __launch_bounds__(256) void seg_lds_scan_runs_kernel(int32_t* __restrict__ run_counts, int32_t n_runs, int32_t n_items,
+                                                               int32_t* __restrict__ counts)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_items) return;
+    int32_t acc = 0;
+    for (int r = 0; r < n_runs; ++r) {
+        const int32_t c = run_counts[(int64_t)r * n_items + i];
+        run_counts[(int64_t)r * n_items + i] = acc;
+        acc += c;
+    }
+    counts[i] = acc;
+}
+
+__global__ __launch_bounds__(1024) void seg_lds_fill_kernel(const int32_t* __restrict__ xu, const int32_t* __restrict__ xi,
+                                                           int64_t n_pairs, int32_t pairs_per_user, int32_t n_items,
+                                                           int64_t run_len, const int32_t* __restrict__ run_base,
+                                                           const int64_t* __restrict__ indptr, int32_t* __restrict__ users_t,
+                                                           int32_t* __restrict__ perm_t)
+{
+    extern __shared__ int32_t l_cur[];
+    const int32_t* base = run_base + (int64_t)blockIdx.x * n_items;
+    for (int i = threadIdx.x; i < n_items; i += 1024) l_cur[i] = base[i];
+    __syncthreads();
+    const int64_t p0 = (int64_t)blockIdx.x * run_len;
+    const int64_t p1 = (p0 + run_len < n_pairs) ? p0 + run_len : n_pairs;
+    for (int64_t p = p0 + threadIdx.x; p < p1; p += 1024) {
+        const int32_t i = xi[p];
+        if (i < 0) continue;
+        const int64_t slot = indptr[i] + atomicAdd(l_cur + i, 1);
+        users_t[slot] = xu ? xu[p] : (int32_t)(p / pairs_per_user);
+        perm_t[slot] = (int32_t)p;
+    }
+}
+
+// runs the LDS form uses for n_pairs (0: the form does not apply) and its workspace: run_counts int32 [n_runs][n_items]
+extern "C" int32_t trec_group_pairs_lds_runs(int64_t n_pairs, int64_t n_items)
+{
+    if (n_items < 1 || n_items > SEG_LDS_MAX || n_pairs < ((int64_t)1 << 22)) return 0;
+    int64_t runs = ceil_div64(n_pairs, 262144);            // >= 256k pairs per run: ~10 per bucket at 26k buckets
+    if (runs > 1024) runs = 1024;
+    if (runs < 1) runs = 1;
+    return (int32_t)runs;
+}
+
+// trec_group_pairs_by_item for <= 32,768 buckets and >= 4M pairs without a single global atomic (see above).
+// workspace_i32: n_items int32 (the buckets' totals); workspace_i64: ceil(n_items / 1024) + 1 int64; run_counts: int32
+// [trec_group_pairs_lds_runs(n_pairs, n_items)][n_items].  Outputs as trec_group_pairs_by_item (users_t, perm_t both required).
+extern "C" int trec_group_pairs_by_item_lds(const int32_t* xu, const int32_t* xi, int64_t n_pairs, int32_t pairs_per_user,
+                                            int64_t n_items, int32_t* workspace_i32, int64_t* workspace_i64,
+                                            int32_t* run_counts, int64_t* indptr_t, int32_t* users_t, int32_t* perm_t,
+                                            void* stream)
+{
+    TREC_REQUIRE(xi && workspace_i32 && workspace_i64 && run_counts && indptr_t && users_t && perm_t, "trec_group_pairs_by_item_lds: null pointer");
+    TREC_REQUIRE(xu || pairs_per_user >= 1, "trec_group_pairs_by_item_lds: need xu or pairs_per_user");
+    TREC_REQUIRE(n_pairs < ((int64_t)1 << 31), "trec_group_pairs_by_item_lds: n_pairs must fit int32");
+    const int32_t n_runs = trec_group_pairs_lds_runs(n_pairs, n_items);
+    TREC_REQUIRE(n_runs >= 1, "trec_group_pairs_by_item_lds: needs <= 32768 buckets and >= 4M pairs (trec_group_pairs_lds_runs)");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t run_len = ceil_div64(n_pairs, n_runs);
+    const int lds = (int)n_items * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)seg_lds_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SEG_LDS_MAX * 4);
+        (void)hipFuncSetAttribute((const void*)seg_lds_fill_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SEG_LDS_MAX * 4);
+        attr_set = true;
+    }
+    int32_t* counts = workspace_i32;
+    const int n_blocks = (int)ceil_div64(n_items, 1024);
+    int64_t* block_sum = workspace_i64;
+    int64_t* total = workspace_i64 + n_blocks;
+    hipLaunchKernelGGL(seg_lds_count_kernel, dim3((unsigned)n_runs), dim3(1024), lds, st, xi, n_pairs, (int32_t)n_items, run_len, run_counts);
+    hipLaunchKernelGGL(seg_lds_scan_runs_kernel, dim3((unsigned)ceil_div64(n_items, 256)), dim3(256), 0, st, run_counts, n_runs, (int32_t)n_items, counts);
+    hipLaunchKernelGGL(seg_scan_local_kernel, dim3((unsigned)n_blocks), dim3(256), 0, st, counts, n_items, indptr_t, block_sum);
+    hipLaunchKernelGGL(seg_scan_blocks_kernel, dim3(1), dim3(256), 0, st, block_sum, n_blocks, total);
+    hipLaunchKernelGGL(seg_add_offsets_kernel, dim3((unsigned)ceil_div64(n_items + 1, 256)), dim3(256), 0, st, indptr_t, n_items, block_sum, total);
+    hipLaunchKernelGGL(seg_lds_fill_kernel, dim3((unsigned)n_runs), dim3(1024), lds, st, xu, xi, n_pairs, pairs_per_user, (int32_t)n_items, run_len, run_counts, indptr_t, users_t, perm_t);
+    return trec_check_launch("trec_group_pairs_by_item_lds");
+}

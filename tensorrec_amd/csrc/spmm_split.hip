@@ -99,8 +99,11 @@ __device__ __forceinline__ Entry load_entry(const int32_t* __restrict__ indices,
     return en;
 }
 
-// acc (+)= sum over non-zeros [j0, j1) of val * x(col), x = W row or (own - W row); CSR order, one fmaf per element;
-// four gathers in flight
+// acc (+)= sum over non-zeros [j0, j1) of val * x(col), x = W row or (own - W row); CSR order, one fmaf per element.
+// Four row gathers in flight, and the NEXT four entries {column, value} are fetched before the current four rows are: an
+// iteration used to be two dependent round trips (entries -> rows), i.e. ~4 us per 4 rows of a subgroup whatever the
+// bandwidth; with the entries one step ahead it is one (round 4: configs[4]'s item-side gather of 3.7e8 sampled pairs,
+// 1 KB rows from a cache-resident table, ran at 3.6 TB/s -- latency-, not bandwidth-bound).  Same chain, same bits.
 template <int ITERS, bool PACKED, int VEC>
 __device__ __forceinline__ void gather_range(const int32_t* __restrict__ indices, const float* __restrict__ values,
                                              const int32_t* __restrict__ val_perm, int64_t j0, int64_t j1,
@@ -111,10 +114,16 @@ __device__ __forceinline__ void gather_range(const int32_t* __restrict__ indices
 {
     typedef typename VecOf<VEC>::T V;
     int64_t j = j0;
-    for (; j + 3 < j1; j += 4) {
-        Entry en[4];
+    Entry en[4];
+    if (j + 3 < j1) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) en[q] = load_entry<PACKED>(indices, values, val_perm, j + q);
+    }
+    for (; j + 3 < j1; j += 4) {
+        Entry nx[4];
+        const bool more = j + 7 < j1;                                     // (uniform over the subgroup)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) nx[q] = more ? load_entry<PACKED>(indices, values, val_perm, j + 4 + q) : en[q];
         V x[4][ITERS];
 #pragma unroll
         for (int q = 0; q < 4; ++q)
@@ -132,16 +141,18 @@ __device__ __forceinline__ void gather_range(const int32_t* __restrict__ indices
                 vfma(acc[it], en[q].val, xv);
             }
         }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) en[q] = nx[q];
     }
     for (; j < j1; ++j) {
-        const Entry en = load_entry<PACKED>(indices, values, val_perm, j);
-        vsum += en.val;
+        const Entry e1 = load_entry<PACKED>(indices, values, val_perm, j);
+        vsum += e1.val;
 #pragma unroll
         for (int it = 0; it < ITERS; ++it)
             if (cvalid[it]) {
-                const V xr = *(const V*)(W + (int64_t)en.col * d + col[it]);
+                const V xr = *(const V*)(W + (int64_t)e1.col * d + col[it]);
                 const V xv = diff ? ownv[it] - xr : xr;
-                vfma(acc[it], en.val, xv);
+                vfma(acc[it], e1.val, xv);
             }
     }
 }

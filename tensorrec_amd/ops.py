@@ -450,6 +450,20 @@ def group_pairs_by_item(xu32, xi32, pairs_per_user, n_items, workspace_with_coun
             entries = torch.stack([users.to(torch.int32), values[order].contiguous().view(torch.int32)], dim=1).contiguous()
             return indptr_t, entries, None
         return indptr_t, users.to(torch.int32).contiguous(), order.to(torch.int32).contiguous()
+    n_runs = int(N.query("trec_group_pairs_lds_runs", int(n_pairs), int(n_items))) \
+        if workspace_with_counts is None and ranks is None and N.load().trec_get_tuning(b"group_pairs_lds", 1) != 0 else 0
+    if n_runs > 0:
+        # few buckets, very many pairs (MovieLens-shaped catalogues): counters in LDS, no global atomics (csrc/segment.hip)
+        ws32 = torch.empty((n_items,), dtype=torch.int32, device=dev)
+        ws64 = torch.empty(((n_items + 1023) // 1024 + 1,), dtype=torch.int64, device=dev)
+        run_counts = torch.empty((n_runs, n_items), dtype=torch.int32, device=dev)
+        indptr_t = torch.empty((n_items + 1,), dtype=torch.int64, device=dev)
+        users_t = torch.empty((n_pairs,), dtype=torch.int32, device=dev)
+        perm_t = torch.empty((n_pairs,), dtype=torch.int32, device=dev)
+        with _timed("group_pairs_by_item"):
+            N.call("trec_group_pairs_by_item_lds", N.ptr(xu32), N.ptr(xi32), n_pairs, pairs_per_user, n_items, N.ptr(ws32),
+                   N.ptr(ws64), N.ptr(run_counts), N.ptr(indptr_t), N.ptr(users_t), N.ptr(perm_t))
+        return indptr_t, users_t, perm_t
     ws32 = workspace_with_counts if workspace_with_counts is not None else \
         torch.empty((2 * n_items,), dtype=torch.int32, device=dev)
     ws64 = torch.empty(((n_items + 1023) // 1024 + 1,), dtype=torch.int64, device=dev)
@@ -1410,7 +1424,13 @@ def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, 
                 N.call("trec_topk_dense_users", N.ptr(table), n_sb, n_u, stride, N.ptr(tau), N.ptr(user_err), N.ptr(iop.sb_stats),
                        kpad, CASCADE_DENSE_USER_LIMIT if n_i >= CASCADE_MIN_ITEMS else 30, N.ptr(cands.floor0), N.ptr(cands.flag),
                        N.ptr(cands.n_flagged))             # (small catalogues: the k-th largest of few maxima keeps half the rows of anybody)
-            cands.items = torch.empty((n_u, cands.cap, 2), dtype=torch.int32, device=dev)     # only the listed part is touched
+            try:
+                cands.items = torch.empty((n_u, cands.cap, 2), dtype=torch.int32, device=dev)     # only the listed part is touched
+            except torch.cuda.OutOfMemoryError:
+                # (2 KB of list slots per user is a reservation, not traffic; on a device that cannot spare it the lists shrink
+                # to 64 slots -- users beyond them are flagged and re-done on their table column -- ADVICE r3)
+                cands.cap = 64
+                cands.items = torch.empty((n_u, cands.cap, 2), dtype=torch.int32, device=dev)
             if N.load().trec_get_tuning(b"cascade_wg_map", 1) != 0:
                 # only the workgroup slots that hold rows are launched (98k of the 1.9M of the [n_sb][rcap / 512] grid at 1M x 1M)
                 wg_cap = min(n_sb * (rcap // 512), max_pairs // 512 + n_sb + 1)

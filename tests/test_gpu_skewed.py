@@ -294,3 +294,43 @@ def test_rank_of_pairs_by_user_equals_wave_per_pair(ops, n_items):
     assert np.array_equal(part, ref)
     empty = ops.rank_of_pairs_by_user(st, 0, 7, 7, dev(indptr), dev(xi), tgt, add_one=True).cpu().numpy()
     assert (empty == 1).all()
+
+
+def test_group_pairs_by_item_with_lds_counters(ops):
+    """trec_group_pairs_by_item_lds (few buckets, very many pairs: MovieLens-shaped catalogues): per-run counters in LDS, a column
+    scan over the runs, placement through LDS cursors -- no global atomic.  The result is a valid grouping: indptr = the prefix of
+    the bucket sizes, every valid pair appears exactly once inside its item's range with its own user, runs stay in order inside
+    a bucket; negative keys are dropped.  ops.group_pairs_by_item picks the form by itself."""
+    import numpy as np
+    import torch
+    from tensorrec_amd import _native as N
+    rng = np.random.default_rng(8)
+    n_users, S, n_items = 60_000, 80, 20_011                       # 4.8M pairs
+    zipf = 1.0 / np.arange(1, n_items + 1) ** 0.7
+    xi = rng.choice(n_items, size=n_users * S, p=zipf / zipf.sum()).astype(np.int32)
+    xi[rng.random(xi.size) < 0.01] = -1                            # dropped pairs
+    n_pairs = xi.size
+    assert N.query("trec_group_pairs_lds_runs", n_pairs, n_items) > 0
+    dxi = torch.from_numpy(xi).cuda()
+    for explicit_users in (False, True):
+        xu = (np.arange(n_pairs) // S).astype(np.int32)
+        dxu = torch.from_numpy(xu).cuda() if explicit_users else None
+        indptr, users_t, perm_t = ops.group_pairs_by_item(dxu, dxi, S, n_items)
+        indptr, users_t, perm_t = indptr.cpu().numpy(), users_t.cpu().numpy(), perm_t.cpu().numpy()
+        counts = np.bincount(xi[xi >= 0], minlength=n_items)
+        assert np.array_equal(indptr, np.concatenate([[0], np.cumsum(counts)]))
+        n_valid = int(indptr[-1])
+        perm = perm_t[:n_valid]
+        assert np.array_equal(np.sort(perm), np.flatnonzero(xi >= 0))              # every valid pair exactly once
+        assert np.array_equal(xi[perm], np.repeat(np.arange(n_items), counts))      # ... inside its item's range
+        assert np.array_equal(users_t[:n_valid], xu[perm])                          # ... with its own user
+    # against the atomic form: the same buckets as SETS
+    N.set_tuning("group_pairs_lds", 0)
+    try:
+        ind2, users2, perm2 = ops.group_pairs_by_item(None, dxi, S, n_items)
+    finally:
+        N.set_tuning("group_pairs_lds", 1)
+    assert np.array_equal(ind2.cpu().numpy(), indptr)
+    p2 = perm2.cpu().numpy()[:n_valid]
+    for b in (0, 1, 17, n_items - 1):
+        assert set(p2[indptr[b]:indptr[b + 1]].tolist()) == set(perm[indptr[b]:indptr[b + 1]].tolist())
