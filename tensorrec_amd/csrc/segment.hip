@@ -299,7 +299,24 @@ __global__ __launch_bounds__(1024) void seg_lds_fill_kernel(const int32_t* __res
     __syncthreads();
     const int64_t p0 = (int64_t)blockIdx.x * run_len;
     const int64_t p1 = (p0 + run_len < n_pairs) ? p0 + run_len : n_pairs;
-    for (int64_t p = p0 + threadIdx.x; p < p1; p += 1024) {
+    // four pairs per thread and step: their key loads, LDS cursors, row-pointer gathers and stores are independent chains
+    int64_t p = p0 + threadIdx.x;
+    for (; p + 3 * 1024 < p1; p += 4 * 1024) {
+        int32_t it[4];
+        int64_t slot[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) it[q] = xi[p + q * 1024];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) slot[q] = it[q] >= 0 ? indptr[it[q]] + atomicAdd(l_cur + it[q], 1) : -1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (slot[q] >= 0) {
+                const int64_t pp = p + q * 1024;
+                users_t[slot[q]] = xu ? xu[pp] : (int32_t)(pp / pairs_per_user);
+                perm_t[slot[q]] = (int32_t)pp;
+            }
+    }
+    for (; p < p1; p += 1024) {
         const int32_t i = xi[p];
         if (i < 0) continue;
         const int64_t slot = indptr[i] + atomicAdd(l_cur + i, 1);
@@ -312,8 +329,10 @@ __global__ __launch_bounds__(1024) void seg_lds_fill_kernel(const int32_t* __res
 extern "C" int32_t trec_group_pairs_lds_runs(int64_t n_pairs, int64_t n_items)
 {
     if (n_items < 1 || n_items > SEG_LDS_MAX || n_pairs < ((int64_t)1 << 22)) return 0;
-    int64_t runs = ceil_div64(n_pairs, 262144);            // >= 256k pairs per run: ~10 per bucket at 26k buckets
-    if (runs > 1024) runs = 1024;
+    // one run per workgroup; long runs make a run's pairs of one bucket a long run of consecutive slots (13,800 pairs per
+    // bucket over 256 runs: 54 slots = whole cache lines; over 1,024 runs: 14 slots, and the fill wrote 23 GB for 3 GB of payload)
+    int64_t runs = ceil_div64(n_pairs, 262144);
+    if (runs > 256) runs = 256;
     if (runs < 1) runs = 1;
     return (int32_t)runs;
 }
