@@ -329,8 +329,10 @@ __global__ __launch_bounds__(1024) void seg_lds_fill_kernel(const int32_t* __res
 extern "C" int32_t trec_group_pairs_lds_runs(int64_t n_pairs, int64_t n_items)
 {
     if (n_items < 1 || n_items > SEG_LDS_MAX || n_pairs < ((int64_t)1 << 22)) return 0;
-    // one run per workgroup; long runs make a run's pairs of one bucket a long run of consecutive slots (13,800 pairs per
-    // bucket over 256 runs: 54 slots = whole cache lines; over 1,024 runs: 14 slots, and the fill wrote 23 GB for 3 GB of payload)
+    // one run per workgroup and CU.  (Measured on configs[4], 3.7e8 pairs over 26,744 buckets: 1,024 runs 21.4 ms, 256 runs
+    // 22.6 ms -- the placement is bound by its 7.4e8 scattered 4-byte stores (PMC: 23 GB written for 3 GB of payload), which a
+    // run's ~54 consecutive slots per bucket do not change: the slots of a cache line are written by different threads far apart
+    // in time.  Coalescing them takes a two-level partition through LDS tiles; not built.)
     int64_t runs = ceil_div64(n_pairs, 262144);
     if (runs > 256) runs = 256;
     if (runs < 1) runs = 1;
