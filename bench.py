@@ -166,8 +166,10 @@ def fit_epochs_per_sec(n_users, n_items, d, per_user=20, n_sampled=100, epochs=3
     K3 over the interactions and the U*S sampled pairs, K6 WMRB fwd+bwd, backward gathers (K1 on transposed / grouped
     structures), K8 dense Adam on every weight.  20 uniform-random positive interactions per user.
     N ranks: data-parallel over users (the reference's batching axis) -- every rank takes a contiguous slice of user
-    rows, items and weights are replicated, ONE all-reduce(SUM) per weight gradient per step (tensorrec_amd/sharding.py);
-    the problem stays 1M x 1M (strong scaling) and the time is the slowest rank's."""
+    rows; per weight the exchange plan of TensorRec._dp_make_plan (sharding.plan_gradient_exchange): tables whose touched
+    rows are rank-disjoint (the user tables under these identity features) are stepped by their owner with no exchange,
+    shared tables reduce-scatter -> Adam on the owned rows -> all-gather, small ones all-reduce; the problem stays 1M x 1M
+    (strong scaling) and the time is the slowest rank's."""
     import scipy.sparse as sp
     import torch
     import tensorrec_amd as T
@@ -249,7 +251,9 @@ def fit_epochs_per_sec(n_users, n_items, d, per_user=20, n_sampled=100, epochs=3
                         "interactions, n_sampled_items=%d, device sampler, 1 optimiser step per epoch"
                         % (n_users, n_items, d, nnz, n_sampled),
             "parallelism": "single GPU" if world == 1 else
-                           "users sharded x%d (data-parallel), items + weights replicated, gradient all-reduce" % world,
+                           "users sharded x%d (data-parallel); gradient exchange per table: %s" % (
+                               world, ", ".join("%s=%s" % kv for kv in sorted((getattr(model, "_dp_plan", None) or
+                                                                               sharding.GradPlan()).mode.items()))),
             "per_call_input_upload_sec": one - per_epoch}
 
 

@@ -344,9 +344,24 @@ __global__ __launch_bounds__(256, WPS) void blockmax_pipe_kernel(ScoreParams p)
 constexpr int LQ_CAP = 448;               // queue entries per wave (20 bytes each: 35,840 bytes per workgroup)
 constexpr int LQ_FLUSH = 192;             // a queue fuller than this is emptied before the next half block step (192 + 4 * 64 <= 448)
 
+#ifdef TREC_CAND_DIAG
+// diagnostics build only: where a workgroup of the refining launch (GRP && LIST) spends its life, summed over workgroups in
+// units of the 100 MHz wall clock -- [0] workgroups, [1] entry -> operands resident (row_index -> user rows, floors, tile 0),
+// [2] the tile loop (bodies, waits for the next tile, barriers), [4] queue flush + maxima stores at the superblock end (issue
+// time: the stores drain behind it), [5] whole life.  Only a handful of stamps per workgroup: stamps around every tile body
+// (a first version) slowed the new prologue's kernel from 8.0 to 16 ms -- the tool, not the code
+__device__ unsigned long long g_refine_clk[8];
+#endif
+
 template <int KT, bool BIAS, bool GRP, int NUB = 8, bool RDL = false, bool LIST = false>
 __global__ __launch_bounds__(256, NUB == 8 ? 2 : 3) void blockmax_bf16x16_kernel(ScoreParams p)
 {
+#ifdef TREC_CAND_DIAG
+    const unsigned long long dg_t0 = wall_clock64();
+    unsigned long long dg_body = 0, dg_wait = 0, dg_flush = 0, dg_t1 = 0, dg_ta = dg_t0, dg_tb = dg_t0;
+    // (cand_diag & 16, with the row-contiguous gather: the hops of the prologue one after the other -- [6] row ids + first item
+    // tile resident, [7] user rows resident; the rest of [1] is the floors / counters / biases and the barrier)
+#endif
     constexpr int RW = 4 * NUB * 16;         // resident rows per workgroup
     constexpr int OW = NUB / 4;
     constexpr int RB = KT * 2;               // bytes per operand row
@@ -372,6 +387,7 @@ __global__ __launch_bounds__(256, NUB == 8 ? 2 : 3) void blockmax_bf16x16_kernel
     float* q_fl = (float*)(smem + LQ_OFF + 4 * LQ_CAP * 20) + wave * (NUB * 16);
     float* q_bu = q_fl + 4 * NUB * 16;
     int32_t* q_id = (int32_t*)(q_bu + 4 * NUB * 16);
+    float* q_ta = (float*)(q_id + 4 * NUB * 16);                // ... and the accumulator threshold of each (read once, in the prologue)
     int qn = 0;                                                  // wave-uniform: entries in the queue
     int rblock = GRP ? (p.wg_map ? p.wg_map[blockIdx.x] : (int)blockIdx.x) : (int)(blockIdx.x % p.n_rblocks);
     if (GRP && p.capacity > 0 && p.grp_band_major && !p.wg_map) {
@@ -404,60 +420,11 @@ __global__ __launch_bounds__(256, NUB == 8 ? 2 : 3) void blockmax_bf16x16_kernel
     // distinct 16-byte positions modulo 128 bytes = all 32 banks
     auto swz = [](int row) { return row & (CH - 1); };
 
-    // ---- resident user fragments: lane holds k = 32 ks + 8 g + 0..7 of user lu of each block ----
-    bf16x8 rfb[NUB][KS];
-    float thr_a[NUB];                                            // LIST: an accumulator below this cannot reach the user's floor
-#pragma unroll
-    for (int ub = 0; ub < NUB; ++ub) {
-        int64_t row = r_base + ub * 16 + lu;
-        bool real = row < p.n_r;
-        if (row >= p.n_r) row = p.n_r - 1;                       // clamped rows are never written
-        if (GRP) {                                               // padding rows compute on user 0
-            const bool pad = fixed && wave * (NUB * 16) + ub * 16 + lu >= rows_here;
-            const int32_t s = pad ? -1 : p.row_index[row];
-            real = s >= 0;
-            row = s < 0 ? 0 : s;
-        }
-        const char* src = (const char*)p.R + row * (int64_t)RB;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) rfb[ub][ks] = *(const bf16x8*)(src + (ks * 4 + g) * 16);
-        thr_a[ub] = INFINITY;
-        if (LIST) {
-            float fl = real ? p.cand_floor[row] : INFINITY;
-            if (real && p.cand_n[row] > p.cand_cap) fl = INFINITY;        // the list is already incomplete: the user will be re-done
-            const float bu = (BIAS && p.r_bias && real) ? p.r_bias[row] : 0.f;
-            // acc + bu >= fl (evaluated exactly when the queue is emptied) implies acc >= thr_a: fl - bu less three roundings
-            const float t = fl - bu;
-            float ta = t - (fabsf(fl) + fabsf(bu) + fabsf(t)) * 2.4e-7f;
-            if (bu == 0.f) ta = fl;
-            if (!(fl < INFINITY)) ta = INFINITY;                 // padding rows, users without a usable bound: nothing is listed
-            else if (!(ta == ta)) ta = -INFINITY;                // (fl = -inf: everything is)
-            thr_a[ub] = ta;
-            if (g == 0) {
-                q_fl[ub * 16 + lu] = fl;
-                q_bu[ub * 16 + lu] = bu;
-                q_id[ub * 16 + lu] = real ? (int32_t)row : -1;
-            }
-        }
-    }
-    // the users this lane stores at superblock ends
-    int64_t own_u[OW];
-    float own_bias[OW];
-#pragma unroll
-    for (int o = 0; o < OW; ++o) {
-        const int64_t row = r_base + (OW * g + o) * 16 + lu;
-        if (GRP) own_u[o] = (fixed && wave * (NUB * 16) + (OW * g + o) * 16 + lu >= rows_here) ? -1 : p.row_index[row];   // -1: padding
-        else own_u[o] = row < p.n_r ? row : -1;
-        own_bias[o] = (BIAS && p.r_bias && own_u[o] >= 0) ? p.r_bias[own_u[o]] : 0.f;
-    }
-
-    int slot_off[NSLOT];
-#pragma unroll
-    for (int i = 0; i < NSLOT; ++i) {
-        const int q = i * 256 + tid;
-        const int row = q / CH, pc = q % CH;
-        slot_off[i] = row * RB + ((pc ^ swz(row)) * 16);
-    }
+    // staging slot q = i * 256 + tid -> (row, physical chunk); 256 / CH rows per slot round is a multiple of CH, so the swizzle
+    // term does not depend on i: ONE offset register, slot i is 256 * 16 bytes further (four separate offsets were spilled by
+    // the LIST form and re-loaded from scratch in every tile step, behind s_waitcnt vmcnt(0) -- in the middle of the next tile's DMA)
+    static_assert((256 / CH) % CH == 0, "swizzle term independent of the slot round");
+    const int slot_off0 = (tid / CH) * RB + (((tid % CH) ^ swz(tid / CH)) * 16);
     const char* t_chunk = (const char*)p.T + t_begin * (int64_t)RB;
     auto stage_issue = [&](int tile, int buf) {
         const int64_t row0 = t_begin + (int64_t)tile * BN;
@@ -475,7 +442,7 @@ __global__ __launch_bounds__(256, NUB == 8 ? 2 : 3) void blockmax_bf16x16_kernel
         const char* tile_base = t_chunk + (int64_t)tile * (BN * RB);
 #pragma unroll
         for (int i = 0; i < NSLOT; ++i) {
-            int off = slot_off[i];
+            int off = slot_off0 + i * 4096;
             if (clamp) {
                 const int last = (int)(p.n_t - 1 - row0);
                 const int row = (i * 256 + tid) / CH;
@@ -486,6 +453,108 @@ __global__ __launch_bounds__(256, NUB == 8 ? 2 : 3) void blockmax_bf16x16_kernel
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         }
     };
+
+    // grouped launches: the first item tile is requested BEFORE the dependent user gathers (row_index -> rows), not behind
+    // them (refining launch 10.25 -> 9.80 ms at 1M x 1M); the dense launches keep their order (contiguous rows, nothing to hide)
+    if (GRP) stage_issue(0, 0);
+    // ---- resident user fragments: lane holds k = 32 ks + 8 g + 0..7 of user lu of each block ----
+    // The prologue of a grouped launch is a chain of dependent gathers (row ids -> user rows, floors, counters, biases).  Written
+    // with the loads under `real ? ... : ...` the compiler made an exec-masked block per load, each ending in s_waitcnt
+    // vmcnt(0): ~30 serial round trips per workgroup, 13 of the 19 us a refining workgroup spent before its first MFMA
+    // (profiles/r04_refine_clocks.json; the row gathers themselves: 4 us).  Now: lane l of a wave owns local rows l, 64 + l, ...
+    // -- ONE coalesced, unconditional read of their row ids, ONE batch of unconditional gathers of their list parameters (each
+    // user once per wave, not once per k-group lane), the results through LDS / shuffles to the lanes that need them.
+    constexpr int NRI = NUB * 16 / 64;
+    int32_t ri[NRI];                                             // source row (of R and the per-user arrays), -1: padding / no user
+#pragma unroll
+    for (int h = 0; h < NRI; ++h) {
+        const int local = h * 64 + lane;
+        const int64_t row = r_base + local;
+        const bool inb = row < p.n_r;
+        int32_t idx = (int32_t)row;
+        if (GRP) idx = p.row_index[inb ? row : p.n_r - 1];
+        const bool pad = !inb || (fixed && wave * (NUB * 16) + local >= rows_here);
+        ri[h] = (pad || idx < 0) ? -1 : idx;
+    }
+    bf16x8 rfb[NUB][KS];
+    float thr_a[NUB];                                            // LIST: an accumulator below this cannot reach the user's floor
+    int64_t frow[NUB];
+    bool real[NUB];
+#pragma unroll
+    for (int ub = 0; ub < NUB; ++ub) {
+        const int32_t s = __shfl(ri[ub >> 2], (ub & 3) * 16 + lu, 64);
+        real[ub] = s >= 0;
+        frow[ub] = s >= 0 ? s : 0;                               // padding rows compute on user 0 (never written)
+        const char* src = (const char*)p.R + frow[ub] * (int64_t)RB;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) rfb[ub][ks] = *(const bf16x8*)(src + (ks * 4 + g) * 16);
+        thr_a[ub] = INFINITY;
+#ifdef TREC_CAND_DIAG
+        // (A/B: the row gathers throttled -- a wait after every block / every second block)
+        if ((p.cand_diag & 64) || ((p.cand_diag & 128) && (ub & 1))) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    }
+    if (LIST) {
+        float flv[NRI], buv[NRI];
+        int32_t cnv[NRI];
+        const float* rbias = (BIAS && p.r_bias) ? p.r_bias : p.cand_floor;
+#pragma unroll
+        for (int h = 0; h < NRI; ++h) {
+            const int64_t r = ri[h] >= 0 ? ri[h] : 0;
+            flv[h] = p.cand_floor[r];
+            cnv[h] = p.cand_n[r];
+            buv[h] = rbias[r];
+        }
+#pragma unroll
+        for (int h = 0; h < NRI; ++h) {
+            const bool rl = ri[h] >= 0;
+            float fl = rl ? flv[h] : INFINITY;
+#ifdef TREC_CAND_DIAG
+            if (!(p.cand_diag & 32))                             // (the cost of this gather)
+#endif
+            if (rl && cnv[h] > p.cand_cap) fl = INFINITY;        // the list is already incomplete: the user will be re-done
+            const float bu = (BIAS && p.r_bias && rl) ? buv[h] : 0.f;
+            // acc + bu >= fl (evaluated exactly when the queue is emptied) implies acc >= thr_a: fl - bu less three roundings
+            const float t = fl - bu;
+            float ta = t - (fabsf(fl) + fabsf(bu) + fabsf(t)) * 2.4e-7f;
+            if (bu == 0.f) ta = fl;
+            if (!(fl < INFINITY)) ta = INFINITY;                 // padding rows, users without a usable bound: nothing is listed
+            else if (!(ta == ta)) ta = -INFINITY;                // (fl = -inf: everything is)
+            q_fl[h * 64 + lane] = fl;
+            q_bu[h * 64 + lane] = bu;
+            q_id[h * 64 + lane] = ri[h];
+            q_ta[h * 64 + lane] = ta;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int ub = 0; ub < NUB; ++ub) thr_a[ub] = q_ta[ub * 16 + lu];
+    }
+    // the users this lane stores at superblock ends: blocks OW g .. OW g + OW - 1 (rows it already holds for block OW g + o).
+    // The LIST form reads them (and their biases) from its LDS arrays when a superblock ends -- six registers it does not have.
+    int64_t own_u[OW];
+    float own_bias[OW];
+#pragma unroll
+    for (int o = 0; o < OW; ++o) { own_u[o] = -1; own_bias[o] = 0.f; }
+    if (!LIST) {
+#pragma unroll
+        for (int o = 0; o < OW; ++o) {
+            const int64_t r0 = real[o] ? frow[o] : -1, r1 = real[OW + o] ? frow[OW + o] : -1;
+            const int64_t r2 = real[2 * OW + o] ? frow[2 * OW + o] : -1, r3 = real[3 * OW + o] ? frow[3 * OW + o] : -1;
+            own_u[o] = g == 0 ? r0 : (g == 1 ? r1 : (g == 2 ? r2 : r3));
+        }
+        if (BIAS && p.r_bias) {
+            float ob[OW];
+#pragma unroll
+            for (int o = 0; o < OW; ++o) {
+                ob[o] = p.r_bias[own_u[o] >= 0 ? own_u[o] : 0];
+                asm volatile("" : "+v"(ob[o]));                  // (keeps the load where it is: not sunk into the select below)
+            }
+#pragma unroll
+            for (int o = 0; o < OW; ++o) own_bias[o] = own_u[o] >= 0 ? ob[o] : 0.f;
+        }
+    }
 
     int koff[KS];
 #pragma unroll
@@ -518,17 +587,18 @@ __global__ __launch_bounds__(256, NUB == 8 ? 2 : 3) void blockmax_bf16x16_kernel
             if (uid >= 0 && v[e] >= fl && item0 + e < p.n_t) slot[e] = atomicAdd(p.cand_n + uid, 1);
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+        for (int e = 0; e < 4; ++e) {
 #ifdef TREC_CAND_DIAG
-            if (p.cand_diag == 2) continue;
+            if ((p.cand_diag & 3) == 2) continue;
 #endif
             if (slot[e] < p.cand_cap)
                 p.cand[(int64_t)uid * p.cand_cap + slot[e]] = make_int2((int32_t)(item0 + e) + p.t_index_base, __float_as_int(v[e]));
+        }
     };
     auto queue_flush = [&](auto unrc) __attribute__((always_inline)) {
         constexpr int UNR = decltype(unrc)::value;              // entries per lane and round (their atomics are in flight together)
 #ifdef TREC_CAND_DIAG                                          // diagnostics build only (the cost of the parts: DESIGN 5e)
-        const int n = p.cand_diag == 1 ? 0 : qn;
+        const int n = (p.cand_diag & 3) == 1 ? 0 : qn;
 #else
         const int n = qn;
 #endif
@@ -602,9 +672,12 @@ __global__ __launch_bounds__(256, NUB == 8 ? 2 : 3) void blockmax_bf16x16_kernel
         }
     };
 
-    stage_issue(0, 0);
+    if (!GRP) stage_issue(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+#ifdef TREC_CAND_DIAG
+    dg_t1 = wall_clock64();
+#endif
 
     for (int t = 0; t < n_tiles; ++t) {
         const int buf = t & 1;
@@ -614,6 +687,9 @@ __global__ __launch_bounds__(256, NUB == 8 ? 2 : 3) void blockmax_bf16x16_kernel
         else tile_body(std::integral_constant<int, 1>{});
 
         if (((t + 1) % p.sb_tiles) == 0 || t + 1 == n_tiles) {
+#ifdef TREC_CAND_DIAG
+            const unsigned long long dg_b = wall_clock64();      // (stamps only at superblock ends: per-tile stamps slowed the loop itself)
+#endif
             if (LIST) { queue_flush(std::integral_constant<int, 3>{}); sb_first = t_begin + (int64_t)(t + 1) * BN; }
             // end of a superblock: the four row-groups' maxima of every user meet; row-group g stores blocks OW g .. OW g + OW - 1
             const int64_t sb = GRP ? (int64_t)chunk : t_begin / ((int64_t)p.sb_tiles * BN) + t / p.sb_tiles;
@@ -628,19 +704,42 @@ __global__ __launch_bounds__(256, NUB == 8 ? 2 : 3) void blockmax_bf16x16_kernel
 #pragma unroll
             for (int o = 0; o < OW; ++o) {
                 float v = g == 0 ? m[o] : (g == 1 ? m[OW + o] : (g == 2 ? m[2 * OW + o] : m[3 * OW + o]));
-                if (BIAS) v = v + own_bias[o];
-                if (own_u[o] >= 0) p.blockmax[sb * p.bm_stride + own_u[o]] = v;
+                int64_t ou = own_u[o];
+                float ob = own_bias[o];
+                if (LIST) { ou = q_id[(OW * g + o) * 16 + lu]; ob = q_bu[(OW * g + o) * 16 + lu]; }
+                if (BIAS) v = v + ob;
+#ifdef TREC_CAND_DIAG
+                if (p.cand_diag & 8) continue;                   // (the cost of the scattered maxima stores)
+#endif
+                if (ou >= 0) p.blockmax[sb * p.bm_stride + ou] = v;
             }
+#ifdef TREC_CAND_DIAG
+            dg_flush += wall_clock64() - dg_b;
+#endif
         }
         if (t + 1 < n_tiles) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
+#ifdef TREC_CAND_DIAG
+    if (GRP && LIST && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long dg_e = wall_clock64();
+        atomicAdd(&g_refine_clk[0], 1ull);
+        atomicAdd(&g_refine_clk[1], dg_t1 - dg_t0);
+        atomicAdd(&g_refine_clk[2], dg_e - dg_t1 - dg_flush);                 // the tile loop without the superblock ends
+        atomicAdd(&g_refine_clk[3], dg_wait);
+        atomicAdd(&g_refine_clk[4], dg_flush);
+        atomicAdd(&g_refine_clk[5], dg_e - dg_t0);
+        atomicAdd(&g_refine_clk[6], dg_ta - dg_t0);
+        atomicAdd(&g_refine_clk[7], dg_tb - dg_ta);
+    }
+#endif
 }
 
 template <int KT, bool BIAS, bool GRP, int NUB = 8, bool RDL = false, bool LIST = false>
 int launch_bf16x16(ScoreParams p, hipStream_t st)
 {
-    constexpr int LDS = 2 * BN * KT * 2 + 2 * BN * 4 + (LIST ? 4 * LQ_CAP * 20 + 3 * 4 * NUB * 16 * 4 : 0);
+    constexpr int LDS = 2 * BN * KT * 2 + 2 * BN * 4 + (LIST ? 4 * LQ_CAP * 20 + 4 * 4 * NUB * 16 * 4 : 0);
     constexpr int RW = 4 * NUB * 16;
     auto kern = blockmax_bf16x16_kernel<KT, BIAS, GRP, NUB, RDL, LIST>;
     static bool attr_set = false;
@@ -944,3 +1043,16 @@ int launch_blockmax_pipelined_f32(const ScoreParams& p, int kt, int sb_rows, hip
     if (kt == 64) return bias ? launch_f32<64, true>(p, sb_rows, st) : launch_f32<64, false>(p, sb_rows, st);
     return TREC_ERR_UNSUPPORTED;
 }
+
+#ifdef TREC_CAND_DIAG
+// diagnostics build only (not in include/tensorrec_hip.h): read and optionally reset the refining launch's clock sums
+extern "C" int trec_refine_diag_read(unsigned long long* out8, int reset)
+{
+    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_refine_clk), sizeof(unsigned long long) * 8) != hipSuccess) return TREC_ERR_LAUNCH;
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_refine_clk), z, sizeof(z)) != hipSuccess) return TREC_ERR_LAUNCH;
+    }
+    return TREC_OK;
+}
+#endif

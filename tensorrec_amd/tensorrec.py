@@ -1092,9 +1092,10 @@ class TensorRec(object):
         uf, itf = self._inference(user_features, item_features)
         dtype = ops.DTYPE_BF16 if self.precision == 'bf16' else ops.DTYPE_F32
         want_sq = graph.engine_mode == ops.MODE_EUCLIDEAN
-        if self.attention_graph_factory is not None:
-            raise NotImplementedError("predict_top_k is not available for attention models: the softmax-weighted sum "
-                                      "over tastes does not decompose into per-taste top-k lists; use predict_rank")
+        # attention models: the softmax-weighted sum over tastes (recommendation_graphs.py:98-107) does not decompose into
+        # per-taste top-k lists, but it IS independent per (user, item): score slabs of a few thousand users through the
+        # collapse kernel (K9), exact ranks pick the k best of every row -- and item shards merge like any other top-k
+        slab_route = self.attention_graph_factory is not None or self.n_components > ops.SCORE_KMAX
         import torch.distributed as dist
         sharded = bool(item_sharded) and sharding.active(self.process_group)
         method, floor_exchange = "auto", None
@@ -1134,23 +1135,34 @@ class TensorRec(object):
                 dist.all_reduce(ubs, op=dist.ReduceOp.MIN, group=self.process_group)
                 user_batch_size = int(ubs.item())
         vals, idx = [], []
-        if self.n_components > ops.SCORE_KMAX:
-            # wider than the fused kernels' resident operand: score slabs (K-looped fp32 GEMM) + exact ranks pick the top-k
-            if sharded:
-                raise NotImplementedError("item-sharded predict_top_k needs n_components <= %d" % ops.SCORE_KMAX)
-            step = max(1, min(int(user_batch_size), (1 << 28) // max(1, itf.shape[0])))
+        if slab_route:
+            # (also: representations wider than the fused kernels' resident operand -- K-looped fp32 GEMM slabs)
+            planes = 1 + (2 * self.n_tastes if self.attention_graph_factory is not None else
+                          (self.n_tastes if self._multi() else 0))
+            step = max(1, min(int(user_batch_size), (1 << 28) // max(1, itf.shape[0] * planes)))
+            if sharded:                  # (each batch ends in a collective: every rank takes the same steps)
+                st = torch.tensor([step], dtype=torch.int64, device=self._store.device)
+                dist.all_reduce(st, op=dist.ReduceOp.MIN, group=self.process_group)
+                step = int(st.item())
             with torch.no_grad(), variable_scope(self._store):
                 user_reprs, attn_reprs, item_repr, user_bias, item_bias, _ = self._representations(uf, itf)
                 for s in range(0, uf.shape[0], step):
                     e = min(s + step, uf.shape[0])
                     ub = user_bias[s:e] if user_bias is not None else None
                     if self._multi():
-                        slab = self._dense_multi([u[s:e] for u in user_reprs], None, item_repr, ub, item_bias)
+                        attn = [a[s:e] for a in attn_reprs] if attn_reprs is not None else None
+                        slab = self._dense_multi([u[s:e] for u in user_reprs], attn, item_repr, ub, item_bias)
                     else:
                         slab = self._dense_prediction(user_reprs[0][s:e], item_repr, ub, item_bias)
                     v, i = ops.topk_from_scores(slab.contiguous(), k)
+                    i = torch.where(i >= 0, i + int(item_offset), i)
+                    if sharded:
+                        if sharding.a2a_available(v, self.process_group):
+                            v, i = sharding.sharded_top_k_a2a(v, i, k, self.process_group, replicate=True)
+                        else:
+                            v, i = sharding.sharded_top_k(v, i, k, self.process_group)
                     vals.append(v)
-                    idx.append(i + int(item_offset))
+                    idx.append(i)
             vals, idx = torch.cat(vals), torch.cat(idx)
             return (vals, idx) if return_device else (_to_host(vals), _to_host(idx))
         with torch.no_grad(), variable_scope(self._store):

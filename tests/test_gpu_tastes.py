@@ -235,6 +235,25 @@ def test_mixture_top_k_with_duplicate_items_across_tastes(T):
     assert np.array_equal(idx, ri) and np.array_equal(vals, rv)
 
 
+@pytest.mark.parametrize("pred", ["dot", "euclidean"])
+def test_attention_top_k_matches_oracle_predictions(T, pred):
+    """predict_top_k of an attention model (recommendation_graphs.py:98-107 feeding rank order): the k best entries of the
+    ORACLE's prediction matrix, in several user batches (user_batch_size below n_users), ties by lower item id."""
+    inter, uf, itf = dummy(T, 70, 300, seed=5)
+    model, oracle = make_pair(T, 12, pred, "rmse", 3, "linear", (inter, uf, itf))
+    ref = oracle.predict(uf, itf)
+    for ubs in (None, 16):
+        vals, idx = model.predict_top_k(uf, itf, k=7, user_batch_size=ubs)
+        rv, ri = O.topk_rows(ref, 7)
+        np.testing.assert_allclose(vals, rv, rtol=2e-6, atol=2e-6)         # (expf: libm here, the device's there)
+        bad = idx != ri                                                      # ids may only differ inside such a near-tie
+        assert np.all(np.abs(np.take_along_axis(ref, idx.astype(np.int64), 1) - rv)[bad] <= 4e-6)
+    got = model.predict(uf, itf)
+    vals, idx = model.predict_top_k(uf, itf, k=7)
+    rv, ri = O.topk_rows(got, 7)
+    assert np.array_equal(idx, ri) and np.array_equal(vals, rv)
+
+
 # ---- API behaviour (test/test_tensorrec.py:299-397 restated) ----------------------------------------------------
 @pytest.mark.parametrize("attention", [False, True])
 def test_mixture_api_shapes(T, attention):
@@ -255,8 +274,9 @@ def test_mixture_api_shapes(T, attention):
     assert len(sims) == 2 and all(len(s) == 5 for s in sims)
     if attention:
         assert model.predict_user_attention_representation(uf).shape == (3, 15, 10)
-        with pytest.raises(NotImplementedError):
-            model.predict_top_k(uf, itf, k=5)
+        vals, idx = model.predict_top_k(uf, itf, k=5)          # slab route: softmax-weighted collapse, exact ranks
+        rv, ri = O.topk_rows(model.predict(uf, itf), 5)
+        assert np.array_equal(idx, ri) and np.array_equal(vals, rv)
     else:
         from tensorrec_amd.errors import ModelWithoutAttentionException
         with pytest.raises(ModelWithoutAttentionException):
