@@ -13,13 +13,15 @@ if __name__ == "__main__":
     bench.main()
     from tensorrec_amd import _native as N
     lib = N.load()
-    out = (ctypes.c_uint64 * 8)()
+    import numpy as np
+    n_wg = 1 << 17
+    out = (ctypes.c_uint64 * (n_wg * 4))()
     fn = lib.trec_refine_diag_read
-    fn.argtypes, fn.restype = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int], ctypes.c_int
-    assert fn(out, 1) == 0
-    n = max(1, int(out[0]))
-    us = lambda x: 0.01 * float(x) / n          # noqa: E731  (100 MHz wall clock -> microseconds per workgroup)
-    print(json.dumps({"refine_workgroups": int(out[0]), "us_per_workgroup": {
-        "prologue_to_operands_resident": us(out[1]), "tile_bodies": us(out[2]), "tile_waits_and_barriers": us(out[3]),
-        "flush_and_maxima_stores": us(out[4]), "whole_life": us(out[5]),
-        "hop_row_ids_and_first_tile (diag 16)": us(out[6]), "hop_user_rows (diag 16)": us(out[7])}}), file=sys.stderr)
+    fn.argtypes, fn.restype = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_longlong, ctypes.c_int], ctypes.c_int
+    assert fn(out, n_wg * 4, 0) == 0
+    a = np.frombuffer(out, dtype=np.uint64).reshape(n_wg, 4).astype(np.float64)
+    a = a[a[:, 3] > 0] * 0.01            # workgroups of the last refining launch; 100 MHz wall clock -> microseconds
+    print(json.dumps({"refine_workgroups_last_launch": int(a.shape[0]), "us_per_workgroup_mean": {
+        "prologue_to_operands_resident": float(a[:, 0].mean()), "tile_loop": float(a[:, 1].mean()),
+        "superblock_end_flush_and_maxima": float(a[:, 2].mean()), "whole_life": float(a[:, 3].mean())},
+        "whole_life_percentiles_10_50_90": [float(x) for x in np.percentile(a[:, 3], [10, 50, 90])]}), file=sys.stderr)

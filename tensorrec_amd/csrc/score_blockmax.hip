@@ -350,7 +350,8 @@ constexpr int LQ_FLUSH = 192;             // a queue fuller than this is emptied
 // [2] the tile loop (bodies, waits for the next tile, barriers), [4] queue flush + maxima stores at the superblock end (issue
 // time: the stores drain behind it), [5] whole life.  Only a handful of stamps per workgroup: stamps around every tile body
 // (a first version) slowed the new prologue's kernel from 8.0 to 16 ms -- the tool, not the code
-__device__ unsigned long long g_refine_clk[8];
+constexpr int REFINE_DIAG_WGS = 1 << 17;
+__device__ unsigned long long g_refine_clk[(size_t)REFINE_DIAG_WGS * 4];      // per workgroup of the LAST launch: prologue, tile loop, superblock end, whole life
 #endif
 
 template <int KT, bool BIAS, bool GRP, int NUB = 8, bool RDL = false, bool LIST = false>
@@ -358,7 +359,7 @@ __global__ __launch_bounds__(256, NUB == 8 ? 2 : 3) void blockmax_bf16x16_kernel
 {
 #ifdef TREC_CAND_DIAG
     const unsigned long long dg_t0 = wall_clock64();
-    unsigned long long dg_body = 0, dg_wait = 0, dg_flush = 0, dg_t1 = 0, dg_ta = dg_t0, dg_tb = dg_t0;
+    unsigned long long dg_flush = 0, dg_t1 = 0;
     // (cand_diag & 16, with the row-contiguous gather: the hops of the prologue one after the other -- [6] row ids + first item
     // tile resident, [7] user rows resident; the rest of [1] is the floors / counters / biases and the barrier)
 #endif
@@ -647,7 +648,6 @@ __global__ __launch_bounds__(256, NUB == 8 ? 2 : 3) void blockmax_bf16x16_kernel
                 }
             }
             if (ks == KS - 1 && LIST) {
-                const int32_t grp = ((tile_now + blk) << 2) + g;                             // 4-item group of the superblock
 #pragma unroll
                 for (int ub = 0; ub < NUB; ++ub) {
                     // (a wave of 128 users meets ~4 hits per 16-item block on Gaussian rows: the branch per accumulator set is taken
@@ -661,8 +661,13 @@ __global__ __launch_bounds__(256, NUB == 8 ? 2 : 3) void blockmax_bf16x16_kernel
                         const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(hm >> 32),
                                                                             __builtin_amdgcn_mbcnt_lo((unsigned int)hm, 0u));
                         if (hit) {
+                            // 4-item group of the superblock, from an opaque copy of the lane id: written as a loop invariant
+                            // the compiler hoists (blk << 2) + g for every blk, spills the copies and re-loads them from
+                            // scratch in every block step -- behind s_waitcnt vmcnt(0), i.e. behind the next tile's DMA
+                            int lo = lane;
+                            asm volatile("" : "+v"(lo));
                             qv[pos] = acc[ub];
-                            qc[pos] = ((ub * 16 + lu) << 16) | grp;
+                            qc[pos] = (((ub * 16) + (lo & 15)) << 16) | (((tile_now + blk) << 2) + (lo >> 4));
                         }
                         qn += __builtin_popcountll(hm);
                     }
@@ -701,17 +706,37 @@ __global__ __launch_bounds__(256, NUB == 8 ? 2 : 3) void blockmax_bf16x16_kernel
                 m[ub] = fmaxf(x, __shfl_xor(x, 32, 64));
                 bm[ub] = -INFINITY;
             }
+            if (LIST) {
+                // (the select over g below compiles to a scratch array indexed by g -- eight scratch stores, two loads and an
+                // s_waitcnt vmcnt(0) that also waits for the queue's stores: the LIST form passes the maxima through the idle
+                // threshold array in LDS instead)
+                if (g == 0) {
 #pragma unroll
-            for (int o = 0; o < OW; ++o) {
-                float v = g == 0 ? m[o] : (g == 1 ? m[OW + o] : (g == 2 ? m[2 * OW + o] : m[3 * OW + o]));
-                int64_t ou = own_u[o];
-                float ob = own_bias[o];
-                if (LIST) { ou = q_id[(OW * g + o) * 16 + lu]; ob = q_bu[(OW * g + o) * 16 + lu]; }
-                if (BIAS) v = v + ob;
+                    for (int ub = 0; ub < NUB; ++ub) q_ta[ub * 16 + lu] = m[ub];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int o = 0; o < OW; ++o) {
+                    const int slot = (OW * g + o) * 16 + lu;
+                    float v = q_ta[slot];
+                    const int32_t ou = q_id[slot];
+                    if (BIAS) v = v + q_bu[slot];
 #ifdef TREC_CAND_DIAG
-                if (p.cand_diag & 8) continue;                   // (the cost of the scattered maxima stores)
+                    if (p.cand_diag & 8) continue;               // (the cost of the scattered maxima stores)
 #endif
-                if (ou >= 0) p.blockmax[sb * p.bm_stride + ou] = v;
+                    if (ou >= 0) p.blockmax[sb * p.bm_stride + ou] = v;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // (dense LIST launches: the next superblock's maxima follow)
+                __builtin_amdgcn_wave_barrier();
+            } else {
+#pragma unroll
+                for (int o = 0; o < OW; ++o) {
+                    float v = g == 0 ? m[o] : (g == 1 ? m[OW + o] : (g == 2 ? m[2 * OW + o] : m[3 * OW + o]));
+                    if (BIAS) v = v + own_bias[o];
+                    if (own_u[o] >= 0) p.blockmax[sb * p.bm_stride + own_u[o]] = v;
+                }
             }
 #ifdef TREC_CAND_DIAG
             dg_flush += wall_clock64() - dg_b;
@@ -721,17 +746,14 @@ __global__ __launch_bounds__(256, NUB == 8 ? 2 : 3) void blockmax_bf16x16_kernel
         __syncthreads();
     }
 #ifdef TREC_CAND_DIAG
-    if (GRP && LIST && tid == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (GRP && LIST && tid == 0 && blockIdx.x < REFINE_DIAG_WGS) {
+        // (plain stores into the workgroup's own row: atomics on eight shared counters -- a first version -- slowed the kernel 2x)
         const unsigned long long dg_e = wall_clock64();
-        atomicAdd(&g_refine_clk[0], 1ull);
-        atomicAdd(&g_refine_clk[1], dg_t1 - dg_t0);
-        atomicAdd(&g_refine_clk[2], dg_e - dg_t1 - dg_flush);                 // the tile loop without the superblock ends
-        atomicAdd(&g_refine_clk[3], dg_wait);
-        atomicAdd(&g_refine_clk[4], dg_flush);
-        atomicAdd(&g_refine_clk[5], dg_e - dg_t0);
-        atomicAdd(&g_refine_clk[6], dg_ta - dg_t0);
-        atomicAdd(&g_refine_clk[7], dg_tb - dg_ta);
+        unsigned long long* row = g_refine_clk + (size_t)blockIdx.x * 4;
+        row[0] = dg_t1 - dg_t0;
+        row[1] = dg_e - dg_t1 - dg_flush;
+        row[2] = dg_flush;
+        row[3] = dg_e - dg_t0;
     }
 #endif
 }
@@ -1046,13 +1068,11 @@ int launch_blockmax_pipelined_f32(const ScoreParams& p, int kt, int sb_rows, hip
 
 #ifdef TREC_CAND_DIAG
 // diagnostics build only (not in include/tensorrec_hip.h): read and optionally reset the refining launch's clock sums
-extern "C" int trec_refine_diag_read(unsigned long long* out8, int reset)
+extern "C" int trec_refine_diag_read(unsigned long long* out, long long n_words, int reset)
 {
-    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_refine_clk), sizeof(unsigned long long) * 8) != hipSuccess) return TREC_ERR_LAUNCH;
-    if (reset) {
-        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(g_refine_clk), z, sizeof(z)) != hipSuccess) return TREC_ERR_LAUNCH;
-    }
+    if (n_words > (long long)REFINE_DIAG_WGS * 4) n_words = (long long)REFINE_DIAG_WGS * 4;
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_refine_clk), sizeof(unsigned long long) * (size_t)n_words) != hipSuccess) return TREC_ERR_LAUNCH;
+    (void)reset;
     return TREC_OK;
 }
 #endif

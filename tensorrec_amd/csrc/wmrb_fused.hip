@@ -76,11 +76,18 @@ __global__ __launch_bounds__(256, (ITERS == 1 && RMAX == 16) ? 4 : 1) void wmrb_
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int sub = tid & 31, sg = tid >> 5;             // 8 subgroups of 32 lanes
-    // the sampled item ids do not depend on the user's interaction range: their loads leave together with indptr's
-    // (one round trip of the index -> row chain less for S of the S + n_pos rows)
+    // Every load of the gather phase is UNCONDITIONAL, from a clamped (always valid) address, and selected afterwards: written
+    // as `cond ? load : 0` the compiler wraps each load in an exec-masked block that ends in s_waitcnt vmcnt(0) -- the 16 loads
+    // of the interaction ids, the biases, the user row and the histogram atomic became ~10 SERIAL round trips per user where
+    // three dependent ones are needed (ids -> rows / biases -> atomics; the refining launch of the top-k cascade had the same
+    // disease).  Rows past R read item 0 and are never used unguarded (predictions not written, dU sum guarded).
+    // The sampled item ids do not depend on the user's interaction range: their loads leave together with indptr's.
     int32_t item[RMAX];
 #pragma unroll
-    for (int r = 0; r < RMAX; ++r) item[r] = (sg + 8 * r < S) ? samples[u * S + sg + 8 * r] : 0;
+    for (int r = 0; r < RMAX; ++r) {
+        const int j = sg + 8 * r;
+        item[r] = samples[u * S + (j < S ? j : S - 1)];
+    }
     const int64_t b = indptr[u], e = indptr[u + 1];
     const int n_pos = (int)(e - b);
     const int R = S + n_pos;                             // rows of this user: samples first, then interactions
@@ -100,24 +107,36 @@ __global__ __launch_bounds__(256, (ITERS == 1 && RMAX == 16) ? 4 : 1) void wmrb_
     }
 
     // interaction `tid` of this user (n_pos <= 256): its slot and weight are fetched now, used in phase (c2)
-    const int32_t my_slot = (tid < n_pos) ? pos_slot[b + tid] : -1;
-    const float my_w = (pos_weight && tid < n_pos) ? pos_weight[b + tid] : 1.f;
+    const int qi = tid < n_pos ? tid : n_pos - 1;
+    const int32_t slot_ld = pos_slot[b + qi];
+    const float w_ld = pos_weight ? pos_weight[b + qi] : 1.f;     // (uniform branch)
+    const int32_t my_slot = (tid < n_pos) ? slot_ld : -1;
+    const float my_w = (tid < n_pos) ? w_ld : 1.f;
 
     // ---- (a) the user's row, in the registers of every subgroup ----
     f32x4 x[ITERS];
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
         const int c = (it * 32 + sub) * 4;
-        x[it] = (c < d) ? *(const f32x4*)(U + u * d + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        const f32x4 v = *(const f32x4*)(U + u * d + (c < d ? c : 0));
+        x[it] = (c < d) ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     const float bu = ub ? ub[u] : 0.f;
 
     // ---- (b) every subgroup gathers its rows j = sg + 8 r (r < RMAX) in ONE batch and keeps them ----
     f32x4 y[RMAX][ITERS];
+    {
+        int32_t xid[RMAX];                               // the interaction item of row j >= S (n_pos >= 1 here)
 #pragma unroll
-    for (int r = 0; r < RMAX; ++r) {
-        const int j = sg + 8 * r;
-        if (j >= S) item[r] = (j < R) ? xi[b + (j - S)] : 0;
+        for (int r = 0; r < RMAX; ++r) {
+            const int q = sg + 8 * r - S;
+            xid[r] = xi[b + (q < 0 ? 0 : (q < n_pos ? q : n_pos - 1))];
+        }
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) {
+            const int j = sg + 8 * r;
+            item[r] = (j < S) ? item[r] : ((j < R) ? xid[r] : 0);
+        }
     }
     // Lane 16 + (r & 15) of a subgroup OWNS the subgroup's row r (lanes 16..31 are where the DPP reduction leaves the
     // 32-lane dot product): it fetches the row's item bias -- in the same batch of loads as the rows --, issues the row's
@@ -125,31 +144,36 @@ __global__ __launch_bounds__(256, (ITERS == 1 && RMAX == 16) ? 4 : 1) void wmrb_
     constexpr int H = RMAX / 16;
     const int own = sub - 16;
     float my_bi[H];
+    int32_t my_item[H];                                  // the item of the owned row (its own two loads: no 16-way select)
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+        const int j = sg + 8 * ((own < 0 ? 0 : own) + 16 * h);
+        const int q = j - S;
+        const int32_t a = samples[u * S + (j < S ? j : S - 1)];
+        const int32_t c2 = xi[b + (q < 0 ? 0 : (q < n_pos ? q : n_pos - 1))];
+        my_item[h] = (j < S) ? a : ((j < R) ? c2 : 0);
+    }
 #pragma unroll
     for (int h = 0; h < H; ++h) {
         const int j = sg + 8 * (own + 16 * h);
-        my_bi[h] = 0.f;
-        if (ib && own >= 0 && j < R) my_bi[h] = ib[(j < S) ? samples[u * S + j] : xi[b + (j - S)]];
+        const float v = ib ? ib[my_item[h]] : 0.f;           // (uniform branch)
+        my_bi[h] = (own >= 0 && j < R) ? v : 0.f;
     }
 #pragma unroll
     for (int r = 0; r < RMAX; ++r) {
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
             const int c = (it * 32 + sub) * 4;
-            y[r][it] = (sg + 8 * r < R && c < d) ? *(const f32x4*)(V + (int64_t)item[r] * d + c)
-                                                 : (f32x4){0.f, 0.f, 0.f, 0.f};
+            y[r][it] = *(const f32x4*)(V + (int64_t)item[r] * d + (c < d ? c : 0));
         }
     }
-    // histogram of the counting sort to come, by the owner lanes: ONE atomic instruction per subgroup and 16 rows instead
-    // of RMAX from lane 0.  The value an atomic returns is the pair's rank inside its item's bucket, which makes the sort's
-    // fill pass atomic-free; it is stored at the very end of the kernel, so nothing in between waits for the atomics.
-    int32_t rk[H];
+    if (d < ITERS * 128) {                               // (uniform: columns past d contribute zeros)
 #pragma unroll
-    for (int h = 0; h < H; ++h) {
-        const int j = sg + 8 * (own + 16 * h);
-        rk[h] = 0;
-        if (sample_hist && own >= 0 && j < S && !TREC_ABLATED(1))
-            rk[h] = __hip_atomic_fetch_add(sample_hist + samples[u * S + j], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int r = 0; r < RMAX; ++r) {
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it)
+                if ((it * 32 + sub) * 4 >= d) y[r][it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
     }
     // predictions: no per-row branch (a wave holds two subgroups with different rows), so the RMAX reduction chains
     // interleave; rows past R are zeros and are simply not written
@@ -183,6 +207,18 @@ __global__ __launch_bounds__(256, (ITERS == 1 && RMAX == 16) ? 4 : 1) void wmrb_
             l_y[j] = s;
             if (j >= S) pred_serial[b + (j - S)] = s;
         }
+    }
+    // histogram of the counting sort to come, by the owner lanes: ONE atomic instruction per subgroup and 16 rows instead
+    // of RMAX from lane 0.  The value an atomic returns is the pair's rank inside its item's bucket, which makes the sort's
+    // fill pass atomic-free; it is stored at the very end of the kernel.  Issued AFTER the rows have been consumed: returning
+    // atomics and loads come back in order, so an atomic issued between the row loads and their first use is waited for first
+    // (rk stays UNDEFINED for lanes that issue none: merging it with a constant would put the wait right here).
+    int32_t rk[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+        const int j = sg + 8 * (own + 16 * h);
+        if (sample_hist && own >= 0 && j < S && !TREC_ABLATED(1))
+            rk[h] = __hip_atomic_fetch_add(sample_hist + my_item[h], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
 
