@@ -26,7 +26,14 @@ __global__ __launch_bounds__(256) void wmrb_fwd_kernel(
     const int64_t u = blockIdx.x;
     const int64_t b = indptr[u], e = indptr[u + 1];
     if (b == e) return;
-    for (int s = threadIdx.x; s < S; s += 256) lds[s] = samp[u * S + s];
+    // (four loads per thread in flight, then the four LDS stores: a load -> store loop waits for every load on its own)
+    for (int s0 = threadIdx.x; s0 < S; s0 += 1024) {
+        float t[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int s = s0 + 256 * k; t[k] = samp[u * S + (s < S ? s : S - 1)]; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int s = s0 + 256 * k; if (s < S) lds[s] = t[k]; }
+    }
     __syncthreads();
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     for (int64_t p = b + wave; p < e; p += 4) {
@@ -57,7 +64,13 @@ __global__ __launch_bounds__(256) void wmrb_bwd_kernel(
     float* l_c = l_yp + WMRB_MAX_POS_LDS;
     const int64_t u = blockIdx.x;
     const int64_t b = indptr[u], e = indptr[u + 1];
-    for (int s = threadIdx.x; s < S; s += 256) l_s[s] = samp[u * S + s];
+    for (int s0 = threadIdx.x; s0 < S; s0 += 1024) {         // (batched like the forward kernel's fill)
+        float t[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int s = s0 + 256 * k; t[k] = samp[u * S + (s < S ? s : S - 1)]; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int s = s0 + 256 * k; if (s < S) l_s[s] = t[k]; }
+    }
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     // per-thread accumulators for the samples this thread owns (s = tid, tid+256, ...): kept in LDS-free registers
     // by walking sample blocks of 256 at a time in the outer loop below.

@@ -40,8 +40,9 @@ __global__ __launch_bounds__(256) void pair_score_fwd_kernel(
     for (int r = 0; r < PP; ++r) {
         const int64_t p = p0 + r;
         ok[r] = p < n_pairs;
-        i[r] = ok[r] ? (int64_t)xi[p] : 0;
-        u[r] = ok[r] ? (xu ? (int64_t)xu[p] : p / pairs_per_user) : 0;
+        const int64_t pc = ok[r] ? p : n_pairs - 1;       // (unconditional loads from a clamped pair: `ok ? xi[p] : 0` made every
+        i[r] = (int64_t)xi[pc];                            // index load its own block behind s_waitcnt vmcnt(0))
+        u[r] = xu ? (int64_t)xu[pc] : pc / pairs_per_user;
     }
     float acc[PP];
 #pragma unroll

@@ -104,8 +104,8 @@ __device__ __forceinline__ Entry load_entry(const int32_t* __restrict__ indices,
 // iteration used to be two dependent round trips (entries -> rows), i.e. ~4 us per 4 rows of a subgroup whatever the
 // bandwidth; with the entries one step ahead it is one (round 4: configs[4]'s item-side gather of 3.7e8 sampled pairs,
 // 1 KB rows from a cache-resident table, ran at 3.6 TB/s -- latency-, not bandwidth-bound).  Same chain, same bits.
-template <int ITERS, bool PACKED, int VEC>
-__device__ __forceinline__ void gather_range(const int32_t* __restrict__ indices, const float* __restrict__ values,
+template <int ITERS, bool PACKED, int VEC, bool PERM>
+__device__ __forceinline__ void gather_range_impl(const int32_t* __restrict__ indices, const float* __restrict__ values,
                                              const int32_t* __restrict__ val_perm, int64_t j0, int64_t j1,
                                              const float* __restrict__ W, int d, const int (&col)[ITERS],
                                              const bool (&cvalid)[ITERS], bool diff,
@@ -114,38 +114,77 @@ __device__ __forceinline__ void gather_range(const int32_t* __restrict__ indices
 {
     typedef typename VecOf<VEC>::T V;
     int64_t j = j0;
-    Entry en[4];
+    // A three-stage pipeline over blocks of four entries, every load UNCONDITIONAL (indices clamped into [j0, j1), columns past
+    // d read column 0 and are zeroed): per iteration the value indices (val_perm) and columns of block b + 2, the values of
+    // block b + 1 (through the indices fetched an iteration ago) and the four row gathers of block b leave together -- ONE
+    // round trip per four rows.  Written entry by entry (`more ? load_entry(...) : ...`, values[val_perm[j]]) each entry was
+    // a dependent perm -> value chain behind its own s_waitcnt vmcnt(0): five to six serial round trips per four rows, and
+    // the MovieLens-20M-shaped epoch spent 100 of its 193 ms in this loop (profiles/r04b_cfg4_fit_kernel_stats.csv).
     if (j + 3 < j1) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) en[q] = load_entry<PACKED>(indices, values, val_perm, j + q);
-    }
-    for (; j + 3 < j1; j += 4) {
-        Entry nx[4];
-        const bool more = j + 7 < j1;                                     // (uniform over the subgroup)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) nx[q] = more ? load_entry<PACKED>(indices, values, val_perm, j + 4 + q) : en[q];
-        V x[4][ITERS];
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int it = 0; it < ITERS; ++it) {
-                x[q][it] = vzero<V>();
-                if (cvalid[it]) x[q][it] = *(const V*)(W + (int64_t)en[q].col * d + col[it]);
-            }
+        const int64_t last = j1 - 1;
+        Entry en[4];                                                      // block b: {column, value}
+        int32_t nc[4];                                                    // block b + 1: columns ...
+        int32_t nv[4];                                                    // ... and where its values are (pair ids fit int32)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            vsum += en[q].val;
-#pragma unroll
-            for (int it = 0; it < ITERS; ++it) {
-                const V xv = diff ? ownv[it] - x[q][it] : x[q][it];
-                vfma(acc[it], en[q].val, xv);
+            const int64_t j2 = j + 4 + q < last ? j + 4 + q : last;
+            if (PACKED) {
+                const int2 e2 = ((const int2*)indices)[j + q];
+                en[q].col = e2.x; en[q].val = __int_as_float(e2.y);
+                nv[q] = (int32_t)j2; nc[q] = 0;
+            } else {
+                en[q].col = indices[j + q];
+                nc[q] = indices[j2];
+                nv[q] = PERM ? val_perm[j2] : (int32_t)j2;
             }
         }
+        if (!PACKED) {
+            int32_t cv[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) en[q] = nx[q];
+            for (int q = 0; q < 4; ++q) cv[q] = PERM ? val_perm[j + q] : (int32_t)(j + q);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) en[q].val = values[cv[q]];
+        }
+        for (; j + 3 < j1; j += 4) {
+            Entry nx[4];
+            int32_t fc[4];
+            int32_t fv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {                                 // values of block b + 1, indices of block b + 2
+                const int64_t j3 = j + 8 + q < last ? j + 8 + q : last;
+                if (PACKED) {
+                    const int2 e2 = ((const int2*)indices)[nv[q]];
+                    nx[q].col = e2.x; nx[q].val = __int_as_float(e2.y);
+                    fv[q] = (int32_t)j3; fc[q] = 0;
+                } else {
+                    nx[q].col = nc[q];
+                    nx[q].val = values[nv[q]];
+                    fc[q] = indices[j3];
+                    fv[q] = PERM ? val_perm[j3] : (int32_t)j3;
+                }
+            }
+            V x[4][ITERS];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int it = 0; it < ITERS; ++it)
+                    x[q][it] = *(const V*)(W + (int64_t)en[q].col * d + (cvalid[it] ? col[it] : 0));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                vsum += en[q].val;
+#pragma unroll
+                for (int it = 0; it < ITERS; ++it) {
+                    const V xq = cvalid[it] ? x[q][it] : vzero<V>();
+                    const V xv = diff ? ownv[it] - xq : xq;
+                    vfma(acc[it], en[q].val, xv);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { en[q] = nx[q]; nc[q] = fc[q]; nv[q] = fv[q]; }
+        }
     }
     for (; j < j1; ++j) {
-        const Entry e1 = load_entry<PACKED>(indices, values, val_perm, j);
+        const Entry e1 = load_entry<PACKED>(indices, values, PERM ? val_perm : nullptr, j);
         vsum += e1.val;
 #pragma unroll
         for (int it = 0; it < ITERS; ++it)
@@ -155,6 +194,19 @@ __device__ __forceinline__ void gather_range(const int32_t* __restrict__ indices
                 vfma(acc[it], e1.val, xv);
             }
     }
+}
+
+// (the loop exists twice -- values through val_perm or in place -- so that no load result meets a constant in a phi)
+template <int ITERS, bool PACKED, int VEC>
+__device__ __forceinline__ void gather_range(const int32_t* __restrict__ indices, const float* __restrict__ values,
+                                             const int32_t* __restrict__ val_perm, int64_t j0, int64_t j1,
+                                             const float* __restrict__ W, int d, const int (&col)[ITERS],
+                                             const bool (&cvalid)[ITERS], bool diff,
+                                             const typename VecOf<VEC>::T (&ownv)[ITERS],
+                                             typename VecOf<VEC>::T (&acc)[ITERS], float& vsum)
+{
+    if (!PACKED && val_perm) gather_range_impl<ITERS, PACKED, VEC, true>(indices, values, val_perm, j0, j1, W, d, col, cvalid, diff, ownv, acc, vsum);
+    else gather_range_impl<ITERS, PACKED, VEC, false>(indices, values, val_perm, j0, j1, W, d, col, cvalid, diff, ownv, acc, vsum);
 }
 
 // rows of at most split_t non-zeros: one row per subgroup of lpr lanes (longer rows are left to the chunk kernels)

@@ -46,19 +46,32 @@ __device__ __forceinline__ UserConsts load_user_consts(const float* __restrict__
     const float infl = 1.0029296875f;                      // 1 + 3 * 2^-10 > (1 + 2^-9) (1 + 2^-12): covers the re-association
     UserConsts c;
     c.valid = 0u;
+    // the eight loads leave together, unconditionally, from clamped users (the empty asm keeps the compiler from sinking each
+    // of them back into the branch that uses it -- four dependent thr -> user_err round trips per workgroup otherwise)
+    float thv[4];
+    f32x4 uvv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int64_t ue_i = u + e < n_users ? u + e : n_users - 1;
+        thv[e] = thr[ue_i];
+        uvv[e] = *(const f32x4*)(user_err + ue_i * 4);                     // {||x||, ||x - a q||, cu, a}
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(thv[e]), "+v"(uvv[e]));
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         // a threshold of +inf keeps nothing WHATEVER the table holds: rows without a source (band padding, the idle int8
         // workgroups of trec_user_prep_sorted, whose table entries were never written) and users flagged before the compaction
-        const bool in = u + e < n_users && thr[u + e] < INFINITY;
+        const bool in = u + e < n_users && thv[e] < INFINITY;
+        const float th = thv[e];
+        const f32x4 uv = uvv[e];
         if (in) c.valid |= 1u << e;
-        f32x4 ue = {0.f, 0.f, 0.f, 0.f};
-        if (in) ue = *(const f32x4*)(user_err + (u + e) * 4);              // {||x||, ||x - a q||, cu, a}
+        const f32x4 ue = in ? uv : (f32x4){0.f, 0.f, 0.f, 0.f};
         c.nx[e] = ue[0];
         c.ex[e] = ue[1];
         c.au[e] = ue[3];
         const float cu = in ? ue[2] * infl + 2e-30f : 0.f;
-        c.f[e] = in ? float_pred(float_pred(thr[u + e])) - cu : INFINITY;        // v + nx A + ex B + C >= thr - cu
+        c.f[e] = in ? float_pred(float_pred(th)) - cu : INFINITY;                 // v + nx A + ex B + C >= thr - cu
         if (in) c.f[e] = float_pred(c.f[e]);                                      // the subtraction may have rounded up
     }
     return c;
@@ -72,24 +85,28 @@ __device__ __forceinline__ unsigned int tile_bits(const float* __restrict__ tabl
     const float ck = (float)(kdim + 6) * 2.98023224e-07f;
     const bool vec = (stride % 4 == 0) && (((uintptr_t)table % 16) == 0) && (u + 3 < stride);
     unsigned int bits = 0;
+    // all CROWS row loads leave together, from clamped (always valid) rows, before the first comparison: with the loads inside
+    // `if (s < n_sb)` every row was its own block ending in s_waitcnt vmcnt(0) -- eight serial round trips per group
+    f32x4 v[CROWS], ss[CROWS];
+#pragma unroll
+    for (int r = 0; r < CROWS; ++r) {
+        const int32_t s = s0 + r < n_sb ? s0 + r : n_sb - 1;
+        const float* src = table + (int64_t)s * stride + u;
+        if (vec) v[r] = __builtin_nontemporal_load((const f32x4*)src);
+        else {
+            v[r] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (u + e < n_users) v[r][e] = src[e];
+        }
+        ss[r] = *(const f32x4*)(sb_stats + (int64_t)s * 4);
+    }
 #pragma unroll
     for (int r = 0; r < CROWS; ++r) {
         const int32_t s = s0 + r;
-        f32x4 v = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-        float A = 0.f, B = 0.f, C = 0.f;
-        if (s < n_sb) {
-            const float* src = table + (int64_t)s * stride + u;
-            if (vec) v = __builtin_nontemporal_load((const f32x4*)src);
-            else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) if (u + e < n_users) v[e] = src[e];
-            }
-            const f32x4 ss = *(const f32x4*)(sb_stats + (int64_t)s * 4);
-            A = (ss[2] + ck * ss[1]) * infl; B = ss[1] * infl; C = ss[3] * infl;
-        }
+        const float A = (ss[r][2] + ck * ss[r][1]) * infl, B = ss[r][1] * infl, C = ss[r][3] * infl;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            if (s < n_sb && ((c.valid >> e) & 1u) && !(__fmaf_rn(c.nx[e], A, __fmaf_rn(c.ex[e], B, __fmaf_rn(c.au[e], C, v[e]))) < c.f[e]))
+            if (s < n_sb && ((c.valid >> e) & 1u) && !(__fmaf_rn(c.nx[e], A, __fmaf_rn(c.ex[e], B, __fmaf_rn(c.au[e], C, v[r][e]))) < c.f[e]))
                 bits |= 1u << (4 * r + e);
     }
     return bits;
