@@ -1,7 +1,8 @@
 #!/bin/bash
 # Round-end evidence: default bench line, rocprofv3 kernel stats of the same command, PMC passes for HBM traffic, the per-rank
 # emulations of the 8-GPU predict and fit (scripts/rank_sim.py, scripts/fit_rank_sim.py), configs[4]'s fit under rocprofv3 + PMC.
-# STAGES (default all): bench prof pmc sims cfg4 tests
+# STAGES (default all but the last three): bench prof pmc sims cfg4 tests | ab rank2 diag     PMC_SETS=2 limits the PMC passes to the
+# two HBM / L2 sets (FETCH_SIZE; WRITE_SIZE TCC_HIT TCC_MISS)
 set +e
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; REPO=$PWD; OUT=$REPO/gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp
 TAG=${1:-r01}
@@ -51,7 +52,9 @@ if has prof; then
 f=$(find $OUT/${TAG}_prof -name "*kernel_stats.csv" | head -1); cp $f $OUT/${TAG}_kernel_stats.csv 2>/dev/null; head -12 $OUT/${TAG}_kernel_stats.csv | cut -c1-200
 fi
 if has pmc; then
+PMC_N=0
 for s in "FETCH_SIZE" "WRITE_SIZE TCC_HIT TCC_MISS" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES"; do
+  PMC_N=$((PMC_N + 1)); if [ -n "$PMC_SETS" ] && [ $PMC_N -gt $PMC_SETS ]; then break; fi
   n=$(echo $s | cut -d' ' -f1)
   ( cd /tmp && timeout 900 rocprofv3 --pmc $s --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_$n -o pmc -- python $REPO/bench.py --configs headline --steps 1 --warmup 0 --prewarm-seconds 0 --no-cpu-baseline --no-fit --no-fp32-mode --no-k1-multi --parity-users 64 > /dev/null 2> $OUT/${TAG}_pmc_$n.err ); echo "pmc $n rc=$?"
 done
@@ -70,4 +73,10 @@ for f in sorted(glob.glob("$OUT/${TAG}_pmc_*/**/*counter_collection.csv", recurs
             out.write("%s | dispatches=%d | "%(k,cnt[k])+" ".join("%s=%.5g"%(c,v/cnt[k]) for c,v in sorted(agg[k].items()))+"\n")
 out.close(); print(open("$OUT/${TAG}_pmc_summary.txt").read())
 PY
+fi
+if has rank2; then         # two ranks over gloo on ONE GPU: the world > 1 path of bench.py end to end (functional, not a scaling number)
+TREC_DIST_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 3 --warmup 1 --users 200000 --configs headline --no-cpu-baseline 2> $OUT/${TAG}_bench_2rank.err | grep -v "^\[Gloo\]" > $OUT/${TAG}_bench_2rank_gloo_one_gpu.json; echo "rank2 rc=$?"
+fi
+if has diag; then          # per-workgroup clock stamps of the refining launch (make -C tensorrec_amd/csrc diag first)
+bash scripts/gpu_refine_diag.sh 0; cp $OUT/refine_diag_clk_0.json $OUT/${TAG}_refine_clocks.json 2>/dev/null
 fi

@@ -345,11 +345,11 @@ constexpr int LQ_CAP = 448;               // queue entries per wave (20 bytes ea
 constexpr int LQ_FLUSH = 192;             // a queue fuller than this is emptied before the next half block step (192 + 4 * 64 <= 448)
 
 #ifdef TREC_CAND_DIAG
-// diagnostics build only: where a workgroup of the refining launch (GRP && LIST) spends its life, summed over workgroups in
-// units of the 100 MHz wall clock -- [0] workgroups, [1] entry -> operands resident (row_index -> user rows, floors, tile 0),
-// [2] the tile loop (bodies, waits for the next tile, barriers), [4] queue flush + maxima stores at the superblock end (issue
-// time: the stores drain behind it), [5] whole life.  Only a handful of stamps per workgroup: stamps around every tile body
-// (a first version) slowed the new prologue's kernel from 8.0 to 16 ms -- the tool, not the code
+// diagnostics build only (make diag; scripts/gpu_refine_diag.sh): where a workgroup of the refining launch (GRP && LIST) spends
+// its life, in units of the 100 MHz wall clock, one row per workgroup of the LAST launch -- {entry -> operands resident (row ids
+// -> user rows, floors, counters, biases, first item tile), the tile loop, the superblock end (queue flush + maxima stores: issue
+// time, the stores drain behind it), whole life}.  Four stamps per workgroup and plain stores: stamps around every tile body and
+// atomics on shared counters (the first version) slowed the kernel itself 2x -- its numbers described the tool.
 constexpr int REFINE_DIAG_WGS = 1 << 17;
 __device__ unsigned long long g_refine_clk[(size_t)REFINE_DIAG_WGS * 4];      // per workgroup of the LAST launch: prologue, tile loop, superblock end, whole life
 #endif
@@ -360,8 +360,6 @@ __global__ __launch_bounds__(256, NUB == 8 ? 2 : 3) void blockmax_bf16x16_kernel
 #ifdef TREC_CAND_DIAG
     const unsigned long long dg_t0 = wall_clock64();
     unsigned long long dg_flush = 0, dg_t1 = 0;
-    // (cand_diag & 16, with the row-contiguous gather: the hops of the prologue one after the other -- [6] row ids + first item
-    // tile resident, [7] user rows resident; the rest of [1] is the floors / counters / biases and the barrier)
 #endif
     constexpr int RW = 4 * NUB * 16;         // resident rows per workgroup
     constexpr int OW = NUB / 4;

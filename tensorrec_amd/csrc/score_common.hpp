@@ -49,7 +49,8 @@ struct ScoreParams {
     int32_t cand_cap;
     const int32_t* wg_map;         // nullable [n_wgs]: grouped launch, fixed-capacity layout: workgroup w of the launch is slot wg_map[w] of the
     int32_t n_wgs;                 //   [n_sb][capacity] grid (trec_topk_rows_wg_map: only the slots that hold rows are launched)
-    int cand_diag;                 // builds with -DTREC_CAND_DIAG only (tuning cascade_cand_diag): 1 = the queues are emptied without looking, 2 = atomics but no stores
+    int cand_diag;                 // builds with -DTREC_CAND_DIAG only (tuning cascade_cand_diag): low bits 1 = the queues are emptied without
+                                   // looking, 2 = atomics but no stores; +8 no maxima stores, +32 no counter gather, +64 / +128 throttled row gathers
     float* chunk_top;              // int8 BLOCKMAX: [n_chunks * top_k][bm_stride]: the top_k largest LOWER BOUNDS of a chunk per user
     int top_k;
 };
