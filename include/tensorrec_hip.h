@@ -463,6 +463,16 @@ int32_t trec_group_pairs_lds_runs(int64_t n_pairs, int64_t n_items);
 int trec_group_pairs_by_item_lds(const int32_t* xu, const int32_t* xi, int64_t n_pairs, int32_t pairs_per_user, int64_t n_items,
                                  int32_t* workspace_i32, int64_t* workspace_i64, int32_t* run_counts, int64_t* indptr_t,
                                  int32_t* users_t, int32_t* perm_t, void* stream);
+/* trec_group_pairs_by_item's ranked PACKED form (counts_given = 1, ranks, values_in; entries int2 [n_pairs] = {user, value bits})
+ * with the fill done in two levels: pairs are first appended to the staging region of their destination WINDOW of
+ * 2^window_log2 entries (one global atomic per workgroup and window), then placed window by window while the window sits in
+ * L2 (csrc/segment.hip) -- the 1e8 sampled pairs of the 1M x 1M fit.  trec_group_pairs_staged_bytes: the staging bytes, 0 when
+ * the size is not covered (fewer than 2 or more than 2,048 windows).  workspace_i32 [2 * n_items]: first half = the histogram. */
+int64_t trec_group_pairs_staged_bytes(int64_t n_pairs, int32_t window_log2);
+int trec_group_pairs_by_item_staged(const int32_t* xu, const int32_t* xi, int64_t n_pairs, int32_t pairs_per_user, int64_t n_items,
+                                    int32_t* workspace_i32, int64_t* workspace_i64, int64_t* indptr_t, int32_t* entries,
+                                    const int32_t* ranks, const float* values_in, void* staging, int64_t staging_bytes,
+                                    int32_t window_log2, void* stream);
 
 /* ---- K4: ranks ----------------------------------------------------------------------------------------------
  * rank_predictions, recommendation_graphs.py:73-82 (double tf.nn.top_k) as an exact count; int32, 1 = best. */

@@ -230,6 +230,157 @@ extern "C" int trec_group_pairs_by_item(const int32_t* xu, const int32_t* xi, in
     return trec_check_launch("trec_group_pairs_by_item");
 }
 
+// ---- the ranked, packed fill in two levels (the data-parallel fit's 1e8 sampled pairs) ----------------------------------------
+// seg_fill_ranked_kernel stores 8 bytes per pair at indptr[item] + rank: 1e8 scattered stores, each the only one its 64-byte
+// sector sees before it leaves L2 -- ~6.4 GB written for 0.8 GB of entries, 3.7 ms of a 26 ms epoch.  Here the destination is cut
+// into WINDOWS of 2^L entries.  Pass A (seg_stage_kernel): a workgroup takes 8,192 consecutive pairs, computes every pair's slot,
+// counts its pairs per window in LDS, reserves room in the windows' staging regions with ONE global atomic per (workgroup,
+// window) and appends {slot} and {user, value} there -- a window's region is as large as the window (slots are unique), so no
+// histogram pass is needed.  Pass B (seg_place_kernel): the workgroups of a window read its region in order and store the
+// entries at their slots; the workgroups of a window share an XCD (workgroup id mod 8).
+// Measured at 1e8 pairs (fill + scan, HIP events): L = 17 (763 windows of 1 MB, the L2-sized design) 6.0 ms -- pass A 4.5 ms:
+// its runs are ~10 pairs per window, i.e. the partial-sector stores it was meant to remove, twice; L = 19 4.4, 21 3.5, **22
+// 3.1** (24 windows of 32 MB: pass A's runs are 340 pairs, pass B's windows live in the Infinity Cache), 23 3.5, 24 3.7 = the
+// one-level fill.  A pass A that sorts its tile in LDS and writes whole sectors is what the 1 MB windows would need; not built.
+constexpr int STG_PT = 32;                 // pairs per thread of pass A (8,192 per workgroup)
+constexpr int STG_MAX_WINDOWS = 2048;      // LDS counters of pass A
+constexpr int STG_CURSOR_STRIDE = 32;      // one global cursor per 128-byte line: every workgroup of pass A adds to every window's cursor,
+                                           // and atomics on one line serialise (measured: no difference at 763 windows -- the stores dominate -- kept)
+
+__global__ __launch_bounds__(256, 4) void seg_stage_kernel(const int32_t* __restrict__ xu, const int32_t* __restrict__ xi,
+                                                       const int32_t* __restrict__ ranks, const float* __restrict__ values_in,
+                                                       int64_t n_pairs, int32_t pairs_per_user, const int64_t* __restrict__ indptr,
+                                                       int32_t window_log2, int32_t n_windows, int32_t* __restrict__ cursor,
+                                                       int32_t* __restrict__ keys, int2* __restrict__ payload)
+{
+    __shared__ int hist[STG_MAX_WINDOWS];
+    for (int i = threadIdx.x; i < n_windows; i += 256) hist[i] = 0;
+    __syncthreads();
+    const int64_t p0 = (int64_t)blockIdx.x * (256 * STG_PT) + threadIdx.x;
+    int32_t slot[STG_PT];
+#pragma unroll
+    for (int k0 = 0; k0 < STG_PT; k0 += 4) {               // four pairs at a time: ids and ranks, then the bucket starts (all unconditional)
+        int32_t it[4], rk[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t p = p0 + (int64_t)(k0 + q) * 256;
+            const int64_t pc = p < n_pairs ? p : n_pairs - 1;
+            it[q] = xi[pc];
+            rk[q] = ranks[pc];
+        }
+        int64_t base[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) base[q] = indptr[it[q] < 0 ? 0 : it[q]];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t p = p0 + (int64_t)(k0 + q) * 256;
+            const bool ok = p < n_pairs && it[q] >= 0;
+            const int32_t sl = ok ? (int32_t)(base[q] + rk[q]) : -1;
+            slot[k0 + q] = sl;
+            if (ok) atomicAdd(&hist[sl >> window_log2], 1);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_windows; i += 256) {
+        const int c = hist[i];
+        hist[i] = c ? atomicAdd(cursor + (int64_t)i * STG_CURSOR_STRIDE, c) : 0;     // this workgroup's first position in window i's region: an LDS cursor from here on
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k0 = 0; k0 < STG_PT; k0 += 4) {               // (values and users of four pairs together, unconditionally)
+        float vl[4];
+        int32_t us[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t p = p0 + (int64_t)(k0 + q) * 256;
+            const int64_t pc = p < n_pairs ? p : n_pairs - 1;
+            vl[q] = values_in[pc];
+            us[q] = xu ? xu[pc] : (int32_t)(pc / pairs_per_user);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int32_t sl = slot[k0 + q];
+            if (sl < 0) continue;
+            const int w = sl >> window_log2;
+            const int64_t pos = ((int64_t)w << window_log2) + atomicAdd(&hist[w], 1);
+            keys[pos] = sl;
+            payload[pos] = make_int2(us[q], __float_as_int(vl[q]));
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void seg_place_kernel(const int32_t* __restrict__ keys, const int2* __restrict__ payload,
+                                                       const int32_t* __restrict__ cursor, int32_t window_log2, int32_t n_windows,
+                                                       int32_t wgs_per_window, int2* __restrict__ entries)
+{
+    const int x = blockIdx.x & 7, t = blockIdx.x >> 3;      // XCD x takes the windows w = x (mod 8), in order
+    const int w = (t / wgs_per_window) * 8 + x, j = t % wgs_per_window;
+    if (w >= n_windows) return;
+    const int n = cursor[(int64_t)w * STG_CURSOR_STRIDE];
+    const int64_t base = (int64_t)w << window_log2;
+    for (int i0 = j * 1024 + (int)threadIdx.x; i0 < n; i0 += wgs_per_window * 1024) {
+        int32_t key[4];
+        int2 pl[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = i0 + 256 * q;
+            const int ic = i < n ? i : n - 1;
+            key[q] = keys[base + ic];
+            pl[q] = payload[base + ic];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (i0 + 256 * q < n) entries[key[q]] = pl[q];
+    }
+}
+
+// staging bytes of trec_group_pairs_by_item_staged for n_pairs pairs and windows of 2^window_log2 entries, or 0 when that form
+// does not cover the size (more than 2,048 windows, fewer than two)
+extern "C" int64_t trec_group_pairs_staged_bytes(int64_t n_pairs, int32_t window_log2)
+{
+    if (n_pairs < 2 || window_log2 < 8 || window_log2 > 24) return 0;
+    const int64_t n_windows = ceil_div64(n_pairs, (int64_t)1 << window_log2);
+    if (n_windows < 2 || n_windows > STG_MAX_WINDOWS) return 0;
+    return (n_windows << window_log2) * 12 + n_windows * STG_CURSOR_STRIDE * 4;
+}
+
+// trec_group_pairs_by_item with counts_given = 1, ranks and values (entries int2 [n_pairs] = {user, value bits}), the fill done in
+// two levels through ``staging`` (trec_group_pairs_staged_bytes).  workspace_i32 [2 * n_items]: its first half holds the histogram.
+extern "C" int trec_group_pairs_by_item_staged(const int32_t* xu, const int32_t* xi, int64_t n_pairs, int32_t pairs_per_user,
+                                               int64_t n_items, int32_t* workspace_i32, int64_t* workspace_i64, int64_t* indptr_t,
+                                               int32_t* entries, const int32_t* ranks, const float* values_in, void* staging,
+                                               int64_t staging_bytes, int32_t window_log2, void* stream)
+{
+    TREC_REQUIRE(xi && workspace_i32 && workspace_i64 && indptr_t && entries && ranks && values_in && staging,
+                 "trec_group_pairs_by_item_staged: null pointer");
+    TREC_REQUIRE(xu || pairs_per_user >= 1, "trec_group_pairs_by_item_staged: need xu or pairs_per_user");
+    TREC_REQUIRE(n_pairs < ((int64_t)1 << 31) && n_items >= 1, "trec_group_pairs_by_item_staged: n_pairs must fit int32");
+    const int64_t need = trec_group_pairs_staged_bytes(n_pairs, window_log2);
+    TREC_REQUIRE(need > 0 && staging_bytes >= need, "trec_group_pairs_by_item_staged: size not covered / staging too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int32_t n_windows = (int32_t)ceil_div64(n_pairs, (int64_t)1 << window_log2);
+    int32_t* keys = (int32_t*)staging;
+    int2* payload = (int2*)(keys + ((int64_t)n_windows << window_log2));
+    int32_t* cursor = (int32_t*)(payload + ((int64_t)n_windows << window_log2));
+    const int n_blocks = (int)ceil_div64(n_items, 1024);
+    int64_t* block_sum = workspace_i64;
+    int64_t* total = workspace_i64 + n_blocks;
+    if (hipMemsetAsync(cursor, 0, sizeof(int32_t) * (size_t)n_windows * STG_CURSOR_STRIDE, st) != hipSuccess) {
+        trec_set_last_error("trec_group_pairs_by_item_staged: memset failed");
+        return TREC_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(seg_scan_local_kernel, dim3((unsigned)n_blocks), dim3(256), 0, st, workspace_i32, n_items, indptr_t, block_sum);
+    hipLaunchKernelGGL(seg_scan_blocks_kernel, dim3(1), dim3(256), 0, st, block_sum, n_blocks, total);
+    hipLaunchKernelGGL(seg_add_offsets_kernel, dim3((unsigned)ceil_div64(n_items + 1, 256)), dim3(256), 0, st, indptr_t, n_items, block_sum, total);
+    hipLaunchKernelGGL(seg_stage_kernel, dim3((unsigned)ceil_div64(n_pairs, 256 * STG_PT)), dim3(256), 0, st, xu, xi, ranks, values_in,
+                       n_pairs, pairs_per_user, indptr_t, window_log2, n_windows, cursor, keys, payload);
+    int32_t wgs = (int32_t)(((int64_t)1 << window_log2) / 2048);
+    if (wgs < 1) wgs = 1;
+    const unsigned blocks = (unsigned)(((n_windows + 7) / 8) * 8 * wgs);
+    hipLaunchKernelGGL(seg_place_kernel, dim3(blocks), dim3(256), 0, st, keys, payload, cursor, window_log2, n_windows, wgs, (int2*)entries);
+    return trec_check_launch("trec_group_pairs_by_item_staged");
+}
+
 // exclusive prefix sum of int32 counts into int64: out[i] = sum_{j<i} counts[j], out[n] = total.
 // workspace_i64: ceil(n/1024) + 1 int64
 extern "C" int trec_exclusive_scan_i32(const int32_t* counts, int64_t n, int64_t* workspace_i64, int64_t* out, void* stream)

@@ -472,6 +472,22 @@ def group_pairs_by_item(xu32, xi32, pairs_per_user, n_items, workspace_with_coun
     users_t = None if carry else torch.empty((n_pairs,), dtype=torch.int32, device=dev)
     if carry:      # packed: entries int2 {user, value bits}, one 8-byte scattered store per pair; (indptr, entries, None)
         entries = torch.empty((n_pairs, 2), dtype=torch.int32, device=dev)
+        lib = N.load()
+        if workspace_with_counts is not None and lib.trec_get_tuning(b"group_pairs_staged", 1) != 0 and \
+                n_pairs >= lib.trec_get_tuning(b"group_pairs_staged_min", 1 << 24):
+            # very many pairs: the fill in two levels (csrc/segment.hip) -- appended to the staging region of their destination
+            # window first, placed window by window afterwards, instead of 8-byte stores scattered over the whole 800 MB of
+            # entries.  Windows of 2^22 entries measured best at 1e8 pairs (fill + scan 3.1 ms against 3.7 in one level; 2^17:
+            # 6.0, 2^19: 4.4, 2^21: 3.5, 2^23: 3.5, 2^24: 3.7 -- the staging pass pays per window, the placing pass per entry)
+            wlog = int(lib.trec_get_tuning(b"group_pairs_window_log2", 22))
+            sbytes = int(N.query("trec_group_pairs_staged_bytes", int(n_pairs), wlog))
+            if sbytes > 0:
+                staging = torch.empty((sbytes,), dtype=torch.uint8, device=dev)
+                with _timed("group_pairs_staged"):
+                    N.call("trec_group_pairs_by_item_staged", N.ptr(xu32), N.ptr(xi32), n_pairs, pairs_per_user, n_items,
+                           N.ptr(ws32), N.ptr(ws64), N.ptr(indptr_t), N.ptr(entries), N.ptr(ranks), N.ptr(values),
+                           N.ptr(staging), sbytes, wlog)
+                return indptr_t, entries, None
         N.call("trec_group_pairs_by_item", N.ptr(xu32), N.ptr(xi32), n_pairs, pairs_per_user, n_items, N.ptr(ws32),
                N.ptr(ws64), N.ptr(indptr_t), N.ptr(entries), None, 1, N.ptr(ranks), N.ptr(values), None)
         return indptr_t, entries, None

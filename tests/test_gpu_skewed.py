@@ -334,3 +334,53 @@ def test_group_pairs_by_item_with_lds_counters(ops):
     p2 = perm2.cpu().numpy()[:n_valid]
     for b in (0, 1, 17, n_items - 1):
         assert set(p2[indptr[b]:indptr[b + 1]].tolist()) == set(perm[indptr[b]:indptr[b + 1]].tolist())
+
+
+def test_ranked_packed_fill_in_two_levels(ops):
+    """trec_group_pairs_by_item_staged (the 1e8 sampled pairs of the data-parallel fit: pairs staged by destination window, placed
+    while the window sits in L2): with the ranks given every pair's slot is fixed -- indptr[item] + rank -- so the entries must be
+    IDENTICAL to the one-level fill's, bit for bit, and to a NumPy placement; explicit and implicit users."""
+    import numpy as np
+    import torch
+    from tensorrec_amd import _native as N
+    rng = np.random.default_rng(21)
+    n_users, S, n_items = 3_000, 50, 5_003
+    zipf = 1.0 / np.arange(1, n_items + 1) ** 0.9
+    xi = rng.choice(n_items, size=n_users * S, p=zipf / zipf.sum()).astype(np.int32)
+    n_pairs = xi.size
+    vals = rng.standard_normal(n_pairs).astype(np.float32)
+    # the rank of a pair inside its item's bucket and the histogram -- what wmrb_user_fused_kernel's atomics hand over
+    order = np.argsort(xi, kind="stable")
+    counts = np.bincount(xi, minlength=n_items).astype(np.int32)
+    indptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    ranks = np.empty(n_pairs, np.int32)
+    ranks[order] = (np.arange(n_pairs) - indptr[xi[order]]).astype(np.int32)
+    want = np.zeros((n_pairs, 2), np.int32)
+    slot = indptr[xi] + ranks
+    want[slot, 0] = (np.arange(n_pairs) // S).astype(np.int32)
+    want[slot, 1] = vals.view(np.int32)
+    dxi, dr, dv = torch.from_numpy(xi).cuda(), torch.from_numpy(ranks).cuda(), torch.from_numpy(vals).cuda()
+    assert N.query("trec_group_pairs_staged_bytes", n_pairs, 12) > 0 and N.query("trec_group_pairs_staged_bytes", n_pairs, 24) == 0
+
+    def run(staged, explicit_users):
+        ws32 = torch.zeros((2 * n_items,), dtype=torch.int32, device="cuda")
+        ws32[:n_items] = torch.from_numpy(counts).cuda()
+        xu = torch.arange(n_pairs, dtype=torch.int32, device="cuda") // S if explicit_users else None
+        N.set_tuning("group_pairs_staged", 1 if staged else 0)
+        N.set_tuning("group_pairs_staged_min", 0)
+        N.set_tuning("group_pairs_window_log2", 12)
+        try:
+            ind, entries, none = ops.group_pairs_by_item(xu, dxi, S, n_items, workspace_with_counts=ws32, ranks=dr, values=dv)
+        finally:
+            N.set_tuning("group_pairs_staged", 1)
+            N.set_tuning("group_pairs_staged_min", 1 << 24)
+            N.set_tuning("group_pairs_window_log2", 22)
+        assert none is None
+        return ind.cpu().numpy(), entries.cpu().numpy()
+
+    for explicit_users in (False, True):
+        ind_a, ent_a = run(True, explicit_users)
+        ind_b, ent_b = run(False, explicit_users)
+        assert np.array_equal(ind_a, indptr) and np.array_equal(ind_b, indptr)
+        assert np.array_equal(ent_a, want)
+        assert np.array_equal(ent_b, want)
