@@ -158,6 +158,12 @@ def test_abi_pure_queries_and_argument_errors():
     assert rc == 1 and b"nnz != 0" in lib.trec_last_error()
     rc = lib.trec_sample_items(3, 0, 5, 6, 0, 0, 0, ctypes.c_void_p(8), None)
     assert rc == 1 and b"larger sample than population" in lib.trec_last_error()
+    # the two-level fill: staging = 12 bytes per window slot + one 128-byte cursor line per window; 2 .. 2,048 windows only
+    assert lib.trec_group_pairs_staged_bytes(100_000_000, 22) == 24 * (1 << 22) * 12 + 24 * 128
+    assert lib.trec_group_pairs_staged_bytes(100_000_000, 17) == 763 * (1 << 17) * 12 + 763 * 128
+    assert lib.trec_group_pairs_staged_bytes(1 << 22, 22) == 0 and lib.trec_group_pairs_staged_bytes(1 << 30, 17) == 0
+    rc = lib.trec_group_pairs_by_item_staged(None, None, 10, 1, 1, None, None, None, None, None, None, None, 0, 22, None)
+    assert rc == 1 and b"null pointer" in lib.trec_last_error()
 
 
 def test_no_oracle_in_product():
