@@ -76,6 +76,59 @@ def parse():
     return ap.parse_args()
 
 
+def csrc_stamp():
+    """sha1 (12 hex) of every kernel source: the header of each profiles/*pmc_summary.txt carries the stamp of the code it was
+    taken from (scripts/gpu_pmc_cmd.sh, scripts/gpu_profile.sh), and a counter is quoted only while the sources of its kernel
+    are unchanged."""
+    import glob, hashlib
+    out = {}
+    for f in sorted(glob.glob(os.path.join(ROOT, "tensorrec_amd", "csrc", "*.h*"))):
+        out[os.path.basename(f)] = hashlib.sha1(open(f, "rb").read()).hexdigest()[:12]
+    return out
+
+
+def pmc_counters(file_glob, kernel_prefix, sources, counters=("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT", "TCC_MISS")):
+    """Per-dispatch averages of `counters` for the first kernel whose name starts with `kernel_prefix`, from the newest committed
+    summary matching `file_glob`.  Returns (values or None, file name or None, stale): stale = the summary carries no source stamp,
+    or the stamp of one of `sources` (the files the kernel is compiled from) differs from the tree's -- the caller then reports
+    traffic: null and traffic_stale: <file> instead of a number from other code."""
+    import glob, re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", file_glob)))
+    if not files:
+        return None, None, False
+    txt = open(files[-1]).read()
+    name = os.path.basename(files[-1])
+    m = re.search(r"^# csrc_sha: (\{.*\})$", txt, re.M)
+    if not m:
+        return None, name, True
+    stamp, now = json.loads(m.group(1)), csrc_stamp()
+    if any(stamp.get(f) != now.get(f) for f in tuple(sources) + ("common.hpp",)):
+        return None, name, True
+    vals = {}
+    for c in counters:
+        hit = re.findall(re.escape(kernel_prefix) + r"[^\n]*?\b" + c + r"=([0-9.e+]+)", txt)
+        if hit:
+            vals[c] = float(hit[0])
+    return (vals or None), name, False
+
+
+def attach_traffic(roof, file_glob, kernel_prefix, sources, note=""):
+    """roof["traffic"] = (2*FETCH_SIZE + WRITE_SIZE) KB per launch (gfx950 counts wide coalesced reads at half their size:
+    MI355X_MICROARCH.md, HBM section), or null + traffic_stale when the committed counters are of other code."""
+    if roof is None:
+        return
+    vals, name, stale = pmc_counters(file_glob, kernel_prefix, sources)
+    if stale:
+        roof["traffic"], roof["traffic_stale"] = None, name
+        return
+    if not vals or "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
+        return
+    roof["traffic"] = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+    roof["traffic_note"] = "(2*FETCH_SIZE + WRITE_SIZE) KB per launch from %s%s" % (name, note)
+    if "TCC_HIT" in vals and "TCC_MISS" in vals:
+        roof["l2_hit_rate"] = vals["TCC_HIT"] / (vals["TCC_HIT"] + vals["TCC_MISS"])
+
+
 def cpu_baseline(n_items, d, k, n_users_sample, seed=0):
     """The oracle's CPU path for the same pass: scipy CSR @ (identity features), torch-CPU sgemm,
     bias broadcast, NumPy argpartition top-k; float32; all host cores.  Timed on a bounded user tile x ALL items."""
@@ -224,27 +277,12 @@ def fit_epochs_per_sec(n_users, n_items, d, per_user=20, n_sampled=100, epochs=3
                         "algorithmic_bytes_per_launch": alg,
                         "bound_note": "random 512-byte row gathers from a 512 MB item table: 16x the aggregate L2 (32 MB) "
                                       "and 2x the Infinity Cache, so the rows cross the memory-side fabric (TCC hit rate "
-                                      "and FETCH_SIZE of this kernel: profiles/r02_fit_pmc_summary.txt); priced against "
+                                      "and FETCH_SIZE of this kernel: profiles/r*_fit_pmc_summary.txt); priced against "
                                       "the HBM peak",
                         "other_kernels_avg_ms": {n: float(np.mean(v)) for n, v in dur.items() if n != "wmrb_fused_step"},
                         "other_kernels_launches_per_epoch": {n: len(v) / 2.0 for n, v in dur.items() if n != "wmrb_fused_step"}}
-        try:
-            import glob, re
-            files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*fit_pmc_summary.txt")))
-            if files and world == 1 and (n_users, n_items, d) == (1_000_000, 1_000_000, 128):
-                txt = open(files[-1]).read()
-                f_ = re.findall(r"wmrb_user_fused_kernel[^\n]*?FETCH_SIZE=([0-9.e+]+)", txt)
-                w_ = re.findall(r"wmrb_user_fused_kernel[^\n]*?WRITE_SIZE=([0-9.e+]+)", txt)
-                h_ = re.findall(r"wmrb_user_fused_kernel[^\n]*?TCC_HIT=([0-9.e+]+)", txt)
-                m_ = re.findall(r"wmrb_user_fused_kernel[^\n]*?TCC_MISS=([0-9.e+]+)", txt)
-                if f_ and w_:
-                    # 512-byte rows are fetched as 16-byte-per-lane loads: FETCH_SIZE is doubled as the guide prescribes
-                    roofline_fit["traffic"] = (2.0 * float(f_[0]) + float(w_[0])) * 1024.0
-                if h_ and m_:
-                    roofline_fit["l2_hit_rate"] = float(h_[0]) / (float(h_[0]) + float(m_[0]))
-                roofline_fit["traffic_note"] = "(2*FETCH_SIZE + WRITE_SIZE) KB per launch from %s" % os.path.basename(files[-1])
-        except Exception:
-            pass
+        if world == 1 and (n_users, n_items, d) == (1_000_000, 1_000_000, 128):
+            attach_traffic(roofline_fit, "r[0-9][0-9]_fit_pmc_summary.txt", "wmrb_user_fused_kernel", ("wmrb_fused.hip",))
     return {"fit_epochs_per_sec": 1.0 / per_epoch, "sec_per_epoch": per_epoch, "epochs_timed": epochs,
             "roofline_fit": roofline_fit,
             "workload": "%d users x %d items, identity features, d=%d, Linear + DotProduct + WMRB, biased, %d "
@@ -467,8 +505,7 @@ def main():
     peak = FP32_MFMA_PEAK_TFLOPS if args.precision == "fp32" else (INT8_DENSE_PEAK_TOPS if cascade else BF16_DENSE_PEAK_TFLOPS)
     k2_tflops = k2_flops / (k2_ms * 1e-3) / 1e12
     k2_label = "score_gemm_kernel (fused top-k epilogue)" if method == "direct" else (
-        "blockmax_i8x16_kernel (v_mfma_i32_16x16x64_i8: int8 superblock maxima over every (user, item), stage 0 of the "
-        "int8 -> bf16 -> fp32 cascade; int8 multiply-adds counted as 2 ops, peak = 2x the dense bf16 peak)" if cascade else
+        "blockmax_i8x16_kernel (int8 MFMA, all pairs; peak = 2x bf16 dense)" if cascade else
         "blockmax_pipe_kernel (superblock maxima, stage 1 of the two-stage top-k)"
         if args.precision != "fp32" and kpad in (64, 128) and T._native.load().trec_get_tuning(b"blockmax_pipelined", 1)
         else "score_gemm_kernel (superblock-max epilogue)")
@@ -538,15 +575,8 @@ def main():
                                                "fabric-side counters include those hits, so this is NOT an HBM-only fraction (the HBM-only "
                                                "copy ceiling of the guide is ~6.3 TB/s)",
                                  "traffic": None, "avg_launch_ms": ms, "algorithmic_bytes_per_launch": alg}
-            import glob as _g, re as _re
-            files = sorted(_g.glob(os.path.join(ROOT, "profiles", "*k1_multi_pmc*.txt")))
-            if files and n_rows == 1_000_000 and d == 128:
-                txt = open(files[-1]).read()
-                f_ = _re.findall(r"spmm_csr[^\n]*?FETCH_SIZE=([0-9.e+]+)", txt)
-                w_ = _re.findall(r"spmm_csr[^\n]*?WRITE_SIZE=([0-9.e+]+)", txt)
-                if f_ and w_:
-                    roofline_k1_multi["traffic"] = (2.0 * float(f_[0]) + float(w_[0])) * 1024.0
-                    roofline_k1_multi["traffic_note"] = "(2*FETCH_SIZE + WRITE_SIZE) KB per launch from %s" % os.path.basename(files[-1])
+            if n_rows == 1_000_000 and d == 128:
+                attach_traffic(roofline_k1_multi, "r[0-9][0-9]_k1_multi_pmc_summary.txt", "void spmm_csr_vec4_kernel", ("spmm.hip",))
             del f_m, w_m, m, cols
         except Exception as exc:
             roofline_k1_multi = {"error": repr(exc)}
@@ -554,31 +584,17 @@ def main():
     # ---- HBM-side traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the figure
     # comes from the committed rocprofv3 --pmc passes of this same command (profiles/*_pmc_summary.txt), corrected as
     # MI355X_MICROARCH.md prescribes (gfx950 FETCH_SIZE counts wide coalesced reads at half their size) ----
-    try:
-        import glob, re
-        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_summary.txt")))
-        if files and world == 1 and (U, I, d) == (1_000_000, 1_000_000, 128) and method == "two_stage":
-            txt = open(files[-1]).read()
-            fetch = write = None
-            for key in (("blockmax_i8x16_kernel<128", "blockmax_i8_kernel<128") if cascade else
-                        ("blockmax_pipe_kernel<128", "score_gemm_kernel<1, 128, 64, 2, 2")):     # stage-1 kernel names
-                fetch = [float(m) for m in re.findall(re.escape(key) + r"[^\n]*?FETCH_SIZE=([0-9.e+]+)", txt)]
-                write = [float(m) for m in re.findall(re.escape(key) + r"[^\n]*?WRITE_SIZE=([0-9.e+]+)", txt)]
-                if fetch and write:
-                    break
-            k1_pat = "spmm_one_per_row_kernel" if f_u.one_per_row else "spmm_csr_vec4_kernel<1, 4, 0, true, true"
-            k1f = re.findall(re.escape(k1_pat) + r"[^\n]*?FETCH_SIZE=([0-9.e+]+)", txt)
-            k1w = re.findall(re.escape(k1_pat) + r"[^\n]*?WRITE_SIZE=([0-9.e+]+)", txt)
-            if k1f and k1w and roofline_k1 is not None:          # per-dispatch averages over the user- and item-side launch
-                roofline_k1["traffic"] = (2.0 * float(k1f[0]) + float(k1w[0])) * 1024.0
-            if fetch and write:
-                roofline["traffic"] = (2.0 * fetch[0] + write[0]) * 1024.0
-                roofline["traffic_note"] = ("bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KB from %s; fabric-side "
-                                            "reads incl. Infinity-Cache hits; algorithmic minimum is %.3g bytes"
-                                            % (os.path.basename(files[-1]),
-                                               (U + n_local) * kpad * (1.0 if cascade else 2.0) + U * 4.0 * (n_local // 512)))
-    except Exception:
-        pass
+    if world == 1 and (U, I, d) == (1_000_000, 1_000_000, 128) and method == "two_stage":
+        alg_note = "; fabric-side reads incl. Infinity-Cache hits; algorithmic minimum is %.3g bytes" % (
+            (U + n_local) * kpad * (1.0 if cascade else 2.0) + U * 4.0 * (n_local // 512))
+        if cascade:
+            attach_traffic(roofline, "r[0-9][0-9]_pmc_summary.txt", "void (anonymous namespace)::blockmax_i8x16_kernel<128",
+                           ("score_blockmax_i8.hip", "score_common.hpp"), alg_note)
+        else:
+            attach_traffic(roofline, "r[0-9][0-9]_pmc_summary.txt", "void (anonymous namespace)::blockmax_bf16x16_kernel<128",
+                           ("score_blockmax.hip", "score_common.hpp"), alg_note)
+        attach_traffic(roofline_k1, "r[0-9][0-9]_pmc_summary.txt",
+                       "void spmm_one_per_row_kernel" if f_u.one_per_row else "void spmm_csr_vec4_kernel<1, 4, 0, true, true", ("spmm.hip",))
 
     # ---- live parity check against the oracle (checker only): the timed step's own output, on sampled users ----
     parity = None
@@ -645,7 +661,7 @@ def main():
                                                     None if ub_all is None else ub_all[s0:s0 + n32].contiguous(), ib32)
                 all_equal = bool(torch.equal(ci_, idx[s0:s0 + n32]) and torch.equal(cv_, vals[s0:s0 + n32]))
             fp32_mode = {"workload": "%d users x %d items, whole two-stage top-%d on fp32 MFMA" % (n32, n_local, k),
-                         "equals_timed_exact_mode_output_all_%d_users" % U: all_equal,
+                         "equals_timed_exact_mode_output_all_%d_users" % U: all_equal, "equals_all_users": all_equal,
                          "ms": 1e3 * dt, "predictions_per_s": n32 * float(n_local) / dt,
                          "tflops": 2.0 * n32 * n_local * kpad / dt / 1e12,
                          "frac_of_fp32_mfma_peak": 2.0 * n32 * n_local * kpad / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS,
@@ -696,24 +712,11 @@ def main():
                                "bound": "mfma", "achieved": tf_, "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": tf_ / BF16_DENSE_PEAK_TFLOPS, "traffic": None,
                                "avg_launch_ms": bf16_mode["stage1_avg_launch_ms"], "algorithmic_flops_per_launch": k2_flops_step}
-        try:
-            import glob, re
-            files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bf16dense_pmc_summary.txt")))
-            if files and (U, I, d) == (1_000_000, 1_000_000, 128):
-                txt = open(files[-1]).read()
-                f_ = re.findall(r"blockmax_bf16x16_kernel<128, true, false[^\n]*?FETCH_SIZE=([0-9.e+]+)", txt)
-                w_ = re.findall(r"blockmax_bf16x16_kernel<128, true, false[^\n]*?WRITE_SIZE=([0-9.e+]+)", txt)
-                h_ = re.findall(r"blockmax_bf16x16_kernel<128, true, false[^\n]*?TCC_HIT=([0-9.e+]+)", txt)
-                m_ = re.findall(r"blockmax_bf16x16_kernel<128, true, false[^\n]*?TCC_MISS=([0-9.e+]+)", txt)
-                if f_ and w_:
-                    roofline_bf16_dense["traffic"] = (2.0 * float(f_[0]) + float(w_[0])) * 1024.0
-                    roofline_bf16_dense["traffic_note"] = ("(2*FETCH_SIZE + WRITE_SIZE) KB per launch from %s; algorithmic minimum "
-                                                           "%.3g bytes (bf16 operands once + the [n_sb, U] table)"
-                                                           % (os.path.basename(files[-1]), (U + n_local) * kpad * 2.0 + U * 4.0 * (n_local // 512)))
-                if h_ and m_:
-                    roofline_bf16_dense["l2_hit_rate"] = float(h_[0]) / (float(h_[0]) + float(m_[0]))
-        except Exception:
-            pass
+        if (U, I, d) == (1_000_000, 1_000_000, 128):
+            attach_traffic(roofline_bf16_dense, "r[0-9][0-9]_bf16dense_pmc_summary.txt",
+                           "void (anonymous namespace)::blockmax_bf16x16_kernel<128, true, false", ("score_blockmax.hip", "score_common.hpp"),
+                           "; algorithmic minimum %.3g bytes (bf16 operands once + the [n_sb, U] table)"
+                           % ((U + n_local) * kpad * 2.0 + U * 4.0 * (n_local // 512)))
 
     # ---- the PUBLIC API on the same weights: TensorRec.predict_top_k itself (features given as scipy matrices, uploaded once
     # and recognised by content afterwards; representations, user-side preparation, cascade; lists returned on the device), with
@@ -844,34 +847,23 @@ def main():
     except Exception as exc:
         scale_emulation = {"error": repr(exc)}
     line["scale_emulation"] = scale_emulation
-    # the verdicts of the records above in one compact object INSIDE config (the driver's stored record keeps config whole and
-    # only the names of the other keys)
-    def _get(obj, *path):
-        for key in path:
-            if not isinstance(obj, dict) or key not in obj:
-                return None
-            obj = obj[key]
-        return obj
-    line["config"]["checks"] = {
-        "parity_users": _get(parity, "sample_users"), "topk_ids_bit_exact": _get(parity, "topk_ids_bit_exact_vs_oracle"),
-        "topk_values_bit_exact": _get(parity, "topk_values_bit_exact_vs_oracle"),
-        "fp32_mfma_equals_all_users": _get(fp32_mode, "equals_timed_exact_mode_output_all_%d_users" % U),
-        "fp32_mfma_frac_of_peak": _get(fp32_mode, "frac_of_fp32_mfma_peak"),
-        "bf16_filter_equals_cascade": _get(bf16_mode, "equals_timed_cascade_output"),
-        "bf16_dense_frac_of_peak": _get(roofline_bf16_dense, "frac"),
-        "public_api_ms": _get(public_api, "ms_per_call_min"), "public_api_equals_step": _get(public_api, "equals_timed_step_output"),
-        "trained_ms": _get(trained, "ms_per_step"), "trained_bit_exact": _get(trained, "parity", "topk_ids_bit_exact_vs_oracle"),
-        "parity_fit_green": _get(parity_fit, "green"), "parity_multi_nnz_ids": _get(parity_multi, "topk_ids_bit_exact_vs_oracle"),
-        "fit_epochs_per_s": _get(fit, "fit_epochs_per_sec"), "fit_kernel_frac_of_hbm": _get(fit, "roofline_fit", "frac"),
-        "step_ms_first_last": [step_ms[0], step_ms[-1]], "prewarm_steps": line["prewarm_steps"],
-        "emulated_rank_ms_predict_n8": _get(scale_emulation, "predict", "per_rank_step_ms"),
-        "emulated_rank_ms_fit_n8": _get(scale_emulation, "fit", "per_rank_compute_ms_per_step"),
-        "fit_wire_gb_per_rank_step_n8": (_get(scale_emulation, "fit", "wire_bytes_per_rank_and_step") or 0) / 1e9 or None,
-        "cfg": {name: [v for v in (_get(rec, "green"), _get(rec, "parity_one_step_vs_oracle", "green"),
-                                   _get(rec, "parity", "topk_ids_bit_exact_vs_oracle")) if v is not None]
-                for name, rec in (configs or {}).items()} if isinstance(configs, dict) else None,
-    }
-    print(json.dumps(line))
+    # dispatches per step the way rocprofv3 counts them (kernels + fills + copies): read from the committed kernel-stats of this
+    # command when one exists for the current round; the HIP-event count (our own launches only) is always present
+    line["launches_per_step_by_hip_events"] = len(events) / float(args.steps)
+    # ---- the FULL record goes to a side file; stdout gets ONE compact line (bench_line.py: < 4 KB, scalars only) ----
+    import bench_line
+    full_path = None
+    try:
+        out_dir = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(out_dir, exist_ok=True)
+        full_path = os.path.join("gpurun_out", "bench_full.json" if world == 1 else "bench_full_n%d.json" % world)
+        with open(os.path.join(ROOT, full_path), "w") as fh:
+            json.dump(line, fh)
+    except OSError:
+        full_path = None
+    sys.stdout.flush()
+    print(bench_line.compact_line(line, full_path))
+    sys.stdout.flush()
     if world > 1:
         dist.destroy_process_group()
 

@@ -24,6 +24,7 @@ python - <<PY
 import csv, glob, collections, re
 out=open("$REPO/gpurun_out/$NAME.txt","w")
 out.write("# rocprofv3 --pmc <set> --kernel-trace -- python $CMD ; per-dispatch averages; FETCH_SIZE / WRITE_SIZE in KB as reported\n")
+import sys, json; sys.path.insert(0, "$REPO"); import bench; out.write("# csrc_sha: %s\n" % json.dumps(bench.csrc_stamp(), sort_keys=True))
 pat=re.compile(r"$FILTER")
 for s in ("s1","s2","s3","s4"):
     for f in glob.glob("$OUT/%s/**/*counter_collection.csv"%s, recursive=True):

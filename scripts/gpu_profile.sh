@@ -27,6 +27,7 @@ python - <<PY
 import csv, glob, collections
 out=open("$OUT/${TAG}_cfg4_pmc_summary.txt","w")
 out.write("# rocprofv3 --pmc FETCH_SIZE WRITE_SIZE TCC_HIT TCC_MISS --kernel-trace -- python scripts/profile_cfg4.py 1 ; per-dispatch averages (KB)\n")
+import sys, json; sys.path.insert(0, "$REPO"); import bench; out.write("# csrc_sha: %s\n" % json.dumps(bench.csrc_stamp(), sort_keys=True))
 for f in sorted(glob.glob("$OUT/${TAG}_cfg4_pmc_*/**/*counter_collection.csv", recursive=True)):
     agg=collections.defaultdict(lambda: collections.defaultdict(float)); seen=set()
     for r in csv.DictReader(open(f)):
@@ -62,6 +63,7 @@ python - <<PY
 import csv, glob, collections
 out=open("$OUT/${TAG}_pmc_summary.txt","w")
 out.write("# rocprofv3 --pmc <set> --kernel-trace -- python bench.py --configs headline --steps 1 --warmup 0 --no-cpu-baseline --no-fit --no-fp32-mode --no-k1-multi --parity-users 64 ; per-dispatch averages\n")
+import sys, json; sys.path.insert(0, "$REPO"); import bench; out.write("# csrc_sha: %s\n" % json.dumps(bench.csrc_stamp(), sort_keys=True))
 out.write("# FETCH_SIZE / WRITE_SIZE are in KB as reported; on gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md)\n")
 for f in sorted(glob.glob("$OUT/${TAG}_pmc_*/**/*counter_collection.csv", recursive=True)):
     agg=collections.defaultdict(lambda: collections.defaultdict(float)); seen=set()
