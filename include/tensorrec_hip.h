@@ -553,6 +553,12 @@ int trec_wmrb_fused_step(const float* U, const float* V, const float* user_bias,
  * trec_dense_loss_bwd: d loss / d pred (same shape as pred) times the upstream gradient gl[0]. */
 int trec_dense_loss_fwd(int32_t kind, const float* pred, int64_t rows, int64_t cols, const int32_t* xu, const int32_t* xi,
                         const float* values, int64_t n_pairs, double* st, float* loss, void* stream);
+/* the forward pass in the three phases a user-sharded fit adds the other ranks' sums between (phase 0: pass 1; 1: means + pass 2;
+ * 2: loss + backward coefficients; the caller all-reduces st[0..9] after phases 0 and 1; n_all_total = dense predictions over
+ * all ranks): the scalar losses of loss_graphs.py:58-134 on the UNION of the user shards (the batching axis of tensorrec.py:199-217) */
+int trec_dense_loss_fwd_phase(int32_t kind, int32_t phase, const float* pred, int64_t rows, int64_t cols, const int32_t* xu,
+                              const int32_t* xi, const float* values, int64_t n_pairs, int64_t n_all_total, double* st, float* loss,
+                              void* stream);
 int trec_dense_loss_bwd(int32_t kind, const float* pred, int64_t rows, int64_t cols, const int32_t* xu, const int32_t* xi,
                         const float* values, int64_t n_pairs, const double* st, const float* gl, float* d_pred, void* stream);
 int trec_rmse_fwd(const float* y, const float* pred, int64_t n, float* partial_ws, int32_t n_partial, float* loss,

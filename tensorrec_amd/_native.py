@@ -129,6 +129,7 @@ SIGNATURES = {
     "trec_wmrb_fused_step": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp,
                              _vp, _vp, _vp, _vp, _vp],
     "trec_dense_loss_fwd": [_i32, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp],
+    "trec_dense_loss_fwd_phase": [_i32, _i32, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp],
     "trec_dense_loss_bwd": [_i32, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp],
     "trec_rmse_fwd": [_vp, _vp, _i64, _vp, _i32, _vp, _vp],
     "trec_rmse_bwd": [_vp, _vp, _vp, _vp, _i64, _vp, _vp],

@@ -195,32 +195,52 @@ unsigned grid_for(int64_t n, int per_thread)
 // kind 1: SeparationDenseLossGraph (pred [rows, cols] row-major, contiguous; xu / xi / values: the interactions, one entry per cell);
 // kind 2: RMSEDenseLossGraph (same inputs as kind 1).
 // st: double[16] workspace (kept for the backward pass), loss: float[1].
+//
+// trec_dense_loss_fwd_phase: the same forward pass cut where a user-sharded (data-parallel) fit has to add the other ranks' sums
+// (tensorrec/tensorrec.py:199-217 is the axis the users are split on; the loss is ONE scalar over the union batch):
+//   phase 0: zero st, pass 1 (counts, sums; RMSE dense: everything)              -> caller all-reduces st[0..9] (SUM)
+//   phase 1: means from st with n_all_total predictions, pass 2 (centred moments) -> caller all-reduces st[0..9] (SUM)   [separation only]
+//   phase 2: the loss and the backward coefficients from st (n_all_total for RMSE dense)
+// n_all_total: the number of dense predictions over ALL ranks (ignored by kind 0).  The backward pass needs no change: every
+// coefficient it reads is in st.
+extern "C" int trec_dense_loss_fwd_phase(int32_t kind, int32_t phase, const float* pred, int64_t rows, int64_t cols, const int32_t* xu,
+                                         const int32_t* xi, const float* values, int64_t n_pairs, int64_t n_all_total, double* st,
+                                         float* loss, void* stream)
+{
+    TREC_REQUIRE(kind >= 0 && kind <= 2 && phase >= 0 && phase <= 2 && pred && st && loss && (values || n_pairs == 0),
+                 "trec_dense_loss_fwd_phase: bad arguments");
+    TREC_REQUIRE(kind == 0 || ((xu && xi) || n_pairs == 0), "trec_dense_loss_fwd_phase: the dense forms need the interaction indices");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n_all = rows * cols;
+    const float* dense = kind == 0 ? (const float*)nullptr : pred;
+    const float* serial = kind == 0 ? pred : (const float*)nullptr;
+    if (phase == 0) {
+        if (hipMemsetAsync(st, 0, 16 * sizeof(double), s) != hipSuccess) { trec_set_last_error("trec_dense_loss_fwd: memset failed"); return TREC_ERR_LAUNCH; }
+        if (kind != 0 && n_all) hipLaunchKernelGGL(dense_moments_kernel, dim3(grid_for(n_all, 16)), dim3(256), 0, s, pred, rows, cols, cols, (const double*)nullptr, st);
+        if (n_pairs) hipLaunchKernelGGL(pair_moments_kernel, dim3(grid_for(n_pairs, 4)), dim3(256), 0, s, dense, cols, serial, xu, xi, values, n_pairs, (const double*)nullptr, st + 2);
+        return trec_check_launch("trec_dense_loss_fwd (pass 1)");
+    }
+    if (phase == 1) {
+        if (kind == 2) return TREC_OK;
+        // ---- means, then pass 2: centred second moments (tf.nn.moments: mean of squared differences from the mean)
+        hipLaunchKernelGGL(separation_means_kernel, dim3(1), dim3(1), 0, s, st, kind == 1 ? (double)n_all_total : -1.0);
+        if (kind == 1 && n_all) hipLaunchKernelGGL(dense_moments_kernel, dim3(grid_for(n_all, 16)), dim3(256), 0, s, pred, rows, cols, cols, (const double*)(st + 12), st);
+        if (n_pairs) hipLaunchKernelGGL(pair_moments_kernel, dim3(grid_for(n_pairs, 4)), dim3(256), 0, s, dense, cols, serial, xu, xi, values, n_pairs, (const double*)(st + 11), st + 2);
+        return trec_check_launch("trec_dense_loss_fwd (pass 2)");
+    }
+    if (kind == 2) hipLaunchKernelGGL(rmse_dense_finish_kernel, dim3(1), dim3(1), 0, s, st, loss, (double)n_all_total);
+    else hipLaunchKernelGGL(separation_finish_kernel, dim3(1), dim3(1), 0, s, st, loss);
+    return trec_check_launch("trec_dense_loss_fwd (finish)");
+}
+
 extern "C" int trec_dense_loss_fwd(int32_t kind, const float* pred, int64_t rows, int64_t cols, const int32_t* xu, const int32_t* xi,
                                    const float* values, int64_t n_pairs, double* st, float* loss, void* stream)
 {
-    TREC_REQUIRE(kind >= 0 && kind <= 2 && pred && st && loss && (values || n_pairs == 0), "trec_dense_loss_fwd: bad arguments");
-    TREC_REQUIRE(kind == 0 || ((xu && xi) || n_pairs == 0), "trec_dense_loss_fwd: the dense forms need the interaction indices");
-    hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(st, 0, 16 * sizeof(double), s) != hipSuccess) { trec_set_last_error("trec_dense_loss_fwd: memset failed"); return TREC_ERR_LAUNCH; }
-    const int64_t n_all = rows * cols;
-    if (kind == 2) {
-        hipLaunchKernelGGL(dense_moments_kernel, dim3(grid_for(n_all, 16)), dim3(256), 0, s, pred, rows, cols, cols, (const double*)nullptr, st);
-        if (n_pairs) hipLaunchKernelGGL(pair_moments_kernel, dim3(grid_for(n_pairs, 4)), dim3(256), 0, s, pred, cols, (const float*)nullptr, xu, xi, values, n_pairs, (const double*)nullptr, st + 2);
-        hipLaunchKernelGGL(rmse_dense_finish_kernel, dim3(1), dim3(1), 0, s, st, loss, (double)n_all);
-        return trec_check_launch("trec_dense_loss_fwd (rmse dense)");
+    for (int phase = 0; phase < 3; ++phase) {
+        const int rc = trec_dense_loss_fwd_phase(kind, phase, pred, rows, cols, xu, xi, values, n_pairs, rows * cols, st, loss, stream);
+        if (rc != TREC_OK) return rc;
     }
-    double n_all_d = kind == 1 ? (double)n_all : -1.0;
-    // ---- pass 1: counts and sums -> means
-    if (kind == 1) hipLaunchKernelGGL(dense_moments_kernel, dim3(grid_for(n_all, 16)), dim3(256), 0, s, pred, rows, cols, cols, (const double*)nullptr, st);
-    if (n_pairs) hipLaunchKernelGGL(pair_moments_kernel, dim3(grid_for(n_pairs, 4)), dim3(256), 0, s, kind == 1 ? pred : (const float*)nullptr, cols,
-                                    kind == 0 ? pred : (const float*)nullptr, xu, xi, values, n_pairs, (const double*)nullptr, st + 2);
-    hipLaunchKernelGGL(separation_means_kernel, dim3(1), dim3(1), 0, s, st, n_all_d);
-    // ---- pass 2: centred second moments (tf.nn.moments: mean of squared differences from the mean)
-    if (kind == 1) hipLaunchKernelGGL(dense_moments_kernel, dim3(grid_for(n_all, 16)), dim3(256), 0, s, pred, rows, cols, cols, (const double*)(st + 12), st);
-    if (n_pairs) hipLaunchKernelGGL(pair_moments_kernel, dim3(grid_for(n_pairs, 4)), dim3(256), 0, s, kind == 1 ? pred : (const float*)nullptr, cols,
-                                    kind == 0 ? pred : (const float*)nullptr, xu, xi, values, n_pairs, (const double*)(st + 11), st + 2);
-    hipLaunchKernelGGL(separation_finish_kernel, dim3(1), dim3(1), 0, s, st, loss);
-    return trec_check_launch("trec_dense_loss_fwd (separation)");
+    return TREC_OK;
 }
 
 // d loss / d pred, same shapes as trec_dense_loss_fwd's pred; st from the forward pass, gl: float[1] upstream gradient

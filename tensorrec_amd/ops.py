@@ -406,6 +406,7 @@ import threading as _threading
 
 class _Local(_threading.local):
     deterministic_grouping = False
+    loss_group = None          # (process group,) while a user-sharded fit step builds its loss: scalar losses span ALL shards
 
 
 _LOCAL = _Local()       # per THREAD: two models fitting in different threads must not switch each other's grouping mode
@@ -426,6 +427,32 @@ class deterministic_grouping(object):
     def __exit__(self, *exc):
         _LOCAL.deterministic_grouping = self.prev
         return False
+
+
+class scalar_loss_group(object):
+    """``with ops.scalar_loss_group(group):`` -- inside, the scalar losses (RMSE, RMSEDense, Separation, SeparationDense:
+    loss_graphs.py:58-134) are those of the UNION of every rank's interactions: their sums are all-reduced over ``group``
+    (a collective: every rank of the group must build the same loss) and the backward pass differentiates the global scalar
+    with respect to this rank's predictions.  TensorRec's data-parallel step wraps its loss construction in it."""
+
+    def __init__(self, group, active=True):
+        self.value = (group,) if active else None
+
+    def __enter__(self):
+        self.prev = _LOCAL.loss_group
+        _LOCAL.loss_group = self.value
+        return self
+
+    def __exit__(self, *exc):
+        _LOCAL.loss_group = self.prev
+        return False
+
+
+def _loss_all_reduce(t):
+    """SUM over the ranks of the current scalar_loss_group, in place (float64 / float32 device tensor)."""
+    import torch.distributed as dist
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=_LOCAL.loss_group[0])
+    return t
 
 
 def group_pairs_by_item(xu32, xi32, pairs_per_user, n_items, workspace_with_counts=None, ranks=None, values=None):
@@ -758,19 +785,35 @@ class _RMSE(torch.autograd.Function):
     def forward(ctx, pred, y):
         pred, y = _f32c(pred), _f32c(y)
         n = pred.numel()
-        n_partial = max(1, min(1024, (n + 4095) // 4096))
-        ws = torch.empty((n_partial,), dtype=torch.float32, device=pred.device)
         loss = torch.empty((1,), dtype=torch.float32, device=pred.device)
-        N.call("trec_rmse_fwd", N.ptr(y), N.ptr(pred), n, N.ptr(ws), n_partial, N.ptr(loss))
+        n_div = n
+        if n:
+            n_partial = max(1, min(1024, (n + 4095) // 4096))
+            ws = torch.empty((n_partial,), dtype=torch.float32, device=pred.device)
+            N.call("trec_rmse_fwd", N.ptr(y), N.ptr(pred), n, N.ptr(ws), n_partial, N.ptr(loss))
+        else:
+            loss.zero_()
+        if _LOCAL.loss_group is not None:
+            # user shards: sqrt(sum of every rank's squared errors / all interactions) -- this rank's sum is loss^2 * n; the
+            # backward kernel divides by (n_div * loss), now the global count and the global loss
+            sums = torch.stack([loss.double()[0] ** 2 * float(n), torch.tensor(float(n), dtype=torch.float64, device=pred.device)])
+            _loss_all_reduce(sums)
+            loss = torch.sqrt(sums[0] / sums[1]).to(torch.float32).reshape(1)
+            n_div = int(sums[1].item())
         ctx.save_for_backward(pred, y, loss)
+        ctx.n_div = n_div
         return loss.reshape(())
 
     @staticmethod
     def backward(ctx, gl):
         pred, y, loss = ctx.saved_tensors
         dp = torch.empty_like(pred)
-        N.call("trec_rmse_bwd", N.ptr(y), N.ptr(pred), N.ptr(loss), N.ptr(_f32c(gl).reshape(1)), pred.numel(),
-               N.ptr(dp))
+        n = pred.numel()
+        g = _f32c(gl).reshape(1)
+        if ctx.n_div != n and n:
+            g = g * (float(n) / float(ctx.n_div))         # (the kernel's divisor is its own n)
+        if n:
+            N.call("trec_rmse_bwd", N.ptr(y), N.ptr(pred), N.ptr(loss), N.ptr(g), n, N.ptr(dp))
         return dp, None
 
 
@@ -797,8 +840,18 @@ class _DenseLoss(torch.autograd.Function):
         n_pairs = int(values.numel())
         st = torch.empty((16,), dtype=torch.float64, device=pred.device)
         loss = torch.empty((1,), dtype=torch.float32, device=pred.device)
-        N.call("trec_dense_loss_fwd", kind, N.ptr(pred), rows, cols, N.ptr(xu32), N.ptr(xi32), N.ptr(values), n_pairs, N.ptr(st),
-               N.ptr(loss))
+        if _LOCAL.loss_group is None:
+            N.call("trec_dense_loss_fwd", kind, N.ptr(pred), rows, cols, N.ptr(xu32), N.ptr(xi32), N.ptr(values), n_pairs, N.ptr(st),
+                   N.ptr(loss))
+        else:
+            # user shards: the sums of both passes are those of every rank's predictions (csrc/loss_dense.hip, "phase")
+            n_all = torch.tensor([float(rows * cols)], dtype=torch.float64, device=pred.device)
+            n_all_total = int(_loss_all_reduce(n_all).item()) if kind != DENSE_LOSS_SEPARATION else 0
+            for phase in (0, 1, 2):
+                N.call("trec_dense_loss_fwd_phase", kind, phase, N.ptr(pred), rows, cols, N.ptr(xu32), N.ptr(xi32), N.ptr(values),
+                       n_pairs, n_all_total, N.ptr(st), N.ptr(loss))
+                if phase == 0 or (phase == 1 and kind != DENSE_LOSS_RMSE_DENSE):
+                    _loss_all_reduce(st[:10])
         ctx.save_for_backward(pred, st)
         ctx.meta = (kind, rows, cols, xu32, xi32, values, n_pairs)
         return loss.reshape(())

@@ -716,7 +716,9 @@ class TensorRec(object):
                     'tf_n_sampled_items': n_sampled_items,
                 })
 
-            basic_loss = loss_graph.connect_loss_graph(**loss_kwargs)
+            # (user shards: a scalar loss is ONE number over the union batch -- its sums cross the ranks inside the loss op)
+            with ops.scalar_loss_group(self.process_group, active=self._dp_active()):
+                basic_loss = loss_graph.connect_loss_graph(**loss_kwargs)
 
         # tf_loss = tf_basic_loss + alpha * reg (broadcast), minimised as a sum (tensorrec.py:487-489)
         n_loss = int(basic_loss.numel())
@@ -837,9 +839,14 @@ class TensorRec(object):
         import torch.distributed as dist
         from . import sharding
         loss_graph = self.loss_graph_factory
-        if basic_loss.dim() == 0:
-            raise NotImplementedError("data-parallel fit needs a loss that is a per-interaction vector (WMRB "
-                                      "family); %s returns a scalar" % type(loss_graph).__name__)
+        scalar = basic_loss.dim() == 0
+        if scalar and type(loss_graph).connect_loss_graph.__module__ != AbstractLossGraph.__module__ and \
+                not getattr(self, "_dp_scalar_warned", False):
+            # the built-in scalar losses all-reduce their sums (ops.scalar_loss_group): one number over the union batch, the
+            # reference's value for user_batch_size=None.  What a user-defined scalar means across shards only its author knows.
+            logging.warning("data-parallel fit with the user-defined scalar loss %s: the objective is the SUM of the ranks' "
+                            "values unless the loss reduces over ops.scalar_loss_group itself" % type(loss_graph).__name__)
+            self._dp_scalar_warned = True
         store, group = self._store, self.process_group
         for name in store.order:
             var = store.variables[name]
@@ -849,7 +856,9 @@ class TensorRec(object):
             self._dp_plan = self._dp_make_plan()
         plan = self._dp_plan
         rank = dist.get_rank(group)
-        n_loss = sharding.all_reduce_scalar(n_loss, store.device, group)
+        # tf_loss = basic_loss + alpha * reg is summed over the loss entries (tensorrec.py:487-489): every interaction's for a
+        # vector loss, ONE for a scalar
+        n_loss = 1 if scalar else sharding.all_reduce_scalar(n_loss, store.device, group)
         if self._capture is not None:                       # (tests: the LOCAL gradients, before any exchange)
             self._capture['loss'] = basic_loss.detach().cpu().numpy().copy()
             self._capture['pred_serial'] = pred_serial.detach().cpu().numpy().copy()

@@ -33,7 +33,12 @@ def _model(dp, kind="linear"):
                            item_repr_graph=T.representation_graphs.ReLURepresentationGraph(),
                            prediction_graph=T.prediction_graphs.EuclideanSimilarityPredictionGraph(),
                            loss_graph=T.loss_graphs.WMRBLossGraph(), seed=5, data_parallel=dp)
+    if kind in _SCALAR_LOSSES:
+        return T.TensorRec(n_components=16, loss_graph=getattr(T.loss_graphs, kind)(), seed=5, data_parallel=dp)
     return T.TensorRec(n_components=16, loss_graph=T.loss_graphs.BalancedWMRBLossGraph(), seed=5, data_parallel=dp)
+
+
+_SCALAR_LOSSES = ("RMSELossGraph", "RMSEDenseLossGraph", "SeparationLossGraph", "SeparationDenseLossGraph")
 
 
 def _free_port():
@@ -54,10 +59,13 @@ def _worker(rank, world, port, bounds, ret, kind="linear", identity_users=False,
         if min_numel is not None:
             sharding.SHARD_MIN_NUMEL = min_numel
         inter, uf, itf = _data(identity_users)
+        if kind in _SCALAR_LOSSES:
+            inter = _signed(inter)
         b, e = bounds[rank], bounds[rank + 1]
         model = _model(True, kind)
         for _ in range(calls):
-            model.fit_partial(inter[b:e], uf[b:e], itf, epochs=3 // calls, learning_rate=0.05, n_sampled_items=20, user_offset=b)
+            model.fit_partial(inter[b:e], uf[b:e], itf, epochs=3 // calls, learning_rate=0.05, user_offset=b,
+                              n_sampled_items=None if kind in _SCALAR_LOSSES else 20)
         out = model.get_weights()
         out["__plan__"] = dict(model._dp_plan.mode)
         model.dp_sync(optimizer_state=True)
@@ -137,6 +145,42 @@ def test_two_rank_fit_relu_euclidean_wmrb():
         if k == "user_feature_biases":
             continue                                   # zero-gradient weight under WMRB (see above)
         assert np.allclose(ret[0][k], v, rtol=2e-3, atol=5e-3), "%s: %g" % (k, np.abs(ret[0][k] - v).max())
+
+
+def _signed(inter):
+    """positive and non-positive interaction values (the separation losses split on the sign, RMSE fits the magnitude)"""
+    inter = inter.copy()
+    rng = np.random.RandomState(3)
+    inter.data[:] = np.where(rng.rand(inter.nnz) < 0.4, -1.0, 1.0) * (0.5 + rng.rand(inter.nnz))
+    return inter.astype(np.float32)
+
+
+@pytest.mark.parametrize("loss", _SCALAR_LOSSES)
+def test_two_rank_fit_scalar_losses_equal_single_process_fit(loss):
+    """The scalar losses (loss_graphs.py:58-134) under user shards: every rank's loss op all-reduces its sums
+    (ops.scalar_loss_group), so both ranks differentiate the ONE scalar of the union batch -- the single-process fit with
+    user_batch_size=None -- and the L2 term counts one loss entry, not one per rank."""
+    inter, uf, itf = _data()
+    inter = _signed(inter)
+    single = _model(False, loss)
+    single.fit(inter, uf, itf, epochs=3, learning_rate=0.05)
+    ref = single.get_weights()
+    init = _model(False, loss)
+    init.build(uf.shape[1], itf.shape[1])
+    init = init.get_weights()
+    mgr = mp.get_context("spawn").Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), [0, 41, 70], ret, loss), nprocs=2, join=True)
+    assert sorted(ret.keys()) == [0, 1]
+    moved = 0.0
+    for k, v in ref.items():
+        assert np.array_equal(ret[0][k], ret[1][k]), "ranks diverged on %s" % k
+        # Adam normalises: a weight whose gradient is rounding noise moves by +-lr whatever the noise is; the weights that carry
+        # signal agree to summation order
+        close = np.isclose(ret[0][k], v, rtol=2e-3, atol=5e-3)
+        assert close.mean() > 0.995, "%s: %.4f of the entries agree, max diff %g" % (k, close.mean(), np.abs(ret[0][k] - v).max())
+        moved = max(moved, float(np.abs(v - init[k]).max()))
+    assert moved > 0.05
 
 
 def _initial(name):
