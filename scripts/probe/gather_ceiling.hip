@@ -6,7 +6,8 @@
 // accumulates into registers and writes one float per wave at the end -- the access pattern of spmm_csr_vec4 / wmrb_user_fused
 // without their arithmetic.  Row ids come from a pre-generated int32 list (streamed, 4 bytes per 512 / 1024 gathered).
 //
-// usage: gather_ceiling [row_bytes=512] [pairs=120000000]     prints one JSON line per table size
+// usage: gather_ceiling [row_bytes=512] [pairs=60000000]     prints one JSON line per table size
+//        gather_ceiling 0 [pairs]                         bandwidth against the bytes in flight per CU (512-byte rows, 512 MB table)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -15,13 +16,12 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int ROW_BYTES>
+template <int ROW_BYTES, int INFLIGHT = 8>
 __global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ table, const int32_t* __restrict__ ids, int64_t n_ids,
                                                      float* __restrict__ out)
 {
     constexpr int LANES_PER_ROW = ROW_BYTES / 16;            // 32 (512 B) or 64 (1 KB)
     constexpr int ROWS_PER_LOAD = 64 / LANES_PER_ROW;        // rows one wave-load covers
-    constexpr int INFLIGHT = 8;
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
     const int64_t n_waves = ((int64_t)gridDim.x * 256) >> 6;
@@ -45,6 +45,41 @@ __global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ t
 
 static uint64_t rng_state = 88172645463325252ull;
 static inline uint64_t xorshift() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return rng_state; }
+
+// bandwidth against the bytes a CU keeps in flight: 512-byte rows from a 512 MB table, wgs workgroups of 4 waves per CU, each lane
+// INFLIGHT 16-byte loads outstanding (one wave-load = 1 KB)
+template <int INFLIGHT>
+void sweep_one(const float* d_table, const int32_t* d_ids, int64_t n_pairs, float* d_out, int wgs)
+{
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const int blocks = 256 * wgs;
+    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL((gather_kernel<512, INFLIGHT>), dim3(blocks), dim3(256), 0, 0, d_table, d_ids, n_pairs, d_out);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int r = 0; r < 3; ++r) hipLaunchKernelGGL((gather_kernel<512, INFLIGHT>), dim3(blocks), dim3(256), 0, 0, d_table, d_ids, n_pairs, d_out);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 3;
+    printf("{\"sweep\": \"inflight\", \"workgroups_per_cu\": %d, \"loads_per_lane\": %d, \"kb_in_flight_per_cu\": %d, \"ms\": %.3f, \"gathered_gb_per_s\": %.1f}\n",
+           wgs, INFLIGHT, wgs * 4 * INFLIGHT, ms, (double)n_pairs * 512 / (ms * 1e-3) / 1e9);
+    fflush(stdout);
+}
+
+void sweep(int64_t n_pairs)
+{
+    int32_t* d_ids; float* d_out; float* d_table;
+    hipMalloc(&d_table, 512ll << 20); hipMemset(d_table, 0, 512ll << 20);
+    hipMalloc(&d_ids, n_pairs * 4);
+    hipMalloc(&d_out, (size_t)256 * 16 * 4 * 4);
+    std::vector<int32_t> ids(n_pairs);
+    for (int64_t i = 0; i < n_pairs; ++i) ids[i] = (int32_t)(xorshift() % (uint64_t)(1 << 20));
+    hipMemcpy(d_ids, ids.data(), n_pairs * 4, hipMemcpyHostToDevice);
+    for (int wgs : {1, 2, 4, 8, 16}) {
+        sweep_one<2>(d_table, d_ids, n_pairs, d_out, wgs);
+        sweep_one<4>(d_table, d_ids, n_pairs, d_out, wgs);
+        sweep_one<8>(d_table, d_ids, n_pairs, d_out, wgs);
+        sweep_one<16>(d_table, d_ids, n_pairs, d_out, wgs);
+    }
+}
 
 template <int ROW_BYTES>
 void run(int64_t n_pairs)
@@ -81,7 +116,8 @@ int main(int argc, char** argv)
 {
     const int row_bytes = argc > 1 ? atoi(argv[1]) : 512;
     const int64_t n_pairs = argc > 2 ? atoll(argv[2]) : 60000000ll;
-    if (row_bytes == 512) run<512>(n_pairs);
+    if (row_bytes == 0) sweep(n_pairs);
+    else if (row_bytes == 512) run<512>(n_pairs);
     else if (row_bytes == 1024) run<1024>(n_pairs);
     else { fprintf(stderr, "row_bytes must be 512 or 1024\n"); return 2; }
     return 0;

@@ -480,6 +480,11 @@ __global__ __launch_bounds__(1024) void seg_lds_fill_kernel(const int32_t* __res
 extern "C" int32_t trec_group_pairs_lds_runs(int64_t n_pairs, int64_t n_items)
 {
     if (n_items < 1 || n_items > SEG_LDS_MAX || n_pairs < ((int64_t)1 << 22)) return 0;
+    // the counters of every bucket live in ONE workgroup's LDS: a device with less of it than the buckets need (a build for an
+    // architecture with 64 KB) takes the global-atomic path instead of failing at launch
+    int dev = 0, lds_max = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || n_items * 4 > lds_max) return 0;
     // one run per workgroup and CU.  (Measured on configs[4], 3.7e8 pairs over 26,744 buckets: 1,024 runs 21.4 ms, 256 runs
     // 22.6 ms -- the placement is bound by its 7.4e8 scattered 4-byte stores (PMC: 23 GB written for 3 GB of payload), which a
     // run's ~54 consecutive slots per bucket do not change: the slots of a cache line are written by different threads far apart
@@ -506,11 +511,15 @@ extern "C" int trec_group_pairs_by_item_lds(const int32_t* xu, const int32_t* xi
     hipStream_t st = (hipStream_t)stream;
     const int64_t run_len = ceil_div64(n_pairs, n_runs);
     const int lds = (int)n_items * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)seg_lds_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SEG_LDS_MAX * 4);
-        (void)hipFuncSetAttribute((const void*)seg_lds_fill_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SEG_LDS_MAX * 4);
-        attr_set = true;
+    // the dynamic-LDS limit is a per-DEVICE attribute of the function: set once per device id, and checked
+    static bool attr_set[64] = {};
+    int dev = 0;
+    TREC_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64, "trec_group_pairs_by_item_lds: no current device");
+    if (!attr_set[dev]) {
+        const hipError_t e1 = hipFuncSetAttribute((const void*)seg_lds_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        const hipError_t e2 = hipFuncSetAttribute((const void*)seg_lds_fill_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        TREC_REQUIRE(e1 == hipSuccess && e2 == hipSuccess, "trec_group_pairs_by_item_lds: the device refused the dynamic LDS size");
+        attr_set[dev] = lds >= SEG_LDS_MAX * 4;          // (a smaller request is repeated until the largest one has been granted)
     }
     int32_t* counts = workspace_i32;
     const int n_blocks = (int)ceil_div64(n_items, 1024);

@@ -1270,19 +1270,30 @@ CASCADE_DENSE_USER_LIMIT = 16    # of 32 sampled superblocks kept (Gaussian rows
 CASCADE_MIN_ITEMS = 262144       # below ~512 superblocks the k-th largest maximum is not selective enough for int8 to pay
 
 
-def topk_user_batch(n_users, n_items, n_components, device, fraction=0.6):
+TOPK_USER_BATCH_MAX = 4_194_304     # users per pass at most, whatever the free memory says (int32 offsets inside the kernels' tables)
+
+
+def topk_user_batch(n_users, n_items, n_components, device, fraction=0.6, route="cascade", k=10):
     """Users per pass of predict_top_k when the caller names no batch size: what ``fraction`` of the FREE device memory holds.
-    Per user the exact top-k's cascade keeps a column of the superblock-maxima table (4 B per superblock), half a column of
-    user-list slots (CASCADE_ROW_CAPACITY x 4 B), the operands three times over (fp32 + bf16 + int8), ~1 KB of chunk lists and
-    CASCADE_CANDIDATES x 8 B of candidate slots; 30 % on top for the allocator.  Never below 65,536 (the old fixed default)."""
+    ``route`` "cascade" (the exact top-k through the int8 / bf16 filters): per user a column of the superblock-maxima table (4 B
+    per superblock), half a column of user-list slots (CASCADE_ROW_CAPACITY x 4 B), the operands three times over (fp32 + bf16 +
+    int8), ~1 KB of chunk lists and CASCADE_CANDIDATES x 8 B of candidate slots.  Any other route (score_topk_two_stage: bf16
+    precision, Euclidean with k > 12 or several tastes, the filters switched off): the table column, the operand once, the
+    gathered operand of the k selected superblocks (k x kpad x 4 B) and the stage-2 lists (2 k parts x capacity x 8 B, twice) --
+    12-20 KB per user at k = 16.  30 % on top for the allocator.  Never below 65,536 (the old fixed default) and
+    never above TOPK_USER_BATCH_MAX."""
     n_sb = (int(n_items) + SUPERBLOCK_ROWS - 1) // SUPERBLOCK_ROWS
     kpad = max(32, (int(n_components) + 31) // 32 * 32)
-    per_user = 1.3 * (n_sb * (4 + 4 * CASCADE_ROW_CAPACITY) + 8 * kpad + 1024 + 8 * CASCADE_CANDIDATES + 256)
+    if route == "cascade":
+        per_user = 1.3 * (n_sb * (4 + 4 * CASCADE_ROW_CAPACITY) + 8 * kpad + 1024 + 8 * CASCADE_CANDIDATES + 256)
+    else:
+        cap = int(N.query("trec_score_topk_capacity", int(k)))
+        per_user = 1.3 * (n_sb * 4 + 6 * kpad + int(k) * kpad * 4 + 2 * (2 * int(k)) * cap * 8 + 1024)
     try:
         free, _total = torch.cuda.mem_get_info(device)
     except Exception:                                   # pragma: no cover
         free = 16 << 30
-    return int(max(65536, min(int(n_users), fraction * free / per_user)))
+    return int(max(65536, min(int(n_users), TOPK_USER_BATCH_MAX, fraction * free / per_user)))
 
 
 def cascade_prefilter_for(n_components, n_items_total):

@@ -43,6 +43,7 @@ from .sparse import SparseFeatures, Interactions, PairIndex
 from .util import calculate_batched_alpha, sample_items
 
 ADAM_BETA1, ADAM_BETA2, ADAM_EPSILON = 0.9, 0.999, 1e-8      # tf.train.AdamOptimizer defaults [external]
+PREDICT_CACHE_MAX_NNZ = 200_000_000     # non-zeros of feature matrices the predict* calls keep uploaded (~4 GB of device memory)
 
 
 class DeviceSampler(object):
@@ -557,15 +558,30 @@ class TensorRec(object):
             self._dp_batches = dev_batches
             for var in self._store.variables.values():
                 var._trec_feats = None
+            # A previous call with dp_sync_every_call=False left rows with their owners.  They stay there while every rank's
+            # feature matrices span the same columns as in that call: the owner's rows are current on the owner, which is all a
+            # step reads of a rank-disjoint table.  Any rank whose ranges moved (it may now read rows another rank stepped) makes
+            # ALL ranks sync first -- one 4-byte all-reduce decides, so that the ranks agree on the collective.
+            from . import sharding
+            ranges = tuple((b[1].col_range, b[2].col_range) for b in dev_batches)
             if getattr(self, "_dp_stale_rows", False):
-                self.dp_sync()                          # (a previous call left rows to their owners: start from equal weights)
+                moved = int(ranges != getattr(self, "_dp_last_ranges", None))
+                if sharding.all_reduce_scalar(moved, device, self.process_group) > 0:
+                    self.dp_sync()
+            self._dp_last_ranges = ranges
             self._dp_prev_plan, self._dp_plan = getattr(self, "_dp_plan", None), None
-        with ops.deterministic_grouping(bool(getattr(self, "deterministic", False))):
-            self._run_epochs(epochs, dev_batches, graphed, learning_rate, alpha, batched_alpha, n_sampled_items, verbose)
-        if dp:
-            self._dp_batches = None
-            if getattr(self, "dp_sync_every_call", True):
-                self.dp_sync()
+        try:
+            with ops.deterministic_grouping(bool(getattr(self, "deterministic", False))):
+                self._run_epochs(epochs, dev_batches, graphed, learning_rate, alpha, batched_alpha, n_sampled_items, verbose)
+        finally:
+            if dp:
+                self._dp_batches = None
+                if self._dp_plan is None:
+                    # no optimiser step was made (epochs=0, no batches, an exception before step 1): the previous plan still
+                    # describes who owns the stale rows / slots
+                    self._dp_plan, self._dp_prev_plan = self._dp_prev_plan, None
+        if dp and getattr(self, "dp_sync_every_call", True):
+            self.dp_sync()
 
     def _run_epochs(self, epochs, dev_batches, graphed, learning_rate, alpha, batched_alpha, n_sampled_items, verbose):
         for epoch in range(epochs):
@@ -825,7 +841,8 @@ class TensorRec(object):
                 plan = sharding.plan_gradient_exchange(store.order, shapes, supports, store.device, self.process_group)
         # Adam slots left with their owners under ANOTHER ownership: bring them together (under the old plan) first
         prev = getattr(self, "_dp_prev_plan", None)
-        if prev is not None and prev.key != plan.key and getattr(self, "_dp_stale_slots", False):
+        if prev is not None and prev.key != plan.key and (getattr(self, "_dp_stale_slots", False) or
+                                                          getattr(self, "_dp_stale_rows", False)):
             self._dp_plan = prev
             self.dp_sync(optimizer_state=True)
         self._dp_prev_plan = None
@@ -931,8 +948,13 @@ class TensorRec(object):
         end unless ``dp_sync_every_call=False``; ``save_model`` needs ``dp_sync(optimizer_state=True)`` first."""
         from . import sharding
         plan = getattr(self, "_dp_plan", None)
-        if plan is None or not sharding.active(self.process_group):
+        if not sharding.active(self.process_group):
             self._dp_stale_rows = self._dp_stale_slots = False
+            return
+        if plan is None:
+            if self._dp_stale_rows or self._dp_stale_slots:
+                raise RuntimeError("dp_sync: rows / Adam slots are with their owners but the exchange plan that says who owns "
+                                   "them is gone (a model copied or unpickled between a fit call and its dp_sync?)")
             return
         store = self._store
         for name in store.order:
@@ -949,6 +971,12 @@ class TensorRec(object):
             self._dp_stale_slots = False
 
     # ------------------------------------------------------------------------------------------ predict
+    def clear_predict_cache(self):
+        """Drop the device copies of the feature matrices the predict* calls keep between calls (at most four matrices and
+        PREDICT_CACHE_MAX_NNZ non-zeros, ~4 GB; kept across fit calls on purpose: the reference's idiom is
+        ``for epoch: fit_partial(epochs=1); evaluate``)."""
+        self.__dict__['_predict_cache'] = {}
+
     def _check_fit(self, method):
         if self._store is None:
             raise ModelNotFitException(method=method)
@@ -971,9 +999,13 @@ class TensorRec(object):
             obj = cache.pop(key, None)
             if obj is None:
                 obj = SparseFeatures(m, device)
-            cache[key] = obj                              # most recently used last; at most four matrices stay resident
-            while len(cache) > 4:
+            cache[key] = obj                              # most recently used last
+            # at most four matrices and PREDICT_CACHE_MAX_NNZ non-zeros stay resident (device CSR arrays + cached transposes:
+            # ~20 B per non-zero); a matrix beyond the budget on its own is used for this call and not kept
+            while len(cache) > 4 or (len(cache) > 1 and sum(f.nnz for f in cache.values()) > PREDICT_CACHE_MAX_NNZ):
                 cache.pop(next(iter(cache)))
+            if obj.nnz > PREDICT_CACHE_MAX_NNZ:
+                cache.pop(key, None)
             return obj
         return one(user_features), one(item_features)
 
@@ -1138,7 +1170,9 @@ class TensorRec(object):
         prefilter = ops.cascade_prefilter_for(self.n_components, n_items_min * (dist.get_world_size(self.process_group) if sharded else 1)) \
             if filtered else None
         if user_batch_size is None:
-            user_batch_size = ops.topk_user_batch(uf.shape[0], itf.shape[0], self.n_components, self._store.device)
+            route = "cascade" if (filtered or euclid_filtered) else "two_stage"
+            user_batch_size = ops.topk_user_batch(uf.shape[0], itf.shape[0], self.n_components, self._store.device,
+                                                  route=route, k=k)
             if sharded:                  # every rank walks the SAME user batches (each batch holds collectives): the smallest wins
                 ubs = torch.tensor([user_batch_size], dtype=torch.int64, device=self._store.device)
                 dist.all_reduce(ubs, op=dist.ReduceOp.MIN, group=self.process_group)
@@ -1181,42 +1215,66 @@ class TensorRec(object):
                 i_f = ops.score_prep_filter(item_repr, normalize=graph.engine_normalize, bias=ib, want_gstats=True)
             else:
                 i_op, i_sq, kpad = ops.score_prep(item_repr, dtype, normalize=graph.engine_normalize, want_sqnorm=want_sq)
-            for s in range(0, uf.shape[0], user_batch_size):
+            s = 0
+            while s < uf.shape[0]:
                 e = min(s + user_batch_size, uf.shape[0])
-                ub = user_bias[s:e].contiguous() if self.biased else None
-                per_taste = []
-                for user_repr in user_reprs:
-                    if euclid_filtered:
-                        per_taste.append(ops.score_topk_euclid_filtered(user_repr[s:e], item_repr, k, ub, ib,
-                                                                        item_index_base=int(item_offset)))
-                        continue
-                    if filtered:
-                        u_f = ops.score_prep_filter(user_repr[s:e], normalize=graph.engine_normalize,
-                                                    sort_users=prefilter == "int8", k=k, user_bias=ub)
-                        # (item shards of >= 4 ranks: a user lists ~27 / world candidates per shard -> four users per wave)
-                        lanes = 16 if sharded and dist.get_world_size(self.process_group) >= 4 else 0
-                        per_taste.append(ops.score_topk_filtered(u_f, i_f, k, ub, ib, item_index_base=int(item_offset),
-                                                                 floor_exchange=floor_exchange,
-                                                                 stats_exchange=stats_exchange, prefilter=prefilter,
-                                                                 finish_lanes=lanes))
-                        continue
-                    u_op, u_sq, _ = ops.score_prep(user_repr[s:e], dtype, normalize=graph.engine_normalize,
-                                                   want_sqnorm=want_sq)
-                    per_taste.append(ops.score_topk(u_op, i_op, dtype, kpad, k, ub, ib, graph.engine_mode, u_sq, i_sq,
-                                                    item_index_base=int(item_offset), method=method,
-                                                    floor_exchange=floor_exchange))
-                v, i = per_taste[0] if len(per_taste) == 1 else _merge_taste_topk(per_taste, k)
-                if sharded:
-                    if sharding.a2a_available(v, self.process_group):
-                        v, i = sharding.sharded_top_k_a2a(v, i, k, self.process_group, replicate=True)
-                    else:
-                        v, i = sharding.sharded_top_k(v, i, k, self.process_group)
+                try:
+                    v, i = self._topk_user_batch(s, e, user_reprs, item_repr, user_bias, ib, k, graph, dtype, want_sq, filtered,
+                                                 euclid_filtered, prefilter, sharded, method, floor_exchange, stats_exchange,
+                                                 item_offset, i_f if filtered else None,
+                                                 None if filtered else (i_op, i_sq, kpad))
+                except torch.cuda.OutOfMemoryError:
+                    # the workspace model of ops.topk_user_batch was too optimistic for this device's state: half the users per
+                    # pass (item shards: the ranks walk the same batches and a rank cannot shrink alone -- the error stands)
+                    if sharded or user_batch_size <= 4096:
+                        raise
+                    torch.cuda.empty_cache()
+                    user_batch_size = max(4096, user_batch_size // 2)
+                    continue
                 vals.append(v)
                 idx.append(i)
+                s = e
         vals, idx = torch.cat(vals), torch.cat(idx)
         if return_device:
             return vals, idx
         return _to_host(vals), _to_host(idx)
+
+    def _topk_user_batch(self, s, e, user_reprs, item_repr, user_bias, ib, k, graph, dtype, want_sq, filtered, euclid_filtered,
+                         prefilter, sharded, method, floor_exchange, stats_exchange, item_offset, i_f, i_ops):
+        """Users [s, e) of predict_top_k: every taste's exact top-k, merged, and (item shards) exchanged."""
+        from . import sharding
+        import torch.distributed as dist
+        ub = user_bias[s:e].contiguous() if self.biased else None
+        if i_ops is not None:
+            i_op, i_sq, kpad = i_ops
+        per_taste = []
+        for user_repr in user_reprs:
+            if euclid_filtered:
+                per_taste.append(ops.score_topk_euclid_filtered(user_repr[s:e], item_repr, k, ub, ib,
+                                                                item_index_base=int(item_offset)))
+                continue
+            if filtered:
+                u_f = ops.score_prep_filter(user_repr[s:e], normalize=graph.engine_normalize,
+                                            sort_users=prefilter == "int8", k=k, user_bias=ub)
+                # (item shards of >= 4 ranks: a user lists ~27 / world candidates per shard -> four users per wave)
+                lanes = 16 if sharded and dist.get_world_size(self.process_group) >= 4 else 0
+                per_taste.append(ops.score_topk_filtered(u_f, i_f, k, ub, ib, item_index_base=int(item_offset),
+                                                         floor_exchange=floor_exchange,
+                                                         stats_exchange=stats_exchange, prefilter=prefilter,
+                                                         finish_lanes=lanes))
+                continue
+            u_op, u_sq, _ = ops.score_prep(user_repr[s:e], dtype, normalize=graph.engine_normalize,
+                                           want_sqnorm=want_sq)
+            per_taste.append(ops.score_topk(u_op, i_op, dtype, kpad, k, ub, ib, graph.engine_mode, u_sq, i_sq,
+                                            item_index_base=int(item_offset), method=method,
+                                            floor_exchange=floor_exchange))
+        v, i = per_taste[0] if len(per_taste) == 1 else _merge_taste_topk(per_taste, k)
+        if sharded:
+            if sharding.a2a_available(v, self.process_group):
+                v, i = sharding.sharded_top_k_a2a(v, i, k, self.process_group, replicate=True)
+            else:
+                v, i = sharding.sharded_top_k(v, i, k, self.process_group)
+        return v, i
 
     @_on_model_device
     def predict_similar_items(self, item_features, item_ids, n_similar):
@@ -1310,11 +1368,19 @@ class TensorRec(object):
         if reset_optimizer:
             self._adam = {}
             self._opt_step = 0
+            self._dp_stale_slots = False            # (there are no slots left to bring together)
+        # every rank sets the same weights (the caller's contract under data_parallel): nothing waits for an owner any more
+        if set(weights.keys()) >= set(self._store.order):
+            self._dp_stale_rows = False
 
     # ------------------------------------------------------------------------------------------ persistence
     def __getstate__(self):
         """The python object without device state (the role of ``_break_graph_hooks``, tensorrec.py:247-257): weights
         and optimiser slots travel in the checkpoint file next to the pickle."""
+        if getattr(self, "_dp_stale_rows", False) or getattr(self, "_dp_stale_slots", False):
+            # (pickle / deepcopy bypass save_model's check: a copy made now would hold rows only their owners have current)
+            raise RuntimeError("data-parallel fit left rows / Adam slots with their owners: call dp_sync(optimizer_state=True) "
+                               "on every rank before pickling or copying the model")
         state = dict(self.__dict__)
         state['_store'] = None
         state['_adam'] = {}
@@ -1327,6 +1393,7 @@ class TensorRec(object):
         state['_dp_plan'] = None
         state['_dp_prev_plan'] = None
         state['_dp_batches'] = None
+        state['_dp_last_ranges'] = None
         state['process_group'] = None
         return state
 
