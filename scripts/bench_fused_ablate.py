@@ -18,18 +18,25 @@ u = torch.randn((U, d), device="cuda") * 0.1; v = torch.randn((I, d), device="cu
 ub = torch.zeros(U, device="cuda"); ib = torch.zeros(I, device="cuda")
 samples = ops.sample_items(U, I, S, False, 0, 1)
 out = {}
-for name, ab in (("full", 0), ("no histogram atomics", 1), ("no loss phases", 2), ("no dU", 4), ("gathers + dots only", 7)):
+modes = (("full", 0), ("no histogram atomics", 1), ("no loss phases", 2), ("no dU", 4), ("gathers + dots only", 7))
+if os.environ.get("ONLY_FULL"):           # A/B of library builds (TREC_HIP_LIB): the shipped kernel's time and a checksum of its outputs
+    modes = modes[:1]
+for name, ab in modes:
     N.set_tuning("wmrb_ablate", ab)
     ts = []
     for it in range(4):
         torch.cuda.synchronize()
         s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ops.KERNEL_EVENTS = []
-        ops.wmrb_fused_step(u, v, ub, ib, inter, samples)
+        res = ops.wmrb_fused_step(u, v, ub, ib, inter, samples)
         torch.cuda.synchronize()
         ev, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
         ts.append([e0.elapsed_time(e1) for n, e0, e1 in ev if n == "wmrb_fused_step"][0])
     out[name] = round(float(np.mean(ts[1:])), 3)
     print(name, out[name], "ms", flush=True)
 N.set_tuning("wmrb_ablate", 0)
+if os.environ.get("ONLY_FULL"):
+    import hashlib
+    out["checksum"] = hashlib.sha1(b"".join(t.detach().cpu().numpy().tobytes() for t in res[:3])).hexdigest()[:16]
+    print("library", os.environ.get("TREC_HIP_LIB", "default"), "full", out["full"], "ms  checksum", out["checksum"], flush=True)
 json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "fused_ablate.json"), "w"), indent=1)

@@ -42,6 +42,15 @@ __device__ __forceinline__ float dpp_add(float x, const int ctrl_tag)
 
 constexpr int SR = 4;                 // sample registers per lane in the loss phase: S <= 256
 
+// A/B switches of the gather (variant libraries: -DTREC_WMRB_NT / -DTREC_WMRB_NO_EARLY).  Non-temporal row loads were MEASURED
+// slower (13.5 ms against 11.4 for the whole kernel at 1M x 1M, profiles/r05_wmrb_fused_ab.txt): the rows are read once per pair,
+// but `nt` loads of 16 B per lane did not stream past the L2 any cheaper -- plain loads stay the default.
+#ifdef TREC_WMRB_NT
+#define TREC_ROW_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define TREC_ROW_LOAD(p) (*(p))
+#endif
+
 // The ablation switches of scripts/bench_fused_ablate.py (histogram atomics / loss phases / dU off: WRONG results, only the
 // time is read) exist only in a build with -DTREC_WMRB_ABLATE; the shipped kernel has none of the branches and no tuning
 // lookup per launch (a knob left set would train wrong gradients silently).
@@ -52,7 +61,9 @@ constexpr int SR = 4;                 // sample registers per lane in the loss p
 #endif
 
 // ITERS: float4 chunks per lane of a 32-lane subgroup (d <= 128 * ITERS); RMAX: item rows a subgroup holds
-template <int ITERS, int RMAX>
+// SURE: the first SURE register rows of every subgroup are sampled items for certain (8 * SURE <= S): their gathers leave as soon
+// as the sample ids are there, without waiting for the indptr -> interaction-id chain the rows past S hang on
+template <int ITERS, int RMAX, int SURE = 0>
 __global__ __launch_bounds__(256, (ITERS == 1 && RMAX == 16) ? 4 : 1) void wmrb_user_fused_kernel(
     const float* __restrict__ U, const float* __restrict__ V, const float* __restrict__ ub, const float* __restrict__ ib,
     const int64_t* __restrict__ indptr, const int32_t* __restrict__ xi, const int32_t* __restrict__ pos_slot,
@@ -118,22 +129,31 @@ __global__ __launch_bounds__(256, (ITERS == 1 && RMAX == 16) ? 4 : 1) void wmrb_
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
         const int c = (it * 32 + sub) * 4;
-        const f32x4 v = *(const f32x4*)(U + u * d + (c < d ? c : 0));
+        const f32x4 v = TREC_ROW_LOAD((const f32x4*)(U + u * d + (c < d ? c : 0)));
         x[it] = (c < d) ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     const float bu = ub ? ub[u] : 0.f;
 
     // ---- (b) every subgroup gathers its rows j = sg + 8 r (r < RMAX) in ONE batch and keeps them ----
     f32x4 y[RMAX][ITERS];
+    // the rows that are samples for certain first: their addresses need nothing but the sample ids
+#pragma unroll
+    for (int r = 0; r < SURE; ++r) {
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int c = (it * 32 + sub) * 4;
+            y[r][it] = TREC_ROW_LOAD((const f32x4*)(V + (int64_t)item[r] * d + (c < d ? c : 0)));
+        }
+    }
     {
         int32_t xid[RMAX];                               // the interaction item of row j >= S (n_pos >= 1 here)
 #pragma unroll
-        for (int r = 0; r < RMAX; ++r) {
+        for (int r = SURE; r < RMAX; ++r) {
             const int q = sg + 8 * r - S;
             xid[r] = xi[b + (q < 0 ? 0 : (q < n_pos ? q : n_pos - 1))];
         }
 #pragma unroll
-        for (int r = 0; r < RMAX; ++r) {
+        for (int r = SURE; r < RMAX; ++r) {
             const int j = sg + 8 * r;
             item[r] = (j < S) ? item[r] : ((j < R) ? xid[r] : 0);
         }
@@ -144,14 +164,16 @@ __global__ __launch_bounds__(256, (ITERS == 1 && RMAX == 16) ? 4 : 1) void wmrb_
     constexpr int H = RMAX / 16;
     const int own = sub - 16;
     float my_bi[H];
-    int32_t my_item[H];                                  // the item of the owned row (its own two loads: no 16-way select)
+    int32_t my_item[H];                                  // the item of the owned row: picked from the ids every lane holds
+    // (16 v_cndmask per owned row instead of two more loads: written as loads -- samples / xi again at the owner's index -- the
+    // compiler sank the xi one into an exec-masked block ending in s_waitcnt vmcnt(0), one more dependent round trip in front of
+    // the bias load and, with the early rows above, a wait for ALL of them before the last rows could leave)
 #pragma unroll
     for (int h = 0; h < H; ++h) {
-        const int j = sg + 8 * ((own < 0 ? 0 : own) + 16 * h);
-        const int q = j - S;
-        const int32_t a = samples[u * S + (j < S ? j : S - 1)];
-        const int32_t c2 = xi[b + (q < 0 ? 0 : (q < n_pos ? q : n_pos - 1))];
-        my_item[h] = (j < S) ? a : ((j < R) ? c2 : 0);
+        int32_t mine = 0;
+#pragma unroll
+        for (int r16 = 0; r16 < 16; ++r16) mine = (own == r16) ? item[r16 + 16 * h] : mine;
+        my_item[h] = mine;                               // (rows past R hold item 0: a valid address, never used unguarded)
     }
 #pragma unroll
     for (int h = 0; h < H; ++h) {
@@ -160,11 +182,11 @@ __global__ __launch_bounds__(256, (ITERS == 1 && RMAX == 16) ? 4 : 1) void wmrb_
         my_bi[h] = (own >= 0 && j < R) ? v : 0.f;
     }
 #pragma unroll
-    for (int r = 0; r < RMAX; ++r) {
+    for (int r = SURE; r < RMAX; ++r) {
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
             const int c = (it * 32 + sub) * 4;
-            y[r][it] = *(const f32x4*)(V + (int64_t)item[r] * d + (c < d ? c : 0));
+            y[r][it] = TREC_ROW_LOAD((const f32x4*)(V + (int64_t)item[r] * d + (c < d ? c : 0)));
         }
     }
     if (d < ITERS * 128) {                               // (uniform: columns past d contribute zeros)
@@ -365,13 +387,27 @@ extern "C" int trec_wmrb_fused_step(const float* U, const float* V, const float*
 #else
     const int ablate = 0;
 #endif
-#define TREC_FUSED(IT, RM)                                                                                             \
-    hipLaunchKernelGGL((wmrb_user_fused_kernel<IT, RM>), dim3((unsigned)n_users), dim3(256), lds, st, U, V, user_bias,  \
+#define TREC_FUSED(IT, RM, SU)                                                                                             \
+    hipLaunchKernelGGL((wmrb_user_fused_kernel<IT, RM, SU>), dim3((unsigned)n_users), dim3(256), lds, st, U, V, user_bias,  \
                        item_bias, indptr, x_item, pos_slot, pos_weight, samples, n_users, n_sampled, d, ratio, max_rows, \
                        loss, pred_serial, dU, d_user_bias, coef_samples, coef_pairs, sample_hist, sample_rank, ablate)
-    if (d <= 128 && max_rows <= 128) TREC_FUSED(1, 16);
-    else if (d <= 128) TREC_FUSED(1, 32);
-    else TREC_FUSED(2, 16);
+#ifdef TREC_WMRB_NO_EARLY
+    const int sure = 0;
+#else
+    const int sure = n_sampled / 8;                      // register rows r < sure hold samples in every subgroup (8 r + 7 < S)
+#endif
+    if (d <= 128 && max_rows <= 128) {
+        if (sure >= 12) TREC_FUSED(1, 16, 12);
+        else if (sure >= 8) TREC_FUSED(1, 16, 8);
+        else if (sure >= 4) TREC_FUSED(1, 16, 4);
+        else TREC_FUSED(1, 16, 0);
+    } else if (d <= 128) {
+        if (sure >= 16) TREC_FUSED(1, 32, 16);
+        else TREC_FUSED(1, 32, 0);
+    } else {
+        if (sure >= 8) TREC_FUSED(2, 16, 8);
+        else TREC_FUSED(2, 16, 0);
+    }
 #undef TREC_FUSED
     return trec_check_launch("trec_wmrb_fused_step");
 }

@@ -731,6 +731,7 @@ def wmrb_fused_step(user_in, item_in, user_bias, item_bias, interactions, sample
     coef_p = torch.empty((nnz,), dtype=torch.float32, device=dev)
     weight = interactions.balanced_weight() if balanced else None
     samples = samples.to(torch.int32).contiguous()
+    xs = samples.reshape(-1)
     ws32 = torch.zeros((2 * n_items,), dtype=torch.int32, device=dev)     # [sample histogram | cursors] of the sort below
     ranks = torch.empty((n_users, S), dtype=torch.int32, device=dev)
     with _timed("wmrb_fused_step"):
@@ -739,6 +740,10 @@ def wmrb_fused_step(user_in, item_in, user_bias, item_bias, interactions, sample
                n_items, S, d, int(interactions.max_row_nnz), N.ptr(loss), N.ptr(pred), N.ptr(d_u), N.ptr(d_ub),
                N.ptr(coef_s), N.ptr(coef_p), N.ptr(ws32), N.ptr(ranks))
     # ---- item side: d item_in = G^T . user_in over both pair lists, d b_i = per-item sums of the coefficients
+    # (MEASURED and dropped, profiles/r05_fit_overlap_ab.txt: the sort on a second stream -- whole, next to the fused kernel with
+    # the coefficients read through the pair permutation: 34.4 ms per epoch against 25.7; only its fill, next to the item-side
+    # gather of the interactions: 26.2 against 26.1 -- every kernel of this step is bound by the same fabric, an overlapped pair
+    # slows down by exactly what it hides)
     d_v = torch.zeros_like(v) if nnz == 0 else None
     d_ib = torch.zeros((n_items,), dtype=torch.float32, device=dev) if ib is not None else None
     # (epilogue 3 of K1: the row sums of the gathered coefficients = d b_i come out of the same pass)
@@ -750,7 +755,16 @@ def wmrb_fused_step(user_in, item_in, user_bias, item_bias, interactions, sample
             d_v = spmm_split(indptr_t, users_t, coef_p, perm_t, n_items, nnz, u, want_rowsum=rowsum)
         else:
             d_v = _spmm_rowsum(indptr_t, users_t, coef_p, perm_t, n_items, nnz, u, epi, False, None, d_ib)
-    xs = samples.reshape(-1)
+    ind_s, entries, _ = group_pairs_by_item(None, xs, S, n_items, workspace_with_counts=ws32, ranks=ranks.reshape(-1),
+                                            values=coef_s.reshape(-1))
+    if xs.numel() > n_items * _SPLIT_MEAN:               # few items: every bucket of samples is long
+        spmm_split(ind_s, None, None, None, n_items, xs.numel(), u, accumulate=True, out=d_v, want_rowsum=rowsum,
+                   packed=entries)
+    else:
+        with _timed("spmm_csr"):
+            N.call("trec_spmm_csr_packed", N.ptr(ind_s), N.ptr(entries), n_items, N.ptr(u), d, epi, 1, N.ptr(d_v),
+                   N.ptr(rowsum))
+    return loss, pred, d_u, d_v, d_ub, d_ib
     ind_s, entries, _ = group_pairs_by_item(None, xs, S, n_items, workspace_with_counts=ws32, ranks=ranks.reshape(-1),
                                             values=coef_s.reshape(-1))
     if xs.numel() > n_items * _SPLIT_MEAN:               # few items: every bucket of samples is long
