@@ -32,6 +32,7 @@ BF16_DENSE_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MF
 INT8_DENSE_PEAK_TOPS = 5000.0       # MI355X_MICROARCH.md: I8 MFMA "~2x bf16 rate" (no spec row; its ubench ceiling is >= 3944 TOPS)
 FP32_MFMA_PEAK_TFLOPS = 157.3
 HBM_PEAK_GBS = 8000.0
+GATHER_CEILING_512MB_GBS = 7420.0    # measured: bare 512-byte row gathers from a 512 MB table (profiles/r05_gather_ceiling_512.jsonl)
 
 
 def parse():
@@ -275,10 +276,14 @@ def fit_epochs_per_sec(n_users, n_items, d, per_user=20, n_sampled=100, epochs=3
                         "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                         "traffic": None, "avg_launch_ms": ms, "launches": len(dur["wmrb_fused_step"]),
                         "algorithmic_bytes_per_launch": alg,
+                        "gather_ceiling": GATHER_CEILING_512MB_GBS, "frac_of_gather_ceiling": gbs / GATHER_CEILING_512MB_GBS,
                         "bound_note": "random 512-byte row gathers from a 512 MB item table: 16x the aggregate L2 (32 MB) "
                                       "and 2x the Infinity Cache, so the rows cross the memory-side fabric (TCC hit rate "
                                       "and FETCH_SIZE of this kernel: profiles/r*_fit_pmc_summary.txt); priced against "
-                                      "the HBM peak",
+                                      "the HBM peak.  gather_ceiling = what BARE 512-byte row gathers from a 512 MB table "
+                                      "deliver on this chip (scripts/probe/gather_ceiling.hip, profiles/r05_gather_ceiling_512.jsonl: "
+                                      "7.4 TB/s; 7.7 TB/s from a table resident in the Infinity Cache -- blocking the pairs for "
+                                      "the cache cannot pay, DESIGN 8)",
                         "other_kernels_avg_ms": {n: float(np.mean(v)) for n, v in dur.items() if n != "wmrb_fused_step"},
                         "other_kernels_launches_per_epoch": {n: len(v) / 2.0 for n, v in dur.items() if n != "wmrb_fused_step"}}
         if world == 1 and (n_users, n_items, d) == (1_000_000, 1_000_000, 128):

@@ -134,6 +134,7 @@ def compact_line(full, full_path=None):
         "fit_epochs_per_s": _num(_get(fit, "fit_epochs_per_sec")),
         "fit_ms_per_epoch": _num(1e3 * _get(fit, "sec_per_epoch"), 5) if _get(fit, "sec_per_epoch") else None,
         "roofline_fit_frac": _num(_get(full, "roofline_fit", "frac"), 4),
+        "roofline_fit_frac_of_gather_ceiling": _num(_get(full, "roofline_fit", "frac_of_gather_ceiling"), 4),
         "roofline_fit": _roofline(full.get("roofline_fit"), 48),
         "cpu_baseline_fit_value": _num(_get(full, "cpu_baseline_fit", "value")),
         "full_record": full_path,

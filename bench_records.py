@@ -17,6 +17,7 @@ import time
 import numpy as np
 import scipy.sparse as sp
 
+GATHER_CEILING_27MB_GBS = 8900.0      # measured: profiles/r05_gather_ceiling_1024.jsonl (1 KB rows, 27 MB table)
 HBM_PEAK_GBS = 8000.0
 BF16_DENSE_PEAK_TFLOPS = 2500.0
 FP32_MFMA_PEAK_TFLOPS = 157.3
@@ -280,12 +281,20 @@ def _one_step_parity(make_model, oracle, inter, uf, itf, table, lr, alpha, S, gr
     gmax = max(float(np.abs(g).max()) for g in grads.values() if g is not None)
     gerr = {k: float(np.abs(cap["grads"][k] - ref).max() / gmax) for k, ref in _rename(grads).items() if ref is not None}
     dl = np.abs(cap["loss"] - basic)
+    # north_star's bar: 1e-4 relative.  Scores and gradients are held to it outright (gradients relative to the largest gradient
+    # entry of the step).  A loss entry is log(1 + a hinge sum that may cancel to ~0): its relative error is ill-conditioned near
+    # zero, so the entries outside 1e-4 relative are reported with their size and held to 1e-4 of the largest loss ABSOLUTELY.
+    rel_ok = dl <= 1e-4 * np.abs(basic)
+    lmax = max(1e-30, float(np.abs(basic).max()))
     rec = {"pred_serial_max_rel_err": float(np.abs(cap["pred_serial"] - pred_serial).max() / max(1e-30, np.abs(pred_serial).max())),
-           "loss_share_within_1e-4": float((dl <= 1e-5 + 1e-4 * np.abs(basic)).mean()),
-           "loss_max_abs_err_over_max_loss": float(dl.max() / max(1e-30, np.abs(basic).max())),
+           "loss_share_within_1e-4": float(rel_ok.mean()),
+           "loss_max_abs_err_over_max_loss": float(dl.max() / lmax),
+           "loss_entries_outside_1e-4_rel": int((~rel_ok).sum()),
+           "loss_outside_max_value_over_max_loss": float(np.abs(basic[~rel_ok]).max() / lmax) if (~rel_ok).any() else 0.0,
+           "loss_outside_max_abs_err_over_max_loss": float(dl[~rel_ok].max() / lmax) if (~rel_ok).any() else 0.0,
            "raw_gradient_max_err_over_gmax": gerr, "gradient_bar": grad_tol}
     rec["green"] = bool(rec["pred_serial_max_rel_err"] <= 1e-4 and rec["loss_share_within_1e-4"] >= 0.999 and
-                        rec["loss_max_abs_err_over_max_loss"] <= 1e-3 and all(v <= grad_tol for v in gerr.values()))
+                        rec["loss_max_abs_err_over_max_loss"] <= 1e-4 and all(v <= grad_tol for v in gerr.values()))
     return rec
 
 
@@ -434,19 +443,24 @@ def config4_record(device, n_users=138_493, n_items=26_744, per_user=160, d=256,
            "sec_per_epoch": per_epoch, "fit_epochs_per_sec": 1.0 / per_epoch,
            "top_kernels_ms_per_epoch": {n: v["total_ms"] / (epochs + 1.0) for n, v in top},
            "roofline": {"kernel": "the pair kernels of one epoch together (score forward, WMRB, structured backward gathers)",
-                        "bound": "l2/mall gathers: the 27 MB item representation table lives in the 256 MB Infinity Cache, so the row "
-                                 "gathers never reach HBM; priced against the HBM peak for reference only",
-                        "achieved": alg / per_epoch / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / per_epoch / 1e9 / HBM_PEAK_GBS,
+                        "bound": "cache-resident row gathers: the 27 MB item representation table and the 142 MB user table live in "
+                                 "the L2 / the 256 MB Infinity Cache and never reach HBM.  Peak = the MEASURED ceiling of bare "
+                                 "uniformly random 1 KB row gathers from a 27 MB table (scripts/probe/gather_ceiling.hip, "
+                                 "profiles/r05_gather_ceiling_1024.jsonl: 8.9 TB/s; 7.75 TB/s from 110 MB, 7.5 TB/s from 512 MB)",
+                        "achieved": alg / per_epoch / 1e9, "peak": GATHER_CEILING_27MB_GBS, "unit": "GB/s",
+                        "frac": alg / per_epoch / 1e9 / GATHER_CEILING_27MB_GBS, "frac_of_hbm_peak": alg / per_epoch / 1e9 / HBM_PEAK_GBS,
                         "algorithmic_bytes_per_epoch": alg,
-                        "note": "whole-epoch rate: every pair's 1 KB item row forward and backward over the epoch time; the kernels "
-                                "named under top_kernels_ms_per_epoch are only those with HIP events around them"}}
+                        "note": "whole-epoch rate: every pair's 1 KB item row forward and backward over the epoch time (the sort of the "
+                                "3.7e8 sampled pairs, the WMRB kernels and the dense layers are inside that time).  The gathers "
+                                "themselves -- split_chunks_kernel, 4 launches of 3.7e8 rows each, ~25 ms -- run at ~15 TB/s, ABOVE "
+                                "the uniform-random ceiling: item popularity is Zipf, the hot rows are L2 hits (34.5 TB/s aggregate)"}}
     # parity: one replayed step of a user tile (same weight shapes) against oracle/model.py
     tile = np.arange(0, n_users, n_users // parity_users)[:parity_users]
     inter_t, uf_t = inter[tile], uf[tile]
     table = np.stack([rng.permutation(n_items)[:S] for _ in range(len(tile))]).astype(np.int64)
     oracle = OracleTensorRec(d, "relu", "relu", "euclidean", "wmrb", True)
     oracle.init_weights(uf.shape[1], itf.shape[1], np.random.default_rng(42))
-    rec["parity_one_step_vs_oracle"] = _one_step_parity(lambda tables: mk(tables), oracle, inter_t, uf_t, itf, table, 0.01, 1e-5, S, 2e-4)
+    rec["parity_one_step_vs_oracle"] = _one_step_parity(lambda tables: mk(tables), oracle, inter_t, uf_t, itf, table, 0.01, 1e-5, S, 1e-4)
     rec["parity_one_step_vs_oracle"]["tile"] = "%d users (every %d-th), all items, the full weight shapes" % (len(tile), n_users // parity_users)
     return rec
 
