@@ -1,25 +1,41 @@
 """
-Item sharding across the GPUs of one node (one process per GPU, torch.distributed; backend "nccl" is RCCL over xGMI).
+Sharding across the GPUs of one node (one process per GPU, torch.distributed; backend "nccl" is RCCL over xGMI).
 
 The reference has no multi-device code at all; this is the MI355X-native scaling path named by
-BASELINE.json's north_star: items (rows of the item feature matrix, hence of the item representation) are split
-row-wise, the user tile is replicated, and exactly ONE small collective finishes a query:
+BASELINE.json's north_star.
 
-  * top-k  : every rank runs the fused score+top-k kernel on its item shard with global item ids
-             (``item_index_base``), then an all-gather of the per-rank [U, k] lists (U*k*8 bytes per rank -- 5 MB
-             for 65,536 users, k = 10) and a local k-way merge (trec_topk_merge).  Every rank ends with the same,
-             exact, global top-k: the merge order (value desc, index asc) is a total order over disjoint item ids.
+PREDICT -- items (rows of the item feature matrix, hence of the item representation) are split row-wise, the user tile is
+replicated, and small per-user exchanges finish a query:
+
+  * top-k  : every rank runs the exact top-k pipeline on its item shard with global item ids (``item_index_base``).  Large
+             catalogues (the filtered / cascade routes) first agree on ONE top-k floor per user -- the k largest lower bounds of
+             every shard, exchanged and reduced (``shared_topk_floor*``) -- so that a shard re-scores only what can reach the
+             GLOBAL top-k; then the per-shard [U, k] lists are merged.  Both exchanges come in two forms: user-partitioned
+             ALL-TO-ALL (``*_a2a``, the default over RCCL: every rank receives 1/world of what an all-gather would deliver and
+             finalises ITS users; ``replicate=True`` adds an all-gather of the finished lists where every rank needs them) and
+             plain ALL-GATHER (backends without a device all-to-all: the gloo tests).  The merge order (value desc, index asc)
+             is a total order over disjoint item ids, so every form ends in the same, exact, global top-k.
   * ranks  : rank = 1 + count of items that beat the target (recommendation_graphs.py:73-82 is a count);
              counts over disjoint item ranges add, so an all-reduce(SUM) of int32 partial counts gives exact ranks.
 
-Training is data-parallel over USERS (the reference's own batching axis, tensorrec.py:199-217): each rank owns a slice of
-user rows (interactions + user features), items and all weights are replicated, and one step = local forward/backward +
-all-reduce(SUM) of the weight gradients + the identical fused Adam on every rank.  Because the WMRB objective is a sum
-over interactions, this equals ONE single-process step on the union batch (not the reference's sequential per-batch
-steps).  The device sampler is keyed by global user id, so shards draw what the whole population would.
+FIT -- data-parallel over USERS (the reference's own batching axis, tensorrec.py:199-217): each rank owns a slice of user rows
+(interactions + user features); the objective is a sum over interactions (a scalar loss all-reduces its sums inside the loss op,
+ops.scalar_loss_group), so one synchronous step equals ONE single-process step on the union batch (not the reference's sequential
+per-batch steps).  What crosses the wire is decided per weight table by ``plan_gradient_exchange``:
 
-No collective sits inside the score kernel; payloads are KBs-MBs against ~10 ms of MFMA work per 65k-user tile, so
-xGMI (7 point-to-point links x ~153 GB/s) is nowhere near a bound and a plain all-gather is the right primitive.
+  * "disjoint"   -- the table's gradient rows are touched by one rank only (identity / one-hot user features under user shards):
+                    NO exchange, the owner steps its rows (weights and Adam slots of other ranks' rows go stale on this replica
+                    until ``TensorRec.dp_sync``);
+  * "sharded"    -- large shared tables: reduce-scatter of the gradient by row range -> Adam on the owned rows -> all-gather of
+                    the updated rows (each Adam slot lives on ONE rank: 1/world of the optimiser traffic and 7/8 of an
+                    all-reduce's bytes at world 8);
+  * "replicated" -- small tensors: all-reduce(SUM) + the identical fused Adam on every rank.
+
+The device sampler is keyed by global user id, so shards draw what the whole population would.
+
+No collective sits inside a score kernel; payloads are KBs-MBs against ~10 ms of MFMA work per 65k-user tile, so xGMI (7
+point-to-point links x ~153 GB/s) is nowhere near a bound for predict; the fit's exchange (0.9 GB per rank and step at 1M x 1M,
+d = 128) is the part that is.
 """
 from __future__ import annotations
 

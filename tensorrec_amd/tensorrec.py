@@ -1122,9 +1122,11 @@ class TensorRec(object):
 
         ``item_sharded=True`` (torch.distributed initialised, one process per GPU): ``item_features`` holds THIS rank's
         rows of the item feature matrix, ``item_offset`` the global id of its first row, ``user_features`` is the same
-        on every rank.  Every rank scores its shard, the shards agree on a top-k floor (one all-gather of k superblock
-        maxima per user), and ONE all-gather of the per-shard lists + a local merge leaves the exact global top-k on
-        every rank (sharding.py)."""
+        on every rank.  Every rank scores its shard; large catalogues first agree on one top-k floor per user (the k largest
+        lower bounds of every shard), then the per-shard lists are merged -- both exchanges as user-partitioned all-to-alls
+        over RCCL (every rank finalises 1/world of the users, the finished lists are then all-gathered so that every rank
+        returns all of them), as plain all-gathers on backends without a device all-to-all (sharding.py).  Euclidean scores:
+        every rank certifies its own shard's first k (no floor exchange), then the same merge."""
         from . import sharding
         self._check_fit('predict_top_k')
         if not self._is_engine_graph():
@@ -1160,9 +1162,13 @@ class TensorRec(object):
                     ops.N.load().trec_get_tuning(b"topk_bf16_filter", 1) != 0)
         # Euclidean scores (one taste, fp32): the same cascade finds the 16 NEAREST items of every user -- nearest = largest
         # u.i - r_i / 2 -- the reference's chain re-scores them and a per-user certificate decides (ops.score_topk_euclid_filtered)
-        euclid_filtered = (dtype == ops.DTYPE_F32 and graph.engine_mode == ops.MODE_EUCLIDEAN and not sharded and
-                           1 <= k <= ops.EUCLID_CANDIDATES - 4 and itf.shape[0] >= ops.TWO_STAGE_MIN_ITEMS and
-                           self.n_components <= 256 and self.n_tastes == 1 and
+        # Item shards: every rank certifies ITS shard's first k on its own (the certificate is local: "no other item of this
+        # shard can enter these k places"), the exact per-shard lists merge like any others -- no shared floor, no collective
+        # inside the route, so the ranks need not agree on who falls back.  Several tastes: the same per taste, then the merge
+        # of the taste lists (max over tastes commutes with the monotone bias additions).
+        euclid_filtered = (dtype == ops.DTYPE_F32 and graph.engine_mode == ops.MODE_EUCLIDEAN and
+                           1 <= k <= ops.EUCLID_CANDIDATES - 4 and n_items_min >= ops.TWO_STAGE_MIN_ITEMS and
+                           self.n_components <= 256 and
                            ops.N.load().trec_get_tuning(b"topk_euclid_filter", 1) != 0)
         stats_exchange = (lambda g: sharding.all_reduce_max(g, self.process_group)) if sharded else None
         # ... and on a catalogue of >= 262,144 items an int8 MFMA pass (exact integer arithmetic, proven bound) first decides

@@ -191,24 +191,27 @@ def _initial(name):
 
 
 # ---- item-sharded predict_top_k through the public API (BASELINE.json configs[3] in miniature) ---------------------------
-def _topk_case(n_items, n_tastes, d=32):
+def _topk_case(n_items, n_tastes, d=32, graph="cosine"):
     import tensorrec_amd as T
     rng = np.random.RandomState(1)
     n_u = 150
     uf = sp.random(n_u, 30, density=0.2, random_state=rng, format="csr", dtype=np.float32)
     itf = sp.hstack([sp.identity(n_items, format="csr", dtype=np.float32),
                      sp.random(n_items, 5, density=0.3, random_state=rng, format="csr", dtype=np.float32)], format="csr")
-    model = T.TensorRec(n_components=d, n_tastes=n_tastes, seed=11,
-                        prediction_graph=T.prediction_graphs.CosineSimilarityPredictionGraph())
+    pg = T.prediction_graphs.EuclideanSimilarityPredictionGraph() if graph == "euclidean" else \
+        T.prediction_graphs.CosineSimilarityPredictionGraph()
+    model = T.TensorRec(n_components=d, n_tastes=n_tastes, seed=11, prediction_graph=pg)
     model.build(uf.shape[1], itf.shape[1])
     w = model.get_weights()
-    w["item_feature_biases"] = (0.05 * rng.standard_normal(w["item_feature_biases"].shape)).astype(np.float32)
+    # (Euclidean: item biases below the distance gaps, so that the per-user certificate holds for most users)
+    w["item_feature_biases"] = ((0.002 if graph == "euclidean" else 0.05) *
+                                rng.standard_normal(w["item_feature_biases"].shape)).astype(np.float32)
     w["user_feature_biases"] = (0.05 * rng.standard_normal(w["user_feature_biases"].shape)).astype(np.float32)
     model.set_weights(w)
     return model, uf, itf
 
 
-def _topk_worker(rank, world, port, n_items, n_tastes, ret, d=32):
+def _topk_worker(rank, world, port, n_items, n_tastes, ret, d=32, graph="cosine"):
     import torch.distributed as dist
     from tensorrec_amd import sharding
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -219,9 +222,12 @@ def _topk_worker(rank, world, port, n_items, n_tastes, ret, d=32):
             from tensorrec_amd import _native
             _native.set_tuning("filter_scan_one_pass", 2)
             _native.set_tuning("cascade_candidates", 0)         # (the table-driven tail; the default is the candidate lists)
-        model, uf, itf = _topk_case(n_items, n_tastes, d)
+        model, uf, itf = _topk_case(n_items, n_tastes, d, graph)
         b, e = sharding.shard_bounds(n_items, world, rank)
         ret[rank] = model.predict_top_k(uf, itf[b:e], k=10, item_sharded=True, item_offset=b)
+        if graph == "euclidean":
+            from tensorrec_amd import ops
+            ret["route%d" % rank] = str(ops.LAST_FILTER_STATS.get("route", ""))
     finally:
         dist.destroy_process_group()
 
@@ -239,6 +245,26 @@ def test_item_sharded_predict_top_k_equals_single_process(n_items, n_tastes, d):
     for r in (0, 1):
         v, i = ret[r]
         assert np.array_equal(i, ref_i) and np.array_equal(v, ref_v), "rank %d" % r
+
+
+@pytest.mark.parametrize("n_items,n_tastes", [(60000, 1), (40000, 2)])
+def test_item_sharded_euclidean_predict_top_k_takes_the_certified_route(n_items, n_tastes):
+    """Euclidean similarity (prediction_graphs.py:84-100) under item shards and with two tastes: every rank runs the dot cascade
+    on u.i - r_i / 2 over ITS shard, certifies its own first k and the exact per-shard lists merge -- the single-process result,
+    bit for bit (these cases used to leave the fast route)."""
+    model, uf, itf = _topk_case(n_items, n_tastes, 32, "euclidean")
+    ref_v, ref_i = model.predict_top_k(uf, itf, k=10)
+    scores = model.predict(uf, itf)                                   # ... which is the dense prediction's order
+    from oracle import oracle as O
+    ov, oi = O.topk_rows(scores, 10)
+    assert np.array_equal(ref_i, oi) and np.array_equal(ref_v, ov)
+    mgr = mp.get_context("spawn").Manager()
+    ret = mgr.dict()
+    mp.spawn(_topk_worker, args=(2, _free_port(), n_items, n_tastes, ret, 32, "euclidean"), nprocs=2, join=True)
+    for r in (0, 1):
+        v, i = ret[r]
+        assert np.array_equal(i, ref_i) and np.array_equal(v, ref_v), "rank %d" % r
+        assert "euclidean" in ret["route%d" % r], ret["route%d" % r]
 
 
 def test_item_sharded_cascade_with_the_one_pass_scan(monkeypatch):
