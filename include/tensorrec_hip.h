@@ -369,6 +369,20 @@ int trec_topk_candidates_finish(const int32_t* cand_n, const void* cand, int32_t
 int trec_topk_cascade_floor(float* tau, const int32_t* src, const float* user_stats, const float* user_bias,
                             const float* item_gstats, int32_t kdim, int64_t n_users, float* floor0, int32_t* flag,
                             int32_t* n_flagged, int32_t* cand_n, void* stream);
+
+/* The cascade's PRE-REFINEMENT (csrc/topk_filter.hip): the k superblocks holding a user's k largest int8 lower bounds
+ * are refined first; tau = max(tau8, min of their bf16 maxima - eps) is a sharper lower bound of the k-th best score of
+ * tf.nn.top_k (recommendation_graphs.py:80) for the compaction and the candidate floor.  trec_topk_prerefine_rows: selection over
+ * the chunk lists written with top_k | 0x100 (tagged lower bounds) -> per-superblock user lists (layout of trec_topk_rows_collect)
+ * + sel_sb [n_users][k] + ok [n_users]; trec_score_gemm_blockmax_grouped refines them; trec_topk_prerefine_tau raises tau and marks
+ * the refined table entries +inf (kept by the compaction unconditionally, written again by the listing launch). */
+int32_t trec_topk_prerefine_max_superblocks(void);
+int trec_topk_prerefine_rows(const int32_t* sel, const float* sel_val, int32_t k, int32_t top_k, int32_t sb_per_chunk, int32_t n_sb,
+                             int64_t n_users, const int32_t* src, int32_t rcap, int32_t* sel_sb, int32_t* row_count,
+                             int32_t* row_user, int32_t* ok, void* stream);
+int trec_topk_prerefine_tau(const int32_t* sel_sb, const int32_t* ok, int32_t k, float* table, int64_t stride, int64_t n_users,
+                            const int32_t* src, const float* user_stats, const float* user_bias, const float* item_gstats,
+                            int32_t kdim, float* tau, void* stream);
 /* The exact EUCLIDEAN top-k (tensorrec/prediction_graphs.py:84-100 + tf.nn.top_k of recommendation_graphs.py:73-82) through the
  * dot-product cascade: per user, nearest = largest g = u.i - r_i / 2, a dot product with item "bias" -r_i / 2.  After the cascade
  * gave the kc = 16 largest g per user and trec_pair_score_exact their reference-chain scores (biases included),

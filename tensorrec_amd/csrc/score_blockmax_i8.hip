@@ -231,6 +231,7 @@ __global__ __launch_bounds__(256, WPS) void blockmax_i8_kernel(ScoreParams p)
                 if (TK) {
                     float lb = v - i8_pair_err(e_nx[cb], e_ex[cb], e_cu[cb], yh, dy, db, KT);
                     lb = (lb == lb) ? lb : -INFINITY;          // a NaN certifies nothing
+                    if (p.top_tag) lb = lb_tag(lb, t / p.sb_tiles);      // (uniform) the superblock's index inside this chunk
                     // sorted insertion into a descending list, one v_med3 per slot: new t_j = median(t_j, t_{j-1}, lb)
                     // (lb <= t_j: t_j stays | t_j < lb <= t_{j-1}: lb lands here | lb > t_{j-1}: t_{j-1} moves down)
 #pragma unroll
@@ -481,6 +482,7 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void blockmax_i8x16_kernel(ScorePa
                 if (TK) {
                     float lb = v - i8_pair_err(e_nx[o], e_ex[o], e_cu[o], yh, dy, db, KT);
                     lb = (lb == lb) ? lb : -INFINITY;          // a NaN certifies nothing
+                    if (p.top_tag) lb = lb_tag(lb, t / p.sb_tiles);      // (uniform) the superblock's index inside this chunk
 #pragma unroll
                     for (int j = TK - 1; j >= 1; --j) top[o][j] = __builtin_amdgcn_fmed3f(top[o][j], top[o][j - 1], lb);
                     top[o][0] = fmaxf(top[o][0], lb);
@@ -936,6 +938,8 @@ extern "C" int trec_score_user_err_i8(const float* user_stats, const float* user
 // user_err + chunk_top + top_k (all or none): chunk_top [n_chunks_eff * top_k][bm_stride] receives, per chunk of superblocks
 // and user, the top_k largest lower bounds M - e(u, s), sorted descending, -inf padded; top_k = 10 or 16;
 // n_chunks_eff = ceil(n_items / chunk_len), chunk_len = ceil(ceil(n_items / n_chunks) / sb_rows) * sb_rows.
+// top_k | 0x100 (TREC_TOPK_TAGGED): every lower bound carries the index of its superblock INSIDE its chunk in its low 12 bits
+// (lb_tag, score_common.hpp: the tagged value is a slightly smaller, still valid lower bound; chunks of at most 4096 superblocks).
 extern "C" int trec_score_gemm_blockmax_i8(const void* users_q, const void* items_q, int32_t kpad, int64_t n_users,
                                            int64_t n_items, const float* user_bias, const int32_t* item_bias_q,
                                            const float* scales, const float* sb_stats, int32_t sb_rows, int32_t n_chunks,
@@ -943,6 +947,8 @@ extern "C" int trec_score_gemm_blockmax_i8(const void* users_q, const void* item
                                            int32_t top_k, const float* wg_scale, const int32_t* wg_class, int32_t wg_rows,
                                            void* stream)
 {
+    const int top_tag = (top_k & 0x100) ? 1 : 0;
+    top_k &= 0xff;
     // wg_rows (with wg_scale): the rows per workgroup the caller laid the users out for -- the scales and bias tables are
     // indexed by workgroup, so a tuning changed between preparation and launch must fail loudly, not shift them
     TREC_REQUIRE(!wg_scale || wg_rows == trec_score_blockmax_i8_rows_per_workgroup(top_k ? top_k : 10),
@@ -962,6 +968,9 @@ extern "C" int trec_score_gemm_blockmax_i8(const void* users_q, const void* item
     p.r_bias = user_bias; p.t_bias = (const float*)item_bias_q;
     p.blockmax = blockmax; p.bm_stride = bm_stride;
     p.scales = scales; p.sb_stats = sb_stats; p.r_err = user_err; p.chunk_top = chunk_top; p.top_k = top_k;
+    p.top_tag = top_tag;
+    TREC_REQUIRE(!top_tag || (top_k && p.chunk_len / sb_rows <= (1 << TREC_LB_TAG_BITS)),
+                 "trec_score_gemm_blockmax_i8: tagged lower bounds need the lists and chunks of at most 4096 superblocks");
     p.wg_scale = wg_scale; p.wg_class = item_bias_q ? wg_class : nullptr; p.bias_stride = n_items;
     hipStream_t st = (hipStream_t)stream;
     const bool bias = user_bias || item_bias_q;

@@ -53,7 +53,29 @@ struct ScoreParams {
                                    // looking, 2 = atomics but no stores; +8 no maxima stores, +32 no counter gather, +64 / +128 throttled row gathers
     float* chunk_top;              // int8 BLOCKMAX: [n_chunks * top_k][bm_stride]: the top_k largest LOWER BOUNDS of a chunk per user
     int top_k;
+    int top_tag;                   // int8 BLOCKMAX: the lower bounds carry the superblock's index inside its chunk in their low
+                                   // TREC_LB_TAG_BITS bits (lb_tag below): the pre-refinement of the cascade needs to know WHICH
+                                   // superblocks hold a user's k largest lower bounds (trec_topk_prerefine_rows)
 };
+
+// A lower bound with an index in its low bits.  tagged <= lb always (a smaller lower bound is still a lower bound: at most two
+// units of 2^-11 relative, ~1 % of the int8 bound itself), tagged values of one chunk are distinct, -inf (nothing certified) stays
+// -inf.  Floats are mapped to a monotone signed integer key (negative floats -> negative keys), the key is floored to the multiple
+// of 4096 strictly below it and the index added; lb_tag_index recovers it (two's complement: key mod 4096).
+#define TREC_LB_TAG_BITS 12
+__device__ __forceinline__ int lb_key(float x)
+{
+    const int b = __float_as_int(x);
+    return b >= 0 ? b : (int)(0x80000000u - (unsigned int)b);
+}
+__device__ __forceinline__ float lb_tag(float lb, int idx)
+{
+    if (!(fabsf(lb) < 1e37f)) return -INFINITY;                               // -inf, NaN, or too large to move: certifies nothing
+    const int k2 = ((lb_key(lb) >> TREC_LB_TAG_BITS) - 1) * (1 << TREC_LB_TAG_BITS) + idx;
+    const int b2 = k2 >= 0 ? k2 : (int)(0x80000000u - (unsigned int)k2);
+    return __int_as_float(b2);
+}
+__device__ __forceinline__ int lb_tag_index(float tagged) { return lb_key(tagged) & ((1 << TREC_LB_TAG_BITS) - 1); }
 
 // |int8 score - fp32 score| <= i8_pair_err for every item of a superblock with statistics (yh, dy, db) and a user with
 // (nx, ex, cu) -- the bound of csrc/topk_cascade.hip; ONE definition, evaluated identically (no contraction) by the int8

@@ -37,6 +37,7 @@
 // the sum is inflated by 2^-9; 1e-30 absorbs flushed denormals.  tests/test_gpu_filter.py measures max |sh - s| / eps
 // on random, adversarially aligned and near-tied inputs.
 #include "topk_common.hpp"
+#include "score_common.hpp"
 
 #define FILTER_CMAX 64          // survivors per user the finish kernel can re-score (one per lane)
 
@@ -204,6 +205,107 @@ __global__ __launch_bounds__(256) void cascade_floor_kernel(float* __restrict__ 
     floor0[u] = bad ? INFINITY : f;                                             // a user without a usable bound lists nothing
     flag[u] = bad ? 1 : 0;
     if (bad) atomicAdd(n_flagged, 1);
+}
+
+// ---- the cascade's PRE-REFINEMENT (round 5): a sharper threshold before the compaction -----------------------------------------
+// tau8 = the k-th largest int8 LOWER bound M8 - e sits a whole e (~0.017 at 1M x 1M normalised rows) below the k-th best score, and
+// the compaction keeps every superblock whose UPPER bound M8 + e reaches it: a window of 2 e.  The k superblocks that hold a user's k
+// largest lower bounds are refined first (the grouped bf16 kernel, 0.5 % of all pairs): each then holds an item with fp32 score >=
+// M16 - eps (eps: the bf16 filter's bound, ~0.003), so tauA = min M16 - eps is ALSO a lower bound of the k-th best score, and it is
+// what the compaction, the candidate floor and the lists then work with: tau = max(tau8, tauA).  Kept pairs 2.6 % -> ~1.3 %,
+// candidates per user 27 -> ~14 (simulated on 256 x 1M; measured: DESIGN 5h).
+//
+// prerefine_rows_kernel: sel [n_users][k] = rows of the chunk lists that hold the user's k largest (tagged) lower bounds, val
+// [k][n_users] their values; row / top_k = the chunk, lb_tag_index(value) = the superblock inside it.  Writes sel_sb [n_users][k]
+// (superblock ids, -1 = no certificate in that slot) and appends the user to its superblocks' lists row_user [n_sb][rcap] (counts
+// row_count [n_sb], zeroed by the caller; LDS counters per workgroup of 1024 users, ONE global atomic per (workgroup, superblock)).
+// ok[u] = 1 when all k slots were placed (the user's tauA is then valid).
+__global__ __launch_bounds__(256) void prerefine_rows_kernel(const int32_t* __restrict__ sel, const float* __restrict__ val, int k,
+                                                            int top_k, int sb_per_chunk, int32_t n_sb, int64_t n_users,
+                                                            const int32_t* __restrict__ src, int32_t rcap,
+                                                            int32_t* __restrict__ sel_sb, int32_t* __restrict__ row_count,
+                                                            int32_t* __restrict__ row_user, int32_t* __restrict__ ok)
+{
+    extern __shared__ int cnt[];                                               // [n_sb]: count, then the global base of this workgroup's run
+    for (int s = threadIdx.x; s < n_sb; s += 256) cnt[s] = 0;
+    __syncthreads();
+    constexpr int UPT = 4;                                                     // users per thread
+    int sb[UPT][16];
+    short lr[UPT][16];
+#pragma unroll
+    for (int i = 0; i < UPT; ++i) {
+        const int64_t u = (int64_t)blockIdx.x * (256 * UPT) + i * 256 + threadIdx.x;
+        const bool live = u < n_users && (!src || src[u] >= 0);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            sb[i][j] = -1; lr[i][j] = 0;
+            if (live && j < k) {
+                const int32_t row = sel[u * k + j];
+                const float v = val[(int64_t)j * n_users + u];
+                if (row >= 0 && v > -INFINITY) {
+                    const int s = (row / top_k) * sb_per_chunk + lb_tag_index(v);
+                    if (s >= 0 && s < n_sb) { sb[i][j] = s; lr[i][j] = (short)atomicAdd(&cnt[s], 1); }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int s = threadIdx.x; s < n_sb; s += 256) {
+        const int c = cnt[s];
+        cnt[s] = c ? atomicAdd(&row_count[s], c) : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < UPT; ++i) {
+        const int64_t u = (int64_t)blockIdx.x * (256 * UPT) + i * 256 + threadIdx.x;
+        if (u >= n_users) continue;
+        bool all = true;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (j >= k) break;
+            const int s = sb[i][j];
+            if (s < 0) { all = false; sel_sb[u * k + j] = -1; continue; }
+            const int pos = cnt[s] + lr[i][j];
+            sel_sb[u * k + j] = s;
+            if (pos < rcap) row_user[(int64_t)s * rcap + pos] = (int32_t)u;
+            else all = false;
+        }
+        ok[u] = all ? 1 : 0;
+    }
+}
+
+// After the pre-refining launch: tau[u] = max(tau[u], min_j table[sel_sb[u][j]][u] - eps_u) for the users with ok[u], and EVERY
+// listed entry of the table becomes +inf: the compaction then keeps those (superblock, user) pairs whatever its own bound says
+// (they hold the k largest lower bounds: they are kept under tau8 anyway) and the refining launch that lists candidates writes
+// their bf16 maxima again -- a refined entry is never compared through the int8 bound e, which need not cover eps.
+__global__ __launch_bounds__(256) void prerefine_tau_kernel(const int32_t* __restrict__ sel_sb, const int32_t* __restrict__ ok, int k,
+                                                           float* __restrict__ table, int64_t stride, int64_t n_users,
+                                                           const int32_t* __restrict__ src, const float2* __restrict__ ustats,
+                                                           const float* __restrict__ user_bias, const float* __restrict__ gstats,
+                                                           int kdim, float* __restrict__ tau)
+{
+    const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (u >= n_users || (src && src[u] < 0)) return;
+    float m = INFINITY;
+    int32_t s[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s[j] = j < k ? sel_sb[u * k + j] : -1;
+    float v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = s[j] >= 0 ? table[(int64_t)s[j] * stride + u] : INFINITY;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) m = fminf(m, (v[j] == v[j]) ? v[j] : -INFINITY);          // a NaN certifies nothing
+    if (ok[u]) {
+        const float eps = filter_eps(ustats[u], user_bias ? fabsf(user_bias[u]) : 0.f, gstats, kdim);
+        float t = m - eps;
+        if (eps < INFINITY && t == t && m < INFINITY) {
+            t = float_pred(float_pred(t));
+            if (t > tau[u]) tau[u] = t;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+        if (s[j] >= 0) table[(int64_t)s[j] * stride + u] = INFINITY;
 }
 
 #define FILTER_RB 8          // survivors re-scored per round (their fp32 rows staged in LDS)
@@ -865,4 +967,38 @@ extern "C" int trec_topk_cascade_floor(float* tau, const int32_t* src, const flo
     hipLaunchKernelGGL(cascade_floor_kernel, dim3((unsigned)ceil_div64(n_users, 256)), dim3(256), 0, (hipStream_t)stream, tau, src,
                        (const float2*)user_stats, user_bias, item_gstats, kdim, n_users, floor0, flag, n_flagged, cand_n);
     return trec_check_launch("trec_topk_cascade_floor");
+}
+
+// The cascade's pre-refinement, step 1 (prerefine_rows_kernel): from the selection over the TAGGED chunk lists (sel [n_users][k]
+// rows, sel_val [k][n_users] values; lists written with top_k | 0x100) to per-superblock user lists in the fixed-capacity layout of
+// trec_topk_rows_collect (row_count [n_sb] zeroed by the caller, row_user [n_sb][rcap], rcap % 512 == 0) for
+// trec_score_gemm_blockmax_grouped, plus sel_sb [n_users][k] (superblock ids, -1 = empty slot) and ok [n_users].
+// n_sb * 4 bytes of LDS: n_sb <= trec_topk_prerefine_max_superblocks().
+extern "C" int32_t trec_topk_prerefine_max_superblocks(void) { return 16000; }
+
+extern "C" int trec_topk_prerefine_rows(const int32_t* sel, const float* sel_val, int32_t k, int32_t top_k, int32_t sb_per_chunk,
+                                        int32_t n_sb, int64_t n_users, const int32_t* src, int32_t rcap, int32_t* sel_sb,
+                                        int32_t* row_count, int32_t* row_user, int32_t* ok, void* stream)
+{
+    TREC_REQUIRE(sel && sel_val && sel_sb && row_count && row_user && ok, "trec_topk_prerefine_rows: null pointer");
+    TREC_REQUIRE(k >= 1 && k <= 16 && top_k >= 1 && sb_per_chunk >= 1 && sb_per_chunk <= (1 << TREC_LB_TAG_BITS) && n_sb >= 1 &&
+                 n_sb <= trec_topk_prerefine_max_superblocks() && rcap >= 512 && rcap % 512 == 0, "trec_topk_prerefine_rows: bad sizes");
+    if (n_users == 0) return TREC_OK;
+    hipLaunchKernelGGL(prerefine_rows_kernel, dim3((unsigned)ceil_div64(n_users, 1024)), dim3(256), (size_t)n_sb * 4, (hipStream_t)stream,
+                       sel, sel_val, k, top_k, sb_per_chunk, n_sb, n_users, src, rcap, sel_sb, row_count, row_user, ok);
+    return trec_check_launch("trec_topk_prerefine_rows");
+}
+
+// Step 2, after the grouped bf16 launch over those lists (prerefine_tau_kernel): tau [n_users] IN / OUT is raised to
+// min_j table[sel_sb[u][j]][u] - eps_u where that is larger (users with ok[u]); every listed table entry becomes +inf.
+extern "C" int trec_topk_prerefine_tau(const int32_t* sel_sb, const int32_t* ok, int32_t k, float* table, int64_t stride,
+                                       int64_t n_users, const int32_t* src, const float* user_stats, const float* user_bias,
+                                       const float* item_gstats, int32_t kdim, float* tau, void* stream)
+{
+    TREC_REQUIRE(sel_sb && ok && table && user_stats && item_gstats && tau && k >= 1 && k <= 16 && stride >= n_users,
+                 "trec_topk_prerefine_tau: bad arguments");
+    if (n_users == 0) return TREC_OK;
+    hipLaunchKernelGGL(prerefine_tau_kernel, dim3((unsigned)ceil_div64(n_users, 256)), dim3(256), 0, (hipStream_t)stream, sel_sb, ok, k,
+                       table, stride, n_users, src, (const float2*)user_stats, user_bias, item_gstats, kdim, tau);
+    return trec_check_launch("trec_topk_prerefine_tau");
 }

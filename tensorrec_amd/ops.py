@@ -1281,6 +1281,8 @@ CASCADE_CANDIDATES = 256         # candidate items per user the refining launche
                                  # every item of a refined pair within eps of the k-th largest int8 lower bound; ~30 at 1M x 1M,
                                  # 138 (median) on clustered rows; the finish reads the first 64 unasked, the rest by the count)
 CASCADE_DENSE_USER_LIMIT = 16    # of 32 sampled superblocks kept (Gaussian rows keep 2.6 % of them, clustered ones 23 %): the int8 bound says nothing about this user -- flagged at once
+CASCADE_PREREFINE_MIN_SB = 32   # superblocks from which the users' k best superblocks are pre-refined (k / n_sb of all pairs; the product
+                                # path runs the cascade from 512 superblocks on, the tests from 40)
 CASCADE_MIN_ITEMS = 262144       # below ~512 superblocks the k-th largest maximum is not selective enough for int8 to pay
 
 
@@ -1449,17 +1451,28 @@ def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, 
     N.call("trec_score_user_err_i8", N.ptr(uop.stats8), N.ptr(user_bias), N.ptr(gstats8), kpad, n_u, N.ptr(iop.scales),
            N.ptr(uop.wg_scale), int(uop.wg_rows or 0) if uop.wg_scale is not None else 0, N.ptr(user_err))
     stride = (n_u + 3) // 4 * 4
-    _, n_ch = blockmax_i8_chunks(n_i, n_chunks, sb_rows)
+    chunk_len, n_ch = blockmax_i8_chunks(n_i, n_chunks, sb_rows)
     table = torch.empty((n_sb, stride), dtype=torch.float32, device=dev)
     chunk_top = torch.empty((n_ch * top_k, stride), dtype=torch.float32, device=dev)
+    lib = N.load()
+    lists = cascade_lists_candidates() and gstats_all is not None and sb_rows <= 65536
+    one_pass = lib.trec_get_tuning(b"cascade_rows_onepass", 1) != 0 and lib.trec_get_tuning(b"blockmax_bf16_mfma16", 1) != 0
+    # PRE-REFINEMENT (csrc/topk_filter.hip): the k superblocks with a user's k largest lower bounds are refined first and
+    # tau rises to min(their bf16 maxima) - eps -- one e closer to the k-th best score, so the compaction keeps about half as many
+    # pairs and the lists half as many candidates.  The chunk lists then carry the superblock's index inside its chunk in their low
+    # bits.  Single process, candidate lists, catalogues the LDS counters cover; item shards keep the exchanged tau8.
+    sb_per_chunk = chunk_len // sb_rows
+    pre = (one_pass and lists and floor_exchange is None and stats_exchange is None and kk <= 16
+           and lib.trec_get_tuning(b"cascade_prerefine", 1) != 0 and sb_per_chunk <= 4096
+           and CASCADE_PREREFINE_MIN_SB <= n_sb <= int(N.query("trec_topk_prerefine_max_superblocks")))
     with _timed("score_gemm_blockmax_i8"):
         N.call("trec_score_gemm_blockmax_i8", N.ptr(uop.i8), N.ptr(iop.i8), kpad, n_u, n_i, N.ptr(user_bias),
                N.ptr(iop.bias_q), N.ptr(iop.scales), N.ptr(iop.sb_stats), sb_rows, n_chunks, N.ptr(table), stride,
-               N.ptr(user_err), N.ptr(chunk_top), top_k, N.ptr(uop.wg_scale), N.ptr(uop.wg_class),
+               N.ptr(user_err), N.ptr(chunk_top), top_k | (0x100 if pre else 0), N.ptr(uop.wg_scale), N.ptr(uop.wg_class),
                int(uop.wg_rows or 0) if uop.wg_scale is not None else 0)
     # tau = the k-th largest LOWER bound: from the chunks' lists (k rows per chunk), not from the 7.8 GB table
     sel = torch.empty((n_u, kk), dtype=torch.int32, device=dev)
-    sel_max = torch.empty((kk, n_u), dtype=torch.float32, device=dev) if floor_exchange is not None else None
+    sel_max = torch.empty((kk, n_u), dtype=torch.float32, device=dev) if (floor_exchange is not None or pre) else None
     tau = torch.empty((n_u,), dtype=torch.float32, device=dev)
     with _timed("topk_select_blocks"):
         N.call("trec_topk_select_blocks", N.ptr(chunk_top), n_ch * top_k, n_u, stride, kk, N.ptr(sel), N.ptr(sel_max),
@@ -1471,9 +1484,27 @@ def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, 
     status = zb[0:6].view(torch.int64)
     n_flagged0 = zb[6:7]
     row_count = zb[8:8 + n_sb]
-    lists = cascade_lists_candidates() and gstats_all is not None and sb_rows <= 65536
-    one_pass = N.load().trec_get_tuning(b"cascade_rows_onepass", 1) != 0 and N.load().trec_get_tuning(b"blockmax_bf16_mfma16", 1) != 0
     cands = None
+    if pre:
+        n_cap_a = int(uop.n_real or n_u)
+        rcap_a = (4 * (n_cap_a * kk // n_sb + 1) + 2048 + 511) // 512 * 512
+        pre_ws = zero_block(n_sb, dev)                                   # row counts of the pre-refining launch
+        sel_sb = torch.empty((n_u, kk), dtype=torch.int32, device=dev)
+        pre_ok = torch.empty((n_u,), dtype=torch.int32, device=dev)
+        pre_rows = torch.empty((n_sb * rcap_a,), dtype=torch.int32, device=dev)        # only the listed part is touched
+        with _timed("topk_prerefine"):
+            N.call("trec_topk_prerefine_rows", N.ptr(sel), N.ptr(sel_max), kk, top_k, sb_per_chunk, n_sb, n_u, N.ptr(uop.src),
+                   rcap_a, N.ptr(sel_sb), N.ptr(pre_ws), N.ptr(pre_rows), N.ptr(pre_ok))
+        with _timed("score_gemm_blockmax_pre"):
+            N.call("trec_score_gemm_blockmax_grouped", N.ptr(uop.bf16), N.ptr(iop.bf16), kpad, n_sb * rcap_a, n_i,
+                   N.ptr(user_bias), N.ptr(item_bias), sb_rows, N.ptr(pre_ws), N.ptr(pre_rows), N.ptr(table), stride,
+                   rcap_a // 512)
+        with _timed("topk_prerefine"):
+            N.call("trec_topk_prerefine_tau", N.ptr(sel_sb), N.ptr(pre_ok), kk, N.ptr(table), stride, n_u, N.ptr(uop.src),
+                   N.ptr(uop.stats), N.ptr(user_bias), N.ptr(gstats_all), kpad, N.ptr(tau))
+        if FILTER_DEBUG is not None:
+            FILTER_DEBUG.update({"prerefine_users_ok": int(pre_ok.sum().item()), "prerefine_rcap": rcap_a,
+                                 "prerefine_row_count_max": int(pre_ws.max().item())})
     if one_pass and lists:
         # the refining launches also list every item that can still reach the top-k: provisional floor = the k-th
         # largest int8 lower bound less ONE eps of the bf16 filter.  ONE pass over the users (trec_topk_cascade_floor) makes the

@@ -448,14 +448,22 @@ def test_cascade_hot_superblocks_of_a_popular_catalogue(ops):
     from tensorrec_amd import _native as N
     ops.FILTER_DEBUG = {}
     N.set_tuning("cascade_rcap_pct", 10)                  # (2,100 users: a list capacity of 10% instead of 50% of them)
+    N.set_tuning("cascade_prerefine", 0)                  # (the threshold of round 4: with the pre-refined one fewer users want them)
     try:
         vals, idx, stats, _, _ = run_cascade(ops, u, v, k, ub, ib)
         dbg = dict(ops.FILTER_DEBUG)
+        N.set_tuning("cascade_prerefine", 1)              # ... and with the pre-refinement: the same lists
+        vals2, idx2, stats2, _, _ = run_cascade(ops, u, v, k, ub, ib)
+        dbg2 = dict(ops.FILTER_DEBUG)
     finally:
         ops.FILTER_DEBUG = None
         N.set_tuning("cascade_rcap_pct", int(100 * ops.CASCADE_ROW_CAPACITY))
+        N.set_tuning("cascade_prerefine", 1)
     rv, ri = O.topk_rows(O.score_dense_exact(u, v, ub, ib), k)
     assert np.array_equal(idx, ri) and np.array_equal(vals, rv)
+    assert np.array_equal(idx2, ri) and np.array_equal(vals2, rv)
+    assert stats2["prefilter"] == "int8" and dbg2["prerefine_users_ok"] >= n_u // 2, (stats2, dbg2)
+    assert dbg2["int8_pairs_wanted"] <= dbg["int8_pairs_wanted"], (dbg, dbg2)      # the sharper threshold never keeps more
     assert stats["prefilter"] == "int8", stats            # the cascade ran: hot rows did not overflow it
     assert dbg["hot_superblocks"] >= 3, dbg               # ... and there were hot rows (wanted by > 1,024 of the 2,100 users)
     assert dbg["int8_pairs_wanted"] < 0.2 * dbg["int8_pairs_total"]
@@ -505,3 +513,44 @@ def test_one_pass_scan_equals_select_plus_collect(ops, cand_cap):
     assert stats["prefilter"] == "int8" and "tail" not in stats
     assert np.array_equal(idx, ri) and np.array_equal(vals, rv)
     assert stats["flagged_users"] <= 13
+
+
+@pytest.mark.parametrize("d,n_u,n_i,k,kind", [(128, 1100, 300_000, 10, "gauss"), (64, 700, 280_000, 7, "gauss"),
+                                              (128, 900, 270_000, 16, "clustered"), (128, 600, 40_000, 10, "gauss")])
+def test_prerefined_threshold_keeps_fewer_pairs_and_the_same_lists(ops, d, n_u, n_i, k, kind):
+    """The pre-refinement (csrc/topk_filter.hip): the k superblocks with a user's k largest int8 lower bounds are refined
+    first and tau = max(tau8, min of their bf16 maxima - eps).  With it and without it the lists are the oracle's, bit for bit;
+    with it the compaction keeps fewer (superblock, user) pairs."""
+    from tensorrec_amd import _native as N
+    rng = np.random.default_rng(d + n_u + k)
+    u = rng.standard_normal((n_u, d)).astype(np.float32)
+    v = rng.standard_normal((n_i, d)).astype(np.float32)
+    if kind == "clustered":                               # fitted-like rows: cluster directions, heterogeneous norms, popular items
+        cu = rng.standard_normal((32, d)).astype(np.float32)
+        u = (0.6 * u + cu[rng.integers(0, 32, n_u)]) * rng.uniform(0.3, 2.0, (n_u, 1)).astype(np.float32)
+        v = (0.6 * v + cu[rng.integers(0, 32, n_i)]) * rng.uniform(0.5, 1.5, (n_i, 1)).astype(np.float32)
+    else:
+        u /= np.linalg.norm(u, axis=1, keepdims=True)
+        v /= np.linalg.norm(v, axis=1, keepdims=True)
+    ub = (0.05 * rng.standard_normal(n_u)).astype(np.float32)
+    ib = (0.05 * rng.standard_normal(n_i)).astype(np.float32)
+    rv, ri = O.topk_rows(O.score_dense_exact(u, v, ub, ib), k)
+    wanted = {}
+    try:
+        for flag in (0, 1):
+            N.set_tuning("cascade_prerefine", flag)
+            ops.FILTER_DEBUG = {}
+            vals, idx, stats, _, _ = run_cascade(ops, u, v, k, ub, ib)
+            dbg = dict(ops.FILTER_DEBUG)
+            assert np.array_equal(idx, ri) and np.array_equal(vals, rv), (flag, stats)
+            if str(stats.get("prefilter")) == "int8":
+                wanted[flag] = dbg["int8_pairs_wanted"]
+                if flag:
+                    assert dbg["prerefine_users_ok"] >= n_u // 2, dbg
+    finally:
+        ops.FILTER_DEBUG = None
+        N.set_tuning("cascade_prerefine", 1)
+    if len(wanted) == 2:
+        assert wanted[1] <= wanted[0], wanted
+        if kind == "gauss" and n_i >= 262_144:
+            assert wanted[1] < 0.8 * wanted[0], wanted     # (Gaussian rows: about half; the k pre-refined superblocks count as kept)
