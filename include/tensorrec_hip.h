@@ -374,15 +374,17 @@ int trec_topk_cascade_floor(float* tau, const int32_t* src, const float* user_st
  * are refined first; tau = max(tau8, min of their bf16 maxima - eps) is a sharper lower bound of the k-th best score of
  * tf.nn.top_k (recommendation_graphs.py:80) for the compaction and the candidate floor.  trec_topk_prerefine_rows: selection over
  * the chunk lists written with top_k | 0x100 (tagged lower bounds) -> per-superblock user lists (layout of trec_topk_rows_collect)
- * + sel_sb [n_users][k] + ok [n_users]; trec_score_gemm_blockmax_grouped refines them; trec_topk_prerefine_tau raises tau and marks
- * the refined table entries +inf (kept by the compaction unconditionally, written again by the listing launch). */
+ * + sel_sb [n_users][k] + ok [n_users]; the bf16 launch over them is trec_score_gemm_refine_candidates (it also lists their
+ * candidates; trec_topk_prerefine_tau with listed = 1 then saves the maxima, takes the pairs out of the compaction (-inf) and raises
+ * tau and the candidate floor) or trec_score_gemm_blockmax_grouped (listed = 0: the entries become +inf and the listing launch
+ * refines them again). */
 int32_t trec_topk_prerefine_max_superblocks(void);
 int trec_topk_prerefine_rows(const int32_t* sel, const float* sel_val, int32_t k, int32_t top_k, int32_t sb_per_chunk, int32_t n_sb,
                              int64_t n_users, const int32_t* src, int32_t rcap, int32_t* sel_sb, int32_t* row_count,
                              int32_t* row_user, int32_t* ok, void* stream);
 int trec_topk_prerefine_tau(const int32_t* sel_sb, const int32_t* ok, int32_t k, float* table, int64_t stride, int64_t n_users,
                             const int32_t* src, const float* user_stats, const float* user_bias, const float* item_gstats,
-                            int32_t kdim, float* tau, void* stream);
+                            int32_t kdim, float* tau, int32_t listed, float* vals, float* cand_floor, void* stream);
 /* The exact EUCLIDEAN top-k (tensorrec/prediction_graphs.py:84-100 + tf.nn.top_k of recommendation_graphs.py:73-82) through the
  * dot-product cascade: per user, nearest = largest g = u.i - r_i / 2, a dot product with item "bias" -r_i / 2.  After the cascade
  * gave the kc = 16 largest g per user and trec_pair_score_exact their reference-chain scores (biases included),

@@ -11,7 +11,7 @@ for T in "$@"; do
 ( timeout 600 python bench.py $ARGS --tune $T > $OUT/bench_ab.json 2> $OUT/bench_ab.err ); tail -1 $OUT/bench_ab.err | grep -v amdgpu.ids
 python - <<PY
 import json
-d=json.loads(open('gpurun_out/bench_ab.json').read().strip().splitlines()[-1])
+d=json.load(open('gpurun_out/bench_full.json'))     # (bench.py prints a compact line; the full record is in the side file)
 o=d['roofline']['other_kernels_avg_ms']
 i8=d['roofline']['avg_launch_ms']*d['roofline'].get('launches_per_step',1)
 print('$T', 'ms_per_step', round(d['ms_per_step'],2), 'i8', round(i8,2), 'others', round(sum(o.values()),2), 'rest', round(d['ms_per_step']-i8-sum(o.values()),2), {k.replace('score_gemm_','').replace('topk_',''): round(v,2) for k,v in o.items()}, d['parity']['topk_ids_bit_exact_vs_oracle'], d['parity']['topk_values_bit_exact_vs_oracle'], d['parity']['filter'].get('flagged_users'))

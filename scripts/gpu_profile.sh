@@ -14,7 +14,8 @@ timeout 300 python scripts/fit_rank_sim.py > $OUT/${TAG}_fit_rank_sim.log 2>&1; 
 mkdir -p profiles; cp $OUT/${TAG}_rank_sim_n8.json $OUT/${TAG}_fit_rank_sim_n8.json profiles/ 2>/dev/null      # (the bench line below reads them: scale_emulation)
 fi
 if has bench; then
-timeout 1200 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err; echo "bench rc=$?"; cat $OUT/${TAG}_bench.json | cut -c1-6000
+timeout 1200 python bench.py ${BENCH_ARGS:-} > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err; echo "bench rc=$?"; cat $OUT/${TAG}_bench.json | cut -c1-6000
+cp $OUT/bench_full.json $OUT/${TAG}_bench_full.json 2>/dev/null      # (stdout is the compact driver line; this is the full record)
 fi
 if has cfg4; then
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_cfg4_prof -o cfg4 -- python $REPO/scripts/profile_cfg4.py 3 > $OUT/${TAG}_cfg4.log 2> $OUT/${TAG}_cfg4.err ); echo "cfg4 rocprof rc=$?"; tail -1 $OUT/${TAG}_cfg4.log
@@ -42,7 +43,7 @@ fi
 if has ab; then          # item chunks of the int8 launch (workgroup rounds / tail): AB="13 26 52"
 for c in ${AB:-13 26}; do
   timeout 300 python bench.py --configs headline --no-cpu-baseline --no-fit --no-fp32-mode --no-k1-multi --parity-users 64 --steps 8 --warmup 2 --chunks $c > $OUT/${TAG}_ab_chunks$c.json 2> /dev/null
-  python -c "import json;d=json.load(open('$OUT/${TAG}_ab_chunks$c.json'));print('chunks $c: ms/step %.2f  int8 %.2f ms  frac %.4f  parity %s' % (d['ms_per_step'], d['roofline']['avg_launch_ms'], d['roofline']['frac'], d['parity']['topk_ids_bit_exact_vs_oracle']))"
+  python -c "import json;d=json.load(open('$OUT/${TAG}_ab_chunks$c.json'));print('chunks $c: ms/step %.2f  int8 %.2f ms  frac %.4f  parity %s' % (d['ms_per_step'], d['roofline']['avg_launch_ms'], d['roofline']['frac'], d['config']['checks']['topk_ids_bit_exact']))"
 done
 fi
 if has tests; then
@@ -75,6 +76,13 @@ for f in sorted(glob.glob("$OUT/${TAG}_pmc_*/**/*counter_collection.csv", recurs
             out.write("%s | dispatches=%d | "%(k,cnt[k])+" ".join("%s=%.5g"%(c,v/cnt[k]) for c,v in sorted(agg[k].items()))+"\n")
 out.close(); print(open("$OUT/${TAG}_pmc_summary.txt").read())
 PY
+fi
+if has pmcx; then          # the counters bench.py quotes for the OTHER kernels: fit leg, dense bf16 filter kernel, K1 on 20 non-zeros per row
+bash scripts/gpu_pmc_cmd.sh "scripts/fit_only.py 1" ${TAG}_fit_pmc_summary "wmrb|spmm|seg_|group|adam|sample_items|stage" s3 s4 > /dev/null; tail -n +3 $OUT/${TAG}_fit_pmc_summary.txt | cut -c1-260
+bash scripts/gpu_pmc_cmd.sh "bench.py --configs headline --prefilter none --steps 1 --warmup 0 --prewarm-seconds 0 --no-cpu-baseline --no-fit --no-fp32-mode --no-k1-multi --parity-users 64" ${TAG}_bf16dense_pmc_summary "blockmax_bf16|select_blocks|collect|finish" s3 s4 > /dev/null; tail -n +3 $OUT/${TAG}_bf16dense_pmc_summary.txt | cut -c1-260
+bash scripts/gpu_pmc_cmd.sh "scripts/k1_multi.py" ${TAG}_k1_multi_pmc_summary "spmm" s3 s4 > /dev/null; tail -n +3 $OUT/${TAG}_k1_multi_pmc_summary.txt | cut -c1-260
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_fit_prof -o fit -- python $REPO/scripts/fit_only.py 4 > $OUT/${TAG}_fit_prof.log 2> $OUT/${TAG}_fit_prof.err ); echo "fit rocprof rc=$?"
+f=$(find $OUT/${TAG}_fit_prof -name "*kernel_stats.csv" | head -1); cp $f $OUT/${TAG}_fit_kernel_stats.csv 2>/dev/null; head -9 $OUT/${TAG}_fit_kernel_stats.csv | cut -c1-160
 fi
 if has rank2; then         # two ranks over gloo on ONE GPU: the world > 1 path of bench.py end to end (functional, not a scaling number)
 TREC_DIST_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 3 --warmup 1 --users 200000 --configs headline --no-cpu-baseline 2> $OUT/${TAG}_bench_2rank.err | grep -v "^\[Gloo\]" > $OUT/${TAG}_bench_2rank_gloo_one_gpu.json; echo "rank2 rc=$?"

@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void prerefine_rows_kernel(const int32_t* __re
             const int s = sb[i][j];
             if (s < 0) { all = false; sel_sb[u * k + j] = -1; continue; }
             const int pos = cnt[s] + lr[i][j];
-            sel_sb[u * k + j] = s;
+            sel_sb[u * k + j] = pos < rcap ? s : -1;                           // (a full list: the pair is left to the compaction)
             if (pos < rcap) row_user[(int64_t)s * rcap + pos] = (int32_t)u;
             else all = false;
         }
@@ -274,38 +274,57 @@ __global__ __launch_bounds__(256) void prerefine_rows_kernel(const int32_t* __re
     }
 }
 
-// After the pre-refining launch: tau[u] = max(tau[u], min_j table[sel_sb[u][j]][u] - eps_u) for the users with ok[u], and EVERY
-// listed entry of the table becomes +inf: the compaction then keeps those (superblock, user) pairs whatever its own bound says
-// (they hold the k largest lower bounds: they are kept under tau8 anyway) and the refining launch that lists candidates writes
-// their bf16 maxima again -- a refined entry is never compared through the int8 bound e, which need not cover eps.
+// After the pre-refining launch: tau[u] = max(tau[u], min_j table[sel_sb[u][j]][u] - eps_u) for the users with ok[u] (all k slots
+// placed).  Then the listed entries are taken out of the compaction's way:
+//   listed == 0 (the pre-refining launch only wrote maxima): every listed entry becomes +inf -- the compaction keeps those pairs
+//     whatever its own bound says and the listing launch refines them again; a refined entry is never compared through the int8
+//     bound e, which need not cover eps;
+//   listed != 0 (it also LISTED their candidates, trec_score_gemm_refine_candidates with the provisional floor tau8 - eps): the
+//     bf16 maxima are saved to vals [n_users][k], the entries become -inf -- the compaction drops the pairs, nothing is refined
+//     twice -- and cand_floor[u] rises to tau - eps for the launches still to come (a user that lists nothing keeps +inf).  The
+//     caller puts vals back into the columns of the users it has to re-do from the table.
 __global__ __launch_bounds__(256) void prerefine_tau_kernel(const int32_t* __restrict__ sel_sb, const int32_t* __restrict__ ok, int k,
                                                            float* __restrict__ table, int64_t stride, int64_t n_users,
                                                            const int32_t* __restrict__ src, const float2* __restrict__ ustats,
                                                            const float* __restrict__ user_bias, const float* __restrict__ gstats,
-                                                           int kdim, float* __restrict__ tau)
+                                                           int kdim, float* __restrict__ tau, int listed, float* __restrict__ vals,
+                                                           float* __restrict__ cand_floor)
 {
     const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (u >= n_users || (src && src[u] < 0)) return;
+    if (u >= n_users) return;
+    const bool live = !(src && src[u] < 0);
     float m = INFINITY;
     int32_t s[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) s[j] = j < k ? sel_sb[u * k + j] : -1;
+    for (int j = 0; j < 16; ++j) s[j] = (live && j < k) ? sel_sb[u * k + j] : -1;
     float v[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) v[j] = s[j] >= 0 ? table[(int64_t)s[j] * stride + u] : INFINITY;
 #pragma unroll
     for (int j = 0; j < 16; ++j) m = fminf(m, (v[j] == v[j]) ? v[j] : -INFINITY);          // a NaN certifies nothing
+    if (listed) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) if (j < k) vals[u * k + j] = v[j];
+    }
+    if (!live) return;
     if (ok[u]) {
         const float eps = filter_eps(ustats[u], user_bias ? fabsf(user_bias[u]) : 0.f, gstats, kdim);
         float t = m - eps;
         if (eps < INFINITY && t == t && m < INFINITY) {
             t = float_pred(float_pred(t));
-            if (t > tau[u]) tau[u] = t;
+            if (t > tau[u]) {
+                tau[u] = t;
+                if (listed && cand_floor[u] < INFINITY) {
+                    const float f = float_pred(float_pred(t - eps));           // the provisional floor of the launches to come
+                    if (f > cand_floor[u]) cand_floor[u] = f;
+                }
+            }
         }
     }
+    const float mark = listed ? -INFINITY : INFINITY;
 #pragma unroll
     for (int j = 0; j < 16; ++j)
-        if (s[j] >= 0) table[(int64_t)s[j] * stride + u] = INFINITY;
+        if (s[j] >= 0) table[(int64_t)s[j] * stride + u] = mark;
 }
 
 #define FILTER_RB 8          // survivors re-scored per round (their fp32 rows staged in LDS)
@@ -989,16 +1008,22 @@ extern "C" int trec_topk_prerefine_rows(const int32_t* sel, const float* sel_val
     return trec_check_launch("trec_topk_prerefine_rows");
 }
 
-// Step 2, after the grouped bf16 launch over those lists (prerefine_tau_kernel): tau [n_users] IN / OUT is raised to
-// min_j table[sel_sb[u][j]][u] - eps_u where that is larger (users with ok[u]); every listed table entry becomes +inf.
+// Step 2, after the bf16 launch over those lists (prerefine_tau_kernel): tau [n_users] IN / OUT is raised to
+// min_j table[sel_sb[u][j]][u] - eps_u where that is larger (users with ok[u]).  listed == 0 (the launch was
+// trec_score_gemm_blockmax_grouped): every listed table entry becomes +inf.  listed != 0 (trec_score_gemm_refine_candidates, which
+// also listed the candidates): vals [n_users][k] receives the bf16 maxima, the entries become -inf (the compaction drops the pairs)
+// and cand_floor [n_users] rises to the new tau - eps where it was finite.
 extern "C" int trec_topk_prerefine_tau(const int32_t* sel_sb, const int32_t* ok, int32_t k, float* table, int64_t stride,
                                        int64_t n_users, const int32_t* src, const float* user_stats, const float* user_bias,
-                                       const float* item_gstats, int32_t kdim, float* tau, void* stream)
+                                       const float* item_gstats, int32_t kdim, float* tau, int32_t listed, float* vals,
+                                       float* cand_floor, void* stream)
 {
     TREC_REQUIRE(sel_sb && ok && table && user_stats && item_gstats && tau && k >= 1 && k <= 16 && stride >= n_users,
                  "trec_topk_prerefine_tau: bad arguments");
+    TREC_REQUIRE(!listed || (vals && cand_floor), "trec_topk_prerefine_tau: the listed form needs vals and cand_floor");
     if (n_users == 0) return TREC_OK;
     hipLaunchKernelGGL(prerefine_tau_kernel, dim3((unsigned)ceil_div64(n_users, 256)), dim3(256), 0, (hipStream_t)stream, sel_sb, ok, k,
-                       table, stride, n_users, src, (const float2*)user_stats, user_bias, item_gstats, kdim, tau);
+                       table, stride, n_users, src, (const float2*)user_stats, user_bias, item_gstats, kdim, tau, listed, vals,
+                       cand_floor);
     return trec_check_launch("trec_topk_prerefine_tau");
 }

@@ -1413,7 +1413,7 @@ class _Candidates(object):
     """What the refining launches listed (trec_score_gemm_refine_candidates): per user ``n`` appended entries of ``items``
     [n_users, cap, 2] = {item id, score bits}, made with the provisional floor ``floor0`` (+inf: nothing listed); ``flag`` /
     ``n_flagged``: users without a usable bound so far."""
-    __slots__ = ("n", "items", "cap", "floor0", "flag", "n_flagged")
+    __slots__ = ("n", "items", "cap", "floor0", "flag", "n_flagged", "pre")
 
 
 def cascade_lists_candidates():
@@ -1485,32 +1485,13 @@ def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, 
     n_flagged0 = zb[6:7]
     row_count = zb[8:8 + n_sb]
     cands = None
-    if pre:
-        n_cap_a = int(uop.n_real or n_u)
-        rcap_a = (4 * (n_cap_a * kk // n_sb + 1) + 2048 + 511) // 512 * 512
-        pre_ws = zero_block(n_sb, dev)                                   # row counts of the pre-refining launch
-        sel_sb = torch.empty((n_u, kk), dtype=torch.int32, device=dev)
-        pre_ok = torch.empty((n_u,), dtype=torch.int32, device=dev)
-        pre_rows = torch.empty((n_sb * rcap_a,), dtype=torch.int32, device=dev)        # only the listed part is touched
-        with _timed("topk_prerefine"):
-            N.call("trec_topk_prerefine_rows", N.ptr(sel), N.ptr(sel_max), kk, top_k, sb_per_chunk, n_sb, n_u, N.ptr(uop.src),
-                   rcap_a, N.ptr(sel_sb), N.ptr(pre_ws), N.ptr(pre_rows), N.ptr(pre_ok))
-        with _timed("score_gemm_blockmax_pre"):
-            N.call("trec_score_gemm_blockmax_grouped", N.ptr(uop.bf16), N.ptr(iop.bf16), kpad, n_sb * rcap_a, n_i,
-                   N.ptr(user_bias), N.ptr(item_bias), sb_rows, N.ptr(pre_ws), N.ptr(pre_rows), N.ptr(table), stride,
-                   rcap_a // 512)
-        with _timed("topk_prerefine"):
-            N.call("trec_topk_prerefine_tau", N.ptr(sel_sb), N.ptr(pre_ok), kk, N.ptr(table), stride, n_u, N.ptr(uop.src),
-                   N.ptr(uop.stats), N.ptr(user_bias), N.ptr(gstats_all), kpad, N.ptr(tau))
-        if FILTER_DEBUG is not None:
-            FILTER_DEBUG.update({"prerefine_users_ok": int(pre_ok.sum().item()), "prerefine_rcap": rcap_a,
-                                 "prerefine_row_count_max": int(pre_ws.max().item())})
     if one_pass and lists:
         # the refining launches also list every item that can still reach the top-k: provisional floor = the k-th
         # largest int8 lower bound less ONE eps of the bf16 filter.  ONE pass over the users (trec_topk_cascade_floor) makes the
         # thresholds: rows without a source keep nothing (tau = floor = +inf), users without a usable bound are flagged and
         # list nothing, the list counters start at zero
         cands = _Candidates()
+        cands.pre = None
         cands.cap = int(N.load().trec_get_tuning(b"cascade_candidates_cap", CASCADE_CANDIDATES))
         cands.floor0 = torch.empty((n_u,), dtype=torch.float32, device=dev)
         cands.flag = torch.empty((n_u,), dtype=torch.int32, device=dev)
@@ -1518,7 +1499,50 @@ def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, 
         cands.n = torch.empty((n_u,), dtype=torch.int32, device=dev)
         N.call("trec_topk_cascade_floor", N.ptr(tau), N.ptr(uop.src), N.ptr(uop.stats), N.ptr(user_bias), N.ptr(gstats_all), kpad,
                n_u, N.ptr(cands.floor0), N.ptr(cands.flag), N.ptr(cands.n_flagged), N.ptr(cands.n))
-    elif uop.src is not None:
+        try:
+            cands.items = torch.empty((n_u, cands.cap, 2), dtype=torch.int32, device=dev)     # only the listed part is touched
+        except torch.cuda.OutOfMemoryError:
+            # (2 KB of list slots per user is a reservation, not traffic; on a device that cannot spare it the lists shrink
+            # to 64 slots -- users beyond them are flagged and re-done on their table column -- ADVICE r3)
+            cands.cap = 64
+            cands.items = torch.empty((n_u, cands.cap, 2), dtype=torch.int32, device=dev)
+    if pre:
+        # ---- the pre-refinement: lists of the users' k best superblocks, the bf16 launch over them, the sharper threshold.
+        # Default (tuning cascade_prerefine = 1): that launch also LISTS the candidates of those pairs (with the provisional floor
+        # tau8 - eps) and the pairs then leave the compaction's sight (table entry -inf, the bf16 maxima saved) -- nothing is refined
+        # twice.  cascade_prerefine = 2: maxima only, the entries marked +inf and refined again by the listing launch (A/B).
+        listed = 1 if lib.trec_get_tuning(b"cascade_prerefine", 1) == 1 else 0
+        n_cap_a = int(uop.n_real or n_u)
+        rcap_a = (4 * (n_cap_a * kk // n_sb + 1) + 2048 + 511) // 512 * 512
+        pre_ws = zero_block(n_sb, dev)                                   # row counts of the pre-refining launch
+        sel_sb = torch.empty((n_u, kk), dtype=torch.int32, device=dev)
+        pre_ok = torch.empty((n_u,), dtype=torch.int32, device=dev)
+        pre_rows = torch.empty((n_sb * rcap_a,), dtype=torch.int32, device=dev)        # only the listed part is touched
+        pre_vals = torch.empty((n_u, kk), dtype=torch.float32, device=dev) if listed else None
+        with _timed("topk_prerefine"):
+            N.call("trec_topk_prerefine_rows", N.ptr(sel), N.ptr(sel_max), kk, top_k, sb_per_chunk, n_sb, n_u, N.ptr(uop.src),
+                   rcap_a, N.ptr(sel_sb), N.ptr(pre_ws), N.ptr(pre_rows), N.ptr(pre_ok))
+        with _timed("score_gemm_blockmax_pre"):
+            if listed:
+                N.call("trec_score_gemm_refine_candidates", N.ptr(uop.bf16), N.ptr(iop.bf16), kpad, n_sb * rcap_a, n_i,
+                       N.ptr(user_bias), N.ptr(item_bias), sb_rows, N.ptr(pre_ws), N.ptr(pre_rows), N.ptr(table), stride,
+                       rcap_a // 512, N.ptr(cands.floor0), N.ptr(cands.n), N.ptr(cands.items), cands.cap, int(item_index_base),
+                       None, 0)
+            else:
+                N.call("trec_score_gemm_blockmax_grouped", N.ptr(uop.bf16), N.ptr(iop.bf16), kpad, n_sb * rcap_a, n_i,
+                       N.ptr(user_bias), N.ptr(item_bias), sb_rows, N.ptr(pre_ws), N.ptr(pre_rows), N.ptr(table), stride,
+                       rcap_a // 512)
+        with _timed("topk_prerefine"):
+            N.call("trec_topk_prerefine_tau", N.ptr(sel_sb), N.ptr(pre_ok), kk, N.ptr(table), stride, n_u, N.ptr(uop.src),
+                   N.ptr(uop.stats), N.ptr(user_bias), N.ptr(gstats_all), kpad, N.ptr(tau), listed, N.ptr(pre_vals),
+                   N.ptr(cands.floor0))
+        if listed:
+            cands.pre = (sel_sb, pre_vals)          # (the saved maxima go back into the columns of users re-done from the table)
+        if FILTER_DEBUG is not None:
+            FILTER_DEBUG.update({"prerefine_users_ok": int(pre_ok.sum().item()), "prerefine_rcap": rcap_a,
+                                 "prerefine_row_count_max": int(pre_ws.max().item()), "prerefine_listed": listed,
+                                 "prerefine_pairs": int((sel_sb >= 0).sum().item())})
+    if cands is None and uop.src is not None:
         tau.masked_fill_(uop.src < 0, float("inf"))     # rows without a source refine nothing (the table-driven tail: A/B reference)
     if one_pass:
         # one pass over the table: a fixed capacity per superblock, slots handed out by atomics (csrc/topk_cascade.hip)
@@ -1549,13 +1573,6 @@ def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, 
                 N.call("trec_topk_dense_users", N.ptr(table), n_sb, n_u, stride, N.ptr(tau), N.ptr(user_err), N.ptr(iop.sb_stats),
                        kpad, CASCADE_DENSE_USER_LIMIT if n_i >= CASCADE_MIN_ITEMS else 30, N.ptr(cands.floor0), N.ptr(cands.flag),
                        N.ptr(cands.n_flagged))             # (small catalogues: the k-th largest of few maxima keeps half the rows of anybody)
-            try:
-                cands.items = torch.empty((n_u, cands.cap, 2), dtype=torch.int32, device=dev)     # only the listed part is touched
-            except torch.cuda.OutOfMemoryError:
-                # (2 KB of list slots per user is a reservation, not traffic; on a device that cannot spare it the lists shrink
-                # to 64 slots -- users beyond them are flagged and re-done on their table column -- ADVICE r3)
-                cands.cap = 64
-                cands.items = torch.empty((n_u, cands.cap, 2), dtype=torch.int32, device=dev)
             if N.load().trec_get_tuning(b"cascade_wg_map", 1) != 0:
                 # only the workgroup slots that hold rows are launched (98k of the 1.9M of the [n_sb][rcap / 512] grid at 1M x 1M)
                 wg_cap = min(n_sb * (rcap // 512), max_pairs // 512 + n_sb + 1)
@@ -1921,9 +1938,18 @@ def _score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index
                 _debug_counts("candidates", cands.n)
             # ONE host read: the flagged-user counter (queued behind the finish kernel)
             n_bad = int(n_flagged.item())
+            if n_bad and cands.pre is not None:
+                # the pre-refined pairs of the users to re-do: their bf16 maxima return to the table (the compaction saw -inf there)
+                sel_sb, pre_vals = cands.pre
+                bad_u = torch.nonzero(flag, as_tuple=False).reshape(-1)
+                sb_b = sel_sb.index_select(0, bad_u).long()
+                hit = sb_b >= 0
+                blockmax[sb_b[hit], bad_u.reshape(-1, 1).expand_as(sb_b)[hit]] = pre_vals.index_select(0, bad_u)[hit]
             LAST_FILTER_STATS.clear()
             LAST_FILTER_STATS.update({"prefilter": "int8", "refined_rows": cascade_rows, "users": n_u, "flagged_users": n_bad,
                                       "tail": "candidate lists", "candidates_cap": cands.cap})
+            if cands.pre is not None:
+                LAST_FILTER_STATS["prerefined"] = "k best superblocks per user, listed"
             if CANDIDATE_STATS:                           # diagnostics (a reduction over the counters + a host read): off the product path
                 LAST_FILTER_STATS["candidates_per_user"] = float(cands.n.clamp(max=cands.cap).sum().item()) / \
                     max(1, int(uop.n_real or n_u))        # (per real user: the layout's rows without a source list nothing)
