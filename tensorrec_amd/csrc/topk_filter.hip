@@ -281,8 +281,8 @@ __global__ __launch_bounds__(256) void prerefine_rows_kernel(const int32_t* __re
 //     bound e, which need not cover eps;
 //   listed != 0 (it also LISTED their candidates, trec_score_gemm_refine_candidates with the provisional floor tau8 - eps): the
 //     bf16 maxima are saved to vals [n_users][k], the entries become -inf -- the compaction drops the pairs, nothing is refined
-//     twice -- and cand_floor[u] rises to tau - eps for the launches still to come (a user that lists nothing keeps +inf).  The
-//     caller puts vals back into the columns of the users it has to re-do from the table.
+//     twice.  The caller puts vals back into the columns of the users it has to re-do from the table.
+// Either way cand_floor[u] (nullable) rises to tau - eps for the launches still to come (a user that lists nothing keeps +inf).
 __global__ __launch_bounds__(256) void prerefine_tau_kernel(const int32_t* __restrict__ sel_sb, const int32_t* __restrict__ ok, int k,
                                                            float* __restrict__ table, int64_t stride, int64_t n_users,
                                                            const int32_t* __restrict__ src, const float2* __restrict__ ustats,
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void prerefine_tau_kernel(const int32_t* __res
             t = float_pred(float_pred(t));
             if (t > tau[u]) {
                 tau[u] = t;
-                if (listed && cand_floor[u] < INFINITY) {
+                if (cand_floor && cand_floor[u] < INFINITY) {
                     const float f = float_pred(float_pred(t - eps));           // the provisional floor of the launches to come
                     if (f > cand_floor[u]) cand_floor[u] = f;
                 }
@@ -1020,7 +1020,7 @@ extern "C" int trec_topk_prerefine_tau(const int32_t* sel_sb, const int32_t* ok,
 {
     TREC_REQUIRE(sel_sb && ok && table && user_stats && item_gstats && tau && k >= 1 && k <= 16 && stride >= n_users,
                  "trec_topk_prerefine_tau: bad arguments");
-    TREC_REQUIRE(!listed || (vals && cand_floor), "trec_topk_prerefine_tau: the listed form needs vals and cand_floor");
+    TREC_REQUIRE(!listed || vals, "trec_topk_prerefine_tau: the listed form needs vals");
     if (n_users == 0) return TREC_OK;
     hipLaunchKernelGGL(prerefine_tau_kernel, dim3((unsigned)ceil_div64(n_users, 256)), dim3(256), 0, (hipStream_t)stream, sel_sb, ok, k,
                        table, stride, n_users, src, (const float2*)user_stats, user_bias, item_gstats, kdim, tau, listed, vals,

@@ -1513,12 +1513,18 @@ def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, 
         # twice.  cascade_prerefine = 2: maxima only, the entries marked +inf and refined again by the listing launch (A/B).
         listed = 1 if lib.trec_get_tuning(b"cascade_prerefine", 1) == 1 else 0
         n_cap_a = int(uop.n_real or n_u)
-        rcap_a = (4 * (n_cap_a * kk // n_sb + 1) + 2048 + 511) // 512 * 512
+        rcap_a = (int(lib.trec_get_tuning(b"cascade_prerefine_cap_x", 2)) * (n_cap_a * kk // n_sb + 1) + 1024 + 511) // 512 * 512
         pre_ws = zero_block(n_sb, dev)                                   # row counts of the pre-refining launch
         sel_sb = torch.empty((n_u, kk), dtype=torch.int32, device=dev)
         pre_ok = torch.empty((n_u,), dtype=torch.int32, device=dev)
         pre_rows = torch.empty((n_sb * rcap_a,), dtype=torch.int32, device=dev)        # only the listed part is touched
         pre_vals = torch.empty((n_u, kk), dtype=torch.float32, device=dev) if listed else None
+        if listed and n_sb >= 32:
+            # users the int8 bound says nothing about (32 sampled superblocks under tau8) list nothing in the pre-refining launch
+            # either: flagged now, as the call after the compaction would
+            N.call("trec_topk_dense_users", N.ptr(table), n_sb, n_u, stride, N.ptr(tau), N.ptr(user_err), N.ptr(iop.sb_stats),
+                   kpad, CASCADE_DENSE_USER_LIMIT if n_i >= CASCADE_MIN_ITEMS else 30, N.ptr(cands.floor0), N.ptr(cands.flag),
+                   N.ptr(cands.n_flagged))
         with _timed("topk_prerefine"):
             N.call("trec_topk_prerefine_rows", N.ptr(sel), N.ptr(sel_max), kk, top_k, sb_per_chunk, n_sb, n_u, N.ptr(uop.src),
                    rcap_a, N.ptr(sel_sb), N.ptr(pre_ws), N.ptr(pre_rows), N.ptr(pre_ok))

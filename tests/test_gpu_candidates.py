@@ -26,7 +26,7 @@ def ops():
 @pytest.fixture
 def tuning():
     from tensorrec_amd import _native
-    defaults = {"cascade_candidates": 1, "cascade_candidates_cap": 256, "cascade_user_batches": 1}
+    defaults = {"cascade_candidates": 1, "cascade_candidates_cap": 256, "cascade_user_batches": 1, "cascade_prerefine": 1}
 
     def set_(name, value):
         assert name in defaults
@@ -73,10 +73,14 @@ def test_candidate_tail_is_exact_and_equals_the_table_tail(ops, tuning, d, biase
     assert np.array_equal(idx0, idx) and np.array_equal(vals0, vals)
 
 
-def test_candidate_lists_hold_what_they_must_and_nothing_twice(ops):
+@pytest.mark.parametrize("prerefine", [0, 1])
+def test_candidate_lists_hold_what_they_must_and_nothing_twice(ops, tuning, prerefine):
     """The lists behind one call, read back: every entry is an item of the catalogue listed once, with a bf16-path score at or
     above the user's provisional floor and within eps of the fp32 score; every item whose fp32 score exceeds the floor by eps
-    is listed (it lies in a refined pair: its score is above the k-th largest lower bound)."""
+    is listed (it lies in a refined pair: its score is above the k-th largest lower bound).  With the pre-refinement the floor
+    rises between the two listing launches: the first one's entries may lie below the FINAL floor (they are only more than needed),
+    everything that must be listed still is, and nothing is listed twice (the pre-refined pairs leave the compaction's sight)."""
+    tuning("cascade_prerefine", prerefine)
     rng = np.random.default_rng(5)
     n_u, n_i, d, k = 800, 300_000, 128, 10
     u = rng.standard_normal((n_u, d)).astype(np.float32)
@@ -103,7 +107,8 @@ def test_candidate_lists_hold_what_they_must_and_nothing_twice(ops):
         ids = items[r, :n[r], 0]
         sh = items[r, :n[r], 1].copy().view(np.float32)
         assert len(np.unique(ids)) == len(ids) and ids.min() >= 0 and ids.max() < n_i
-        assert (sh >= floor0[r]).all()
+        if not prerefine:
+            assert (sh >= floor0[r]).all()
         s = exact[perm[r]]
         eps = st[r, 1] * g[0] * 1.01 + st[r, 0] * g[1] + (d + 2) * 3e-7 * (st[r, 0] * g[0] * 1.01 + abs(ub[perm[r]]) + g[2])
         assert np.abs(sh - s[ids]).max() <= eps * 1.01
