@@ -516,13 +516,16 @@ def main():
         else "score_gemm_kernel (superblock-max epilogue)")
     roofline_bf16_stage = None
     if cascade and "score_gemm_blockmax_grouped" in dur:
-        rows = float(ops.LAST_FILTER_STATS.get("refined_rows", 0))
-        g_ms = per_step(dur["score_gemm_blockmax_grouped"])
+        # (superblock, user) pairs the bf16 kernel works on: the pre-refinement's k per user (its own launch) + the compaction's
+        rows = float(ops.LAST_FILTER_STATS.get("refined_rows", 0)) + float(ops.LAST_FILTER_STATS.get("prerefined_pairs", 0))
+        g_ms = per_step(dur["score_gemm_blockmax_grouped"]) + per_step(dur.get("score_gemm_blockmax_pre", [0.0]))
         g_tf = 2.0 * rows * ops.SUPERBLOCK_ROWS * kpad / (g_ms * 1e-3) / 1e12
         roofline_bf16_stage = {"kernel": "blockmax_bf16x16_kernel, grouped form (v_mfma_f32_16x16x32_bf16: bf16 maxima of the "
                                          "(superblock, user) pairs the int8 bound cannot rule out)", "bound": "mfma", "achieved": g_tf,
                                "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": g_tf / BF16_DENSE_PEAK_TFLOPS,
                                "avg_launch_ms": g_ms, "resident_rows": rows,
+                               "prerefine_launch_ms": per_step(dur.get("score_gemm_blockmax_pre", [0.0])),
+                               "prerefined_pairs": float(ops.LAST_FILTER_STATS.get("prerefined_pairs", 0)),
                                "refined_fraction_of_pairs": rows / (float(U) * ((n_local + ops.SUPERBLOCK_ROWS - 1) // ops.SUPERBLOCK_ROWS))}
     roofline = {"kernel": k2_label,
                 "bound": "mfma", "achieved": k2_tflops,

@@ -1955,7 +1955,8 @@ def _score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index
             LAST_FILTER_STATS.update({"prefilter": "int8", "refined_rows": cascade_rows, "users": n_u, "flagged_users": n_bad,
                                       "tail": "candidate lists", "candidates_cap": cands.cap})
             if cands.pre is not None:
-                LAST_FILTER_STATS["prerefined"] = "k best superblocks per user, listed"
+                # (at most: a slot whose superblock list was full stays with the compaction)
+                LAST_FILTER_STATS["prerefined_pairs"] = int(uop.n_real or n_u) * int(k)
             if CANDIDATE_STATS:                           # diagnostics (a reduction over the counters + a host read): off the product path
                 LAST_FILTER_STATS["candidates_per_user"] = float(cands.n.clamp(max=cands.cap).sum().item()) / \
                     max(1, int(uop.n_real or n_u))        # (per real user: the layout's rows without a source list nothing)
