@@ -72,7 +72,7 @@ for f in sorted(glob.glob("$OUT/${TAG}_pmc_*/**/*counter_collection.csv", recurs
         k=r["Kernel_Name"][:70]; agg[k][r["Counter_Name"]]+=float(r["Counter_Value"]); seen.add((k,r["Dispatch_Id"]))
     cnt=collections.Counter(k for k,_ in seen)
     for k in agg:
-        if any(x in k for x in ("score_gemm","blockmax","spmm","topk","select_blocks","collect_blocks","rows_","fill_groups","prep_","filter_","seg_","natscale","bias_i8")):
+        if any(x in k for x in ("score_gemm","blockmax","spmm","topk","select_blocks","collect_blocks","rows_","fill_groups","prep_","filter_","seg_","natscale","bias_i8","prerefine","finish","cascade_floor","dense_users")):
             out.write("%s | dispatches=%d | "%(k,cnt[k])+" ".join("%s=%.5g"%(c,v/cnt[k]) for c,v in sorted(agg[k].items()))+"\n")
 out.close(); print(open("$OUT/${TAG}_pmc_summary.txt").read())
 PY

@@ -1302,6 +1302,8 @@ def topk_user_batch(n_users, n_items, n_components, device, fraction=0.6, route=
     kpad = max(32, (int(n_components) + 31) // 32 * 32)
     if route == "cascade":
         per_user = 1.3 * (n_sb * (4 + 4 * CASCADE_ROW_CAPACITY) + 8 * kpad + 1024 + 8 * CASCADE_CANDIDATES + 256)
+    elif route == "wide":            # score_topk_filtered_wide: 1,024 candidate slots, their exact scores, masks and the merged lists
+        per_user = 1.3 * (n_sb * (4 + 4 * CASCADE_ROW_CAPACITY) + 8 * kpad + 1024 + 40 * WIDE_CANDIDATES + 16 * int(k))
     else:
         cap = int(N.query("trec_score_topk_capacity", int(k)))
         per_user = 1.3 * (n_sb * 4 + 6 * kpad + int(k) * kpad * 4 + 2 * (2 * int(k)) * cap * 8 + 1024)
@@ -1475,8 +1477,14 @@ def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, 
     sel_max = torch.empty((kk, n_u), dtype=torch.float32, device=dev) if (floor_exchange is not None or pre) else None
     tau = torch.empty((n_u,), dtype=torch.float32, device=dev)
     with _timed("topk_select_blocks"):
-        N.call("trec_topk_select_blocks", N.ptr(chunk_top), n_ch * top_k, n_u, stride, kk, N.ptr(sel), N.ptr(sel_max),
-               N.ptr(tau))
+        if kk <= 16:
+            N.call("trec_topk_select_blocks", N.ptr(chunk_top), n_ch * top_k, n_u, stride, kk, N.ptr(sel), N.ptr(sel_max),
+                   N.ptr(tau))
+        else:
+            # k up to 64 (score_topk_filtered_wide): the k-th largest entry of the UNION of the chunks' 16-entry lists -- at most the
+            # k-th largest lower bound of the column, and still k distinct superblocks that each hold an item at or above it
+            N.call("trec_topk_select_blocks_ex", N.ptr(chunk_top), n_ch * top_k, n_u, stride, kk, kk, N.ptr(sel), N.ptr(sel_max),
+                   N.ptr(tau))
     if floor_exchange is not None:
         tau = floor_exchange(sel_max).contiguous()
     # the counters this call starts from, as ONE zeroed block: status int64 [3] | n_flagged | row_count [n_sb]
@@ -1513,8 +1521,14 @@ def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, 
         # twice.  cascade_prerefine = 2: maxima only, the entries marked +inf and refined again by the listing launch (A/B).
         listed = 1 if lib.trec_get_tuning(b"cascade_prerefine", 1) == 1 else 0
         n_cap_a = int(uop.n_real or n_u)
-        rcap_a = (int(lib.trec_get_tuning(b"cascade_prerefine_cap_x", 2)) * (n_cap_a * kk // n_sb + 1) + 1024 + 511) // 512 * 512
-        pre_ws = zero_block(n_sb, dev)                                   # row counts of the pre-refining launch
+        if listed:
+            # the compaction's own capacity (half of the users per superblock: on fitted / Zipf catalogues the k best superblocks of
+            # most users are the same few popular ones) -- only the workgroup slots that hold rows are launched (wg_map below)
+            rcap_frac_a = lib.trec_get_tuning(b"cascade_rcap_pct", int(100 * CASCADE_ROW_CAPACITY)) / 100.0
+            rcap_a = (int(rcap_frac_a * n_cap_a) + 511) // 512 * 512 + 512
+        else:
+            rcap_a = (2 * (n_cap_a * kk // n_sb + 1) + 1024 + 511) // 512 * 512
+        pre_ws = zero_block(n_sb + 1, dev)                               # row counts of the pre-refining launch (+ one empty row: idle slots)
         sel_sb = torch.empty((n_u, kk), dtype=torch.int32, device=dev)
         pre_ok = torch.empty((n_u,), dtype=torch.int32, device=dev)
         pre_rows = torch.empty((n_sb * rcap_a,), dtype=torch.int32, device=dev)        # only the listed part is touched
@@ -1528,12 +1542,19 @@ def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, 
         with _timed("topk_prerefine"):
             N.call("trec_topk_prerefine_rows", N.ptr(sel), N.ptr(sel_max), kk, top_k, sb_per_chunk, n_sb, n_u, N.ptr(uop.src),
                    rcap_a, N.ptr(sel_sb), N.ptr(pre_ws), N.ptr(pre_rows), N.ptr(pre_ok))
+        if listed:
+            # occupied workgroup slots only: at most pairs / 512 + one partial slot per superblock; the entries the map kernel does
+            # not reach point at the empty extra row
+            n_wgs_a = n_cap_a * kk // 512 + n_sb + 1
+            wg_start_a = torch.empty((n_sb + 1,), dtype=torch.int32, device=dev)
+            wg_map_a = torch.full((n_wgs_a,), n_sb * (rcap_a // 512), dtype=torch.int32, device=dev)
+            N.call("trec_topk_rows_wg_map", N.ptr(pre_ws), n_sb, rcap_a // 512, N.ptr(wg_start_a), N.ptr(wg_map_a), n_wgs_a)
         with _timed("score_gemm_blockmax_pre"):
             if listed:
                 N.call("trec_score_gemm_refine_candidates", N.ptr(uop.bf16), N.ptr(iop.bf16), kpad, n_sb * rcap_a, n_i,
                        N.ptr(user_bias), N.ptr(item_bias), sb_rows, N.ptr(pre_ws), N.ptr(pre_rows), N.ptr(table), stride,
                        rcap_a // 512, N.ptr(cands.floor0), N.ptr(cands.n), N.ptr(cands.items), cands.cap, int(item_index_base),
-                       None, 0)
+                       N.ptr(wg_map_a), n_wgs_a)
             else:
                 N.call("trec_score_gemm_blockmax_grouped", N.ptr(uop.bf16), N.ptr(iop.bf16), kpad, n_sb * rcap_a, n_i,
                        N.ptr(user_bias), N.ptr(item_bias), sb_rows, N.ptr(pre_ws), N.ptr(pre_rows), N.ptr(table), stride,
@@ -1546,7 +1567,7 @@ def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, 
             cands.pre = (sel_sb, pre_vals)          # (the saved maxima go back into the columns of users re-done from the table)
         if FILTER_DEBUG is not None:
             FILTER_DEBUG.update({"prerefine_users_ok": int(pre_ok.sum().item()), "prerefine_rcap": rcap_a,
-                                 "prerefine_row_count_max": int(pre_ws.max().item()), "prerefine_listed": listed,
+                                 "prerefine_row_count_max": int(pre_ws[:n_sb].max().item()), "prerefine_listed": listed,
                                  "prerefine_pairs": int((sel_sb >= 0).sum().item())})
     if cands is None and uop.src is not None:
         tau.masked_fill_(uop.src < 0, float("inf"))     # rows without a source refine nothing (the table-driven tail: A/B reference)
@@ -2072,6 +2093,100 @@ def _redo_flagged(uop, iop, blockmax, flag, n_bad, n_sb, k, user_bias, item_bias
         ov[rows_of(bad)] = fv
         oi[rows_of(bad)] = fi
     return ov, oi
+
+
+WIDE_K_MAX = 64                   # largest k of score_topk_filtered_wide
+WIDE_CANDIDATES = 1024            # candidate slots per user there (trec_topk_merge takes up to 1024 entries)
+
+
+def score_topk_filtered_wide(uop, iop, k, user_bias=None, item_bias=None, item_index_base=0, sb_rows=None):
+    """EXACT fp32 top-k for 17 <= k <= 64 through the int8 -> bf16 cascade (k > 16 used to take the all-fp32 MFMA
+    path, ~17x the cascade's time per pair): stages 0 and 1 of score_topk_filtered as they are -- the int8 pass over every pair,
+    tau = the k-th largest of the chunks' lower-bound lists, the compaction, the bf16 refining launch that LISTS every item able to
+    reach the top-k (1,024 slots per user here) -- and a finish made of library calls: the reference's fp32 chain on every listed
+    pair (trec_pair_score_exact) and the k best of each list (trec_topk_merge).  A list holds every item whose fp32 score reaches
+    the k-th best (that argument does not depend on k), so its k best ARE the answer.  Users whose list is incomplete
+    (more candidates than slots, no usable bound) are re-done from exact fp32 score slabs and exact ranks; if the int8 bound is
+    too loose for the catalogue nobody is listed and everybody is.  ``uop``: score_prep_filter(sort_users=True, k=k).  Single process.
+    Returns (values [n_users, k], ids [n_users, k]) in the caller's order, bit-identical to score_topk(..., DTYPE_F32)."""
+    kk = int(k)
+    if not 16 < kk <= WIDE_K_MAX:
+        raise ValueError("score_topk_filtered_wide covers 17 <= k <= %d" % WIDE_K_MAX)
+    if uop.kpad not in (64, 128) or iop.gstats is None or uop.wg_rows is None:
+        raise ValueError("score_topk_filtered_wide needs class-sorted users (sort_users=True), kpad 64 / 128 and item gstats")
+    dev = uop.bf16.device
+    sb_rows = int(sb_rows or SUPERBLOCK_ROWS)
+    n_u, n_i, kpad = uop.n, iop.n, uop.kpad
+    n_sb = (n_i + sb_rows - 1) // sb_rows
+    n_real = int(uop.n_real)
+    if user_bias is None:
+        ub = None
+    elif uop.bias_sorted is not None and uop.bias_ref is user_bias:
+        ub = uop.bias_sorted
+    else:
+        ub = user_bias.reshape(-1).index_select(0, uop.perm).masked_fill_(uop.pad, 0.0)
+    ib = _f32c(item_bias.detach()).reshape(-1) if item_bias is not None else None
+    rows_wg = N.query("trec_score_rows_per_workgroup", DTYPE_BF16, kpad)
+    rblocks = (n_u + rows_wg - 1) // rows_wg
+    n_chunks = max(-(-kk // 16) + 1, min(n_sb, -(-32 * 768 // rblocks)))        # k distinct entries need ceil(k / 16) lists
+    LAST_FILTER_STATS.clear()
+    lib = N.load()
+    saved_cap = lib.trec_get_tuning(b"cascade_candidates_cap", CASCADE_CANDIDATES)
+    table = cands = None
+    bad = None
+    if n_sb >= kk:
+        lib.trec_set_tuning(b"cascade_candidates_cap", WIDE_CANDIDATES)
+        try:
+            table, _stride, (rows, overflow), _tau, cands = _cascade_stage1(uop, iop, kk, ub, ib, sb_rows, n_sb, n_chunks, None, None,
+                                                                             iop.gstats, item_index_base)
+        finally:
+            lib.trec_set_tuning(b"cascade_candidates_cap", saved_cap)
+        del table
+    ov = torch.empty((n_u, kk), dtype=torch.float32, device=dev)
+    oi = torch.empty((n_u, kk), dtype=torch.int32, device=dev)
+    real = uop.src >= 0
+    if cands is None:
+        bad = real.clone()                                  # (too loose, or fewer superblocks than k: the fp32 path for everybody)
+        LAST_FILTER_STATS["prefilter"] = "int8 (too loose: fp32 path)"
+    else:
+        n = cands.n
+        complete = real & (cands.flag == 0) & (n <= cands.cap) & (n >= kk) & torch.isfinite(cands.floor0)
+        bad = real & ~complete
+        ids = cands.items[:, :, 0]
+        slot = (torch.arange(cands.cap, device=dev, dtype=torch.int32).reshape(1, -1) < n.clamp(max=cands.cap).reshape(-1, 1)) & \
+            complete.reshape(-1, 1)
+        pr = torch.nonzero(slot, as_tuple=False)
+        xu32 = pr[:, 0].to(torch.int32).contiguous()
+        xi32 = ids[slot].contiguous()
+        with _timed("topk_wide_finish"):
+            exact = pair_scores_exact(uop.f32, iop.f32, kpad, uop.d, xu32, xi32, ub, ib, MODE_DOT,
+                                      item_index_base=item_index_base)
+            vals = torch.full((n_u, cands.cap), float("-inf"), dtype=torch.float32, device=dev)
+            vals[slot] = exact
+            idm = torch.where(slot, ids, torch.full_like(ids, -1)).contiguous()
+            mv, mi = topk_merge(vals, idm, kk)
+        ov.copy_(mv)
+        oi.copy_(mi)
+        LAST_FILTER_STATS.update({"prefilter": "int8", "refined_rows": int(rows), "tail": "candidate lists, wide finish",
+                                  "candidates_cap": cands.cap,
+                                  "candidates_per_user": float(n.clamp(max=cands.cap)[complete].float().mean().item()) if bool(complete.any()) else 0.0})
+    n_bad = int(bad.sum().item())
+    if n_bad:
+        rows_b = torch.nonzero(bad, as_tuple=False).reshape(-1)
+        # (the fused fp32 top-k kernels hold 16 entries per list: these users take exact fp32 score slabs + exact ranks)
+        step = max(1, (1 << 28) // max(1, n_i))
+        with _timed("topk_filter_fallback"):
+            for b0 in range(0, n_bad, step):
+                rb = rows_b[b0:b0 + step]
+                slab = score_store(uop.f32[rb].contiguous(), iop.f32, DTYPE_F32, kpad, ub[rb].contiguous() if ub is not None else None,
+                                   ib, MODE_DOT)
+                fv, fi = topk_from_scores(slab, kk)
+                ov[rb] = fv
+                oi[rb] = torch.where(fi >= 0, fi + int(item_index_base), fi)
+                del slab
+    pos = uop.pos.long()                                    # the caller's rows
+    LAST_FILTER_STATS.update({"users": n_real, "layout_rows": int(n_u), "flagged_users": n_bad, "route": "cascade, k up to %d" % WIDE_K_MAX})
+    return ov.index_select(0, pos), oi.index_select(0, pos)
 
 
 EUCLID_CANDIDATES = 16       # K' of the Euclidean route: the cascade's largest list

@@ -1170,13 +1170,18 @@ class TensorRec(object):
                            1 <= k <= ops.EUCLID_CANDIDATES - 4 and n_items_min >= ops.TWO_STAGE_MIN_ITEMS and
                            self.n_components <= 256 and
                            ops.N.load().trec_get_tuning(b"topk_euclid_filter", 1) != 0)
+        # 17 <= k <= 64 on a catalogue the cascade runs on: the same int8 -> bf16 stages, 1,024 candidate slots per user and a finish
+        # made of library calls (ops.score_topk_filtered_wide); single process (item shards keep the fp32 two-stage path)
+        wide = (dtype == ops.DTYPE_F32 and graph.engine_mode == ops.MODE_DOT and 16 < k <= ops.WIDE_K_MAX and not sharded and
+                ops.cascade_prefilter_for(self.n_components, itf.shape[0]) == "int8" and
+                ops.N.load().trec_get_tuning(b"topk_bf16_filter", 1) != 0 and ops.i8_user_classes_enabled())
         stats_exchange = (lambda g: sharding.all_reduce_max(g, self.process_group)) if sharded else None
         # ... and on a catalogue of >= 262,144 items an int8 MFMA pass (exact integer arithmetic, proven bound) first decides
         # which (superblock, user) pairs the bf16 stage has to look at at all (csrc/topk_cascade.hip)
         prefilter = ops.cascade_prefilter_for(self.n_components, n_items_min * (dist.get_world_size(self.process_group) if sharded else 1)) \
             if filtered else None
         if user_batch_size is None:
-            route = "cascade" if (filtered or euclid_filtered) else "two_stage"
+            route = "cascade" if (filtered or euclid_filtered) else ("wide" if wide else "two_stage")
             user_batch_size = ops.topk_user_batch(uf.shape[0], itf.shape[0], self.n_components, self._store.device,
                                                   route=route, k=k)
             if sharded:                  # every rank walks the SAME user batches (each batch holds collectives): the smallest wins
@@ -1217,9 +1222,9 @@ class TensorRec(object):
         with torch.no_grad(), variable_scope(self._store):
             user_reprs, _, item_repr, user_bias, item_bias, _ = self._representations(uf, itf)
             ib = item_bias.contiguous() if self.biased else None
-            if filtered:
+            if filtered or wide:
                 i_f = ops.score_prep_filter(item_repr, normalize=graph.engine_normalize, bias=ib, want_gstats=True)
-            else:
+            if not filtered:
                 i_op, i_sq, kpad = ops.score_prep(item_repr, dtype, normalize=graph.engine_normalize, want_sqnorm=want_sq)
             s = 0
             while s < uf.shape[0]:
@@ -1227,8 +1232,8 @@ class TensorRec(object):
                 try:
                     v, i = self._topk_user_batch(s, e, user_reprs, item_repr, user_bias, ib, k, graph, dtype, want_sq, filtered,
                                                  euclid_filtered, prefilter, sharded, method, floor_exchange, stats_exchange,
-                                                 item_offset, i_f if filtered else None,
-                                                 None if filtered else (i_op, i_sq, kpad))
+                                                 item_offset, i_f if (filtered or wide) else None,
+                                                 None if filtered else (i_op, i_sq, kpad), wide=wide)
                 except torch.cuda.OutOfMemoryError:
                     # the workspace model of ops.topk_user_batch was too optimistic for this device's state: half the users per
                     # pass (item shards: the ranks walk the same batches and a rank cannot shrink alone -- the error stands)
@@ -1246,7 +1251,7 @@ class TensorRec(object):
         return _to_host(vals), _to_host(idx)
 
     def _topk_user_batch(self, s, e, user_reprs, item_repr, user_bias, ib, k, graph, dtype, want_sq, filtered, euclid_filtered,
-                         prefilter, sharded, method, floor_exchange, stats_exchange, item_offset, i_f, i_ops):
+                         prefilter, sharded, method, floor_exchange, stats_exchange, item_offset, i_f, i_ops, wide=False):
         """Users [s, e) of predict_top_k: every taste's exact top-k, merged, and (item shards) exchanged."""
         from . import sharding
         import torch.distributed as dist
@@ -1258,6 +1263,10 @@ class TensorRec(object):
             if euclid_filtered:
                 per_taste.append(ops.score_topk_euclid_filtered(user_repr[s:e], item_repr, k, ub, ib,
                                                                 item_index_base=int(item_offset)))
+                continue
+            if wide:
+                u_f = ops.score_prep_filter(user_repr[s:e], normalize=graph.engine_normalize, sort_users=True, k=k, user_bias=ub)
+                per_taste.append(ops.score_topk_filtered_wide(u_f, i_f, k, ub, ib, item_index_base=int(item_offset)))
                 continue
             if filtered:
                 u_f = ops.score_prep_filter(user_repr[s:e], normalize=graph.engine_normalize,

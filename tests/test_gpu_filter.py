@@ -376,3 +376,51 @@ def test_wide_pass_tier_two_respects_the_collect_limit_above_two_million_items(o
     rv, ri = O.topk_rows(ref, k)
     assert np.array_equal(idx.cpu().numpy(), ri) and np.array_equal(vals.cpu().numpy(), rv)
     assert stats["flagged_users"] >= 1, stats
+
+
+# ---- 17 <= k <= 64 through the cascade (ops.score_topk_filtered_wide) ------------------------------------------------------------
+@pytest.mark.parametrize("d,n_u,n_i,k,biased", [(128, 700, 300_000, 17, True), (128, 500, 280_000, 64, True), (64, 400, 270_000, 32, False),
+                                                (128, 300, 40_000, 40, True), (128, 260, 1_000_000, 64, True)])
+def test_wide_k_topk_through_the_cascade_is_the_oracles(ops, d, n_u, n_i, k, biased):
+    """k above the 16 slots of the fused lists: the cascade's int8 / bf16 stages with tau = the k-th largest of the chunks'
+    lower-bound lists, 1,024 candidate slots per user, the reference chain on every listed pair and the k best of each list.
+    Values and ids == the oracle's (tf.nn.top_k of recommendation_graphs.py:80 over prediction_graphs.py:49-50)."""
+    rng = np.random.default_rng(d + n_u + k)
+    u = rng.standard_normal((n_u, d)).astype(np.float32)
+    v = (rng.standard_normal((n_i, d)) * rng.uniform(0.8, 1.2, (n_i, 1))).astype(np.float32)
+    ub = (0.1 * rng.standard_normal(n_u)).astype(np.float32) if biased else None
+    ib = (0.1 * rng.standard_normal(n_i)).astype(np.float32) if biased else None
+    du, dv = dev(u), dev(v)
+    dub = dev(ub) if biased else None
+    dib = dev(ib) if biased else None
+    uop = ops.score_prep_filter(du, sort_users=True, k=k, user_bias=dub)
+    iop = ops.score_prep_filter(dv, bias=dib, want_gstats=True)
+    vals, idx = ops.score_topk_filtered_wide(uop, iop, k, dub, dib, item_index_base=500)
+    stats = dict(ops.LAST_FILTER_STATS)
+    rv, ri = O.topk_rows(O.score_dense_exact(u, v, ub, ib), k)
+    assert np.array_equal(idx.cpu().numpy(), ri + 500) and np.array_equal(vals.cpu().numpy(), rv), stats
+    # (k = 64 of 547 superblocks: the 64th largest lower bound keeps more than 45 % of all pairs -- "too loose", score slabs answer;
+    # from ~1,000 superblocks on the lists do)
+    if n_i >= 262_144 and (k <= 32 or n_i >= 1_000_000):
+        assert stats["prefilter"] == "int8" and stats["flagged_users"] <= n_u // 10, stats       # the lists answered, not the fallback
+
+
+def test_wide_k_predict_top_k_through_the_public_api(ops):
+    """TensorRec.predict_top_k(k=40) on a catalogue the cascade runs on takes the wide route and equals the dense prediction's order."""
+    import scipy.sparse as sp
+    import tensorrec_amd as T
+    rng = np.random.RandomState(6)
+    n_u, n_i, d = 180, 270_000, 64
+    uf = sp.random(n_u, 30, density=0.3, random_state=rng, format="csr", dtype=np.float32)
+    itf = sp.hstack([sp.identity(n_i, format="csr", dtype=np.float32),
+                     sp.random(n_i, 4, density=0.3, random_state=rng, format="csr", dtype=np.float32)], format="csr")
+    model = T.TensorRec(n_components=d, seed=3)
+    model.build(uf.shape[1], itf.shape[1])
+    w = model.get_weights()
+    w["item_feature_biases"] = (0.05 * rng.standard_normal(w["item_feature_biases"].shape)).astype(np.float32)
+    model.set_weights(w)
+    vals, idx = model.predict_top_k(uf, itf, k=40)
+    assert "cascade, k up to" in str(ops.LAST_FILTER_STATS.get("route", "")), dict(ops.LAST_FILTER_STATS)
+    scores = model.predict(uf, itf)
+    rv, ri = O.topk_rows(scores, 40)
+    assert np.array_equal(idx, ri) and np.array_equal(vals, rv)
