@@ -275,3 +275,24 @@ def test_cascade_user_batches_is_off_by_default_and_only_for_the_single_process_
         assert ops.cascade_user_batches(u, i, "int8", None, None) == 1
     finally:
         _native.set_tuning("cascade_user_batches", 1)
+
+
+def test_ops_facade_forwards_module_switches():
+    """tensorrec_amd.ops re-exports ops_base / ops_topk; a switch set on the facade (bench.py, the tests and the scripts do
+    ``ops.KERNEL_EVENTS = []``) must reach the module whose functions read it."""
+    from tensorrec_amd import ops, ops_base, ops_topk
+    assert ops._cascade_stage1 is ops_topk._cascade_stage1 and ops.wmrb_fused_step is ops_base.wmrb_fused_step
+    assert ops.LAST_FILTER_STATS is ops_topk.LAST_FILTER_STATS
+    old = ops_topk.FILTER_CANDIDATES
+    try:
+        ops.KERNEL_EVENTS = []
+        assert ops_base.KERNEL_EVENTS is ops.KERNEL_EVENTS
+        ops.FILTER_DEBUG = {}
+        assert ops_topk.FILTER_DEBUG is ops.FILTER_DEBUG
+        ops.FILTER_CANDIDATES = 7
+        assert ops_topk.FILTER_CANDIDATES == 7
+    finally:
+        ops.KERNEL_EVENTS = None
+        ops.FILTER_DEBUG = None
+        ops.FILTER_CANDIDATES = old
+    assert ops_base.KERNEL_EVENTS is None and ops_topk.FILTER_DEBUG is None
