@@ -404,16 +404,17 @@ TOPK_USER_BATCH_MAX = 4_194_304     # users per pass at most, whatever the free 
 def topk_user_batch(n_users, n_items, n_components, device, fraction=0.6, route="cascade", k=10):
     """Users per pass of predict_top_k when the caller names no batch size: what ``fraction`` of the FREE device memory holds.
     ``route`` "cascade" (the exact top-k through the int8 / bf16 filters): per user a column of the superblock-maxima table (4 B
-    per superblock), half a column of user-list slots (CASCADE_ROW_CAPACITY x 4 B), the operands three times over (fp32 + bf16 +
-    int8), ~1 KB of chunk lists and CASCADE_CANDIDATES x 8 B of candidate slots.  Any other route (score_topk_two_stage: bf16
+    per superblock), two half columns of user-list slots (CASCADE_ROW_CAPACITY x 4 B each: pre-refinement and compaction), the
+    operands three times over (fp32 + bf16 + int8), ~1 KB of chunk lists and CASCADE_CANDIDATES x 8 B of candidate slots;
+    "wide" (17 <= k <= 64): 1,024 candidate slots with their exact scores and masks.  Any other route (score_topk_two_stage: bf16
     precision, Euclidean with k > 12 or several tastes, the filters switched off): the table column, the operand once, the
     gathered operand of the k selected superblocks (k x kpad x 4 B) and the stage-2 lists (2 k parts x capacity x 8 B, twice) --
     12-20 KB per user at k = 16.  30 % on top for the allocator.  Never below 65,536 (the old fixed default) and
     never above TOPK_USER_BATCH_MAX."""
     n_sb = (int(n_items) + SUPERBLOCK_ROWS - 1) // SUPERBLOCK_ROWS
     kpad = max(32, (int(n_components) + 31) // 32 * 32)
-    if route == "cascade":
-        per_user = 1.3 * (n_sb * (4 + 4 * CASCADE_ROW_CAPACITY) + 8 * kpad + 1024 + 8 * CASCADE_CANDIDATES + 256)
+    if route == "cascade":           # (two user lists per superblock since round 5: the pre-refinement's and the compaction's)
+        per_user = 1.3 * (n_sb * (4 + 8 * CASCADE_ROW_CAPACITY) + 8 * kpad + 1024 + 8 * CASCADE_CANDIDATES + 256 + 12 * int(k))
     elif route == "wide":            # score_topk_filtered_wide: 1,024 candidate slots, their exact scores, masks and the merged lists
         per_user = 1.3 * (n_sb * (4 + 4 * CASCADE_ROW_CAPACITY) + 8 * kpad + 1024 + 40 * WIDE_CANDIDATES + 16 * int(k))
     else:
