@@ -327,7 +327,9 @@ __global__ __launch_bounds__(256) void prerefine_tau_kernel(const int32_t* __res
         if (s[j] >= 0) table[(int64_t)s[j] * stride + u] = mark;
 }
 
+#ifndef FILTER_RB
 #define FILTER_RB 8          // survivors re-scored per round (their fp32 rows staged in LDS)
+#endif
 // The second half of the finish kernels: ``total`` (<= FILTER_CMAX) survivors' item ids sit in cand[] (LDS of this wave), the
 // user's row in registers uw.  Exact fp32 scores by the reference's k-ordered fmaf chain, then (s + b_u) + b_i, then the k
 // best by (value desc, index asc) to ov / oi.
