@@ -227,6 +227,28 @@ def test_int8_table_is_exact_integer_arithmetic_and_bound_holds(ops):
     for c in range(n_ch):
         ref = -np.sort(-lb[c * spc:(c + 1) * spc], axis=0)[:10]
         assert np.array_equal(ct[c][:ref.shape[0]], ref) and np.all(ct[c][ref.shape[0]:] == -np.inf)
+    # the TAGGED lists (top_k | 0x100, the pre-refinement's input): every entry is a lower bound at most 2^-11 of its size below the
+    # untagged one, and its low 12 bits name the superblock (inside the chunk) it came from; the table does not change
+    table_t = torch.empty((n_sb, n_u), dtype=torch.float32, device="cuda")
+    ctop_t = torch.empty((n_ch * 10, n_u), dtype=torch.float32, device="cuda")
+    N.call("trec_score_gemm_blockmax_i8", N.ptr(uop.i8), N.ptr(iop.i8), d, n_u, n_i, N.ptr(dub), N.ptr(iop.bias_q),
+           N.ptr(iop.scales), N.ptr(iop.sb_stats), sb, n_chunks, N.ptr(table_t), n_u, N.ptr(uerr), N.ptr(ctop_t), 10 | 0x100, None, None, 0)
+    assert np.array_equal(table_t.cpu().numpy(), got)
+    tg = ctop_t.cpu().numpy().reshape(n_ch, 10, n_u)
+    bits = tg.view(np.int32).astype(np.int64)
+    key = np.where(bits >= 0, bits, -(bits & 0x7FFFFFFF))                     # the monotone integer key of lb_tag (score_common.hpp)
+    tag = key & 0xFFF
+    for c in range(n_ch):
+        n_here = min(10, lb[c * spc:(c + 1) * spc].shape[0])
+        t, r = tg[c][:n_here], ct[c][:n_here]
+        assert np.all(t <= r) and np.all(r - t <= np.abs(r) * 2.0 ** -10 + 1e-30)
+        assert np.all(tg[c][n_here:] == -np.inf)
+        # the tagged superblock's own (untagged) lower bound stands right above the entry; lists sorted by tagged value may order two
+        # bounds within 2^-11 of each other differently, so the comparison is per entry, and the smallest source is (nearly) the 10th
+        src = lb[c * spc + tag[c][:n_here], np.arange(n_u)[None, :]]
+        assert np.all(t <= src) and np.all(src - t <= np.abs(src) * 2.0 ** -10 + 1e-30), c
+        assert np.all(src.min(axis=0) >= r[-1] - np.abs(r[-1]) * 2.0 ** -10 - 1e-30), c
+        assert all(len(np.unique(tag[c][:n_here, j])) == n_here for j in range(0, n_u, 37))     # distinct superblocks per user
     # the bound: e(u, s) against the observed |int8 score - fp32 score| of every item of the superblock
     s8 = s_int.astype(np.float64) * sp_row[None, :].astype(np.float64) + ub[:, None]
     s32 = O.score_dense_exact(u, v, ub, ib).astype(np.float64)
