@@ -490,6 +490,16 @@ int trec_group_pairs_by_item_staged(const int32_t* xu, const int32_t* xi, int64_
                                     const int32_t* ranks, const float* values_in, void* staging, int64_t staging_bytes,
                                     int32_t window_log2, void* stream);
 
+/* Grouping by item WITHOUT ranks (csrc/segment.hip, round 5): bins of 4,096 items; tiles of 8,192 pairs sorted by bin in LDS and
+ * written out run by run; ONE workgroup per bin counts, scans (= indptr of its items) and places.  No global atomic per pair: the
+ * fused WMRB kernel then needs no histogram (sample_hist = NULL).  For pair lists roughly uniform over the items -- the sampled pairs
+ * of tensorrec.py:298-302, whose item-side gradient is the gather of trec_spmm_csr_packed over these entries.
+ * trec_group_pairs_binned_bytes: workspace bytes, 0 = size not covered (more than 2M items, fewer than 2^22 pairs). */
+int64_t trec_group_pairs_binned_bytes(int64_t n_pairs, int64_t n_items);
+int trec_group_pairs_by_item_binned(const int32_t* xu, const int32_t* xi, const float* values, int64_t n_pairs, int32_t pairs_per_user,
+                                    int64_t n_items, void* workspace, int64_t workspace_bytes, int64_t* indptr_t, int32_t* entries,
+                                    void* stream);
+
 /* ---- K4: ranks ----------------------------------------------------------------------------------------------
  * rank_predictions, recommendation_graphs.py:73-82 (double tf.nn.top_k) as an exact count; int32, 1 = best. */
 int trec_rank_rows(const float* scores, int64_t n_users, int64_t n_items, int64_t ld_scores, int32_t* ranks,

@@ -20,7 +20,7 @@ _vp, _i32, _i64, _u32, _u64, _f = (ctypes.c_void_p, ctypes.c_int32, ctypes.c_int
                                    ctypes.c_uint64, ctypes.c_float)
 
 _RETURNS_I64 = ("trec_csr_split_workspace_bytes", "trec_rank_rows_workspace_bytes", "trec_user_prep_alloc_rows",
-                "trec_user_prep_workspace_bytes", "trec_group_pairs_staged_bytes")      # sizing queries that return a byte count
+                "trec_user_prep_workspace_bytes", "trec_group_pairs_staged_bytes", "trec_group_pairs_binned_bytes")      # sizing queries that return a byte count
 
 # name -> argtypes, in the order of include/tensorrec_hip.h
 SIGNATURES = {
@@ -116,6 +116,8 @@ SIGNATURES = {
     "trec_group_pairs_lds_runs": [_i64, _i64],
     "trec_group_pairs_by_item_lds": [_vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "trec_group_pairs_staged_bytes": [_i64, _i32],
+    "trec_group_pairs_binned_bytes": [_i64, _i64],
+    "trec_group_pairs_by_item_binned": [_vp, _vp, _vp, _i64, _i32, _i64, _vp, _i64, _vp, _vp, _vp],
     "trec_group_pairs_by_item_staged": [_vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp],
     "trec_rank_rows": [_vp, _i64, _i64, _i64, _vp, _i64, _vp],
     "trec_rank_rows_workspace_bytes": [_i64, _i64],

@@ -701,6 +701,9 @@ class _WMRB(torch.autograd.Function):
         return dp, ds, None, None
 
 
+GROUP_BINNED_MIN_PAIRS = 1 << 24     # sampled pairs from which the rank-free binned grouping replaces histogram atomics + ranked fill
+
+
 def wmrb_fused_supported(n_sampled, interactions, d):
     """Can the one-pass WMRB step (csrc/wmrb_fused.hip) run this shape?  (LDS holds S + max interactions-per-user rows.)"""
     if not N.load().trec_get_tuning(b"wmrb_fused", 1):
@@ -731,8 +734,18 @@ def wmrb_fused_step(user_in, item_in, user_bias, item_bias, interactions, sample
     weight = interactions.balanced_weight() if balanced else None
     samples = samples.to(torch.int32).contiguous()
     xs = samples.reshape(-1)
-    ws32 = torch.zeros((2 * n_items,), dtype=torch.int32, device=dev)     # [sample histogram | cursors] of the sort below
-    ranks = torch.empty((n_users, S), dtype=torch.int32, device=dev)
+    # very many sampled pairs: grouped by item through a two-level LDS partition that needs no ranks (csrc/segment.hip, "binned") --
+    # the fused kernel then issues no histogram atomics at all; otherwise the histogram rides in the fused kernel and the ranks its
+    # atomics return make the fill atomic-free
+    binned_bytes = 0
+    if xs.numel() >= GROUP_BINNED_MIN_PAIRS and not _LOCAL.deterministic_grouping and \
+            N.load().trec_get_tuning(b"group_pairs_binned", 1) != 0:
+        binned_bytes = int(N.query("trec_group_pairs_binned_bytes", int(xs.numel()), int(n_items)))
+    if binned_bytes > 0:
+        ws32 = ranks = None
+    else:
+        ws32 = torch.zeros((2 * n_items,), dtype=torch.int32, device=dev)     # [sample histogram | cursors] of the sort below
+        ranks = torch.empty((n_users, S), dtype=torch.int32, device=dev)
     with _timed("wmrb_fused_step"):
         N.call("trec_wmrb_fused_step", N.ptr(u), N.ptr(v), N.ptr(ub), N.ptr(ib), N.ptr(interactions.indptr),
                N.ptr(interactions.x_item32), N.ptr(interactions.pos_slot), N.ptr(weight), N.ptr(samples), n_users,
@@ -754,18 +767,16 @@ def wmrb_fused_step(user_in, item_in, user_bias, item_bias, interactions, sample
             d_v = spmm_split(indptr_t, users_t, coef_p, perm_t, n_items, nnz, u, want_rowsum=rowsum)
         else:
             d_v = _spmm_rowsum(indptr_t, users_t, coef_p, perm_t, n_items, nnz, u, epi, False, None, d_ib)
-    ind_s, entries, _ = group_pairs_by_item(None, xs, S, n_items, workspace_with_counts=ws32, ranks=ranks.reshape(-1),
-                                            values=coef_s.reshape(-1))
-    if xs.numel() > n_items * _SPLIT_MEAN:               # few items: every bucket of samples is long
-        spmm_split(ind_s, None, None, None, n_items, xs.numel(), u, accumulate=True, out=d_v, want_rowsum=rowsum,
-                   packed=entries)
+    if binned_bytes > 0:
+        ind_s = torch.empty((n_items + 1,), dtype=torch.int64, device=dev)
+        entries = torch.empty((xs.numel(), 2), dtype=torch.int32, device=dev)
+        bws = torch.empty((binned_bytes,), dtype=torch.uint8, device=dev)
+        with _timed("group_pairs_binned"):
+            N.call("trec_group_pairs_by_item_binned", None, N.ptr(xs), N.ptr(coef_s.reshape(-1)), int(xs.numel()), S, n_items,
+                   N.ptr(bws), binned_bytes, N.ptr(ind_s), N.ptr(entries))
     else:
-        with _timed("spmm_csr"):
-            N.call("trec_spmm_csr_packed", N.ptr(ind_s), N.ptr(entries), n_items, N.ptr(u), d, epi, 1, N.ptr(d_v),
-                   N.ptr(rowsum))
-    return loss, pred, d_u, d_v, d_ub, d_ib
-    ind_s, entries, _ = group_pairs_by_item(None, xs, S, n_items, workspace_with_counts=ws32, ranks=ranks.reshape(-1),
-                                            values=coef_s.reshape(-1))
+        ind_s, entries, _ = group_pairs_by_item(None, xs, S, n_items, workspace_with_counts=ws32, ranks=ranks.reshape(-1),
+                                                values=coef_s.reshape(-1))
     if xs.numel() > n_items * _SPLIT_MEAN:               # few items: every bucket of samples is long
         spmm_split(ind_s, None, None, None, n_items, xs.numel(), u, accumulate=True, out=d_v, want_rowsum=rowsum,
                    packed=entries)

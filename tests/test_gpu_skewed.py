@@ -384,3 +384,45 @@ def test_ranked_packed_fill_in_two_levels(ops):
         assert np.array_equal(ind_a, indptr) and np.array_equal(ind_b, indptr)
         assert np.array_equal(ent_a, want)
         assert np.array_equal(ent_b, want)
+
+
+@pytest.mark.gpu
+def test_binned_grouping_without_ranks(ops):
+    """trec_group_pairs_by_item_binned (the sampled pairs of the 1M x 1M fit: tiles sorted by 4,096-item bin in LDS, one workgroup per
+    bin counts / scans / places -- no rank per pair, no global atomic per pair): indptr is the histogram's prefix and every item's
+    bucket holds exactly its (user, value) pairs; negative items are skipped; implicit and explicit users."""
+    import numpy as np
+    import torch
+    from tensorrec_amd import _native as N
+    rng = np.random.default_rng(33)
+    n_users, S, n_items = 90_000, 50, 50_003
+    xi = rng.integers(0, n_items, size=n_users * S, dtype=np.int32)
+    xi[rng.integers(0, xi.size, 1000)] = -1                     # skipped pairs
+    n_pairs = xi.size
+    vals = rng.standard_normal(n_pairs).astype(np.float32)
+    nbytes = int(N.query("trec_group_pairs_binned_bytes", n_pairs, n_items))
+    assert nbytes > 0 and int(N.query("trec_group_pairs_binned_bytes", 1000, n_items)) == 0
+    assert int(N.query("trec_group_pairs_binned_bytes", n_pairs, 3_000_000)) == 0          # more than 512 bins
+    keep = xi >= 0
+    counts = np.bincount(xi[keep], minlength=n_items)
+    indptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    users = (np.arange(n_pairs) // S).astype(np.int32)
+    dxi, dv = torch.from_numpy(xi).cuda(), torch.from_numpy(vals).cuda()
+    for explicit in (False, True):
+        xu = torch.from_numpy(users).cuda() if explicit else None
+        ind = torch.empty((n_items + 1,), dtype=torch.int64, device="cuda")
+        ent = torch.full((n_pairs, 2), -7, dtype=torch.int32, device="cuda")
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device="cuda")
+        N.call("trec_group_pairs_by_item_binned", N.ptr(xu), N.ptr(dxi), N.ptr(dv), n_pairs, S, n_items, N.ptr(ws), nbytes,
+               N.ptr(ind), N.ptr(ent))
+        assert np.array_equal(ind.cpu().numpy(), indptr)
+        got = ent.cpu().numpy()
+        n_valid = int(indptr[-1])
+        assert np.all(got[n_valid:] == -7)                       # nothing written past the valid pairs
+        item_of_slot = np.repeat(np.arange(n_items), counts)
+        order_g = np.lexsort((got[:n_valid, 1], got[:n_valid, 0], item_of_slot))
+        ref_item, ref_user, ref_val = xi[keep], users[keep], vals[keep].view(np.int32)
+        order_r = np.lexsort((ref_val, ref_user, ref_item))
+        assert np.array_equal(item_of_slot[order_g], ref_item[order_r])
+        assert np.array_equal(got[:n_valid, 0][order_g], ref_user[order_r])
+        assert np.array_equal(got[:n_valid, 1][order_g], ref_val[order_r])
