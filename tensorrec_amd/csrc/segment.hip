@@ -381,6 +381,277 @@ extern "C" int trec_group_pairs_by_item_staged(const int32_t* xu, const int32_t*
     return trec_check_launch("trec_group_pairs_by_item_staged");
 }
 
+// ---- grouping WITHOUT ranks: a two-level partition through LDS (round 5) ----------------------------------------------------------
+// The ranked forms above need, per pair, the rank its histogram atomic returned: 1e8 global atomics inside the fused WMRB kernel
+// (1.3 ms of its 11.4) before a fill of 3.0 ms.  The sampled pairs are uniform over the items BY CONSTRUCTION (the sampler draws
+// uniformly), so a fixed partition is balanced:
+//   bins of 4,096 consecutive items (245 at 1M items).
+//   (1) seg_bin_count_kernel: pairs per bin (LDS counters per tile, one global atomic per tile and bin); a one-workgroup scan gives
+//       the bins' bases.
+//   (2) seg_bin_partition_kernel: a workgroup sorts a TILE of 8,192 pairs by bin IN LDS (counting sort: LDS atomics give the local
+//       ranks, a scan the bin starts), reserves its run in every bin's region with one global atomic per bin and writes the records
+//       {item, user, value} bin after bin, dword by dword: consecutive lanes write consecutive addresses, whole sectors (a run is
+//       ~33 records of 12 B at 1M items; scattered per-record stores at that run length were what made 1 MB windows slow above).
+//   (3) per bin: its records are counted per item in LDS (4,096 counters), the scan of the counts IS indptr for its items -- no
+//       global histogram, no global scan --, and {user, value} go to base + (LDS cursor of the item)++: 8-byte stores scattered
+//       inside the bin's own ~3 MB of output (three launches, BIN_SLICES workgroups per bin: see below).
+// No global atomic per pair anywhere.  The order of pairs inside an item's bucket follows atomic arrival, as in every other form.
+// Measured at 1e8 pairs over 1M items (rocprofv3, profiles/r05_fit_kernel_stats.csv): count 0.14, partition 0.65, item counts
+// 0.25, placement 1.68 ms -- the placement's scattered stores are what is left of the old fill; 16 slices per bin kept on one XCD
+// were slower (2.9-3.1 ms in all against 2.55).
+constexpr int BIN_LOG2 = 12;
+constexpr int BIN_ITEMS = 1 << BIN_LOG2;
+constexpr int BIN_MAX_BINS = 512;          // LDS tables of the partition pass; 2M items
+constexpr int BIN_TILE = 8192;             // pairs per workgroup of the partition pass (96 KB of records in LDS)
+constexpr int BIN_SLICES = 4;              // workgroups per bin of the placement
+
+struct __attribute__((packed, aligned(4))) BinRecord { int32_t item, user; float value; };
+
+__global__ __launch_bounds__(1024) void seg_bin_count_kernel(const int32_t* __restrict__ xi, int64_t n_pairs, int32_t n_bins,
+                                                            int32_t* __restrict__ bin_count)
+{
+    __shared__ int cnt[BIN_MAX_BINS];
+    for (int i = threadIdx.x; i < n_bins; i += 1024) cnt[i] = 0;
+    __syncthreads();
+    const int64_t p0 = (int64_t)blockIdx.x * (4 * BIN_TILE);
+#pragma unroll 4
+    for (int q = 0; q < 32; ++q) {
+        const int64_t p = p0 + q * 1024 + threadIdx.x;
+        const int32_t it = p < n_pairs ? xi[p] : -1;
+        if (it >= 0) atomicAdd(&cnt[it >> BIN_LOG2], 1);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_bins; i += 1024)
+        if (cnt[i]) atomicAdd(bin_count + i, cnt[i]);
+}
+
+// bin_base [n_bins + 1] = exclusive scan of bin_count; bin_cursor [n_bins] = 0.  One workgroup.
+__global__ __launch_bounds__(256) void seg_bin_scan_kernel(const int32_t* __restrict__ bin_count, int32_t n_bins,
+                                                          int64_t* __restrict__ bin_base, int32_t* __restrict__ bin_cursor)
+{
+    __shared__ long long part[256];
+    const int per = (n_bins + 255) / 256;
+    long long s = 0;
+    for (int j = 0; j < per; ++j) { const int i = threadIdx.x * per + j; if (i < n_bins) s += bin_count[i]; }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long acc = 0;
+        for (int t = 0; t < 256; ++t) { const long long c = part[t]; part[t] = acc; acc += c; }
+        bin_base[n_bins] = acc;
+    }
+    __syncthreads();
+    long long acc = part[threadIdx.x];
+    for (int j = 0; j < per; ++j) {
+        const int i = threadIdx.x * per + j;
+        if (i < n_bins) { bin_base[i] = acc; acc += bin_count[i]; bin_cursor[i] = 0; }
+    }
+}
+
+__global__ __launch_bounds__(1024) void seg_bin_partition_kernel(const int32_t* __restrict__ xu, const int32_t* __restrict__ xi,
+                                                                const float* __restrict__ values, int64_t n_pairs,
+                                                                int32_t pairs_per_user, int32_t n_bins,
+                                                                const int64_t* __restrict__ bin_base, int32_t* __restrict__ bin_cursor,
+                                                                int32_t* __restrict__ records)
+{
+    extern __shared__ __attribute__((aligned(16))) char bsm[];
+    int32_t* flat = (int32_t*)bsm;                                      // [3 * BIN_TILE] the tile's records {item, user, value}, sorted by bin
+    int* start = (int*)(bsm + (size_t)BIN_TILE * 12);                   // [n_bins + 1] local start of every bin in the sorted tile
+    int* cnt = start + BIN_MAX_BINS + 1;                                // [n_bins] counts
+    long long* off = (long long*)(cnt + BIN_MAX_BINS + 1);              // [n_bins] record index in the bin's region of local record 0 of the bin
+    for (int i = threadIdx.x; i < n_bins; i += 1024) cnt[i] = 0;
+    __syncthreads();
+    constexpr int PT = BIN_TILE / 1024;
+    const int64_t p0 = (int64_t)blockIdx.x * BIN_TILE;
+    // everything the tile reads leaves together: items, values, users
+    int32_t it[PT], us[PT], lr[PT];
+    float vl[PT];
+#pragma unroll
+    for (int q = 0; q < PT; ++q) {
+        const int64_t p = p0 + q * 1024 + threadIdx.x;
+        const int64_t pc = p < n_pairs ? p : n_pairs - 1;
+        const int32_t t = xi[pc];
+        it[q] = p < n_pairs ? t : -1;
+        vl[q] = values[pc];
+        us[q] = xu ? xu[pc] : (int32_t)((uint32_t)pc / (uint32_t)pairs_per_user);          // (n_pairs < 2^31)
+    }
+#pragma unroll
+    for (int q = 0; q < PT; ++q) lr[q] = it[q] >= 0 ? atomicAdd(&cnt[it[q] >> BIN_LOG2], 1) : 0;
+    __syncthreads();
+    // exclusive scan of the counts (n_bins <= 512: the first 512 threads matter, two wave levels)
+    {
+        __shared__ int wsum[16];
+        const int i = threadIdx.x;
+        const int c = i < n_bins ? cnt[i] : 0;
+        int inc = c;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(inc, o, 64);
+            if ((i & 63) >= o) inc += t;
+        }
+        if ((i & 63) == 63) wsum[i >> 6] = inc;
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < (i >> 6); ++w) base += wsum[w];
+        if (i < n_bins) {
+            start[i] = base + inc - c;
+            // the tile's run in the bin's region: one global atomic per bin that has records
+            const int g = c ? atomicAdd(bin_cursor + i, c) : 0;
+            off[i] = bin_base[i] + g - (base + inc - c);
+        }
+        if (i == n_bins - 1) start[n_bins] = base + inc;
+        __syncthreads();
+    }
+    // the records, sorted by bin, in LDS (three dwords each: stride 3 is conflict-free)
+#pragma unroll
+    for (int q = 0; q < PT; ++q) {
+        if (it[q] >= 0) {
+            const int w = (start[it[q] >> BIN_LOG2] + lr[q]) * 3;
+            flat[w] = it[q];
+            flat[w + 1] = us[q];
+            flat[w + 2] = __float_as_int(vl[q]);
+        }
+    }
+    __syncthreads();
+    // ... and out, DWORD by dword: consecutive lanes write consecutive addresses of the bin's run (12-byte stores per lane would be
+    // three instructions of stride-12 partial writes each)
+    const int total3 = start[n_bins] * 3;
+    for (int w = threadIdx.x; w < total3; w += 1024) {
+        const int j = w / 3;
+        const int b = flat[j * 3] >> BIN_LOG2;
+        records[(off[b] + j) * 3 + (w - j * 3)] = flat[w];
+    }
+}
+
+// (3) in three launches, BIN_SLICES workgroups per bin (one workgroup per bin had 245 of them walk 4.9 MB twice: latency): slice g
+// of a bin's records is counted per item in LDS (seg_bin_count_items_kernel -> run_counts [bin][slice][4096]); one workgroup per bin
+// turns the counts into every slice's first slot per item and writes the bin's indptr (seg_bin_scan_items_kernel); every slice
+// places its records from LDS cursors that start there (seg_bin_place_kernel).  Slices keep their order inside a bucket.
+__global__ __launch_bounds__(1024) void seg_bin_count_items_kernel(const BinRecord* __restrict__ records, const int64_t* __restrict__ bin_base,
+                                                                  int32_t* __restrict__ run_counts)
+{
+    __shared__ int cnt[BIN_ITEMS];
+    const int b = blockIdx.x / BIN_SLICES, g = blockIdx.x % BIN_SLICES;
+    const int64_t r0 = bin_base[b], n = bin_base[b + 1] - r0;
+    const int64_t s0 = r0 + n * g / BIN_SLICES, s1 = r0 + n * (g + 1) / BIN_SLICES;
+    for (int i = threadIdx.x; i < BIN_ITEMS; i += 1024) cnt[i] = 0;
+    __syncthreads();
+    const int32_t item0 = b << BIN_LOG2;
+    for (int64_t j = s0 + threadIdx.x; j < s1; j += 1024) atomicAdd(&cnt[records[j].item - item0], 1);
+    __syncthreads();
+    int32_t* out = run_counts + (int64_t)blockIdx.x * BIN_ITEMS;
+    for (int i = threadIdx.x; i < BIN_ITEMS; i += 1024) out[i] = cnt[i];
+}
+
+__global__ __launch_bounds__(1024) void seg_bin_scan_items_kernel(int32_t* __restrict__ run_counts, const int64_t* __restrict__ bin_base,
+                                                                 int64_t n_items, int64_t* __restrict__ indptr)
+{
+    __shared__ int wsum[16];
+    const int b = blockIdx.x;
+    const int64_t r0 = bin_base[b], r1 = bin_base[b + 1];
+    int32_t* rc = run_counts + (int64_t)b * BIN_SLICES * BIN_ITEMS;
+    const int i4 = threadIdx.x * 4;
+    int tot[4] = {0, 0, 0, 0};
+    // per item: the slices' counts become their exclusive prefix over the slices; tot = the item's count
+#pragma unroll
+    for (int g = 0; g < BIN_SLICES; ++g) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = rc[g * BIN_ITEMS + i4 + e];
+            rc[g * BIN_ITEMS + i4 + e] = tot[e];
+            tot[e] += c;
+        }
+    }
+    const int c = tot[0] + tot[1] + tot[2] + tot[3];
+    int inc = c;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(inc, off, 64);
+        if ((threadIdx.x & 63) >= off) inc += t;
+    }
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base += wsum[w];
+    int st[4];
+    st[0] = base + inc - c; st[1] = st[0] + tot[0]; st[2] = st[1] + tot[1]; st[3] = st[2] + tot[2];
+    const int32_t item0 = b << BIN_LOG2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (item0 + i4 + e < n_items) indptr[item0 + i4 + e] = r0 + st[e];
+#pragma unroll
+        for (int g = 0; g < BIN_SLICES; ++g) rc[g * BIN_ITEMS + i4 + e] += st[e];      // the slice's first slot of the item, relative to r0
+    }
+    if (b == (int)gridDim.x - 1 && threadIdx.x == 0) indptr[n_items] = r1;
+}
+
+__global__ __launch_bounds__(1024) void seg_bin_place_kernel(const BinRecord* __restrict__ records, const int64_t* __restrict__ bin_base,
+                                                            const int32_t* __restrict__ run_base, int2* __restrict__ entries)
+{
+    __shared__ int cur[BIN_ITEMS];
+    const int b = blockIdx.x / BIN_SLICES, g = blockIdx.x % BIN_SLICES;
+    const int64_t r0 = bin_base[b], n = bin_base[b + 1] - r0;
+    const int64_t s0 = r0 + n * g / BIN_SLICES, s1 = r0 + n * (g + 1) / BIN_SLICES;
+    const int32_t* rb = run_base + (int64_t)blockIdx.x * BIN_ITEMS;
+    for (int i = threadIdx.x; i < BIN_ITEMS; i += 1024) cur[i] = rb[i];
+    __syncthreads();
+    const int32_t item0 = b << BIN_LOG2;
+    for (int64_t j = s0 + threadIdx.x; j < s1; j += 1024) {
+        const BinRecord r = records[j];
+        const int slot = atomicAdd(&cur[r.item - item0], 1);
+        entries[r0 + slot] = make_int2(r.user, __float_as_int(r.value));
+    }
+}
+
+// workspace bytes of trec_group_pairs_by_item_binned, or 0 when the form does not cover the size (more than 512 bins of 4,096
+// items, fewer than 2^22 pairs)
+extern "C" int64_t trec_group_pairs_binned_bytes(int64_t n_pairs, int64_t n_items)
+{
+    const int64_t n_bins = ceil_div64(n_items, BIN_ITEMS);
+    if (n_items < 1 || n_bins > BIN_MAX_BINS || n_pairs < ((int64_t)1 << 22) || n_pairs >= ((int64_t)1 << 31)) return 0;
+    return n_pairs * (int64_t)sizeof(BinRecord) + (n_bins + 1) * 8 + 2 * n_bins * 4 + n_bins * BIN_SLICES * (int64_t)BIN_ITEMS * 4 + 64;
+}
+
+// Group (user, item, value) pairs by item without ranks (see above): xi [n_pairs] items (negative: skipped), users from xu or
+// p / pairs_per_user, values [n_pairs].  Writes indptr_t int64 [n_items + 1] and entries int2 [n_pairs] = {user, value bits} (the
+// operand of trec_spmm_csr_packed).  Meant for pair lists that are roughly uniform over the items (sampled pairs): a bin is
+// placed by BIN_SLICES workgroups.  workspace: trec_group_pairs_binned_bytes(n_pairs, n_items) bytes.
+extern "C" int trec_group_pairs_by_item_binned(const int32_t* xu, const int32_t* xi, const float* values, int64_t n_pairs,
+                                               int32_t pairs_per_user, int64_t n_items, void* workspace, int64_t workspace_bytes,
+                                               int64_t* indptr_t, int32_t* entries, void* stream)
+{
+    TREC_REQUIRE(xi && values && workspace && indptr_t && entries, "trec_group_pairs_by_item_binned: null pointer");
+    TREC_REQUIRE(xu || pairs_per_user >= 1, "trec_group_pairs_by_item_binned: need xu or pairs_per_user");
+    const int64_t need = trec_group_pairs_binned_bytes(n_pairs, n_items);
+    TREC_REQUIRE(need > 0 && workspace_bytes >= need, "trec_group_pairs_by_item_binned: size not covered / workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int32_t n_bins = (int32_t)ceil_div64(n_items, BIN_ITEMS);
+    BinRecord* records = (BinRecord*)workspace;
+    int64_t* bin_base = (int64_t*)((char*)workspace + (n_pairs * (int64_t)sizeof(BinRecord) + 7) / 8 * 8);
+    int32_t* bin_count = (int32_t*)(bin_base + n_bins + 1);
+    int32_t* bin_cursor = bin_count + n_bins;
+    int32_t* run_counts = bin_cursor + n_bins;
+    if (hipMemsetAsync(bin_count, 0, sizeof(int32_t) * (size_t)n_bins, st) != hipSuccess) {
+        trec_set_last_error("trec_group_pairs_by_item_binned: memset failed");
+        return TREC_ERR_LAUNCH;
+    }
+    static bool attr_set[64] = {};
+    int dev = 0;
+    TREC_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64, "trec_group_pairs_by_item_binned: no current device");
+    const int lds = BIN_TILE * 12 + (2 * BIN_MAX_BINS + 2) * 4 + BIN_MAX_BINS * 8 + 16;
+    if (!attr_set[dev]) {
+        TREC_REQUIRE(hipFuncSetAttribute((const void*)seg_bin_partition_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess,
+                     "trec_group_pairs_by_item_binned: the device refused the dynamic LDS size");
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(seg_bin_count_kernel, dim3((unsigned)ceil_div64(n_pairs, 4 * BIN_TILE)), dim3(1024), 0, st, xi, n_pairs, n_bins, bin_count);
+    hipLaunchKernelGGL(seg_bin_scan_kernel, dim3(1), dim3(256), 0, st, bin_count, n_bins, bin_base, bin_cursor);
+    hipLaunchKernelGGL(seg_bin_partition_kernel, dim3((unsigned)ceil_div64(n_pairs, BIN_TILE)), dim3(1024), lds, st, xu, xi, values, n_pairs,
+                       pairs_per_user, n_bins, bin_base, bin_cursor, (int32_t*)records);
+    hipLaunchKernelGGL(seg_bin_count_items_kernel, dim3((unsigned)(n_bins * BIN_SLICES)), dim3(1024), 0, st, records, bin_base, run_counts);
+    hipLaunchKernelGGL(seg_bin_scan_items_kernel, dim3((unsigned)n_bins), dim3(1024), 0, st, run_counts, bin_base, n_items, indptr_t);
+    hipLaunchKernelGGL(seg_bin_place_kernel, dim3((unsigned)(n_bins * BIN_SLICES)), dim3(1024), 0, st, records, bin_base, run_counts, (int2*)entries);
+    return trec_check_launch("trec_group_pairs_by_item_binned");
+}
+
 // exclusive prefix sum of int32 counts into int64: out[i] = sum_{j<i} counts[j], out[n] = total.
 // workspace_i64: ceil(n/1024) + 1 int64
 extern "C" int trec_exclusive_scan_i32(const int32_t* counts, int64_t n, int64_t* workspace_i64, int64_t* out, void* stream)
