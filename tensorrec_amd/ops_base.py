@@ -701,7 +701,11 @@ class _WMRB(torch.autograd.Function):
         return dp, ds, None, None
 
 
-GROUP_BINNED_MIN_PAIRS = 1 << 24     # sampled pairs from which the rank-free binned grouping replaces histogram atomics + ranked fill
+import os as _os
+
+# sampled pairs from which the rank-free binned grouping replaces histogram atomics + ranked fill (TREC_BINNED_MIN_PAIRS: A/B runs)
+GROUP_BINNED_MIN_PAIRS = int(_os.environ.get("TREC_BINNED_MIN_PAIRS", 1 << 22))     # (2^22: the kernels' own minimum; one rank of 8 at
+                                                                                     # 1M x 1M has 1.25e7 pairs: 3.91 vs 4.10 ms per step)
 
 
 def wmrb_fused_supported(n_sampled, interactions, d):
