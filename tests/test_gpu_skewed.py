@@ -426,3 +426,48 @@ def test_binned_grouping_without_ranks(ops):
         assert np.array_equal(item_of_slot[order_g], ref_item[order_r])
         assert np.array_equal(got[:n_valid, 0][order_g], ref_user[order_r])
         assert np.array_equal(got[:n_valid, 1][order_g], ref_val[order_r])
+
+
+@pytest.mark.gpu
+def test_fused_wmrb_step_with_the_binned_sort_equals_the_ranked_sort(ops):
+    """From 2^22 sampled pairs on, the fused WMRB step groups them by item through the rank-free binned partition (no histogram
+    atomics in the fused kernel) instead of histogram ranks + fill: losses, predictions and user-side gradients identical (the user
+    side does not depend on the sort), item-side gradients equal up to the summation order inside an item's bucket."""
+    import numpy as np
+    import scipy.sparse as sp
+    import torch
+    from tensorrec_amd import _native as N
+    from tensorrec_amd.sparse import Interactions
+    rng = np.random.default_rng(12)
+    n_users, n_items, d, S, per = 45_000, 20_000, 32, 100, 5
+    cols = rng.integers(0, n_items, size=(n_users, per), dtype=np.int32)
+    m = sp.csr_matrix((np.ones(n_users * per, np.float32), cols.reshape(-1), np.arange(0, (n_users + 1) * per, per, dtype=np.int64)),
+                      shape=(n_users, n_items))
+    m.sum_duplicates()
+    m.data[:] = 1.0
+    inter = Interactions(m, n_users, n_items, "cuda")
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    u = 0.3 * torch.randn((n_users, d), device="cuda", generator=g)
+    v = 0.3 * torch.randn((n_items, d), device="cuda", generator=g)
+    ub = 0.1 * torch.randn((n_users,), device="cuda", generator=g)
+    ib = 0.1 * torch.randn((n_items,), device="cuda", generator=g)
+    samples = ops.sample_items(n_users, n_items, S, False, 0, 1)
+    assert n_users * S >= ops.GROUP_BINNED_MIN_PAIRS
+    outs = []
+    try:
+        for binned in (1, 0):
+            N.set_tuning("group_pairs_binned", binned)
+            ops.KERNEL_EVENTS = []
+            outs.append([t.cpu().numpy() for t in ops.wmrb_fused_step(u, v, ub, ib, inter, samples)])
+            names = {n for n, _, _ in ops.KERNEL_EVENTS}
+            ops.KERNEL_EVENTS = None
+            assert ("group_pairs_binned" in names) == bool(binned), names
+    finally:
+        ops.KERNEL_EVENTS = None
+        N.set_tuning("group_pairs_binned", 1)
+    (la, pa, dua, dva, duba, diba), (lb, pb, dub, dvb, dubb, dibb) = outs
+    assert np.array_equal(la, lb) and np.array_equal(pa, pb) and np.array_equal(dua, dub) and np.array_equal(duba, dubb)
+    gmax = np.abs(dvb).max()
+    assert gmax > 0 and np.abs(dva - dvb).max() <= 2e-5 * gmax
+    assert np.abs(diba - dibb).max() <= 2e-5 * max(1e-30, np.abs(dibb).max())
