@@ -497,8 +497,8 @@ int trec_group_pairs_by_item_staged(const int32_t* xu, const int32_t* xi, int64_
  * trec_group_pairs_binned_bytes: workspace bytes, 0 = size not covered (more than 2M items, fewer than 2^22 pairs). */
 int64_t trec_group_pairs_binned_bytes(int64_t n_pairs, int64_t n_items);
 int trec_group_pairs_by_item_binned(const int32_t* xu, const int32_t* xi, const float* values, int64_t n_pairs, int32_t pairs_per_user,
-                                    int64_t n_items, void* workspace, int64_t workspace_bytes, int64_t* indptr_t, int32_t* entries,
-                                    void* stream);
+                                    int64_t n_items, int32_t drop_zero_values, void* workspace, int64_t workspace_bytes,
+                                    int64_t* indptr_t, int32_t* entries, void* stream);
 
 /* ---- K4: ranks ----------------------------------------------------------------------------------------------
  * rank_predictions, recommendation_graphs.py:73-82 (double tf.nn.top_k) as an exact count; int32, 1 = best. */

@@ -117,7 +117,7 @@ SIGNATURES = {
     "trec_group_pairs_by_item_lds": [_vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "trec_group_pairs_staged_bytes": [_i64, _i32],
     "trec_group_pairs_binned_bytes": [_i64, _i64],
-    "trec_group_pairs_by_item_binned": [_vp, _vp, _vp, _i64, _i32, _i64, _vp, _i64, _vp, _vp, _vp],
+    "trec_group_pairs_by_item_binned": [_vp, _vp, _vp, _i64, _i32, _i64, _i32, _vp, _i64, _vp, _vp, _vp],
     "trec_group_pairs_by_item_staged": [_vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp],
     "trec_rank_rows": [_vp, _i64, _i64, _i64, _vp, _i64, _vp],
     "trec_rank_rows_workspace_bytes": [_i64, _i64],

@@ -407,8 +407,8 @@ constexpr int BIN_SLICES = 4;              // workgroups per bin of the placemen
 
 struct __attribute__((packed, aligned(4))) BinRecord { int32_t item, user; float value; };
 
-__global__ __launch_bounds__(1024) void seg_bin_count_kernel(const int32_t* __restrict__ xi, int64_t n_pairs, int32_t n_bins,
-                                                            int32_t* __restrict__ bin_count)
+__global__ __launch_bounds__(1024) void seg_bin_count_kernel(const int32_t* __restrict__ xi, const float* __restrict__ drop_zero_of,
+                                                            int64_t n_pairs, int32_t n_bins, int32_t* __restrict__ bin_count)
 {
     __shared__ int cnt[BIN_MAX_BINS];
     for (int i = threadIdx.x; i < n_bins; i += 1024) cnt[i] = 0;
@@ -417,7 +417,8 @@ __global__ __launch_bounds__(1024) void seg_bin_count_kernel(const int32_t* __re
 #pragma unroll 4
     for (int q = 0; q < 32; ++q) {
         const int64_t p = p0 + q * 1024 + threadIdx.x;
-        const int32_t it = p < n_pairs ? xi[p] : -1;
+        int32_t it = p < n_pairs ? xi[p] : -1;
+        if (drop_zero_of && p < n_pairs && drop_zero_of[p] == 0.f) it = -1;
         if (it >= 0) atomicAdd(&cnt[it >> BIN_LOG2], 1);
     }
     __syncthreads();
@@ -450,7 +451,7 @@ __global__ __launch_bounds__(256) void seg_bin_scan_kernel(const int32_t* __rest
 
 __global__ __launch_bounds__(1024) void seg_bin_partition_kernel(const int32_t* __restrict__ xu, const int32_t* __restrict__ xi,
                                                                 const float* __restrict__ values, int64_t n_pairs,
-                                                                int32_t pairs_per_user, int32_t n_bins,
+                                                                int32_t pairs_per_user, int32_t drop_zero, int32_t n_bins,
                                                                 const int64_t* __restrict__ bin_base, int32_t* __restrict__ bin_cursor,
                                                                 int32_t* __restrict__ records)
 {
@@ -471,8 +472,8 @@ __global__ __launch_bounds__(1024) void seg_bin_partition_kernel(const int32_t* 
         const int64_t p = p0 + q * 1024 + threadIdx.x;
         const int64_t pc = p < n_pairs ? p : n_pairs - 1;
         const int32_t t = xi[pc];
-        it[q] = p < n_pairs ? t : -1;
         vl[q] = values[pc];
+        it[q] = (p < n_pairs && !(drop_zero && vl[q] == 0.f)) ? t : -1;
         us[q] = xu ? xu[pc] : (int32_t)((uint32_t)pc / (uint32_t)pairs_per_user);          // (n_pairs < 2^31)
     }
 #pragma unroll
@@ -612,11 +613,13 @@ extern "C" int64_t trec_group_pairs_binned_bytes(int64_t n_pairs, int64_t n_item
 
 // Group (user, item, value) pairs by item without ranks (see above): xi [n_pairs] items (negative: skipped), users from xu or
 // p / pairs_per_user, values [n_pairs].  Writes indptr_t int64 [n_items + 1] and entries int2 [n_pairs] = {user, value bits} (the
-// operand of trec_spmm_csr_packed).  Meant for pair lists that are roughly uniform over the items (sampled pairs): a bin is
+// operand of trec_spmm_csr_packed).  drop_zero_values != 0: pairs whose value is exactly 0 are left out as well (a WMRB sample that
+// violates no margin has coefficient 0 and adds nothing to its item's gradient: the sort and the item-side gather shrink to the
+// active pairs -- most of them are inactive once a model has learned anything); indptr_t[n_items] = pairs kept.  Meant for pair lists that are roughly uniform over the items (sampled pairs): a bin is
 // placed by BIN_SLICES workgroups.  workspace: trec_group_pairs_binned_bytes(n_pairs, n_items) bytes.
 extern "C" int trec_group_pairs_by_item_binned(const int32_t* xu, const int32_t* xi, const float* values, int64_t n_pairs,
-                                               int32_t pairs_per_user, int64_t n_items, void* workspace, int64_t workspace_bytes,
-                                               int64_t* indptr_t, int32_t* entries, void* stream)
+                                               int32_t pairs_per_user, int64_t n_items, int32_t drop_zero_values, void* workspace,
+                                               int64_t workspace_bytes, int64_t* indptr_t, int32_t* entries, void* stream)
 {
     TREC_REQUIRE(xi && values && workspace && indptr_t && entries, "trec_group_pairs_by_item_binned: null pointer");
     TREC_REQUIRE(xu || pairs_per_user >= 1, "trec_group_pairs_by_item_binned: need xu or pairs_per_user");
@@ -642,10 +645,11 @@ extern "C" int trec_group_pairs_by_item_binned(const int32_t* xu, const int32_t*
                      "trec_group_pairs_by_item_binned: the device refused the dynamic LDS size");
         attr_set[dev] = true;
     }
-    hipLaunchKernelGGL(seg_bin_count_kernel, dim3((unsigned)ceil_div64(n_pairs, 4 * BIN_TILE)), dim3(1024), 0, st, xi, n_pairs, n_bins, bin_count);
+    hipLaunchKernelGGL(seg_bin_count_kernel, dim3((unsigned)ceil_div64(n_pairs, 4 * BIN_TILE)), dim3(1024), 0, st, xi,
+                       drop_zero_values ? values : (const float*)nullptr, n_pairs, n_bins, bin_count);
     hipLaunchKernelGGL(seg_bin_scan_kernel, dim3(1), dim3(256), 0, st, bin_count, n_bins, bin_base, bin_cursor);
     hipLaunchKernelGGL(seg_bin_partition_kernel, dim3((unsigned)ceil_div64(n_pairs, BIN_TILE)), dim3(1024), lds, st, xu, xi, values, n_pairs,
-                       pairs_per_user, n_bins, bin_base, bin_cursor, (int32_t*)records);
+                       pairs_per_user, drop_zero_values, n_bins, bin_base, bin_cursor, (int32_t*)records);
     hipLaunchKernelGGL(seg_bin_count_items_kernel, dim3((unsigned)(n_bins * BIN_SLICES)), dim3(1024), 0, st, records, bin_base, run_counts);
     hipLaunchKernelGGL(seg_bin_scan_items_kernel, dim3((unsigned)n_bins), dim3(1024), 0, st, run_counts, bin_base, n_items, indptr_t);
     hipLaunchKernelGGL(seg_bin_place_kernel, dim3((unsigned)(n_bins * BIN_SLICES)), dim3(1024), 0, st, records, bin_base, run_counts, (int2*)entries);

@@ -704,6 +704,7 @@ class _WMRB(torch.autograd.Function):
 import os as _os
 
 # sampled pairs from which the rank-free binned grouping replaces histogram atomics + ranked fill (TREC_BINNED_MIN_PAIRS: A/B runs)
+LAST_FUSED_STATS = {}          # filled while KERNEL_EVENTS is collecting: sampled pairs / the pairs the item side kept (device scalar)
 GROUP_BINNED_MIN_PAIRS = int(_os.environ.get("TREC_BINNED_MIN_PAIRS", 1 << 22))     # (2^22: the kernels' own minimum; one rank of 8 at
                                                                                      # 1M x 1M has 1.25e7 pairs: 3.91 vs 4.10 ms per step)
 
@@ -771,17 +772,26 @@ def wmrb_fused_step(user_in, item_in, user_bias, item_bias, interactions, sample
             d_v = spmm_split(indptr_t, users_t, coef_p, perm_t, n_items, nnz, u, want_rowsum=rowsum)
         else:
             d_v = _spmm_rowsum(indptr_t, users_t, coef_p, perm_t, n_items, nnz, u, epi, False, None, d_ib)
+    split_samples = xs.numel() > n_items * _SPLIT_MEAN
     if binned_bytes > 0:
         ind_s = torch.empty((n_items + 1,), dtype=torch.int64, device=dev)
         entries = torch.empty((xs.numel(), 2), dtype=torch.int32, device=dev)
         bws = torch.empty((binned_bytes,), dtype=torch.uint8, device=dev)
+        # a sample that violates no margin of its user has coefficient exactly 0 and adds nothing to its item's gradient: such pairs
+        # are left out of the sort and of the item-side gather (the chunked gather below is sized by the pair count: all pairs there)
+        drop_zero = 0 if split_samples else int(N.load().trec_get_tuning(b"group_pairs_drop_zero", 1) != 0)
         with _timed("group_pairs_binned"):
             N.call("trec_group_pairs_by_item_binned", None, N.ptr(xs), N.ptr(coef_s.reshape(-1)), int(xs.numel()), S, n_items,
-                   N.ptr(bws), binned_bytes, N.ptr(ind_s), N.ptr(entries))
+                   drop_zero, N.ptr(bws), binned_bytes, N.ptr(ind_s), N.ptr(entries))
     else:
         ind_s, entries, _ = group_pairs_by_item(None, xs, S, n_items, workspace_with_counts=ws32, ranks=ranks.reshape(-1),
                                                 values=coef_s.reshape(-1))
-    if xs.numel() > n_items * _SPLIT_MEAN:               # few items: every bucket of samples is long
+    if KERNEL_EVENTS is not None:                        # (measurement runs only: how many sampled pairs the item side still sees)
+        LAST_FUSED_STATS["sampled_pairs"] = int(xs.numel())
+        LAST_FUSED_STATS["sampled_pairs_kept"] = ind_s[-1:].clone()
+        LAST_FUSED_STATS["sampled_pairs_with_coefficient_0"] = (coef_s == 0).sum()
+        LAST_FUSED_STATS["loss_mean"] = loss.mean()
+    if split_samples:                                    # few items: every bucket of samples is long
         spmm_split(ind_s, None, None, None, n_items, xs.numel(), u, accumulate=True, out=d_v, want_rowsum=rowsum,
                    packed=entries)
     else:

@@ -390,7 +390,8 @@ def test_ranked_packed_fill_in_two_levels(ops):
 def test_binned_grouping_without_ranks(ops):
     """trec_group_pairs_by_item_binned (the sampled pairs of the 1M x 1M fit: tiles sorted by 4,096-item bin in LDS, one workgroup per
     bin counts / scans / places -- no rank per pair, no global atomic per pair): indptr is the histogram's prefix and every item's
-    bucket holds exactly its (user, value) pairs; negative items are skipped; implicit and explicit users."""
+    bucket holds exactly its (user, value) pairs; negative items are skipped; implicit and explicit users; with drop_zero_values the
+    pairs whose value is +0 / -0 are left out as well (WMRB samples that violate no margin)."""
     import numpy as np
     import torch
     from tensorrec_amd import _native as N
@@ -400,21 +401,23 @@ def test_binned_grouping_without_ranks(ops):
     xi[rng.integers(0, xi.size, 1000)] = -1                     # skipped pairs
     n_pairs = xi.size
     vals = rng.standard_normal(n_pairs).astype(np.float32)
+    zero = rng.random(n_pairs) < 0.6
+    vals[zero] = np.where(rng.random(int(zero.sum())) < 0.5, np.float32(0.0), np.float32(-0.0))
     nbytes = int(N.query("trec_group_pairs_binned_bytes", n_pairs, n_items))
     assert nbytes > 0 and int(N.query("trec_group_pairs_binned_bytes", 1000, n_items)) == 0
     assert int(N.query("trec_group_pairs_binned_bytes", n_pairs, 3_000_000)) == 0          # more than 512 bins
-    keep = xi >= 0
-    counts = np.bincount(xi[keep], minlength=n_items)
-    indptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
     users = (np.arange(n_pairs) // S).astype(np.int32)
     dxi, dv = torch.from_numpy(xi).cuda(), torch.from_numpy(vals).cuda()
-    for explicit in (False, True):
+    for explicit, drop in ((False, 0), (True, 0), (False, 1), (True, 1)):
+        keep = (xi >= 0) & (vals != 0) if drop else xi >= 0
+        counts = np.bincount(xi[keep], minlength=n_items)
+        indptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
         xu = torch.from_numpy(users).cuda() if explicit else None
         ind = torch.empty((n_items + 1,), dtype=torch.int64, device="cuda")
         ent = torch.full((n_pairs, 2), -7, dtype=torch.int32, device="cuda")
         ws = torch.empty((nbytes,), dtype=torch.uint8, device="cuda")
-        N.call("trec_group_pairs_by_item_binned", N.ptr(xu), N.ptr(dxi), N.ptr(dv), n_pairs, S, n_items, N.ptr(ws), nbytes,
-               N.ptr(ind), N.ptr(ent))
+        N.call("trec_group_pairs_by_item_binned", N.ptr(xu), N.ptr(dxi), N.ptr(dv), n_pairs, S, n_items, drop, N.ptr(ws),
+               nbytes, N.ptr(ind), N.ptr(ent))
         assert np.array_equal(ind.cpu().numpy(), indptr)
         got = ent.cpu().numpy()
         n_valid = int(indptr[-1])
@@ -454,20 +457,26 @@ def test_fused_wmrb_step_with_the_binned_sort_equals_the_ranked_sort(ops):
     ib = 0.1 * torch.randn((n_items,), device="cuda", generator=g)
     samples = ops.sample_items(n_users, n_items, S, False, 0, 1)
     assert n_users * S >= ops.GROUP_BINNED_MIN_PAIRS
-    outs = []
+    outs, kept = [], []
     try:
-        for binned in (1, 0):
+        for binned, drop in ((1, 1), (1, 0), (0, 1)):
             N.set_tuning("group_pairs_binned", binned)
+            N.set_tuning("group_pairs_drop_zero", drop)
             ops.KERNEL_EVENTS = []
             outs.append([t.cpu().numpy() for t in ops.wmrb_fused_step(u, v, ub, ib, inter, samples)])
             names = {n for n, _, _ in ops.KERNEL_EVENTS}
             ops.KERNEL_EVENTS = None
             assert ("group_pairs_binned" in names) == bool(binned), names
+            kept.append(int(ops.LAST_FUSED_STATS["sampled_pairs_kept"].item()))
     finally:
         ops.KERNEL_EVENTS = None
         N.set_tuning("group_pairs_binned", 1)
-    (la, pa, dua, dva, duba, diba), (lb, pb, dub, dvb, dubb, dibb) = outs
-    assert np.array_equal(la, lb) and np.array_equal(pa, pb) and np.array_equal(dua, dub) and np.array_equal(duba, dubb)
+        N.set_tuning("group_pairs_drop_zero", 1)
+    # (samples that violate no margin of their user have coefficient 0: left out of the sort by default, nothing else changes)
+    assert kept[1] == kept[2] == n_users * S and 0 < kept[0] < kept[1], kept
+    lb, pb, dub, dvb, dubb, dibb = outs[2]
     gmax = np.abs(dvb).max()
-    assert gmax > 0 and np.abs(dva - dvb).max() <= 2e-5 * gmax
-    assert np.abs(diba - dibb).max() <= 2e-5 * max(1e-30, np.abs(dibb).max())
+    for la, pa, dua, dva, duba, diba in outs[:2]:
+        assert np.array_equal(la, lb) and np.array_equal(pa, pb) and np.array_equal(dua, dub) and np.array_equal(duba, dubb)
+        assert gmax > 0 and np.abs(dva - dvb).max() <= 2e-5 * gmax
+        assert np.abs(diba - dibb).max() <= 2e-5 * max(1e-30, np.abs(dibb).max())
