@@ -25,6 +25,9 @@ __device__ __forceinline__ void adam_elem(float& w, float& m, float& v, float g,
     w = __fsub_rn(w, __fdiv_rn(__fmul_rn(m, lr_t), __fadd_rn(sqrtf(v), eps)));
 }
 
+// V (tuning "adam_variant", measured in profiles/r05_adam_ab.txt): bit 0 = non-temporal stores, bit 1 = non-temporal loads,
+// bit 2 = two float4 per array in flight per thread.
+template <int V>
 __global__ __launch_bounds__(256) void adam_tf_kernel(float* __restrict__ w, float* __restrict__ m, float* __restrict__ v,
                                                      const float* __restrict__ g, int64_t n, float lr_t, float beta1,
                                                      float beta2, float eps, float l2,
@@ -33,16 +36,40 @@ __global__ __launch_bounds__(256) void adam_tf_kernel(float* __restrict__ w, flo
     if (sched) lr_t = sched[2];                 // schedule state on the device (HIP-graph replays)
     const float omb1 = __fsub_rn(1.0f, beta1), omb2 = __fsub_rn(1.0f, beta2);
     const int64_t n4 = n >> 2;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-        f32x4 ww = ((f32x4*)w)[i], mm = ((f32x4*)m)[i], vv = ((f32x4*)v)[i];
-        const f32x4 gg = ((const f32x4*)g)[i];
+    constexpr int UN = (V & 4) ? 2 : 1;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n4; i0 += stride * UN) {
+        f32x4 ww[UN], mm[UN], vv[UN], gg[UN];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float we = ww[e], me = mm[e], ve = vv[e];
-            adam_elem(we, me, ve, gg[e], lr_t, omb1, omb2, eps, l2);
-            ww[e] = we; mm[e] = me; vv[e] = ve;
+        for (int q = 0; q < UN; ++q) {
+            const int64_t i = i0 + q * stride;
+            if (i < n4) {
+                if (V & 2) {
+                    ww[q] = __builtin_nontemporal_load((f32x4*)w + i); mm[q] = __builtin_nontemporal_load((f32x4*)m + i);
+                    vv[q] = __builtin_nontemporal_load((f32x4*)v + i); gg[q] = __builtin_nontemporal_load((const f32x4*)g + i);
+                } else {
+                    ww[q] = ((f32x4*)w)[i]; mm[q] = ((f32x4*)m)[i]; vv[q] = ((f32x4*)v)[i]; gg[q] = ((const f32x4*)g)[i];
+                }
+            }
         }
-        ((f32x4*)w)[i] = ww; ((f32x4*)m)[i] = mm; ((f32x4*)v)[i] = vv;
+#pragma unroll
+        for (int q = 0; q < UN; ++q) {
+            const int64_t i = i0 + q * stride;
+            if (i < n4) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float we = ww[q][e], me = mm[q][e], ve = vv[q][e];
+                    adam_elem(we, me, ve, gg[q][e], lr_t, omb1, omb2, eps, l2);
+                    ww[q][e] = we; mm[q][e] = me; vv[q][e] = ve;
+                }
+                if (V & 1) {
+                    __builtin_nontemporal_store(ww[q], (f32x4*)w + i); __builtin_nontemporal_store(mm[q], (f32x4*)m + i);
+                    __builtin_nontemporal_store(vv[q], (f32x4*)v + i);
+                } else {
+                    ((f32x4*)w)[i] = ww[q]; ((f32x4*)m)[i] = mm[q]; ((f32x4*)v)[i] = vv[q];
+                }
+            }
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const int64_t i = (n4 << 2) + threadIdx.x;
@@ -52,16 +79,34 @@ __global__ __launch_bounds__(256) void adam_tf_kernel(float* __restrict__ w, flo
     }
 }
 
+static int adam_launch(float* w, float* m, float* v, const float* grad, int64_t n, float lr_t, float beta1, float beta2,
+                       float epsilon, float l2_coef, const float* state, hipStream_t st)
+{
+    int64_t blocks = ceil_div64(ceil_div64(n, 4), 256);
+    const int cap = trec_get_tuning("adam_blocks", 1 << 20);     // (a 4,096-workgroup grid-stride loop: 0.745 ms per 1M x 128 table; one float4 per thread: 0.615)
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+#define TREC_ADAM(VV) hipLaunchKernelGGL(adam_tf_kernel<VV>, dim3((unsigned)blocks), dim3(256), 0, st, w, m, v, grad, n, lr_t, beta1, \
+                                         beta2, epsilon, l2_coef, state)
+    switch (trec_get_tuning("adam_variant", 7)) {
+    case 1: TREC_ADAM(1); break;
+    case 2: TREC_ADAM(2); break;
+    case 3: TREC_ADAM(3); break;
+    case 4: TREC_ADAM(4); break;
+    case 5: TREC_ADAM(5); break;
+    case 0: TREC_ADAM(0); break;
+    default: TREC_ADAM(7); break;
+    }
+#undef TREC_ADAM
+    return TREC_OK;
+}
+
 extern "C" int trec_adam_tf_step(float* w, float* m, float* v, const float* grad, int64_t n, float lr_t, float beta1,
                                  float beta2, float epsilon, float l2_coef, void* stream)
 {
     TREC_REQUIRE(w && m && v && grad, "trec_adam_tf_step: null pointer");
     if (n == 0) return TREC_OK;
-    int64_t blocks = ceil_div64(ceil_div64(n, 4), 256);
-    if (blocks > 4096) blocks = 4096;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(adam_tf_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, m, v, grad, n, lr_t,
-                       beta1, beta2, epsilon, l2_coef);
+    adam_launch(w, m, v, grad, n, lr_t, beta1, beta2, epsilon, l2_coef, nullptr, (hipStream_t)stream);
     return trec_check_launch("trec_adam_tf_step");
 }
 
@@ -94,10 +139,6 @@ extern "C" int trec_adam_tf_step_dev(float* w, float* m, float* v, const float* 
 {
     TREC_REQUIRE(w && m && v && grad && state, "trec_adam_tf_step_dev: null pointer");
     if (n == 0) return TREC_OK;
-    int64_t blocks = ceil_div64(ceil_div64(n, 4), 256);
-    if (blocks > 4096) blocks = 4096;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(adam_tf_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, m, v, grad, n, 0.f,
-                       beta1, beta2, epsilon, l2_coef, state);
+    adam_launch(w, m, v, grad, n, 0.f, beta1, beta2, epsilon, l2_coef, state, (hipStream_t)stream);
     return trec_check_launch("trec_adam_tf_step_dev");
 }
