@@ -286,6 +286,12 @@ def fit_epochs_per_sec(n_users, n_items, d, per_user=20, n_sampled=100, epochs=3
                                       "the cache cannot pay, DESIGN 8)",
                         "other_kernels_avg_ms": {n: float(np.mean(v)) for n, v in dur.items() if n != "wmrb_fused_step"},
                         "other_kernels_launches_per_epoch": {n: len(v) / 2.0 for n, v in dur.items() if n != "wmrb_fused_step"}}
+        try:                                                         # (the pairs the item side still sorts and gathers: DESIGN 0 (5c))
+            st = ops.LAST_FUSED_STATS
+            if st.get("sampled_pairs"):
+                roofline_fit["sampled_pairs_kept_fraction"] = int(st["sampled_pairs_kept"].item()) / float(st["sampled_pairs"])
+        except Exception:
+            pass
         if world == 1 and (n_users, n_items, d) == (1_000_000, 1_000_000, 128):
             attach_traffic(roofline_fit, "r[0-9][0-9]_fit_pmc_summary.txt", "wmrb_user_fused_kernel", ("wmrb_fused.hip",))
     return {"fit_epochs_per_sec": 1.0 / per_epoch, "sec_per_epoch": per_epoch, "epochs_timed": epochs,
