@@ -32,6 +32,7 @@ BF16_DENSE_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MF
 INT8_DENSE_PEAK_TOPS = 5000.0       # MI355X_MICROARCH.md: I8 MFMA "~2x bf16 rate" (no spec row; its ubench ceiling is >= 3944 TOPS)
 FP32_MFMA_PEAK_TFLOPS = 157.3
 HBM_PEAK_GBS = 8000.0
+FIT_SHARD_USERS = 49152             # the oracle's large fit shard: 4.9M sampled pairs (>= 2^22: the binned route), ~30 s of CPU per step
 GATHER_CEILING_512MB_GBS = 7420.0    # measured: bare 512-byte row gathers from a 512 MB table (profiles/r05_gather_ceiling_512.jsonl)
 
 
@@ -72,6 +73,9 @@ def parse():
                     help="K1 emits the filter's operands in its epilogue (trec_spmm_csr_filter) instead of a separate prep "
                          "pass: 0.1 ms per side less in total, but the gather kernel itself then runs at 0.49 of the HBM "
                          "roofline instead of 0.68 (DESIGN.md section 8)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="launcher path only: every rank joins the process group, runs the collective self-check and rank 0 prints "
+                         "one line -- no workload (runs without a GPU under TREC_DIST_BACKEND=gloo: tests/test_host_logic.py)")
     ap.add_argument("--tune", action="append", default=[], metavar="NAME=INT",
                     help="diagnostic: set a kernel tuning knob (trec_set_tuning), e.g. blockmax_pipelined=0")
     return ap.parse_args()
@@ -166,13 +170,14 @@ def cpu_baseline(n_items, d, k, n_users_sample, seed=0):
 
 
 def cpu_baseline_fit(n_users_total, n_items, d, per_user=20, n_sampled=100, shard=49152, small_shard=4096,
-                     small_shard_seconds=None, seed=0):
+                     small_shard_seconds=None, shard_seconds=None, seed=0):
     """CPU leg of the fit half of the metric: ONE optimiser step of the oracle's model (oracle/model.py -- the restated
     _build_tf_graph + TF-form Adam, torch-CPU autograd, float32, all host cores) on a user shard of the same 1M-item, d = 128,
     WMRB workload.  Reported: the MEASURED rate of a 49,152-user shard, timed twice (both times given -- round 2's driver run
     moved 2-3x between runs), and, separately and labelled as such, the extrapolation to one step over all users: a step costs
     a + b * users (a: the item-side dense work -- 1M x 128 weights, their Adam update), a and b from the 4,096-user step
-    that parity_fit times anyway and the faster of the two large-shard times."""
+    that parity_fit times anyway and the faster of the two large-shard times.  `shard_seconds`: a step of this shard size the
+    run has already timed (parity_fit_binned's oracle step, same workload) -- it then counts as the first of the two."""
     import scipy.sparse as sp
     import torch
     from oracle.model import OracleTensorRec
@@ -196,7 +201,7 @@ def cpu_baseline_fit(n_users_total, n_items, d, per_user=20, n_sampled=100, shar
     if small_shard_seconds is None:
         one(64)                                           # the first, tiny step pays the one-time costs and is dropped
         small_shard_seconds = one(small_shard)
-    big = [one(shard), one(shard)]
+    big = [one(shard) if shard_seconds is None else float(shard_seconds), one(shard)]
     t2 = min(big)
     b = max(0.0, (t2 - small_shard_seconds) / float(shard - small_shard))
     a = max(0.0, small_shard_seconds - b * small_shard)
@@ -306,18 +311,77 @@ def fit_epochs_per_sec(n_users, n_items, d, per_user=20, n_sampled=100, epochs=3
             "per_call_input_upload_sec": one - per_epoch}
 
 
+def launch_ranks(n_ranks, argv, n_devices, env=None):
+    """`python bench.py --gpus N` without a launcher around it: re-run this file as N ranks under torch.distributed.run (one
+    process per GPU, rendezvous on 127.0.0.1 at a free port) and hand back its exit code.  The ranks speak RCCL, so N GPUs must
+    be visible; with fewer the call is refused -- unless TREC_DIST_BACKEND=gloo asks for the functional form in which ranks
+    share a GPU (tests, one-GPU boxes: never a reported number).  Rank 0 alone prints the JSON line (main())."""
+    import socket
+    import subprocess
+    env = dict(os.environ if env is None else env)
+    backend = env.get("TREC_DIST_BACKEND", "nccl")
+    if backend == "nccl" and n_devices < n_ranks:
+        raise SystemExit("--gpus %d: %d GPU(s) visible and RCCL needs one per rank (TREC_DIST_BACKEND=gloo runs the ranks "
+                         "functionally on fewer GPUs)" % (n_ranks, n_devices))
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # (dmabuf IPC: the only form the host driver supports)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n_ranks)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def launch_check(world, rank):
+    """--launch-check: what a rank does to prove the launcher path without the workload -- join the process group, run
+    sharding.collective_selfcheck on this rank's device (CPU tensors under gloo without a GPU), rank 0 prints one line."""
+    import torch
+    import torch.distributed as dist
+    from tensorrec_amd import sharding
+    backend = os.environ.get("TREC_DIST_BACKEND", "nccl")
+    if torch.cuda.is_available():
+        dev_index = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()
+        torch.cuda.set_device(dev_index)
+        device = torch.device("cuda", dev_index)
+    else:
+        device = torch.device("cpu")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    check = sharding.collective_selfcheck(device) if world > 1 else "single"
+    total = sharding.all_reduce_scalar(rank + 1, device)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"launch_check": check, "n_gpus": world, "backend": backend if world > 1 else None,
+                          "rank_sum": total, "device": device.type}))
+        sys.stdout.flush()
+    return 0 if check in ("ok", "single") and total == world * (world + 1) // 2 else 1
+
+
 def main():
     args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # started bare (the driver's `python bench.py --gpus N`): become the launcher of N ranks of this same command
+        import torch
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:], torch.cuda.device_count()))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d under a launcher with WORLD_SIZE=%d: start the ranks with --nproc-per-node %d (or "
+                         "run `python bench.py --gpus %d`, which launches them itself)" % (args.gpus, world, args.gpus, args.gpus))
+    if args.launch_check:
+        raise SystemExit(launch_check(world, rank))
     import torch
     import torch.distributed as dist
     import scipy.sparse as sp
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
     n_dev = torch.cuda.device_count()
     dev_index = local_rank % max(1, n_dev)          # ranks share a GPU only in the single-GPU functional test below
     torch.cuda.set_device(dev_index)
@@ -775,8 +839,8 @@ def main():
             public_api = {"error": repr(exc)}
 
     # ---- further driver-visible records (rank 0, one GPU): fitted weights, fit parity, multi-nnz parity, the other configs
-    trained = parity_fit = parity_multi = configs = None
-    oracle_small_shard_s = None
+    trained = parity_fit = parity_fit_binned = parity_multi = configs = None
+    oracle_small_shard_s = oracle_shard_s = None
     if world == 1 and args.configs == "all" and exact:
         import bench_records as BR
         try:
@@ -796,6 +860,13 @@ def main():
                 parity_fit, oracle_small_shard_s = BR.parity_fit_record(I, d)
             except Exception as exc:
                 parity_fit = {"error": repr(exc)}
+            try:
+                # the route the 1M x 1M fit itself takes (>= 2^22 sampled pairs: rank-free binned grouping, zero coefficients
+                # dropped) against the oracle -- the 49,152-user oracle step is the one cpu_baseline_fit times anyway
+                torch.cuda.empty_cache()
+                parity_fit_binned, oracle_shard_s = BR.parity_fit_record(I, d, n_users=FIT_SHARD_USERS, expect_route="binned")
+            except Exception as exc:
+                parity_fit_binned = {"error": repr(exc)}
         torch.cuda.empty_cache()
         configs = BR.config_records(device)
 
@@ -804,7 +875,8 @@ def main():
         cpu = cpu_baseline(I, d, k, args.cpu_users)
         if fit is not None and "error" not in fit:
             try:
-                cpu_fit = cpu_baseline_fit(U, I, d, small_shard_seconds=oracle_small_shard_s)
+                cpu_fit = cpu_baseline_fit(U, I, d, shard=FIT_SHARD_USERS, small_shard_seconds=oracle_small_shard_s,
+                                           shard_seconds=oracle_shard_s)
             except Exception as exc:
                 cpu_fit = {"error": repr(exc)}
 
@@ -835,7 +907,7 @@ def main():
                    "score_kernel_variant": "global_load_lds" if args.variant & 1 else "register-staged"},
         "roofline": roofline, "roofline_bf16_stage": roofline_bf16_stage, "roofline_k1": roofline_k1, "roofline_k1_multi_nnz": roofline_k1_multi, "cpu_baseline": cpu, "parity": parity,
         "fp32_mfma_mode": fp32_mode, "bf16_filter_mode": bf16_mode, "roofline_bf16_dense": roofline_bf16_dense,
-        "public_api_mode": public_api, "trained_weights_mode": trained, "parity_fit": parity_fit, "parity_multi_nnz": parity_multi, "configs": configs, "fit": fit,
+        "public_api_mode": public_api, "trained_weights_mode": trained, "parity_fit": parity_fit, "parity_fit_binned": parity_fit_binned, "parity_multi_nnz": parity_multi, "configs": configs, "fit": fit,
         "roofline_fit": (fit or {}).get("roofline_fit"), "cpu_baseline_fit": cpu_fit,
     }
     # ---- what ONE rank of an 8-GPU run does per step, emulated on one GPU (scripts/rank_sim.py, scripts/fit_rank_sim.py: every

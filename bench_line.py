@@ -89,6 +89,7 @@ def compact_line(full, full_path=None):
         "trained_int8_ms": _num(_get(full, "trained_weights_mode", "kernels_avg_ms", "score_gemm_blockmax_i8"), 4),
         "trained_bit_exact": _get(full, "trained_weights_mode", "parity", "topk_ids_bit_exact_vs_oracle"),
         "parity_fit_green": _get(full, "parity_fit", "green"),
+        "parity_fit_binned": _get(full, "parity_fit_binned", "green"),
         "parity_multi_nnz_ids": _get(full, "parity_multi_nnz", "topk_ids_bit_exact_vs_oracle"),
         "step_ms_first": _num(step_ms.get("first"), 4), "step_ms_last": _num(step_ms.get("last"), 4),
         "step_ms_min": _num(step_ms.get("min"), 4), "step_ms_max": _num(step_ms.get("max"), 4),
@@ -104,7 +105,7 @@ def compact_line(full, full_path=None):
             if key.startswith("equals_timed_exact_mode_output_all_"):
                 checks["fp32_mfma_equals_all_users"] = val
     for name in ("parity", "fit", "fp32_mfma_mode", "bf16_filter_mode", "public_api_mode", "trained_weights_mode", "parity_fit",
-                 "parity_multi_nnz", "cpu_baseline_fit", "roofline_k1_multi_nnz"):
+                 "parity_fit_binned", "parity_multi_nnz", "cpu_baseline_fit", "roofline_k1_multi_nnz"):
         err = _get(full, name, "error")
         if err is not None:
             checks.setdefault("errors", {})[name] = _short(err, 60)

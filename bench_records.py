@@ -125,13 +125,19 @@ def trained_weights_record(make_step, device, U, I, d, k, steps=3, epochs=20, lr
     return rec
 
 
-def parity_fit_record(n_items, d, n_users=4096, per_user=20, n_sampled=100, lr=0.1, alpha=1e-5, seed=0):
+def parity_fit_record(n_items, d, n_users=4096, per_user=20, n_sampled=100, lr=0.1, alpha=1e-5, seed=0, learned=False,
+                      expect_route=None):
     """ONE optimiser step of a WMRB shard (n_users x n_items, identity features, non-zero biases) on the GPU through the public
     API (ReplaySampler with the oracle's samples) against oracle/model.py: serial predictions, loss vector (1e-4), raw
     gradients (1e-4 of the largest), post-step weights (Adam-aware bar, oracle/parity.py).  Returns (record, oracle step
-    seconds) -- the oracle step doubles as the small shard of cpu_baseline_fit."""
+    seconds) -- the oracle step doubles as a shard of cpu_baseline_fit.
+    n_users * n_sampled >= 2^22 puts the step on the route the 1M x 1M fit takes: sampled pairs grouped by the rank-free binned
+    partition, pairs with coefficient 0 left out of it (ops.wmrb_fused_step); `expect_route` makes the record red when the step
+    took another one.  learned=True starts from weights under which most samples violate no margin (every user's row points at
+    the sum of its positives' rows), the state in which dropping zero coefficients removes most of the pairs."""
     import torch
     import tensorrec_amd as T
+    from tensorrec_amd import ops
     from oracle.model import OracleTensorRec
     from oracle.parity import check_weights_after_adam
     cores = os.cpu_count() or 1
@@ -153,8 +159,15 @@ def parity_fit_record(n_items, d, n_users=4096, per_user=20, n_sampled=100, lr=0
     oracle.init_weights(n_users, n_items, rng)
     oracle.weights["user_feature_biases"] = (0.1 * rng.standard_normal((n_users, 1))).astype(np.float32)
     oracle.weights["item_feature_biases"] = (0.1 * rng.standard_normal((n_items, 1))).astype(np.float32)
+    if learned:
+        w_item = oracle.weights["linear_weights_item"]
+        acc = np.zeros((n_users, d), np.float32)
+        np.add.at(acc, np.repeat(np.arange(n_users), np.diff(inter.indptr)), w_item[inter.indices])
+        acc /= np.maximum(1e-12, np.linalg.norm(acc, axis=1, keepdims=True))
+        oracle.weights["linear_weights_user"] = (np.float32(10.0 * np.sqrt(d / 32.0)) * acc).astype(np.float32)
     rename = lambda w: {(k_ + "_0" if k_.endswith("_user") else k_): v for k_, v in w.items()}     # noqa: E731
     w0 = {k_: v.copy() for k_, v in oracle.weights.items()}
+    ops.LAST_FUSED_STATS.pop("route", None)
     model = T.TensorRec(n_components=d, loss_graph=T.loss_graphs.WMRBLossGraph(), sampler=T.ReplaySampler([samples]), seed=1)
     model.build(n_users, n_items)
     model.set_weights(rename(w0))
@@ -163,6 +176,8 @@ def parity_fit_record(n_items, d, n_users=4096, per_user=20, n_sampled=100, lr=0
     cap = model._capture
     model._capture = None
     got_w = model.get_weights()
+    route = {"grouping": ops.LAST_FUSED_STATS.get("route"), "drop_zero": ops.LAST_FUSED_STATS.get("drop_zero"),
+             "sampled_pairs": int(n_users) * int(n_sampled)}
     del model
     t0 = time.perf_counter()
     basic, _, pred_serial = oracle.step(inter, uf, itf, lr, alpha, samples)
@@ -175,7 +190,7 @@ def parity_fit_record(n_items, d, n_users=4096, per_user=20, n_sampled=100, lr=0
     rec = {"workload": "%d users x %d items, identity features, d=%d, Linear + DotProduct + WMRB, biased (non-zero biases), %d "
                        "interactions, %d replayed samples per user, lr %.3g, alpha %.1e: one optimiser step, GPU (public API) vs "
                        "oracle/model.py" % (n_users, n_items, d, inter.nnz, n_sampled, lr, alpha),
-           "oracle_step_seconds": oracle_s}
+           "oracle_step_seconds": oracle_s, "route": route, "learned_state": bool(learned)}
     ps_err = float(np.abs(cap["pred_serial"] - pred_serial).max() / max(1e-30, np.abs(pred_serial).max()))
     loss_err = float(np.abs(cap["loss"] - basic).max())
     rec["pred_serial_max_rel_err"] = ps_err
@@ -197,7 +212,7 @@ def parity_fit_record(n_items, d, n_users=4096, per_user=20, n_sampled=100, lr=0
         rec["weights_ok_adam_aware_bar"] = False
         rec["weights_error"] = str(exc)
     rec["green"] = bool(ps_err <= 1e-4 and rec["loss_vector_ok_1e-4"] and rec["raw_gradients_ok_1e-4"] and
-                        rec["weights_ok_adam_aware_bar"])
+                        rec["weights_ok_adam_aware_bar"] and (expect_route is None or route["grouping"] == expect_route))
     return rec, oracle_s
 
 

@@ -786,6 +786,9 @@ def wmrb_fused_step(user_in, item_in, user_bias, item_bias, interactions, sample
     else:
         ind_s, entries, _ = group_pairs_by_item(None, xs, S, n_items, workspace_with_counts=ws32, ranks=ranks.reshape(-1),
                                                 values=coef_s.reshape(-1))
+    # which grouping this call took (host-side facts only: parity records and tests assert the route they mean to cover)
+    LAST_FUSED_STATS["route"] = "binned" if binned_bytes > 0 else "ranked"
+    LAST_FUSED_STATS["drop_zero"] = bool(binned_bytes > 0 and drop_zero)
     if KERNEL_EVENTS is not None:                        # (measurement runs only: how many sampled pairs the item side still sees)
         LAST_FUSED_STATS["sampled_pairs"] = int(xs.numel())
         LAST_FUSED_STATS["sampled_pairs_kept"] = ind_s[-1:].clone()

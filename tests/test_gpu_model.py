@@ -429,6 +429,30 @@ def test_fused_wmrb_step_equals_unfused(pred, loss, biased, d, S):
         assert np.allclose(wa[k], wb[k], rtol=1e-3, atol=2e-3), k
 
 
+@pytest.mark.parametrize("learned", [False, True])
+def test_fit_step_on_the_binned_drop_zero_route_equals_the_oracle(learned):
+    """The route the 1M x 1M fit takes -- >= 2^22 sampled pairs: grouped by item through the rank-free binned partition, pairs whose
+    coefficient is 0 left out (ops.wmrb_fused_step) -- against oracle/model.py (loss_graphs.py:153-180, tensorrec.py:487-489): one
+    optimiser step through the public API on 45,000 users x 20,000 items x S = 100; serial predictions, loss vector, raw
+    gradients at 1e-4 of the largest, weights under the Adam-aware bar.  learned=True: a state in which most samples violate no
+    margin, so most pairs really are dropped."""
+    import bench_records as BR
+    from tensorrec_amd import ops, _native as N
+    assert N.load().trec_get_tuning(b"group_pairs_binned", 1) and N.load().trec_get_tuning(b"group_pairs_drop_zero", 1)
+    ops.KERNEL_EVENTS = []                                 # (statistics on: how many pairs the item side kept)
+    try:
+        rec, _ = BR.parity_fit_record(20_000, 32, n_users=45_000, per_user=5, n_sampled=100, learned=learned, expect_route="binned")
+        kept = int(ops.LAST_FUSED_STATS["sampled_pairs_kept"].item())
+    finally:
+        ops.KERNEL_EVENTS = None
+    assert rec["route"] == {"grouping": "binned", "drop_zero": True, "sampled_pairs": 4_500_000}, rec["route"]
+    assert rec["green"], rec
+    if learned:
+        assert 0 < kept < 0.5 * 4_500_000, kept           # most coefficients are zero and were dropped
+    else:
+        assert kept > 0.9 * 4_500_000, kept
+
+
 def test_fused_wmrb_falls_back_when_rows_do_not_fit():
     """A user with more interactions than LDS can hold next to the samples -> the composed path runs (same results as
     ever); custom WMRB subclasses are never fused."""

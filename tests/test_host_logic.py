@@ -192,6 +192,29 @@ def test_bench_cpu_baseline_leg_and_defaults(monkeypatch):
     assert a.steps >= 1 and a.warmup >= 0
 
 
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` started BARE (no torch.distributed.run around it, the driver's multi-GPU command): the process
+    becomes the launcher of two ranks of the same command; rank 0 alone prints the line.  --launch-check stops each rank after
+    the collective self-check (no GPU here: gloo on CPU tensors).  With RCCL and fewer GPUs than ranks the call is refused."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["TREC_DIST_BACKEND"] = "gloo"
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    rec = json.loads(lines[0])
+    assert rec["launch_check"] == "ok" and rec["n_gpus"] == 2 and rec["backend"] == "gloo" and rec["rank_sum"] == 3
+    import bench
+    with pytest.raises(SystemExit) as exc:
+        bench.launch_ranks(2, ["--gpus", "2"], n_devices=1, env={"TREC_DIST_BACKEND": "nccl"})
+    assert "RCCL needs one per rank" in str(exc.value)
+
+
 def test_upload_fingerprint_and_split_policies():
     """host-side keys of the upload cache and the dispatch rules of the chunked gathers (no GPU involved)"""
     from tensorrec_amd.tensorrec import _fingerprint
