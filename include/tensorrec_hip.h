@@ -571,6 +571,28 @@ int trec_wmrb_fused_step(const float* U, const float* V, const float* user_bias,
                          int32_t max_interactions_per_user, float* loss, float* pred_serial, float* dU,
                          float* d_user_bias, float* coef_samples, float* coef_pairs, int32_t* sample_hist,
                          int32_t* sample_rank, void* stream);
+/* The same step for S in the thousands, long interaction rows and Euclidean scores (csrc/wmrb_tiled.hip): the user's S + n_u item
+ * rows are streamed twice in tiles (scores into LDS, then the coefficient-weighted sum dU) instead of living in registers.
+ * mode 0: dot scores (prediction_graphs.py:52-55; cosine = dot on normalised rows, :70-72); mode 1: euclidean,
+ * -sqrt(max(sum (u - i)^2, 1e-16)) (:105-117).  val_samples [n_users, n_sampled] / val_pairs [nnz]: per pair the value the item
+ * side sums -- mode 0: g = d(sum loss)/d score, dV[i] = sum g U[u]; mode 1: c = -g / sqrt(D) (0 where D was clamped),
+ * dV[i] = sum c (V[i] - U[u]).  raw_samples / raw_pairs (both or neither; mode 1 with item biases): g itself, d b_i = sum g.
+ * dense_g (or NULL): a ZEROED [n_users, ldg] matrix, ldg >= n_items -- every pair's value is added at (user, item); the item side
+ * is then G^T . U (trec_gemm_f32) instead of a sort + gather, the right form when n_sampled is a sizeable share of n_items.
+ * trec_wmrb_tiled_lds_bytes: dynamic LDS of the launch, or -1 when not covered (d % 4 == 0, d <= 512, and
+ * 2 (n_sampled + longest row) + 2 (longest row) + 8 d floats within 128 KB) -- then run the unfused kernels.                     */
+int trec_wmrb_tiled_lds_bytes(int32_t n_sampled, int32_t max_interactions_per_user, int32_t d);
+int trec_wmrb_tiled_step(const float* U, const float* V, const float* user_bias, const float* item_bias,
+                         const int64_t* indptr, const int32_t* x_item, const int32_t* pos_slot, const float* pos_weight,
+                         const int32_t* samples, int64_t n_users, int64_t n_items, int32_t n_sampled, int32_t d, int32_t mode,
+                         int32_t max_interactions_per_user, float* loss, float* pred_serial, float* dU, float* d_user_bias,
+                         float* val_samples, float* val_pairs, float* raw_samples, float* raw_pairs, float* dense_g,
+                         int64_t ldg, void* stream);
+/* out[i] += sum of val over the pairs of two lists (either may be empty) whose id is i -- the item-bias gradient d b_i = sum g of
+ * bias_prediction_serial (recommendation_graphs.py:44-57) under scores whose row gradient carries another coefficient.  out is
+ * NOT cleared; ids outside [0, n_items) are skipped; the sums of an item are added in arrival order.                           */
+int trec_item_weighted_hist(const int32_t* ids_a, const float* val_a, int64_t n_a, const int32_t* ids_b, const float* val_b,
+                            int64_t n_b, int32_t n_items, float* out, void* stream);
 /* RMSE, loss_graphs.py:58-59 */
 /* Dense and separation losses (csrc/loss_dense.hip) -- tensorrec/loss_graphs.py:62-72 (RMSEDense), :75-97 (Separation), :100-134
  * (SeparationDense) as streaming reductions: kind 0 = Separation over the serial predictions (pred [n_pairs], values [n_pairs],

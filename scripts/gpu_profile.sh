@@ -84,8 +84,8 @@ bash scripts/gpu_pmc_cmd.sh "scripts/k1_multi.py" ${TAG}_k1_multi_pmc_summary "s
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_fit_prof -o fit -- python $REPO/scripts/fit_only.py 4 > $OUT/${TAG}_fit_prof.log 2> $OUT/${TAG}_fit_prof.err ); echo "fit rocprof rc=$?"
 f=$(find $OUT/${TAG}_fit_prof -name "*kernel_stats.csv" | head -1); cp $f $OUT/${TAG}_fit_kernel_stats.csv 2>/dev/null; head -9 $OUT/${TAG}_fit_kernel_stats.csv | cut -c1-160
 fi
-if has rank2; then         # two ranks over gloo on ONE GPU: the world > 1 path of bench.py end to end (functional, not a scaling number)
-TREC_DIST_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 3 --warmup 1 --users 200000 --configs headline --no-cpu-baseline 2> $OUT/${TAG}_bench_2rank.err | grep -v "^\[Gloo\]" > $OUT/${TAG}_bench_2rank_gloo_one_gpu.json; echo "rank2 rc=$?"
+if has rank2; then         # two ranks over gloo on ONE GPU, started BARE (bench.py launches its own ranks): the world > 1 path end to end (functional, not a scaling number)
+TREC_DIST_BACKEND=gloo timeout 900 python bench.py --gpus 2 --steps 3 --warmup 1 --users 200000 --configs headline --no-cpu-baseline 2> $OUT/${TAG}_bench_2rank.err | grep -v "^\[Gloo\]" > $OUT/${TAG}_bench_2rank_gloo_one_gpu.json; echo "rank2 rc=$?"
 fi
 if has diag; then          # per-workgroup clock stamps of the refining launch (make -C tensorrec_amd/csrc diag first)
 bash scripts/gpu_refine_diag.sh 0; cp $OUT/refine_diag_clk_0.json $OUT/${TAG}_refine_clocks.json 2>/dev/null

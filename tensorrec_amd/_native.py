@@ -133,6 +133,10 @@ SIGNATURES = {
     "trec_wmrb_fused_lds_bytes": [_i32, _i32, _i32],
     "trec_wmrb_fused_step": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp,
                              _vp, _vp, _vp, _vp, _vp],
+    "trec_wmrb_tiled_lds_bytes": [_i32, _i32, _i32],
+    "trec_wmrb_tiled_step": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp,
+                             _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
+    "trec_item_weighted_hist": [_vp, _vp, _i64, _vp, _vp, _i64, _i32, _vp, _vp],
     "trec_dense_loss_fwd": [_i32, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp],
     "trec_dense_loss_fwd_phase": [_i32, _i32, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp],
     "trec_dense_loss_bwd": [_i32, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp],

@@ -804,6 +804,94 @@ def wmrb_fused_step(user_in, item_in, user_bias, item_bias, interactions, sample
     return loss, pred, d_u, d_v, d_ub, d_ib
 
 
+DENSE_G_MIN_DENSITY = 1.0 / 32.0      # pairs per user / items from which the item side of the tiled step is a GEMM (G^T . U)
+
+
+def wmrb_tiled_supported(n_sampled, interactions, d):
+    """Can the tiled one-pass WMRB step (csrc/wmrb_tiled.hip: any S, dot or Euclidean scores) run this shape?"""
+    if not N.load().trec_get_tuning(b"wmrb_tiled", 1):
+        return False
+    return N.query("trec_wmrb_tiled_lds_bytes", int(n_sampled), int(interactions.max_row_nnz), int(d)) >= 0
+
+
+def _dense_g_fits(n_users, n_items, n_sampled, nnz, dev):
+    """The dense coefficient matrix G [n_users, n_items] pays when the pairs of a user are a sizeable share of the items (the
+    GEMM does n_items * d MACs per user on fp32 MFMA, the gathers move pairs * d * 4 bytes twice) and fits beside everything else."""
+    if not N.load().trec_get_tuning(b"wmrb_dense_g", 1) or n_users == 0:
+        return False
+    if (n_sampled + nnz / float(n_users)) < DENSE_G_MIN_DENSITY * n_items:
+        return False
+    free, _ = torch.cuda.mem_get_info(dev)
+    free += torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+    return float(n_users) * ((n_items + 3) // 4 * 4) * 4.0 <= 0.4 * free
+
+
+def wmrb_tiled_step(user_in, item_in, user_bias, item_bias, interactions, samples, balanced=False, mode=MODE_DOT):
+    """wmrb_fused_step for S in the thousands, long rows and Euclidean scores: (loss [P+], pred_serial [P], d user_in, d item_in,
+    d user_bias, d item_bias), upstream gradient 1.  User side: ONE kernel, the user's item rows streamed twice (scores into LDS,
+    then dU).  Item side: when a user's pairs are a sizeable share of the catalogue (configs[4]: 10 %), the pairs' values were
+    also added into a dense G [n_users, n_items] and d item_in is G^T . U on fp32 MFMA -- no sort, no second gather of 3.7e8
+    rows; otherwise the grouped gathers of the composed path (transposed interactions + counting sort of the samples)."""
+    u, v = _f32c(user_in.detach()), _f32c(item_in.detach())
+    ub = _f32c(user_bias.detach()) if user_bias is not None else None
+    ib = _f32c(item_bias.detach()) if item_bias is not None else None
+    n_users, n_items = interactions.shape
+    S = int(samples.shape[1])
+    d = u.shape[1]
+    dev = u.device
+    nnz = interactions.nnz
+    euclid = mode == MODE_EUCLIDEAN
+    loss = torch.empty((interactions.n_positive,), dtype=torch.float32, device=dev)
+    pred = torch.empty((nnz,), dtype=torch.float32, device=dev)
+    d_u = torch.empty_like(u)
+    d_ub = torch.empty((n_users,), dtype=torch.float32, device=dev) if ub is not None else None
+    val_s = torch.empty((n_users, S), dtype=torch.float32, device=dev)
+    val_p = torch.empty((nnz,), dtype=torch.float32, device=dev)
+    need_raw = euclid and ib is not None
+    raw_s = torch.empty((n_users, S), dtype=torch.float32, device=dev) if need_raw else None
+    raw_p = torch.empty((nnz,), dtype=torch.float32, device=dev) if need_raw else None
+    weight = interactions.balanced_weight() if balanced else None
+    samples = samples.to(torch.int32).contiguous()
+    xs = samples.reshape(-1)
+    dense = _dense_g_fits(n_users, n_items, S, nnz, dev) and not _LOCAL.deterministic_grouping
+    ldg = (n_items + 3) // 4 * 4
+    G = torch.zeros((n_users, ldg), dtype=torch.float32, device=dev) if dense else None
+    with _timed("wmrb_tiled_step"):
+        N.call("trec_wmrb_tiled_step", N.ptr(u), N.ptr(v), N.ptr(ub), N.ptr(ib), N.ptr(interactions.indptr),
+               N.ptr(interactions.x_item32), N.ptr(interactions.pos_slot), N.ptr(weight), N.ptr(samples), n_users, n_items, S, d,
+               int(mode), int(interactions.max_row_nnz), N.ptr(loss), N.ptr(pred), N.ptr(d_u), N.ptr(d_ub), N.ptr(val_s),
+               N.ptr(val_p), N.ptr(raw_s), N.ptr(raw_p), N.ptr(G), ldg)
+    LAST_FUSED_STATS["route"] = "tiled+dense_g" if dense else "tiled+grouped"
+    LAST_FUSED_STATS["drop_zero"] = False
+    d_ib = None
+    if dense:
+        # d item_in: dot  dV[i] = sum_u G[u, i] U[u];  euclidean  dV[i] = sum c (V[i] - U[u]) = colsum(G)[i] V[i] - (G^T U)[i]
+        with _timed("dense_g_gemm"):
+            t = gemm_raw(G, u, trans_a=True)[:n_items]
+        cs = colsum(G)[:n_items] if (euclid or ib is not None) else None
+        d_v = cs.unsqueeze(1) * v - t if euclid else t.contiguous()
+        if ib is not None and not euclid:
+            d_ib = cs.contiguous()
+        del G
+    else:
+        d_v = torch.zeros_like(v) if nnz == 0 else None
+        want_rs = ib is not None and not euclid
+        if want_rs:
+            d_ib = torch.zeros((n_items,), dtype=torch.float32, device=dev)
+        if nnz:
+            indptr_t, users_t, perm_t = interactions.transposed()
+            d_v = spmm_split(indptr_t, users_t, val_p, perm_t, n_items, nnz, u, own=v if euclid else None,
+                             want_rowsum=d_ib if want_rs else False)
+        ind_s, users_s, perm_s = group_pairs_by_item(None, xs, S, n_items)
+        spmm_split(ind_s, users_s, val_s.reshape(-1), perm_s, n_items, xs.numel(), u, own=v if euclid else None,
+                   accumulate=True, out=d_v, want_rowsum=d_ib if want_rs else False)      # (row sums accumulate with the rows)
+    if need_raw:
+        d_ib = torch.zeros((n_items,), dtype=torch.float32, device=dev)
+        N.call("trec_item_weighted_hist", N.ptr(xs), N.ptr(raw_s.reshape(-1)), int(xs.numel()), N.ptr(interactions.x_item32),
+               N.ptr(raw_p), int(nnz), int(n_items), N.ptr(d_ib))
+    return loss, pred, d_u, d_v, d_ub, d_ib
+
+
 def _spmm_rowsum(indptr, indices, values, perm, n_rows, nnz, w, epilogue, accumulate, out, rowsum):
     w = _f32c(w)
     if out is None:

@@ -418,8 +418,11 @@ def topk_user_batch(n_users, n_items, n_components, device, fraction=0.6, route=
     elif route == "wide":            # score_topk_filtered_wide: 1,024 candidate slots, their exact scores, masks and the merged lists
         per_user = 1.3 * (n_sb * (4 + 4 * CASCADE_ROW_CAPACITY) + 8 * kpad + 1024 + 40 * WIDE_CANDIDATES + 16 * int(k))
     else:
-        cap = int(N.query("trec_score_topk_capacity", int(k)))
-        per_user = 1.3 * (n_sb * 4 + 6 * kpad + int(k) * kpad * 4 + 2 * (2 * int(k)) * cap * 8 + 1024)
+        # (the fused lists hold up to 16 entries: trec_score_topk_capacity is -1 beyond that, and k > 16 finishes through score
+        # slabs of [users, SUPERBLOCK_ROWS * k] fp32 instead -- sized by the larger of the two)
+        cap = max(16, int(N.query("trec_score_topk_capacity", min(16, int(k)))))
+        lists = 2 * (2 * int(k)) * cap * 8 if int(k) <= 16 else max(2 * (2 * int(k)) * cap * 8, 2 * 4 * SUPERBLOCK_ROWS * int(k))
+        per_user = 1.3 * (n_sb * 4 + 6 * kpad + int(k) * kpad * 4 + lists + 1024)
     try:
         free, _total = torch.cuda.mem_get_info(device)
     except Exception:                                   # pragma: no cover
@@ -539,7 +542,7 @@ def cascade_lists_candidates():
 
 
 def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, floor_exchange, stats_exchange, gstats_all=None,
-                    item_index_base=0, tail_stream=None):
+                    item_index_base=0, tail_stream=None, candidates_cap=None):
     """Stages 0-1 of the int8 -> bf16 -> fp32 cascade (csrc/topk_cascade.hip): the [n_sb, n_users] table of superblock
     maxima whose entries are bf16 maxima wherever a top-k item can be and int8 maxima elsewhere (None after an overflow), its
     row stride, (resident rows of the bf16 launches, overflow), the k-th largest int8 lower bounds, and -- the default, DESIGN
@@ -613,7 +616,10 @@ def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, 
         # list nothing, the list counters start at zero
         cands = _Candidates()
         cands.pre = None
-        cands.cap = int(N.load().trec_get_tuning(b"cascade_candidates_cap", CASCADE_CANDIDATES))
+        # (an argument, not a process-global knob flipped around the call: another thread's predict_top_k must not see the wide
+        # route's 1,024 slots; the tuning knob stays for A/B runs of the default)
+        cands.cap = int(candidates_cap) if candidates_cap is not None else \
+            int(N.load().trec_get_tuning(b"cascade_candidates_cap", CASCADE_CANDIDATES))
         cands.floor0 = torch.empty((n_u,), dtype=torch.float32, device=dev)
         cands.flag = torch.empty((n_u,), dtype=torch.int32, device=dev)
         cands.n_flagged = n_flagged0
@@ -1244,16 +1250,12 @@ def score_topk_filtered_wide(uop, iop, k, user_bias=None, item_bias=None, item_i
     n_chunks = max(-(-kk // 16) + 1, min(n_sb, -(-32 * 768 // rblocks)))        # k distinct entries need ceil(k / 16) lists
     LAST_FILTER_STATS.clear()
     lib = N.load()
-    saved_cap = lib.trec_get_tuning(b"cascade_candidates_cap", CASCADE_CANDIDATES)
     table = cands = None
     bad = None
     if n_sb >= kk:
-        lib.trec_set_tuning(b"cascade_candidates_cap", WIDE_CANDIDATES)
-        try:
-            table, _stride, (rows, overflow), _tau, cands = _cascade_stage1(uop, iop, kk, ub, ib, sb_rows, n_sb, n_chunks, None, None,
-                                                                             iop.gstats, item_index_base)
-        finally:
-            lib.trec_set_tuning(b"cascade_candidates_cap", saved_cap)
+        table, _stride, (rows, overflow), _tau, cands = _cascade_stage1(uop, iop, kk, ub, ib, sb_rows, n_sb, n_chunks, None, None,
+                                                                         iop.gstats, item_index_base,
+                                                                         candidates_cap=WIDE_CANDIDATES)
         del table
     ov = torch.empty((n_u, kk), dtype=torch.float32, device=dev)
     oi = torch.empty((n_u, kk), dtype=torch.int32, device=dev)

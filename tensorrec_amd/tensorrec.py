@@ -258,6 +258,7 @@ class TensorRec(object):
 
         self._store = None
         self._graph_pool_owner = []
+        self.last_route = None        # what predict_top_k did last (route report)
         self._capture = None          # tests set this to a dict to receive the last step's loss and raw gradients
         self._adam = {}
         self._opt_step = 0
@@ -667,20 +668,26 @@ class TensorRec(object):
             engine = self._is_engine_graph()
             # built-in WMRB on dot / cosine scores: one fused pass per user (csrc/wmrb_fused.hip) instead of
             # serial scores -> loss -> autograd; only the exact built-in classes qualify (subclasses may override)
-            fused = (engine and not multi and graph.engine_mode == ops.MODE_DOT
-                     and type(loss_graph) in (WMRBLossGraph, BalancedWMRBLossGraph)
-                     and n_sampled_items is not None and item_repr.dim() == 2 and user_reprs[0].dim() == 2
-                     and user_reprs[0].shape[1] == item_repr.shape[1]
-                     and ops.wmrb_fused_supported(n_sampled_items, inter, int(item_repr.shape[1])))
+            # (rows in registers: dot scores, S + the longest row <= 256; otherwise -- S in the thousands, Euclidean scores --
+            # the tiled form of the same step, csrc/wmrb_tiled.hip)
+            fused = tiled = False
+            if (engine and not multi and graph.engine_mode in (ops.MODE_DOT, ops.MODE_EUCLIDEAN)
+                    and type(loss_graph) in (WMRBLossGraph, BalancedWMRBLossGraph)
+                    and n_sampled_items is not None and item_repr.dim() == 2 and user_reprs[0].dim() == 2
+                    and user_reprs[0].shape[1] == item_repr.shape[1]):
+                fused = graph.engine_mode == ops.MODE_DOT and \
+                    ops.wmrb_fused_supported(n_sampled_items, inter, int(item_repr.shape[1]))
+                tiled = not fused and ops.wmrb_tiled_supported(n_sampled_items, inter, int(item_repr.shape[1]))
             u_ins, a_ins, i_in = user_reprs, attn_reprs, item_repr
             if engine and graph.engine_normalize:     # cosine: normalise once, share between all serial calls
                 u_ins = [ops.l2_normalize_rows(u) for u in user_reprs]
                 a_ins = [ops.l2_normalize_rows(a) for a in attn_reprs] if attn_reprs is not None else None
                 i_in = ops.l2_normalize_rows(item_repr)
             u_in = u_ins[0]
-            if fused:
+            if fused or tiled:
                 return self._fused_wmrb_step(inter, u_in, i_in, user_bias, item_bias, weights, learning_rate, alpha,
-                                             n_sampled_items, want_stats, samples, apply)
+                                             n_sampled_items, want_stats, samples, apply,
+                                             tiled_mode=graph.engine_mode if tiled else None)
             if multi:
                 pred_serial = self._serial_multi(u_ins, a_ins, i_in, x_user, x_item, user_bias, item_bias)
             elif engine:
@@ -744,7 +751,7 @@ class TensorRec(object):
         return self._apply_gradients(basic_loss, pred_serial, weights, n_loss, learning_rate, alpha, want_stats)
 
     def _fused_wmrb_step(self, inter, u_in, i_in, user_bias, item_bias, weights, learning_rate, alpha, n_sampled_items,
-                         want_stats, samples=None, apply=True):
+                         want_stats, samples=None, apply=True, tiled_mode=None):
         """The WMRB step with the user side in one kernel: loss values and d(sum loss)/d(representations, biases) come
         from ops.wmrb_fused_step; autograd then only carries them through the representation graphs (K1 backward)."""
         loss_graph = self.loss_graph_factory
@@ -752,8 +759,12 @@ class TensorRec(object):
             samples = self._draw_samples(inter, n_sampled_items)
         ub = user_bias if self.biased else None
         ib = item_bias if self.biased else None
-        basic_loss, pred_serial, d_u, d_v, d_ub, d_ib = ops.wmrb_fused_step(u_in, i_in, ub, ib, inter, samples,
-                                                                            balanced=loss_graph.balanced)
+        if tiled_mode is not None:
+            basic_loss, pred_serial, d_u, d_v, d_ub, d_ib = ops.wmrb_tiled_step(u_in, i_in, ub, ib, inter, samples,
+                                                                                balanced=loss_graph.balanced, mode=tiled_mode)
+        else:
+            basic_loss, pred_serial, d_u, d_v, d_ub, d_ib = ops.wmrb_fused_step(u_in, i_in, ub, ib, inter, samples,
+                                                                                balanced=loss_graph.balanced)
         tensors, grads = [u_in, i_in], [d_u, d_v]
         if self.biased:
             tensors += [user_bias, item_bias]
@@ -1113,7 +1124,7 @@ class TensorRec(object):
 
     @_on_model_device
     def predict_top_k(self, user_features, item_features, k=10, user_batch_size=None, return_device=False,
-                      item_sharded=False, item_offset=0):
+                      item_sharded=False, item_offset=0, return_route=False):
         """EXTENSION: the k best items per user -- (scores [n_users, k] float32, item ids [n_users, k] int32),
         ordered like the first k ranks of ``predict_rank`` -- computed by the fused MFMA score + top-k kernel without
         materialising [n_users, n_items] (which is 4 TB at 1M x 1M).  ``user_batch_size`` None (default): as many users per
@@ -1126,7 +1137,12 @@ class TensorRec(object):
         lower bounds of every shard), then the per-shard lists are merged -- both exchanges as user-partitioned all-to-alls
         over RCCL (every rank finalises 1/world of the users, the finished lists are then all-gathered so that every rank
         returns all of them), as plain all-gathers on backends without a device all-to-all (sharding.py).  Euclidean scores:
-        every rank certifies its own shard's first k (no floor exchange), then the same merge."""
+        every rank certifies its own shard's first k (no floor exchange), then the same merge.
+
+        Which of the routes the call took is kept in ``self.last_route`` (a dict: "route" = cascade_int8 | bf16_filter |
+        euclid_certified | wide_cascade | two_stage | direct | slab, "k", "sharded", "user_batch_size", "n_items") and, with
+        ``return_route=True``, returned as a third value -- a silently slower route is the likeliest regression of this method
+        (tests/test_gpu_routes.py pins the route of every BASELINE.json configuration)."""
         from . import sharding
         self._check_fit('predict_top_k')
         if not self._is_engine_graph():
@@ -1188,6 +1204,19 @@ class TensorRec(object):
                 ubs = torch.tensor([user_batch_size], dtype=torch.int64, device=self._store.device)
                 dist.all_reduce(ubs, op=dist.ReduceOp.MIN, group=self.process_group)
                 user_batch_size = int(ubs.item())
+        if slab_route:
+            route_name = "slab"
+        elif euclid_filtered:
+            route_name = "euclid_certified"
+        elif filtered:
+            route_name = "cascade_int8" if prefilter == "int8" else "bf16_filter"
+        elif wide:
+            route_name = "wide_cascade"
+        else:
+            route_name = method if method != "auto" else ("two_stage" if itf.shape[0] >= ops.TWO_STAGE_MIN_ITEMS else "direct")
+        self.last_route = {"route": route_name, "k": int(k), "sharded": bool(sharded), "n_items": int(itf.shape[0]),
+                           "user_batch_size": int(user_batch_size), "precision": self.precision}
+        _ret = (lambda v_, i_: (v_, i_, dict(self.last_route))) if return_route else (lambda v_, i_: (v_, i_))
         vals, idx = [], []
         if slab_route:
             # (also: representations wider than the fused kernels' resident operand -- K-looped fp32 GEMM slabs)
@@ -1218,37 +1247,43 @@ class TensorRec(object):
                     vals.append(v)
                     idx.append(i)
             vals, idx = torch.cat(vals), torch.cat(idx)
-            return (vals, idx) if return_device else (_to_host(vals), _to_host(idx))
+            return _ret(vals, idx) if return_device else _ret(_to_host(vals), _to_host(idx))
         with torch.no_grad(), variable_scope(self._store):
             user_reprs, _, item_repr, user_bias, item_bias, _ = self._representations(uf, itf)
             ib = item_bias.contiguous() if self.biased else None
             if filtered or wide:
                 i_f = ops.score_prep_filter(item_repr, normalize=graph.engine_normalize, bias=ib, want_gstats=True)
-            if not filtered:
+            if not filtered and not wide:         # (the wide route works on the filter operand alone)
                 i_op, i_sq, kpad = ops.score_prep(item_repr, dtype, normalize=graph.engine_normalize, want_sqnorm=want_sq)
             s = 0
             while s < uf.shape[0]:
                 e = min(s + user_batch_size, uf.shape[0])
+                retry = False
                 try:
                     v, i = self._topk_user_batch(s, e, user_reprs, item_repr, user_bias, ib, k, graph, dtype, want_sq, filtered,
                                                  euclid_filtered, prefilter, sharded, method, floor_exchange, stats_exchange,
                                                  item_offset, i_f if (filtered or wide) else None,
-                                                 None if filtered else (i_op, i_sq, kpad), wide=wide)
+                                                 None if (filtered or wide) else (i_op, i_sq, kpad), wide=wide)
                 except torch.cuda.OutOfMemoryError:
                     # the workspace model of ops.topk_user_batch was too optimistic for this device's state: half the users per
                     # pass (item shards: the ranks walk the same batches and a rank cannot shrink alone -- the error stands)
-                    if sharded or user_batch_size <= 4096:
+                    if sharded or e - s <= 4096:
                         raise
+                    retry = True
+                if retry:
+                    # (outside the except block: the traceback no longer pins the failed call's tensors, so the cache really is
+                    # returned; halved from the size that RAN -- the nominal one may exceed the users that were left)
                     torch.cuda.empty_cache()
-                    user_batch_size = max(4096, user_batch_size // 2)
+                    user_batch_size = max(4096, min(user_batch_size, e - s) // 2)
                     continue
                 vals.append(v)
                 idx.append(i)
                 s = e
         vals, idx = torch.cat(vals), torch.cat(idx)
+        self.last_route["user_batch_size"] = int(user_batch_size)          # (after any out-of-memory halving)
         if return_device:
-            return vals, idx
-        return _to_host(vals), _to_host(idx)
+            return _ret(vals, idx)
+        return _ret(_to_host(vals), _to_host(idx))
 
     def _topk_user_batch(self, s, e, user_reprs, item_repr, user_bias, ib, k, graph, dtype, want_sq, filtered, euclid_filtered,
                          prefilter, sharded, method, floor_exchange, stats_exchange, item_offset, i_f, i_ops, wide=False):

@@ -453,6 +453,92 @@ def test_fit_step_on_the_binned_drop_zero_route_equals_the_oracle(learned):
         assert kept > 0.9 * 4_500_000, kept
 
 
+@pytest.mark.parametrize("pred,loss,biased,d,S,dense_g", [
+    ("euclidean", "wmrb", True, 256, 300, 1), ("euclidean", "balanced_wmrb", True, 64, 37, 0), ("dot", "wmrb", True, 128, 320, 1),
+    ("cosine", "wmrb", False, 100, 300, 0), ("euclidean", "wmrb", False, 36, 50, 1), ("dot", "balanced_wmrb", True, 512, 280, 0)])
+def test_tiled_wmrb_step_equals_unfused(pred, loss, biased, d, S, dense_g):
+    """The tiled one-pass WMRB step (csrc/wmrb_tiled.hip: item rows streamed twice, scores in LDS; dot / cosine / Euclidean; item
+    side through the dense G^T . U GEMM or through the grouped gathers) against the composed path (serial scores -> loss kernels ->
+    autograd, prediction_graphs.py:52-55 / :70-72 / :105-117, loss_graphs.py:153-227): serial predictions, loss vector, raw
+    gradients and weights equal up to summation order."""
+    from tensorrec_amd import ops
+    inter, uf, itf = dummy(150, 333, seed=4)
+    inter = sp.csr_matrix(inter)
+    inter[7, :] = 0                                   # a user without interactions
+    inter.eliminate_zeros()
+    rng = np.random.RandomState(5)
+    tables = [O.sample_items(itf.shape[0], uf.shape[0], S, False, rng)[:, 1].reshape(uf.shape[0], S)]
+    caps = []
+    for tiled in (1, 0):
+        T._native.set_tuning("wmrb_fused", 0)
+        T._native.set_tuning("wmrb_tiled", tiled)
+        T._native.set_tuning("wmrb_dense_g", dense_g)
+        ops.LAST_FUSED_STATS.pop("route", None)
+        try:
+            model = T.TensorRec(n_components=d, prediction_graph=PRED[pred](), loss_graph=LOSS[loss](), biased=biased,
+                                sampler=T.ReplaySampler(tables), seed=3)
+            model.build(uf.shape[1], itf.shape[1])
+            if biased:
+                w = model.get_weights()
+                r2 = np.random.default_rng(7)
+                w["user_feature_biases"] = (0.1 * r2.standard_normal(w["user_feature_biases"].shape)).astype(np.float32)
+                w["item_feature_biases"] = (0.1 * r2.standard_normal(w["item_feature_biases"].shape)).astype(np.float32)
+                model.set_weights(w)
+            model._capture = {}
+            model.fit_partial(inter, uf, itf, epochs=1, learning_rate=0.05, alpha=1e-4, n_sampled_items=S)
+            caps.append((model._capture, model.get_weights(), ops.LAST_FUSED_STATS.get("route")))
+        finally:
+            T._native.set_tuning("wmrb_fused", 1)
+            T._native.set_tuning("wmrb_tiled", 1)
+            T._native.set_tuning("wmrb_dense_g", 1)
+    (a, wa, route_a), (b, wb, route_b) = caps
+    assert route_a == ("tiled+dense_g" if dense_g else "tiled+grouped") and route_b is None, (route_a, route_b)
+    assert np.allclose(a['loss'], b['loss'], rtol=1e-5, atol=1e-6)
+    assert np.allclose(a['pred_serial'], b['pred_serial'], rtol=1e-5, atol=1e-6)
+    gmax = max(np.abs(g).max() for g in b['grads'].values() if g is not None)
+    for k, gb in b['grads'].items():
+        if gb is None:
+            assert a['grads'][k] is None or not np.abs(a['grads'][k]).any(), k
+            continue
+        assert np.abs(a['grads'][k] - gb).max() <= 2e-5 * gmax, "%s: %g (gmax %g)" % (k, np.abs(a['grads'][k] - gb).max(), gmax)
+    for k in wa:
+        if k == "user_feature_biases":
+            continue                                  # zero-gradient weight under WMRB: Adam amplifies rounding noise
+        assert np.allclose(wa[k], wb[k], rtol=1e-3, atol=2e-3), k
+
+
+def test_tiled_wmrb_step_vs_oracle_with_long_rows():
+    """The tiled step against oracle/model.py directly: Euclidean scores, S = 1,200 of 3,000 items, users with up to 700
+    interactions (rows far beyond the register kernel), negative interactions among them (no loss term, loss_graphs.py:160-163),
+    ReLU representations; one optimiser step, the bar of the config records (1e-4)."""
+    import bench_records as BR
+    from tensorrec_amd import ops
+    rng = np.random.default_rng(3)
+    n_users, n_items, d, S = 64, 3000, 64, 1200
+    rows, cols, vals = [], [], []
+    for u_ in range(n_users):
+        n = int(rng.integers(1, 700)) if u_ % 3 else 0
+        c = rng.choice(n_items, size=n, replace=False)
+        rows += [u_] * n
+        cols += list(c)
+        vals += list(np.where(rng.random(n) < 0.8, 1.0, -1.0))
+    inter = sp.csr_matrix((np.array(vals, np.float32), (rows, cols)), shape=(n_users, n_items))
+    uf = sp.identity(n_users, dtype=np.float32, format="csr")
+    itf = BR._side_features(n_items, 40, 3, rng)
+    table = np.stack([rng.permutation(n_items)[:S] for _ in range(n_users)]).astype(np.int64)
+    oracle = OracleTensorRec(d, "relu", "relu", "euclidean", "wmrb", True)
+    oracle.init_weights(uf.shape[1], itf.shape[1], np.random.default_rng(42))
+
+    def mk(tables):
+        return T.TensorRec(n_components=d, user_repr_graph=ReLURepresentationGraph(), item_repr_graph=ReLURepresentationGraph(),
+                           prediction_graph=EuclideanSimilarityPredictionGraph(), loss_graph=WMRBLossGraph(), seed=0,
+                           sampler=T.ReplaySampler(tables))
+    ops.LAST_FUSED_STATS.pop("route", None)
+    rec = BR._one_step_parity(mk, oracle, inter, uf, itf, table, 0.01, 1e-5, S, 1e-4)
+    assert ops.LAST_FUSED_STATS.get("route") == "tiled+dense_g"
+    assert rec["green"], rec
+
+
 def test_fused_wmrb_falls_back_when_rows_do_not_fit():
     """A user with more interactions than LDS can hold next to the samples -> the composed path runs (same results as
     ever); custom WMRB subclasses are never fused."""

@@ -337,4 +337,8 @@ def test_topk_user_batch_sizes_by_route():
         ops.topk_user_batch(10_000_000, 4_000_000, 128, dev, route="cascade", k=16)
     assert ops.topk_user_batch(10_000_000, 8_000_000, 128, dev, route="two_stage", k=16) <= \
         ops.topk_user_batch(10_000_000, 8_000_000, 128, dev, route="two_stage", k=4)
+    # k > 16 on the two-stage route (item shards, bf16, Euclidean): trec_score_topk_capacity is -1 there -- the size must not GROW
+    # with k because a negative capacity shrank the per-user estimate
+    assert ops.topk_user_batch(10_000_000, 8_000_000, 128, dev, route="two_stage", k=32) <= \
+        ops.topk_user_batch(10_000_000, 8_000_000, 128, dev, route="two_stage", k=16)
     assert ops.topk_user_batch(1000, 1_000_000, 128, dev) == 65536          # (the floor; callers clamp to their user count)
