@@ -125,6 +125,35 @@ def trained_weights_record(make_step, device, U, I, d, k, steps=3, epochs=20, lr
     return rec
 
 
+def _hinge_kink_rows(w, inter, samples, tol, chunk=4096):
+    """Users and items (boolean masks) that take part in a WMRB hinge whose argument 1 - y_p + y_s (loss_graphs.py:171-174) is
+    within `tol` of 0 under the oracle's weights `w` (identity features: representation rows = weight rows; dot scores + biases)."""
+    wu, wi = w["linear_weights_user"], w["linear_weights_item"]
+    bu = w.get("user_feature_biases")
+    bi = w.get("item_feature_biases")
+    n_users, n_items = wu.shape[0], wi.shape[0]
+    skip_u, skip_i = np.zeros(n_users, bool), np.zeros(n_items, bool)
+    indptr, indices, data = inter.indptr, inter.indices, inter.data
+    for u0 in range(0, n_users, chunk):
+        u1 = min(n_users, u0 + chunk)
+        ys = np.einsum("ud,usd->us", wu[u0:u1], wi[samples[u0:u1]], dtype=np.float64)
+        if bu is not None:
+            ys += bu[u0:u1].reshape(-1, 1) + bi.reshape(-1)[samples[u0:u1]]
+        for u in range(u0, u1):
+            cols = indices[indptr[u]:indptr[u + 1]][data[indptr[u]:indptr[u + 1]] > 0]
+            if cols.size == 0:
+                continue
+            yp = wi[cols].astype(np.float64) @ wu[u].astype(np.float64)
+            if bu is not None:
+                yp += float(bu[u, 0]) + bi.reshape(-1)[cols]
+            near = np.abs(1.0 - yp[:, None] + ys[u - u0][None, :]) < tol
+            if near.any():
+                skip_u[u] = True
+                skip_i[cols[near.any(axis=1)]] = True
+                skip_i[samples[u][near.any(axis=0)]] = True
+    return skip_u, skip_i
+
+
 def parity_fit_record(n_items, d, n_users=4096, per_user=20, n_sampled=100, lr=0.1, alpha=1e-5, seed=0, learned=False,
                       expect_route=None):
     """ONE optimiser step of a WMRB shard (n_users x n_items, identity features, non-zero biases) on the GPU through the public
@@ -204,15 +233,32 @@ def parity_fit_record(n_items, d, n_users=4096, per_user=20, n_sampled=100, lr=0
     rec["loss_max_abs_err_over_max_loss"] = float(dl.max() / lmax)
     rec["loss_vector_ok_1e-4"] = bool(np.allclose(cap["loss"], basic, rtol=1e-4, atol=1e-5) or
                                       (rec["loss_share_within_1e-4_rel"] >= 0.999 and rec["loss_max_abs_err_over_max_loss"] <= 1e-4))
+    # learned state: most positives have NO active hinge, so d loss / d (hinge sum) is the full I / S, and a hinge whose argument
+    # 1 - y_p + y_s lies within rounding of its kink is legitimately active for one summation order and inactive for another --
+    # a jump of I / S in one user row and two item rows.  Those rows (a handful of 65,000) are named from the oracle's own scores
+    # and left out of the gradient / weight comparison; everything else is held to the bar.
+    skip_u = skip_i = None
+    if learned:
+        skip_u, skip_i = _hinge_kink_rows(w0, inter, samples, 2e-5)
+        rec["rows_at_a_hinge_kink_left_out"] = {"users": int(skip_u.sum()), "items": int(skip_i.sum())}
+
+    def _masked(name, a):
+        if skip_u is None:
+            return a
+        keep = ~(skip_u if "user" in name else skip_i)
+        return a[keep] if a.shape[0] == keep.shape[0] else a
     gerr = {}
     for k_, ref in rename(raw).items():
         if ref is None:
             continue
-        gerr[k_] = float(np.abs(cap["grads"][k_] - ref).max() / gmax)
+        gerr[k_] = float(np.abs(_masked(k_, cap["grads"][k_]) - _masked(k_, ref)).max() / gmax)
     rec["raw_gradient_max_err_over_gmax"] = gerr
     rec["raw_gradients_ok_1e-4"] = bool(all(v <= 1e-4 for v in gerr.values()))
     try:
-        rep = check_weights_after_adam(got_w, rename(oracle.weights), cap["grads"], rename(raw), lr, 1,
+        rep = check_weights_after_adam({k_: _masked(k_, v) for k_, v in got_w.items()},
+                                       {k_: _masked(k_, v) for k_, v in rename(oracle.weights).items()},
+                                       {k_: (None if v is None else _masked(k_, v)) for k_, v in cap["grads"].items()},
+                                       {k_: (None if v is None else _masked(k_, v)) for k_, v in rename(raw).items()}, lr, 1,
                                        exempt=("user_feature_biases",), label="bench parity_fit")
         rec["weights_after_step"] = {k_: {"max_abs_dw": v[0], "share_beyond_1e-4_lr": v[1]} for k_, v in rep.items()}
         rec["weights_ok_adam_aware_bar"] = True

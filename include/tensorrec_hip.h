@@ -579,6 +579,8 @@ int trec_wmrb_fused_step(const float* U, const float* V, const float* user_bias,
  * dV[i] = sum c (V[i] - U[u]).  raw_samples / raw_pairs (both or neither; mode 1 with item biases): g itself, d b_i = sum g.
  * dense_g (or NULL): a ZEROED [n_users, ldg] matrix, ldg >= n_items -- every pair's value is added at (user, item); the item side
  * is then G^T . U (trec_gemm_f32) instead of a sort + gather, the right form when n_sampled is a sizeable share of n_items.
+ * dU may be NULL with dense_g: the second sweep over the rows is skipped, val_rowsum [n_users] receives the sum of each user's
+ * values and the caller forms dU = G . V (mode 0) or val_rowsum[u] U[u] - (G . V)[u] (mode 1).
  * trec_wmrb_tiled_lds_bytes: dynamic LDS of the launch, or -1 when not covered (d % 4 == 0, d <= 512, and
  * 2 (n_sampled + longest row) + 2 (longest row) + 8 d floats within 128 KB) -- then run the unfused kernels.                     */
 int trec_wmrb_tiled_lds_bytes(int32_t n_sampled, int32_t max_interactions_per_user, int32_t d);
@@ -587,7 +589,7 @@ int trec_wmrb_tiled_step(const float* U, const float* V, const float* user_bias,
                          const int32_t* samples, int64_t n_users, int64_t n_items, int32_t n_sampled, int32_t d, int32_t mode,
                          int32_t max_interactions_per_user, float* loss, float* pred_serial, float* dU, float* d_user_bias,
                          float* val_samples, float* val_pairs, float* raw_samples, float* raw_pairs, float* dense_g,
-                         int64_t ldg, void* stream);
+                         int64_t ldg, float* val_rowsum, void* stream);
 /* out[i] += sum of val over the pairs of two lists (either may be empty) whose id is i -- the item-bias gradient d b_i = sum g of
  * bias_prediction_serial (recommendation_graphs.py:44-57) under scores whose row gradient carries another coefficient.  out is
  * NOT cleared; ids outside [0, n_items) are skipped; the sums of an item are added in arrival order.                           */

@@ -135,7 +135,7 @@ SIGNATURES = {
                              _vp, _vp, _vp, _vp, _vp],
     "trec_wmrb_tiled_lds_bytes": [_i32, _i32, _i32],
     "trec_wmrb_tiled_step": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp,
-                             _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
+                             _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
     "trec_item_weighted_hist": [_vp, _vp, _i64, _vp, _vp, _i64, _i32, _vp, _vp],
     "trec_dense_loss_fwd": [_i32, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp],
     "trec_dense_loss_fwd_phase": [_i32, _i32, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp],

@@ -41,6 +41,7 @@ struct TiledOut {
     float* val_samples; float* val_pairs;      // what the item side sums per pair (g, or c = -g / sqrt(D))
     float* raw_samples; float* raw_pairs;      // g itself (euclidean + item biases), or null
     float* dense_g; int64_t ldg;               // zeroed [n_users, ldg]: += value at (user, item), or null
+    float* val_rowsum;                         // [n_users] sum of the user's values, written when dU is null (no pass 2: dU from G . V)
 };
 
 // ITERS: float4 chunks per lane of a 32-lane subgroup (d <= 128 * ITERS); RB: rows in flight per subgroup; MODE 0 dot, 1 euclid
@@ -74,7 +75,8 @@ __global__ __launch_bounds__(256, ITERS <= 2 ? 4 : 2) void wmrb_user_tiled_kerne
             o.val_samples[u * S + s] = 0.f;
             if (o.raw_samples) o.raw_samples[u * S + s] = 0.f;
         }
-        for (int c = tid; c < d; c += 256) o.dU[u * d + c] = 0.f;
+        if (o.dU) for (int c = tid; c < d; c += 256) o.dU[u * d + c] = 0.f;
+        if (o.val_rowsum && tid == 0) o.val_rowsum[u] = 0.f;
         if (o.dub && tid == 0) o.dub[u] = 0.f;
         return;
     }
@@ -155,6 +157,7 @@ __global__ __launch_bounds__(256, ITERS <= 2 ? 4 : 2) void wmrb_user_tiled_kerne
     // ---- loss terms (loss_graphs.py:153-180): 8 threads per interaction walk the S sample scores; lane k == 0 of the eight
     // then holds hinge sum and active count (fixed combination order), and finishes the interaction ----
     float raw_sum = 0.f;                                     // this thread's share of d b_u = sum of every pair's g
+    float val_sum = 0.f;                                     // ... and of the sum of the values (euclidean: dU = val_sum U - G . V)
     for (int q0 = 0; q0 < n_pos; q0 += 32) {
         const int q = q0 + (tid >> 3), k = tid & 7;
         const bool live = q < n_pos;
@@ -197,6 +200,7 @@ __global__ __launch_bounds__(256, ITERS <= 2 ? 4 : 2) void wmrb_user_tiled_kerne
             if (o.raw_pairs) o.raw_pairs[b + q] = dp;
             if (o.dense_g) unsafeAtomicAdd(o.dense_g + u * o.ldg + xi[b + q], val);
             raw_sum += dp;
+            val_sum += val;
         }
     }
     __syncthreads();
@@ -226,13 +230,15 @@ __global__ __launch_bounds__(256, ITERS <= 2 ? 4 : 2) void wmrb_user_tiled_kerne
                 if (o.raw_samples) o.raw_samples[u * S + s] = g[m];
                 if (o.dense_g) unsafeAtomicAdd(o.dense_g + u * o.ldg + samples[u * S + s], val);
                 raw_sum += g[m];
+                val_sum += val;
             }
         }
     }
     __syncthreads();
 
-    // ---- pass 2: dU_u = sum_j val_j * row_j (dot) / sum_j val_j * (U_u - row_j) (euclidean) ----
-    {
+    // ---- pass 2: dU_u = sum_j val_j * row_j (dot) / sum_j val_j * (U_u - row_j) (euclidean); skipped when the caller takes dU
+    // from the dense matrix (G . V on fp32 MFMA: the second sweep over the rows is 45 ms of configs[4]'s step, the GEMM 19) ----
+    if (o.dU) {
         f32x4 part[ITERS];
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) part[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -279,14 +285,21 @@ __global__ __launch_bounds__(256, ITERS <= 2 ? 4 : 2) void wmrb_user_tiled_kerne
         for (int off = 32; off > 0; off >>= 1) raw_sum += __shfl_xor(raw_sum, off, 64);
         if (lane == 0) l_red[wave] = raw_sum;
     }
+    if (o.val_rowsum) {
+        for (int off = 32; off > 0; off >>= 1) val_sum += __shfl_xor(val_sum, off, 64);
+        if (lane == 0) l_red[4 + wave] = val_sum;
+    }
     __syncthreads();
-    for (int c = tid; c < d; c += 256) {
-        float acc = l_part[c];
+    if (o.dU) {
+        for (int c = tid; c < d; c += 256) {
+            float acc = l_part[c];
 #pragma unroll
-        for (int g8 = 1; g8 < 8; ++g8) acc += l_part[g8 * d + c];
-        o.dU[u * d + c] = acc;
+            for (int g8 = 1; g8 < 8; ++g8) acc += l_part[g8 * d + c];
+            o.dU[u * d + c] = acc;
+        }
     }
     if (o.dub && tid == 0) o.dub[u] = (l_red[0] + l_red[1]) + (l_red[2] + l_red[3]);
+    if (o.val_rowsum && tid == 0) o.val_rowsum[u] = (l_red[4] + l_red[5]) + (l_red[6] + l_red[7]);
 }
 
 // d b_i = sum of g over the pairs of item i, for two pair lists (sampled pairs, interactions): a weighted histogram.  The item
@@ -349,10 +362,12 @@ extern "C" int trec_wmrb_tiled_step(const float* U, const float* V, const float*
                                     const float* pos_weight, const int32_t* samples, int64_t n_users, int64_t n_items,
                                     int32_t n_sampled, int32_t d, int32_t mode, int32_t max_interactions_per_user, float* loss,
                                     float* pred_serial, float* dU, float* d_user_bias, float* val_samples, float* val_pairs,
-                                    float* raw_samples, float* raw_pairs, float* dense_g, int64_t ldg, void* stream)
+                                    float* raw_samples, float* raw_pairs, float* dense_g, int64_t ldg, float* val_rowsum,
+                                    void* stream)
 {
-    TREC_REQUIRE(U && V && indptr && samples && loss && pred_serial && dU && val_samples && val_pairs,
+    TREC_REQUIRE(U && V && indptr && samples && loss && pred_serial && val_samples && val_pairs,
                  "trec_wmrb_tiled_step: null pointer");
+    TREC_REQUIRE(dU || (dense_g && val_rowsum), "trec_wmrb_tiled_step: without dU the caller needs dense_g and val_rowsum");
     TREC_REQUIRE(mode == 0 || mode == 1, "trec_wmrb_tiled_step: mode must be 0 (dot) or 1 (euclidean)");
     TREC_REQUIRE(!user_bias == !d_user_bias, "trec_wmrb_tiled_step: user_bias and d_user_bias go together");
     TREC_REQUIRE(!raw_samples == !raw_pairs, "trec_wmrb_tiled_step: raw_samples and raw_pairs go together");
@@ -367,7 +382,7 @@ extern "C" int trec_wmrb_tiled_step(const float* U, const float* V, const float*
     const float ratio = (float)n_items / (float)n_sampled;
     const int32_t max_rows = n_sampled + max_interactions_per_user;
     hipStream_t st = (hipStream_t)stream;
-    TiledOut o = {loss, pred_serial, dU, d_user_bias, val_samples, val_pairs, raw_samples, raw_pairs, dense_g, ldg};
+    TiledOut o = {loss, pred_serial, dU, d_user_bias, val_samples, val_pairs, raw_samples, raw_pairs, dense_g, ldg, val_rowsum};
 #define TREC_TILED(IT, RB, MD)                                                                                                  \
     do {                                                                                                                        \
         if (lds > 64 * 1024)                                                                                                    \

@@ -843,7 +843,6 @@ def wmrb_tiled_step(user_in, item_in, user_bias, item_bias, interactions, sample
     euclid = mode == MODE_EUCLIDEAN
     loss = torch.empty((interactions.n_positive,), dtype=torch.float32, device=dev)
     pred = torch.empty((nnz,), dtype=torch.float32, device=dev)
-    d_u = torch.empty_like(u)
     d_ub = torch.empty((n_users,), dtype=torch.float32, device=dev) if ub is not None else None
     val_s = torch.empty((n_users, S), dtype=torch.float32, device=dev)
     val_p = torch.empty((nnz,), dtype=torch.float32, device=dev)
@@ -856,16 +855,23 @@ def wmrb_tiled_step(user_in, item_in, user_bias, item_bias, interactions, sample
     dense = _dense_g_fits(n_users, n_items, S, nnz, dev) and not _LOCAL.deterministic_grouping
     ldg = (n_items + 3) // 4 * 4
     G = torch.zeros((n_users, ldg), dtype=torch.float32, device=dev) if dense else None
+    # with G the user side needs no second sweep over the rows either: dU = G . V (euclidean: rowsum(G) U - G . V)
+    d_u = None if dense else torch.empty_like(u)
+    val_rs = torch.empty((n_users,), dtype=torch.float32, device=dev) if dense else None
     with _timed("wmrb_tiled_step"):
         N.call("trec_wmrb_tiled_step", N.ptr(u), N.ptr(v), N.ptr(ub), N.ptr(ib), N.ptr(interactions.indptr),
                N.ptr(interactions.x_item32), N.ptr(interactions.pos_slot), N.ptr(weight), N.ptr(samples), n_users, n_items, S, d,
                int(mode), int(interactions.max_row_nnz), N.ptr(loss), N.ptr(pred), N.ptr(d_u), N.ptr(d_ub), N.ptr(val_s),
-               N.ptr(val_p), N.ptr(raw_s), N.ptr(raw_p), N.ptr(G), ldg)
+               N.ptr(val_p), N.ptr(raw_s), N.ptr(raw_p), N.ptr(G), ldg, N.ptr(val_rs))
     LAST_FUSED_STATS["route"] = "tiled+dense_g" if dense else "tiled+grouped"
     LAST_FUSED_STATS["drop_zero"] = False
     d_ib = None
     if dense:
         # d item_in: dot  dV[i] = sum_u G[u, i] U[u];  euclidean  dV[i] = sum c (V[i] - U[u]) = colsum(G)[i] V[i] - (G^T U)[i]
+        v_pad = v if ldg == n_items else torch.cat([v, torch.zeros((ldg - n_items, d), dtype=torch.float32, device=dev)])
+        with _timed("dense_g_gemm"):
+            gv = gemm_raw(G, v_pad)                            # [n_users, d]
+        d_u = val_rs.unsqueeze(1) * u - gv if euclid else gv
         with _timed("dense_g_gemm"):
             t = gemm_raw(G, u, trans_a=True)[:n_items]
         cs = colsum(G)[:n_items] if (euclid or ib is not None) else None
