@@ -611,6 +611,19 @@ int trec_dense_loss_fwd_phase(int32_t kind, int32_t phase, const float* pred, in
                               void* stream);
 int trec_dense_loss_bwd(int32_t kind, const float* pred, int64_t rows, int64_t cols, const int32_t* xu, const int32_t* xi,
                         const float* values, int64_t n_pairs, const double* st, const float* gl, float* d_pred, void* stream);
+/* The dense losses WITHOUT the [n_users, n_items] prediction (csrc/loss_dense.hip, "factored"): dot-product scores are bilinear,
+ * p_ui = x_u . y_i with x_u = [u | b_u | 1], y_i = [v_i | 1 | b_i], so RMSEDense / SeparationDense (loss_graphs.py:62-72, :100-134)
+ * need sum p = (sum x) . (sum y) and sum p^2 = <X^T X, Y^T Y>_F only, and their gradient is A X (Y^T Y) + B 1 (sum y)^T.
+ * trec_gram_f64: G [D, D] double = X^T X (X float [n, D], row stride ld; D <= 1024; G cleared inside).
+ * trec_dense_loss_factored_phase: trec_dense_loss_fwd_phase with the dense sums given as m = {sum p, sum p^2} over this rank's
+ * n_all_local predictions and the interactions given by their serial predictions (kind 1 / 2).
+ * trec_dense_loss_factored_bwd: coef double[2] = {A, B}; d_serial [n_pairs] = the corrections at the interaction cells.      */
+int trec_gram_f64(const float* X, int64_t n, int32_t D, int64_t ld, double* G, void* stream);
+int trec_dense_loss_factored_phase(int32_t kind, int32_t phase, const double* m, const float* pred_serial, const float* values,
+                                   int64_t n_pairs, int64_t n_all_local, int64_t n_all_total, double* st, float* loss,
+                                   void* stream);
+int trec_dense_loss_factored_bwd(int32_t kind, const float* pred_serial, const float* values, int64_t n_pairs, const double* st,
+                                 const float* gl, float* d_serial, double* coef, void* stream);
 int trec_rmse_fwd(const float* y, const float* pred, int64_t n, float* partial_ws, int32_t n_partial, float* loss,
                   void* stream);
 int trec_rmse_bwd(const float* y, const float* pred, const float* loss, const float* grad_loss, int64_t n,

@@ -140,6 +140,9 @@ SIGNATURES = {
     "trec_dense_loss_fwd": [_i32, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp],
     "trec_dense_loss_fwd_phase": [_i32, _i32, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp],
     "trec_dense_loss_bwd": [_i32, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp],
+    "trec_gram_f64": [_vp, _i64, _i32, _i64, _vp, _vp],
+    "trec_dense_loss_factored_phase": [_i32, _i32, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp],
+    "trec_dense_loss_factored_bwd": [_i32, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp],
     "trec_rmse_fwd": [_vp, _vp, _i64, _vp, _i32, _vp, _vp],
     "trec_rmse_bwd": [_vp, _vp, _vp, _vp, _i64, _vp, _vp],
     "trec_sample_items": [_i64, _i64, _i32, _i32, _i32, _u64, _u32, _vp, _vp],

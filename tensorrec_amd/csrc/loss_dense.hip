@@ -181,6 +181,87 @@ __global__ __launch_bounds__(256) void rmse_dense_bwd_pairs_kernel(int64_t ld, c
     dx[(int64_t)xu[p] * ld + xi[p]] -= c * y[p];                           // (duplicates were summed at upload: one entry per cell)
 }
 
+// ---- the dense losses WITHOUT the dense prediction: dot-product scores are bilinear, p_ui = x_u . y_i with x_u = [u | b_u | 1] and
+// y_i = [v_i | 1 | b_i], so the two sums the dense passes take over all n_users x n_items predictions are
+//     sum p = (sum_u x_u) . (sum_i y_i)          sum p^2 = sum_ui (x_u^T y_i)^2 = <X^T X, Y^T Y>_F
+// -- two D x D Gram matrices (D = d + 2) in double instead of U * I predictions: 1M x 1M in milliseconds, where the [U, I]
+// tensor (4 TB) cannot exist.  Likewise backward: every cell's gradient is affine in its prediction (A p + B), hence
+//     dX = A X (Y^T Y) + B 1 (sum y)^T,   dY = A Y (X^T X) + B 1 (sum x)^T,
+// plus the corrections at the interaction cells, which flow through the serial predictions.
+
+// G[D, D] += X^T X over a slice of rows (double accumulation; X float [n, ld]); one workgroup = one 32 x 32 tile of G x one slice
+__global__ __launch_bounds__(256) void gram_f64_kernel(const float* __restrict__ X, int64_t n, int D, int64_t ld,
+                                                      int64_t rows_per_slice, double* __restrict__ G)
+{
+    __shared__ float As[32][33], Bs[32][33];
+    const int ti = blockIdx.x, tj = blockIdx.y;
+    if (tj < ti) return;                                  // G is symmetric: the upper triangle of tiles is computed, mirrored below
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int64_t r0 = (int64_t)blockIdx.z * rows_per_slice;
+    const int64_t r1 = r0 + rows_per_slice < n ? r0 + rows_per_slice : n;
+    double acc[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+    for (int64_t rb = r0; rb < r1; rb += 32) {
+        for (int e = threadIdx.x; e < 1024; e += 256) {
+            const int rr = e >> 5, cc = e & 31;
+            const int64_t row = rb + rr;
+            const int ca = ti * 32 + cc, cb = tj * 32 + cc;
+            As[rr][cc] = (row < r1 && ca < D) ? X[row * ld + ca] : 0.f;
+            Bs[rr][cc] = (row < r1 && cb < D) ? X[row * ld + cb] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int rr = 0; rr < 32; ++rr) {
+            const double a0 = (double)As[rr][2 * ty], a1 = (double)As[rr][2 * ty + 1];
+            const double b0 = (double)Bs[rr][2 * tx], b1 = (double)Bs[rr][2 * tx + 1];
+            acc[0][0] += a0 * b0; acc[0][1] += a0 * b1; acc[1][0] += a1 * b0; acc[1][1] += a1 * b1;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int gi = ti * 32 + 2 * ty + i, gj = tj * 32 + 2 * tx + j;
+            if (gi < D && gj < D) {
+                atomicAdd(G + (int64_t)gi * D + gj, acc[i][j]);
+                if (tj != ti) atomicAdd(G + (int64_t)gj * D + gi, acc[i][j]);
+            }
+        }
+}
+
+// st[0] += sum p, st[1] += sum (p - mu)^2 over n predictions whose plain sums are m = {sum p, sum p^2}
+__global__ void factored_moments_add_kernel(const double* __restrict__ m, double n, const double* __restrict__ mu_ptr,
+                                            double* __restrict__ st)
+{
+    const double mu = mu_ptr ? mu_ptr[0] : 0.0;
+    st[0] += m[0];
+    st[1] += m[1] - 2.0 * mu * m[0] + n * mu * mu;
+}
+
+// backward of the factored forms: d loss / d p = A p + B on EVERY cell (coef[0] = A, coef[1] = B), and the correction of the
+// interaction cells as the gradient of their serial predictions
+//   RMSE dense:        A = gl / (loss n), B = 0;                cell correction  -A y
+//   separation dense:  every cell as a negative;                 cell correction  g_pos(p) - g_neg(p) for y > 0
+__global__ __launch_bounds__(256) void factored_bwd_kernel(int kind, const float* __restrict__ serial, const float* __restrict__ y,
+                                                          int64_t n_pairs, const double* __restrict__ st, const float* __restrict__ gl,
+                                                          float* __restrict__ d_serial, double* __restrict__ coef)
+{
+    const double g = (double)gl[0];
+    const double np = st[2], nn = st[10] - st[2];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (kind == 2) { coef[0] = g * st[15]; coef[1] = 0.0; }
+        else {
+            const double s2 = st[13] * st[13];
+            coef[0] = g * st[15] / nn * st[14] / s2;
+            coef[1] = g * st[15] / nn * (-1.0 - st[14] * st[12] / s2);
+        }
+    }
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n_pairs) return;
+    if (kind == 2) d_serial[p] = (float)(-(g * st[15]) * (double)y[p]);
+    else d_serial[p] = (y[p] > 0.f) ? sep_grad((double)serial[p], true, st, np, nn, g) - sep_grad((double)serial[p], false, st, np, nn, g) : 0.f;
+}
+
 unsigned grid_for(int64_t n, int per_thread)
 {
     int64_t b = ceil_div64(n, 256 * (int64_t)per_thread);
@@ -261,4 +342,67 @@ extern "C" int trec_dense_loss_bwd(int32_t kind, const float* pred, int64_t rows
         if (n_pairs) hipLaunchKernelGGL(rmse_dense_bwd_pairs_kernel, dim3((unsigned)ceil_div64(n_pairs, 256)), dim3(256), 0, s, cols, xu, xi, values, n_pairs, st, gl, d_pred);
     }
     return trec_check_launch("trec_dense_loss_bwd");
+}
+
+// G[D, D] (double, row-major) = X^T X for X float [n, D] with row stride ld; G is cleared here.  With a column of ones in X the
+// matching row of G holds the column sums.  D <= 1024.
+extern "C" int trec_gram_f64(const float* X, int64_t n, int32_t D, int64_t ld, double* G, void* stream)
+{
+    TREC_REQUIRE(X && G && n >= 0 && D >= 1 && D <= 1024 && ld >= D, "trec_gram_f64: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(G, 0, (size_t)D * D * sizeof(double), s) != hipSuccess) { trec_set_last_error("trec_gram_f64: memset failed"); return TREC_ERR_LAUNCH; }
+    if (n == 0) return TREC_OK;
+    const int tiles = (D + 31) / 32;
+    // ~2,048 workgroups over the upper triangle of tiles; slices of whole 32-row blocks
+    int64_t slices = 2048 / ((int64_t)tiles * (tiles + 1) / 2);
+    if (slices < 1) slices = 1;
+    int64_t per = ceil_div64(ceil_div64(n, slices), 32) * 32;
+    if (per < 32) per = 32;
+    slices = ceil_div64(n, per);
+    TREC_REQUIRE(slices <= 65535, "trec_gram_f64: too many row slices");
+    hipLaunchKernelGGL(gram_f64_kernel, dim3((unsigned)tiles, (unsigned)tiles, (unsigned)slices), dim3(256), 0, s, X, n, (int)D, ld, per, G);
+    return trec_check_launch("trec_gram_f64");
+}
+
+// trec_dense_loss_fwd_phase for the factored dense forms (kind 1 / 2 only): the dense sums come from m = {sum p, sum p^2} over this
+// rank's n_all_local predictions (Gram matrices, see above) instead of a pass over a [rows, cols] tensor; the interactions enter
+// through their SERIAL predictions.  Phases and all-reduce points exactly as trec_dense_loss_fwd_phase.
+extern "C" int trec_dense_loss_factored_phase(int32_t kind, int32_t phase, const double* m, const float* pred_serial,
+                                              const float* values, int64_t n_pairs, int64_t n_all_local, int64_t n_all_total,
+                                              double* st, float* loss, void* stream)
+{
+    TREC_REQUIRE((kind == 1 || kind == 2) && phase >= 0 && phase <= 2 && m && st && loss && ((pred_serial && values) || n_pairs == 0),
+                 "trec_dense_loss_factored_phase: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    if (phase == 0) {
+        if (hipMemsetAsync(st, 0, 16 * sizeof(double), s) != hipSuccess) { trec_set_last_error("trec_dense_loss_factored_phase: memset failed"); return TREC_ERR_LAUNCH; }
+        hipLaunchKernelGGL(factored_moments_add_kernel, dim3(1), dim3(1), 0, s, m, (double)n_all_local, (const double*)nullptr, st);
+        if (n_pairs) hipLaunchKernelGGL(pair_moments_kernel, dim3(grid_for(n_pairs, 4)), dim3(256), 0, s, (const float*)nullptr, (int64_t)0, pred_serial,
+                                        (const int32_t*)nullptr, (const int32_t*)nullptr, values, n_pairs, (const double*)nullptr, st + 2);
+        return trec_check_launch("trec_dense_loss_factored_phase (pass 1)");
+    }
+    if (phase == 1) {
+        if (kind == 2) return TREC_OK;
+        hipLaunchKernelGGL(separation_means_kernel, dim3(1), dim3(1), 0, s, st, (double)n_all_total);
+        hipLaunchKernelGGL(factored_moments_add_kernel, dim3(1), dim3(1), 0, s, m, (double)n_all_local, (const double*)(st + 12), st);
+        if (n_pairs) hipLaunchKernelGGL(pair_moments_kernel, dim3(grid_for(n_pairs, 4)), dim3(256), 0, s, (const float*)nullptr, (int64_t)0, pred_serial,
+                                        (const int32_t*)nullptr, (const int32_t*)nullptr, values, n_pairs, (const double*)(st + 11), st + 2);
+        return trec_check_launch("trec_dense_loss_factored_phase (pass 2)");
+    }
+    if (kind == 2) hipLaunchKernelGGL(rmse_dense_finish_kernel, dim3(1), dim3(1), 0, s, st, loss, (double)n_all_total);
+    else hipLaunchKernelGGL(separation_finish_kernel, dim3(1), dim3(1), 0, s, st, loss);
+    return trec_check_launch("trec_dense_loss_factored_phase (finish)");
+}
+
+// backward of the factored forms: coef (double[2]) = {A, B} of d loss / d p = A p + B on every cell, d_serial [n_pairs] = the
+// corrections at the interaction cells (gradient of their serial predictions); gl: float[1] upstream gradient
+extern "C" int trec_dense_loss_factored_bwd(int32_t kind, const float* pred_serial, const float* values, int64_t n_pairs,
+                                            const double* st, const float* gl, float* d_serial, double* coef, void* stream)
+{
+    TREC_REQUIRE((kind == 1 || kind == 2) && st && gl && coef && ((pred_serial && values && d_serial) || n_pairs == 0),
+                 "trec_dense_loss_factored_bwd: bad arguments");
+    const int64_t blocks = n_pairs ? ceil_div64(n_pairs, 256) : 1;
+    hipLaunchKernelGGL(factored_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (int)kind, pred_serial, values,
+                       n_pairs, st, gl, d_serial, coef);
+    return trec_check_launch("trec_dense_loss_factored_bwd");
 }

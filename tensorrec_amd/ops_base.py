@@ -1001,6 +1001,83 @@ class _DenseLoss(torch.autograd.Function):
         return d_pred, None, None, None, None
 
 
+class FactoredPrediction(object):
+    """The dense prediction of a dot-product (or cosine: rows normalised) model kept as its FACTORS -- user / item
+    representations, biases -- plus the serial predictions of the interactions.  TensorRec hands it to the built-in dense losses
+    in place of the [n_users, n_items] tensor (which is 4 TB at 1M x 1M): they need two Gram matrices, not the predictions."""
+
+    def __init__(self, user_repr, item_repr, user_bias, item_bias, pred_serial):
+        self.user_repr, self.item_repr, self.user_bias, self.item_bias, self.pred_serial = \
+            user_repr, item_repr, user_bias, item_bias, pred_serial
+        self.shape = (int(user_repr.shape[0]), int(item_repr.shape[0]))
+
+
+def _augment(rows, bias, ones_first):
+    """X = [u | b_u | 1] (ones_first False) / Y = [v | 1 | b_i] (True), float32, contiguous; a missing bias is a zero column"""
+    n = rows.shape[0]
+    one = torch.ones((n, 1), dtype=torch.float32, device=rows.device)
+    b = bias.detach().reshape(n, 1).to(torch.float32) if bias is not None else torch.zeros_like(one)
+    return torch.cat([rows.detach().to(torch.float32), one, b] if ones_first else [rows.detach().to(torch.float32), b, one], dim=1).contiguous()
+
+
+class _FactoredDenseLoss(torch.autograd.Function):
+    """RMSEDense / SeparationDense (loss_graphs.py:62-72, :100-134) of p_ui = x_u . y_i from the Gram matrices X^T X, Y^T Y (double,
+    csrc/loss_dense.hip): forward O((U + I) d^2) instead of O(U I d), no [U, I] tensor; backward dX = A X (Y^T Y) + B 1 (sum y)^T
+    on fp32 MFMA.  The interaction cells' corrections flow into the serial predictions' gradient (K3 backward)."""
+
+    @staticmethod
+    def forward(ctx, user_repr, item_repr, user_bias, item_bias, pred_serial, kind, values):
+        X, Y = _augment(user_repr, user_bias, False), _augment(item_repr, item_bias, True)
+        dev, D, d = X.device, X.shape[1], user_repr.shape[1]
+        gx = torch.empty((D, D), dtype=torch.float64, device=dev)
+        gy = torch.empty((D, D), dtype=torch.float64, device=dev)
+        with _timed("gram_f64"):
+            N.call("trec_gram_f64", N.ptr(X), X.shape[0], D, D, N.ptr(gx))
+            N.call("trec_gram_f64", N.ptr(Y), Y.shape[0], D, D, N.ptr(gy))
+        # sum p = (sum x) . (sum y): the column of ones makes row d + 1 of X^T X the column sums of X (row d of Y^T Y those of Y)
+        m = torch.stack([(gx[d + 1] * gy[d]).sum(), (gx * gy).sum()]).contiguous()
+        ps = _f32c(pred_serial.detach()).reshape(-1)
+        n_pairs = int(values.numel())
+        n_local = int(X.shape[0]) * int(Y.shape[0])
+        st = torch.empty((16,), dtype=torch.float64, device=dev)
+        loss = torch.empty((1,), dtype=torch.float32, device=dev)
+        n_total = n_local
+        if _LOCAL.loss_group is not None:
+            n_total = int(_loss_all_reduce(torch.tensor([float(n_local)], dtype=torch.float64, device=dev)).item())
+        for phase in (0, 1, 2):
+            N.call("trec_dense_loss_factored_phase", kind, phase, N.ptr(m), N.ptr(ps), N.ptr(values), n_pairs, n_local, n_total,
+                   N.ptr(st), N.ptr(loss))
+            if _LOCAL.loss_group is not None and (phase == 0 or (phase == 1 and kind != DENSE_LOSS_RMSE_DENSE)):
+                _loss_all_reduce(st[:10])
+        ctx.save_for_backward(X, Y, gx, gy, ps, st)
+        ctx.meta = (kind, values, n_pairs, d, user_bias is not None, item_bias is not None)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gl):
+        X, Y, gx, gy, ps, st = ctx.saved_tensors
+        kind, values, n_pairs, d, has_ub, has_ib = ctx.meta
+        dev = X.device
+        d_serial = torch.empty_like(ps)
+        coef = torch.empty((2,), dtype=torch.float64, device=dev)
+        N.call("trec_dense_loss_factored_bwd", kind, N.ptr(ps), N.ptr(values), n_pairs, N.ptr(st), N.ptr(_f32c(gl).reshape(1)),
+               N.ptr(d_serial), N.ptr(coef))
+        a, b = coef[0].to(torch.float32), coef[1].to(torch.float32)
+        # dX = A X Gy + B 1 sy^T, dY = A Y Gx + B 1 sx^T   (sx = row d + 1 of Gx, sy = row d of Gy); the scalars stay on the device
+        dX = gemm_raw(X, gy.to(torch.float32)) * a + (gy[d].to(torch.float32) * b).unsqueeze(0)
+        dY = gemm_raw(Y, gx.to(torch.float32)) * a + (gx[d + 1].to(torch.float32) * b).unsqueeze(0)
+        du, dv = dX[:, :d].contiguous(), dY[:, :d].contiguous()
+        dub = dX[:, d].contiguous() if has_ub else None            # X = [u | b_u | 1]
+        dib = dY[:, d + 1].contiguous() if has_ib else None        # Y = [v | 1 | b_i]
+        return du, dv, dub, dib, d_serial, None, None
+
+
+def factored_dense_loss(pred, interactions, kind):
+    ub = pred.user_bias.reshape(-1) if pred.user_bias is not None else None
+    ib = pred.item_bias.reshape(-1) if pred.item_bias is not None else None
+    return _FactoredDenseLoss.apply(pred.user_repr, pred.item_repr, ub, ib, pred.pred_serial, kind, interactions.values)
+
+
 def separation_loss(pred_serial, interactions_serial):
     """SeparationLossGraph (loss_graphs.py:75-97): 1 - Normal(mu_n - mu_p, sqrt(var_n + var_p)).cdf(0) over the interactions"""
     return _DenseLoss.apply(pred_serial.reshape(-1), DENSE_LOSS_SEPARATION, None, None, _f32c(interactions_serial).reshape(-1))
@@ -1008,11 +1085,15 @@ def separation_loss(pred_serial, interactions_serial):
 
 def separation_dense_loss(prediction, interactions):
     """SeparationDenseLossGraph (loss_graphs.py:100-134): the same over every user-item pair, non-positives as negatives"""
+    if isinstance(prediction, FactoredPrediction):
+        return factored_dense_loss(prediction, interactions, DENSE_LOSS_SEPARATION_DENSE)
     return _DenseLoss.apply(prediction, DENSE_LOSS_SEPARATION_DENSE, interactions.x_user32, interactions.x_item32, interactions.values)
 
 
 def rmse_dense_loss(prediction, interactions):
     """RMSEDenseLossGraph (loss_graphs.py:62-72): RMSE against the dense interaction matrix"""
+    if isinstance(prediction, FactoredPrediction):
+        return factored_dense_loss(prediction, interactions, DENSE_LOSS_RMSE_DENSE)
     return _DenseLoss.apply(prediction, DENSE_LOSS_RMSE_DENSE, interactions.x_user32, interactions.x_item32, interactions.values)
 
 

@@ -703,7 +703,15 @@ class TensorRec(object):
                 'tf_n_items': n_items,
             }
             if loss_graph.is_dense:
-                if multi:
+                # the built-in dense losses on dot / cosine scores need two Gram matrices, not the [n_users, n_items] tensor
+                # (ops.FactoredPrediction, csrc/loss_dense.hip): O((U + I) d^2), and 1M x 1M -- 4 TB of predictions -- runs at all
+                factored = (engine and not multi and graph.engine_mode == ops.MODE_DOT
+                            and type(loss_graph) in (RMSEDenseLossGraph, SeparationDenseLossGraph)
+                            and ops.N.load().trec_get_tuning(b"dense_loss_factored", 1) != 0)
+                if factored:
+                    tf_prediction = ops.FactoredPrediction(u_in, i_in, user_bias if self.biased else None,
+                                                           item_bias if self.biased else None, pred_serial)
+                elif multi:
                     tf_prediction = self._dense_multi(user_reprs, attn_reprs, item_repr, user_bias, item_bias,
                                                       differentiable=True)
                 else:
@@ -711,7 +719,7 @@ class TensorRec(object):
                                                            differentiable=True)
                 # TF evaluates the rankings node only when a loss uses it, and no built-in loss does: the U * I^2 counting
                 # kernel runs for custom loss graphs only (50 ms of a 54 ms RMSEDense step at 20000 x 5000)
-                builtin = type(loss_graph).connect_loss_graph.__module__ == AbstractLossGraph.__module__
+                builtin = factored or type(loss_graph).connect_loss_graph.__module__ == AbstractLossGraph.__module__
                 loss_kwargs.update({'tf_prediction': tf_prediction,
                                     'tf_rankings': None if builtin else rank_predictions(tf_prediction)})
             if loss_graph.is_sample_based:
