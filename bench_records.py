@@ -193,7 +193,10 @@ def parity_fit_record(n_items, d, n_users=4096, per_user=20, n_sampled=100, lr=0
         acc = np.zeros((n_users, d), np.float32)
         np.add.at(acc, np.repeat(np.arange(n_users), np.diff(inter.indptr)), w_item[inter.indices])
         acc /= np.maximum(1e-12, np.linalg.norm(acc, axis=1, keepdims=True))
-        oracle.weights["linear_weights_user"] = (np.float32(10.0 * np.sqrt(d / 32.0)) * acc).astype(np.float32)
+        # (scale 6: ~2/3 of the sampled pairs violate no margin.  Larger scores make the LOSS ill-conditioned in fp32, not the
+        # kernels: d loss / d(hinge sum) = r / (1 + r h) with r = I / S = 200 moves by r^2 dh = 4e4 dh near h = 0, so one rounding
+        # of a score of size 10 (1e-6) already shifts a coefficient by 2e-4 of itself -- measured at scale 10: 1.3e-4 of gmax)
+        oracle.weights["linear_weights_user"] = (np.float32(6.0 * np.sqrt(d / 32.0)) * acc).astype(np.float32)
     rename = lambda w: {(k_ + "_0" if k_.endswith("_user") else k_): v for k_, v in w.items()}     # noqa: E731
     w0 = {k_: v.copy() for k_, v in oracle.weights.items()}
     ops.LAST_FUSED_STATS.pop("route", None)

@@ -45,6 +45,11 @@ class SparseFeatures(object):
         # exactly one non-zero in every row (identity / indicator features): K1 then skips the row pointer
         self.one_per_row = bool(m.shape[0] > 0 and m.nnz == m.shape[0] and
                                 np.array_equal(m.indptr, np.arange(m.shape[0] + 1)))
+        # the identity matrix itself (sp.identity user / item features, BASELINE.json configs[2]): X . W IS W -- the linear
+        # representation then aliases the weight table instead of copying it through K1 (ops.sparse_dense_matmul)
+        self.is_identity = bool(self.one_per_row and m.shape[0] == m.shape[1] and
+                                np.array_equal(m.indices, np.arange(m.shape[0], dtype=m.indices.dtype)) and
+                                bool(np.all(m.data == 1.0)))
         # column support [min col, max col + 1) of the non-zeros: the rows of a weight table this matrix can touch (the
         # data-parallel fit skips the gradient exchange of tables whose supports do not overlap between ranks: sharding.py)
         self.col_range = (int(m.indices.min()), int(m.indices.max()) + 1) if m.nnz else (0, 0)

@@ -777,9 +777,7 @@ class TensorRec(object):
         if self.biased:
             tensors += [user_bias, item_bias]
             grads += [d_ub, d_ib]
-        live = [(t, g) for t, g in zip(tensors, grads) if t.requires_grad]      # weight-less graphs have no history
-        if live:
-            torch.autograd.backward([t for t, _ in live], [g for _, g in live])
+        ops.accumulate_grads(tensors, grads)                    # (weight-less graphs have no history: skipped inside)
         if not apply:
             return basic_loss, pred_serial, weights, int(basic_loss.numel())
         return self._apply_gradients(basic_loss, pred_serial, weights, int(basic_loss.numel()), learning_rate, alpha,

@@ -126,6 +126,33 @@ def test_sparse_transposed_structure_on_cpu():
         Interactions(m, 2, 5, "cpu")
 
 
+def test_identity_features_alias_the_weight_table():
+    """sp.identity features: X . W is W itself -- the linear representation is a view of the table (no K1 copy forward, no gather-copy
+    backward), and the fused steps hand its gradient to the table without AccumulateGrad's clone.  Anything else (a permutation, a
+    value other than 1, a non-square indicator matrix) goes through K1."""
+    import torch
+    from tensorrec_amd import ops
+    from tensorrec_amd.sparse import SparseFeatures
+    n = 7
+    ident = SparseFeatures(sp.identity(n, dtype=np.float32, format="csr"), "cpu")
+    assert ident.is_identity and ident.one_per_row
+    perm = sp.csr_matrix((np.ones(n, np.float32), (np.arange(n), np.roll(np.arange(n), 1))), shape=(n, n))
+    scaled = sp.identity(n, dtype=np.float32, format="csr") * 2.0
+    wide = sp.csr_matrix((np.ones(n, np.float32), (np.arange(n), np.arange(n))), shape=(n, n + 3))
+    for m in (perm, scaled, wide):
+        assert not SparseFeatures(m, "cpu").is_identity
+    w = torch.randn((n, 4), requires_grad=True)
+    out = ops.sparse_dense_matmul(ident, w)
+    assert out.data_ptr() == w.data_ptr() and out._trec_alias_of is w and out.requires_grad
+    g = torch.ones_like(w)
+    ops.accumulate_grads([out], [g])
+    assert w.grad is g                                        # handed over, not cloned
+    w.grad = None
+    out2 = ops.sparse_dense_matmul(ident, w)
+    (out2 * 2.0).sum().backward()                             # the ordinary autograd route through the view still works
+    assert torch.equal(w.grad, torch.full_like(w, 2.0))
+
+
 # ---- C ABI -----------------------------------------------------------------------------------------------------
 def _declared_symbols():
     text = open(os.path.join(ROOT, "include", "tensorrec_hip.h")).read()
