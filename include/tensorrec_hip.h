@@ -359,6 +359,17 @@ int trec_topk_candidates_finish(const int32_t* cand_n, const void* cand, int32_t
                                 const float* user_bias, const float* item_bias, int32_t item_index_base, int64_t n_users,
                                 int32_t k, float* out_vals, int32_t* out_idx, int32_t* flag, int32_t* n_flagged,
                                 const int32_t* out_index, int32_t lanes_per_user, void* stream);
+/* The same finish in two launches for lists of mixed length (the single-GPU cascade: ~15 candidates per user, a few users with
+ * hundreds): 16 lanes per user with cands_per_lane (1 / 2 / 4) candidates per lane -- four users per wave --, users with longer
+ * lists appended to over_list [n_users] (over_count [1], zeroed by the caller) and finished by the wave-per-user form on a fixed
+ * grid that reads the count on the device.  Same results (recommendation_graphs.py:73-82 restricted to the first k places).      */
+int trec_topk_candidates_finish_mixed(const int32_t* cand_n, const void* cand, int32_t cand_cap, const float* cand_floor,
+                                      const float* user_stats, const float* item_gstats, const float* users_f32,
+                                      const float* items_f32, int64_t ld_users, int64_t ld_items, int32_t kdim,
+                                      const float* user_bias, const float* item_bias, int32_t item_index_base, int64_t n_users,
+                                      int32_t k, float* out_vals, int32_t* out_idx, int32_t* flag, int32_t* n_flagged,
+                                      const int32_t* out_index, int32_t cands_per_lane, int32_t* over_list, int32_t* over_count,
+                                      void* stream);
 /* The cascade's thresholds in one pass over the users, before trec_topk_rows_collect: tau [n_users] IN / OUT = the k-th largest
  * int8 lower bound (+inf on return for layout rows without a source: src [n_users] nullable, trec_user_prep_sorted);
  * floor0 = tau - eps rounded down twice (the provisional floor of the candidate lists; +inf and flag = 1 when the bound is

@@ -618,8 +618,8 @@ __global__ __launch_bounds__(256) void filter_finish_wide_kernel(
 // A user with more than ``cap`` candidates (its list is incomplete) or more than FILTER_CMAX survivors is flagged; a user whose
 // provisional floor is +inf (padding rows; users the floor kernel flagged for an unusable bound) is skipped.
 template <int CPL>
-__global__ __launch_bounds__(256) void candidates_finish_kernel(
-    const int32_t* __restrict__ cand_n, const int2* __restrict__ cand_list, int cap, const float* __restrict__ cand_floor,
+__device__ __forceinline__ void candidates_finish_user(
+    const int64_t u, const int32_t* __restrict__ cand_n, const int2* __restrict__ cand_list, int cap, const float* __restrict__ cand_floor,
     const float2* __restrict__ ustats, const float* __restrict__ gstats, const float* __restrict__ U,
     const float* __restrict__ V, int64_t ld_u, int64_t ld_v, int kdim, const float* __restrict__ user_bias,
     const float* __restrict__ item_bias, int32_t item_index_base, int64_t n_users, int k, float* __restrict__ ov,
@@ -628,7 +628,6 @@ __global__ __launch_bounds__(256) void candidates_finish_kernel(
 {
     extern __shared__ __attribute__((aligned(16))) char fsmem[];
     const int wave = threadIdx.x >> 6;
-    const int64_t u = (int64_t)blockIdx.x * 4 + wave;
     if (u >= n_users) return;
     // users sorted by scale class: the result row is the CALLER's row of this layout row; rows without one write nothing
     const int64_t uo = out_index ? (int64_t)out_index[u] : u;
@@ -718,6 +717,37 @@ __global__ __launch_bounds__(256) void candidates_finish_kernel(
                         user_bias != nullptr, bu, k, ov, oi, uo);
 }
 
+template <int CPL>
+__global__ __launch_bounds__(256) void candidates_finish_kernel(
+    const int32_t* __restrict__ cand_n, const int2* __restrict__ cand_list, int cap, const float* __restrict__ cand_floor,
+    const float2* __restrict__ ustats, const float* __restrict__ gstats, const float* __restrict__ U,
+    const float* __restrict__ V, int64_t ld_u, int64_t ld_v, int kdim, const float* __restrict__ user_bias,
+    const float* __restrict__ item_bias, int32_t item_index_base, int64_t n_users, int k, float* __restrict__ ov,
+    int32_t* __restrict__ oi, int32_t* __restrict__ flag, int32_t* __restrict__ n_flagged,
+    const int32_t* __restrict__ out_index)
+{
+    candidates_finish_user<CPL>((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), cand_n, cand_list, cap, cand_floor, ustats, gstats, U, V,
+                                ld_u, ld_v, kdim, user_bias, item_bias, item_index_base, n_users, k, ov, oi, flag, n_flagged, out_index);
+}
+
+// the same wave-per-user finish over a LIST of users (the ones whose lists are too long for the 16-lane form): a fixed grid whose
+// waves stride over the list; its length is read from device memory, so no host read sits between the two finish launches
+template <int CPL>
+__global__ __launch_bounds__(256) void candidates_finish_listed_kernel(
+    const int32_t* __restrict__ user_list, const int32_t* __restrict__ user_count,
+    const int32_t* __restrict__ cand_n, const int2* __restrict__ cand_list, int cap, const float* __restrict__ cand_floor,
+    const float2* __restrict__ ustats, const float* __restrict__ gstats, const float* __restrict__ U,
+    const float* __restrict__ V, int64_t ld_u, int64_t ld_v, int kdim, const float* __restrict__ user_bias,
+    const float* __restrict__ item_bias, int32_t item_index_base, int64_t n_users, int k, float* __restrict__ ov,
+    int32_t* __restrict__ oi, int32_t* __restrict__ flag, int32_t* __restrict__ n_flagged,
+    const int32_t* __restrict__ out_index)
+{
+    const int count = *user_count;
+    for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < count; i += gridDim.x * 4)
+        candidates_finish_user<CPL>((int64_t)user_list[i], cand_n, cand_list, cap, cand_floor, ustats, gstats, U, V, ld_u, ld_v, kdim,
+                                    user_bias, item_bias, item_index_base, n_users, k, ov, oi, flag, n_flagged, out_index);
+}
+
 // ---- the same finish for SHORT lists: four users per wave ---------------------------------------------------------------------
 // One wave per user is a latency chain (count -> list -> floor -> item rows -> 128-step fmaf chain -> k rounds of maxima): ~17 us
 // however few candidates the user has.  On an item shard of an N-GPU run a user lists ~27 / N candidates (3-4 at N = 8) and the
@@ -735,13 +765,17 @@ __device__ __forceinline__ unsigned long long row16_max_u64(unsigned long long x
     return x;
 }
 
+// CPL candidates per lane (lane j owns candidates j, 16 + j, ...: lists of up to 16 * CPL entries; the single-GPU cascade lists ~15
+// per user, a wave then finishes FOUR users where the wave-per-user form finishes one).  over_list / over_count (nullable): users with
+// a longer list are appended there for candidates_finish_listed_kernel instead of being flagged.
+template <int CPL>
 __global__ __launch_bounds__(256) void candidates_finish16_kernel(
     const int32_t* __restrict__ cand_n, const int2* __restrict__ cand_list, int cap, const float* __restrict__ cand_floor,
     const float2* __restrict__ ustats, const float* __restrict__ gstats, const float* __restrict__ U,
     const float* __restrict__ V, int64_t ld_u, int64_t ld_v, int kdim, const float* __restrict__ user_bias,
     const float* __restrict__ item_bias, int32_t item_index_base, int64_t n_users, int k, float* __restrict__ ov,
     int32_t* __restrict__ oi, int32_t* __restrict__ flag, int32_t* __restrict__ n_flagged,
-    const int32_t* __restrict__ out_index)
+    const int32_t* __restrict__ out_index, int32_t* __restrict__ over_list, int32_t* __restrict__ over_count)
 {
     extern __shared__ __attribute__((aligned(16))) char fsmem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -754,7 +788,9 @@ __global__ __launch_bounds__(256) void candidates_finish16_kernel(
     const int64_t uo = out_index ? (int64_t)out_index[uc] : uc;
     const int n = cand_n[uc];
     const float f0 = cand_floor[uc];
-    const int2 ent = cand_list[uc * (int64_t)cap + gl];
+    int2 ent[CPL];                                           // (unconditional loads inside the list's capacity, masked by the count)
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) ent[c] = cand_list[uc * (int64_t)cap + (gl + 16 * c < cap ? gl + 16 * c : cap - 1)];
     const bool vec = ((ld_v & 3) == 0) && ((ld_u & 3) == 0);
     for (int ch = gl; ch < (kd4 >> 2); ch += 16) {
         f32x4 w = {0.f, 0.f, 0.f, 0.f};
@@ -770,13 +806,20 @@ __global__ __launch_bounds__(256) void candidates_finish16_kernel(
     const float2 st = ustats[uc];
     const unsigned long long EMPTY = merge_key(-INFINITY, 0x7fffffff);
     const bool skip = !live || uo < 0 || !(f0 < INFINITY);                 // (uniform over the 16 lanes of the user)
-    const bool over = n > 16 || n > cap;
+    const bool over = n > 16 * CPL || n > cap;
     // ---- tau = the k-th largest listed score of this user (row maxima: nothing crosses the 16-lane rows)
-    unsigned long long wkey = (!skip && !over && gl < n) ? merge_key(__int_as_float(ent.y), ent.x) : EMPTY;
+    unsigned long long wkey[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c)
+        wkey[c] = (!skip && !over && gl + 16 * c < n) ? merge_key(__int_as_float(ent[c].y), ent[c].x) : EMPTY;
     unsigned long long kth = EMPTY;
     for (int t = 0; t < k; ++t) {
-        kth = row16_max_u64(wkey);
-        if (wkey == kth && kth != EMPTY) wkey = EMPTY;
+        unsigned long long m = wkey[0];
+#pragma unroll
+        for (int c = 1; c < CPL; ++c) m = wkey[c] > m ? wkey[c] : m;
+        kth = row16_max_u64(m);
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) if (wkey[c] == kth && kth != EMPTY) wkey[c] = EMPTY;
     }
     float tau = -INFINITY;
     if (kth != EMPTY) {
@@ -787,12 +830,15 @@ __global__ __launch_bounds__(256) void candidates_finish16_kernel(
     float fl = tau - 2.0f * eps;
     if (tau == -INFINITY) fl = -INFINITY;
     else fl = float_pred(float_pred(fl));
-    const bool keep = !skip && !over && gl < n && __int_as_float(ent.y) >= fl;
     __builtin_amdgcn_wave_barrier();                                       // urow is private to this wave: DS operations of a wave execute in order
-    // ---- exact fp32 score of this lane's candidate: the reference's k-ordered fmaf chain, then (s + b_u) + b_i
-    unsigned long long mine = EMPTY;
-    {
-        const int64_t it = keep ? (int64_t)ent.x - item_index_base : 0;
+    // ---- exact fp32 score of this lane's candidates: the reference's k-ordered fmaf chain, then (s + b_u) + b_i
+    unsigned long long mine[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+        const bool keep = !skip && !over && gl + 16 * c < n && __int_as_float(ent[c].y) >= fl;
+        mine[c] = EMPTY;
+        if (c > 0 && __builtin_amdgcn_ballot_w64(keep) == 0ull) continue;   // (wave-uniform: nobody holds a survivor in this slot)
+        const int64_t it = keep ? (int64_t)ent[c].x - item_index_base : 0;
         const float* b = V + it * ld_v;
         float acc = 0.0f;
         int kk = 0;
@@ -807,23 +853,31 @@ __global__ __launch_bounds__(256) void candidates_finish16_kernel(
         for (; kk < kdim; ++kk) acc = __fmaf_rn(urow[kk], b[kk], acc);
         if (user_bias) acc = acc + bu;
         if (item_bias) acc = acc + item_bias[it];
-        if (keep) mine = merge_key(acc, ent.x);
+        if (keep) mine[c] = merge_key(acc, ent[c].x);
     }
     // ---- the k best by (value desc, index asc): lane t of the user's row writes place t
     unsigned long long place = EMPTY;
     for (int t = 0; t < k; ++t) {
-        const unsigned long long best = row16_max_u64(mine);
-        if (mine == best && best != EMPTY) mine = EMPTY;
+        unsigned long long m = mine[0];
+#pragma unroll
+        for (int c = 1; c < CPL; ++c) m = mine[c] > m ? mine[c] : m;
+        const unsigned long long best = row16_max_u64(m);
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) if (mine[c] == best && best != EMPTY) mine[c] = EMPTY;
         if (gl == t) place = best;
     }
     if (live && uo >= 0) {
-        if (gl < k) {
+        const bool handed_on = over && !skip && over_list != nullptr;      // the listed kernel writes this user's rows
+        if (gl < k && !handed_on) {
             const unsigned int hi = (unsigned int)(place >> 32);
             const unsigned int bits = (hi & 0x80000000u) ? (hi & 0x7fffffffu) : ~hi;
             ov[uo * k + gl] = (place == EMPTY) ? -INFINITY : __uint_as_float(bits);
             oi[uo * k + gl] = (place == EMPTY) ? -1 : (int32_t)(~(unsigned int)place);
         }
-        if (over && !skip && gl == 0 && flag[u] == 0) { flag[u] = 1; atomicAdd(n_flagged, 1); }
+        if (over && !skip && gl == 0) {
+            if (over_list) over_list[atomicAdd(over_count, 1)] = (int32_t)u;
+            else if (flag[u] == 0) { flag[u] = 1; atomicAdd(n_flagged, 1); }
+        }
     }
 }
 
@@ -955,10 +1009,10 @@ extern "C" int trec_topk_candidates_finish(const int32_t* cand_n, const void* ca
         // short lists (item shards): 16 lanes per user, 16 users per workgroup; users with more than 16 candidates are flagged
         TREC_REQUIRE(k <= 16, "trec_topk_candidates_finish: the 16-lane form needs k <= 16");
         const size_t lds16 = (size_t)16 * kd4 * 4;
-        hipLaunchKernelGGL(candidates_finish16_kernel, dim3((unsigned)ceil_div64(n_users, 16)), dim3(256), lds16, st, cand_n,
+        hipLaunchKernelGGL(candidates_finish16_kernel<1>, dim3((unsigned)ceil_div64(n_users, 16)), dim3(256), lds16, st, cand_n,
                            (const int2*)cand, cand_cap, cand_floor, (const float2*)user_stats, item_gstats, users_f32, items_f32,
                            ld_users, ld_items, kdim, user_bias, item_bias, item_index_base, n_users, k, out_vals, out_idx, flag,
-                           n_flagged, out_index);
+                           n_flagged, out_index, (int32_t*)nullptr, (int32_t*)nullptr);
         return trec_check_launch("trec_topk_candidates_finish (16 lanes per user)");
     }
     const unsigned blocks = (unsigned)ceil_div64(n_users, 4);
@@ -974,6 +1028,53 @@ extern "C" int trec_topk_candidates_finish(const int32_t* cand_n, const void* ca
     else { TREC_CF(4); }
 #undef TREC_CF
     return trec_check_launch("trec_topk_candidates_finish");
+}
+
+// The finish in two launches for lists of MIXED length (the single-GPU cascade: ~15 candidates per user, a few users with hundreds):
+// (1) 16 lanes per user, cands_per_lane (1 / 2 / 4) candidates per lane -- four users per wave instead of one; users whose list is
+// longer than 16 * cands_per_lane are appended to over_list [n_users] (over_count [1] zeroed by the caller); (2) the wave-per-user
+// finish over that list on a fixed grid, its length read on the device.  Same results as trec_topk_candidates_finish.
+extern "C" int trec_topk_candidates_finish_mixed(const int32_t* cand_n, const void* cand, int32_t cand_cap, const float* cand_floor,
+                                                 const float* user_stats, const float* item_gstats, const float* users_f32,
+                                                 const float* items_f32, int64_t ld_users, int64_t ld_items, int32_t kdim,
+                                                 const float* user_bias, const float* item_bias, int32_t item_index_base,
+                                                 int64_t n_users, int32_t k, float* out_vals, int32_t* out_idx, int32_t* flag,
+                                                 int32_t* n_flagged, const int32_t* out_index, int32_t cands_per_lane,
+                                                 int32_t* over_list, int32_t* over_count, void* stream)
+{
+    TREC_REQUIRE(cands_per_lane == 1 || cands_per_lane == 2 || cands_per_lane == 4, "trec_topk_candidates_finish_mixed: cands_per_lane must be 1, 2 or 4");
+    TREC_REQUIRE(cand_n && cand && cand_floor && user_stats && item_gstats && users_f32 && items_f32 && out_vals && out_idx &&
+                 flag && n_flagged && over_list && over_count, "trec_topk_candidates_finish_mixed: null pointer");
+    TREC_REQUIRE(cand_cap >= 64 && cand_cap % 64 == 0 && cand_cap <= 256, "trec_topk_candidates_finish_mixed: cand_cap must be 64, 128, 192 or 256");
+    TREC_REQUIRE(k >= 1 && k <= 16, "trec_topk_candidates_finish_mixed: need k <= 16");
+    TREC_REQUIRE(kdim >= 1 && kdim <= 1024 && ld_users >= kdim && ld_items >= ((kdim + 3) & ~3) && n_users < ((int64_t)1 << 31),
+                 "trec_topk_candidates_finish_mixed: need kdim <= 1024, item rows padded to a multiple of 4, n_users < 2^31");
+    if (n_users == 0) return TREC_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int kd4 = (kdim + 3) & ~3;
+    const size_t lds16 = (size_t)16 * kd4 * 4;
+#define TREC_CF16(CPLV)                                                                                                         \
+    hipLaunchKernelGGL(candidates_finish16_kernel<CPLV>, dim3((unsigned)ceil_div64(n_users, 16)), dim3(256), lds16, st, cand_n,  \
+                       (const int2*)cand, cand_cap, cand_floor, (const float2*)user_stats, item_gstats, users_f32, items_f32,    \
+                       ld_users, ld_items, kdim, user_bias, item_bias, item_index_base, n_users, k, out_vals, out_idx, flag,     \
+                       n_flagged, out_index, over_list, over_count)
+    if (cands_per_lane == 1) TREC_CF16(1); else if (cands_per_lane == 2) TREC_CF16(2); else TREC_CF16(4);
+#undef TREC_CF16
+    const int64_t want = ceil_div64(n_users, 4 * 64);                    // (a wave of the listed kernel per ~64 users: lists that long are rare)
+    const unsigned blocks = (unsigned)(want < 64 ? 64 : (want > 4096 ? 4096 : want));
+    const size_t lds = 4 * FILTER_CMAX * 4 + (size_t)4 * kd4 * 4 + (size_t)4 * FILTER_RB * (kd4 + 4) * 4;
+#define TREC_CFL(CPLV)                                                                                                          \
+    (void)hipFuncSetAttribute((const void*)candidates_finish_listed_kernel<CPLV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((candidates_finish_listed_kernel<CPLV>), dim3(blocks), dim3(256), lds, st, (const int32_t*)over_list,      \
+                       (const int32_t*)over_count, cand_n, (const int2*)cand, cand_cap, cand_floor, (const float2*)user_stats,   \
+                       item_gstats, users_f32, items_f32, ld_users, ld_items, kdim, user_bias, item_bias, item_index_base, n_users, \
+                       k, out_vals, out_idx, flag, n_flagged, out_index)
+    if (cand_cap == 64) { TREC_CFL(1); }
+    else if (cand_cap == 128) { TREC_CFL(2); }
+    else if (cand_cap == 192) { TREC_CFL(3); }
+    else { TREC_CFL(4); }
+#undef TREC_CFL
+    return trec_check_launch("trec_topk_candidates_finish_mixed");
 }
 
 // The cascade's thresholds in one pass (cascade_floor_kernel): tau [n_users] IN / OUT (+inf for rows without a source), src

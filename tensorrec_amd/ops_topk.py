@@ -1073,11 +1073,23 @@ def _score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index
         ov = torch.empty((n_out, kk), dtype=torch.float32, device=dev)
         oi = torch.empty((n_out, kk), dtype=torch.int32, device=dev)
         flag, n_flagged = cands.flag, cands.n_flagged
+        # single process, no lane count asked for: lists are ~15 entries long (a few users hold hundreds) -- 16 lanes x 4 candidates
+        # per user, four users per wave, and the wave-per-user form only for the users beyond 64 entries (tuning finish_mixed: 0 =
+        # a wave per user for everybody, the A/B reference; 1 / 2 / 4 = candidates per lane)
+        mixed = int(N.load().trec_get_tuning(b"finish_mixed", 4)) if not finish_lanes and cands.cap <= 256 else 0
         with _tail_of(tail_stream, ov, oi, flag, n_flagged, gstats), _timed("topk_filter_finish"):
-            N.call("trec_topk_candidates_finish", N.ptr(cands.n), N.ptr(cands.items), cands.cap, N.ptr(cands.floor0),
-                   N.ptr(uop.stats), N.ptr(gstats), N.ptr(uop.f32), N.ptr(iop.f32), kpad, kpad, uop.d, N.ptr(user_bias),
-                   N.ptr(item_bias), item_index_base, n_u, kk, N.ptr(ov), N.ptr(oi), N.ptr(flag), N.ptr(n_flagged),
-                   N.ptr(out_index), int(finish_lanes or 0))
+            if mixed in (1, 2, 4):
+                over_count = zero_block(2, dev)             # (allocated inside the tail-stream context: they live on the stream they are used on)
+                over_list = torch.empty((n_u,), dtype=torch.int32, device=dev)
+                N.call("trec_topk_candidates_finish_mixed", N.ptr(cands.n), N.ptr(cands.items), cands.cap, N.ptr(cands.floor0),
+                       N.ptr(uop.stats), N.ptr(gstats), N.ptr(uop.f32), N.ptr(iop.f32), kpad, kpad, uop.d, N.ptr(user_bias),
+                       N.ptr(item_bias), item_index_base, n_u, kk, N.ptr(ov), N.ptr(oi), N.ptr(flag), N.ptr(n_flagged),
+                       N.ptr(out_index), mixed, N.ptr(over_list), N.ptr(over_count))
+            else:
+                N.call("trec_topk_candidates_finish", N.ptr(cands.n), N.ptr(cands.items), cands.cap, N.ptr(cands.floor0),
+                       N.ptr(uop.stats), N.ptr(gstats), N.ptr(uop.f32), N.ptr(iop.f32), kpad, kpad, uop.d, N.ptr(user_bias),
+                       N.ptr(item_bias), item_index_base, n_u, kk, N.ptr(ov), N.ptr(oi), N.ptr(flag), N.ptr(n_flagged),
+                       N.ptr(out_index), int(finish_lanes or 0))
 
         def complete(cands=cands, blockmax=blockmax):
             if FILTER_DEBUG is not None:

@@ -26,7 +26,8 @@ def ops():
 @pytest.fixture
 def tuning():
     from tensorrec_amd import _native
-    defaults = {"cascade_candidates": 1, "cascade_candidates_cap": 256, "cascade_user_batches": 1, "cascade_prerefine": 1}
+    defaults = {"cascade_candidates": 1, "cascade_candidates_cap": 256, "cascade_user_batches": 1, "cascade_prerefine": 1,
+                "finish_mixed": 4}
 
     def set_(name, value):
         assert name in defaults
@@ -205,6 +206,34 @@ def test_users_the_int8_bound_says_nothing_about_are_flagged_before_the_lists(op
     assert np.array_equal(idx, ri) and np.array_equal(vals, rv)
     assert stats["prefilter"] == "int8" and 30 <= stats["flagged_users"] <= 90
     assert dbg["candidates_q50_90_99_999_max"][-1] <= 256
+
+
+@pytest.mark.parametrize("kind", ["gauss", "clustered"])
+def test_mixed_finish_equals_the_wave_per_user_finish(ops, tuning, kind):
+    """trec_topk_candidates_finish_mixed (16 lanes x 1 / 2 / 4 candidates per user -- four users per wave --, users with longer lists
+    handed to the wave-per-user form through a device-side list) against trec_topk_candidates_finish (a wave per user for everybody,
+    finish_mixed = 0) and the oracle: Gaussian rows list ~30 candidates per user at this size (every form takes both routes),
+    clustered rows > 100 for most users (nearly everybody through the hand-over); values and ids bit-identical in all forms."""
+    rng = np.random.default_rng(17)
+    n_u, n_i, d, k = 1500, 300_000, 128, 10
+    if kind == "gauss":
+        u = rng.standard_normal((n_u, d)).astype(np.float32)
+        v = rng.standard_normal((n_i, d)).astype(np.float32)
+    else:
+        cu, cv = rng.standard_normal((256, d)), rng.standard_normal((256, d))
+        u = (cu[rng.integers(0, 256, n_u)] + 0.3 * rng.standard_normal((n_u, d))).astype(np.float32)
+        v = (cv[rng.integers(0, 256, n_i)] + 0.3 * rng.standard_normal((n_i, d))).astype(np.float32)
+    ub = (0.2 * rng.standard_normal(n_u)).astype(np.float32)
+    ib = (0.2 * rng.standard_normal(n_i)).astype(np.float32)
+    rv, ri = O.topk_rows(O.score_dense_exact(u, v, ub, ib), k)
+    cpu = None
+    for mixed in (0, 1, 2, 4):
+        tuning("finish_mixed", mixed)
+        vals, idx, st = run(ops, u, v, k, ub, ib)
+        assert st.get("tail") == "candidate lists", st
+        assert np.array_equal(idx, ri) and np.array_equal(vals, rv), (kind, mixed)
+        cpu = st.get("candidates_per_user") if cpu is None else cpu
+    assert cpu > (60 if kind == "clustered" else 10), cpu
 
 
 @pytest.mark.parametrize("n_shards,short", [(8, True), (2, False)])
