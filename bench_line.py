@@ -48,6 +48,8 @@ def _roofline(r, kernel_chars=80):
            "avg_launch_ms": _num(r.get("avg_launch_ms"))}
     if r.get("traffic_stale"):
         out["traffic_stale"] = _short(r["traffic_stale"], 48)
+    if r.get("traffic") is not None:
+        out["traffic_from_profile"] = True            # PMC counters cannot be read inside the run: committed profiles/ file of the same sources
     return out
 
 
@@ -99,6 +101,8 @@ def compact_line(full, full_path=None):
         "emulated_rank_ms_fit_n8": _num(_get(full, "scale_emulation", "fit", "per_rank_compute_ms_per_step"), 4),
         "cfg": _cfg_verdicts(full.get("configs")),
     }
+    if checks.get("emulated_rank_ms_predict_n8") is not None or checks.get("emulated_rank_ms_fit_n8") is not None:
+        checks["emulated_from_profile"] = True        # one-GPU emulations of one rank of 8, read from profiles/ -- not measured in this run
     if _get(full, "fp32_mfma_mode") and checks["fp32_mfma_equals_all_users"] is None:
         # (records of round 4 carry the user count inside the key)
         for key, val in full["fp32_mfma_mode"].items():

@@ -846,9 +846,14 @@ def _dense_g_fits(n_users, n_items, n_sampled, nnz, dev):
         return False
     if (n_sampled + nnz / float(n_users)) < DENSE_G_MIN_DENSITY * n_items:
         return False
+    need = float(n_users) * ((n_items + 3) // 4 * 4) * 4.0
+    if need <= float(1 << 30):                # (small models: no memory query -- the step may be inside a HIP-graph capture)
+        return True
+    if torch.cuda.is_current_stream_capturing():
+        return False
     free, _ = torch.cuda.mem_get_info(dev)
     free += torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
-    return float(n_users) * ((n_items + 3) // 4 * 4) * 4.0 <= 0.4 * free
+    return need <= 0.4 * free
 
 
 def wmrb_tiled_step(user_in, item_in, user_bias, item_bias, interactions, samples, balanced=False, mode=MODE_DOT):
