@@ -601,6 +601,25 @@ int trec_wmrb_tiled_step(const float* U, const float* V, const float* user_bias,
                          int32_t max_interactions_per_user, float* loss, float* pred_serial, float* dU, float* d_user_bias,
                          float* val_samples, float* val_pairs, float* raw_samples, float* raw_pairs, float* dense_g,
                          int64_t ldg, float* val_rowsum, void* stream);
+/* ONE kernel per training step for models that fit on chip (csrc/step_coop.hip; BASELINE.json configs[1]): the whole of
+ * session.run(tf_optimizer) (tensorrec.py:617-622) for LinearRepresentation (identity user features; any item features) + DotProduct +
+ * WMRB / BalancedWMRB -- item tower forward, sampling, the tiled WMRB step per user, d V = G^T . U, item tower backward, TF-form Adam on
+ * every variable -- as one cooperative launch with grid-wide barriers between its four phases.  Weights W* and Adam slots *_m / *_v are
+ * updated in place (bias pointers: all six or none); loss [P+] and pred_serial [nnz] are written for the caller's log.  samples
+ * [n_users, n_sampled] or NULL: drawn in the kernel, the same bits as trec_sample_items(n_users, user_base, n_items, n_sampled, 0,
+ * seed, step).  f_* : CSR of the item features, ft_*: CSR of their transpose (values through ft_perm).  lr_t / l2 as
+ * trec_adam_tf_step (l2 on the two weight tables only).  trec_fit_step_coop_workspace_floats: floats of workspace, or -1 when the model
+ * is not covered (d % 4 == 0, d <= 128, phases' LDS within 64 KB, G = n_users x n_items within 256 MB); TREC_ERR_UNSUPPORTED (3) when the
+ * device refuses the cooperative launch -- the caller then runs the multi-launch step.                                            */
+int64_t trec_fit_step_coop_workspace_floats(int64_t n_users, int64_t n_items, int32_t d, int32_t n_sampled,
+                                            int32_t max_interactions_per_user);
+int trec_fit_step_coop(float* Wu, float* Wu_m, float* Wu_v, float* Wi, float* Wi_m, float* Wi_v, float* bu, float* bu_m, float* bu_v,
+                       float* bi, float* bi_m, float* bi_v, const int64_t* f_indptr, const int32_t* f_indices, const float* f_values,
+                       const int64_t* ft_indptr, const int32_t* ft_rows, const int32_t* ft_perm, const int64_t* indptr,
+                       const int32_t* x_item, const int32_t* pos_slot, const float* pos_weight, const int32_t* samples, int64_t n_users,
+                       int64_t n_items, int64_t n_item_features, int32_t d, int32_t n_sampled, int32_t max_interactions_per_user,
+                       int64_t user_base, uint64_t seed, uint32_t step, float lr_t, float beta1, float beta2, float eps, float l2,
+                       float* workspace, int64_t workspace_floats, float* loss, float* pred_serial, void* stream);
 /* out[i] += sum of val over the pairs of two lists (either may be empty) whose id is i -- the item-bias gradient d b_i = sum g of
  * bias_prediction_serial (recommendation_graphs.py:44-57) under scores whose row gradient carries another coefficient.  out is
  * NOT cleared; ids outside [0, n_items) are skipped; the sums of an item are added in arrival order.                           */

@@ -20,7 +20,8 @@ _vp, _i32, _i64, _u32, _u64, _f = (ctypes.c_void_p, ctypes.c_int32, ctypes.c_int
                                    ctypes.c_uint64, ctypes.c_float)
 
 _RETURNS_I64 = ("trec_csr_split_workspace_bytes", "trec_rank_rows_workspace_bytes", "trec_user_prep_alloc_rows",
-                "trec_user_prep_workspace_bytes", "trec_group_pairs_staged_bytes", "trec_group_pairs_binned_bytes")      # sizing queries that return a byte count
+                "trec_user_prep_workspace_bytes", "trec_group_pairs_staged_bytes", "trec_group_pairs_binned_bytes",
+                "trec_fit_step_coop_workspace_floats")      # sizing queries that return a byte count
 
 # name -> argtypes, in the order of include/tensorrec_hip.h
 SIGNATURES = {
@@ -138,6 +139,9 @@ SIGNATURES = {
     "trec_wmrb_tiled_lds_bytes": [_i32, _i32, _i32],
     "trec_wmrb_tiled_step": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp,
                              _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
+    "trec_fit_step_coop_workspace_floats": [_i64, _i64, _i32, _i32, _i32],
+    "trec_fit_step_coop": [_vp] * 12 + [_vp] * 6 + [_vp] * 5 + [_i64, _i64, _i64, _i32, _i32, _i32, _i64, _u64, _u32, _f, _f, _f, _f, _f,
+                                                            _vp, _i64, _vp, _vp, _vp],
     "trec_item_weighted_hist": [_vp, _vp, _i64, _vp, _vp, _i64, _i32, _vp, _vp],
     "trec_dense_loss_fwd": [_i32, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp],
     "trec_dense_loss_fwd_phase": [_i32, _i32, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp],

@@ -17,50 +17,7 @@
 // Keys come from Philox4x32-10 with counter (user, 0, step, stream) and key (seed_lo, seed_hi).
 #include "common.hpp"
 
-#define PHILOX_M0 0xD2511F53u
-#define PHILOX_M1 0xCD9E8D57u
-#define PHILOX_W0 0x9E3779B9u
-#define PHILOX_W1 0xBB67AE85u
-
-struct u4 { uint32_t x, y, z, w; };
-
-__host__ __device__ inline u4 philox4x32_10(u4 c, uint32_t k0, uint32_t k1)
-{
-    for (int r = 0; r < 10; ++r) {
-        const uint64_t p0 = (uint64_t)PHILOX_M0 * c.x, p1 = (uint64_t)PHILOX_M1 * c.z;
-        u4 n;
-        n.x = (uint32_t)(p1 >> 32) ^ c.y ^ k0;
-        n.y = (uint32_t)p1;
-        n.z = (uint32_t)(p0 >> 32) ^ c.w ^ k1;
-        n.w = (uint32_t)p0;
-        c = n;
-        k0 += PHILOX_W0; k1 += PHILOX_W1;
-    }
-    return c;
-}
-
-__host__ __device__ inline uint32_t feistel_f(uint32_t r, uint32_t key)
-{
-    uint32_t h = r * 0x9E3779B1u + key;
-    h ^= h >> 15; h *= 0x85EBCA77u;
-    h ^= h >> 13; h *= 0xC2B2AE3Du;
-    h ^= h >> 16;
-    return h;
-}
-
-// one application of the keyed permutation on [0, 2^bits)
-__host__ __device__ inline uint32_t feistel_permute(uint32_t x, int bits, const uint32_t* keys)
-{
-    int wl = bits >> 1, wr = bits - wl;                 // widths of (L, R)
-    uint32_t L = x >> wr, R = x & ((1u << wr) - 1u);
-    for (int r = 0; r < 6; ++r) {
-        const uint32_t nl = R;
-        const uint32_t nr = (L ^ feistel_f(R, keys[r])) & ((1u << wl) - 1u);
-        L = nl; R = nr;
-        const int t = wl; wl = wr; wr = t;
-    }
-    return (L << wr) | R;
-}
+#include "sampler_common.hpp"
 
 __global__ __launch_bounds__(256) void sample_items_kernel(int64_t n_users, int64_t user_base, int32_t n_items,
                                                           int32_t n_sampled, int replace, uint32_t seed_lo,
@@ -81,12 +38,8 @@ __global__ __launch_bounds__(256) void sample_items_kernel(int64_t n_users, int6
         out[idx] = (int32_t)(((uint64_t)w * (uint64_t)(uint32_t)n_items) >> 32);
         return;
     }
-    const u4 ka = philox4x32_10(u4{(uint32_t)u, (uint32_t)(u >> 32), step, 0u}, seed_lo, seed_hi);
-    const u4 kb = philox4x32_10(u4{(uint32_t)u, (uint32_t)(u >> 32), step, 1u}, seed_lo, seed_hi);
-    const uint32_t keys[6] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y};
-    uint32_t x = s;
-    do { x = feistel_permute(x, bits, keys); } while (x >= (uint32_t)n_items);   // cycle-walk back into [0, n_items)
-    out[idx] = (int32_t)x;
+    const SampleKeys keys = sample_keys(u, step, seed_lo, seed_hi);
+    out[idx] = sample_distinct(s, bits, keys, n_items);                         // cycle-walk back into [0, n_items)
 }
 
 static int sample_items_impl(int64_t n_users, int64_t user_base, int32_t n_items, int32_t n_sampled, int32_t replace,
@@ -116,8 +69,7 @@ static int sample_items_impl(int64_t n_users, int64_t user_base, int32_t n_items
     // np.random.choice(replace=False) raises when size > population (util.py:13); same contract here
     TREC_REQUIRE(replace || n_sampled <= n_items, "trec_sample_items: cannot take a larger sample than population when replace is false");
     if (n_users == 0) return TREC_OK;
-    int bits = 2;
-    while (bits < 31 && (1u << bits) < (uint32_t)n_items) ++bits;
+    const int bits = sample_bits(n_items);
     const int64_t total = n_users * (int64_t)n_sampled;
     hipLaunchKernelGGL(sample_items_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, (hipStream_t)stream,
                        n_users, user_base, n_items, n_sampled, replace, (uint32_t)seed, (uint32_t)(seed >> 32), step, bits,

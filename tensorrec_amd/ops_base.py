@@ -197,7 +197,8 @@ def colsum(x):
     out = torch.empty((d,), dtype=torch.float32, device=x.device)
     n_slices = max(1, min(512, n_rows // 256))
     ws = torch.empty((n_slices, d), dtype=torch.float32, device=x.device) if n_slices > 1 else None
-    N.call("trec_colsum", N.ptr(x), n_rows, d, N.ptr(out), N.ptr(ws), n_slices)
+    with _timed("colsum"):
+        N.call("trec_colsum", N.ptr(x), n_rows, d, N.ptr(out), N.ptr(ws), n_slices)
     return out
 
 
@@ -923,8 +924,9 @@ def wmrb_tiled_step(user_in, item_in, user_bias, item_bias, interactions, sample
                    accumulate=True, out=d_v, want_rowsum=d_ib if want_rs else False)      # (row sums accumulate with the rows)
     if need_raw:
         d_ib = torch.zeros((n_items,), dtype=torch.float32, device=dev)
-        N.call("trec_item_weighted_hist", N.ptr(xs), N.ptr(raw_s.reshape(-1)), int(xs.numel()), N.ptr(interactions.x_item32),
-               N.ptr(raw_p), int(nnz), int(n_items), N.ptr(d_ib))
+        with _timed("item_weighted_hist"):
+            N.call("trec_item_weighted_hist", N.ptr(xs), N.ptr(raw_s.reshape(-1)), int(xs.numel()), N.ptr(interactions.x_item32),
+                   N.ptr(raw_p), int(nnz), int(n_items), N.ptr(d_ib))
     return loss, pred, d_u, d_v, d_ub, d_ib
 
 
@@ -1221,14 +1223,16 @@ def rank_of_pairs_by_user(scores, col_offset, begin, end, pair_indptr, xi32, tar
 
 def sample_items(n_users, n_items, n_sampled, replace, seed, step, device="cuda", user_base=0):
     out = torch.empty((n_users, n_sampled), dtype=torch.int32, device=device)
-    N.call("trec_sample_items", n_users, int(user_base), n_items, n_sampled, 1 if replace else 0,
-           int(seed) & (2 ** 64 - 1), int(step) & 0xFFFFFFFF, N.ptr(out))
+    with _timed("sample_items"):
+        N.call("trec_sample_items", n_users, int(user_base), n_items, n_sampled, 1 if replace else 0,
+               int(seed) & (2 ** 64 - 1), int(step) & 0xFFFFFFFF, N.ptr(out))
     return out
 
 
 def adam_tf_step(w, m, v, grad, lr_t, l2_coef, beta1=0.9, beta2=0.999, eps=1e-8):
-    N.call("trec_adam_tf_step", N.ptr(w), N.ptr(m), N.ptr(v), N.ptr(_f32c(grad)), w.numel(), float(lr_t), beta1, beta2,
-           eps, float(l2_coef))
+    with _timed("adam_tf_step"):
+        N.call("trec_adam_tf_step", N.ptr(w), N.ptr(m), N.ptr(v), N.ptr(_f32c(grad)), w.numel(), float(lr_t), beta1, beta2,
+               eps, float(l2_coef))
 
 
 # ------------------------------------------------------------------------------------------------ schedule on the device

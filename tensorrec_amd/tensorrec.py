@@ -585,8 +585,22 @@ class TensorRec(object):
             self.dp_sync()
 
     def _run_epochs(self, epochs, dev_batches, graphed, learning_rate, alpha, batched_alpha, n_sampled_items, verbose):
+        coops = {} if self.loss_graph_factory.is_sample_based else None
         for epoch in range(epochs):
             for batch, (inter, uf, itf) in enumerate(dev_batches):
+                # models that fit on chip: the whole step as one cooperative kernel (from the second step on: the first creates the
+                # variables and their Adam slots)
+                coop = coops.get(batch) if coops is not None else None
+                if coop is None and coops is not None and batch not in coops and (epoch >= 1 or self._opt_step > 0):
+                    coop = coops[batch] = _CoopStep.plan(self, inter, uf, itf, n_sampled_items)
+                if coop is not None and coop.ok:
+                    out = coop.run(self, learning_rate, batched_alpha, verbose)
+                    if out is not False:
+                        loss, serial_predictions, wr_loss = out
+                        if verbose:
+                            logging.info('EPOCH {} BATCH {} loss = {}, weight_reg_l2_loss = {}, mean_pred = {}'.format(
+                                epoch, batch, float(loss.mean()), alpha * wr_loss, float(serial_predictions.mean())))
+                        continue
                 step = graphed.get(batch)
                 if step is None and epoch >= 1 and epochs - epoch >= 2 and batch not in graphed and \
                         self._graph_eligible(inter, n_sampled_items, verbose):
@@ -1598,6 +1612,110 @@ class _GraphedStep(object):
             with torch.no_grad():
                 wr = float(sum(0.5 * float((w.detach() ** 2).sum()) for w in self.weights))
             return self.loss.detach(), self.pred_serial.detach(), wr
+        return None, None, None
+
+
+class _CoopStep(object):
+    """One training step of one user batch as ONE cooperative kernel (csrc/step_coop.hip; trec_fit_step_coop): models that fit on
+    chip -- BASELINE.json configs[1], 943 x 1,682, d = 64 -- are bound by launches, not by memory (~25 graph-replayed launches = 0.68 ms
+    per epoch).  Covered: LinearRepresentation on identity user features, LinearRepresentation on any item features, DotProduct,
+    WMRB / BalancedWMRB, one taste, single process.  Everything else keeps the multi-launch / HIP-graph step."""
+
+    @classmethod
+    def plan(cls, model, inter, uf, itf, n_sampled_items):
+        from .representation_graphs import LinearRepresentationGraph
+        N = ops.N
+        if N.load().trec_get_tuning(b"fit_step_coop", 1) == 0 or model._dp_active() or model._capture is not None or \
+                getattr(model, 'deterministic', False) or model._multi() or model.attention_graph_factory is not None:
+            return None
+        if type(model.user_repr_graph_factory) is not LinearRepresentationGraph or \
+                type(model.item_repr_graph_factory) is not LinearRepresentationGraph or \
+                type(model.prediction_graph_factory) is not DotProductPredictionGraph or \
+                type(model.loss_graph_factory) not in (WMRBLossGraph, BalancedWMRBLossGraph) or not n_sampled_items:
+            return None
+        if not getattr(uf, "is_identity", False) or uf.shape[0] != inter.shape[0] or int(n_sampled_items) > inter.shape[1]:
+            return None
+        store = model._store
+        names = ["linear_weights_user_0", "linear_weights_item"] + (["user_feature_biases", "item_feature_biases"] if model.biased else [])
+        if set(store.variables) != set(names) or any(n not in model._adam for n in names):
+            return None                                         # (the first eager step creates variables and Adam slots)
+        n_users, n_items = inter.shape
+        d = int(model.n_components)
+        if store.variables[names[0]].shape != (n_users, d) or store.variables[names[1]].shape != (itf.shape[1], d):
+            return None
+        need = int(N.query("trec_fit_step_coop_workspace_floats", n_users, n_items, d, int(n_sampled_items), int(inter.max_row_nnz)))
+        if need < 0:
+            return None
+        self = cls()
+        self.inter, self.itf, self.S, self.names = inter, itf, int(n_sampled_items), names
+        dev = store.device
+        self.ws = torch.empty((need,), dtype=torch.float32, device=dev)
+        self.loss = torch.empty((inter.n_positive,), dtype=torch.float32, device=dev)
+        self.pred = torch.empty((inter.nnz,), dtype=torch.float32, device=dev)
+        self.weight = inter.balanced_weight() if model.loss_graph_factory.balanced else None
+        self.device_sampler = type(model.sampler) is DeviceSampler
+        self.powers = None                                      # (opt step, beta1^t, beta2^t) as TF keeps them: float32 running products
+        self.ok = True
+        return self
+
+    def _lr_t(self, lr, t):
+        if self.powers is None or self.powers[0] != t - 1:
+            b1p, b2p = np.float32(1.0), np.float32(1.0)
+            for _ in range(int(t) - 1):
+                b1p = np.float32(b1p * np.float32(ADAM_BETA1))
+                b2p = np.float32(b2p * np.float32(ADAM_BETA2))
+        else:
+            _, b1p, b2p = self.powers
+        b1p = np.float32(b1p * np.float32(ADAM_BETA1))
+        b2p = np.float32(b2p * np.float32(ADAM_BETA2))
+        self.powers = (t, b1p, b2p)
+        return float(np.float32(np.float32(lr) * np.sqrt(np.float32(1.0) - b2p) / (np.float32(1.0) - b1p)))
+
+    def run(self, model, learning_rate, alpha, want_stats):
+        """Returns (loss, serial predictions, weight-reg loss) like _train_step, or False when the device refused the launch (the
+        caller falls back for good)."""
+        N = ops.N
+        store, inter, itf = model._store, self.inter, self.itf
+        v = store.variables
+        wu, wi = v[self.names[0]], v[self.names[1]]
+        mu, vu = model._adam[self.names[0]]
+        mi, vi = model._adam[self.names[1]]
+        if model.biased:
+            bu, bi = v[self.names[2]], v[self.names[3]]
+            (bum, buv), (bim, biv) = model._adam[self.names[2]], model._adam[self.names[3]]
+        else:
+            bu = bi = bum = buv = bim = biv = None
+        model._sample_step += 1
+        samples = None
+        if not self.device_sampler:
+            samples = model.sampler.sample(inter.shape[1], inter.shape[0], self.S, False, model._sample_step, store.device,
+                                           getattr(inter, 'user_base', 0)).to(torch.int32).contiguous()
+        t = model._opt_step + 1
+        lr_t = self._lr_t(learning_rate, t)
+        l2 = float(np.float32(np.float32(inter.n_positive) * np.float32(alpha)))
+        ft_indptr, ft_rows, ft_perm = itf.transposed()
+        seed = (model.sampler.seed if self.device_sampler else 0) & (2 ** 64 - 1)
+        lib = N.load()
+        with torch.no_grad():
+            rc = lib.trec_fit_step_coop(
+                N.ptr(wu), N.ptr(mu), N.ptr(vu), N.ptr(wi), N.ptr(mi), N.ptr(vi), N.ptr(bu), N.ptr(bum), N.ptr(buv), N.ptr(bi),
+                N.ptr(bim), N.ptr(biv), N.ptr(itf.indptr), N.ptr(itf.indices), N.ptr(itf.values), N.ptr(ft_indptr), N.ptr(ft_rows),
+                N.ptr(ft_perm), N.ptr(inter.indptr), N.ptr(inter.x_item32), N.ptr(inter.pos_slot), N.ptr(self.weight), N.ptr(samples),
+                inter.shape[0], inter.shape[1], itf.shape[1], int(model.n_components), self.S, int(inter.max_row_nnz),
+                int(getattr(inter, 'user_base', 0)), seed, int(model._sample_step) & 0xFFFFFFFF, lr_t, ADAM_BETA1, ADAM_BETA2,
+                ADAM_EPSILON, l2, N.ptr(self.ws), int(self.ws.numel()), N.ptr(self.loss), N.ptr(self.pred), N.stream())
+        if rc == 3:                                             # TREC_ERR_UNSUPPORTED: no cooperative launch on this device / occupancy
+            model._sample_step -= 1
+            self.ok = False
+            return False
+        if rc != 0:
+            raise RuntimeError("trec_fit_step_coop failed (code %d): %s" % (rc, lib.trec_last_error().decode()))
+        model._opt_step = t
+        model._schedule_mirror = None                           # (the device-side schedule of graph replays is stale now)
+        if want_stats:
+            with torch.no_grad():
+                wr = float(0.5 * float((wu.detach() ** 2).sum()) + 0.5 * float((wi.detach() ** 2).sum()))
+            return self.loss.detach(), self.pred.detach(), wr
         return None, None, None
 
 

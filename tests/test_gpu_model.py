@@ -646,6 +646,54 @@ def test_hip_graph_replay_equals_eager_steps(loss, kw, batch):
             assert np.allclose(wa[k], wb[k], rtol=1e-3, atol=2e-3), k
 
 
+@pytest.mark.parametrize("loss,biased,sampler,d,S", [("wmrb", True, "device", 64, 40), ("balanced_wmrb", False, "replay", 32, 25),
+                                                     ("wmrb", True, "replay", 128, 60), ("wmrb", True, "device", 20, 7)])
+def test_single_kernel_step_equals_multi_launch_steps(loss, biased, sampler, d, S, monkeypatch):
+    """csrc/step_coop.hip: the whole optimiser step of a model that fits on chip (tensorrec.py:617-622 -- sampling, both towers,
+    serial + sampled predictions, WMRB, autodiff, Adam) as ONE cooperative kernel, against the same fit made of separate launches:
+    the same step and sample counters, the same weights up to summation order -- with the samples drawn INSIDE the kernel (device
+    sampler: the bits of trec_sample_items, or the fits would diverge within a step) and with replayed tables; item features with
+    side columns, a user without interactions, negative interactions."""
+    import tensorrec_amd.tensorrec as TT
+    rng = np.random.default_rng(11)
+    n_users, n_items, steps = 150, 333, 7
+    inter = sp.random(n_users, n_items, density=0.08, random_state=3, format="csr", dtype=np.float32)
+    inter.data[:] = np.where(rng.random(inter.nnz) < 0.85, 1.0, -1.0)
+    inter[7, :] = 0
+    inter.eliminate_zeros()
+    uf = sp.identity(n_users, dtype=np.float32, format="csr")
+    import bench_records as BR
+    itf = BR._side_features(n_items, 19, 3, rng)
+    srng = np.random.RandomState(5)
+    tables = [O.sample_items(n_items, n_users, S, False, srng)[:, 1].reshape(n_users, S) for _ in range(steps)]
+    calls = {"run": 0}
+    orig_run = TT._CoopStep.run
+
+    def run(self, *a, **k):
+        out = orig_run(self, *a, **k)
+        calls["run"] += out is not False
+        return out
+    monkeypatch.setattr(TT._CoopStep, "run", run)
+    out = []
+    for coop in (1, 0):
+        T._native.set_tuning("fit_step_coop", coop)
+        try:
+            kw = {"sampler": T.ReplaySampler(tables)} if sampler == "replay" else {}
+            model = T.TensorRec(n_components=d, loss_graph=LOSS[loss](), biased=biased, seed=9, hip_graphs=False, **kw)
+            model.fit(inter, uf, itf, epochs=steps, learning_rate=0.05, n_sampled_items=S)
+            out.append((model.get_weights(), model._opt_step, model._sample_step, model.predict(uf, itf)))
+        finally:
+            T._native.set_tuning("fit_step_coop", 1)
+        if coop:
+            assert calls["run"] == steps - 1, calls                  # (the first step is eager: it creates variables and slots)
+    (wa, oa, sa, pa), (wb, ob, sb, pb) = out
+    assert (oa, sa) == (ob, sb) == (steps, steps) and calls["run"] == steps - 1
+    for k in wa:
+        if k != "user_feature_biases":                                # (zero-gradient weight under WMRB: Adam amplifies rounding noise)
+            assert np.allclose(wa[k], wb[k], rtol=1e-3, atol=2e-3), k
+    assert np.abs(pa - pb).max() <= 2e-2 * max(1.0, np.abs(pb).max())
+
+
 def test_hip_graph_is_actually_used(monkeypatch):
     import tensorrec_amd.tensorrec as TT
     calls = {"capture": 0, "run": 0}
