@@ -394,6 +394,7 @@ def config1_record(device):
     model.fit_partial(inter, uf, itf, epochs=220, learning_rate=lr, n_sampled_items=S)
     torch.cuda.synchronize()
     per_epoch = (time.perf_counter() - t0 - t20) / 200.0
+    step_form = getattr(model, "last_step_form", None)
     del model
     # algorithmic bytes of a step: every pair's item row once + user rows in / out + the dense Adam update
     pairs = n_users * S + inter.nnz
@@ -411,8 +412,11 @@ def config1_record(device):
     return {"workload": "BASELINE.json configs[1]: %d x %d (MovieLens-100K-shaped, %d interactions, Zipf items; item features "
                         "identity (+) 19 indicator columns), Linear d=%d + DotProduct + WMRB, S=%d" % (n_users, n_items, inter.nnz, d, S),
             "ms_per_epoch": 1e3 * per_epoch, "fit_epochs_per_sec": 1.0 / per_epoch,
-            "note": "latency-bound: the whole step is one HIP-graph replay (~25 kernels of a few microseconds each)",
-            "roofline": {"bound": "latency (graph replay); priced against HBM for reference", "achieved": alg / per_epoch / 1e9,
+            "step_form": step_form,
+            "note": "latency-bound by construction (69 MB of algorithmic traffic per step): the step is ONE cooperative kernel "
+                    "(csrc/step_coop.hip: four phases between grid-wide barriers) when step_form is 'coop'; 'graph' = a HIP-graph replay "
+                    "of ~20 launches (0.44-0.68 ms)",
+            "roofline": {"bound": "latency (one cooperative launch per step); priced against HBM for reference", "achieved": alg / per_epoch / 1e9,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / per_epoch / 1e9 / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_step": alg},
             "parity_one_step_vs_oracle": parity}

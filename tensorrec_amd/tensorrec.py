@@ -259,6 +259,7 @@ class TensorRec(object):
         self._store = None
         self._graph_pool_owner = []
         self.last_route = None        # what predict_top_k did last (route report)
+        self.last_step_form = None    # how the last training step ran: "coop" (one cooperative kernel), "graph" (HIP-graph replay), "eager"
         self._capture = None          # tests set this to a dict to receive the last step's loss and raw gradients
         self._adam = {}
         self._opt_step = 0
@@ -596,6 +597,7 @@ class TensorRec(object):
                 if coop is not None and coop.ok:
                     out = coop.run(self, learning_rate, batched_alpha, verbose)
                     if out is not False:
+                        self.last_step_form = "coop"
                         loss, serial_predictions, wr_loss = out
                         if verbose:
                             logging.info('EPOCH {} BATCH {} loss = {}, weight_reg_l2_loss = {}, mean_pred = {}'.format(
@@ -606,6 +608,7 @@ class TensorRec(object):
                         self._graph_eligible(inter, n_sampled_items, verbose):
                     step = graphed[batch] = _GraphedStep.capture(self, inter, uf, itf, n_sampled_items, learning_rate,
                                                                  batched_alpha)
+                self.last_step_form = "graph" if step else "eager"
                 if step:
                     loss, serial_predictions, wr_loss = step.run(self, verbose)
                 else:

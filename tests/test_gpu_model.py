@@ -680,17 +680,25 @@ def test_single_kernel_step_equals_multi_launch_steps(loss, biased, sampler, d, 
         try:
             kw = {"sampler": T.ReplaySampler(tables)} if sampler == "replay" else {}
             model = T.TensorRec(n_components=d, loss_graph=LOSS[loss](), biased=biased, seed=9, hip_graphs=False, **kw)
-            model.fit(inter, uf, itf, epochs=steps, learning_rate=0.05, n_sampled_items=S)
-            out.append((model.get_weights(), model._opt_step, model._sample_step, model.predict(uf, itf)))
+            model.fit(inter, uf, itf, epochs=1, learning_rate=0.05, n_sampled_items=S)              # eager: variables + slots
+            m1 = {n: mv[0].cpu().numpy().copy() for n, mv in model._adam.items()}
+            model.fit_partial(inter, uf, itf, epochs=1, learning_rate=0.05, n_sampled_items=S)      # the step under test
+            # the step's gradient (L2 term included) read back from Adam's first moment: m2 = b1 m1 + (1 - b1) g
+            g2 = {n: (mv[0].cpu().numpy() - np.float32(0.9) * m1[n]) / np.float32(0.1) for n, mv in model._adam.items()}
+            model.fit_partial(inter, uf, itf, epochs=steps - 2, learning_rate=0.05, n_sampled_items=S)
+            out.append((g2, model._opt_step, model._sample_step, model.predict(uf, itf)))
         finally:
             T._native.set_tuning("fit_step_coop", 1)
         if coop:
-            assert calls["run"] == steps - 1, calls                  # (the first step is eager: it creates variables and slots)
-    (wa, oa, sa, pa), (wb, ob, sb, pb) = out
+            assert calls["run"] == steps - 1, calls                  # (every step but the first)
+    (ga, oa, sa, pa), (gb, ob, sb, pb) = out
     assert (oa, sa) == (ob, sb) == (steps, steps) and calls["run"] == steps - 1
-    for k in wa:
-        if k != "user_feature_biases":                                # (zero-gradient weight under WMRB: Adam amplifies rounding noise)
-            assert np.allclose(wa[k], wb[k], rtol=1e-3, atol=2e-3), k
+    gmax = max(np.abs(g).max() for g in gb.values())
+    for k in gb:
+        # (read back through m: its fp32 rounding, 6e-8 |m| / (1 - b1), is part of the bar)
+        assert np.abs(ga[k] - gb[k]).max() <= 3e-5 * gmax, "%s: %g (gmax %g)" % (k, np.abs(ga[k] - gb[k]).max(), gmax)
+    # five more steps each way: Adam turns rounding noise of near-zero gradients into steps of up to lr, so the fits are compared
+    # by what they predict
     assert np.abs(pa - pb).max() <= 2e-2 * max(1.0, np.abs(pb).max())
 
 
