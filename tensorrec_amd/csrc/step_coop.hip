@@ -11,8 +11,8 @@
 //   phase 2  per user (identity user features: the user's representation IS its row of W_u): the samples drawn in the kernel (the same
 //            Philox / Feistel bits as trec_sample_items) or read from a table, then the tiled WMRB body of csrc/wmrb_tiled_body.hpp --
 //            scores in LDS, loss, coefficients scatter-added into G, dU from a second sweep over the rows
-//   phase 3  d V = G^T . U (the item side of the backward pass; G is ~15 % dense at S = 168 of 1,682 items) in four user segments,
-//            d b_i = column sums of G
+//   phase 3  d V = G^T . U (the item side of the backward pass; G is ~15 % dense at S = 168 of 1,682 items): tiles of 16 items x a
+//            segment of users staged in LDS, d b_i = column sums of G
 //   phase 4  item tower backward on the transposed CSR (d W_i = X_i^T . dV, d beta_i = X_i^T . d b_i, fmaf in transposed-CSR order)
 //            with the TF-form Adam update of every row right behind its gradient; Adam on the users' rows
 // Results: within summation order of the multi-launch path (same bar against the oracle: tests/test_gpu_shapes.py, the configs[1]
@@ -34,8 +34,18 @@ __device__ __forceinline__ void adam_elem(float& w, float& m, float& v, float g,
     w = __fsub_rn(w, __fdiv_rn(__fmul_rn(m, lr_t), __fadd_rn(sqrtf(v), eps)));
 }
 
-constexpr int COOP_SEGMENTS = 4;      // user segments of phase 3 (their partial d V are added in segment order)
 constexpr int COOP_IB = 16;           // items per workgroup tile of phase 3
+constexpr int COOP_P3_LDS = 32 * 1024;   // LDS of a phase-3 tile: a segment of user rows + their coefficients for COOP_IB items
+
+// users per phase-3 segment: at least 8 segments (tiles = item blocks x segments must cover every workgroup), and a segment's
+// [seg_len][COOP_IB + d] floats within COOP_P3_LDS
+__host__ __device__ inline int64_t coop_seg_len(int64_t n_users, int d)
+{
+    int64_t by_lds = COOP_P3_LDS / (4 * (COOP_IB + d));
+    int64_t by_count = (n_users + 7) / 8;
+    int64_t s = by_count < by_lds ? by_count : by_lds;
+    return s < 16 ? 16 : s;
+}
 
 struct CoopArgs {
     // weights and their Adam slots (updated in place)
@@ -50,7 +60,7 @@ struct CoopArgs {
     const int64_t* indptr; const int32_t* xi; const int32_t* pos_slot; const float* pos_weight;
     const int32_t* samples;                         // [n_users, S] or null: drawn here
     // workspace
-    float* V; float* ib; float* G; float* dU; float* dub; float* dV_part; float* dib;
+    float* V; float* ib; float* G; float* dU; float* dub; float* dV; float* dib;
     // outputs
     float* loss; float* pred_serial;
     int64_t n_users, n_items, n_item_features, ldg, user_base;
@@ -90,6 +100,9 @@ __global__ __launch_bounds__(256) void fit_step_coop_kernel(CoopArgs a)
         const int64_t n4 = (a.n_users * a.ldg) >> 2;     // (ldg % 4 == 0)
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
         for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < n4; i += (int64_t)gridDim.x * 256) ((f32x4*)a.G)[i] = z;
+        // (d V [n_items, d] and d b_i [n_items, padded to 4] follow each other in the workspace: phase 3 adds its segments into them)
+        const int64_t m4 = (a.n_items * d + ((a.n_items + 3) & ~(int64_t)3)) >> 2;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < m4; i += (int64_t)gridDim.x * 256) ((f32x4*)a.dV)[i] = z;
     }
     grid.sync();
 
@@ -113,48 +126,44 @@ __global__ __launch_bounds__(256) void fit_step_coop_kernel(CoopArgs a)
     }
     grid.sync();
 
-    // ---- phase 3: d V = G^T . U in COOP_SEGMENTS user segments (a tile = COOP_IB items x one segment), d b_i = column sums of G ----
+    // ---- phase 3: d V += G^T . U, d b_i += column sums of G.  A tile = COOP_IB items x one segment of users; the segment's user
+    // rows and its coefficients for these items are staged in LDS (coalesced), every thread = (item, float4 column group) then runs
+    // over the segment from LDS; the segments' partial sums meet in d V by float atomics (order-free up to rounding) ----
     {
         const int64_t n_tiles_i = (a.n_items + COOP_IB - 1) / COOP_IB;
-        const int64_t seg_len = (a.n_users + COOP_SEGMENTS - 1) / COOP_SEGMENTS;
-        float* l_g = lds;                                  // [seg_len][COOP_IB] coefficients of this tile
-        const int k = tid / 16, c4 = tid % 16;             // thread = (item k of the tile, float4 column groups c4, c4 + 16, ...)
-        for (int64_t t = blockIdx.x; t < n_tiles_i * COOP_SEGMENTS; t += gridDim.x) {
-            const int64_t ti = t / COOP_SEGMENTS, seg = t % COOP_SEGMENTS;
+        const int64_t seg_len = coop_seg_len(a.n_users, d);
+        const int64_t n_seg = (a.n_users + seg_len - 1) / seg_len;
+        float* l_g = lds;                                  // [seg_len][COOP_IB]
+        float* l_u = lds + seg_len * COOP_IB;              // [seg_len][d]
+        const int k = tid / 16, c4 = tid % 16;
+        for (int64_t t = blockIdx.x; t < n_tiles_i * n_seg; t += gridDim.x) {
+            const int64_t ti = t / n_seg, seg = t % n_seg;
             const int64_t i0 = ti * COOP_IB, u0 = seg * seg_len;
             const int64_t u1 = u0 + seg_len < a.n_users ? u0 + seg_len : a.n_users;
-            const int nu = (int)(u1 > u0 ? u1 - u0 : 0);
+            const int nu = (int)(u1 - u0);
             __syncthreads();
             for (int e = tid; e < nu * COOP_IB; e += 256) {
                 const int uu = e / COOP_IB, kk = e % COOP_IB;
                 l_g[e] = (i0 + kk < a.n_items) ? a.G[(u0 + uu) * a.ldg + i0 + kk] : 0.f;
             }
+            for (int e = tid; e < nu * d4; e += 256) ((f32x4*)l_u)[e] = ((const f32x4*)(a.Wu + u0 * d))[e];
             __syncthreads();
-            float bsum = 0.f;
-            for (int cc = c4; cc < d4; cc += 16) {
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                int uu = 0;
-                for (; uu + 4 <= nu; uu += 4) {            // four user rows in flight
-                    f32x4 w[4];
-                    float g[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) { w[q] = *(const f32x4*)(a.Wu + (u0 + uu + q) * d + cc * 4); g[q] = l_g[(uu + q) * COOP_IB + k]; }
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        acc.x = fmaf(g[q], w[q].x, acc.x); acc.y = fmaf(g[q], w[q].y, acc.y);
-                        acc.z = fmaf(g[q], w[q].z, acc.z); acc.w = fmaf(g[q], w[q].w, acc.w);
+            if (i0 + k < a.n_items) {
+                for (int cc = c4; cc < d4; cc += 16) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    for (int uu = 0; uu < nu; ++uu) {
+                        const float g = l_g[uu * COOP_IB + k];
+                        const f32x4 w = *(const f32x4*)(l_u + uu * d + cc * 4);
+                        acc.x = fmaf(g, w.x, acc.x); acc.y = fmaf(g, w.y, acc.y); acc.z = fmaf(g, w.z, acc.z); acc.w = fmaf(g, w.w, acc.w);
                     }
+                    float* out = a.dV + (i0 + k) * d + cc * 4;
+                    unsafeAtomicAdd(out + 0, acc.x); unsafeAtomicAdd(out + 1, acc.y); unsafeAtomicAdd(out + 2, acc.z); unsafeAtomicAdd(out + 3, acc.w);
                 }
-                for (; uu < nu; ++uu) {
-                    const f32x4 w = *(const f32x4*)(a.Wu + (u0 + uu) * d + cc * 4);
-                    const float g = l_g[uu * COOP_IB + k];
-                    acc.x = fmaf(g, w.x, acc.x); acc.y = fmaf(g, w.y, acc.y); acc.z = fmaf(g, w.z, acc.z); acc.w = fmaf(g, w.w, acc.w);
+                if (a.bi && c4 == 0) {
+                    float bsum = 0.f;
+                    for (int uu = 0; uu < nu; ++uu) bsum += l_g[uu * COOP_IB + k];
+                    unsafeAtomicAdd(a.dib + i0 + k, bsum);
                 }
-                if (i0 + k < a.n_items) *(f32x4*)(a.dV_part + (seg * a.n_items + i0 + k) * d + cc * 4) = acc;
-            }
-            if (a.bi && c4 == 0 && i0 + k < a.n_items) {
-                for (int uu = 0; uu < nu; ++uu) bsum += l_g[uu * COOP_IB + k];
-                a.dib[seg * a.n_items + i0 + k] = bsum;
             }
         }
     }
@@ -170,23 +179,29 @@ __global__ __launch_bounds__(256) void fit_step_coop_kernel(CoopArgs a)
             float accb = 0.f;
             // the row's entries are dealt to the groups in turn; every group keeps CSR order inside its share, the shares are added
             // in group order (deterministic)
-            for (int64_t j = j0 + grp; j < j1; j += n_grp) {
-                const float x = a.f_values[a.ft_perm[j]];
-                const int64_t r = a.ft_rows[j];
-                if (col_ok) {
-                    f32x4 g = *(const f32x4*)(a.dV_part + r * d + sub * 4);
+            for (int64_t jb = j0 + grp; jb < j1; jb += 4 * n_grp) {          // four of the group's entries in flight
+                int32_t pj[4], rj[4];
+                float xj[4];
+                f32x4 gj[4];
+                float bj[4];
 #pragma unroll
-                    for (int s = 1; s < COOP_SEGMENTS; ++s) {
-                        const f32x4 p = *(const f32x4*)(a.dV_part + (s * a.n_items + r) * d + sub * 4);
-                        g.x += p.x; g.y += p.y; g.z += p.z; g.w += p.w;
-                    }
-                    acc.x = fmaf(x, g.x, acc.x); acc.y = fmaf(x, g.y, acc.y); acc.z = fmaf(x, g.z, acc.z); acc.w = fmaf(x, g.w, acc.w);
+                for (int q = 0; q < 4; ++q) {
+                    const int64_t j = jb + q * n_grp < j1 ? jb + q * n_grp : j1 - 1;
+                    pj[q] = a.ft_perm[j]; rj[q] = a.ft_rows[j];
                 }
-                if (a.bi && sub == 0) {
-                    float gb = a.dib[r];
 #pragma unroll
-                    for (int s = 1; s < COOP_SEGMENTS; ++s) gb += a.dib[s * a.n_items + r];
-                    accb = fmaf(x, gb, accb);
+                for (int q = 0; q < 4; ++q) {
+                    xj[q] = a.f_values[pj[q]];
+                    gj[q] = *(const f32x4*)(a.dV + (int64_t)rj[q] * d + (col_ok ? sub * 4 : 0));
+                    bj[q] = a.bi ? a.dib[rj[q]] : 0.f;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (jb + q * n_grp < j1) {
+                        acc.x = fmaf(xj[q], gj[q].x, acc.x); acc.y = fmaf(xj[q], gj[q].y, acc.y);
+                        acc.z = fmaf(xj[q], gj[q].z, acc.z); acc.w = fmaf(xj[q], gj[q].w, acc.w);
+                        accb = fmaf(xj[q], bj[q], accb);
+                    }
                 }
             }
             __syncthreads();
@@ -235,8 +250,7 @@ int64_t coop_lds_bytes(int32_t n_sampled, int32_t max_pos, int32_t d, int64_t n_
 {
     const int64_t mr4 = ((int64_t)n_sampled + max_pos + 3) & ~(int64_t)3, mp4 = ((int64_t)max_pos + 3) & ~(int64_t)3;
     const int64_t p2 = (2 * mr4 + 2 * mp4 + 8 * (int64_t)d + 8 + n_sampled + 4) * 4;
-    const int64_t seg_len = (n_users + COOP_SEGMENTS - 1) / COOP_SEGMENTS;
-    const int64_t p3 = seg_len * COOP_IB * 4;
+    const int64_t p3 = coop_seg_len(n_users, d) * (COOP_IB + d) * 4;
     const int64_t p4 = 16 * ((int64_t)d + 4) * 4;
     int64_t m = p2 > p3 ? p2 : p3;
     return m > p4 ? m : p4;
@@ -246,7 +260,7 @@ int64_t coop_lds_bytes(int32_t n_sampled, int32_t max_pos, int32_t d, int64_t n_
 
 // Workspace floats of trec_fit_step_coop, or -1 when the model is not covered: d % 4 == 0, d <= 128, the LDS of its phases within
 // 64 KB (n_sampled + longest interaction row in the low thousands; n_users <= ~4,000), ldg = n_items rounded up to 4.
-// Layout: V [n_items, d] | ib [n_items] | G [n_users, ldg] | dU [n_users, d] | dub [n_users] | dV_part [4, n_items, d] | dib [4, n_items]
+// Layout: V [n_items, d] | ib [n_items] | G [n_users, ldg] | dU [n_users, d] | dub [n_users] | dV [n_items, d] | dib [n_items]
 extern "C" int64_t trec_fit_step_coop_workspace_floats(int64_t n_users, int64_t n_items, int32_t d, int32_t n_sampled,
                                                        int32_t max_interactions_per_user)
 {
@@ -255,7 +269,7 @@ extern "C" int64_t trec_fit_step_coop_workspace_floats(int64_t n_users, int64_t 
     if (coop_lds_bytes(n_sampled, max_interactions_per_user, d, n_users) > 64 * 1024) return -1;
     const int64_t ldg = (n_items + 3) / 4 * 4;
     if (n_users * ldg > ((int64_t)1 << 26)) return -1;                 // G up to 256 MB: beyond that the multi-launch path is not launch-bound
-    return n_items * d + n_items + n_users * ldg + n_users * d + n_users + COOP_SEGMENTS * n_items * d + COOP_SEGMENTS * n_items + 64;
+    return n_items * d + n_items + n_users * ldg + n_users * d + n_users + n_items * d + n_items + 64;
 }
 
 // One optimiser step of Linear (identity user features) + Linear (any item features) + DotProduct + WMRB / BalancedWMRB in ONE
@@ -296,7 +310,7 @@ extern "C" int trec_fit_step_coop(float* Wu, float* Wu_m, float* Wu_v, float* Wi
     a.G = w; w += n_users * ldg;
     a.dU = w; w += n_users * d;
     a.dub = w; w += (n_users + 3) / 4 * 4;
-    a.dV_part = w; w += COOP_SEGMENTS * n_items * d;
+    a.dV = w; w += n_items * d;
     a.dib = w;
     a.loss = loss; a.pred_serial = pred_serial;
     a.n_users = n_users; a.n_items = n_items; a.n_item_features = n_item_features; a.ldg = ldg; a.user_base = user_base;
@@ -318,7 +332,8 @@ extern "C" int trec_fit_step_coop(float* Wu, float* Wu_m, float* Wu_v, float* Wi
         trec_set_last_error("trec_fit_step_coop: no workgroup of the step fits a compute unit");
         return TREC_ERR_UNSUPPORTED;
     }
-    const hipError_t e = hipLaunchCooperativeKernel(fn, dim3((unsigned)cus), dim3(256), args, (unsigned)lds, (hipStream_t)stream);
+    if (per_cu > 4) per_cu = 4;                         // (more resident workgroups shorten every phase's rounds; the barrier grows with them)
+    const hipError_t e = hipLaunchCooperativeKernel(fn, dim3((unsigned)(cus * per_cu)), dim3(256), args, (unsigned)lds, (hipStream_t)stream);
     if (e != hipSuccess) {
         (void)hipGetLastError();
         trec_set_last_error("trec_fit_step_coop: cooperative launch refused");

@@ -697,9 +697,12 @@ def test_single_kernel_step_equals_multi_launch_steps(loss, biased, sampler, d, 
     for k in gb:
         # (read back through m: its fp32 rounding, 6e-8 |m| / (1 - b1), is part of the bar)
         assert np.abs(ga[k] - gb[k]).max() <= 3e-5 * gmax, "%s: %g (gmax %g)" % (k, np.abs(ga[k] - gb[k]).max(), gmax)
-    # five more steps each way: Adam turns rounding noise of near-zero gradients into steps of up to lr, so the fits are compared
-    # by what they predict
-    assert np.abs(pa - pb).max() <= 2e-2 * max(1.0, np.abs(pb).max())
+    # five more steps each way: Adam turns the rounding noise of near-zero gradients into steps of up to lr -- the user biases above
+    # all, whose WMRB gradient is exactly 0 in exact arithmetic (b_u cancels inside every hinge) -- so the fits are compared by what
+    # they predict, up to each user's constant offset (which no ranking and no WMRB loss sees)
+    diff = pa - pb
+    diff = diff - diff.mean(axis=1, keepdims=True)
+    assert np.abs(diff).max() <= 2e-2 * max(1.0, np.abs(pb).max())
 
 
 def test_hip_graph_is_actually_used(monkeypatch):
