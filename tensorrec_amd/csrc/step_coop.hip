@@ -67,6 +67,7 @@ struct CoopArgs {
     int32_t S, d, max_rows, max_pos, sample_bits;
     uint32_t seed_lo, seed_hi, step;
     float ratio, lr_t, beta1, beta2, eps, l2;
+    long long* clk;                                 // diagnostics (tuning coop_clocks): wall_clock64 of workgroup 0 at the phase boundaries, or null
 };
 
 template <int ITERS, int RB>
@@ -79,6 +80,8 @@ __global__ __launch_bounds__(256) void fit_step_coop_kernel(CoopArgs a)
     const int lpr = d4 <= 16 ? 16 : 32;                  // lanes that share a row (float4 each); rows per workgroup pass = 256 / lpr
     const int sub = tid % lpr, grp = tid / lpr, n_grp = 256 / lpr;
     const bool col_ok = sub < d4;
+#define COOP_STAMP(i) do { if (a.clk && blockIdx.x == 0 && tid == 0) a.clk[i] = wall_clock64(); } while (0)
+    COOP_STAMP(0);
 
     // ---- phase 1: item tower forward + clear G -------------------------------------------------------------------------------
     for (int64_t r = (int64_t)blockIdx.x * n_grp + grp; r < a.n_items; r += (int64_t)gridDim.x * n_grp) {
@@ -104,7 +107,9 @@ __global__ __launch_bounds__(256) void fit_step_coop_kernel(CoopArgs a)
         const int64_t m4 = (a.n_items * d + ((a.n_items + 3) & ~(int64_t)3)) >> 2;
         for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < m4; i += (int64_t)gridDim.x * 256) ((f32x4*)a.dV)[i] = z;
     }
+    COOP_STAMP(1);
     grid.sync();
+    COOP_STAMP(2);
 
     // ---- phase 2: the users ---------------------------------------------------------------------------------------------------
     {
@@ -124,7 +129,9 @@ __global__ __launch_bounds__(256) void fit_step_coop_kernel(CoopArgs a)
                                           a.S, d, a.ratio, a.max_rows, a.max_pos, o);
         }
     }
+    COOP_STAMP(3);
     grid.sync();
+    COOP_STAMP(4);
 
     // ---- phase 3: d V += G^T . U, d b_i += column sums of G.  A tile = COOP_IB items x one segment of users; the segment's user
     // rows and its coefficients for these items are staged in LDS (coalesced), every thread = (item, float4 column group) then runs
@@ -167,7 +174,9 @@ __global__ __launch_bounds__(256) void fit_step_coop_kernel(CoopArgs a)
             }
         }
     }
+    COOP_STAMP(5);
     grid.sync();
+    COOP_STAMP(6);
 
     // ---- phase 4: item tower backward + Adam; Adam on the users' rows ------------------------------------------------------------
     {
@@ -244,6 +253,8 @@ __global__ __launch_bounds__(256) void fit_step_coop_kernel(CoopArgs a)
             }
         }
     }
+    COOP_STAMP(7);
+#undef COOP_STAMP
 }
 
 int64_t coop_lds_bytes(int32_t n_sampled, int32_t max_pos, int32_t d, int64_t n_users)
@@ -317,6 +328,8 @@ extern "C" int trec_fit_step_coop(float* Wu, float* Wu_m, float* Wu_v, float* Wi
     a.S = n_sampled; a.d = d; a.max_rows = n_sampled + max_interactions_per_user; a.max_pos = max_interactions_per_user;
     a.sample_bits = sample_bits((int32_t)n_items);
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.step = step;
+    // (the last 64 floats of the workspace are slack: eight 8-byte clock stamps fit there)
+    a.clk = trec_get_tuning("coop_clocks", 0) ? (long long*)(workspace + ((need - 64 + 1) & ~(int64_t)1)) : nullptr;
     a.ratio = (float)n_items / (float)n_sampled; a.lr_t = lr_t; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.l2 = l2;
     const size_t lds = (size_t)coop_lds_bytes(n_sampled, max_interactions_per_user, d, n_users);
     int dev = 0, cus = 0, coop = 0;
@@ -332,7 +345,8 @@ extern "C" int trec_fit_step_coop(float* Wu, float* Wu_m, float* Wu_v, float* Wi
         trec_set_last_error("trec_fit_step_coop: no workgroup of the step fits a compute unit");
         return TREC_ERR_UNSUPPORTED;
     }
-    if (per_cu > 4) per_cu = 4;                         // (more resident workgroups shorten every phase's rounds; the barrier grows with them)
+    const int cap = trec_get_tuning("coop_wg_per_cu", 4);
+    if (per_cu > cap) per_cu = cap < 1 ? 1 : cap;                         // (more resident workgroups shorten every phase's rounds; the barrier grows with them)
     const hipError_t e = hipLaunchCooperativeKernel(fn, dim3((unsigned)(cus * per_cu)), dim3(256), args, (unsigned)lds, (hipStream_t)stream);
     if (e != hipSuccess) {
         (void)hipGetLastError();

@@ -61,10 +61,11 @@ def indicator_features(n, n_ind, rng, density):
 
 
 # ------------------------------------------------------------------------------------------------ configs[1]
-@pytest.mark.parametrize("mean_per_user", [160, 40])
-def test_config1_movielens100k_shape_wmrb_steps_match_oracle(mean_per_user):
+@pytest.mark.parametrize("mean_per_user,single_kernel", [(160, False), (40, False), (160, True)])
+def test_config1_movielens100k_shape_wmrb_steps_match_oracle(mean_per_user, single_kernel):
     """160 draws per user from the Zipf popularity = ~90k distinct positives (MovieLens-100K's count); 40 = a sparser
-    variant of the same shape."""
+    variant of the same shape.  single_kernel: steps 2 and 3 run as ONE cooperative kernel each (csrc/step_coop.hip -- the form a fit of
+    this shape takes; the first step, whose gradients are read back here, is made of separate launches)."""
     rng = np.random.default_rng(0)
     n_users, n_items, d, S, steps, lr, alpha = 943, 1682, 64, 168, 3, 0.05, 1e-5
     inter = zipf_interactions(n_users, n_items, mean_per_user, rng)     # Zipf item popularity
@@ -102,7 +103,10 @@ def test_config1_movielens100k_shape_wmrb_steps_match_oracle(mean_per_user):
             for k, ref in _rename(grads).items():
                 assert np.abs(cap['grads'][k] - ref).max() <= 1e-4 * gmax, k
             cap0, grads0 = {'grads': dict(cap['grads'])}, grads
+            if single_kernel:
+                model._capture = None                       # (capturing raw gradients keeps a step on the multi-launch path)
         oracle.step(inter, uf, itf, lr, alpha, tables[t])
+    assert model.last_step_form == ("coop" if single_kernel else "eager"), model.last_step_form
     # weights after 3 Adam steps (tests/parity_util.py: 1e-4 * lr per step wherever the gradient stands clear of the
     # fp32 summation noise, proportionally looser below).  Exempt, provably zero gradient in exact arithmetic:
     # user_feature_biases under WMRB -- the positive and the sampled predictions of a user carry the same b_u, which
