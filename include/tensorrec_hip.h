@@ -608,7 +608,7 @@ int trec_wmrb_tiled_step(const float* U, const float* V, const float* user_bias,
  * updated in place (bias pointers: all six or none); loss [P+] and pred_serial [nnz] are written for the caller's log.  samples
  * [n_users, n_sampled] or NULL: drawn in the kernel, the same bits as trec_sample_items(n_users, user_base, n_items, n_sampled, 0,
  * seed, step).  f_* : CSR of the item features, ft_*: CSR of their transpose (values through ft_perm).  lr_t / l2 as
- * trec_adam_tf_step (l2 on the two weight tables only).  trec_fit_step_coop_workspace_floats: floats of workspace, or -1 when the model
+ * trec_adam_tf_step (l2 on all four variables: the reference regularises its bias variables too, tensorrec.py:313).  trec_fit_step_coop_workspace_floats: floats of workspace, or -1 when the model
  * is not covered (d % 4 == 0, d <= 128, phases' LDS within 64 KB, G = n_users x n_items within 256 MB); TREC_ERR_UNSUPPORTED (3) when the
  * device refuses the cooperative launch -- the caller then runs the multi-launch step.                                            */
 int64_t trec_fit_step_coop_workspace_floats(int64_t n_users, int64_t n_items, int32_t d, int32_t n_sampled,

@@ -44,6 +44,7 @@ __host__ __device__ inline int64_t coop_seg_len(int64_t n_users, int d)
     int64_t by_lds = COOP_P3_LDS / (4 * (COOP_IB + d));
     int64_t by_count = (n_users + 7) / 8;
     int64_t s = by_count < by_lds ? by_count : by_lds;
+    if (s > 128) s = 128;                    // (phase 3 stages a segment with 8 loads per thread: 128 x 16 coefficients, <= 2,048 float4 of rows)
     return s < 16 ? 16 : s;
 }
 
@@ -149,11 +150,29 @@ __global__ __launch_bounds__(256) void fit_step_coop_kernel(CoopArgs a)
             const int64_t u1 = u0 + seg_len < a.n_users ? u0 + seg_len : a.n_users;
             const int nu = (int)(u1 - u0);
             __syncthreads();
-            for (int e = tid; e < nu * COOP_IB; e += 256) {
-                const int uu = e / COOP_IB, kk = e % COOP_IB;
-                l_g[e] = (i0 + kk < a.n_items) ? a.G[(u0 + uu) * a.ldg + i0 + kk] : 0.f;
+            {
+                // every load of the tile leaves before the first LDS store (a copy loop of unknown length is one round trip per
+                // iteration: measured 20 us per tile): at most 8 + 8 per thread by coop_seg_len's caps
+                float gq[8];
+                f32x4 uq[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int e = tid + 256 * q;
+                    const int ec = e < nu * COOP_IB ? e : 0;
+                    const int uu = ec / COOP_IB, kk = ec % COOP_IB;
+                    const int64_t col = i0 + kk < a.n_items ? i0 + kk : a.n_items - 1;
+                    gq[q] = a.G[(u0 + uu) * a.ldg + col];
+                    if (i0 + kk >= a.n_items) gq[q] = 0.f;
+                    const int e4 = e < nu * d4 ? e : 0;
+                    uq[q] = ((const f32x4*)(a.Wu + u0 * d))[e4];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int e = tid + 256 * q;
+                    if (e < nu * COOP_IB) l_g[e] = gq[q];
+                    if (e < nu * d4) ((f32x4*)l_u)[e] = uq[q];
+                }
             }
-            for (int e = tid; e < nu * d4; e += 256) ((f32x4*)l_u)[e] = ((const f32x4*)(a.Wu + u0 * d))[e];
             __syncthreads();
             if (i0 + k < a.n_items) {
                 for (int cc = c4; cc < d4; cc += 16) {
@@ -233,7 +252,7 @@ __global__ __launch_bounds__(256) void fit_step_coop_kernel(CoopArgs a)
                     float g = l_red[d];
                     for (int q = 1; q < n_grp; ++q) g += l_red[q * (d + 4) + d];
                     float w = a.bi[f], m = a.bi_m[f], v = a.bi_v[f];
-                    adam_elem(w, m, v, g, a.lr_t, omb1, omb2, a.eps, 0.f);
+                    adam_elem(w, m, v, g, a.lr_t, omb1, omb2, a.eps, a.l2);      // (the bias variables are regularised too: tensorrec.py:313, :487)
                     a.bi[f] = w; a.bi_m[f] = m; a.bi_v[f] = v;
                 }
             }
@@ -248,7 +267,7 @@ __global__ __launch_bounds__(256) void fit_step_coop_kernel(CoopArgs a)
             }
             if (a.bu && sub == 0) {
                 float w = a.bu[u], m = a.bu_m[u], v = a.bu_v[u];
-                adam_elem(w, m, v, a.dub[u], a.lr_t, omb1, omb2, a.eps, 0.f);
+                adam_elem(w, m, v, a.dub[u], a.lr_t, omb1, omb2, a.eps, a.l2);
                 a.bu[u] = w; a.bu_m[u] = m; a.bu_v[u] = v;
             }
         }
@@ -345,7 +364,7 @@ extern "C" int trec_fit_step_coop(float* Wu, float* Wu_m, float* Wu_v, float* Wi
         trec_set_last_error("trec_fit_step_coop: no workgroup of the step fits a compute unit");
         return TREC_ERR_UNSUPPORTED;
     }
-    const int cap = trec_get_tuning("coop_wg_per_cu", 4);
+    const int cap = trec_get_tuning("coop_wg_per_cu", 1);   // (measured at configs[1]: 2 and 4 per CU are slower -- the workgroups that wait in the barrier poll)
     if (per_cu > cap) per_cu = cap < 1 ? 1 : cap;                         // (more resident workgroups shorten every phase's rounds; the barrier grows with them)
     const hipError_t e = hipLaunchCooperativeKernel(fn, dim3((unsigned)(cus * per_cu)), dim3(256), args, (unsigned)lds, (hipStream_t)stream);
     if (e != hipSuccess) {

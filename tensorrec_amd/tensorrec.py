@@ -1717,7 +1717,7 @@ class _CoopStep(object):
         model._schedule_mirror = None                           # (the device-side schedule of graph replays is stale now)
         if want_stats:
             with torch.no_grad():
-                wr = float(0.5 * float((wu.detach() ** 2).sum()) + 0.5 * float((wi.detach() ** 2).sum()))
+                wr = float(sum(0.5 * float((v[n].detach() ** 2).sum()) for n in self.names))
             return self.loss.detach(), self.pred.detach(), wr
         return None, None, None
 

@@ -695,8 +695,13 @@ def test_single_kernel_step_equals_multi_launch_steps(loss, biased, sampler, d, 
     assert (oa, sa) == (ob, sb) == (steps, steps) and calls["run"] == steps - 1
     gmax = max(np.abs(g).max() for g in gb.values())
     for k in gb:
-        # (read back through m: its fp32 rounding, 6e-8 |m| / (1 - b1), is part of the bar)
-        assert np.abs(ga[k] - gb[k]).max() <= 3e-5 * gmax, "%s: %g (gmax %g)" % (k, np.abs(ga[k] - gb[k]).max(), gmax)
+        # (read back through m: its fp32 rounding, 6e-8 |m| / (1 - b1), is part of the bar.)  Per TENSOR as well: Adam rescales
+        # every variable by its own gradient history, so a bias gradient wrong by an amount that is small next to the largest
+        # weight gradient still moves the fit (found that way: the bias variables' L2 term)
+        err = np.abs(ga[k] - gb[k]).max()
+        assert err <= 3e-5 * gmax, "%s: %g (gmax %g)" % (k, err, gmax)
+        if k != "user_feature_biases":
+            assert err <= 2e-3 * np.abs(gb[k]).max(), "%s: %g of %g" % (k, err, np.abs(gb[k]).max())
     # five more steps each way: Adam turns the rounding noise of near-zero gradients into steps of up to lr -- the user biases above
     # all, whose WMRB gradient is exactly 0 in exact arithmetic (b_u cancels inside every hinge) -- so the fits are compared by what
     # they predict, up to each user's constant offset (which no ranking and no WMRB loss sees)
