@@ -593,7 +593,7 @@ int trec_wmrb_fused_step(const float* U, const float* V, const float* user_bias,
  * dU may be NULL with dense_g: the second sweep over the rows is skipped, val_rowsum [n_users] receives the sum of each user's
  * values and the caller forms dU = G . V (mode 0) or val_rowsum[u] U[u] - (G . V)[u] (mode 1).
  * trec_wmrb_tiled_lds_bytes: dynamic LDS of the launch, or -1 when not covered (d % 4 == 0, d <= 512, and
- * 2 (n_sampled + longest row) + 2 (longest row) + 8 d floats within 128 KB) -- then run the unfused kernels.                     */
+ * 2 (n_sampled + longest row) + 2 (longest row) + 8 d (16 d for d <= 64) floats within 128 KB) -- then run the unfused kernels.                     */
 int trec_wmrb_tiled_lds_bytes(int32_t n_sampled, int32_t max_interactions_per_user, int32_t d);
 int trec_wmrb_tiled_step(const float* U, const float* V, const float* user_bias, const float* item_bias,
                          const int64_t* indptr, const int32_t* x_item, const int32_t* pos_slot, const float* pos_weight,

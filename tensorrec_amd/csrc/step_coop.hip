@@ -71,7 +71,7 @@ struct CoopArgs {
     long long* clk;                                 // diagnostics (tuning coop_clocks): wall_clock64 of workgroup 0 at the phase boundaries, or null
 };
 
-template <int ITERS, int RB>
+template <int ITERS, int RB, int LPR>
 __global__ __launch_bounds__(256) void fit_step_coop_kernel(CoopArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -114,8 +114,7 @@ __global__ __launch_bounds__(256) void fit_step_coop_kernel(CoopArgs a)
 
     // ---- phase 2: the users ---------------------------------------------------------------------------------------------------
     {
-        const int mr4 = (a.max_rows + 3) & ~3, mp4 = (a.max_pos + 3) & ~3;
-        int32_t* l_samp = (int32_t*)(lds + 2 * mr4 + 2 * mp4 + 8 * d + 8);      // behind the body's own arrays
+        int32_t* l_samp = (int32_t*)(lds + tiled_lds_floats(a.max_rows, a.max_pos, d));      // behind the body's own arrays
         TiledOut o = {a.loss, a.pred_serial, a.dU, a.bu ? a.dub : nullptr, nullptr, nullptr, nullptr, nullptr, a.G, a.ldg, nullptr};
         for (int64_t u = blockIdx.x; u < a.n_users; u += gridDim.x) {
             const int32_t* samp;
@@ -126,7 +125,7 @@ __global__ __launch_bounds__(256) void fit_step_coop_kernel(CoopArgs a)
                 __syncthreads();
                 samp = l_samp;
             }
-            wmrb_tiled_user<ITERS, RB, 0>(lds, u, a.Wu, a.V, a.bu, a.bi ? a.ib : nullptr, a.indptr, a.xi, a.pos_slot, a.pos_weight, samp,
+            wmrb_tiled_user<ITERS, RB, 0, LPR>(lds, u, a.Wu, a.V, a.bu, a.bi ? a.ib : nullptr, a.indptr, a.xi, a.pos_slot, a.pos_weight, samp,
                                           a.S, d, a.ratio, a.max_rows, a.max_pos, o);
         }
     }
@@ -177,6 +176,7 @@ __global__ __launch_bounds__(256) void fit_step_coop_kernel(CoopArgs a)
             if (i0 + k < a.n_items) {
                 for (int cc = c4; cc < d4; cc += 16) {
                     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
                     for (int uu = 0; uu < nu; ++uu) {
                         const float g = l_g[uu * COOP_IB + k];
                         const f32x4 w = *(const f32x4*)(l_u + uu * d + cc * 4);
@@ -278,8 +278,7 @@ __global__ __launch_bounds__(256) void fit_step_coop_kernel(CoopArgs a)
 
 int64_t coop_lds_bytes(int32_t n_sampled, int32_t max_pos, int32_t d, int64_t n_users)
 {
-    const int64_t mr4 = ((int64_t)n_sampled + max_pos + 3) & ~(int64_t)3, mp4 = ((int64_t)max_pos + 3) & ~(int64_t)3;
-    const int64_t p2 = (2 * mr4 + 2 * mp4 + 8 * (int64_t)d + 8 + n_sampled + 4) * 4;
+    const int64_t p2 = (tiled_lds_floats((int64_t)n_sampled + max_pos, max_pos, d) + n_sampled + 4) * 4;
     const int64_t p3 = coop_seg_len(n_users, d) * (COOP_IB + d) * 4;
     const int64_t p4 = 16 * ((int64_t)d + 4) * 4;
     int64_t m = p2 > p3 ? p2 : p3;
@@ -358,7 +357,7 @@ extern "C" int trec_fit_step_coop(float* Wu, float* Wu_m, float* Wu_v, float* Wi
         return TREC_ERR_UNSUPPORTED;
     }
     void* args[] = {(void*)&a};
-    const void* fn = (d <= 64) ? (const void*)fit_step_coop_kernel<1, 12> : (const void*)fit_step_coop_kernel<1, 12>;
+    const void* fn = (d <= 64) ? (const void*)fit_step_coop_kernel<1, 12, 16> : (const void*)fit_step_coop_kernel<1, 12, 32>;
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds) != hipSuccess || per_cu < 1) {
         trec_set_last_error("trec_fit_step_coop: no workgroup of the step fits a compute unit");

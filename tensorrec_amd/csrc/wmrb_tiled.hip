@@ -19,7 +19,7 @@
 
 namespace {
 
-template <int ITERS, int RB, int MODE>
+template <int ITERS, int RB, int MODE, int LPR>
 __global__ __launch_bounds__(256, ITERS <= 2 ? 4 : 2) void wmrb_user_tiled_kernel(
     const float* __restrict__ U, const float* __restrict__ V, const float* __restrict__ ub, const float* __restrict__ ib,
     const int64_t* __restrict__ indptr, const int32_t* __restrict__ xi, const int32_t* __restrict__ pos_slot,
@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256, ITERS <= 2 ? 4 : 2) void wmrb_user_tiled_kerne
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int64_t u = blockIdx.x;
-    wmrb_tiled_user<ITERS, RB, MODE>(lds, u, U, V, ub, ib, indptr, xi, pos_slot, pos_weight, samples + u * S, S, d, ratio, max_rows,
+    wmrb_tiled_user<ITERS, RB, MODE, LPR>(lds, u, U, V, ub, ib, indptr, xi, pos_slot, pos_weight, samples + u * S, S, d, ratio, max_rows,
                                      max_pos, o);
 }
 
@@ -77,13 +77,11 @@ constexpr int64_t TILED_MAX_LDS = 128 * 1024;
 }  // namespace
 
 // Dynamic LDS of trec_wmrb_tiled_step, or -1 when the configuration is not covered: d % 4 == 0, d <= 512, n_sampled >= 1, and
-// 2 * (n_sampled + longest interaction row) + 2 * (longest row) + 8 * d floats within 128 KB.
+// 2 * (n_sampled + longest interaction row) + 2 * (longest row) + 8 * d (16 * d for d <= 64) floats within 128 KB.
 extern "C" int trec_wmrb_tiled_lds_bytes(int32_t n_sampled, int32_t max_interactions_per_user, int32_t d)
 {
     if (n_sampled < 1 || d < 4 || d % 4 != 0 || d > 512 || max_interactions_per_user < 0) return -1;
-    const int64_t mr4 = ((int64_t)n_sampled + max_interactions_per_user + 3) & ~(int64_t)3;
-    const int64_t mp4 = ((int64_t)max_interactions_per_user + 3) & ~(int64_t)3;
-    const int64_t bytes = (2 * mr4 + 2 * mp4 + 8 * (int64_t)d + 8) * 4;
+    const int64_t bytes = tiled_lds_floats((int64_t)n_sampled + max_interactions_per_user, max_interactions_per_user, d) * 4;
     return bytes <= TILED_MAX_LDS ? (int)bytes : -1;
 }
 
@@ -113,23 +111,25 @@ extern "C" int trec_wmrb_tiled_step(const float* U, const float* V, const float*
     const int32_t max_rows = n_sampled + max_interactions_per_user;
     hipStream_t st = (hipStream_t)stream;
     TiledOut o = {loss, pred_serial, dU, d_user_bias, val_samples, val_pairs, raw_samples, raw_pairs, dense_g, ldg, val_rowsum};
-#define TREC_TILED(IT, RB, MD)                                                                                                  \
+#define TREC_TILED(IT, RB, MD, LP)                                                                                                \
     do {                                                                                                                        \
         if (lds > 64 * 1024)                                                                                                    \
-            (void)hipFuncSetAttribute((const void*)wmrb_user_tiled_kernel<IT, RB, MD>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+            (void)hipFuncSetAttribute((const void*)wmrb_user_tiled_kernel<IT, RB, MD, LP>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                       (int)TILED_MAX_LDS);                                                                      \
-        hipLaunchKernelGGL((wmrb_user_tiled_kernel<IT, RB, MD>), dim3((unsigned)n_users), dim3(256), lds, st, U, V, user_bias,   \
+        hipLaunchKernelGGL((wmrb_user_tiled_kernel<IT, RB, MD, LP>), dim3((unsigned)n_users), dim3(256), lds, st, U, V, user_bias,   \
                            item_bias, indptr, x_item, pos_slot, pos_weight, samples, n_users, n_sampled, d, ratio, max_rows,    \
                            max_interactions_per_user, o);                                                                       \
     } while (0)
     if (mode == 0) {
-        if (d <= 128) TREC_TILED(1, 12, 0);
-        else if (d <= 256) TREC_TILED(2, 8, 0);
-        else TREC_TILED(4, 4, 0);
+        if (d <= 64) TREC_TILED(1, 12, 0, 16);
+        else if (d <= 128) TREC_TILED(1, 12, 0, 32);
+        else if (d <= 256) TREC_TILED(2, 8, 0, 32);
+        else TREC_TILED(4, 4, 0, 32);
     } else {
-        if (d <= 128) TREC_TILED(1, 12, 1);
-        else if (d <= 256) TREC_TILED(2, 8, 1);
-        else TREC_TILED(4, 4, 1);
+        if (d <= 64) TREC_TILED(1, 12, 1, 16);
+        else if (d <= 128) TREC_TILED(1, 12, 1, 32);
+        else if (d <= 256) TREC_TILED(2, 8, 1, 32);
+        else TREC_TILED(4, 4, 1, 32);
     }
 #undef TREC_TILED
     return trec_check_launch("trec_wmrb_tiled_step");

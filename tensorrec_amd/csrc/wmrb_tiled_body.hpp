@@ -34,8 +34,18 @@ struct TiledOut {
 
 // One user's step.  lds: the workgroup's dynamic LDS (trec_wmrb_tiled_lds_bytes); samp: the user's S sampled item ids (global or
 // LDS memory).  All 256 threads of the workgroup call it together; it ends with a barrier, so the caller may reuse the LDS at once.
-// ITERS: float4 chunks per lane of a 32-lane subgroup (d <= 128 * ITERS); RB: rows in flight per subgroup; MODE 0 dot, 1 euclid
-template <int ITERS, int RB, int MODE>
+// ITERS: float4 chunks per lane of an LPR-lane subgroup (d <= 4 * LPR * ITERS); RB: rows in flight per subgroup; MODE 0 dot, 1 euclid;
+// LPR: lanes that share a row -- 32, or 16 for d <= 64 (a 64-wide row fills 16 float4 lanes: sixteen subgroups keep twice the rows in
+// flight, which is what a latency-bound sweep over a few hundred rows is short of)
+constexpr int tiled_subgroups(int d) { return d <= 64 ? 16 : 8; }
+// floats of dynamic LDS the body needs: y [mr4] | cf [mr4] | bc [mp4] float2 | partial dU [subgroups][d] | red [8]
+__host__ __device__ inline int64_t tiled_lds_floats(int64_t max_rows, int64_t max_pos, int d)
+{
+    const int64_t mr4 = (max_rows + 3) & ~(int64_t)3, mp4 = (max_pos + 3) & ~(int64_t)3;
+    return 2 * mr4 + 2 * mp4 + (int64_t)tiled_subgroups(d) * d + 8;
+}
+
+template <int ITERS, int RB, int MODE, int LPR = 32>
 __device__ __forceinline__ void wmrb_tiled_user(
     float* __restrict__ lds, const int64_t u, const float* __restrict__ U, const float* __restrict__ V, const float* __restrict__ ub,
     const float* __restrict__ ib, const int64_t* __restrict__ indptr, const int32_t* __restrict__ xi,
@@ -48,11 +58,12 @@ __device__ __forceinline__ void wmrb_tiled_user(
     float* l_cf = l_y + mr4;
     float2* l_bc = (float2*)(l_cf + mr4);
     float* l_part = (float*)(l_bc + mp4);
-    float* l_red = l_part + 8 * d;
+    constexpr int NSG = 256 / LPR;                       // subgroups of the workgroup
+    float* l_red = l_part + NSG * d;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int sub = tid & 31, sg = tid >> 5;
+    const int sub = tid & (LPR - 1), sg = tid / LPR;
     const int64_t b = indptr[u], e = indptr[u + 1];
     const int n_pos = (int)(e - b);
     const int R = S + n_pos;
@@ -72,7 +83,7 @@ __device__ __forceinline__ void wmrb_tiled_user(
     f32x4 x[ITERS];
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
-        const int c = (it * 32 + sub) * 4;
+        const int c = (it * LPR + sub) * 4;
         const f32x4 v = *(const f32x4*)(U + u * d + (c < d ? c : 0));
         x[it] = (c < d) ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
@@ -80,11 +91,11 @@ __device__ __forceinline__ void wmrb_tiled_user(
 
     // ---- pass 1: scores of the rows j = j0 + sg + 8 r.  Every load is unconditional, from a clamped (valid) address, selected
     // afterwards (`cond ? load : 0` becomes an exec-masked block behind s_waitcnt vmcnt(0)) ----
-    for (int j0 = 0; j0 < R; j0 += 8 * RB) {
+    for (int j0 = 0; j0 < R; j0 += NSG * RB) {
         int32_t item[RB];
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
-            const int j = j0 + sg + 8 * r;
+            const int j = j0 + sg + NSG * r;
             const int q = j - S;
             const int32_t is = samp[j < S ? j : S - 1];
             const int32_t iq = xi[b + (q < 0 ? 0 : (q < n_pos ? q : n_pos - 1))];
@@ -96,7 +107,7 @@ __device__ __forceinline__ void wmrb_tiled_user(
         for (int r = 0; r < RB; ++r) {
 #pragma unroll
             for (int it = 0; it < ITERS; ++it) {
-                const int c = (it * 32 + sub) * 4;
+                const int c = (it * LPR + sub) * 4;
                 y[r][it] = *(const f32x4*)(V + (int64_t)item[r] * d + (c < d ? c : 0));
             }
             bi[r] = ib ? ib[item[r]] : 0.f;                   // (uniform branch; one address per subgroup)
@@ -107,7 +118,7 @@ __device__ __forceinline__ void wmrb_tiled_user(
             float a = 0.f;
 #pragma unroll
             for (int it = 0; it < ITERS; ++it) {
-                const bool in = (it * 32 + sub) * 4 < d;      // (columns past d: both sides count as zero)
+                const bool in = (it * LPR + sub) * 4 < d;      // (columns past d: both sides count as zero)
                 if (MODE == 0) {
                     const f32x4 w = in ? y[r][it] : (f32x4){0.f, 0.f, 0.f, 0.f};
                     a = fmaf(x[it].x, w.x, a); a = fmaf(x[it].y, w.y, a); a = fmaf(x[it].z, w.z, a); a = fmaf(x[it].w, w.w, a);
@@ -122,13 +133,13 @@ __device__ __forceinline__ void wmrb_tiled_user(
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
             float t = acc[r];
-            t = dpp_add(t, 8); t = dpp_add(t, 4); t = dpp_add(t, 2); t = dpp_add(t, 1);
-            acc[r] = dpp_add(t, 0);
+            t = dpp_add(t, 8); t = dpp_add(t, 4); t = dpp_add(t, 2); t = dpp_add(t, 1);     // every lane of a 16-lane row: the row's sum
+            acc[r] = (LPR == 32) ? dpp_add(t, 0) : t;                                        // 32 lanes: row 0's sum into row 1
         }
-        if (sub == 31) {
+        if (sub == LPR - 1) {
 #pragma unroll
             for (int r = 0; r < RB; ++r) {
-                const int j = j0 + sg + 8 * r;
+                const int j = j0 + sg + NSG * r;
                 if (j < R) {
                     float s = acc[r];
                     if (MODE == 1) { l_cf[j] = s; s = -1.0f * sqrtf(fmaxf(s, EUCLID_EPS)); }
@@ -151,6 +162,11 @@ __device__ __forceinline__ void wmrb_tiled_user(
         const bool live = q < n_pos;
         const float yq = l_y[S + (live ? q : 0)];
         const float base = 1.0f - yq;
+        // what lane k == 0 needs from memory once the sums are there leaves now (clamped, unconditional), under the walk over S
+        const int64_t pq = b + (live ? q : 0);
+        const int32_t slot_ld = pos_slot[pq];
+        const float w_ld = pos_weight ? pos_weight[pq] : 1.f;
+        const int32_t xi_ld = xi[pq];
         float acc = 0.f;
         int cnt = 0;
         if (live) {
@@ -169,10 +185,10 @@ __device__ __forceinline__ void wmrb_tiled_user(
         acc += __shfl_xor(acc, 2, 64); fc += __shfl_xor(fc, 2, 64);
         acc += __shfl_xor(acc, 4, 64); fc += __shfl_xor(fc, 4, 64);
         if (live && k == 0) {
-            const int32_t slot = pos_slot[b + q];
+            const int32_t slot = slot_ld;
             float c = 0.f, dp = 0.f;
             if (slot >= 0) {
-                const float w = pos_weight ? pos_weight[b + q] : 1.f;
+                const float w = w_ld;
                 float smr = ratio * acc;
                 if (pos_weight) smr = smr * w;
                 c = ratio / (1.0f + smr);                               // d loss_p / d (hinge sum), upstream gradient 1
@@ -186,7 +202,7 @@ __device__ __forceinline__ void wmrb_tiled_user(
             l_cf[S + q] = val;
             if (o.val_pairs) o.val_pairs[b + q] = val;
             if (o.raw_pairs) o.raw_pairs[b + q] = dp;
-            if (o.dense_g) unsafeAtomicAdd(o.dense_g + u * o.ldg + xi[b + q], val);
+            if (o.dense_g) unsafeAtomicAdd(o.dense_g + u * o.ldg + xi_ld, val);
             raw_sum += dp;
             val_sum += val;
         }
@@ -202,6 +218,7 @@ __device__ __forceinline__ void wmrb_tiled_user(
             ys[m] = l_y[s < S ? s : S - 1];
             g[m] = 0.f;
         }
+#pragma unroll 4
         for (int q = 0; q < n_pos; ++q) {
             const float2 bc = l_bc[q];
 #pragma unroll
@@ -230,12 +247,12 @@ __device__ __forceinline__ void wmrb_tiled_user(
         f32x4 part[ITERS];
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) part[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int j0 = 0; j0 < R; j0 += 8 * RB) {
+        for (int j0 = 0; j0 < R; j0 += NSG * RB) {
             int32_t item[RB];
             float cf[RB];
 #pragma unroll
             for (int r = 0; r < RB; ++r) {
-                const int j = j0 + sg + 8 * r;
+                const int j = j0 + sg + NSG * r;
                 const int q = j - S;
                 const int32_t is = samp[j < S ? j : S - 1];
                 const int32_t iq = xi[b + (q < 0 ? 0 : (q < n_pos ? q : n_pos - 1))];
@@ -248,7 +265,7 @@ __device__ __forceinline__ void wmrb_tiled_user(
             for (int r = 0; r < RB; ++r) {
 #pragma unroll
                 for (int it = 0; it < ITERS; ++it) {
-                    const int c = (it * 32 + sub) * 4;
+                    const int c = (it * LPR + sub) * 4;
                     y[r][it] = *(const f32x4*)(V + (int64_t)item[r] * d + (c < d ? c : 0));
                 }
             }
@@ -265,7 +282,7 @@ __device__ __forceinline__ void wmrb_tiled_user(
         }
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
-            const int c = (it * 32 + sub) * 4;
+            const int c = (it * LPR + sub) * 4;
             if (c < d) *(f32x4*)(l_part + sg * d + c) = part[it];
         }
     }
@@ -282,7 +299,7 @@ __device__ __forceinline__ void wmrb_tiled_user(
         for (int c = tid; c < d; c += 256) {
             float acc = l_part[c];
 #pragma unroll
-            for (int g8 = 1; g8 < 8; ++g8) acc += l_part[g8 * d + c];
+            for (int g8 = 1; g8 < NSG; ++g8) acc += l_part[g8 * d + c];
             o.dU[u * d + c] = acc;
         }
     }
