@@ -278,7 +278,9 @@ def fit_epochs_per_sec(n_users, n_items, d, per_user=20, n_sampled=100, epochs=3
         alg = (pairs_s + pairs_p) * d * 4 + 2.0 * n_loc * d * 4 + pairs_s * 12 + pairs_p * 16
         gbs = alg / (ms * 1e-3) / 1e9
         roofline_fit = {"kernel": "wmrb_user_fused_kernel (one-pass WMRB step, user side: every pair's item row gathered once)",
-                        "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                        # ("hbm+mall": half of the 512 MB item table is served by the 256 MB Infinity Cache, so the algorithmic rate may
+                        # exceed what HBM alone streams (~6.3 TB/s); priced against the 8 TB/s peak and the measured gather ceiling)
+                        "bound": "hbm+mall", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                         "traffic": None, "avg_launch_ms": ms, "launches": len(dur["wmrb_fused_step"]),
                         "algorithmic_bytes_per_launch": alg,
                         "gather_ceiling": GATHER_CEILING_512MB_GBS, "frac_of_gather_ceiling": gbs / GATHER_CEILING_512MB_GBS,

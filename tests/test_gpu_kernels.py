@@ -544,7 +544,9 @@ def test_rmse_fwd_bwd(ops, n):
 @pytest.mark.parametrize("replace", [False, True])
 def test_sampler_bit_exact_vs_restatement(ops, replace):
     for (nu, ni, S, seed, step) in ((7, 1000, 50, 0x1234567890ABCDEF, 3), (300, 97, 30, 5, 1), (2, 5, 5, 9, 2),
-                                    (1000, 1682, 168, 0, 7)):
+                                    (1000, 1682, 168, 0, 7), (5000, 100_000, 9, 77, 4), (3, 70_000, 2500, 1, 1)):
+        # (without replacement and >= 8 samples per user: the keyed kernel -- a workgroup owns 2,048 consecutive samples, up to 228
+        # users' keys in LDS; below, and with replacement: one thread per sample)
         got = ops.sample_items(nu, ni, S, replace, seed, step).cpu().numpy()
         assert np.array_equal(got, DS.sample_items(nu, ni, S, replace, seed, step))
         # a user shard draws exactly the rows of the whole-population table
