@@ -419,6 +419,7 @@ __global__ __launch_bounds__(1024) void seg_bin_count_kernel(const int32_t* __re
         const int64_t p = p0 + q * 1024 + threadIdx.x;
         int32_t it = p < n_pairs ? xi[p] : -1;
         if (drop_zero_of && p < n_pairs && drop_zero_of[p] == 0.f) it = -1;
+        if ((it >> BIN_LOG2) >= n_bins) it = -1;              // (an id beyond the catalogue would index LDS out of bounds: skipped)
         if (it >= 0) atomicAdd(&cnt[it >> BIN_LOG2], 1);
     }
     __syncthreads();
@@ -473,7 +474,7 @@ __global__ __launch_bounds__(1024) void seg_bin_partition_kernel(const int32_t* 
         const int64_t pc = p < n_pairs ? p : n_pairs - 1;
         const int32_t t = xi[pc];
         vl[q] = values[pc];
-        it[q] = (p < n_pairs && !(drop_zero && vl[q] == 0.f)) ? t : -1;
+        it[q] = (p < n_pairs && !(drop_zero && vl[q] == 0.f) && (t >> BIN_LOG2) < n_bins) ? t : -1;     // (ids beyond the catalogue: skipped as in the count pass)
         us[q] = xu ? xu[pc] : (int32_t)((uint32_t)pc / (uint32_t)pairs_per_user);          // (n_pairs < 2^31)
     }
 #pragma unroll
@@ -608,6 +609,13 @@ extern "C" int64_t trec_group_pairs_binned_bytes(int64_t n_pairs, int64_t n_item
 {
     const int64_t n_bins = ceil_div64(n_items, BIN_ITEMS);
     if (n_items < 1 || n_bins > BIN_MAX_BINS || n_pairs < ((int64_t)1 << 22) || n_pairs >= ((int64_t)1 << 31)) return 0;
+    {
+        // the partition pass needs ~106.5 KB of dynamic LDS per workgroup: a device that cannot give it takes the ranked grouping
+        int dev = 0, max_lds = 0;
+        const int need_lds = BIN_TILE * 12 + (2 * BIN_MAX_BINS + 2) * 4 + BIN_MAX_BINS * 8 + 16;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess &&
+            max_lds > 0 && max_lds < need_lds) return 0;
+    }
     return n_pairs * (int64_t)sizeof(BinRecord) + (n_bins + 1) * 8 + 2 * n_bins * 4 + n_bins * BIN_SLICES * (int64_t)BIN_ITEMS * 4 + 64;
 }
 
