@@ -403,7 +403,7 @@ constexpr int BIN_LOG2 = 12;
 constexpr int BIN_ITEMS = 1 << BIN_LOG2;
 constexpr int BIN_MAX_BINS = 512;          // LDS tables of the partition pass; 2M items
 constexpr int BIN_TILE = 8192;             // pairs per workgroup of the partition pass (96 KB of records in LDS)
-constexpr int BIN_SLICES = 4;              // workgroups per bin of the placement
+constexpr int BIN_SLICES_MAX = 32;         // workgroups per bin of the placement: tuning group_pairs_bin_slices (default 4), at most this
 
 struct __attribute__((packed, aligned(4))) BinRecord { int32_t item, user; float value; };
 
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(1024) void seg_bin_partition_kernel(const int32_t* 
 // turns the counts into every slice's first slot per item and writes the bin's indptr (seg_bin_scan_items_kernel); every slice
 // places its records from LDS cursors that start there (seg_bin_place_kernel).  Slices keep their order inside a bucket.
 __global__ __launch_bounds__(1024) void seg_bin_count_items_kernel(const BinRecord* __restrict__ records, const int64_t* __restrict__ bin_base,
-                                                                  int32_t* __restrict__ run_counts)
+                                                                  int32_t* __restrict__ run_counts, int BIN_SLICES)
 {
     __shared__ int cnt[BIN_ITEMS];
     const int b = blockIdx.x / BIN_SLICES, g = blockIdx.x % BIN_SLICES;
@@ -545,7 +545,7 @@ __global__ __launch_bounds__(1024) void seg_bin_count_items_kernel(const BinReco
 }
 
 __global__ __launch_bounds__(1024) void seg_bin_scan_items_kernel(int32_t* __restrict__ run_counts, const int64_t* __restrict__ bin_base,
-                                                                 int64_t n_items, int64_t* __restrict__ indptr)
+                                                                 int64_t n_items, int64_t* __restrict__ indptr, int BIN_SLICES)
 {
     __shared__ int wsum[16];
     const int b = blockIdx.x;
@@ -554,7 +554,6 @@ __global__ __launch_bounds__(1024) void seg_bin_scan_items_kernel(int32_t* __res
     const int i4 = threadIdx.x * 4;
     int tot[4] = {0, 0, 0, 0};
     // per item: the slices' counts become their exclusive prefix over the slices; tot = the item's count
-#pragma unroll
     for (int g = 0; g < BIN_SLICES; ++g) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -579,14 +578,13 @@ __global__ __launch_bounds__(1024) void seg_bin_scan_items_kernel(int32_t* __res
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         if (item0 + i4 + e < n_items) indptr[item0 + i4 + e] = r0 + st[e];
-#pragma unroll
         for (int g = 0; g < BIN_SLICES; ++g) rc[g * BIN_ITEMS + i4 + e] += st[e];      // the slice's first slot of the item, relative to r0
     }
     if (b == (int)gridDim.x - 1 && threadIdx.x == 0) indptr[n_items] = r1;
 }
 
 __global__ __launch_bounds__(1024) void seg_bin_place_kernel(const BinRecord* __restrict__ records, const int64_t* __restrict__ bin_base,
-                                                            const int32_t* __restrict__ run_base, int2* __restrict__ entries)
+                                                            const int32_t* __restrict__ run_base, int2* __restrict__ entries, int BIN_SLICES)
 {
     __shared__ int cur[BIN_ITEMS];
     const int b = blockIdx.x / BIN_SLICES, g = blockIdx.x % BIN_SLICES;
@@ -616,7 +614,7 @@ extern "C" int64_t trec_group_pairs_binned_bytes(int64_t n_pairs, int64_t n_item
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess &&
             max_lds > 0 && max_lds < need_lds) return 0;
     }
-    return n_pairs * (int64_t)sizeof(BinRecord) + (n_bins + 1) * 8 + 2 * n_bins * 4 + n_bins * BIN_SLICES * (int64_t)BIN_ITEMS * 4 + 64;
+    return n_pairs * (int64_t)sizeof(BinRecord) + (n_bins + 1) * 8 + 2 * n_bins * 4 + n_bins * BIN_SLICES_MAX * (int64_t)BIN_ITEMS * 4 + 64;
 }
 
 // Group (user, item, value) pairs by item without ranks (see above): xi [n_pairs] items (negative: skipped), users from xu or
@@ -658,9 +656,12 @@ extern "C" int trec_group_pairs_by_item_binned(const int32_t* xu, const int32_t*
     hipLaunchKernelGGL(seg_bin_scan_kernel, dim3(1), dim3(256), 0, st, bin_count, n_bins, bin_base, bin_cursor);
     hipLaunchKernelGGL(seg_bin_partition_kernel, dim3((unsigned)ceil_div64(n_pairs, BIN_TILE)), dim3(1024), lds, st, xu, xi, values, n_pairs,
                        pairs_per_user, drop_zero_values, n_bins, bin_base, bin_cursor, (int32_t*)records);
-    hipLaunchKernelGGL(seg_bin_count_items_kernel, dim3((unsigned)(n_bins * BIN_SLICES)), dim3(1024), 0, st, records, bin_base, run_counts);
-    hipLaunchKernelGGL(seg_bin_scan_items_kernel, dim3((unsigned)n_bins), dim3(1024), 0, st, run_counts, bin_base, n_items, indptr_t);
-    hipLaunchKernelGGL(seg_bin_place_kernel, dim3((unsigned)(n_bins * BIN_SLICES)), dim3(1024), 0, st, records, bin_base, run_counts, (int2*)entries);
+    int slices = trec_get_tuning("group_pairs_bin_slices", 4);
+    if (slices < 1) slices = 1;
+    if (slices > BIN_SLICES_MAX) slices = BIN_SLICES_MAX;
+    hipLaunchKernelGGL(seg_bin_count_items_kernel, dim3((unsigned)(n_bins * slices)), dim3(1024), 0, st, records, bin_base, run_counts, slices);
+    hipLaunchKernelGGL(seg_bin_scan_items_kernel, dim3((unsigned)n_bins), dim3(1024), 0, st, run_counts, bin_base, n_items, indptr_t, slices);
+    hipLaunchKernelGGL(seg_bin_place_kernel, dim3((unsigned)(n_bins * slices)), dim3(1024), 0, st, records, bin_base, run_counts, (int2*)entries, slices);
     return trec_check_launch("trec_group_pairs_by_item_binned");
 }
 
