@@ -370,6 +370,15 @@ int trec_topk_candidates_finish_mixed(const int32_t* cand_n, const void* cand, i
                                       int32_t k, float* out_vals, int32_t* out_idx, int32_t* flag, int32_t* n_flagged,
                                       const int32_t* out_index, int32_t cands_per_lane, int32_t* over_list, int32_t* over_count,
                                       void* stream);
+/* The finish of the wide route (17 <= k <= 64; lists of up to 1,024 candidates made with the provisional floor): one wave per user
+ * re-scores EVERY listed item with the reference's fp32 chain and takes the k best (recommendation_graphs.py:73-82 restricted to the
+ * first k places); users whose list is incomplete (more entries than cand_cap, fewer than k) are flagged, users flagged before or
+ * with a +inf floor are skipped.  out_index as for trec_topk_candidates_finish.                                                  */
+int trec_topk_candidates_finish_wide(const int32_t* cand_n, const void* cand, int32_t cand_cap, const float* cand_floor,
+                                     const float* users_f32, const float* items_f32, int64_t ld_users, int64_t ld_items,
+                                     int32_t kdim, const float* user_bias, const float* item_bias, int32_t item_index_base,
+                                     int64_t n_users, int32_t k, float* out_vals, int32_t* out_idx, int32_t* flag, int32_t* n_flagged,
+                                     const int32_t* out_index, void* stream);
 /* The cascade's thresholds in one pass over the users, before trec_topk_rows_collect: tau [n_users] IN / OUT = the k-th largest
  * int8 lower bound (+inf on return for layout rows without a source: src [n_users] nullable, trec_user_prep_sorted);
  * floor0 = tau - eps rounded down twice (the provisional floor of the candidate lists; +inf and flag = 1 when the bound is

@@ -93,6 +93,8 @@ SIGNATURES = {
                                     _vp, _vp, _vp, _vp, _i32, _vp],
     "trec_topk_candidates_finish_mixed": [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _i32, _i64, _i32,
                                           _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp],
+    "trec_topk_candidates_finish_wide": [_vp, _vp, _i32, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp,
+                                         _vp, _vp],
     "trec_topk_euclid_certify": [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp],
     "trec_topk_filter_floor": [_vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp],
     "trec_topk_collect_blocks": [_vp, _i32, _i64, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp],

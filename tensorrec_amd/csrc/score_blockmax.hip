@@ -475,6 +475,16 @@ __global__ __launch_bounds__(256, NUB == 8 ? 2 : 3) void blockmax_bf16x16_kernel
         const bool pad = !inb || (fixed && wave * (NUB * 16) + local >= rows_here);
         ri[h] = (pad || idx < 0) ? -1 : idx;
     }
+    if (LIST && !GRP) {
+        // the dense listing launch over the HOT superblocks (trec_score_gemm_refine_candidates_hot): a user whose entry of this
+        // superblock is -inf was listed for it by the pre-refining launch already (trec_topk_prerefine_tau marked it) -- it sits
+        // this superblock out (no second copy of its candidates in its 128 slots, the saved maximum stays where it is)
+        float mk[NRI];
+#pragma unroll
+        for (int h = 0; h < NRI; ++h) mk[h] = p.blockmax[(int64_t)chunk * p.bm_stride + (ri[h] >= 0 ? ri[h] : 0)];
+#pragma unroll
+        for (int h = 0; h < NRI; ++h) if (mk[h] == -INFINITY) ri[h] = -1;
+    }
     bf16x8 rfb[NUB][KS];
     float thr_a[NUB];                                            // LIST: an accumulator below this cannot reach the user's floor
     int64_t frow[NUB];

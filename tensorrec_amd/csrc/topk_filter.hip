@@ -1030,6 +1030,123 @@ extern "C" int trec_topk_candidates_finish(const int32_t* cand_n, const void* ca
     return trec_check_launch("trec_topk_candidates_finish");
 }
 
+// ---- the finish of the WIDE route (17 <= k <= 64, lists of up to 1,024 candidates): one wave per user, lane j owns candidates j,
+// 64 + j, ... (CPL per lane), re-scores every one of them with the reference's k-ordered fmaf chain straight from its fp32 item row
+// (the user row broadcast from LDS) and the wave takes the k best by k rounds of a 64-bit wave maximum -- no floor, no survivor limit:
+// a list holds every item whose fp32 score reaches the k-th best, so its k best ARE the answer.  Replaces a finish made of
+// library calls and dense [n_users, 1024] torch masks.  A user whose list is incomplete (more entries than slots, fewer than k) is
+// flagged; a user flagged before, or whose provisional floor is +inf, is skipped (-inf / -1 rows).
+template <int CPL>
+__global__ __launch_bounds__(256) void candidates_finish_wide_kernel(
+    const int32_t* __restrict__ cand_n, const int2* __restrict__ cand_list, int cap, const float* __restrict__ cand_floor,
+    const float* __restrict__ U, const float* __restrict__ V, int64_t ld_u, int64_t ld_v, int kdim,
+    const float* __restrict__ user_bias, const float* __restrict__ item_bias, int32_t item_index_base, int64_t n_users, int k,
+    float* __restrict__ ov, int32_t* __restrict__ oi, int32_t* __restrict__ flag, int32_t* __restrict__ n_flagged,
+    const int32_t* __restrict__ out_index)
+{
+    extern __shared__ __attribute__((aligned(16))) char fsmem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t u = (int64_t)blockIdx.x * 4 + wave;
+    if (u >= n_users) return;
+    const int64_t uo = out_index ? (int64_t)out_index[u] : u;
+    if (uo < 0) return;
+    const int kd4 = (kdim + 3) & ~3;
+    float* urow = (float*)fsmem + (size_t)wave * kd4;
+    const int n = cand_n[u];
+    const float f0 = cand_floor[u];
+    const bool vec = ((ld_v & 3) == 0) && ((ld_u & 3) == 0);
+    for (int ch = lane; ch < (kd4 >> 2); ch += 64) {
+        f32x4 w = {0.f, 0.f, 0.f, 0.f};
+        const float* src = U + u * ld_u + ch * 4;
+        if (vec) w = *(const f32x4*)src;
+        else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[e] = (ch * 4 + e < kdim) ? src[e] : 0.f;
+        }
+        *(f32x4*)(urow + ch * 4) = w;
+    }
+    const float bu = user_bias ? user_bias[u] : 0.f;
+    const unsigned long long EMPTY = merge_key(-INFINITY, 0x7fffffff);
+    const bool skip = !(f0 < INFINITY) || flag[u] != 0;      // (wave-uniform)
+    const bool bad = n > cap || n < k;
+    if (skip || bad) {
+        if (bad && !skip && lane == 0) { flag[u] = 1; atomicAdd(n_flagged, 1); }
+        if (lane < k) { ov[uo * k + lane] = -INFINITY; oi[uo * k + lane] = -1; }
+        return;
+    }
+    __builtin_amdgcn_wave_barrier();
+    unsigned long long key[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+        key[c] = EMPTY;
+        if (c * 64 >= n) continue;                            // (wave-uniform)
+        const bool have = c * 64 + lane < n;
+        const int2 ent = cand_list[u * (int64_t)cap + (have ? c * 64 + lane : 0)];
+        const int64_t it = (int64_t)ent.x - item_index_base;
+        const float* b = V + it * ld_v;
+        float acc = 0.0f;
+        int kk = 0;
+        if (vec) {
+            for (; kk + 4 <= kdim; kk += 4) {
+                const f32x4 a4 = *(const f32x4*)(urow + kk);
+                const f32x4 b4 = *(const f32x4*)(b + kk);
+                acc = __fmaf_rn(a4[0], b4[0], acc); acc = __fmaf_rn(a4[1], b4[1], acc);
+                acc = __fmaf_rn(a4[2], b4[2], acc); acc = __fmaf_rn(a4[3], b4[3], acc);
+            }
+        }
+        for (; kk < kdim; ++kk) acc = __fmaf_rn(urow[kk], b[kk], acc);
+        if (user_bias) acc = acc + bu;
+        if (item_bias) acc = acc + item_bias[it];
+        if (have) key[c] = merge_key(acc, ent.x);
+    }
+    // ---- the k best by (value desc, index asc): lane t keeps place t (an item is listed once: keys are unique, and equal keys -- the
+    // harmless double listing of a pre-refined pair inside a hot superblock -- leave together)
+    unsigned long long place = EMPTY;
+    for (int t = 0; t < k; ++t) {
+        unsigned long long m = key[0];
+#pragma unroll
+        for (int c = 1; c < CPL; ++c) m = key[c] > m ? key[c] : m;
+        const unsigned long long best = wave_max_u64(m);
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) if (key[c] == best && best != EMPTY) key[c] = EMPTY;
+        if (lane == t) place = best;
+    }
+    if (lane < k) {
+        const unsigned int hi = (unsigned int)(place >> 32);
+        const unsigned int bits = (hi & 0x80000000u) ? (hi & 0x7fffffffu) : ~hi;
+        ov[uo * k + lane] = (place == EMPTY) ? -INFINITY : __uint_as_float(bits);
+        oi[uo * k + lane] = (place == EMPTY) ? -1 : (int32_t)(~(unsigned int)place);
+    }
+}
+
+extern "C" int trec_topk_candidates_finish_wide(const int32_t* cand_n, const void* cand, int32_t cand_cap, const float* cand_floor,
+                                                const float* users_f32, const float* items_f32, int64_t ld_users, int64_t ld_items,
+                                                int32_t kdim, const float* user_bias, const float* item_bias, int32_t item_index_base,
+                                                int64_t n_users, int32_t k, float* out_vals, int32_t* out_idx, int32_t* flag,
+                                                int32_t* n_flagged, const int32_t* out_index, void* stream)
+{
+    TREC_REQUIRE(cand_n && cand && cand_floor && users_f32 && items_f32 && out_vals && out_idx && flag && n_flagged,
+                 "trec_topk_candidates_finish_wide: null pointer");
+    TREC_REQUIRE(cand_cap >= 64 && cand_cap % 64 == 0 && cand_cap <= 1024, "trec_topk_candidates_finish_wide: cand_cap must be a multiple of 64 up to 1024");
+    TREC_REQUIRE(k >= 1 && k <= 64, "trec_topk_candidates_finish_wide: need k <= 64");
+    TREC_REQUIRE(kdim >= 1 && kdim <= 1024 && ld_users >= kdim && ld_items >= ((kdim + 3) & ~3),
+                 "trec_topk_candidates_finish_wide: need kdim <= 1024 and item rows padded to a multiple of 4");
+    if (n_users == 0) return TREC_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int kd4 = (kdim + 3) & ~3;
+    const size_t lds = (size_t)4 * kd4 * 4;
+    const unsigned blocks = (unsigned)ceil_div64(n_users, 4);
+#define TREC_CFW(CPLV)                                                                                                          \
+    hipLaunchKernelGGL((candidates_finish_wide_kernel<CPLV>), dim3(blocks), dim3(256), lds, st, cand_n, (const int2*)cand, cand_cap, \
+                       cand_floor, users_f32, items_f32, ld_users, ld_items, kdim, user_bias, item_bias, item_index_base, n_users, k, \
+                       out_vals, out_idx, flag, n_flagged, out_index)
+    if (cand_cap <= 256) { TREC_CFW(4); }
+    else if (cand_cap <= 512) { TREC_CFW(8); }
+    else { TREC_CFW(16); }
+#undef TREC_CFW
+    return trec_check_launch("trec_topk_candidates_finish_wide");
+}
+
 // The finish in two launches for lists of MIXED length (the single-GPU cascade: ~15 candidates per user, a few users with hundreds):
 // (1) 16 lanes per user, cands_per_lane (1 / 2 / 4) candidates per lane -- four users per wave instead of one; users whose list is
 // longer than 16 * cands_per_lane are appended to over_list [n_users] (over_count [1] zeroed by the caller); (2) the wave-per-user

@@ -59,11 +59,37 @@ def dense_scores(user_repr, item_repr, dtype, normalize=False, mode=MODE_DOT, us
     return s
 
 
+TOPK_THRESHOLD_MIN_ITEMS = 8192       # from this row length on topk_from_scores selects by the k-th value instead of ranking the row
+
+
 def topk_from_scores(scores, k):
     """(values [n_users, k], item ids int32 [n_users, k]) of a score slab in rank_predictions' order (value desc, index
     asc): exact ranks (rank_rows) select the entries -- the route of models the fused top-k kernels do not cover."""
     n_u, n_i = scores.shape
     kk = min(int(k), n_i)
+    if n_i >= TOPK_THRESHOLD_MIN_ITEMS and 1 <= kk <= 256 and n_u >= 1:
+        # long rows, few places: the k-th largest VALUE of a row does not depend on any tie rule (a selection, not a sort of the
+        # row), the entries reaching it are k plus its ties, and trec_topk_merge orders them (value desc, index asc).  Rows with
+        # NaN, a -inf k-th value or more than 1,024 such entries keep the exact-rank form below.
+        kth = torch.topk(scores, kk, dim=1, sorted=True).values[:, kk - 1:kk]
+        mask = scores >= kth
+        cnt = mask.sum(dim=1)
+        if bool((torch.isfinite(kth).all() & (cnt.max() <= 1024) & (cnt.min() >= kk)).item()):
+            rows, cols = torch.nonzero(mask, as_tuple=True)
+            first = torch.cumsum(cnt, 0) - cnt
+            slot = torch.arange(rows.numel(), device=scores.device) - first[rows]
+            width = max(int(cnt.max().item()), kk)
+            cv = torch.full((n_u, width), float('-inf'), dtype=torch.float32, device=scores.device)
+            ci = torch.full((n_u, width), -1, dtype=torch.int32, device=scores.device)
+            cv[rows, slot] = scores[rows, cols]
+            ci[rows, slot] = cols.to(torch.int32)
+            mv, mi = topk_merge(cv, ci, kk)
+            if kk == int(k):
+                return mv, mi
+            vals = torch.full((n_u, int(k)), float('-inf'), dtype=torch.float32, device=scores.device)
+            idx = torch.full((n_u, int(k)), -1, dtype=torch.int32, device=scores.device)
+            vals[:, :kk], idx[:, :kk] = mv, mi
+            return vals, idx
     ranks = rank_rows(scores)
     rows, cols = torch.nonzero(ranks <= kk, as_tuple=True)
     pos = (ranks[rows, cols] - 1).long()
@@ -1277,23 +1303,14 @@ def score_topk_filtered_wide(uop, iop, k, user_bias=None, item_bias=None, item_i
         LAST_FILTER_STATS["prefilter"] = "int8 (too loose: fp32 path)"
     else:
         n = cands.n
-        complete = real & (cands.flag == 0) & (n <= cands.cap) & (n >= kk) & torch.isfinite(cands.floor0)
-        bad = real & ~complete
-        ids = cands.items[:, :, 0]
-        slot = (torch.arange(cands.cap, device=dev, dtype=torch.int32).reshape(1, -1) < n.clamp(max=cands.cap).reshape(-1, 1)) & \
-            complete.reshape(-1, 1)
-        pr = torch.nonzero(slot, as_tuple=False)
-        xu32 = pr[:, 0].to(torch.int32).contiguous()
-        xi32 = ids[slot].contiguous()
         with _timed("topk_wide_finish"):
-            exact = pair_scores_exact(uop.f32, iop.f32, kpad, uop.d, xu32, xi32, ub, ib, MODE_DOT,
-                                      item_index_base=item_index_base)
-            vals = torch.full((n_u, cands.cap), float("-inf"), dtype=torch.float32, device=dev)
-            vals[slot] = exact
-            idm = torch.where(slot, ids, torch.full_like(ids, -1)).contiguous()
-            mv, mi = topk_merge(vals, idm, kk)
-        ov.copy_(mv)
-        oi.copy_(mi)
+            # one wave per user: the reference's fp32 chain on every listed item, the k best by value then index; users whose
+            # list is incomplete (more entries than slots, fewer than k) get flagged there
+            N.call("trec_topk_candidates_finish_wide", N.ptr(n), N.ptr(cands.items), cands.cap, N.ptr(cands.floor0),
+                   N.ptr(uop.f32), N.ptr(iop.f32), kpad, kpad, uop.d, N.ptr(ub), N.ptr(ib), item_index_base, n_u, kk,
+                   N.ptr(ov), N.ptr(oi), N.ptr(cands.flag), N.ptr(cands.n_flagged), None)
+        complete = real & (cands.flag == 0) & torch.isfinite(cands.floor0)
+        bad = real & ~complete
         LAST_FILTER_STATS.update({"prefilter": "int8", "refined_rows": int(rows), "tail": "candidate lists, wide finish",
                                   "candidates_cap": cands.cap,
                                   "candidates_per_user": float(n.clamp(max=cands.cap)[complete].float().mean().item()) if bool(complete.any()) else 0.0})

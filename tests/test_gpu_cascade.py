@@ -491,6 +491,45 @@ def test_cascade_hot_superblocks_of_a_popular_catalogue(ops):
     assert dbg["int8_pairs_wanted"] < 0.2 * dbg["int8_pairs_total"]
 
 
+def test_hot_launch_skips_the_users_the_pre_refinement_listed(ops):
+    """Pre-refinement AND hot rows at once: 12 popular items are everybody's k best superblocks, so the
+    pre-refining launch lists them for as many users as a superblock's list holds (512 here) and the compaction finds the same
+    superblocks wanted by the ~1,200 others -- hot.  The dense launch over the hot superblocks skips the users whose entry the
+    pre-refinement marked (-inf): nobody's candidates are listed twice, so the lists are never longer than without the
+    pre-refinement (same provisional floor there, a sharper one elsewhere).  Exact either way."""
+    rng = np.random.default_rng(22)
+    n_u, n_i, d, k = 2100, 300_000, 128, 10
+    u = rng.standard_normal((n_u, d)).astype(np.float32) / np.sqrt(d)
+    v = rng.standard_normal((n_i, d)).astype(np.float32) / np.sqrt(d)
+    pop = rng.permutation(n_i)[:12]
+    v[pop] *= 3.0
+    ub = (0.05 * rng.standard_normal(n_u)).astype(np.float32)
+    ib = (0.05 * rng.standard_normal(n_i)).astype(np.float32)
+    ib[pop] += 2.0
+    from tensorrec_amd import _native as N
+    ops.FILTER_DEBUG = {}
+    stats_were = ops.CANDIDATE_STATS
+    ops.CANDIDATE_STATS = True
+    N.set_tuning("cascade_rcap_pct", 0)                   # (a list capacity of 512 users per superblock)
+    try:
+        N.set_tuning("cascade_prerefine", 0)
+        vals, idx, stats, _, _ = run_cascade(ops, u, v, k, ub, ib)
+        N.set_tuning("cascade_prerefine", 1)
+        vals2, idx2, stats2, _, _ = run_cascade(ops, u, v, k, ub, ib)
+        dbg2 = dict(ops.FILTER_DEBUG)
+    finally:
+        ops.FILTER_DEBUG = None
+        ops.CANDIDATE_STATS = stats_were
+        N.set_tuning("cascade_rcap_pct", int(100 * ops.CASCADE_ROW_CAPACITY))
+        N.set_tuning("cascade_prerefine", 1)
+    rv, ri = O.topk_rows(O.score_dense_exact(u, v, ub, ib), k)
+    assert np.array_equal(idx, ri) and np.array_equal(vals, rv)
+    assert np.array_equal(idx2, ri) and np.array_equal(vals2, rv)
+    assert stats2["prefilter"] == "int8" and stats2["tail"] == "candidate lists", stats2
+    assert dbg2["prerefine_listed"] == 1 and dbg2["prerefine_pairs"] > 0 and dbg2["hot_superblocks"] >= 1, dbg2
+    assert stats2["candidates_per_user"] <= stats["candidates_per_user"] + 1e-9, (stats, stats2)
+
+
 def test_rows_hot_lists_rows_over_capacity(ops):
     """trec_topk_rows_hot: rows with count > rcap, ascending, -1 padded; their counts zeroed; status = {rows, overflow, hot rows}."""
     from tensorrec_amd import _native as N

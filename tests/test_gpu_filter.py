@@ -424,3 +424,23 @@ def test_wide_k_predict_top_k_through_the_public_api(ops):
     scores = model.predict(uf, itf)
     rv, ri = O.topk_rows(scores, 40)
     assert np.array_equal(idx, ri) and np.array_equal(vals, rv)
+
+
+@pytest.mark.parametrize("n_i,k", [(20_000, 40), (9_000, 3), (300, 5)])
+def test_topk_from_scores_selects_by_the_kth_value_and_keeps_the_tie_rule(ops, n_i, k):
+    """ops.topk_from_scores on long rows: the k-th largest value selects, trec_topk_merge orders -- equal to the oracle's
+    tf.nn.top_k order (value desc, index asc; recommendation_graphs.py:80) on rows with heavy ties, +inf entries, and -- through the
+    exact-rank form it falls back to -- rows whose k-th value is -inf or that hold NaN-free but mostly -inf entries."""
+    rng = np.random.default_rng(n_i + k)
+    s = np.round(rng.standard_normal((23, n_i)) * 4).astype(np.float32) / 4      # quarter-integer values: ties everywhere
+    s[3, 2:40:9] = np.inf
+    s[5, 10:] = -np.inf                                                          # fewer finite entries than k (when k > 10)
+    s[6, :] = 1.5                                                                # one value: the first k indices
+    rv, ri = O.topk_rows(s, k)
+    vals, idx = ops.topk_from_scores(dev(s), k)
+    assert np.array_equal(idx.cpu().numpy(), ri) and np.array_equal(vals.cpu().numpy(), rv)
+    # without the degenerate rows the threshold form itself answers
+    s2 = np.delete(s, [5, 6], axis=0)
+    rv, ri = O.topk_rows(s2, k)
+    vals, idx = ops.topk_from_scores(dev(s2), k)
+    assert np.array_equal(idx.cpu().numpy(), ri) and np.array_equal(vals.cpu().numpy(), rv)
