@@ -602,6 +602,276 @@ __global__ __launch_bounds__(1024) void seg_bin_place_kernel(const BinRecord* __
     }
 }
 
+// ---- (3'), round 6: a SECOND partition level instead of the scattered placement --------------------------------------------------
+// The placement above writes one 8-byte entry per record to base + (LDS cursor of its item)++ : 1e8 scattered stores into 3 MB
+// regions, 1.5 ms of the grouping's 2.6.  Two levels make every store part of a whole run:
+//   fine bins of 2^sub_log2 consecutive items, sized so that a fine bin's records (~13,000 expected) fit in LDS;
+//   (1') seg_fine_count_kernel counts the pairs per FINE bin (LDS counters, a few hundred persistent workgroups, one global atomic
+//        per workgroup and non-empty counter); seg_fine_scan_kernel turns them into the fine bins' bases, the bins' bases (a bin =
+//        2^(12 - sub_log2) fine bins) and the tile map of level 2;
+//   (2)  seg_bin_partition_kernel as above (bins of 4,096 items);
+//   (2') seg_bin_subpartition_kernel: a workgroup takes a tile of 8,192 records of ONE bin, sorts it by fine bin in LDS (ranks from
+//        wave ballots: <= 64 fine bins per bin, plain LDS atomics on so few counters would serialise) and writes the runs (~128-256
+//        records each) into the fine bins' regions, dword by dword;
+//   (3') seg_fine_place_kernel: one workgroup per fine bin loads its records, counts per item in LDS, scans (= indptr of its items),
+//        places {user, value} in LDS and copies the fine bin's entries out as ONE contiguous run.  A fine bin with more records
+//        than FINE_CAP (skewed lists, drop-zero on a learned model) places straight into global memory from LDS cursors instead.
+constexpr int FINE_CAP = 16384;            // entries of a fine bin staged in LDS (128 KB)
+constexpr int FINE_EXPECT = 13000;         // expected records per fine bin the size is chosen for (3,000 above the mean = 26 sigma)
+constexpr int FINE_MAX = 16384;            // fine bins (LDS counters of the count pass)
+constexpr int FINE_Q = FINE_CAP / 1024;    // records per thread of the placement's fast path
+
+// fine-bin size for a pair list, or BIN_LOG2 (= no second level) when a bin itself is small enough / the list is too dense
+static int fine_log2_for(int64_t n_pairs, int64_t n_items)
+{
+    int s = BIN_LOG2;
+    while (s > 6 && (double)n_pairs / (double)n_items * (double)((int64_t)1 << s) > (double)FINE_EXPECT) --s;
+    const int64_t n_bins = ceil_div64(n_items, BIN_ITEMS);
+    while (s < BIN_LOG2 && (n_bins << (BIN_LOG2 - s)) > FINE_MAX) ++s;
+    return s;
+}
+
+__global__ __launch_bounds__(1024) void seg_fine_count_kernel(const int32_t* __restrict__ xi, const float* __restrict__ drop_zero_of,
+                                                             int64_t n_pairs, int32_t n_bins, int32_t sub_log2, int32_t n_fine,
+                                                             int32_t* __restrict__ fine_count)
+{
+    extern __shared__ __attribute__((aligned(16))) char csm[];
+    int* cnt = (int*)csm;                                               // [n_fine]
+    for (int i = threadIdx.x; i < n_fine; i += 1024) cnt[i] = 0;
+    __syncthreads();
+    for (int64_t p0 = (int64_t)blockIdx.x * BIN_TILE; p0 < n_pairs; p0 += (int64_t)gridDim.x * BIN_TILE) {
+        int32_t it[BIN_TILE / 1024];
+        float vl[BIN_TILE / 1024];
+#pragma unroll
+        for (int q = 0; q < BIN_TILE / 1024; ++q) {
+            const int64_t p = p0 + q * 1024 + threadIdx.x;
+            const int64_t pc = p < n_pairs ? p : n_pairs - 1;
+            it[q] = xi[pc];
+            vl[q] = drop_zero_of ? drop_zero_of[pc] : 1.f;
+            if (p >= n_pairs) it[q] = -1;
+        }
+#pragma unroll
+        for (int q = 0; q < BIN_TILE / 1024; ++q) {
+            if (vl[q] == 0.f || (it[q] >> BIN_LOG2) >= n_bins) it[q] = -1;
+            if (it[q] >= 0) atomicAdd(&cnt[it[q] >> sub_log2], 1);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_fine; i += 1024)
+        if (cnt[i]) atomicAdd(fine_count + i, cnt[i]);
+}
+
+// One workgroup: fine_base [n_fine + 1] = exclusive scan of fine_count, fine_cursor = 0; bin_base [n_bins + 1] = the fine bases at
+// bin boundaries, bin_cursor = 0; tile_start [n_bins + 1] = exclusive scan of ceil(records of the bin / BIN_TILE).
+__global__ __launch_bounds__(1024) void seg_fine_scan_kernel(const int32_t* __restrict__ fine_count, int32_t n_fine, int32_t n_bins,
+                                                            int32_t sub_log2, int64_t* __restrict__ fine_base,
+                                                            int32_t* __restrict__ fine_cursor, int64_t* __restrict__ bin_base,
+                                                            int32_t* __restrict__ bin_cursor, int32_t* __restrict__ tile_start)
+{
+    __shared__ long long part[1024];
+    __shared__ int tiles[BIN_MAX_BINS + 1];
+    const int per = (n_fine + 1023) / 1024;
+    long long s = 0;
+    for (int j = 0; j < per; ++j) { const int i = threadIdx.x * per + j; if (i < n_fine) s += fine_count[i]; }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long acc = 0;
+        for (int t = 0; t < 1024; ++t) { const long long c = part[t]; part[t] = acc; acc += c; }
+        fine_base[n_fine] = acc;
+    }
+    __syncthreads();
+    long long acc = part[threadIdx.x];
+    for (int j = 0; j < per; ++j) {
+        const int i = threadIdx.x * per + j;
+        if (i < n_fine) { fine_base[i] = acc; acc += fine_count[i]; fine_cursor[i] = 0; }
+    }
+    __threadfence_block();
+    __syncthreads();
+    const int sh = BIN_LOG2 - sub_log2;
+    if ((int)threadIdx.x <= n_bins) {
+        const int b = threadIdx.x;
+        const long long lo = fine_base[(int64_t)b << sh < n_fine ? (int64_t)b << sh : n_fine];
+        bin_base[b] = lo;
+        if (b < n_bins) {
+            const long long hi = fine_base[(int64_t)(b + 1) << sh < n_fine ? (int64_t)(b + 1) << sh : n_fine];
+            tiles[b] = (int)((hi - lo + BIN_TILE - 1) / BIN_TILE);
+            bin_cursor[b] = 0;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int a = 0;
+        for (int b = 0; b < n_bins; ++b) { tile_start[b] = a; a += tiles[b]; }
+        tile_start[n_bins] = a;
+    }
+}
+
+__global__ __launch_bounds__(1024) void seg_bin_subpartition_kernel(const BinRecord* __restrict__ rec_in, const int64_t* __restrict__ bin_base,
+                                                                   const int32_t* __restrict__ tile_start, int32_t n_bins,
+                                                                   int32_t sub_log2, const int64_t* __restrict__ fine_base,
+                                                                   int32_t* __restrict__ fine_cursor, int32_t* __restrict__ rec_out)
+{
+    extern __shared__ __attribute__((aligned(16))) char bsm[];
+    int32_t* flat = (int32_t*)bsm;                                      // [3 * BIN_TILE] the tile's records, sorted by fine bin
+    long long* off = (long long*)(bsm + (size_t)BIN_TILE * 12);         // [64] record index in the fine bin's region of local record 0 of it
+    int* start = (int*)(off + 64);                                      // [65]
+    int* cnt = start + 65;                                              // [64]
+    if ((int)blockIdx.x >= tile_start[n_bins]) return;
+    // the bin of this tile: the last b with tile_start[b] <= blockIdx.x (every thread the same search: uniform, cached loads)
+    int lo = 0, hi = n_bins - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tile_start[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const int b = lo;
+    const int64_t r0 = bin_base[b] + (int64_t)((int)blockIdx.x - tile_start[b]) * BIN_TILE;
+    const int64_t rest = bin_base[b + 1] - r0;
+    const int n = rest < BIN_TILE ? (int)rest : BIN_TILE;
+    const int sh = BIN_LOG2 - sub_log2, nsub = 1 << sh;
+    if (threadIdx.x < 64) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    constexpr int PT = BIN_TILE / 1024;
+    const int lane = threadIdx.x & 63;
+    BinRecord rc[PT];
+    int lr[PT];
+#pragma unroll
+    for (int q = 0; q < PT; ++q) {
+        const int j = q * 1024 + threadIdx.x;
+        rc[q] = rec_in[r0 + (j < n ? j : 0)];
+    }
+#pragma unroll
+    for (int q = 0; q < PT; ++q) {
+        const int j = q * 1024 + threadIdx.x;
+        const bool valid = j < n;
+        const int sb = (rc[q].item >> sub_log2) & (nsub - 1);
+        // the lanes of this wave with the same fine bin (six ballots), rank = the ones below me; ONE LDS atomic per distinct fine bin
+        unsigned long long m = __builtin_amdgcn_ballot_w64(valid);
+#pragma unroll
+        for (int bit = 0; bit < 6; ++bit) {
+            const unsigned long long bb = __builtin_amdgcn_ballot_w64((sb >> bit) & 1);
+            m &= ((sb >> bit) & 1) ? bb : ~bb;
+        }
+        lr[q] = 0;
+        if (valid) {
+            const int leader = __builtin_ctzll(m);
+            const int below = __builtin_popcountll(m & ((1ull << lane) - 1ull));
+            int base = 0;
+            if (lane == leader) base = atomicAdd(&cnt[sb], __builtin_popcountll(m));
+            base = __shfl(base, leader, 64);
+            lr[q] = base + below;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int i = threadIdx.x;
+        const int c = i < nsub ? cnt[i] : 0;
+        int inc = c;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(inc, o, 64);
+            if (i >= o) inc += t;
+        }
+        start[i] = inc - c;
+        if (i == 63) start[64] = inc;
+        if (c) {
+            const int64_t f = ((int64_t)b << sh) + i;
+            const int g = atomicAdd(fine_cursor + f, c);
+            off[i] = fine_base[f] + g - (inc - c);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < PT; ++q) {
+        if (q * 1024 + (int)threadIdx.x < n) {
+            const int sb = (rc[q].item >> sub_log2) & (nsub - 1);
+            const int w = (start[sb] + lr[q]) * 3;
+            flat[w] = rc[q].item;
+            flat[w + 1] = rc[q].user;
+            flat[w + 2] = __float_as_int(rc[q].value);
+        }
+    }
+    __syncthreads();
+    const int total3 = n * 3;
+    for (int w = threadIdx.x; w < total3; w += 1024) {
+        const int j = w / 3;
+        const int sb = (flat[j * 3] >> sub_log2) & (nsub - 1);
+        rec_out[(off[sb] + j) * 3 + (w - j * 3)] = flat[w];
+    }
+}
+
+__global__ __launch_bounds__(1024) void seg_fine_place_kernel(const BinRecord* __restrict__ records, const int64_t* __restrict__ fine_base,
+                                                             int32_t sub_log2, int32_t n_fine, int64_t n_items,
+                                                             int64_t* __restrict__ indptr, int2* __restrict__ entries)
+{
+    extern __shared__ __attribute__((aligned(16))) char psm[];
+    int2* out = (int2*)psm;                                             // [FINE_CAP]
+    int* cnt = (int*)(psm + (size_t)FINE_CAP * 8);                      // [BIN_ITEMS]
+    __shared__ int wsum[16];
+    const int f = blockIdx.x;
+    const int64_t r0 = fine_base[f];
+    const int64_t n = fine_base[f + 1] - r0;
+    const int64_t item0 = (int64_t)f << sub_log2;
+    for (int i = threadIdx.x; i < BIN_ITEMS; i += 1024) cnt[i] = 0;
+    __syncthreads();
+    const bool fast = n <= FINE_CAP;
+    const int64_t safe = r0 > 0 ? r0 - 1 : 0;                            // (an empty fine bin at the very end: no read past the records)
+    int it[FINE_Q], us[FINE_Q], vl[FINE_Q], rk[FINE_Q];
+    if (fast) {
+#pragma unroll
+        for (int q = 0; q < FINE_Q; ++q) {
+            const int j = q * 1024 + threadIdx.x;
+            const BinRecord r = records[j < n ? r0 + j : safe];
+            it[q] = j < n ? (int)(r.item - item0) : -1;
+            us[q] = r.user;
+            vl[q] = __float_as_int(r.value);
+        }
+#pragma unroll
+        for (int q = 0; q < FINE_Q; ++q) { rk[q] = 0; if (it[q] >= 0) rk[q] = atomicAdd(&cnt[it[q]], 1); }
+    } else {
+        for (int64_t j = threadIdx.x; j < n; j += 1024) atomicAdd(&cnt[records[r0 + j].item - item0], 1);
+    }
+    __syncthreads();
+    // exclusive scan of the (up to 4,096) counts in place: thread t owns entries 4 t .. 4 t + 3
+    {
+        const int i4 = threadIdx.x * 4;
+        int c4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) c4[e] = cnt[i4 + e];
+        const int c = c4[0] + c4[1] + c4[2] + c4[3];
+        int inc = c;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(inc, o, 64);
+            if ((int)(threadIdx.x & 63) >= o) inc += t;
+        }
+        if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base += wsum[w];
+        int st = base + inc - c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            cnt[i4 + e] = st;
+            if (i4 + e < (1 << sub_log2) && item0 + i4 + e < n_items) indptr[item0 + i4 + e] = r0 + st;
+            st += c4[e];
+        }
+    }
+    if (f == n_fine - 1 && threadIdx.x == 0) indptr[n_items] = fine_base[n_fine];
+    __syncthreads();
+    if (fast) {
+#pragma unroll
+        for (int q = 0; q < FINE_Q; ++q)
+            if (it[q] >= 0) out[cnt[it[q]] + rk[q]] = make_int2(us[q], vl[q]);
+        __syncthreads();
+        for (int j = threadIdx.x; j < (int)n; j += 1024) entries[r0 + j] = out[j];
+    } else {
+        for (int64_t j = threadIdx.x; j < n; j += 1024) {
+            const BinRecord r = records[r0 + j];
+            const int slot = atomicAdd(&cnt[r.item - item0], 1);
+            entries[r0 + slot] = make_int2(r.user, __float_as_int(r.value));
+        }
+    }
+}
+
 // workspace bytes of trec_group_pairs_by_item_binned, or 0 when the form does not cover the size (more than 512 bins of 4,096
 // items, fewer than 2^22 pairs)
 extern "C" int64_t trec_group_pairs_binned_bytes(int64_t n_pairs, int64_t n_items)
@@ -615,7 +885,9 @@ extern "C" int64_t trec_group_pairs_binned_bytes(int64_t n_pairs, int64_t n_item
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess &&
             max_lds > 0 && max_lds < need_lds) return 0;
     }
-    return n_pairs * (int64_t)sizeof(BinRecord) + (n_bins + 1) * 8 + 2 * n_bins * 4 + n_bins * BIN_SLICES_MAX * (int64_t)BIN_ITEMS * 4 + 64;
+    // (the two-level form's second record array, the fine bins' counts / bases / cursors and the tile map come on top)
+    return n_pairs * (int64_t)sizeof(BinRecord) + (n_bins + 1) * 8 + 2 * n_bins * 4 + n_bins * BIN_SLICES_MAX * (int64_t)BIN_ITEMS * 4 + 64 +
+           n_pairs * (int64_t)sizeof(BinRecord) + 8 + (FINE_MAX + 1) * 8 + 2 * FINE_MAX * 4 + (BIN_MAX_BINS + 1) * 4 + 64;
 }
 
 // Group (user, item, value) pairs by item without ranks (see above): xi [n_pairs] items (negative: skipped), users from xu or
@@ -639,6 +911,58 @@ extern "C" int trec_group_pairs_by_item_binned(const int32_t* xu, const int32_t*
     int32_t* bin_count = (int32_t*)(bin_base + n_bins + 1);
     int32_t* bin_cursor = bin_count + n_bins;
     int32_t* run_counts = bin_cursor + n_bins;
+    const int sub_log2 = fine_log2_for(n_pairs, n_items);
+    int max_lds_dev = 0;
+    {
+        int d0 = 0;
+        if (hipGetDevice(&d0) != hipSuccess || hipDeviceGetAttribute(&max_lds_dev, hipDeviceAttributeMaxSharedMemoryPerBlock, d0) != hipSuccess)
+            max_lds_dev = 0;
+    }
+    // (the fine bins' placement stages 128 KB of entries in LDS: a device without it keeps the one-level form)
+    if (sub_log2 < BIN_LOG2 && trec_get_tuning("group_pairs_two_level", 1) != 0 && max_lds_dev >= FINE_CAP * 8 + BIN_ITEMS * 4 + 64) {
+        // ---- two partition levels, every store part of a run (see above)
+        char* extra = (char*)(run_counts + (int64_t)n_bins * BIN_SLICES_MAX * BIN_ITEMS);
+        extra = (char*)(((uintptr_t)extra + 7) / 8 * 8);
+        BinRecord* records2 = (BinRecord*)extra;
+        int64_t* fine_base = (int64_t*)(extra + (n_pairs * (int64_t)sizeof(BinRecord) + 7) / 8 * 8);
+        int32_t* fine_count = (int32_t*)(fine_base + FINE_MAX + 1);
+        int32_t* fine_cursor = fine_count + FINE_MAX;
+        int32_t* tile_start = fine_cursor + FINE_MAX;
+        const int32_t n_fine = n_bins << (BIN_LOG2 - sub_log2);
+        if (hipMemsetAsync(fine_count, 0, sizeof(int32_t) * (size_t)n_fine, st) != hipSuccess) {
+            trec_set_last_error("trec_group_pairs_by_item_binned: memset failed");
+            return TREC_ERR_LAUNCH;
+        }
+        static bool attr2_set[64] = {};
+        int dev2 = 0;
+        TREC_REQUIRE(hipGetDevice(&dev2) == hipSuccess && dev2 >= 0 && dev2 < 64, "trec_group_pairs_by_item_binned: no current device");
+        const int lds1 = BIN_TILE * 12 + (2 * BIN_MAX_BINS + 2) * 4 + BIN_MAX_BINS * 8 + 16;
+        const int lds2 = BIN_TILE * 12 + 64 * 8 + (65 + 64) * 4 + 16;
+        const int lds3 = FINE_CAP * 8 + BIN_ITEMS * 4;
+        const int ldsc = FINE_MAX * 4;
+        if (!attr2_set[dev2]) {
+            TREC_REQUIRE(hipFuncSetAttribute((const void*)seg_bin_partition_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds1) == hipSuccess &&
+                         hipFuncSetAttribute((const void*)seg_bin_subpartition_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds2) == hipSuccess &&
+                         hipFuncSetAttribute((const void*)seg_fine_place_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds3) == hipSuccess &&
+                         hipFuncSetAttribute((const void*)seg_fine_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ldsc) == hipSuccess,
+                         "trec_group_pairs_by_item_binned: the device refused the dynamic LDS size");
+            attr2_set[dev2] = true;
+        }
+        int64_t count_wgs = ceil_div64(n_pairs, 24 * (int64_t)BIN_TILE);
+        if (count_wgs > 1024) count_wgs = 1024;
+        if (count_wgs < 1) count_wgs = 1;
+        hipLaunchKernelGGL(seg_fine_count_kernel, dim3((unsigned)count_wgs), dim3(1024), (size_t)n_fine * 4, st, xi,
+                           drop_zero_values ? values : (const float*)nullptr, n_pairs, n_bins, sub_log2, n_fine, fine_count);
+        hipLaunchKernelGGL(seg_fine_scan_kernel, dim3(1), dim3(1024), 0, st, fine_count, n_fine, n_bins, sub_log2, fine_base, fine_cursor,
+                           bin_base, bin_cursor, tile_start);
+        hipLaunchKernelGGL(seg_bin_partition_kernel, dim3((unsigned)ceil_div64(n_pairs, BIN_TILE)), dim3(1024), lds1, st, xu, xi, values,
+                           n_pairs, pairs_per_user, drop_zero_values, n_bins, bin_base, bin_cursor, (int32_t*)records);
+        hipLaunchKernelGGL(seg_bin_subpartition_kernel, dim3((unsigned)(ceil_div64(n_pairs, BIN_TILE) + n_bins)), dim3(1024), lds2, st, records,
+                           bin_base, tile_start, n_bins, sub_log2, fine_base, fine_cursor, (int32_t*)records2);
+        hipLaunchKernelGGL(seg_fine_place_kernel, dim3((unsigned)n_fine), dim3(1024), lds3, st, records2, fine_base, sub_log2, n_fine, n_items,
+                           indptr_t, (int2*)entries);
+        return trec_check_launch("trec_group_pairs_by_item_binned (two levels)");
+    }
     if (hipMemsetAsync(bin_count, 0, sizeof(int32_t) * (size_t)n_bins, st) != hipSuccess) {
         trec_set_last_error("trec_group_pairs_by_item_binned: memset failed");
         return TREC_ERR_LAUNCH;

@@ -387,18 +387,25 @@ def test_ranked_packed_fill_in_two_levels(ops):
 
 
 @pytest.mark.gpu
-def test_binned_grouping_without_ranks(ops):
-    """trec_group_pairs_by_item_binned (the sampled pairs of the 1M x 1M fit: tiles sorted by 4,096-item bin in LDS, one workgroup per
-    bin counts / scans / places -- no rank per pair, no global atomic per pair): indptr is the histogram's prefix and every item's
+@pytest.mark.parametrize("two_level,skewed", [(1, False), (0, False), (1, True)])
+def test_binned_grouping_without_ranks(ops, two_level, skewed):
+    """trec_group_pairs_by_item_binned (the sampled pairs of the 1M x 1M fit: tiles sorted by 4,096-item bin in LDS, then -- two_level,
+    the default -- by fine bin, a fine bin's entries placed in LDS and written as one run; two_level = 0: one workgroup slice per bin
+    counts / scans / places -- no rank per pair, no global atomic per pair): indptr is the histogram's prefix and every item's
     bucket holds exactly its (user, value) pairs; negative items are skipped; implicit and explicit users; with drop_zero_values the
-    pairs whose value is +0 / -0 are left out as well (WMRB samples that violate no margin)."""
+    pairs whose value is +0 / -0 are left out as well (WMRB samples that violate no margin).  skewed: a third of the pairs fall on
+    100 neighbouring items -- their fine bin holds more records than its LDS stage and is placed from cursors instead."""
     import numpy as np
     import torch
     from tensorrec_amd import _native as N
     rng = np.random.default_rng(33)
     n_users, S, n_items = 90_000, 50, 50_003
     xi = rng.integers(0, n_items, size=n_users * S, dtype=np.int32)
+    if skewed:
+        hot = rng.random(xi.size) < 0.33
+        xi[hot] = rng.integers(20_000, 20_100, size=int(hot.sum()), dtype=np.int32)
     xi[rng.integers(0, xi.size, 1000)] = -1                     # skipped pairs
+    N.set_tuning("group_pairs_two_level", two_level)
     n_pairs = xi.size
     vals = rng.standard_normal(n_pairs).astype(np.float32)
     zero = rng.random(n_pairs) < 0.6
@@ -429,6 +436,7 @@ def test_binned_grouping_without_ranks(ops):
         assert np.array_equal(item_of_slot[order_g], ref_item[order_r])
         assert np.array_equal(got[:n_valid, 0][order_g], ref_user[order_r])
         assert np.array_equal(got[:n_valid, 1][order_g], ref_val[order_r])
+    N.set_tuning("group_pairs_two_level", 1)
 
 
 @pytest.mark.gpu
