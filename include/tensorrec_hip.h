@@ -348,6 +348,21 @@ int trec_score_gemm_refine_candidates(const void* users_bf16, const void* items_
  * (1.9M at 1M users, 98k of them with rows); wg_map NULL = the full grid. */
 int trec_topk_rows_wg_map(const int32_t* row_count, int32_t n_sb, int32_t wgs_per_row, int32_t* wg_start, int32_t* wg_map,
                           int64_t map_cap, void* stream);
+/* The same map with group_rows users per workgroup slot instead of 512 (entries beyond wg_start[n_sb] are left as the caller
+ * preset them: an id >= n_sb * wgs_per_row is an idle workgroup of trec_score_gemm_refine_candidates_resident). */
+int trec_topk_rows_wg_map_ex(const int32_t* row_count, int32_t n_sb, int32_t wgs_per_row, int32_t group_rows, int32_t* wg_start,
+                             int32_t* wg_map, int64_t map_cap, void* stream);
+/* trec_score_gemm_refine_candidates with the ITEMS resident (csrc/refine_resident.hip; same bf16-path maxima over the table entries,
+ * same candidate lists -- tensorrec/prediction_graphs.py:50 + recommendation_graphs.py:41 reduced towards the first tf.nn.top_k of
+ * recommendation_graphs.py:80): workgroup w keeps the 512 items of superblock wg_map[w] / segs_per_row in registers and streams
+ * segment wg_map[w] % segs_per_row (seg_rows users, a multiple of 64) of its user list row_user [n_sb][rcap] through LDS.
+ * sb_rows must be 512; row_count [n_sb] is clamped to rcap (0 = nothing to do: hot superblocks). */
+int trec_score_gemm_refine_candidates_resident(const void* users_bf16, const void* items_bf16, int32_t kpad, int64_t n_items,
+                                               const float* user_bias, const float* item_bias, int32_t sb_rows, int32_t n_sb,
+                                               const int32_t* row_count, const int32_t* row_user, int32_t rcap, float* blockmax,
+                                               int64_t bm_stride, const float* cand_floor, int32_t* cand_n, void* cand,
+                                               int32_t cand_cap, int32_t item_index_base, const int32_t* wg_map, int32_t n_wgs,
+                                               int32_t segs_per_row, int32_t seg_rows, void* stream);
 int trec_score_gemm_refine_candidates_hot(const void* users_bf16, const void* items_bf16, int32_t kpad, int64_t n_users,
                                           int64_t n_items, const float* user_bias, const float* item_bias, int32_t sb_rows,
                                           const int32_t* hot_list, int32_t hot_cap, float* blockmax, int64_t bm_stride,

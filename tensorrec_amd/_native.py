@@ -87,6 +87,9 @@ SIGNATURES = {
     "trec_score_gemm_refine_candidates": [_vp, _vp, _i32, _i64, _i64, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp,
                                           _i32, _i32, _vp, _i32, _vp],
     "trec_topk_rows_wg_map": [_vp, _i32, _i32, _vp, _vp, _i64, _vp],
+    "trec_topk_rows_wg_map_ex": [_vp, _i32, _i32, _i32, _vp, _vp, _i64, _vp],
+    "trec_score_gemm_refine_candidates_resident": [_vp, _vp, _i32, _i64, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _i64, _vp, _vp, _vp,
+                                                   _i32, _i32, _vp, _i32, _i32, _i32, _vp],
     "trec_score_gemm_refine_candidates_hot": [_vp, _vp, _i32, _i64, _i64, _vp, _vp, _i32, _vp, _i32, _vp, _i64, _vp, _vp, _vp,
                                               _i32, _i32, _vp],
     "trec_topk_candidates_finish": [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _i32, _i64, _i32, _vp,

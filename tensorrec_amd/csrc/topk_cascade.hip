@@ -282,15 +282,18 @@ __global__ __launch_bounds__(256) void rows_collect_kernel(const float* __restri
                                                           int64_t stride, const float* __restrict__ thr,
                                                           const float* __restrict__ user_err,
                                                           const float* __restrict__ sb_stats, int kdim, int32_t rcap,
-                                                          int32_t* __restrict__ row_count, int32_t* __restrict__ row_user)
+                                                          int32_t* __restrict__ row_count, int32_t* __restrict__ row_user, int rows_fast)
 {
     __shared__ int wsum[2][CROWS][4];
     __shared__ int base_s[2][CROWS];
-    const int64_t u = (int64_t)blockIdx.x * CUSERS + threadIdx.x * 4;
+    // rows_fast: consecutive workgroups take DIFFERENT row groups of one user block (grid x = row groups): the ~2,000 workgroups in
+    // flight then spread their slot atomics over every row counter instead of queueing on the 32 counters of one row group
+    const unsigned ublk = rows_fast ? blockIdx.y : blockIdx.x, rgrp = rows_fast ? blockIdx.x : blockIdx.y;
+    const int64_t u = (int64_t)ublk * CUSERS + threadIdx.x * 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const UserConsts c = load_user_consts(thr, user_err, n_users, u);
     for (int g = 0; g < CGROUPS; ++g) {
-        const int32_t s0 = (blockIdx.y * CGROUPS + g) * CROWS;
+        const int32_t s0 = (rgrp * CGROUPS + g) * CROWS;
         if (s0 >= n_sb) break;
         const unsigned int bits = tile_bits(table, n_sb, n_users, stride, c, sb_stats, kdim, s0, u);
         int pre[CROWS];
@@ -320,6 +323,59 @@ __global__ __launch_bounds__(256) void rows_collect_kernel(const float* __restri
             if (m) {
                 int idx = base_s[g & 1][r] + pre[r];
                 for (int w = 0; w < wave; ++w) idx += wsum[g & 1][r][w];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if ((m >> e) & 1u) {
+                        if (idx < rcap) row_user[(int64_t)s * rcap + idx] = (int32_t)(u + e);
+                        ++idx;
+                    }
+            }
+        }
+    }
+}
+
+// The same pass without any workgroup barrier: every WAVE (256 users) takes its own run of slots per row -- the eight rows' wave
+// totals sit in lanes 0..7, which issue the eight atomics together -- so the waves of a workgroup drift apart and one wave's loads
+// overlap another's atomics and stores (the barrier form holds a workgroup's four waves in step: load, scan, atomic, store).
+// Runs are ~4 users long instead of ~15; the list order inside a superblock is as undetermined as before.
+__global__ __launch_bounds__(256) void rows_collect_wave_kernel(const float* __restrict__ table, int32_t n_sb, int64_t n_users,
+                                                               int64_t stride, const float* __restrict__ thr,
+                                                               const float* __restrict__ user_err,
+                                                               const float* __restrict__ sb_stats, int kdim, int32_t rcap,
+                                                               int32_t* __restrict__ row_count, int32_t* __restrict__ row_user)
+{
+    const int64_t u = (int64_t)blockIdx.y * CUSERS + threadIdx.x * 4;
+    const int lane = threadIdx.x & 63;
+    const UserConsts c = load_user_consts(thr, user_err, n_users, u);
+    for (int g = 0; g < CGROUPS; ++g) {
+        const int32_t s0 = (blockIdx.x * CGROUPS + g) * CROWS;
+        if (s0 >= n_sb) break;
+        const unsigned int bits = tile_bits(table, n_sb, n_users, stride, c, sb_stats, kdim, s0, u);
+        if (__builtin_amdgcn_ballot_w64(bits != 0u) == 0ull) continue;      // (wave-uniform: nothing kept in these 8 rows x 256 users)
+        int pre[CROWS];
+        int mine = 0;
+#pragma unroll
+        for (int r = 0; r < CROWS; ++r) {
+            const int k = __builtin_popcount((bits >> (4 * r)) & 15u);
+            int inc = k;
+            for (int off = 1; off < 64; off <<= 1) {
+                const int t = __shfl_up(inc, off, 64);
+                if (lane >= off) inc += t;
+            }
+            pre[r] = inc - k;
+            const int tot = __shfl(inc, 63, 64);
+            if (lane == r) mine = tot;
+        }
+        int base = 0;
+        if (lane < CROWS && mine > 0 && s0 + lane < n_sb) base = atomicAdd(&row_count[s0 + lane], mine);
+#pragma unroll
+        for (int r = 0; r < CROWS; ++r) {
+            const int32_t s = s0 + r;
+            const int b = __shfl(base, r, 64);
+            if (s >= n_sb) break;
+            const unsigned int m = (bits >> (4 * r)) & 15u;
+            if (m) {
+                int idx = b + pre[r];
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     if ((m >> e) & 1u) {
@@ -497,8 +553,14 @@ extern "C" int trec_topk_rows_collect(const float* table, int32_t n_sb, int64_t 
     TREC_REQUIRE(rcap >= GROUP_ROWS && rcap % GROUP_ROWS == 0, "trec_topk_rows_collect: rcap must be a multiple of 512");
     hipStream_t st = (hipStream_t)stream;
     const int n_ublk = (int)ceil_div64(n_users, CUSERS);
-    hipLaunchKernelGGL(rows_collect_kernel, dim3((unsigned)n_ublk, (unsigned)((n_sb + CROWS * CGROUPS - 1) / (CROWS * CGROUPS))),
-                       dim3(256), 0, st, table, n_sb, n_users, stride, thr, user_err, sb_stats, kdim, rcap, row_count, row_user);
+    const unsigned n_rgrp = (unsigned)((n_sb + CROWS * CGROUPS - 1) / (CROWS * CGROUPS));
+    const int rows_fast = trec_get_tuning("rows_collect_rows_fast", 1) != 0 && n_ublk <= 65535;
+    if (rows_fast && trec_get_tuning("rows_collect_per_wave", 1) != 0)
+        hipLaunchKernelGGL(rows_collect_wave_kernel, dim3(n_rgrp, (unsigned)n_ublk), dim3(256), 0, st, table, n_sb, n_users, stride, thr,
+                           user_err, sb_stats, kdim, rcap, row_count, row_user);
+    else
+    hipLaunchKernelGGL(rows_collect_kernel, rows_fast ? dim3(n_rgrp, (unsigned)n_ublk) : dim3((unsigned)n_ublk, n_rgrp),
+                       dim3(256), 0, st, table, n_sb, n_users, stride, thr, user_err, sb_stats, kdim, rcap, row_count, row_user, rows_fast);
     hipLaunchKernelGGL(rows_status_kernel, dim3(1), dim3(256), 0, st, row_count, n_sb, rcap, status);
     return trec_check_launch("trec_topk_rows_collect");
 }
@@ -652,7 +714,7 @@ extern "C" int trec_topk_dense_users(const float* table, int32_t n_sb, int64_t n
 // status of trec_topk_rows_hot ((rows - hot rows * padded users) / 512) and launches exactly that many.
 namespace {
 __global__ __launch_bounds__(256) void wg_start_kernel(const int32_t* __restrict__ row_count, int32_t n_sb, int32_t wgs_per_row,
-                                                      int32_t* __restrict__ wg_start)
+                                                      int32_t* __restrict__ wg_start, int32_t group_rows)
 {
     __shared__ int wsum[4];
     __shared__ int base_s;
@@ -661,7 +723,7 @@ __global__ __launch_bounds__(256) void wg_start_kernel(const int32_t* __restrict
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int s0 = 0; s0 < n_sb; s0 += 256) {
         const int s = s0 + threadIdx.x;
-        int c = s < n_sb ? (row_count[s] + GROUP_ROWS - 1) / GROUP_ROWS : 0;
+        int c = s < n_sb ? (row_count[s] + group_rows - 1) / group_rows : 0;
         if (c > wgs_per_row) c = wgs_per_row;
         int inc = c;
         for (int off = 1; off < 64; off <<= 1) {
@@ -697,7 +759,22 @@ extern "C" int trec_topk_rows_wg_map(const int32_t* row_count, int32_t n_sb, int
     TREC_REQUIRE(n_sb >= 1 && wgs_per_row >= 1 && map_cap >= 0 && (int64_t)n_sb * wgs_per_row < ((int64_t)1 << 31),
                  "trec_topk_rows_wg_map: bad sizes");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(wg_start_kernel, dim3(1), dim3(256), 0, st, row_count, n_sb, wgs_per_row, wg_start);
+    hipLaunchKernelGGL(wg_start_kernel, dim3(1), dim3(256), 0, st, row_count, n_sb, wgs_per_row, wg_start, GROUP_ROWS);
     hipLaunchKernelGGL(wg_map_kernel, dim3((unsigned)n_sb), dim3(256), 0, st, wg_start, wgs_per_row, map_cap, wg_map);
     return trec_check_launch("trec_topk_rows_wg_map");
+}
+
+// The same map with group_rows users per workgroup slot instead of 512 (the item-resident refining launch,
+// trec_score_gemm_refine_candidates_resident: segments of 2,048 users): wg_map[wg_start[s] + j] = s * wgs_per_row + j for
+// j < min(ceil(row_count[s] / group_rows), wgs_per_row); entries beyond wg_start[n_sb] are not written (the caller presets them idle).
+extern "C" int trec_topk_rows_wg_map_ex(const int32_t* row_count, int32_t n_sb, int32_t wgs_per_row, int32_t group_rows,
+                                        int32_t* wg_start, int32_t* wg_map, int64_t map_cap, void* stream)
+{
+    TREC_REQUIRE(row_count && wg_start && wg_map, "trec_topk_rows_wg_map_ex: null pointer");
+    TREC_REQUIRE(n_sb >= 1 && wgs_per_row >= 1 && group_rows >= 1 && map_cap >= 0 && (int64_t)n_sb * wgs_per_row < ((int64_t)1 << 31),
+                 "trec_topk_rows_wg_map_ex: bad sizes");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(wg_start_kernel, dim3(1), dim3(256), 0, st, row_count, n_sb, wgs_per_row, wg_start, group_rows);
+    hipLaunchKernelGGL(wg_map_kernel, dim3((unsigned)n_sb), dim3(256), 0, st, wg_start, wgs_per_row, map_cap, wg_map);
+    return trec_check_launch("trec_topk_rows_wg_map_ex");
 }

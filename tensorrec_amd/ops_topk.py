@@ -560,6 +560,21 @@ class _Candidates(object):
     __slots__ = ("n", "items", "cap", "floor0", "flag", "n_flagged", "pre")
 
 
+RESIDENT_SEGMENT = 2048          # users of a superblock's list one workgroup of the item-resident refining launch streams
+
+
+def _refine_resident(sb_rows, kpad):
+    """The refining launches keep the ITEMS resident (csrc/refine_resident.hip) when the superblock is the 512 items its four
+    waves hold; tuning refine_resident = 0: the user-resident kernel (the A/B reference, other superblock sizes)."""
+    return int(sb_rows) == 512 and kpad in (64, 128) and N.load().trec_get_tuning(b"refine_resident", 1) != 0
+
+
+def _resident_segments(rcap):
+    seg = int(N.load().trec_get_tuning(b"refine_resident_seg", RESIDENT_SEGMENT))
+    seg = max(64, seg // 64 * 64)
+    return seg, (int(rcap) + seg - 1) // seg
+
+
 def cascade_lists_candidates():
     """Tuning ``cascade_candidates`` (default 1): the bf16 refining launches of the cascade also list, per user, the items
     that can still reach the top-k, and trec_topk_candidates_finish ends the call -- no table scan, no grouping by superblock,
@@ -687,7 +702,15 @@ def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, 
         with _timed("topk_prerefine"):
             N.call("trec_topk_prerefine_rows", N.ptr(sel), N.ptr(sel_max), kk, top_k, sb_per_chunk, n_sb, n_u, N.ptr(uop.src),
                    rcap_a, N.ptr(sel_sb), N.ptr(pre_ws), N.ptr(pre_rows), N.ptr(pre_ok))
-        if listed:
+        resident_a = listed and _refine_resident(sb_rows, kpad)
+        if resident_a:
+            # the items of a superblock stay in registers, its user list streams through LDS in segments (csrc/refine_resident.hip)
+            seg_a, segs_a = _resident_segments(rcap_a)
+            n_wgs_a = n_cap_a * kk // seg_a + n_sb + 1
+            wg_start_a = torch.empty((n_sb + 1,), dtype=torch.int32, device=dev)
+            wg_map_a = torch.full((n_wgs_a,), n_sb * segs_a, dtype=torch.int32, device=dev)
+            N.call("trec_topk_rows_wg_map_ex", N.ptr(pre_ws), n_sb, segs_a, seg_a, N.ptr(wg_start_a), N.ptr(wg_map_a), n_wgs_a)
+        elif listed:
             # occupied workgroup slots only: at most pairs / 512 + one partial slot per superblock; the entries the map kernel does
             # not reach point at the empty extra row
             n_wgs_a = n_cap_a * kk // 512 + n_sb + 1
@@ -695,7 +718,12 @@ def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, 
             wg_map_a = torch.full((n_wgs_a,), n_sb * (rcap_a // 512), dtype=torch.int32, device=dev)
             N.call("trec_topk_rows_wg_map", N.ptr(pre_ws), n_sb, rcap_a // 512, N.ptr(wg_start_a), N.ptr(wg_map_a), n_wgs_a)
         with _timed("score_gemm_blockmax_pre"):
-            if listed:
+            if resident_a:
+                N.call("trec_score_gemm_refine_candidates_resident", N.ptr(uop.bf16), N.ptr(iop.bf16), kpad, n_i,
+                       N.ptr(user_bias), N.ptr(item_bias), sb_rows, n_sb, N.ptr(pre_ws), N.ptr(pre_rows), rcap_a, N.ptr(table),
+                       stride, N.ptr(cands.floor0), N.ptr(cands.n), N.ptr(cands.items), cands.cap, int(item_index_base),
+                       N.ptr(wg_map_a), n_wgs_a, segs_a, seg_a)
+            elif listed:
                 N.call("trec_score_gemm_refine_candidates", N.ptr(uop.bf16), N.ptr(iop.bf16), kpad, n_sb * rcap_a, n_i,
                        N.ptr(user_bias), N.ptr(item_bias), sb_rows, N.ptr(pre_ws), N.ptr(pre_rows), N.ptr(table), stride,
                        rcap_a // 512, N.ptr(cands.floor0), N.ptr(cands.n), N.ptr(cands.items), cands.cap, int(item_index_base),
@@ -745,7 +773,16 @@ def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, 
                 N.call("trec_topk_dense_users", N.ptr(table), n_sb, n_u, stride, N.ptr(tau), N.ptr(user_err), N.ptr(iop.sb_stats),
                        kpad, CASCADE_DENSE_USER_LIMIT if n_i >= CASCADE_MIN_ITEMS else 30, N.ptr(cands.floor0), N.ptr(cands.flag),
                        N.ptr(cands.n_flagged))             # (small catalogues: the k-th largest of few maxima keeps half the rows of anybody)
-            if N.load().trec_get_tuning(b"cascade_wg_map", 1) != 0:
+            resident = _refine_resident(sb_rows, kpad)
+            if resident:
+                # the items of a superblock resident, its user list in segments (csrc/refine_resident.hip): the map lists the
+                # occupied (superblock, segment) slots; the rest of its entries stay idle
+                seg_r, segs_r = _resident_segments(rcap)
+                wg_cap = min(n_sb * segs_r, max_pairs // seg_r + n_sb + 1)
+                wg_start = torch.empty((n_sb + 1,), dtype=torch.int32, device=dev)
+                wg_map = torch.full((wg_cap,), n_sb * segs_r, dtype=torch.int32, device=dev)
+                N.call("trec_topk_rows_wg_map_ex", N.ptr(row_count), n_sb, segs_r, seg_r, N.ptr(wg_start), N.ptr(wg_map), wg_cap)
+            elif N.load().trec_get_tuning(b"cascade_wg_map", 1) != 0:
                 # only the workgroup slots that hold rows are launched (98k of the 1.9M of the [n_sb][rcap / 512] grid at 1M x 1M)
                 wg_cap = min(n_sb * (rcap // 512), max_pairs // 512 + n_sb + 1)
                 wg_start = torch.empty((n_sb + 1,), dtype=torch.int32, device=dev)
@@ -761,13 +798,20 @@ def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, 
             return None, stride, (int(rows), True), tau, None
         n_hot = min(int(n_hot), hot_cap)                # the hot launch's grid: nothing is launched when no superblock is hot
         n_wgs = 0
-        if wg_map is not None:
+        if wg_map is not None and cands is not None and resident:
+            n_wgs = min(wg_cap, (int(rows) - n_hot * ((n_u + 511) // 512 * 512)) // seg_r + n_sb + 1)
+        elif wg_map is not None:
             n_wgs = min(wg_cap, (int(rows) - n_hot * ((n_u + 511) // 512 * 512)) // 512)
         # (user batches in a pipeline: from here on the launches go to the tail stream, next to the following batch's int8 stage)
         tail = _tail_of(tail_stream if cands is not None else None, table, row_count, row_user, hot_list, wg_map,
                         *((cands.floor0, cands.n, cands.items) if cands is not None else ()))
         with tail, _timed("score_gemm_blockmax_grouped"):
-            if cands is not None:
+            if cands is not None and resident:
+                N.call("trec_score_gemm_refine_candidates_resident", N.ptr(uop.bf16), N.ptr(iop.bf16), kpad, n_i,
+                       N.ptr(user_bias), N.ptr(item_bias), sb_rows, n_sb, N.ptr(row_count), N.ptr(row_user), rcap, N.ptr(table),
+                       stride, N.ptr(cands.floor0), N.ptr(cands.n), N.ptr(cands.items), cands.cap, int(item_index_base),
+                       N.ptr(wg_map), n_wgs, segs_r, seg_r)
+            elif cands is not None:
                 N.call("trec_score_gemm_refine_candidates", N.ptr(uop.bf16), N.ptr(iop.bf16), kpad, n_sb * rcap, n_i,
                        N.ptr(user_bias), N.ptr(item_bias), sb_rows, N.ptr(row_count), N.ptr(row_user), N.ptr(table), stride,
                        rcap // 512, N.ptr(cands.floor0), N.ptr(cands.n), N.ptr(cands.items), cands.cap, int(item_index_base),
