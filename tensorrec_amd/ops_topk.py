@@ -564,9 +564,10 @@ RESIDENT_SEGMENT = 2048          # users of a superblock's list one workgroup of
 
 
 def _refine_resident(sb_rows, kpad):
-    """The refining launches keep the ITEMS resident (csrc/refine_resident.hip) when the superblock is the 512 items its four
-    waves hold; tuning refine_resident = 0: the user-resident kernel (the A/B reference, other superblock sizes)."""
-    return int(sb_rows) == 512 and kpad in (64, 128) and N.load().trec_get_tuning(b"refine_resident", 1) != 0
+    """tuning refine_resident = 1: the refining launches keep the ITEMS resident (csrc/refine_resident.hip; the superblock must be
+    the 512 items its four waves hold).  Measured on par with the user-resident kernel, not faster (1.92 + 2.70 against 1.81 + 2.73 ms
+    at 1M x 1M, profiles/r06_refine_resident_ab.txt): the default stays the user-resident kernel, this one is the A/B alternative."""
+    return int(sb_rows) == 512 and kpad in (64, 128) and N.load().trec_get_tuning(b"refine_resident", 0) != 0
 
 
 def _resident_segments(rcap):

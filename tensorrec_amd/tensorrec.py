@@ -1209,10 +1209,12 @@ class TensorRec(object):
                            1 <= k <= ops.EUCLID_CANDIDATES - 4 and n_items_min >= ops.TWO_STAGE_MIN_ITEMS and
                            self.n_components <= 256 and
                            ops.N.load().trec_get_tuning(b"topk_euclid_filter", 1) != 0)
-        # 17 <= k <= 64 on a catalogue the cascade runs on: the same int8 -> bf16 stages, 1,024 candidate slots per user and a finish
-        # made of library calls (ops.score_topk_filtered_wide); single process (item shards keep the fp32 two-stage path)
-        wide = (dtype == ops.DTYPE_F32 and graph.engine_mode == ops.MODE_DOT and 16 < k <= ops.WIDE_K_MAX and not sharded and
-                ops.cascade_prefilter_for(self.n_components, itf.shape[0]) == "int8" and
+        # 17 <= k <= 64 on a catalogue the cascade runs on: the same int8 -> bf16 stages, 1,024 candidate slots per user and a
+        # wave-per-user finish over every listed item (ops.score_topk_filtered_wide).  Item shards: every rank finds ITS shard's
+        # exact first k on its own (local thresholds, no collective inside the route -- the ranks agree on taking it because the
+        # smallest shard decides), the per-shard lists merge like any others.
+        wide = (dtype == ops.DTYPE_F32 and graph.engine_mode == ops.MODE_DOT and 16 < k <= ops.WIDE_K_MAX and
+                ops.cascade_prefilter_for(self.n_components, n_items_min) == "int8" and
                 ops.N.load().trec_get_tuning(b"topk_bf16_filter", 1) != 0 and ops.i8_user_classes_enabled())
         stats_exchange = (lambda g: sharding.all_reduce_max(g, self.process_group)) if sharded else None
         # ... and on a catalogue of >= 262,144 items an int8 MFMA pass (exact integer arithmetic, proven bound) first decides

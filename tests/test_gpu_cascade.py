@@ -615,3 +615,29 @@ def test_prerefined_threshold_keeps_fewer_pairs_and_the_same_lists(ops, d, n_u, 
         assert wanted[1] <= wanted[0], wanted
         if kind == "gauss" and n_i >= 262_144:
             assert wanted[1] < 0.8 * wanted[0], wanted     # (Gaussian rows: about half; the k pre-refined superblocks count as kept)
+
+
+@pytest.mark.parametrize("d,biased,n_u,n_i", [(128, True, 5000, 300_000), (64, False, 3000, 280_000 + 77), (128, True, 700, 1_000_000)])
+def test_cascade_with_the_item_resident_refining_kernel(ops, d, biased, n_u, n_i):
+    """tuning refine_resident = 1: the refining launches keep a superblock's 512 items in registers and stream its user list in
+    segments (csrc/refine_resident.hip) -- same maxima, same candidate lists, so the same exact result as the oracle's
+    tf.matmul + tf.nn.top_k (prediction_graphs.py:49-50, recommendation_graphs.py:80); segments of 64 users make every superblock
+    span several workgroups, the last catalogue ends inside a superblock."""
+    from tensorrec_amd import _native as N
+    rng = np.random.default_rng(d + n_u)
+    k = 10
+    u = rng.standard_normal((n_u, d)).astype(np.float32)
+    v = rng.standard_normal((n_i, d)).astype(np.float32)
+    ub = (0.1 * rng.standard_normal(n_u)).astype(np.float32) if biased else None
+    ib = (0.1 * rng.standard_normal(n_i)).astype(np.float32) if biased else None
+    rv, ri = O.topk_rows(O.score_dense_exact(u, v, ub, ib), k)
+    try:
+        for seg in (2048, 64):
+            N.set_tuning("refine_resident", 1)
+            N.set_tuning("refine_resident_seg", seg)
+            vals, idx, stats, _, _ = run_cascade(ops, u, v, k, ub, ib)
+            assert np.array_equal(idx, ri) and np.array_equal(vals, rv), (seg, stats)
+            assert stats["prefilter"] == "int8" and stats["tail"] == "candidate lists" and stats["flagged_users"] <= n_u // 20, stats
+    finally:
+        N.set_tuning("refine_resident", 0)
+        N.set_tuning("refine_resident_seg", 2048)

@@ -211,7 +211,7 @@ def _topk_case(n_items, n_tastes, d=32, graph="cosine"):
     return model, uf, itf
 
 
-def _topk_worker(rank, world, port, n_items, n_tastes, ret, d=32, graph="cosine"):
+def _topk_worker(rank, world, port, n_items, n_tastes, ret, d=32, graph="cosine", k=10):
     import torch.distributed as dist
     from tensorrec_amd import sharding
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -224,7 +224,8 @@ def _topk_worker(rank, world, port, n_items, n_tastes, ret, d=32, graph="cosine"
             _native.set_tuning("cascade_candidates", 0)         # (the table-driven tail; the default is the candidate lists)
         model, uf, itf = _topk_case(n_items, n_tastes, d, graph)
         b, e = sharding.shard_bounds(n_items, world, rank)
-        ret[rank] = model.predict_top_k(uf, itf[b:e], k=10, item_sharded=True, item_offset=b)
+        ret[rank] = model.predict_top_k(uf, itf[b:e], k=k, item_sharded=True, item_offset=b)
+        ret["api_route%d" % rank] = dict(model.last_route)
         if graph == "euclidean":
             from tensorrec_amd import ops
             ret["route%d" % rank] = str(ops.LAST_FILTER_STATS.get("route", ""))
@@ -279,3 +280,23 @@ def test_item_sharded_cascade_with_the_one_pass_scan(monkeypatch):
     for r in (0, 1):
         v, i = ret[r]
         assert np.array_equal(i, ref_i) and np.array_equal(v, ref_v), "rank %d" % r
+
+
+def test_item_sharded_wide_k_takes_the_cascade_on_every_shard():
+    """k = 40 (above the 16 slots of the fused lists) under item shards: every rank runs the wide cascade route on ITS 300,000-item
+    shard -- local thresholds, no collective inside the route -- and the exact per-shard lists of 40 merge: the single-process
+    result (itself the dense prediction's order, recommendation_graphs.py:73-82 truncated to 40 places), on both ranks."""
+    model, uf, itf = _topk_case(600000, 1, 64)
+    ref_v, ref_i = model.predict_top_k(uf, itf, k=40)
+    assert model.last_route["route"] == "wide_cascade", model.last_route
+    scores = model.predict(uf, itf)
+    from oracle import oracle as O
+    ov, oi = O.topk_rows(scores, 40)
+    assert np.array_equal(ref_i, oi) and np.array_equal(ref_v, ov)
+    mgr = mp.get_context("spawn").Manager()
+    ret = mgr.dict()
+    mp.spawn(_topk_worker, args=(2, _free_port(), 600000, 1, ret, 64, "cosine", 40), nprocs=2, join=True)
+    for r in (0, 1):
+        v, i = ret[r]
+        assert np.array_equal(i, ref_i) and np.array_equal(v, ref_v), "rank %d" % r
+        assert ret["api_route%d" % r]["route"] == "wide_cascade" and ret["api_route%d" % r]["sharded"], ret["api_route%d" % r]
