@@ -420,6 +420,24 @@ int trec_topk_prerefine_rows(const int32_t* sel, const float* sel_val, int32_t k
 int trec_topk_prerefine_tau(const int32_t* sel_sb, const int32_t* ok, int32_t k, float* table, int64_t stride, int64_t n_users,
                             const int32_t* src, const float* user_stats, const float* user_bias, const float* item_gstats,
                             int32_t kdim, float* tau, int32_t listed, float* vals, float* cand_floor, void* stream);
+/* The pre-refinement without a table pass behind its launch (round 6): trec_topk_prerefine_rows_pos also records sel_pos [n_users][k],
+ * the position of every placed pair inside its superblock's list; trec_score_gemm_refine_candidates_marked (declared with the other
+ * refining launches) leaves the bf16 maxima in pre_max [n_sb * rcap] by list position and marks the table entries -inf itself;
+ * trec_topk_prerefine_tau_listed reads the maxima back from there (vals, tau, cand_floor as trec_topk_prerefine_tau with listed != 0).
+ * Same reference arithmetic as the calls they replace (recommendation_graphs.py:73-82 restricted to what the exact top-k needs). */
+int trec_topk_prerefine_rows_pos(const int32_t* sel, const float* sel_val, int32_t k, int32_t top_k, int32_t sb_per_chunk,
+                                 int32_t n_sb, int64_t n_users, const int32_t* src, int32_t rcap, int32_t* sel_sb,
+                                 int32_t* row_count, int32_t* row_user, int32_t* ok, int32_t* sel_pos, void* stream);
+int trec_topk_prerefine_tau_listed(const int32_t* sel_sb, const int32_t* sel_pos, const int32_t* ok, int32_t k, const float* pre_max,
+                                   int32_t rcap, int64_t n_users, const int32_t* src, const float* user_stats,
+                                   const float* user_bias, const float* item_gstats, int32_t kdim, float* tau, float* vals,
+                                   float* cand_floor, void* stream);
+int trec_score_gemm_refine_candidates_marked(const void* users_bf16, const void* items_bf16, int32_t kpad, int64_t n_rows_g,
+                                             int64_t n_items, const float* user_bias, const float* item_bias, int32_t sb_rows,
+                                             const int32_t* row_count, const int32_t* row_user, float* blockmax, int64_t bm_stride,
+                                             int32_t wgs_per_row, const float* cand_floor, int32_t* cand_n, void* cand,
+                                             int32_t cand_cap, int32_t item_index_base, const int32_t* wg_map, int32_t n_wgs,
+                                             float* pre_max, void* stream);
 /* The exact EUCLIDEAN top-k (tensorrec/prediction_graphs.py:84-100 + tf.nn.top_k of recommendation_graphs.py:73-82) through the
  * dot-product cascade: per user, nearest = largest g = u.i - r_i / 2, a dot product with item "bias" -r_i / 2.  After the cascade
  * gave the kc = 16 largest g per user and trec_pair_score_exact their reference-chain scores (biases included),

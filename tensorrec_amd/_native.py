@@ -79,6 +79,10 @@ SIGNATURES = {
     "trec_topk_prerefine_max_superblocks": [],
     "trec_topk_prerefine_rows": [_vp, _vp, _i32, _i32, _i32, _i32, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
     "trec_topk_prerefine_tau": [_vp, _vp, _i32, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp],
+    "trec_topk_prerefine_rows_pos": [_vp, _vp, _i32, _i32, _i32, _i32, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
+    "trec_topk_prerefine_tau_listed": [_vp, _vp, _vp, _i32, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp],
+    "trec_score_gemm_refine_candidates_marked": [_vp, _vp, _i32, _i64, _i64, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp,
+                                                 _i32, _i32, _vp, _i32, _vp, _vp],
     "trec_topk_rows_collect": [_vp, _i32, _i64, _i64, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp],
     "trec_score_gemm_blockmax_grouped": [_vp, _vp, _i32, _i64, _i64, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _i32, _vp],
     "trec_topk_rows_hot": [_vp, _i32, _i32, _i64, _vp, _i32, _i64, _vp, _vp],

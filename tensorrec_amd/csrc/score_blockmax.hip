@@ -734,7 +734,16 @@ __global__ __launch_bounds__(256, NUB == 8 ? 2 : 3) void blockmax_bf16x16_kernel
 #ifdef TREC_CAND_DIAG
                     if (p.cand_diag & 8) continue;               // (the cost of the scattered maxima stores)
 #endif
-                    if (ou >= 0) p.blockmax[sb * p.bm_stride + ou] = v;
+                    if (GRP && p.pre_max) {
+                        // the pre-refining launch: the maximum stays with the list (coalesced, read back by list position), the
+                        // table entry is marked -inf -- the compaction no longer sees the pair -- in the same breath
+                        if (ou >= 0) {
+                            // (the wave's first list row from scalars: r_base itself, kept alive to here, cost the LIST form a spill)
+                            const int64_t rb = ((int64_t)__builtin_amdgcn_readfirstlane(rblock) * 4 + wave) * (NUB * 16);
+                            p.pre_max[rb + slot] = v;
+                            p.blockmax[sb * p.bm_stride + ou] = -INFINITY;
+                        }
+                    } else if (ou >= 0) p.blockmax[sb * p.bm_stride + ou] = v;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // (dense LIST launches: the next superblock's maxima follow)
                 __builtin_amdgcn_wave_barrier();

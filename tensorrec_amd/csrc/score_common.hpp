@@ -49,6 +49,9 @@ struct ScoreParams {
     int32_t cand_cap;
     const int32_t* wg_map;         // nullable [n_wgs]: grouped launch, fixed-capacity layout: workgroup w of the launch is slot wg_map[w] of the
     int32_t n_wgs;                 //   [n_sb][capacity] grid (trec_topk_rows_wg_map: only the slots that hold rows are launched)
+    float* pre_max;                // grouped LIST launch of the PRE-refinement (nullable): the bf16 maximum of resident row r goes to pre_max[r]
+                                   // (the list's own layout, next to row_index[r]) and the table entry is marked -inf right here -- the
+                                   // threshold kernel behind the launch then never touches the table (trec_topk_prerefine_tau_listed)
     int cand_diag;                 // builds with -DTREC_CAND_DIAG only (tuning cascade_cand_diag): low bits 1 = the queues are emptied without
                                    // looking, 2 = atomics but no stores; +8 no maxima stores, +32 no counter gather, +64 / +128 throttled row gathers
     float* chunk_top;              // int8 BLOCKMAX: [n_chunks * top_k][bm_stride]: the top_k largest LOWER BOUNDS of a chunk per user

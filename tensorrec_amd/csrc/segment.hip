@@ -626,6 +626,9 @@ static int fine_log2_for(int64_t n_pairs, int64_t n_items)
 {
     int s = BIN_LOG2;
     while (s > 6 && (double)n_pairs / (double)n_items * (double)((int64_t)1 << s) > (double)FINE_EXPECT) --s;
+    // (lists so dense that even 64 items overflow the LDS stage -- thousands of pairs per item -- keep the one-level form: every
+    // fine bin would take the cursor path)
+    if ((double)n_pairs / (double)n_items * (double)((int64_t)1 << s) > (double)FINE_CAP) return BIN_LOG2;
     const int64_t n_bins = ceil_div64(n_items, BIN_ITEMS);
     while (s < BIN_LOG2 && (n_bins << (BIN_LOG2 - s)) > FINE_MAX) ++s;
     return s;

@@ -669,6 +669,41 @@ extern "C" int trec_score_gemm_refine_candidates(const void* users_bf16, const v
     return launch_blockmax_pipelined_grouped(p, kpad, (hipStream_t)stream);
 }
 
+// The PRE-refining launch in its marking form: as trec_score_gemm_refine_candidates, but the bf16 maximum of list entry r (row_user[r])
+// goes to pre_max[r] (float [n_rows_g], the list's layout) and the table entry becomes -inf at once; trec_topk_prerefine_tau_listed
+// reads the maxima back by list position.
+extern "C" int trec_score_gemm_refine_candidates_marked(const void* users_bf16, const void* items_bf16, int32_t kpad, int64_t n_rows_g,
+                                                        int64_t n_items, const float* user_bias, const float* item_bias,
+                                                        int32_t sb_rows, const int32_t* row_count, const int32_t* row_user,
+                                                        float* blockmax, int64_t bm_stride, int32_t wgs_per_row,
+                                                        const float* cand_floor, int32_t* cand_n, void* cand, int32_t cand_cap,
+                                                        int32_t item_index_base, const int32_t* wg_map, int32_t n_wgs, float* pre_max,
+                                                        void* stream)
+{
+    TREC_REQUIRE(users_bf16 && items_bf16 && row_count && row_user && blockmax && cand_floor && cand_n && cand && pre_max,
+                 "trec_score_gemm_refine_candidates_marked: null pointer");
+    TREC_REQUIRE(n_wgs >= 0 && (wg_map || n_wgs == 0), "trec_score_gemm_refine_candidates_marked: n_wgs without wg_map");
+    if (wg_map && n_wgs == 0) return TREC_OK;
+    TREC_REQUIRE(wgs_per_row > 0 && cand_cap >= 1, "trec_score_gemm_refine_candidates_marked: needs the fixed-capacity layout (wgs_per_row > 0)");
+    TREC_REQUIRE(kpad == 64 || kpad == 128, "trec_score_gemm_refine_candidates_marked: kpad must be 64 or 128");
+    TREC_REQUIRE(n_rows_g % GROUP_ROWS == 0 && n_rows_g < ((int64_t)1 << 40), "trec_score_gemm_refine_candidates_marked: n_rows_g % 512 != 0");
+    TREC_REQUIRE(sb_rows >= 64 && sb_rows % 64 == 0 && sb_rows <= 65536, "trec_score_gemm_refine_candidates_marked: sb_rows must be a multiple of 64, <= 65536");
+    TREC_REQUIRE(trec_get_tuning("blockmax_bf16_mfma16", 1) != 0, "trec_score_gemm_refine_candidates_marked: needs the 16x16x32 kernel (tuning blockmax_bf16_mfma16)");
+    if (n_rows_g == 0) return TREC_OK;
+    TREC_REQUIRE(n_rows_g / GROUP_ROWS < ((int64_t)1 << 31), "trec_score_gemm_refine_candidates_marked: too many workgroups");
+    ScoreParams p = {};
+    p.R = users_bf16; p.T = items_bf16; p.n_r = n_rows_g; p.n_t = n_items;
+    p.chunk_len = sb_rows; p.n_chunks = 1;
+    p.r_bias = user_bias; p.t_bias = item_bias;
+    p.blockmax = blockmax; p.bm_stride = bm_stride; p.sb_tiles = sb_rows / 64;
+    p.rblock_chunk = row_count; p.row_index = row_user; p.capacity = wgs_per_row;
+    p.cand_floor = cand_floor; p.cand_n = cand_n; p.cand = (int2*)cand; p.cand_cap = cand_cap; p.t_index_base = item_index_base;
+    p.cand_diag = trec_get_tuning("cascade_cand_diag", 0);
+    p.wg_map = wg_map; p.n_wgs = n_wgs;
+    p.pre_max = pre_max;
+    return launch_blockmax_pipelined_grouped(p, kpad, (hipStream_t)stream);
+}
+
 extern "C" int trec_score_gemm_refine_candidates_hot(const void* users_bf16, const void* items_bf16, int32_t kpad, int64_t n_users,
                                                      int64_t n_items, const float* user_bias, const float* item_bias,
                                                      int32_t sb_rows, const int32_t* hot_list, int32_t hot_cap, float* blockmax,

@@ -700,10 +700,19 @@ def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, 
             N.call("trec_topk_dense_users", N.ptr(table), n_sb, n_u, stride, N.ptr(tau), N.ptr(user_err), N.ptr(iop.sb_stats),
                    kpad, CASCADE_DENSE_USER_LIMIT if n_i >= CASCADE_MIN_ITEMS else 30, N.ptr(cands.floor0), N.ptr(cands.flag),
                    N.ptr(cands.n_flagged))
-        with _timed("topk_prerefine"):
-            N.call("trec_topk_prerefine_rows", N.ptr(sel), N.ptr(sel_max), kk, top_k, sb_per_chunk, n_sb, n_u, N.ptr(uop.src),
-                   rcap_a, N.ptr(sel_sb), N.ptr(pre_ws), N.ptr(pre_rows), N.ptr(pre_ok))
         resident_a = listed and _refine_resident(sb_rows, kpad)
+        # (default) the listing launch keeps its maxima by list position and marks the table itself: the threshold kernel behind it
+        # reads a few tens of MB back instead of 10 random entries per user of the table (tuning prerefine_marked = 0: the table pass)
+        marked = bool(listed) and not resident_a and lib.trec_get_tuning(b"prerefine_marked", 1) != 0
+        sel_pos = torch.empty((n_u, kk), dtype=torch.int32, device=dev) if marked else None
+        pre_max = torch.empty((n_sb * rcap_a,), dtype=torch.float32, device=dev) if marked else None       # only the listed part is touched
+        with _timed("topk_prerefine"):
+            if marked:
+                N.call("trec_topk_prerefine_rows_pos", N.ptr(sel), N.ptr(sel_max), kk, top_k, sb_per_chunk, n_sb, n_u, N.ptr(uop.src),
+                       rcap_a, N.ptr(sel_sb), N.ptr(pre_ws), N.ptr(pre_rows), N.ptr(pre_ok), N.ptr(sel_pos))
+            else:
+                N.call("trec_topk_prerefine_rows", N.ptr(sel), N.ptr(sel_max), kk, top_k, sb_per_chunk, n_sb, n_u, N.ptr(uop.src),
+                       rcap_a, N.ptr(sel_sb), N.ptr(pre_ws), N.ptr(pre_rows), N.ptr(pre_ok))
         if resident_a:
             # the items of a superblock stay in registers, its user list streams through LDS in segments (csrc/refine_resident.hip)
             seg_a, segs_a = _resident_segments(rcap_a)
@@ -724,6 +733,11 @@ def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, 
                        N.ptr(user_bias), N.ptr(item_bias), sb_rows, n_sb, N.ptr(pre_ws), N.ptr(pre_rows), rcap_a, N.ptr(table),
                        stride, N.ptr(cands.floor0), N.ptr(cands.n), N.ptr(cands.items), cands.cap, int(item_index_base),
                        N.ptr(wg_map_a), n_wgs_a, segs_a, seg_a)
+            elif marked:
+                N.call("trec_score_gemm_refine_candidates_marked", N.ptr(uop.bf16), N.ptr(iop.bf16), kpad, n_sb * rcap_a, n_i,
+                       N.ptr(user_bias), N.ptr(item_bias), sb_rows, N.ptr(pre_ws), N.ptr(pre_rows), N.ptr(table), stride,
+                       rcap_a // 512, N.ptr(cands.floor0), N.ptr(cands.n), N.ptr(cands.items), cands.cap, int(item_index_base),
+                       N.ptr(wg_map_a), n_wgs_a, N.ptr(pre_max))
             elif listed:
                 N.call("trec_score_gemm_refine_candidates", N.ptr(uop.bf16), N.ptr(iop.bf16), kpad, n_sb * rcap_a, n_i,
                        N.ptr(user_bias), N.ptr(item_bias), sb_rows, N.ptr(pre_ws), N.ptr(pre_rows), N.ptr(table), stride,
@@ -734,9 +748,14 @@ def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, 
                        N.ptr(user_bias), N.ptr(item_bias), sb_rows, N.ptr(pre_ws), N.ptr(pre_rows), N.ptr(table), stride,
                        rcap_a // 512)
         with _timed("topk_prerefine"):
-            N.call("trec_topk_prerefine_tau", N.ptr(sel_sb), N.ptr(pre_ok), kk, N.ptr(table), stride, n_u, N.ptr(uop.src),
-                   N.ptr(uop.stats), N.ptr(user_bias), N.ptr(gstats_all), kpad, N.ptr(tau), listed, N.ptr(pre_vals),
-                   N.ptr(cands.floor0))
+            if marked:
+                N.call("trec_topk_prerefine_tau_listed", N.ptr(sel_sb), N.ptr(sel_pos), N.ptr(pre_ok), kk, N.ptr(pre_max), rcap_a, n_u,
+                       N.ptr(uop.src), N.ptr(uop.stats), N.ptr(user_bias), N.ptr(gstats_all), kpad, N.ptr(tau), N.ptr(pre_vals),
+                       N.ptr(cands.floor0))
+            else:
+                N.call("trec_topk_prerefine_tau", N.ptr(sel_sb), N.ptr(pre_ok), kk, N.ptr(table), stride, n_u, N.ptr(uop.src),
+                       N.ptr(uop.stats), N.ptr(user_bias), N.ptr(gstats_all), kpad, N.ptr(tau), listed, N.ptr(pre_vals),
+                       N.ptr(cands.floor0))
         if listed:
             cands.pre = (sel_sb, pre_vals)          # (the saved maxima go back into the columns of users re-done from the table)
         if FILTER_DEBUG is not None:
