@@ -351,7 +351,9 @@ def test_ops_facade_forwards_module_switches():
 def test_topk_user_batch_sizes_by_route():
     """predict_top_k's default user batch (ops_topk.topk_user_batch) from the memory a user costs on each route: never below 65,536 nor
     above TOPK_USER_BATCH_MAX, smaller on a larger catalogue, smaller for the wide-k route (1,024 candidate slots per user) than for
-    the cascade at the same shape, smaller for a larger k on the two-stage route.  (No GPU here: the free-memory query falls back to
+    the cascade on a SMALL catalogue (where the slots dominate; on a large one the cascade's three user-list columns per superblock
+    -- pre-refinement list, its maxima, compaction list -- outweigh them: the wide route keeps one), smaller for a larger k on the
+    two-stage route.  (No GPU here: the free-memory query falls back to
     16 GB, which is what makes the sizes comparable.)"""
     from tensorrec_amd import ops
     dev = "cpu"
@@ -360,8 +362,10 @@ def test_topk_user_batch_sizes_by_route():
         small = ops.topk_user_batch(10_000_000, 1_000_000, 128, dev, route=route, k=k)
         large = ops.topk_user_batch(10_000_000, 16_000_000, 128, dev, route=route, k=k)
         assert 65536 <= large <= small <= ops.TOPK_USER_BATCH_MAX, (route, small, large)
+    assert ops.topk_user_batch(10_000_000, 300_000, 128, dev, route="wide", k=64) <= \
+        ops.topk_user_batch(10_000_000, 300_000, 128, dev, route="cascade", k=16)
     assert ops.topk_user_batch(10_000_000, 4_000_000, 128, dev, route="wide", k=64) <= \
-        ops.topk_user_batch(10_000_000, 4_000_000, 128, dev, route="cascade", k=16)
+        ops.topk_user_batch(10_000_000, 4_000_000, 128, dev, route="wide", k=17)
     assert ops.topk_user_batch(10_000_000, 8_000_000, 128, dev, route="two_stage", k=16) <= \
         ops.topk_user_batch(10_000_000, 8_000_000, 128, dev, route="two_stage", k=4)
     # k > 16 on the two-stage route (item shards, bf16, Euclidean): trec_score_topk_capacity is -1 there -- the size must not GROW
