@@ -53,7 +53,8 @@ for kind in KINDS:
             torch.cuda.synchronize(); times.append(1e3 * (time.perf_counter() - t))
         st = dict(ops.LAST_FILTER_STATS)
         ops.FILTER_DEBUG = {}
-        iop = ops.score_prep_filter(v, bias=ib, want_gstats=True); uop.i8 = None
+        iop = ops.score_prep_filter(v, bias=ib, want_gstats=True)
+        uop = ops.score_prep_filter(u, sort_users=pre == "int8")           # (a class-sorted operand owns its int8 rows: made again)
         ops.score_topk_filtered(uop, iop, K, ub, ib, prefilter=pre)
         out[name] = {"ms": min(times), "stats": st, "debug": dict(ops.FILTER_DEBUG)}
         ops.FILTER_DEBUG = None
