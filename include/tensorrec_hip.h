@@ -111,6 +111,12 @@ int trec_colsum(const float* x, int64_t n_rows, int32_t d, float* out, float* wo
 int trec_gemm_f32(int32_t trans_a, int32_t trans_b, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
                   const float* B, int64_t ldb, float* C, int64_t ldc, int32_t accumulate, float* workspace,
                   int32_t splits, void* stream);
+/* trec_gemm_f32's contract with both operands split into two bf16 terms (x = hi + lo) and three bf16 MFMAs per product block, fp32
+ * accumulation: ~1e-5 relative per product.  For products that ARE gradients (TF's autodiff of tensorrec.py:487-489 on the dense
+ * coefficient matrix of the tiled WMRB step: 1e-4 bar), not for values compared with the oracle's fmaf chain. */
+int trec_gemm_f32_split_bf16(int32_t trans_a, int32_t trans_b, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                             const float* B, int64_t ldb, float* C, int64_t ldc, int32_t accumulate, float* workspace,
+                             int32_t splits, void* stream);
 
 /* ---- K2: user x item score contraction --------------------------------------------------------------------
  * tf.matmul(user_repr, item_repr, transpose_b=True): prediction_graphs.py:50 (DotProduct), :94 (Euclidean),

@@ -308,7 +308,9 @@ def l2_normalize_rows(x):
     return _RowL2Norm.apply(x)
 
 
-def gemm_raw(a, b, trans_a=False, trans_b=False):
+def gemm_raw(a, b, trans_a=False, trans_b=False, split_bf16=False):
+    """fp32 C = op(a) . op(b).  ``split_bf16``: both operands as two bf16 terms on bf16 MFMA (three products, fp32 accumulation:
+    ~1e-5 relative) -- for gradients held to 1e-4, never for a value the oracle's fmaf chain is compared with."""
     a, b = _f32c(a), _f32c(b)
     m = a.shape[1] if trans_a else a.shape[0]
     k = a.shape[0] if trans_a else a.shape[1]
@@ -319,8 +321,8 @@ def gemm_raw(a, b, trans_a=False, trans_b=False):
     tiles = ((m + 127) // 128) * ((n + 127) // 128)
     splits = max(1, min(1024 // max(tiles, 1), k // 512)) if tiles < 512 else 1
     ws = torch.empty((splits, m, n), dtype=torch.float32, device=a.device) if splits > 1 else None
-    N.call("trec_gemm_f32", 1 if trans_a else 0, 1 if trans_b else 0, m, n, k, N.ptr(a), a.shape[1], N.ptr(b),
-           b.shape[1], N.ptr(c), n, 0, N.ptr(ws), splits)
+    N.call("trec_gemm_f32_split_bf16" if split_bf16 else "trec_gemm_f32", 1 if trans_a else 0, 1 if trans_b else 0, m, n, k,
+           N.ptr(a), a.shape[1], N.ptr(b), b.shape[1], N.ptr(c), n, 0, N.ptr(ws), splits)
     return c
 
 
@@ -900,11 +902,14 @@ def wmrb_tiled_step(user_in, item_in, user_bias, item_bias, interactions, sample
     if dense:
         # d item_in: dot  dV[i] = sum_u G[u, i] U[u];  euclidean  dV[i] = sum c (V[i] - U[u]) = colsum(G)[i] V[i] - (G^T U)[i]
         v_pad = v if ldg == n_items else torch.cat([v, torch.zeros((ldg - n_items, d), dtype=torch.float32, device=dev)])
+        # (both GEMMs are gradients, held to 1e-4: split-bf16 operands on bf16 MFMA, bound by reading G instead of by the fp32
+        # matrix pipe -- tuning dense_g_split_bf16 = 0: exact fp32 products)
+        split = N.load().trec_get_tuning(b"dense_g_split_bf16", 1) != 0
         with _timed("dense_g_gemm"):
-            gv = gemm_raw(G, v_pad)                            # [n_users, d]
+            gv = gemm_raw(G, v_pad, split_bf16=split)          # [n_users, d]
         d_u = val_rs.unsqueeze(1) * u - gv if euclid else gv
         with _timed("dense_g_gemm"):
-            t = gemm_raw(G, u, trans_a=True)[:n_items]
+            t = gemm_raw(G, u, trans_a=True, split_bf16=split)[:n_items]
         cs = colsum(G)[:n_items] if (euclid or ib is not None) else None
         d_v = cs.unsqueeze(1) * v - t if euclid else t.contiguous()
         if ib is not None and not euclid:

@@ -229,6 +229,26 @@ def test_gemm_f32_tiles_edges_and_split_k(ops, ta, tb, M, N, K):
     assert np.allclose(got.cpu().numpy(), ref, rtol=1e-5, atol=1e-5 * np.sqrt(K) * 8)
 
 
+@pytest.mark.parametrize("ta,tb", [(False, False), (True, False), (False, True), (True, True)])
+@pytest.mark.parametrize("M,N,K", [(300, 260, 129), (1000, 256, 5000), (130, 70, 9000), (64, 1024, 33), (2000, 256, 1003)])
+def test_gemm_split_bf16_is_an_fp32_product_to_a_few_1e5(ops, ta, tb, M, N, K):
+    """trec_gemm_f32_split_bf16 (the dense-coefficient GEMMs of the tiled WMRB step: gradients of tensorrec.py:487-489, 1e-4 bar):
+    both operands as hi + lo bf16 terms, three bf16 MFMAs per block, fp32 accumulation -- within 3e-5 of the largest entry of the
+    float64 product on ragged tiles, every transposition, split K, sparse operands and operands of mixed magnitudes (the
+    coefficient matrix is 90 % zeros with entries over several decades)."""
+    rng = np.random.default_rng(M + K + ta + 2 * tb)
+    a = rng.standard_normal((K, M) if ta else (M, K)).astype(np.float32)
+    a *= np.exp(2.0 * rng.standard_normal(a.shape)).astype(np.float32) * (rng.random(a.shape) < 0.3)
+    b = rng.standard_normal((N, K) if tb else (K, N)).astype(np.float32)
+    ref = (a.T if ta else a).astype(np.float64) @ (b.T if tb else b).astype(np.float64)
+    got = ops.gemm_raw(dev(a), dev(b), trans_a=ta, trans_b=tb, split_bf16=True)
+    assert torch.equal(got, ops.gemm_raw(dev(a), dev(b), trans_a=ta, trans_b=tb, split_bf16=True))
+    err = np.abs(got.cpu().numpy() - ref).max()
+    assert err <= 3e-5 * np.abs(ref).max(), (err, np.abs(ref).max())
+    exact = ops.gemm_raw(dev(a), dev(b), trans_a=ta, trans_b=tb).cpu().numpy()
+    assert np.abs(exact - ref).max() <= err + 1e-5 * np.abs(ref).max()          # (the fp32 product is at least as close)
+
+
 def test_euclid_coef_from_kept_squared_distances_equals_recomputed(ops):
     from tensorrec_amd import _native as N
     rng = np.random.default_rng(8)
