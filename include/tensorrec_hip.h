@@ -116,7 +116,9 @@ int trec_gemm_f32(int32_t trans_a, int32_t trans_b, int64_t M, int64_t N, int64_
  * coefficient matrix of the tiled WMRB step: 1e-4 bar), not for values compared with the oracle's fmaf chain. */
 int trec_gemm_f32_split_bf16(int32_t trans_a, int32_t trans_b, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
                              const float* B, int64_t ldb, float* C, int64_t ldc, int32_t accumulate, float* workspace,
-                             int32_t splits, void* stream);
+                             int32_t splits, float* a_colsum_parts, void* stream);
+/* (a_colsum_parts, nullable, trans_a only: float [splits][M] -- per K slice the column sums of the stored [K, M] matrix A, taken by
+ * the threads that stage A: the separate pass over a 14.8 GB coefficient matrix for its column sums disappears) */
 
 /* ---- K2: user x item score contraction --------------------------------------------------------------------
  * tf.matmul(user_repr, item_repr, transpose_b=True): prediction_graphs.py:50 (DotProduct), :94 (Euclidean),

@@ -45,7 +45,7 @@ SIGNATURES = {
     "trec_relu_bwd": [_vp, _vp, _i64, _vp, _vp],
     "trec_colsum": [_vp, _i64, _i32, _vp, _vp, _i32, _vp],
     "trec_gemm_f32": [_i32, _i32, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp, _i32, _vp],
-    "trec_gemm_f32_split_bf16": [_i32, _i32, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp, _i32, _vp],
+    "trec_gemm_f32_split_bf16": [_i32, _i32, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp, _i32, _vp, _vp],
     "trec_score_kpad": [_i32],
     "trec_score_rows_per_workgroup": [_i32, _i32],
     "trec_score_tile_rows": [_i32, _i32],

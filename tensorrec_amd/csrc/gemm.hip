@@ -255,7 +255,8 @@ template <bool AK, bool BK>
 __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(int64_t M, int64_t N, int64_t K, int64_t k_per_split,
                                                             const float* __restrict__ A, int64_t lda,
                                                             const float* __restrict__ B, int64_t ldb, float* __restrict__ C,
-                                                            int64_t ldc, int accumulate, float* __restrict__ partial)
+                                                            int64_t ldc, int accumulate, float* __restrict__ partial,
+                                                            float* __restrict__ a_sums)
 {
     extern __shared__ __attribute__((aligned(16))) char gsm[];           // four [128][SK] bf16 arrays: 65,536 bytes
     unsigned short* Ah = (unsigned short*)gsm;
@@ -287,8 +288,16 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(int64_t M, int64_t 
         if (stage_a) split_load<AK>(A, lda, m0, k0, M, ke, a_vec, t, rr);
         else split_load<BK>(B, ldb, n0, k0, N, ke, b_vec, t, rr);
     };
+    // a_sums (A stored [K, M] only): sum over k of every row of op(A) -- the column sums of the stored matrix -- ride along in the
+    // threads that stage A (they hold its values anyway): four running sums per thread for its four rows, met at the end
+    const bool want_sums = !AK && a_sums != nullptr && blockIdx.x == 0;  // (one column of workgroups reports them)
+    f32x4 asum = {0.f, 0.f, 0.f, 0.f};
     if (kb < ke) load_slab(kb);
     for (int64_t k0 = kb; k0 < ke; k0 += SK) {
+        if (!AK && want_sums && stage_a) {
+#pragma unroll
+            for (int q = 0; q < NR; ++q) { asum[0] += rr[q][0]; asum[1] += rr[q][1]; asum[2] += rr[q][2]; asum[3] += rr[q][3]; }
+        }
         if (stage_a) split_store<AK>(Ah, Al, t, rr);
         else split_store<BK>(Bh, Bl, t, rr);
         __syncthreads();
@@ -317,6 +326,17 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(int64_t M, int64_t 
             __builtin_amdgcn_sched_barrier(0);                   // (the next k-step's eight fragments are not read ahead: registers)
         }
         __syncthreads();
+    }
+    if (!AK && want_sums) {
+        // the four k-groups' partial sums of each row meet through LDS (the operand buffers are free now), in k-group order
+        float* red = (float*)gsm;                                // [4][128]
+        if (stage_a) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[(t >> 5) * TM + 4 * (t & 31) + e] = asum[e];
+        }
+        __syncthreads();
+        if (tid < TM && m0 + tid < M)
+            a_sums[(int64_t)blockIdx.z * M + m0 + tid] = ((red[tid] + red[TM + tid]) + red[2 * TM + tid]) + red[3 * TM + tid];
     }
     float* dst = partial ? partial + (int64_t)blockIdx.z * M * N : C;
     const int64_t ldd = partial ? N : ldc;
@@ -375,8 +395,11 @@ extern "C" int trec_gemm_f32(int32_t trans_a, int32_t trans_b, int64_t M, int64_
 // WMRB step), not for values compared with the oracle's fmaf chain.
 extern "C" int trec_gemm_f32_split_bf16(int32_t trans_a, int32_t trans_b, int64_t M, int64_t N, int64_t K, const float* A,
                                         int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int32_t accumulate,
-                                        float* workspace, int32_t splits, void* stream)
+                                        float* workspace, int32_t splits, float* a_colsum_parts, void* stream)
 {
+    // a_colsum_parts (nullable; trans_a only): float [splits][M] -- per K slice the sums over k of op(A)'s rows, i.e. the column
+    // sums of the stored [K, M] matrix; the caller adds the slices (in order)
+    TREC_REQUIRE(!a_colsum_parts || trans_a, "trec_gemm_f32_split_bf16: column sums come with trans_a (A stored [K, M])");
     TREC_REQUIRE(A && B && C, "trec_gemm_f32_split_bf16: null pointer");
     TREC_REQUIRE(M >= 0 && N >= 0 && K >= 0, "trec_gemm_f32_split_bf16: negative size");
     TREC_REQUIRE(splits <= 1 || workspace, "trec_gemm_f32_split_bf16: splits > 1 needs a workspace of splits * M * N floats");
@@ -399,7 +422,7 @@ extern "C" int trec_gemm_f32_split_bf16(int32_t trans_a, int32_t trans_b, int64_
             attr_set = true;                                                                                           \
         }                                                                                                              \
         hipLaunchKernelGGL((gemm_bf16x3_kernel<AKV, BKV>), grid, dim3(256), LDS3, st, M, N, K, k_per, A, lda, B, ldb, C, ldc, \
-                           accumulate, partial);                                                                       \
+                           accumulate, partial, a_colsum_parts);                                                       \
     } while (0)
     if (!trans_a && !trans_b) { TREC_GEMM3(true, false); }
     else if (!trans_a && trans_b) { TREC_GEMM3(true, true); }

@@ -308,9 +308,10 @@ def l2_normalize_rows(x):
     return _RowL2Norm.apply(x)
 
 
-def gemm_raw(a, b, trans_a=False, trans_b=False, split_bf16=False):
+def gemm_raw(a, b, trans_a=False, trans_b=False, split_bf16=False, a_colsum=False):
     """fp32 C = op(a) . op(b).  ``split_bf16``: both operands as two bf16 terms on bf16 MFMA (three products, fp32 accumulation:
-    ~1e-5 relative) -- for gradients held to 1e-4, never for a value the oracle's fmaf chain is compared with."""
+    ~1e-5 relative) -- for gradients held to 1e-4, never for a value the oracle's fmaf chain is compared with.  ``a_colsum`` (with
+    split_bf16 and trans_a): also returns the column sums of the stored ``a`` -- (C, colsum) -- taken while ``a`` is staged."""
     a, b = _f32c(a), _f32c(b)
     m = a.shape[1] if trans_a else a.shape[0]
     k = a.shape[0] if trans_a else a.shape[1]
@@ -321,9 +322,18 @@ def gemm_raw(a, b, trans_a=False, trans_b=False, split_bf16=False):
     tiles = ((m + 127) // 128) * ((n + 127) // 128)
     splits = max(1, min(1024 // max(tiles, 1), k // 512)) if tiles < 512 else 1
     ws = torch.empty((splits, m, n), dtype=torch.float32, device=a.device) if splits > 1 else None
-    N.call("trec_gemm_f32_split_bf16" if split_bf16 else "trec_gemm_f32", 1 if trans_a else 0, 1 if trans_b else 0, m, n, k,
-           N.ptr(a), a.shape[1], N.ptr(b), b.shape[1], N.ptr(c), n, 0, N.ptr(ws), splits)
-    return c
+    if split_bf16:
+        k_per = -(-(-(-k // splits)) // 64) * 64                           # (the slices the entry point makes: whole 64-wide slabs)
+        n_slices = max(1, -(-k // max(k_per, 64)))
+        parts = torch.empty((n_slices, m), dtype=torch.float32, device=a.device) if (a_colsum and trans_a) else None
+        N.call("trec_gemm_f32_split_bf16", 1 if trans_a else 0, 1 if trans_b else 0, m, n, k, N.ptr(a), a.shape[1], N.ptr(b),
+               b.shape[1], N.ptr(c), n, 0, N.ptr(ws), splits, N.ptr(parts))
+        if a_colsum:
+            return c, (parts.sum(dim=0) if parts is not None else colsum(a))
+        return c
+    N.call("trec_gemm_f32", 1 if trans_a else 0, 1 if trans_b else 0, m, n, k, N.ptr(a), a.shape[1], N.ptr(b),
+           b.shape[1], N.ptr(c), n, 0, N.ptr(ws), splits)
+    return (c, colsum(a)) if a_colsum else c
 
 
 class _MatMul(torch.autograd.Function):
@@ -908,9 +918,13 @@ def wmrb_tiled_step(user_in, item_in, user_bias, item_bias, interactions, sample
         with _timed("dense_g_gemm"):
             gv = gemm_raw(G, v_pad, split_bf16=split)          # [n_users, d]
         d_u = val_rs.unsqueeze(1) * u - gv if euclid else gv
-        with _timed("dense_g_gemm"):
-            t = gemm_raw(G, u, trans_a=True, split_bf16=split)[:n_items]
-        cs = colsum(G)[:n_items] if (euclid or ib is not None) else None
+        want_cs = euclid or ib is not None
+        with _timed("dense_g_gemm"):                          # (the column sums of G ride in the threads that stage it)
+            t = gemm_raw(G, u, trans_a=True, split_bf16=split, a_colsum=want_cs and split)
+            t, cs = t if (want_cs and split) else (t, None)
+            t = t[:n_items]
+        if want_cs:
+            cs = cs[:n_items] if cs is not None else colsum(G)[:n_items]
         d_v = cs.unsqueeze(1) * v - t if euclid else t.contiguous()
         if ib is not None and not euclid:
             d_ib = cs.contiguous()

@@ -247,6 +247,11 @@ def test_gemm_split_bf16_is_an_fp32_product_to_a_few_1e5(ops, ta, tb, M, N, K):
     assert err <= 3e-5 * np.abs(ref).max(), (err, np.abs(ref).max())
     exact = ops.gemm_raw(dev(a), dev(b), trans_a=ta, trans_b=tb).cpu().numpy()
     assert np.abs(exact - ref).max() <= err + 1e-5 * np.abs(ref).max()          # (the fp32 product is at least as close)
+    # the column sums of the stored A ride along (trans_a: taken by the threads that stage A; otherwise the colsum kernel)
+    c2, cs = ops.gemm_raw(dev(a), dev(b), trans_a=ta, trans_b=tb, split_bf16=True, a_colsum=True)
+    assert torch.equal(c2, got)
+    ref_cs = a.astype(np.float64).sum(0)
+    assert np.allclose(cs.cpu().numpy(), ref_cs, rtol=1e-5, atol=1e-5 * np.abs(a).max() * np.sqrt(a.shape[0]) * 4)
 
 
 def test_euclid_coef_from_kept_squared_distances_equals_recomputed(ops):
