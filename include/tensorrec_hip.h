@@ -455,7 +455,7 @@ int trec_score_gemm_refine_candidates_marked(const void* users_bf16, const void*
 int trec_topk_euclid_certify(const int32_t* cand_idx, const float* cand_g, const float* exact, int32_t kc, int32_t k,
                              const float* user_sq, const float* user_bias, const float* item_gstats, const float* bias_max,
                              int32_t kdim, int64_t n_users, float* out_vals, int32_t* out_idx, int32_t* flag,
-                             int32_t* n_flagged, void* stream);
+                             int32_t* n_flagged, const float* lambda_, const float* bias_min, void* stream);
 int trec_topk_filter_floor(const float* tau, const float* user_stats, const float* user_bias, const float* item_gstats,
                            int32_t kdim, int64_t n_users, float* floor, int32_t* flag, int32_t* n_flagged, void* stream);
 int trec_topk_collect_blocks(const float* blockmax, int32_t n_sb, int64_t n_users, int64_t stride, const float* floor,

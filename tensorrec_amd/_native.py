@@ -103,7 +103,7 @@ SIGNATURES = {
                                           _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp],
     "trec_topk_candidates_finish_wide": [_vp, _vp, _i32, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp,
                                          _vp, _vp],
-    "trec_topk_euclid_certify": [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp],
+    "trec_topk_euclid_certify": [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "trec_topk_filter_floor": [_vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp],
     "trec_topk_collect_blocks": [_vp, _i32, _i64, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
     "trec_topk_filter_floor_ex": [_vp, _vp, _vp, _vp, _i32, _i64, _f, _vp, _vp, _vp, _vp],

@@ -1399,9 +1399,14 @@ def score_topk_filtered_wide(uop, iop, k, user_bias=None, item_bias=None, item_i
 
 
 EUCLID_CANDIDATES = 16       # K' of the Euclidean route: the cascade's largest list
+EUCLID_SECOND_PASS_MIN = 32  # users without a certificate from which the cascade runs once more with a measured weight (fewer: the fp32 path)
+EUCLID_LAMBDA_PCT = 70       # weight of the item bias in its ordering, in percent of the typical distance sqrt(mean r_u + mean r_i): the NEAREST
+                             # items sit closer than the typical one, and a weight above their distance moves the bound's maximum to the
+                             # smallest bias (measured, 700 x 280,000, d = 128: sigma_b = 0.02 -> 53 / 0 / 155 users re-done at 100 / 70 / 25 %;
+                             # sigma_b = 0.2 -> 700 / 201 / 700; profiles/r06_euclid_bias_ab.json)
 
 
-def score_topk_euclid_filtered(user_repr, item_repr, k, user_bias=None, item_bias=None, item_index_base=0):
+def score_topk_euclid_filtered(user_repr, item_repr, k, user_bias=None, item_bias=None, item_index_base=0, _lam=None):
     """EXACT top-k of the Euclidean scores -sqrt(max(r_u - 2 u.i + r_i, 1e-16)) (+ biases) -- prediction_graphs.py:84-100 +
     recommendation_graphs.py:33-41, :73-82 -- through the DOT-product cascade (csrc/euclid_topk.hip): per user, nearest = largest
     g = u.i - r_i / 2, so the cascade runs with the item "bias" -r_i / 2 and lists the K' = 16 nearest items; the reference's own
@@ -1421,6 +1426,18 @@ def score_topk_euclid_filtered(user_repr, item_repr, k, user_bias=None, item_bia
     u32, u_sq, kpad = score_prep(u, DTYPE_F32, want_sqnorm=True)
     i32, i_sq, _ = score_prep(v, DTYPE_F32, want_sqnorm=True)
     c = i_sq * -0.5                                                   # exact halving: the item "bias" of the g ordering
+    ub = _f32c(user_bias.detach()).reshape(-1) if user_bias is not None else None
+    ib = _f32c(item_bias.detach()).reshape(-1) if item_bias is not None else None
+    # item biases in the ordering: h = u.i - r_i / 2 + lambda b_i with lambda = the typical distance of unrelated rows (any lambda
+    # >= 0 is valid: the certificate's bound follows it; tuning euclid_bias_in_order = 0 gives the plain g ordering back).  On the
+    # device: no host read.
+    lam = bmin = None
+    if ib is not None and N.load().trec_get_tuning(b"euclid_bias_in_order", 1) != 0:
+        lam = _lam if _lam is not None else \
+            (torch.sqrt(u_sq.mean() + i_sq.mean()) *
+             (N.load().trec_get_tuning(b"euclid_lambda_pct", EUCLID_LAMBDA_PCT) / 100.0)).reshape(1).contiguous()
+        c = c + lam * ib
+        bmin = ib.min().reshape(1)
     prefilter = cascade_prefilter_for(d, n_i)
     u_f = score_prep_filter(u, sort_users=prefilter == "int8", k=EUCLID_CANDIDATES)
     i_f = score_prep_filter(v, bias=c, want_gstats=True)
@@ -1429,8 +1446,6 @@ def score_topk_euclid_filtered(user_repr, item_repr, k, user_bias=None, item_bia
     # ---- the reference's chain on the U x 16 candidate pairs
     xu32 = torch.arange(n_u, dtype=torch.int32, device=dev).repeat_interleave(EUCLID_CANDIDATES)
     xi32 = gi.reshape(-1).clamp(min=0).contiguous()
-    ub = _f32c(user_bias.detach()).reshape(-1) if user_bias is not None else None
-    ib = _f32c(item_bias.detach()).reshape(-1) if item_bias is not None else None
     exact = pair_scores_exact(u32, i32, kpad, d, xu32, xi32, ub, ib, MODE_EUCLIDEAN, u_sq, i_sq)
     bmax = ib.max().reshape(1) if ib is not None else None
     ov = torch.empty((n_u, kk), dtype=torch.float32, device=dev)
@@ -1439,8 +1454,25 @@ def score_topk_euclid_filtered(user_repr, item_repr, k, user_bias=None, item_bia
     n_flagged = zero_block(1, dev)
     with _timed("topk_euclid_certify"):
         N.call("trec_topk_euclid_certify", N.ptr(gi), N.ptr(gv), N.ptr(exact), EUCLID_CANDIDATES, kk, N.ptr(u_sq), N.ptr(ub),
-               N.ptr(i_f.gstats), N.ptr(bmax), int(d), n_u, N.ptr(ov), N.ptr(oi), N.ptr(flag), N.ptr(n_flagged))
+               N.ptr(i_f.gstats), N.ptr(bmax), int(d), n_u, N.ptr(ov), N.ptr(oi), N.ptr(flag), N.ptr(n_flagged), N.ptr(lam),
+               N.ptr(bmin))
     n_bad = int(n_flagged.item())
+    n_second = 0
+    if n_bad >= EUCLID_SECOND_PASS_MIN and lam is not None and _lam is None:
+        # the weight was a guess (a fraction of the TYPICAL distance); the candidates just re-scored say how far the NEAREST items
+        # really are: the users without a certificate take the cascade once more with the median of those distances as the weight
+        # (its optimum is sharp: profiles/r06_euclid_bias_ab.json) before anybody goes to the fp32 path
+        bad = torch.nonzero(flag, as_tuple=False).reshape(-1)
+        near = ib[xi32.long()].reshape(n_u, EUCLID_CANDIDATES) - exact.reshape(n_u, EUCLID_CANDIDATES)      # = sqrt(D) - b_u
+        if ub is not None:
+            near = near + ub.reshape(-1, 1)
+        lam2 = near[gi >= 0].median().clamp(min=0.0).reshape(1).contiguous()
+        sv, si = score_topk_euclid_filtered(u[bad].contiguous(), v, kk, ub[bad].contiguous() if ub is not None else None, ib,
+                                            item_index_base=0, _lam=lam2)
+        n_second = n_bad - int(LAST_FILTER_STATS.get("euclid_uncertified_users", 0))
+        ov[bad] = sv
+        oi[bad] = si
+        n_bad = 0                                           # (the second pass finished its own leftovers on the fp32 path)
     if n_bad:
         bad = torch.nonzero(flag, as_tuple=False).reshape(-1)
         with _timed("topk_filter_fallback"):
@@ -1453,8 +1485,10 @@ def score_topk_euclid_filtered(user_repr, item_repr, k, user_bias=None, item_bia
         oi = torch.where(oi >= 0, oi + int(item_index_base), oi)
     LAST_FILTER_STATS.clear()
     LAST_FILTER_STATS.update(stats)
+    if n_second or (lam is not None and _lam is None and int(n_flagged.item()) >= EUCLID_SECOND_PASS_MIN):
+        n_bad = int(n_flagged.item()) - n_second            # users that reached the fp32 path in the end
     LAST_FILTER_STATS.update({"route": "euclidean via the dot-product cascade (g = u.i - r_i / 2, %d nearest, certificate)" % EUCLID_CANDIDATES,
-                              "users": n_u, "euclid_uncertified_users": n_bad})
+                              "users": n_u, "euclid_uncertified_users": n_bad, "euclid_second_pass_certified": n_second})
     return ov, oi
 
 

@@ -322,12 +322,21 @@ def test_euclidean_topk_through_the_dot_cascade_is_the_oracles(ops, d, n_u, n_i,
     ref = O.score_dense_euclid_exact(u, v, u_sq.cpu().numpy(), v_sq.cpu().numpy(), ub, ib)
     rv, ri = O.topk_rows(ref, k)
     assert np.array_equal(idx.cpu().numpy(), ri) and np.array_equal(vals.cpu().numpy(), rv)
-    # the certificate compares the gap between the k-th and the 16th nearest item (a few hundredths of a distance of ~16 here)
-    # with the largest item bias: it holds for unbiased models and for biases below that gap, and honestly fails above it
-    if bias_scale <= 0.001:
+    # the cascade orders by u.i - r_i / 2 + lambda b_i (round 6): item biases of the size of the distance gaps between neighbours
+    # (0.02 at distances of ~16: with the plain nearest-16 ordering 456 of 700 users had to be re-done) no longer break the
+    # certificate; biases that dwarf every distance difference (2.0) are certified where the bound's curvature term allows
+    if bias_scale <= 0.02:
         assert stats["euclid_uncertified_users"] <= n_u // 10, stats
-    elif bias_scale >= 2.0:
-        assert stats["euclid_uncertified_users"] > n_u // 2, stats
+    if bias_scale == 0.02:
+        from tensorrec_amd import _native as N
+        N.set_tuning("euclid_bias_in_order", 0)                     # the plain g ordering: exact as well, through the fp32 path
+        try:
+            vals0, idx0 = ops.score_topk_euclid_filtered(du, dv, k, dub, dib)
+            stats0 = dict(ops.LAST_FILTER_STATS)
+        finally:
+            N.set_tuning("euclid_bias_in_order", 1)
+        assert np.array_equal(idx0.cpu().numpy(), ri) and np.array_equal(vals0.cpu().numpy(), rv)
+        assert stats0["euclid_uncertified_users"] > 4 * max(1, stats["euclid_uncertified_users"]), (stats0, stats)
     if n_i >= 262_144 and d in (64, 128):
         assert str(stats.get("prefilter", "")).startswith("int8"), stats      # the int8 -> bf16 -> fp32 cascade itself ran
 
