@@ -281,8 +281,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(int64_t M, int64_t 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // (one slab of global loads in flight per workgroup, in registers; two slabs of 32 with the multiply loop written twice spilled
-    // and ran 2.8x slower: measured, dropped for one slab of 64)
+    // (one slab of global loads in flight per workgroup, in registers.  Measured and dropped: two slabs of 32 with the multiply loop
+    // written twice -- spills at two workgroups per CU, 2.8x slower; two slabs of 64 at ONE workgroup per CU (launch bounds (256, 1),
+    // 140 AGPRs of overflow, no scratch) -- 14.1 / 9.6 ms against 9.6 / 7.7: the second workgroup hides more than the second slab)
     f32x4 rr[NR];
     auto load_slab = [&](int64_t k0) __attribute__((always_inline)) {
         if (stage_a) split_load<AK>(A, lda, m0, k0, M, ke, a_vec, t, rr);
