@@ -13,7 +13,14 @@ v = torch.randn((I, d), device="cuda", generator=g) * 0.1
 ub = torch.randn(U, device="cuda", generator=g) * 0.01
 ib = torch.randn(I, device="cuda", generator=g) * 0.01
 out = {"users": U, "items": I, "d": d}
-for k in (32, 64):
+from tensorrec_amd import _native as N
+if os.environ.get("WIDE_PREREFINE") is not None:            # A/B: WIDE_PREREFINE=0 -> the wide route without the pre-refinement
+    N.set_tuning("wide_prerefine", int(os.environ["WIDE_PREREFINE"]))
+    out["wide_prerefine"] = int(os.environ["WIDE_PREREFINE"])
+if os.environ.get("EARLY_DENSE") is not None:
+    N.set_tuning("prerefine_early_dense", int(os.environ["EARLY_DENSE"]))
+    out["prerefine_early_dense"] = int(os.environ["EARLY_DENSE"])
+for k in tuple(int(x) for x in os.environ.get("KS", "32,64").split(",")):
     def step():
         uop = ops.score_prep_filter(u, sort_users=True, k=k, user_bias=ub)
         iop = ops.score_prep_filter(v, bias=ib, want_gstats=True)
@@ -37,4 +44,4 @@ for k in (32, 64):
                       "stats": {kk: vv for kk, vv in dict(ops.LAST_FILTER_STATS).items()}, "equals_fp32_path_on_sample": same}
 print(json.dumps(out, indent=1, default=str))
 os.makedirs("gpurun_out", exist_ok=True)
-json.dump(out, open("gpurun_out/wide_k_bench.json", "w"), indent=1, default=str)
+json.dump(out, open("gpurun_out/wide_k_bench%s.json" % os.environ.get("TAG", ""), "w"), indent=1, default=str)

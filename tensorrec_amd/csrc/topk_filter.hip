@@ -220,6 +220,8 @@ __global__ __launch_bounds__(256) void cascade_floor_kernel(float* __restrict__ 
 // (superblock ids, -1 = no certificate in that slot) and appends the user to its superblocks' lists row_user [n_sb][rcap] (counts
 // row_count [n_sb], zeroed by the caller; LDS counters per workgroup of 1024 users, ONE global atomic per (workgroup, superblock)).
 // ok[u] = 1 when all k slots were placed (the user's tauA is then valid).
+// KS = slots per user held in registers (16: k <= 16, four users per thread; 64: the wide route's k <= 64, one user per thread).
+template <int KS>
 __global__ __launch_bounds__(256) void prerefine_rows_kernel(const int32_t* __restrict__ sel, const float* __restrict__ val, int k,
                                                             int top_k, int sb_per_chunk, int32_t n_sb, int64_t n_users,
                                                             const int32_t* __restrict__ src, int32_t rcap,
@@ -230,15 +232,15 @@ __global__ __launch_bounds__(256) void prerefine_rows_kernel(const int32_t* __re
     extern __shared__ int cnt[];                                               // [n_sb]: count, then the global base of this workgroup's run
     for (int s = threadIdx.x; s < n_sb; s += 256) cnt[s] = 0;
     __syncthreads();
-    constexpr int UPT = 4;                                                     // users per thread
-    int sb[UPT][16];
-    short lr[UPT][16];
+    constexpr int UPT = 64 / KS;                                               // users per thread
+    int sb[UPT][KS];
+    short lr[UPT][KS];
 #pragma unroll
     for (int i = 0; i < UPT; ++i) {
         const int64_t u = (int64_t)blockIdx.x * (256 * UPT) + i * 256 + threadIdx.x;
         const bool live = u < n_users && (!src || src[u] >= 0);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
+        for (int j = 0; j < KS; ++j) {
             sb[i][j] = -1; lr[i][j] = 0;
             if (live && j < k) {
                 const int32_t row = sel[u * k + j];
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(256) void prerefine_rows_kernel(const int32_t* __re
         if (u >= n_users) continue;
         bool all = true;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
+        for (int j = 0; j < KS; ++j) {
             if (j >= k) break;
             const int s = sb[i][j];
             if (s < 0) { all = false; sel_sb[u * k + j] = -1; continue; }
@@ -342,20 +344,22 @@ __global__ __launch_bounds__(256) void prerefine_tau_listed_kernel(const int32_t
     const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (u >= n_users) return;
     const bool live = !(src && src[u] < 0);
-    int32_t s[16], ps[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        s[j] = (live && j < k) ? sel_sb[u * k + j] : -1;
-        ps[j] = (live && j < k) ? sel_pos[u * k + j] : 0;
-    }
-    float v[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) v[j] = s[j] >= 0 ? pre_max[(int64_t)s[j] * rcap + ps[j]] : INFINITY;
     float m = INFINITY;
+    for (int j0 = 0; j0 < k; j0 += 16) {                                       // (k <= 16: one round; the wide route: up to four)
+        int32_t s[16], ps[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) m = fminf(m, (v[j] == v[j]) ? v[j] : -INFINITY);          // a NaN certifies nothing
+        for (int j = 0; j < 16; ++j) {
+            s[j] = (live && j0 + j < k) ? sel_sb[u * k + j0 + j] : -1;
+            ps[j] = (live && j0 + j < k) ? sel_pos[u * k + j0 + j] : 0;
+        }
+        float v[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) if (j < k) vals[u * k + j] = v[j];
+        for (int j = 0; j < 16; ++j) v[j] = s[j] >= 0 ? pre_max[(int64_t)s[j] * rcap + ps[j]] : INFINITY;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) m = fminf(m, (v[j] == v[j]) ? v[j] : -INFINITY);      // a NaN certifies nothing
+#pragma unroll
+        for (int j = 0; j < 16; ++j) if (j0 + j < k) vals[u * k + j0 + j] = v[j];
+    }
     if (!live || !ok[u]) return;
     const float eps = filter_eps(ustats[u], user_bias ? fabsf(user_bias[u]) : 0.f, gstats, kdim);
     float t = m - eps;
@@ -1267,7 +1271,7 @@ extern "C" int trec_topk_prerefine_rows(const int32_t* sel, const float* sel_val
     TREC_REQUIRE(k >= 1 && k <= 16 && top_k >= 1 && sb_per_chunk >= 1 && sb_per_chunk <= (1 << TREC_LB_TAG_BITS) && n_sb >= 1 &&
                  n_sb <= trec_topk_prerefine_max_superblocks() && rcap >= 512 && rcap % 512 == 0, "trec_topk_prerefine_rows: bad sizes");
     if (n_users == 0) return TREC_OK;
-    hipLaunchKernelGGL(prerefine_rows_kernel, dim3((unsigned)ceil_div64(n_users, 1024)), dim3(256), (size_t)n_sb * 4, (hipStream_t)stream,
+    hipLaunchKernelGGL(prerefine_rows_kernel<16>, dim3((unsigned)ceil_div64(n_users, 1024)), dim3(256), (size_t)n_sb * 4, (hipStream_t)stream,
                        sel, sel_val, k, top_k, sb_per_chunk, n_sb, n_users, src, rcap, sel_sb, row_count, row_user, ok, (int32_t*)nullptr);
     return trec_check_launch("trec_topk_prerefine_rows");
 }
@@ -1279,11 +1283,17 @@ extern "C" int trec_topk_prerefine_rows_pos(const int32_t* sel, const float* sel
                                             int32_t* row_count, int32_t* row_user, int32_t* ok, int32_t* sel_pos, void* stream)
 {
     TREC_REQUIRE(sel && sel_val && sel_sb && row_count && row_user && ok && sel_pos, "trec_topk_prerefine_rows_pos: null pointer");
-    TREC_REQUIRE(k >= 1 && k <= 16 && top_k >= 1 && sb_per_chunk >= 1 && sb_per_chunk <= (1 << TREC_LB_TAG_BITS) && n_sb >= 1 &&
+    TREC_REQUIRE(k >= 1 && k <= 64 && top_k >= 1 && sb_per_chunk >= 1 && sb_per_chunk <= (1 << TREC_LB_TAG_BITS) && n_sb >= 1 &&
                  n_sb <= trec_topk_prerefine_max_superblocks() && rcap >= 512 && rcap % 512 == 0, "trec_topk_prerefine_rows_pos: bad sizes");
     if (n_users == 0) return TREC_OK;
-    hipLaunchKernelGGL(prerefine_rows_kernel, dim3((unsigned)ceil_div64(n_users, 1024)), dim3(256), (size_t)n_sb * 4, (hipStream_t)stream,
-                       sel, sel_val, k, top_k, sb_per_chunk, n_sb, n_users, src, rcap, sel_sb, row_count, row_user, ok, sel_pos);
+    if (k <= 16)
+        hipLaunchKernelGGL(prerefine_rows_kernel<16>, dim3((unsigned)ceil_div64(n_users, 1024)), dim3(256), (size_t)n_sb * 4,
+                           (hipStream_t)stream, sel, sel_val, k, top_k, sb_per_chunk, n_sb, n_users, src, rcap, sel_sb, row_count, row_user,
+                           ok, sel_pos);
+    else                                                    // (the wide route, 17 <= k <= 64: one user per thread)
+        hipLaunchKernelGGL(prerefine_rows_kernel<64>, dim3((unsigned)ceil_div64(n_users, 256)), dim3(256), (size_t)n_sb * 4,
+                           (hipStream_t)stream, sel, sel_val, k, top_k, sb_per_chunk, n_sb, n_users, src, rcap, sel_sb, row_count, row_user,
+                           ok, sel_pos);
     return trec_check_launch("trec_topk_prerefine_rows_pos");
 }
 
@@ -1295,7 +1305,7 @@ extern "C" int trec_topk_prerefine_tau_listed(const int32_t* sel_sb, const int32
                                               const float* user_stats, const float* user_bias, const float* item_gstats, int32_t kdim,
                                               float* tau, float* vals, float* cand_floor, void* stream)
 {
-    TREC_REQUIRE(sel_sb && sel_pos && ok && pre_max && user_stats && item_gstats && tau && vals && k >= 1 && k <= 16 && rcap >= 1,
+    TREC_REQUIRE(sel_sb && sel_pos && ok && pre_max && user_stats && item_gstats && tau && vals && k >= 1 && k <= 64 && rcap >= 1,
                  "trec_topk_prerefine_tau_listed: bad arguments");
     if (n_users == 0) return TREC_OK;
     hipLaunchKernelGGL(prerefine_tau_listed_kernel, dim3((unsigned)ceil_div64(n_users, 256)), dim3(256), 0, (hipStream_t)stream, sel_sb,

@@ -623,9 +623,15 @@ def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, 
     # pairs and the lists half as many candidates.  The chunk lists then carry the superblock's index inside its chunk in their low
     # bits.  Single process, candidate lists, catalogues the LDS counters cover; item shards keep the exchanged tau8.
     sb_per_chunk = chunk_len // sb_rows
-    pre = (one_pass and lists and floor_exchange is None and stats_exchange is None and kk <= 16
+    pre = (one_pass and lists and floor_exchange is None and stats_exchange is None and kk <= WIDE_K_MAX
            and lib.trec_get_tuning(b"cascade_prerefine", 1) != 0 and sb_per_chunk <= 4096
            and CASCADE_PREREFINE_MIN_SB <= n_sb <= int(N.query("trec_topk_prerefine_max_superblocks")))
+    if pre and kk > 16:
+        # the wide route (17 <= k <= 64): only in the default form -- the listing + marking launch and the threshold read back from
+        # its lists -- whose kernels take up to 64 slots per user (tuning wide_prerefine = 0: as before round 6, without)
+        pre = (lib.trec_get_tuning(b"cascade_prerefine", 1) == 1 and lib.trec_get_tuning(b"prerefine_marked", 1) != 0
+               and lib.trec_get_tuning(b"wide_prerefine", 1) != 0 and not _refine_resident(sb_rows, kpad)
+               and n_sb >= 4 * kk)                          # (k of n_sb superblocks per user: a small share of the pairs only then)
     with _timed("score_gemm_blockmax_i8"):
         N.call("trec_score_gemm_blockmax_i8", N.ptr(uop.i8), N.ptr(iop.i8), kpad, n_u, n_i, N.ptr(user_bias),
                N.ptr(iop.bias_q), N.ptr(iop.scales), N.ptr(iop.sb_stats), sb_rows, n_chunks, N.ptr(table), stride,
@@ -695,9 +701,11 @@ def _cascade_stage1(uop, iop, k, user_bias, item_bias, sb_rows, n_sb, n_chunks, 
         pre_ok = torch.empty((n_u,), dtype=torch.int32, device=dev)
         pre_rows = torch.empty((n_sb * rcap_a,), dtype=torch.int32, device=dev)        # only the listed part is touched
         pre_vals = torch.empty((n_u, kk), dtype=torch.float32, device=dev) if listed else None
-        if listed and n_sb >= 32:
+        if listed and n_sb >= 32 and lib.trec_get_tuning(b"prerefine_early_dense", 1 if kk <= 16 else 0) != 0:
             # users the int8 bound says nothing about (32 sampled superblocks under tau8) list nothing in the pre-refining launch
-            # either: flagged now, as the call after the compaction would
+            # either: flagged now, as the call after the compaction would.  (The wide route leaves them to that later call: the
+            # 64th largest lower bound keeps half of the sampled superblocks of a few users per 100,000 whom the RAISED threshold
+            # certifies -- and each flagged user costs an fp32 score slab there.  A user listed here and flagged later is re-done all the same.)
             N.call("trec_topk_dense_users", N.ptr(table), n_sb, n_u, stride, N.ptr(tau), N.ptr(user_err), N.ptr(iop.sb_stats),
                    kpad, CASCADE_DENSE_USER_LIMIT if n_i >= CASCADE_MIN_ITEMS else 30, N.ptr(cands.floor0), N.ptr(cands.flag),
                    N.ptr(cands.n_flagged))
@@ -1377,7 +1385,7 @@ def score_topk_filtered_wide(uop, iop, k, user_bias=None, item_bias=None, item_i
         complete = real & (cands.flag == 0) & torch.isfinite(cands.floor0)
         bad = real & ~complete
         LAST_FILTER_STATS.update({"prefilter": "int8", "refined_rows": int(rows), "tail": "candidate lists, wide finish",
-                                  "candidates_cap": cands.cap,
+                                  "candidates_cap": cands.cap, "prerefined_pairs": n_real * kk if cands.pre is not None else 0,
                                   "candidates_per_user": float(n.clamp(max=cands.cap)[complete].float().mean().item()) if bool(complete.any()) else 0.0})
     n_bad = int(bad.sum().item())
     if n_bad:

@@ -412,6 +412,19 @@ def test_wide_k_topk_through_the_cascade_is_the_oracles(ops, d, n_u, n_i, k, bia
     # from ~1,000 superblocks on the lists do)
     if n_i >= 262_144 and (k <= 32 or n_i >= 1_000_000):
         assert stats["prefilter"] == "int8" and stats["flagged_users"] <= n_u // 10, stats       # the lists answered, not the fallback
+        assert stats["prerefined_pairs"] == n_u * k, stats                     # ... behind the pre-refinement of each user's k best superblocks
+        # the same call without it (tuning wide_prerefine = 0): the same bits from longer lists
+        from tensorrec_amd import _native as N
+        N.set_tuning("wide_prerefine", 0)
+        try:
+            uop = ops.score_prep_filter(du, sort_users=True, k=k, user_bias=dub)
+            iop = ops.score_prep_filter(dv, bias=dib, want_gstats=True)
+            vals0, idx0 = ops.score_topk_filtered_wide(uop, iop, k, dub, dib, item_index_base=500)
+            stats0 = dict(ops.LAST_FILTER_STATS)
+        finally:
+            N.set_tuning("wide_prerefine", 1)
+        assert torch.equal(vals0, vals) and torch.equal(idx0, idx)
+        assert stats0["prerefined_pairs"] == 0 and stats0["refined_rows"] >= stats["refined_rows"], (stats0, stats)
 
 
 def test_wide_k_predict_top_k_through_the_public_api(ops):
