@@ -432,6 +432,7 @@ int trec_topk_prerefine_tau(const int32_t* sel_sb, const int32_t* ok, int32_t k,
  * the position of every placed pair inside its superblock's list; trec_score_gemm_refine_candidates_marked (declared with the other
  * refining launches) leaves the bf16 maxima in pre_max [n_sb * rcap] by list position and marks the table entries -inf itself;
  * trec_topk_prerefine_tau_listed reads the maxima back from there (vals, tau, cand_floor as trec_topk_prerefine_tau with listed != 0).
+ * These two take k <= 64 (the wide route, 17 <= k <= 64, pre-refines too); trec_topk_prerefine_rows / _tau keep k <= 16.
  * Same reference arithmetic as the calls they replace (recommendation_graphs.py:73-82 restricted to what the exact top-k needs). */
 int trec_topk_prerefine_rows_pos(const int32_t* sel, const float* sel_val, int32_t k, int32_t top_k, int32_t sb_per_chunk,
                                  int32_t n_sb, int64_t n_users, const int32_t* src, int32_t rcap, int32_t* sel_sb,
