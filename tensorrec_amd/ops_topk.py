@@ -442,8 +442,9 @@ def topk_user_batch(n_users, n_items, n_components, device, fraction=0.6, route=
     if route == "cascade":           # (two user lists per superblock since round 5: the pre-refinement's and the compaction's; round 6:
         # the pre-refinement's maxima in its list's layout -- a third half column -- and its list positions, 4 B per slot)
         per_user = 1.3 * (n_sb * (4 + 12 * CASCADE_ROW_CAPACITY) + 8 * kpad + 1024 + 8 * CASCADE_CANDIDATES + 256 + 16 * int(k))
-    elif route == "wide":            # score_topk_filtered_wide: 1,024 candidate slots (8 B each) and the k places; one user list per superblock
-        per_user = 1.3 * (n_sb * (4 + 4 * CASCADE_ROW_CAPACITY) + 8 * kpad + 1024 + 8 * WIDE_CANDIDATES + 16 * int(k))
+    elif route == "wide":            # score_topk_filtered_wide: 1,024 candidate slots (8 B each) and the k places; the cascade's three
+        # half columns of user-list slots (the wide route pre-refines too) and 16 B per pre-refined slot (superblock, position, value, place)
+        per_user = 1.3 * (n_sb * (4 + 12 * CASCADE_ROW_CAPACITY) + 8 * kpad + 1024 + 8 * WIDE_CANDIDATES + 32 * int(k))
     else:
         # (the fused lists hold up to 16 entries: trec_score_topk_capacity is -1 beyond that, and k > 16 finishes through score
         # slabs of [users, SUPERBLOCK_ROWS * k] fp32 instead -- sized by the larger of the two)
