@@ -449,7 +449,8 @@ int trec_score_gemm_refine_candidates_marked(const void* users_bf16, const void*
                                              float* pre_max, void* stream);
 /* The exact EUCLIDEAN top-k (tensorrec/prediction_graphs.py:84-100 + tf.nn.top_k of recommendation_graphs.py:73-82) through the
  * dot-product cascade: per user, nearest = largest g = u.i - r_i / 2, a dot product with item "bias" -r_i / 2.  After the cascade
- * gave the kc = 16 largest g per user and trec_pair_score_exact their reference-chain scores (biases included),
+ * gave the kc largest g per user (16 for k <= 12; 32 / 64 from the wide cascade's lists for k up to 48; kc <= 64) and
+ * trec_pair_score_exact their reference-chain scores (biases included),
  * trec_topk_euclid_certify orders them by (score desc, id asc), writes the first k, and flags the users for whom an item OUTSIDE the
  * kc could still reach the first k places (score upper bound from the kc-th largest g and the largest item bias; csrc/euclid_topk.hip):
  * those are re-done on the exact fp32 MFMA path.  item_gstats: trec_score_prep_filter's maxima with bias = -r / 2. */

@@ -31,8 +31,10 @@
 
 namespace {
 
-constexpr int EC_MAX = 16;
+constexpr int EC_MAX_ALL = 64;
 
+// EC_MAX = candidate slots held in registers: 16 (k <= 12, the cascade's fused lists), 32 / 64 (k up to 48: the wide cascade's lists)
+template <int EC_MAX>
 __global__ __launch_bounds__(256) void euclid_certify_kernel(const int32_t* __restrict__ cand_idx, const float* __restrict__ cand_g,
                                                             const float* __restrict__ exact, int kc, int k,
                                                             const float* __restrict__ user_sq, const float* __restrict__ user_bias,
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(256) void euclid_certify_kernel(const int32_t* __re
             else key[j] = merge_key(exact[u * kc + j], id);
         }
     }
-    // insertion sort, descending keys = (score desc, id asc): kc <= 16 entries in registers
+    // insertion sort, descending keys = (score desc, id asc): kc <= EC_MAX entries in registers
 #pragma unroll
     for (int a = 1; a < EC_MAX; ++a) {
 #pragma unroll
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(256) void euclid_certify_kernel(const int32_t* __re
 // (trec_pair_score_exact); user_sq [n_users] = r_u as the score kernels use it; item_gstats [3] = the item operand's maxima
 // {||v||, -, max r_i / 2} (trec_score_prep_filter with bias = -r / 2); bias_max [1] = max item bias (NULL: none).
 // Writes the first k by (score desc, id asc); flag[u] = 1 (n_flagged [1], zeroed by the caller, counts them) when the certificate
-// does not hold.  kc <= 16, k <= kc.  lambda_ [1] / bias_min [1] (nullable: 0 / = bias_max): the cascade ordered by
+// does not hold.  kc <= 64, k <= kc.  lambda_ [1] / bias_min [1] (nullable: 0 / = bias_max): the cascade ordered by
 // u.i - r_i / 2 + lambda b_i -- cand_g holds those values, item_gstats[2] their largest |item term|.
 extern "C" int trec_topk_euclid_certify(const int32_t* cand_idx, const float* cand_g, const float* exact, int32_t kc, int32_t k,
                                         const float* user_sq, const float* user_bias, const float* item_gstats,
@@ -126,10 +128,15 @@ extern "C" int trec_topk_euclid_certify(const int32_t* cand_idx, const float* ca
 {
     TREC_REQUIRE(cand_idx && cand_g && exact && user_sq && item_gstats && out_vals && out_idx && flag && n_flagged,
                  "trec_topk_euclid_certify: null pointer");
-    TREC_REQUIRE(kc >= 1 && kc <= EC_MAX && k >= 1 && k <= kc && kdim >= 1, "trec_topk_euclid_certify: need 1 <= k <= kc <= 16");
+    TREC_REQUIRE(kc >= 1 && kc <= EC_MAX_ALL && k >= 1 && k <= kc && kdim >= 1, "trec_topk_euclid_certify: need 1 <= k <= kc <= 64");
     if (n_users == 0) return TREC_OK;
-    hipLaunchKernelGGL(euclid_certify_kernel, dim3((unsigned)ceil_div64(n_users, 256)), dim3(256), 0, (hipStream_t)stream, cand_idx,
-                       cand_g, exact, kc, k, user_sq, user_bias, item_gstats, bias_max, kdim, n_users, out_vals, out_idx, flag,
-                       n_flagged, lambda_, bias_min);
+#define TREC_EC(M)                                                                                                                  \
+    hipLaunchKernelGGL(euclid_certify_kernel<M>, dim3((unsigned)ceil_div64(n_users, 256)), dim3(256), 0, (hipStream_t)stream, cand_idx, \
+                       cand_g, exact, kc, k, user_sq, user_bias, item_gstats, bias_max, kdim, n_users, out_vals, out_idx, flag,       \
+                       n_flagged, lambda_, bias_min)
+    if (kc <= 16) TREC_EC(16);
+    else if (kc <= 32) TREC_EC(32);
+    else TREC_EC(64);
+#undef TREC_EC
     return trec_check_launch("trec_topk_euclid_certify");
 }

@@ -71,10 +71,24 @@ def topk_from_scores(scores, k):
         # long rows, few places: the k-th largest VALUE of a row does not depend on any tie rule (a selection, not a sort of the
         # row), the entries reaching it are k plus its ties, and trec_topk_merge orders them (value desc, index asc).  Rows with
         # NaN, a -inf k-th value or more than 1,024 such entries keep the exact-rank form below.
-        kth = torch.topk(scores, kk, dim=1, sorted=True).values[:, kk - 1:kk]
-        mask = scores >= kth
-        cnt = mask.sum(dim=1)
-        if bool((torch.isfinite(kth).all() & (cnt.max() <= 1024) & (cnt.min() >= kk)).item()):
+        # The selecting value need not BE the k-th largest: any t <= it keeps a superset whose k best are the row's.  First try the
+        # k-th largest of the maxima of 512-entry blocks (k blocks hold an entry >= t each; two streaming passes over the slab where
+        # a row-wise selection of the k-th value costs several times that); rows with heavy ties overflow the 1,024 slots there
+        # and take the exact k-th value.
+        bounds = (["blocks"] if n_i // 512 >= 2 * kk and N.load().trec_get_tuning(b"topk_slab_block_bound", 1) != 0 else []) + ["exact"]
+        for bound in bounds:
+            if bound == "blocks":
+                n_full = n_i // 512 * 512
+                bm = scores[:, :n_full].unflatten(1, (-1, 512)).amax(dim=2)
+                if n_full < n_i:
+                    bm = torch.cat([bm, scores[:, n_full:].amax(dim=1, keepdim=True)], dim=1)
+                kth = torch.topk(bm, kk, dim=1, sorted=True).values[:, kk - 1:kk]
+            else:
+                kth = torch.topk(scores, kk, dim=1, sorted=True).values[:, kk - 1:kk]
+            mask = scores >= kth
+            cnt = mask.sum(dim=1)
+            if not bool((torch.isfinite(kth).all() & (cnt.max() <= 1024) & (cnt.min() >= kk)).item()):
+                continue
             rows, cols = torch.nonzero(mask, as_tuple=True)
             first = torch.cumsum(cnt, 0) - cnt
             slot = torch.arange(rows.numel(), device=scores.device) - first[rows]
@@ -1408,6 +1422,19 @@ def score_topk_filtered_wide(uop, iop, k, user_bias=None, item_bias=None, item_i
 
 
 EUCLID_CANDIDATES = 16       # K' of the Euclidean route: the cascade's largest list
+EUCLID_WIDE_K_MAX = 48       # ... and through the WIDE cascade's lists (score_topk_filtered_wide): K' = 32 for 13 <= k <= 24, 64 up to 48
+
+
+def euclid_candidates_for(k):
+    """K' -- how many nearest items the Euclidean route lists per user for the first k places (a third more than k)."""
+    kk = int(k)
+    if kk <= EUCLID_CANDIDATES - 4:
+        return EUCLID_CANDIDATES
+    if kk <= 24:
+        return 32
+    if kk <= EUCLID_WIDE_K_MAX:
+        return 64
+    raise ValueError("the filtered Euclidean top-k supports k <= %d" % EUCLID_WIDE_K_MAX)
 EUCLID_SECOND_PASS_MIN = 32  # users without a certificate from which the cascade runs once more with a measured weight (fewer: the fp32 path)
 EUCLID_LAMBDA_PCT = 70       # weight of the item bias in its ordering, in percent of the typical distance sqrt(mean r_u + mean r_i): the NEAREST
                              # items sit closer than the typical one, and a weight above their distance moves the bound's maximum to the
@@ -1415,23 +1442,30 @@ EUCLID_LAMBDA_PCT = 70       # weight of the item bias in its ordering, in perce
                              # sigma_b = 0.2 -> 700 / 201 / 700; profiles/r06_euclid_bias_ab.json)
 
 
-def score_topk_euclid_filtered(user_repr, item_repr, k, user_bias=None, item_bias=None, item_index_base=0, _lam=None):
+EUCLID_LAMBDA_SAMPLE_MIN = 8192   # users from which the bias weight is MEASURED on a sample of 512 users first (below: the guess, then the second pass)
+
+
+def score_topk_euclid_filtered(user_repr, item_repr, k, user_bias=None, item_bias=None, item_index_base=0, _lam=None, _kc=None,
+                               _measure=False):
     """EXACT top-k of the Euclidean scores -sqrt(max(r_u - 2 u.i + r_i, 1e-16)) (+ biases) -- prediction_graphs.py:84-100 +
     recommendation_graphs.py:33-41, :73-82 -- through the DOT-product cascade (csrc/euclid_topk.hip): per user, nearest = largest
-    g = u.i - r_i / 2, so the cascade runs with the item "bias" -r_i / 2 and lists the K' = 16 nearest items; the reference's own
+    g = u.i - r_i / 2, so the cascade runs with the item "bias" -r_i / 2 and lists the K' = 16 nearest items (k <= 12; K' = 32 / 64 through the wide cascade for 13 <= k <= 48, int8-cascade catalogues only); the reference's own
     chain re-scores those pairs (trec_pair_score_exact: the oracle's bits, biases included); a per-user certificate -- no item
-    outside the 16 can reach the first k places, given the 16th largest g and the largest item bias -- decides whether the first
+    outside the K' can reach the first k places, given the K'-th largest g and the largest item bias -- decides whether the first
     k of them ARE the answer; users without it (item biases outweighing the distance gap, near-ties) are re-done on the exact
     fp32 MFMA path.  Values and ids are bit-identical to score_topk(..., DTYPE_F32, MODE_EUCLIDEAN) either way.
     Returns (values [U, k], ids [U, k]); LAST_FILTER_STATS["euclid_uncertified_users"] counts the re-done users."""
     kk = int(k)
-    if not 1 <= kk <= EUCLID_CANDIDATES - 4:
-        raise ValueError("the filtered Euclidean top-k supports k <= %d" % (EUCLID_CANDIDATES - 4))
+    if kk < 1:
+        raise ValueError("the filtered Euclidean top-k needs k >= 1")
+    kc = int(_kc) if _kc is not None else euclid_candidates_for(kk)   # K': 16 (k <= 12) from the cascade's fused lists, 32 / 64 from the wide route's
     u = _f32c(user_repr.detach())
     v = _f32c(item_repr.detach())
     n_u, d = u.shape
     n_i = v.shape[0]
     dev = u.device
+    if kc > EUCLID_CANDIDATES and not (cascade_prefilter_for(d, n_i) == "int8" and i8_user_classes_enabled()):
+        raise ValueError("the filtered Euclidean top-k with k > %d needs a catalogue the int8 cascade runs on" % (EUCLID_CANDIDATES - 4))
     u32, u_sq, kpad = score_prep(u, DTYPE_F32, want_sqnorm=True)
     i32, i_sq, _ = score_prep(v, DTYPE_F32, want_sqnorm=True)
     c = i_sq * -0.5                                                   # exact halving: the item "bias" of the g ordering
@@ -1445,39 +1479,67 @@ def score_topk_euclid_filtered(user_repr, item_repr, k, user_bias=None, item_bia
         lam = _lam if _lam is not None else \
             (torch.sqrt(u_sq.mean() + i_sq.mean()) *
              (N.load().trec_get_tuning(b"euclid_lambda_pct", EUCLID_LAMBDA_PCT) / 100.0)).reshape(1).contiguous()
+        lam_source = "given" if _lam is not None else "guess"
+        if _lam is None and n_u >= EUCLID_LAMBDA_SAMPLE_MIN and N.load().trec_get_tuning(b"euclid_lambda_sample", 1) != 0:
+            # the guess is a fraction of the TYPICAL distance; what counts is how far the NEAREST items are, and the optimum is sharp
+            # (profiles/r06_euclid_bias_ab.json): 512 users go through the cascade first and the median distance of their candidates
+            # is the weight of the call (~2 ms; before, every eighth user of a 200,000 x 1M call needed the second pass below)
+            sel = torch.arange(0, n_u, n_u // 512, device=dev)[:512]
+            lam = score_topk_euclid_filtered(u[sel].contiguous(), v, kk, ub[sel].contiguous() if ub is not None else None, ib,
+                                             _lam=lam, _kc=kc, _measure=True)
+            lam_source = "sampled"
         c = c + lam * ib
         bmin = ib.min().reshape(1)
     prefilter = cascade_prefilter_for(d, n_i)
-    u_f = score_prep_filter(u, sort_users=prefilter == "int8", k=EUCLID_CANDIDATES)
     i_f = score_prep_filter(v, bias=c, want_gstats=True)
-    gv, gi = score_topk_filtered(u_f, i_f, EUCLID_CANDIDATES, None, c, item_index_base=0, prefilter=prefilter)
+    if kc > EUCLID_CANDIDATES:
+        # 13 <= k <= 48: the K' = 32 / 64 largest h through the wide cascade (lists of up to 1,024 candidates, the wave-per-user finish)
+        u_f = score_prep_filter(u, sort_users=True, k=kc)
+        gv, gi = score_topk_filtered_wide(u_f, i_f, kc, None, c, item_index_base=0)
+    else:
+        u_f = score_prep_filter(u, sort_users=prefilter == "int8", k=kc)
+        gv, gi = score_topk_filtered(u_f, i_f, kc, None, c, item_index_base=0, prefilter=prefilter)
+    gv, gi = gv.contiguous(), gi.contiguous()
     stats = dict(LAST_FILTER_STATS)
-    # ---- the reference's chain on the U x 16 candidate pairs
-    xu32 = torch.arange(n_u, dtype=torch.int32, device=dev).repeat_interleave(EUCLID_CANDIDATES)
+    # ---- the reference's chain on the U x K' candidate pairs
+    xu32 = torch.arange(n_u, dtype=torch.int32, device=dev).repeat_interleave(kc)
     xi32 = gi.reshape(-1).clamp(min=0).contiguous()
     exact = pair_scores_exact(u32, i32, kpad, d, xu32, xi32, ub, ib, MODE_EUCLIDEAN, u_sq, i_sq)
+
+    def measured_weight():
+        near = ib[xi32.long()].reshape(n_u, kc) - exact.reshape(n_u, kc)      # = sqrt(D) - b_u
+        if ub is not None:
+            near = near + ub.reshape(-1, 1)
+        return near[gi >= 0].median().clamp(min=0.0).reshape(1).contiguous()
+
+    if _measure:
+        return measured_weight()                                              # (the sampling call above: the weight, nothing else)
     bmax = ib.max().reshape(1) if ib is not None else None
     ov = torch.empty((n_u, kk), dtype=torch.float32, device=dev)
     oi = torch.empty((n_u, kk), dtype=torch.int32, device=dev)
     flag = torch.empty((n_u,), dtype=torch.int32, device=dev)
     n_flagged = zero_block(1, dev)
     with _timed("topk_euclid_certify"):
-        N.call("trec_topk_euclid_certify", N.ptr(gi), N.ptr(gv), N.ptr(exact), EUCLID_CANDIDATES, kk, N.ptr(u_sq), N.ptr(ub),
+        N.call("trec_topk_euclid_certify", N.ptr(gi), N.ptr(gv), N.ptr(exact), kc, kk, N.ptr(u_sq), N.ptr(ub),
                N.ptr(i_f.gstats), N.ptr(bmax), int(d), n_u, N.ptr(ov), N.ptr(oi), N.ptr(flag), N.ptr(n_flagged), N.ptr(lam),
                N.ptr(bmin))
     n_bad = int(n_flagged.item())
     n_second = 0
-    if n_bad >= EUCLID_SECOND_PASS_MIN and lam is not None and _lam is None:
+    second_pass = False
+    wider = (kc < 64 and cascade_prefilter_for(d, n_i) == "int8" and i8_user_classes_enabled() and
+             N.load().trec_get_tuning(b"euclid_second_pass_wider", 1) != 0)
+    # (a weight measured on a sample and no larger K' to go to: a second pass would repeat the first)
+    if n_bad >= EUCLID_SECOND_PASS_MIN and lam is not None and _lam is None and (wider or lam_source != "sampled"):
         # the weight was a guess (a fraction of the TYPICAL distance); the candidates just re-scored say how far the NEAREST items
         # really are: the users without a certificate take the cascade once more with the median of those distances as the weight
         # (its optimum is sharp: profiles/r06_euclid_bias_ab.json) before anybody goes to the fp32 path
+        # ... and with the next larger K' where the wide cascade runs (16 -> 32 -> 64): the gap to the K'-th nearest item grows
+        second_pass = True
         bad = torch.nonzero(flag, as_tuple=False).reshape(-1)
-        near = ib[xi32.long()].reshape(n_u, EUCLID_CANDIDATES) - exact.reshape(n_u, EUCLID_CANDIDATES)      # = sqrt(D) - b_u
-        if ub is not None:
-            near = near + ub.reshape(-1, 1)
-        lam2 = near[gi >= 0].median().clamp(min=0.0).reshape(1).contiguous()
+        lam2 = measured_weight()
+        kc2 = 2 * kc if wider else kc
         sv, si = score_topk_euclid_filtered(u[bad].contiguous(), v, kk, ub[bad].contiguous() if ub is not None else None, ib,
-                                            item_index_base=0, _lam=lam2)
+                                            item_index_base=0, _lam=lam2, _kc=kc2)
         n_second = n_bad - int(LAST_FILTER_STATS.get("euclid_uncertified_users", 0))
         ov[bad] = sv
         oi[bad] = si
@@ -1485,19 +1547,32 @@ def score_topk_euclid_filtered(user_repr, item_repr, k, user_bias=None, item_bia
     if n_bad:
         bad = torch.nonzero(flag, as_tuple=False).reshape(-1)
         with _timed("topk_filter_fallback"):
-            fv, fi = score_topk(u32[bad].contiguous(), i32, DTYPE_F32, kpad, kk, ub[bad].contiguous() if ub is not None else None,
-                                ib, MODE_EUCLIDEAN, u_sq[bad].contiguous(), i_sq,
-                                method="two_stage" if n_i >= TWO_STAGE_MIN_ITEMS else "direct")
-        ov[bad] = fv
-        oi[bad] = fi
+            if kk <= 16:
+                fv, fi = score_topk(u32[bad].contiguous(), i32, DTYPE_F32, kpad, kk, ub[bad].contiguous() if ub is not None else None,
+                                    ib, MODE_EUCLIDEAN, u_sq[bad].contiguous(), i_sq,
+                                    method="two_stage" if n_i >= TWO_STAGE_MIN_ITEMS else "direct")
+                ov[bad] = fv
+                oi[bad] = fi
+            else:
+                # (the fused fp32 top-k kernels hold 16 entries per list: exact fp32 score slabs and the k best of every row)
+                step = max(1, (1 << 28) // max(1, n_i))
+                for b0 in range(0, n_bad, step):
+                    rb = bad[b0:b0 + step]
+                    slab = score_store(u32[rb].contiguous(), i32, DTYPE_F32, kpad, ub[rb].contiguous() if ub is not None else None,
+                                       ib, MODE_EUCLIDEAN, u_sq[rb].contiguous(), i_sq)
+                    fv, fi = topk_from_scores(slab, kk)
+                    ov[rb] = fv
+                    oi[rb] = fi
+                    del slab
     if item_index_base:
         oi = torch.where(oi >= 0, oi + int(item_index_base), oi)
     LAST_FILTER_STATS.clear()
     LAST_FILTER_STATS.update(stats)
-    if n_second or (lam is not None and _lam is None and int(n_flagged.item()) >= EUCLID_SECOND_PASS_MIN):
+    if second_pass:
         n_bad = int(n_flagged.item()) - n_second            # users that reached the fp32 path in the end
-    LAST_FILTER_STATS.update({"route": "euclidean via the dot-product cascade (g = u.i - r_i / 2, %d nearest, certificate)" % EUCLID_CANDIDATES,
-                              "users": n_u, "euclid_uncertified_users": n_bad, "euclid_second_pass_certified": n_second})
+    LAST_FILTER_STATS.update({"route": "euclidean via the dot-product cascade (g = u.i - r_i / 2, %d nearest, certificate)" % kc,
+                              "users": n_u, "euclid_uncertified_users": n_bad, "euclid_second_pass_certified": n_second,
+                              "euclid_bias_weight": lam_source if lam is not None else "none"})
     return ov, oi
 
 

@@ -1163,11 +1163,13 @@ class TensorRec(object):
         every rank certifies its own shard's first k (no floor exchange), then the same merge.
 
         Which of the routes the call took is kept in ``self.last_route`` (a dict: "route" = cascade_int8 | bf16_filter |
-        euclid_certified | wide_cascade | two_stage | direct | slab, "k", "sharded", "user_batch_size", "n_items") and, with
+        euclid_certified | wide_cascade | two_stage | direct | slab (attention models, k > 16 off the wide route), "k", "sharded", "user_batch_size", "n_items") and, with
         ``return_route=True``, returned as a third value -- a silently slower route is the likeliest regression of this method
         (tests/test_gpu_routes.py pins the route of every BASELINE.json configuration)."""
         from . import sharding
         self._check_fit('predict_top_k')
+        if int(k) < 1:
+            raise ValueError("predict_top_k needs k >= 1 (got %r)" % (k,))
         if not self._is_engine_graph():
             raise ValueError("predict_top_k needs a built-in prediction graph")
         graph = self.prediction_graph_factory
@@ -1205,8 +1207,11 @@ class TensorRec(object):
         # shard can enter these k places"), the exact per-shard lists merge like any others -- no shared floor, no collective
         # inside the route, so the ranks need not agree on who falls back.  Several tastes: the same per taste, then the merge
         # of the taste lists (max over tastes commutes with the monotone bias additions).
+        # 13 <= k <= 48: the same with the 32 / 64 nearest items from the WIDE cascade's lists, where the int8 cascade runs.
+        euclid_wide = (ops.EUCLID_CANDIDATES - 4 < k <= ops.EUCLID_WIDE_K_MAX and
+                       ops.cascade_prefilter_for(self.n_components, n_items_min) == "int8" and ops.i8_user_classes_enabled())
         euclid_filtered = (dtype == ops.DTYPE_F32 and graph.engine_mode == ops.MODE_EUCLIDEAN and
-                           1 <= k <= ops.EUCLID_CANDIDATES - 4 and n_items_min >= ops.TWO_STAGE_MIN_ITEMS and
+                           (1 <= k <= ops.EUCLID_CANDIDATES - 4 or euclid_wide) and n_items_min >= ops.TWO_STAGE_MIN_ITEMS and
                            self.n_components <= 256 and
                            ops.N.load().trec_get_tuning(b"topk_euclid_filter", 1) != 0)
         # 17 <= k <= 64 on a catalogue the cascade runs on: the same int8 -> bf16 stages, 1,024 candidate slots per user and a
@@ -1216,13 +1221,18 @@ class TensorRec(object):
         wide = (dtype == ops.DTYPE_F32 and graph.engine_mode == ops.MODE_DOT and 16 < k <= ops.WIDE_K_MAX and
                 ops.cascade_prefilter_for(self.n_components, n_items_min) == "int8" and
                 ops.N.load().trec_get_tuning(b"topk_bf16_filter", 1) != 0 and ops.i8_user_classes_enabled())
+        # k beyond the 16 entries of the fused lists and off the wide routes (small catalogues, bf16 scores, k > 64 / 48 Euclidean):
+        # exact fp32 score slabs and the k best of every row (ops.topk_from_scores) -- any k, places beyond the catalogue -inf / -1
+        if int(k) > 16 and not wide and not euclid_filtered:
+            slab_route = True
         stats_exchange = (lambda g: sharding.all_reduce_max(g, self.process_group)) if sharded else None
         # ... and on a catalogue of >= 262,144 items an int8 MFMA pass (exact integer arithmetic, proven bound) first decides
         # which (superblock, user) pairs the bf16 stage has to look at at all (csrc/topk_cascade.hip)
         prefilter = ops.cascade_prefilter_for(self.n_components, n_items_min * (dist.get_world_size(self.process_group) if sharded else 1)) \
             if filtered else None
         if user_batch_size is None:
-            route = "cascade" if (filtered or euclid_filtered) else ("wide" if wide else "two_stage")
+            route = "wide" if (wide or (euclid_filtered and k > ops.EUCLID_CANDIDATES - 4)) else \
+                ("cascade" if (filtered or euclid_filtered) else "two_stage")
             user_batch_size = ops.topk_user_batch(uf.shape[0], itf.shape[0], self.n_components, self._store.device,
                                                   route=route, k=k)
             if sharded:                  # every rank walks the SAME user batches (each batch holds collectives): the smallest wins

@@ -302,11 +302,14 @@ def test_wide_second_pass_certifies_users_beyond_the_first_pass_capacities(ops):
 
 # ---- Euclidean scores through the dot-product cascade (csrc/euclid_topk.hip) ----------------------------------------------
 @pytest.mark.parametrize("d,n_u,n_i,k,bias_scale", [(128, 900, 300_000, 10, 0.0), (128, 700, 280_000, 10, 0.001), (64, 400, 40_000, 5, 0.0005),
-                                                    (100, 300, 30_000, 12, 0.0), (128, 700, 280_000, 10, 0.02), (128, 500, 270_000, 10, 2.0)])
+                                                    (100, 300, 30_000, 12, 0.0), (128, 700, 280_000, 10, 0.02), (128, 500, 270_000, 10, 2.0),
+                                                    (128, 600, 300_000, 20, 0.001), (128, 500, 290_000, 40, 0.0), (64, 400, 280_000, 48, 0.02),
+                                                    (128, 300, 270_000, 30, 2.0)])
 def test_euclidean_topk_through_the_dot_cascade_is_the_oracles(ops, d, n_u, n_i, k, bias_scale):
     """-sqrt(max(r_u - 2 u.i + r_i, 1e-16)) (+ biases): per user the nearest items are the largest u.i - r_i / 2, so the dot
-    cascade lists the 16 nearest, the reference chain re-scores them and a certificate decides per user; without it (the last
-    case: item biases that outweigh the distance gaps) the exact fp32 path answers.  Values and ids == the oracle's, always."""
+    cascade lists the 16 nearest (k <= 12; the 32 / 64 nearest through the wide cascade up to k = 48), the reference chain re-scores
+    them and a certificate decides per user; without it (item biases of 2.0: they outweigh the distance gaps) the exact fp32 path
+    answers.  Values and ids == the oracle's, always."""
     rng = np.random.default_rng(d + n_u + k)
     u = rng.standard_normal((n_u, d)).astype(np.float32)
     v = (rng.standard_normal((n_i, d)) * rng.uniform(0.7, 1.3, (n_i, 1))).astype(np.float32)
@@ -327,6 +330,8 @@ def test_euclidean_topk_through_the_dot_cascade_is_the_oracles(ops, d, n_u, n_i,
     # certificate; biases that dwarf every distance difference (2.0) are certified where the bound's curvature term allows
     if bias_scale <= 0.02:
         assert stats["euclid_uncertified_users"] <= n_u // 10, stats
+    if k > 12:
+        assert "%d nearest" % ops.euclid_candidates_for(k) in stats["route"] and "cascade, k up to" not in stats["route"], stats
     if bias_scale == 0.02:
         from tensorrec_amd import _native as N
         N.set_tuning("euclid_bias_in_order", 0)                     # the plain g ordering: exact as well, through the fp32 path
@@ -446,6 +451,29 @@ def test_wide_k_predict_top_k_through_the_public_api(ops):
     scores = model.predict(uf, itf)
     rv, ri = O.topk_rows(scores, 40)
     assert np.array_equal(idx, ri) and np.array_equal(vals, rv)
+
+
+@pytest.mark.parametrize("n_i,k", [(300_000, 40), (70_001, 17), (9_000, 3)])
+def test_topk_from_scores_block_maxima_bound_selects_the_same_entries(ops, n_i, k):
+    """Long rows of continuous scores: the k-th largest of the 512-entry block maxima selects a superset of the row's k best (two
+    streaming passes instead of a row-wise selection); the result equals the oracle's order and the form with the exact k-th value
+    (tuning topk_slab_block_bound = 0) bit for bit -- also with a ragged last block, +inf entries and a few duplicated values."""
+    from tensorrec_amd import _native as N
+    rng = np.random.default_rng(n_i + k)
+    s = rng.standard_normal((37, n_i)).astype(np.float32)
+    s[2, 5:60:7] = np.inf
+    s[4, n_i - 3:] = 9.0                                                         # the row's best entries in the ragged tail, tied
+    s[7, 100:100 + 2 * k] = s[7].max()                                          # 2k copies of the maximum: ties across the k-th place
+    rv, ri = O.topk_rows(s, k)
+    ds = dev(s)
+    vals, idx = ops.topk_from_scores(ds, k)
+    assert np.array_equal(idx.cpu().numpy(), ri) and np.array_equal(vals.cpu().numpy(), rv)
+    N.set_tuning("topk_slab_block_bound", 0)
+    try:
+        vals0, idx0 = ops.topk_from_scores(ds, k)
+    finally:
+        N.set_tuning("topk_slab_block_bound", 1)
+    assert torch.equal(vals0, vals) and torch.equal(idx0, idx)
 
 
 @pytest.mark.parametrize("n_i,k", [(20_000, 40), (9_000, 3), (300, 5)])

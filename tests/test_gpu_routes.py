@@ -84,3 +84,23 @@ def test_routes_off_the_headline_shapes():
     _check(mm, uf, sp.identity(nm, dtype=np.float32, format="csr"), 10, "bf16_filter")
     ma = _model(64, 3000, 16, DotProductPredictionGraph, n_tastes=2, attention_graph=LinearRepresentationGraph())
     _check(ma, sp.identity(64, dtype=np.float32, format="csr"), sp.identity(3000, dtype=np.float32, format="csr"), 5, "slab")
+
+
+def test_k_beyond_the_fused_lists_off_the_wide_route_takes_score_slabs():
+    """k > 16 where the wide cascade does not run -- a small catalogue (configs[1]'s shape), Euclidean scores, bf16 precision, k > 64
+    -- used to end in the fused kernels' "k <= 16" error: exact score slabs + the k best of every row answer instead, any k."""
+    nu, ni = 300, 1682
+    uf, itf = sp.identity(nu, dtype=np.float32, format="csr"), sp.identity(ni, dtype=np.float32, format="csr")
+    _check(_model(nu, ni, 64, DotProductPredictionGraph), uf, itf, 20, "slab")
+    _check(_model(nu, ni, 64, EuclideanSimilarityPredictionGraph), uf, itf, 40, "slab")
+    _check(_model(nu, ni, 64, CosineSimilarityPredictionGraph, n_tastes=2), uf, itf, 17, "slab")
+    big = 300_000
+    m = _model(nu, big, 128, DotProductPredictionGraph)
+    itb = sp.identity(big, dtype=np.float32, format="csr")
+    _check(m, uf, itb, 100, "slab")                           # (above the wide route's 64)
+    _check(m, uf, itb, 64, "wide_cascade")
+    me = _model(nu, big, 128, EuclideanSimilarityPredictionGraph)
+    _check(me, uf, itb, 20, "euclid_certified")               # (13 <= k <= 48 where the int8 cascade runs: the wide lists, certified)
+    _check(me, uf, itb, 60, "slab")
+    with pytest.raises(ValueError):
+        m.predict_top_k(uf, itb, k=0)
