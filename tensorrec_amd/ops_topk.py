@@ -1449,7 +1449,8 @@ def score_topk_euclid_filtered(user_repr, item_repr, k, user_bias=None, item_bia
                                _measure=False):
     """EXACT top-k of the Euclidean scores -sqrt(max(r_u - 2 u.i + r_i, 1e-16)) (+ biases) -- prediction_graphs.py:84-100 +
     recommendation_graphs.py:33-41, :73-82 -- through the DOT-product cascade (csrc/euclid_topk.hip): per user, nearest = largest
-    g = u.i - r_i / 2, so the cascade runs with the item "bias" -r_i / 2 and lists the K' = 16 nearest items (k <= 12; K' = 32 / 64 through the wide cascade for 13 <= k <= 48, int8-cascade catalogues only); the reference's own
+    g = u.i - r_i / 2, so the cascade runs with the item "bias" -r_i / 2 and lists the K' = 16 nearest items (k <= 12; K' = 32 / 64
+    through the wide cascade for 13 <= k <= 48, int8-cascade catalogues only); the reference's own
     chain re-scores those pairs (trec_pair_score_exact: the oracle's bits, biases included); a per-user certificate -- no item
     outside the K' can reach the first k places, given the K'-th largest g and the largest item bias -- decides whether the first
     k of them ARE the answer; users without it (item biases outweighing the distance gap, near-ties) are re-done on the exact

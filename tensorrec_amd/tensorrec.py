@@ -1163,7 +1163,8 @@ class TensorRec(object):
         every rank certifies its own shard's first k (no floor exchange), then the same merge.
 
         Which of the routes the call took is kept in ``self.last_route`` (a dict: "route" = cascade_int8 | bf16_filter |
-        euclid_certified | wide_cascade | two_stage | direct | slab (attention models, k > 16 off the wide route), "k", "sharded", "user_batch_size", "n_items") and, with
+        euclid_certified | wide_cascade | two_stage | direct | slab (attention models, k > 16 off the wide routes), "k", "sharded",
+        "user_batch_size", "n_items") and, with
         ``return_route=True``, returned as a third value -- a silently slower route is the likeliest regression of this method
         (tests/test_gpu_routes.py pins the route of every BASELINE.json configuration)."""
         from . import sharding
