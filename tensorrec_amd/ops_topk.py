@@ -72,9 +72,11 @@ def topk_from_scores(scores, k):
         # row), the entries reaching it are k plus its ties, and trec_topk_merge orders them (value desc, index asc).  Rows with
         # NaN, a -inf k-th value or more than 1,024 such entries keep the exact-rank form below.
         # The selecting value need not BE the k-th largest: any t <= it keeps a superset whose k best are the row's.  First try the
-        # k-th largest of the maxima of 512-entry blocks (k blocks hold an entry >= t each; two streaming passes over the slab where
-        # a row-wise selection of the k-th value costs several times that); rows with heavy ties overflow the 1,024 slots there
-        # and take the exact k-th value.
+        # k-th largest of the maxima of 512-entry blocks (k blocks hold an entry >= t each): ONE streaming pass over the slab, then
+        # only the blocks whose maximum reaches t are looked at again (a few dozen per row) -- where a row-wise selection of the
+        # k-th value, the comparison and the compaction of a [rows, 1M] mask cost ten times that.  Rows with heavy ties overflow
+        # the limits there and take the exact k-th value.
+        dev = scores.device
         bounds = (["blocks"] if n_i // 512 >= 2 * kk and N.load().trec_get_tuning(b"topk_slab_block_bound", 1) != 0 else []) + ["exact"]
         for bound in bounds:
             if bound == "blocks":
@@ -83,19 +85,34 @@ def topk_from_scores(scores, k):
                 if n_full < n_i:
                     bm = torch.cat([bm, scores[:, n_full:].amax(dim=1, keepdim=True)], dim=1)
                 kth = torch.topk(bm, kk, dim=1, sorted=True).values[:, kk - 1:kk]
+                bmask = bm >= kth
+                n_blk = bmask.sum()
+                if not bool((torch.isfinite(kth).all() & ~torch.isnan(bm).any() & (n_blk <= (4 * kk + 8) * n_u) &
+                             (n_blk * 512 <= (1 << 28))).item()):
+                    continue                                                    # (NaN / -inf rows, or ties across many blocks)
+                rows_b, blk = torch.nonzero(bmask, as_tuple=True)              # row-major: rows ascending, blocks ascending
+                cols_b = blk.reshape(-1, 1) * 512 + torch.arange(512, device=dev).reshape(1, -1)
+                inside = cols_b < n_i                                           # (the ragged last block)
+                vals_b = scores[rows_b.reshape(-1, 1), cols_b.clamp(max=n_i - 1)]
+                pr, pc = torch.nonzero((vals_b >= kth[rows_b]) & inside, as_tuple=True)
+                rows, cols, picked = rows_b[pr], cols_b[pr, pc], vals_b[pr, pc]
+                cnt = torch.bincount(rows, minlength=n_u)
             else:
                 kth = torch.topk(scores, kk, dim=1, sorted=True).values[:, kk - 1:kk]
-            mask = scores >= kth
-            cnt = mask.sum(dim=1)
+                mask = scores >= kth
+                cnt = mask.sum(dim=1)
+                rows = None
             if not bool((torch.isfinite(kth).all() & (cnt.max() <= 1024) & (cnt.min() >= kk)).item()):
                 continue
-            rows, cols = torch.nonzero(mask, as_tuple=True)
+            if rows is None:
+                rows, cols = torch.nonzero(mask, as_tuple=True)
+                picked = scores[rows, cols]
             first = torch.cumsum(cnt, 0) - cnt
-            slot = torch.arange(rows.numel(), device=scores.device) - first[rows]
+            slot = torch.arange(rows.numel(), device=dev) - first[rows]
             width = max(int(cnt.max().item()), kk)
             cv = torch.full((n_u, width), float('-inf'), dtype=torch.float32, device=scores.device)
             ci = torch.full((n_u, width), -1, dtype=torch.int32, device=scores.device)
-            cv[rows, slot] = scores[rows, cols]
+            cv[rows, slot] = picked
             ci[rows, slot] = cols.to(torch.int32)
             mv, mi = topk_merge(cv, ci, kk)
             if kk == int(k):

@@ -104,3 +104,15 @@ def test_k_beyond_the_fused_lists_off_the_wide_route_takes_score_slabs():
     _check(me, uf, itb, 60, "slab")
     with pytest.raises(ValueError):
         m.predict_top_k(uf, itb, k=0)
+
+
+@pytest.mark.parametrize("nu,ni,k", [(7, 5, 10), (7, 5, 5), (7, 30, 40), (3, 1, 1)])
+def test_k_at_and_beyond_the_catalogue_size(nu, ni, k):
+    """k >= n_items on either kind of route: the first n_items places are the oracle's order, the places beyond hold -inf / -1."""
+    m = _model(nu, ni, 8, DotProductPredictionGraph)
+    uf, itf = sp.identity(nu, dtype=np.float32, format="csr"), sp.identity(ni, dtype=np.float32, format="csr")
+    vals, idx = m.predict_top_k(uf, itf, k=k)
+    kk = min(k, ni)
+    rv, ri = O.topk_rows(m.predict(uf, itf), kk)
+    assert np.array_equal(idx[:, :kk], ri) and np.array_equal(vals[:, :kk], rv)
+    assert np.all(idx[:, kk:] == -1) and np.all(np.isneginf(vals[:, kk:]))
