@@ -12,6 +12,9 @@ v = torch.randn((I, d), device="cuda", generator=g) * 0.1
 ib = torch.randn(I, device="cuda", generator=g) * 0.01
 iop = ops.score_prep_filter(v, bias=ib, want_gstats=True)
 out = {"items": I, "d": d}
+if os.environ.get("MAX_CHUNKS"):                           # A/B: item chunks of the stage-1 launches at most
+    from tensorrec_amd import _native as N
+    N.set_tuning("cascade_max_chunks", int(os.environ["MAX_CHUNKS"])); out["cascade_max_chunks"] = int(os.environ["MAX_CHUNKS"])
 for U in (256, 512, 4096):
     u = torch.randn((U, d), device="cuda", generator=g) * 0.1
     ub = torch.randn(U, device="cuda", generator=g) * 0.01

@@ -450,7 +450,9 @@ CASCADE_CANDIDATES = 256         # candidate items per user the refining launche
                                  # every item of a refined pair within eps of the k-th largest int8 lower bound; ~30 at 1M x 1M,
                                  # 138 (median) on clustered rows; the finish reads the first 64 unasked, the rest by the count)
 CASCADE_DENSE_USER_LIMIT = 16    # of 32 sampled superblocks kept (Gaussian rows keep 2.6 % of them, clustered ones 23 %): the int8 bound says nothing about this user -- flagged at once
-CASCADE_MAX_CHUNKS = 256        # item chunks of the int8 / bf16 stage-1 launches at most (small user batches: 2 row blocks x 256 chunks still fill the chip)
+CASCADE_MAX_CHUNKS = 128        # item chunks of the int8 / bf16 stage-1 launches at most: small user batches pay the selection's serial walk over
+                                # chunks x k list rows (256 users x 1M items, k = 10: 1.41 ms per call at 256 chunks, 1.11 at 128, 1.24 at 64 where the
+                                # int8 launch runs short of workgroups; tuning cascade_max_chunks, profiles/r06_small_batch_bench.json)
 CASCADE_PREREFINE_MIN_SB = 32   # superblocks from which the users' k best superblocks are pre-refined (k / n_sb of all pairs; the product
                                 # path runs the cascade from 512 superblocks on, the tests from 40)
 CASCADE_MIN_ITEMS = 262144       # below ~512 superblocks the k-th largest maximum is not selective enough for int8 to pay
@@ -1157,9 +1159,8 @@ def _score_topk_filtered(uop, iop, k, user_bias=None, item_bias=None, item_index
     rows_wg = N.query("trec_score_rows_per_workgroup", DTYPE_BF16, kpad)
     if n_chunks is None:
         rblocks = (n_u + rows_wg - 1) // rows_wg
-        # (few users: at most CASCADE_MAX_CHUNKS item chunks -- the selection walks chunks x k list entries per user, and with a
-        # chunk per superblock that walk took 2.5 ms for 512 users x 1M items where the int8 launch itself takes 0.2)
-        n_chunks = max(1, min(n_sb, CASCADE_MAX_CHUNKS, -(-32 * 768 // rblocks)))
+        # (few users: at most CASCADE_MAX_CHUNKS item chunks -- the selection walks chunks x k list entries per user)
+        n_chunks = max(1, min(n_sb, N.load().trec_get_tuning(b"cascade_max_chunks", CASCADE_MAX_CHUNKS), -(-32 * 768 // rblocks)))
     LAST_FILTER_STATS.clear()
     blockmax, bm_stride, cascade_status, tau8, cands = None, n_u, None, None, None
     # item shards: the item-side maxima behind both bounds (norms, rounding-error norms, |bias|) are MAX-reduced ONCE per call
@@ -1393,7 +1394,8 @@ def score_topk_filtered_wide(uop, iop, k, user_bias=None, item_bias=None, item_i
     ib = _f32c(item_bias.detach()).reshape(-1) if item_bias is not None else None
     rows_wg = N.query("trec_score_rows_per_workgroup", DTYPE_BF16, kpad)
     rblocks = (n_u + rows_wg - 1) // rows_wg
-    n_chunks = max(-(-kk // 16) + 1, min(n_sb, CASCADE_MAX_CHUNKS, -(-32 * 768 // rblocks)))   # k distinct entries need ceil(k / 16) lists
+    n_chunks = max(-(-kk // 16) + 1, min(n_sb, N.load().trec_get_tuning(b"cascade_max_chunks", CASCADE_MAX_CHUNKS),
+                                         -(-32 * 768 // rblocks)))             # k distinct entries need ceil(k / 16) lists
     LAST_FILTER_STATS.clear()
     lib = N.load()
     table = cands = None
