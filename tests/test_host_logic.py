@@ -373,3 +373,15 @@ def test_topk_user_batch_sizes_by_route():
     assert ops.topk_user_batch(10_000_000, 8_000_000, 128, dev, route="two_stage", k=32) <= \
         ops.topk_user_batch(10_000_000, 8_000_000, 128, dev, route="two_stage", k=16)
     assert ops.topk_user_batch(1000, 1_000_000, 128, dev) == 65536          # (the floor; callers clamp to their user count)
+
+
+def test_euclidean_candidate_counts_by_k():
+    """K' of the certified Euclidean top-k (ops.euclid_candidates_for): 16 candidates for the first 12 places (the cascade's fused lists),
+    32 / 64 from the wide cascade's lists up to k = 48, an error beyond -- and always at least a third more candidates than places."""
+    import pytest
+    from tensorrec_amd import ops
+    assert [ops.euclid_candidates_for(k) for k in (1, 12, 13, 24, 25, 48)] == [16, 16, 32, 32, 64, 64]
+    assert all(ops.euclid_candidates_for(k) * 3 >= 4 * k for k in range(1, ops.EUCLID_WIDE_K_MAX + 1))
+    assert ops.EUCLID_WIDE_K_MAX <= ops.WIDE_K_MAX and ops.CASCADE_MAX_CHUNKS >= 64
+    with pytest.raises(ValueError):
+        ops.euclid_candidates_for(ops.EUCLID_WIDE_K_MAX + 1)
